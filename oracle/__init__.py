@@ -1,0 +1,23 @@
+"""CPU oracle for the XingTian PPO/IMPALA learner-update hot path.
+
+THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+anything from this package, and there only as the *checker* -- never as the
+thing that is measured or shipped.  The product path (``xingtian_amd``) never
+imports ``oracle`` and fails loudly when its HIP extension is missing.
+
+Parity status
+-------------
+* GAE (``oracle.returns.gae``): **pinned** -- checked bit-for-bit against the
+  reference's own numpy implementation (``xt/agent/ppo/ppo.py:77-106``) executed
+  under import stubs; the resulting vectors are committed in
+  ``tests/golden/gae_*.npz`` together with ``oracle/gen_golden.py``.
+* Everything the reference delegates to TensorFlow (conv/dense fwd+bwd, the PPO
+  and v-trace losses, clip_by_global_norm, AdamOptimizer): **parity unpinned**.
+  TensorFlow (1.15 / 2.3.1, un-vendored, not installable here) holds the
+  arithmetic and the reference's tests pin no numbers for it, so this package
+  restates TF's published semantics (VALID/SAME padding, NHWC/HWIO layouts,
+  softmax-CE, TF1 Adam, clip_by_global_norm) in float64 numpy and is
+  cross-checked against an independent torch-autograd float64 implementation
+  (``oracle/torch_ref.py``) in ``tests/test_oracle.py``.
+"""

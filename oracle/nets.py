@@ -1,0 +1,522 @@
+"""Oracle (test infrastructure): float64 numpy restatement of the TF graphs on the hot path.
+
+The reference builds these with Keras/TensorFlow (an un-vendored dependency), so
+this file restates TF's published semantics; every function cites the reference
+call site it stands in for.  Layouts are TensorFlow's: activations NHWC, conv
+kernels HWIO ``[kh,kw,cin,cout]``, dense kernels ``[in,out]``, Flatten in
+(H,W,C) order.  Parameter dict keys are the TF variable names produced by the
+reference's Keras layer names (xt/model/model_utils.py:34-36,87,96).
+
+Parity unpinned at the TF boundary (see oracle/__init__.py); gradients here are
+hand-derived and cross-checked against torch autograd in tests/test_oracle.py.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+
+# ----------------------------------------------------------------------------
+# geometry
+# ----------------------------------------------------------------------------
+def conv_out_size(size, k, s, padding):
+    """TF output size + (pad_before, pad_after).  SAME pads the extra cell after."""
+    if padding == "valid":
+        return (size - k) // s + 1, 0, 0
+    out = -(-size // s)
+    total = max((out - 1) * s + k - size, 0)
+    before = total // 2
+    return out, before, total - before
+
+
+class LayerSpec(object):
+    """One Conv2D / Dense layer of a trunk."""
+
+    def __init__(self, name, kind, cin, cout, act, k=1, s=1, padding="valid", in_hw=(1, 1)):
+        self.name, self.kind, self.cin, self.cout, self.act = name, kind, cin, cout, act
+        self.k, self.s, self.padding = k, s, padding
+        self.in_h, self.in_w = in_hw
+        if kind == "conv":
+            self.out_h, self.pt, self.pb = conv_out_size(self.in_h, k, s, padding)
+            self.out_w, self.pl, self.pr = conv_out_size(self.in_w, k, s, padding)
+        else:
+            self.out_h = self.out_w = 1
+            self.pt = self.pb = self.pl = self.pr = 0
+
+    @property
+    def kernel_shape(self):
+        if self.kind == "conv":
+            return (self.k, self.k, self.cin, self.cout)
+        return (self.cin, self.cout)
+
+
+def ppo_cnn_filters(state_dim):
+    """xt/model/model_utils.py:120-149 (``get_default_filters``), (cout, k, s)."""
+    hw = list(state_dim[:2])
+    if hw == [84, 84]:
+        return [(32, 8, 4), (32, 4, 2), (64, 3, 1)]
+    if hw == [42, 42]:
+        return [(32, 4, 2), (32, 4, 2), (64, 3, 1)]
+    if hw == [15, 15]:
+        return [(32, 5, 1), (64, 3, 1), (64, 3, 1)]
+    raise ValueError("no default filters for %r" % (state_dim,))
+
+
+def impala_filters(state_dim):
+    """xt/model/atari_model.py:4-23 (``get_atari_filter``)."""
+    hw = list(state_dim[:2])
+    if hw == [84, 84]:
+        return [(16, 8, 4), (32, 4, 2), (256, 11, 1)]
+    if hw == [42, 42]:
+        return [(16, 4, 2), (32, 4, 2), (256, 11, 1)]
+    raise ValueError("no default filters for %r" % (state_dim,))
+
+
+def _conv_trunk(prefix_fmt, state_dim, filters, act, paddings):
+    h, w, c = state_dim
+    layers = []
+    for i, (cout, k, s) in enumerate(filters):
+        spec = LayerSpec(prefix_fmt.format(i), "conv", c, cout, act, k, s, paddings[i], (h, w))
+        layers.append(spec)
+        h, w, c = spec.out_h, spec.out_w, cout
+    return layers, h * w * c
+
+
+def _mlp_trunk(prefix, in_dim, hidden_sizes, act):
+    layers = []
+    for i, hsz in enumerate(hidden_sizes):
+        layers.append(LayerSpec("{}_hidden_mlp_{}".format(prefix, i), "dense", in_dim, hsz, act))
+        in_dim = hsz
+    return layers, in_dim
+
+
+def ppo_cnn_spec(state_dim, action_dim, hidden_sizes=(512,), act="relu", vf_share=True):
+    """Layer lists for ``get_cnn_backbone`` xt/model/model_utils.py:49-80."""
+    trunks = []
+    for prefix in (["shared"] if vf_share else ["pi", "v"]):
+        convs, flat = _conv_trunk(prefix + "_conv_layer_{}", state_dim, ppo_cnn_filters(state_dim),
+                                  act, ["valid"] * 3)
+        mlps, feat = _mlp_trunk(prefix, flat, hidden_sizes, act)
+        trunks.append(convs + mlps)
+    return dict(trunks=trunks, feat=feat, action_dim=action_dim, pi_name="pi_latent",
+                v_name="output_value", input_scale=("div", 0.0, 255.0))
+
+
+def ppo_mlp_spec(state_dim, action_dim, hidden_sizes=(64, 64), act="tanh", vf_share=False):
+    """Layer lists for ``get_mlp_backbone`` xt/model/model_utils.py:22-46."""
+    trunks = []
+    for prefix in (["shared"] if vf_share else ["pi", "v"]):
+        mlps, feat = _mlp_trunk(prefix, int(state_dim[0]), hidden_sizes, act)
+        trunks.append(mlps)
+    return dict(trunks=trunks, feat=feat, action_dim=action_dim, pi_name="pi_latent",
+                v_name="output_value", input_scale=None)
+
+
+def impala_cnn_opt_spec(state_dim, action_dim, state_mean=0.0, state_std=255.0):
+    """Layer list for ``ImpalaCnnOpt.create_model`` impala_cnn_opt.py:110-152.
+
+    Keras auto-names the Conv2D layers conv2d, conv2d_1, conv2d_2 (trunk) and
+    conv2d_3 (1x1 policy head) under scope ``explore_agent``; the baseline is
+    ``tf.layers.dense`` -> ``dense``.
+    """
+    filt = impala_filters(state_dim)
+    names = ["explore_agent/conv2d", "explore_agent/conv2d_1", "explore_agent/conv2d_2"]
+    h, w, c = state_dim
+    layers = []
+    for i, (cout, k, s) in enumerate(filt):
+        pad = "same" if i < len(filt) - 1 else "valid"
+        spec = LayerSpec(names[i], "conv", c, cout, "relu", k, s, pad, (h, w))
+        layers.append(spec)
+        h, w, c = spec.out_h, spec.out_w, cout
+    assert (h, w) == (1, 1)
+    return dict(trunks=[layers], feat=c, action_dim=action_dim, pi_name="explore_agent/conv2d_3",
+                v_name="explore_agent/dense",
+                input_scale=("affine", float(state_mean), float(state_std)))
+
+
+# ----------------------------------------------------------------------------
+# initialisers (Keras defaults) -- only used to make seeded test weights
+# ----------------------------------------------------------------------------
+def glorot_uniform(rng, shape, dtype=np.float32):
+    if len(shape) == 4:
+        rf = shape[0] * shape[1]
+        fan_in, fan_out = rf * shape[2], rf * shape[3]
+    else:
+        fan_in, fan_out = shape
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=shape).astype(dtype)
+
+
+def init_params(spec, seed=0, dtype=np.float32, bias_scale=0.0):
+    """OrderedDict of TF-named variables in TF creation order."""
+    rng = np.random.default_rng(seed)
+    params = OrderedDict()
+
+    def add(name, shape):
+        params[name + "/kernel"] = glorot_uniform(rng, shape, dtype)
+        b = np.zeros((shape[-1],), dtype)
+        if bias_scale:
+            b = (rng.standard_normal(shape[-1]) * bias_scale).astype(dtype)
+        params[name + "/bias"] = b
+
+    n_tr = len(spec["trunks"])
+    if n_tr == 1:
+        for lay in spec["trunks"][0]:
+            add(lay.name, lay.kernel_shape)
+        add(spec["pi_name"], (spec["feat"], spec["action_dim"]))
+        add(spec["v_name"], (spec["feat"], 1))
+    else:
+        # get_mlp_backbone: pi trunk, pi_latent, v trunk, output_value (model_utils.py:32-36);
+        # get_cnn_backbone unshared: pi convs, v convs, pi mlp, v mlp, heads (:67-74)
+        pi, v = spec["trunks"]
+        if pi[0].kind == "dense":
+            for lay in pi:
+                add(lay.name, lay.kernel_shape)
+            add(spec["pi_name"], (spec["feat"], spec["action_dim"]))
+            for lay in v:
+                add(lay.name, lay.kernel_shape)
+            add(spec["v_name"], (spec["feat"], 1))
+        else:
+            for grp in ("conv", "dense"):
+                for tr in (pi, v):
+                    for lay in tr:
+                        if lay.kind == grp:
+                            add(lay.name, lay.kernel_shape)
+            add(spec["pi_name"], (spec["feat"], spec["action_dim"]))
+            add(spec["v_name"], (spec["feat"], 1))
+    return params
+
+
+# ----------------------------------------------------------------------------
+# layer math
+# ----------------------------------------------------------------------------
+def im2col(x, lay):
+    """x [B,H,W,C] -> cols [B*OH*OW, k*k*C] with TF padding (zeros)."""
+    b = x.shape[0]
+    xp = np.pad(x, ((0, 0), (lay.pt, lay.pb), (lay.pl, lay.pr), (0, 0)))
+    k, s = lay.k, lay.s
+    cols = np.empty((b, lay.out_h, lay.out_w, k, k, lay.cin), x.dtype)
+    for ky in range(k):
+        for kx in range(k):
+            cols[:, :, :, ky, kx, :] = xp[:, ky:ky + s * lay.out_h:s, kx:kx + s * lay.out_w:s, :]
+    return cols.reshape(b * lay.out_h * lay.out_w, k * k * lay.cin)
+
+
+def col2im(dcols, lay, b):
+    k, s = lay.k, lay.s
+    dcols = dcols.reshape(b, lay.out_h, lay.out_w, k, k, lay.cin)
+    dxp = np.zeros((b, lay.in_h + lay.pt + lay.pb, lay.in_w + lay.pl + lay.pr, lay.cin), dcols.dtype)
+    for ky in range(k):
+        for kx in range(k):
+            dxp[:, ky:ky + s * lay.out_h:s, kx:kx + s * lay.out_w:s, :] += dcols[:, :, :, ky, kx, :]
+    return dxp[:, lay.pt:lay.pt + lay.in_h, lay.pl:lay.pl + lay.in_w, :]
+
+
+def act_fwd(z, act):
+    if act == "relu":
+        return np.maximum(z, 0)
+    if act == "tanh":
+        return np.tanh(z)
+    if act is None or act == "none":
+        return z
+    raise KeyError(act)
+
+
+def act_bwd(dy, y, act):
+    """d(pre-activation) from d(post) and the saved OUTPUT y."""
+    if act == "relu":
+        return dy * (y > 0)
+    if act == "tanh":
+        return dy * (1.0 - y * y)
+    return dy
+
+
+class ActorCritic(object):
+    """Forward/backward of the pi/v network described by a spec, in ``dtype``."""
+
+    def __init__(self, spec, params, dtype=np.float64):
+        self.spec, self.dtype = spec, dtype
+        self.params = OrderedDict((k, np.asarray(v, dtype)) for k, v in params.items())
+
+    def _transform(self, obs):
+        sc = self.spec["input_scale"]
+        x = np.asarray(obs).astype(self.dtype)
+        if sc is None or np.asarray(obs).dtype != np.uint8:
+            return x
+        kind, mean, std = sc
+        if kind == "div":  # layer_function, model_utils.py:187-189
+            return x / self.dtype(std)
+        # state_transform, model_utils.py:192-201
+        if abs(mean) < 1e-4:
+            return x / self.dtype(std)
+        return (x - self.dtype(mean)) / self.dtype(std)
+
+    def forward(self, obs):
+        x0 = self._transform(obs)
+        b = x0.shape[0]
+        self.cache = []
+        feats = []
+        for trunk in self.spec["trunks"]:
+            x = x0
+            tc = []
+            for lay in trunk:
+                w = self.params[lay.name + "/kernel"]
+                bias = self.params[lay.name + "/bias"]
+                if lay.kind == "conv":
+                    cols = im2col(x.reshape(b, lay.in_h, lay.in_w, lay.cin), lay)
+                    y = act_fwd(cols @ w.reshape(-1, lay.cout) + bias, lay.act)
+                    y = y.reshape(b, lay.out_h, lay.out_w, lay.cout)
+                else:
+                    cols = x.reshape(b, -1)
+                    y = act_fwd(cols @ w + bias, lay.act)
+                tc.append((cols, y))
+                x = y
+            self.cache.append(tc)
+            feats.append(x.reshape(b, -1))
+        self.feats = feats
+        f_pi, f_v = feats[0], feats[-1]
+        logits = f_pi @ self.params[self.spec["pi_name"] + "/kernel"].reshape(f_pi.shape[1], -1) \
+            + self.params[self.spec["pi_name"] + "/bias"]
+        value = f_v @ self.params[self.spec["v_name"] + "/kernel"] + self.params[self.spec["v_name"] + "/bias"]
+        return logits, value
+
+    def backward(self, dlogits, dvalue):
+        """dlogits [B,A], dvalue [B,1] -> grads dict (same keys as params)."""
+        grads = OrderedDict()
+        f_pi, f_v = self.feats[0], self.feats[-1]
+        wpi = self.params[self.spec["pi_name"] + "/kernel"]
+        wv = self.params[self.spec["v_name"] + "/kernel"]
+        grads[self.spec["pi_name"] + "/kernel"] = (f_pi.T @ dlogits).reshape(wpi.shape)
+        grads[self.spec["pi_name"] + "/bias"] = dlogits.sum(0)
+        grads[self.spec["v_name"] + "/kernel"] = f_v.T @ dvalue
+        grads[self.spec["v_name"] + "/bias"] = dvalue.sum(0)
+        dfeat = [None] * len(self.spec["trunks"])
+        dfeat[0] = dlogits @ wpi.reshape(f_pi.shape[1], -1).T
+        dv_feat = dvalue @ wv.T
+        if len(dfeat) == 1:
+            dfeat[0] = dfeat[0] + dv_feat
+        else:
+            dfeat[1] = dv_feat
+        b = dlogits.shape[0]
+        for trunk, tc, dy in zip(self.spec["trunks"], self.cache, dfeat):
+            for li in range(len(trunk) - 1, -1, -1):
+                lay = trunk[li]
+                cols, y = tc[li]
+                dz = act_bwd(dy.reshape(y.shape), y, lay.act)
+                dz2 = dz.reshape(-1, lay.cout)
+                w = self.params[lay.name + "/kernel"]
+                grads[lay.name + "/kernel"] = (cols.T @ dz2).reshape(w.shape)
+                grads[lay.name + "/bias"] = dz2.sum(0)
+                if li > 0:
+                    dcols = dz2 @ w.reshape(-1, lay.cout).T
+                    dy = col2im(dcols, lay, b) if lay.kind == "conv" else dcols
+        return OrderedDict((k, grads[k]) for k in self.params)
+
+
+# ----------------------------------------------------------------------------
+# categorical distribution + PPO loss (xt/model/tf_dist.py:89-130, xt/model/ppo/__init__.py:4-25)
+# ----------------------------------------------------------------------------
+def softmax_stats(logits):
+    m = logits.max(axis=-1, keepdims=True)
+    rl = logits - m
+    e = np.exp(rl)
+    z = e.sum(axis=-1, keepdims=True)
+    p = e / z
+    logp_all = rl - np.log(z)
+    ent = (p * (np.log(z) - rl)).sum(axis=-1, keepdims=True)  # tf_dist.py:108-113
+    return p, logp_all, ent
+
+
+def ppo_loss_and_grads(logits, value, action, old_logp, adv, old_v, target_v,
+                       clip_ratio, ent_coef, vf_clip, critic_coef):
+    """loss = actor_loss_with_entropy + critic_coef*critic_loss (xt/model/ppo/ppo.py:89-92).
+
+    All label arrays are [B,1] (action [B]).  Returns (loss, dlogits [B,A], dvalue [B,1],
+    parts dict).  Gradient conventions follow TF: min/max send the gradient to the
+    first argument on ties, clip_by_value passes gradient on the closed interval.
+    """
+    dt = logits.dtype
+    bsz = logits.shape[0]
+    p, logp_all, ent = softmax_stats(logits)
+    a = np.asarray(action).astype(np.int64).reshape(-1, 1)
+    logp = np.take_along_axis(logp_all, a, axis=1)          # -neglog_prob, tf_dist.py:103-106
+    ratio = np.exp(logp - old_logp)
+    surr1 = ratio * adv
+    clipped = np.clip(ratio, 1.0 - clip_ratio, 1.0 + clip_ratio)
+    surr2 = clipped * adv
+    surr = np.minimum(surr1, surr2)
+    actor_loss = -surr.mean() - ent_coef * ent.mean()
+    vf1 = np.square(value - target_v)
+    vclip = old_v + np.clip(value - old_v, -vf_clip, vf_clip)
+    vf2 = np.square(vclip - target_v)
+    critic = 0.5 * np.maximum(vf1, vf2).mean()
+    loss = actor_loss + critic_coef * critic
+
+    # gradients
+    first = surr1 <= surr2                       # tf.minimum: grad to x where x <= y
+    in_rng = (ratio >= 1.0 - clip_ratio) & (ratio <= 1.0 + clip_ratio)
+    dsurr_dratio = np.where(first, adv, np.where(in_rng, adv, 0.0))
+    dlogp = -(dsurr_dratio * ratio) / bsz
+    onehot = np.zeros_like(logits)
+    np.put_along_axis(onehot, a, 1.0, axis=1)
+    dlogits = dlogp * (onehot - p)
+    dent_dlogits = -p * (logp_all + ent)
+    dlogits = dlogits - (ent_coef / bsz) * dent_dlogits
+    take1 = vf1 >= vf2                           # tf.maximum: grad to x where x >= y
+    in_v = np.abs(value - old_v) <= vf_clip
+    dv = np.where(take1, 2.0 * (value - target_v), np.where(in_v, 2.0 * (vclip - target_v), 0.0))
+    dvalue = (critic_coef * 0.5 / bsz) * dv
+    parts = dict(actor_loss=actor_loss, critic_loss=critic, entropy=ent.mean(), logp=logp)
+    return dt.type(loss), dlogits.astype(dt), dvalue.astype(dt), parts
+
+
+# ----------------------------------------------------------------------------
+# IMPALA v-trace loss (impala_cnn_opt.py:188-196, 299-351)
+# ----------------------------------------------------------------------------
+def impala_loss_and_grads(logits, baseline, bp_logits, actions, dones, rewards, batch_step,
+                          gamma=0.99, dtype=np.float64):
+    """Flat env-major inputs [B*T(,A)] -> (loss, dlogits [B*T,A], dbaseline [B*T]).
+
+    pi_loss + 0.5*baseline_loss + 0.01*entropy_loss, all sums (impala_cnn_opt.py:299-351);
+    the last time step of every trajectory is only the bootstrap (:188-196).
+    """
+    from oracle.returns import split_batches, vtrace_from_logits, sparse_softmax_ce
+    logits = np.asarray(logits, dtype)
+    baseline = np.asarray(baseline, dtype)
+    tp = split_batches(logits, batch_step, drop_last=True)
+    bp = split_batches(np.asarray(bp_logits, dtype), batch_step, drop_last=True)
+    act = split_batches(np.asarray(actions), batch_step, drop_last=True)
+    disc = split_batches((~np.asarray(dones, bool)).astype(dtype) * dtype(gamma), batch_step, drop_last=True)
+    rew = split_batches(np.clip(np.asarray(rewards, dtype), -1, 1), batch_step, drop_last=True)
+    vals = split_batches(baseline, batch_step, drop_last=True)
+    boot = split_batches(baseline, batch_step)[-1]
+    vs, pg_adv = vtrace_from_logits(bp, tp, act, disc, rew, vals, boot, dtype=dtype)
+    ce = sparse_softmax_ce(tp, act)
+    pi_loss = (ce * pg_adv).sum()
+    val_loss = 0.5 * np.square(vs - vals).sum()
+    p, logp_all, ent = softmax_stats(tp)
+    entropy_loss = -(-(p * logp_all).sum(axis=-1)).sum()
+    loss = pi_loss + 0.5 * val_loss + 0.01 * entropy_loss
+    # grads (vs, pg_adv are stop_gradient)
+    onehot = np.zeros_like(tp)
+    np.put_along_axis(onehot, act[..., None].astype(np.int64), 1.0, axis=-1)
+    d_tp = pg_adv[..., None] * (p - onehot)
+    h = -(p * logp_all).sum(axis=-1, keepdims=True)
+    d_tp = d_tp + 0.01 * (p * (logp_all + h))      # d(-H)/dlogits = p*(log p + H)
+    d_vals = 0.5 * (vals - vs)
+    tlen = batch_step
+    bcount = logits.shape[0] // tlen
+    dlogits = np.zeros((bcount, tlen, logits.shape[-1]), dtype)
+    dlogits[:, :-1] = np.swapaxes(d_tp, 0, 1)
+    dbase = np.zeros((bcount, tlen), dtype)
+    dbase[:, :-1] = np.swapaxes(d_vals, 0, 1)
+    return dtype(loss), dlogits.reshape(logits.shape), dbase.reshape(baseline.shape), dict(vs=vs, pg_adv=pg_adv)
+
+
+# ----------------------------------------------------------------------------
+# optimiser (tf.clip_by_global_norm + tf.train.AdamOptimizer, xt/model/ppo/ppo.py:97-102)
+# ----------------------------------------------------------------------------
+def clip_by_global_norm(grads, clip_norm):
+    """grads dict -> (clipped dict, global_norm).  t*clip/max(norm, clip)."""
+    dt = next(iter(grads.values())).dtype
+    gn = np.sqrt(sum(np.square(g.astype(np.float64)).sum() for g in grads.values())).astype(dt)
+    scale = dt.type(clip_norm) * min(dt.type(1.0) / gn if gn > 0 else np.inf, dt.type(1.0) / dt.type(clip_norm))
+    return OrderedDict((k, g * scale) for k, g in grads.items()), gn
+
+
+class AdamTF(object):
+    """TF1 ``AdamOptimizer``: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); theta -= lr_t*m/(sqrt(v)+eps)."""
+
+    def __init__(self, params, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+        self.t = 0
+        self.m = OrderedDict((k, np.zeros_like(v)) for k, v in params.items())
+        self.v = OrderedDict((k, np.zeros_like(v)) for k, v in params.items())
+
+    def apply(self, params, grads):
+        self.t += 1
+        dt = next(iter(params.values())).dtype.type
+        lr_t = dt(self.lr) * np.sqrt(dt(1.0) - dt(self.b2) ** self.t) / (dt(1.0) - dt(self.b1) ** self.t)
+        for k in params:
+            g = grads[k]
+            self.m[k] += (g - self.m[k]) * dt(1.0 - self.b1)
+            self.v[k] += (g * g - self.v[k]) * dt(1.0 - self.b2)
+            params[k] -= lr_t * self.m[k] / (np.sqrt(self.v[k]) + dt(self.eps))
+
+
+# ----------------------------------------------------------------------------
+# whole updates
+# ----------------------------------------------------------------------------
+class PpoLearnerOracle(object):
+    """``PPO.train`` of xt/model/ppo/ppo.py:111-132 with injected permutations."""
+
+    def __init__(self, spec, params, cfg, dtype=np.float64):
+        self.net = ActorCritic(spec, params, dtype)
+        self.cfg = cfg
+        self.opt = AdamTF(self.net.params, cfg["LR"])
+        self.dtype = dtype
+
+    def step(self, obs, action, old_logp, adv, old_v, target_v, apply=True):
+        c, dt = self.cfg, self.dtype
+        logits, value = self.net.forward(obs)
+        loss, dlogits, dvalue, parts = ppo_loss_and_grads(
+            logits, value, action, np.asarray(old_logp, dt), np.asarray(adv, dt),
+            np.asarray(old_v, dt), np.asarray(target_v, dt),
+            c["LOSS_CLIPPING"], c["ENTROPY_LOSS"], c["VF_CLIP"], c["CRITIC_LOSS_COEF"])
+        grads = self.net.backward(dlogits, dvalue)
+        clipped, gnorm = clip_by_global_norm(grads, c["MAX_GRAD_NORM"])
+        if apply:
+            self.opt.apply(self.net.params, clipped)
+        return dict(loss=loss, logits=logits, value=value, dlogits=dlogits, dvalue=dvalue,
+                    grads=grads, clipped=clipped, gnorm=gnorm, parts=parts)
+
+    def train(self, state, label, perms):
+        """perms: list (one per epoch) of index permutations replacing np.random.shuffle (:118)."""
+        obs = state[0]
+        nbatch = obs.shape[0]
+        bs = self.cfg["BATCH_SIZE"]
+        losses = []
+        for ep in range(self.cfg["NUM_SGD_ITER"]):
+            inds = np.asarray(perms[ep])
+            for start in range(0, nbatch, bs):
+                mb = inds[start:start + bs]
+                # fed through float32 placeholders (xt/model/ppo/ppo.py:65-68)
+                out = self.step(obs[mb], label[0][mb], label[1][mb].astype(np.float32),
+                                label[2][mb].astype(np.float32), label[3][mb].astype(np.float32),
+                                label[4][mb].astype(np.float32))
+                losses.append(out["loss"])
+        return np.mean(losses)
+
+
+class ImpalaLearnerOracle(object):
+    """``ImpalaCnnOpt.train`` (impala_cnn_opt.py:251-265) + ``IMPALAOpt.train`` chunking."""
+
+    def __init__(self, spec, params, cfg, dtype=np.float64):
+        self.net = ActorCritic(spec, params, dtype)
+        self.cfg = cfg
+        self.opt = AdamTF(self.net.params, cfg["LR"])
+        self.dtype = dtype
+
+    def step(self, state, bp_logits, actions, dones, rewards, apply=True):
+        c = self.cfg
+        logits, value = self.net.forward(state)
+        baseline = value[:, 0]
+        loss, dlogits, dbase, parts = impala_loss_and_grads(
+            logits, baseline, bp_logits, actions, dones, rewards, c["sample_batch_step"],
+            c.get("GAMMA", 0.99), self.dtype)
+        grads = self.net.backward(dlogits, dbase[:, None])
+        clipped, gnorm = clip_by_global_norm(grads, c["grad_norm_clip"])
+        if apply:
+            self.opt.apply(self.net.params, clipped)
+        return dict(loss=loss, logits=logits, baseline=baseline, dlogits=dlogits, dbaseline=dbase,
+                    grads=grads, clipped=clipped, gnorm=gnorm, parts=parts)
+
+    def train(self, states, bp_logits, actions, dones, rewards):
+        """xt/algorithm/impala/impala_opt.py:73-106: sequential BATCH_SIZE chunks, mean of losses."""
+        bs = self.cfg["BATCH_SIZE"]
+        n = len(states)
+        losses = []
+        for s in range(0, n, bs):
+            out = self.step(states[s:s + bs], bp_logits[s:s + bs], actions[s:s + bs],
+                            dones[s:s + bs], np.asarray(rewards[s:s + bs], np.float32))
+            losses.append(out["loss"])
+        return np.mean(losses)

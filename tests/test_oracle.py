@@ -1,0 +1,137 @@
+"""CPU tests of the oracle itself: golden vectors from the executed reference (GAE),
+autograd cross-checks of the hand-derived TF-graph restatement, properties."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets, returns, torch_ref
+
+
+def test_gae_matches_reference_goldens_bit_exact(golden_dir):
+    files = sorted(glob.glob(os.path.join(golden_dir, "gae_*.npz")))
+    assert len(files) >= 10
+    for f in files:
+        g = np.load(f)
+        adv, old_v, tgt = returns.gae(g["value"], g["reward"], g["done"], float(g["gamma"]), float(g["lam"]))
+        assert adv.dtype == np.float64 and old_v.dtype == np.float32
+        assert np.array_equal(adv, g["adv"]), f
+        assert np.array_equal(old_v, g["old_value"]), f
+        assert np.array_equal(tgt, g["target_value"]), f
+
+
+def test_gae_all_done_is_one_step_td():
+    rng = np.random.default_rng(0)
+    v = rng.standard_normal((17, 1)).astype(np.float32)
+    r = rng.standard_normal(16)
+    adv, _, _ = returns.gae(v, r, np.ones(16, bool))
+    assert np.array_equal(adv[:, 0], r - v[:-1, 0].astype(np.float64))
+
+
+def _tiny_cnn_spec():
+    return nets.ppo_cnn_spec((15, 15, 4), 5, hidden_sizes=(16,), act="relu", vf_share=True)
+
+
+def _labels(rng, b, a):
+    action = rng.integers(0, a, b).astype(np.int32)
+    old_logp = (-np.abs(rng.standard_normal((b, 1))) - 0.5)
+    adv = rng.standard_normal((b, 1))
+    old_v = rng.standard_normal((b, 1))
+    target_v = old_v + rng.standard_normal((b, 1)) * 3
+    return action, old_logp, adv, old_v, target_v
+
+
+@pytest.mark.parametrize("which", ["cnn15", "mlp", "cnn_unshared"])
+def test_ppo_grads_match_torch_autograd_fp64(which):
+    rng = np.random.default_rng(1)
+    b = 6
+    if which == "cnn15":
+        spec = _tiny_cnn_spec()
+        obs = rng.integers(0, 256, (b, 15, 15, 4)).astype(np.uint8)
+    elif which == "cnn_unshared":
+        spec = nets.ppo_cnn_spec((15, 15, 4), 3, hidden_sizes=(8,), act="tanh", vf_share=False)
+        obs = rng.integers(0, 256, (b, 15, 15, 4)).astype(np.uint8)
+    else:
+        spec = nets.ppo_mlp_spec((4,), 2)
+        obs = rng.standard_normal((b, 4)).astype(np.float32)
+    params = nets.init_params(spec, seed=3, bias_scale=0.1)
+    cfg = dict(LR=3e-4, LOSS_CLIPPING=0.2, ENTROPY_LOSS=0.01, VF_CLIP=0.7, CRITIC_LOSS_COEF=0.8,
+               MAX_GRAD_NORM=0.5, BATCH_SIZE=b, NUM_SGD_ITER=1)
+    lab = _labels(rng, b, spec["action_dim"])
+    o = nets.PpoLearnerOracle(spec, params, cfg, np.float64)
+    t = torch_ref.TorchPpoLearner(spec, params, cfg, torch.float64)
+    for it in range(3):   # also checks Adam + clip through 3 steps
+        out = o.step(obs, *lab)
+        tl, tg, gn = t.step(obs, *lab)
+        assert abs(out["loss"] - tl) < 1e-10 * max(1, abs(tl))
+        for k in tg:
+            np.testing.assert_allclose(out["grads"][k], tg[k].numpy(), rtol=1e-8, atol=1e-12, err_msg=k)
+        assert abs(out["gnorm"] - gn) < 1e-9
+        for k in tg:
+            np.testing.assert_allclose(o.net.params[k], t.net.params[k].detach().numpy(), rtol=1e-9, atol=1e-12)
+
+
+def test_same_padding_geometry():
+    assert nets.conv_out_size(84, 8, 4, "same") == (21, 2, 2)
+    assert nets.conv_out_size(21, 4, 2, "same") == (11, 1, 2)
+    assert nets.conv_out_size(42, 4, 2, "same") == (21, 1, 1)
+    assert nets.conv_out_size(84, 8, 4, "valid") == (20, 0, 0)
+
+
+def test_param_counts_match_survey():
+    p = nets.init_params(nets.ppo_cnn_spec((84, 84, 4), 4, hidden_sizes=(256,)))
+    assert sum(v.size for v in p.values()) == 847493
+    p = nets.init_params(nets.impala_cnn_opt_spec((84, 84, 4), 4))
+    assert sum(v.size for v in p.values()) == 1005109
+    p = nets.init_params(nets.impala_cnn_opt_spec((42, 42, 4), 6, 128.0, 128.0))
+    assert sum(v.size for v in p.values()) == 1002551
+    p = nets.init_params(nets.ppo_mlp_spec((4,), 2))
+    assert sum(v.size for v in p.values()) == 9155
+
+
+def test_impala_grads_match_torch_autograd_fp64():
+    rng = np.random.default_rng(5)
+    spec = nets.impala_cnn_opt_spec((42, 42, 4), 6, 128.0, 128.0)
+    params = nets.init_params(spec, seed=2, bias_scale=0.05)
+    tlen, bc = 5, 2
+    n = tlen * bc
+    obs = rng.integers(0, 256, (n, 42, 42, 4)).astype(np.uint8)
+    bp = rng.standard_normal((n, 6)).astype(np.float32)
+    act = rng.integers(0, 6, n).astype(np.int32)
+    dones = rng.random(n) < 0.2
+    rew = rng.standard_normal(n) * 2
+    cfg = dict(LR=1e-3, grad_norm_clip=40.0, sample_batch_step=tlen, BATCH_SIZE=n)
+    o = nets.ImpalaLearnerOracle(spec, params, cfg, np.float64)
+    t = torch_ref.TorchImpalaLearner(spec, params, cfg, torch.float64)
+    for it in range(2):
+        out = o.step(obs, bp, act, dones, rew)
+        tl, tg, gn = t.step(obs, bp, act, dones, rew)
+        assert abs(out["loss"] - tl) < 1e-9 * max(1, abs(tl))
+        for k in tg:
+            np.testing.assert_allclose(out["grads"][k], tg[k].numpy(), rtol=1e-7, atol=1e-11, err_msg=k)
+
+
+def test_vtrace_on_policy_equals_nstep_returns():
+    """rho == 1 (same logits), no dones: vs_t = sum gamma^k r_{t+k} + gamma^n V_boot."""
+    rng = np.random.default_rng(0)
+    tl, b, a = 7, 3, 4
+    lg = rng.standard_normal((tl, b, a))
+    act = rng.integers(0, a, (tl, b))
+    disc = np.full((tl, b), 0.9)
+    rew = rng.standard_normal((tl, b))
+    vals = rng.standard_normal((tl, b))
+    boot = rng.standard_normal(b)
+    vs, pg = returns.vtrace_from_logits(lg, lg, act, disc, rew, vals, boot)
+    ret = boot.copy()
+    for t in range(tl - 1, -1, -1):
+        ret = rew[t] + 0.9 * ret
+        np.testing.assert_allclose(vs[t], ret, rtol=1e-12)
+
+
+def test_split_batches_env_major():
+    x = np.arange(12)
+    s = returns.split_batches(x, 4)
+    assert s.shape == (4, 3) and s[1, 2] == 2 * 4 + 1
+    assert returns.split_batches(x, 4, drop_last=True).shape == (3, 3)
