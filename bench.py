@@ -1,0 +1,230 @@
+#!/usr/bin/env python
+"""Learner-throughput benchmark of the MI355X-native PPO update (BASELINE.json metric).
+
+One "step" = one complete learner update on one synthetic rollout batch that is already
+resident in HBM: GAE over env_num x T transitions (xt/agent/ppo/ppo.py:77-106 moved to the
+learner) followed by Model.train (xt/model/ppo/ppo.py:111-132): NUM_SGD_ITER epochs x
+ceil(N/BATCH_SIZE) minibatch SGD steps (forward, PPO loss, backward, global-norm clip,
+Adam).  Workload = BASELINE.json configs[1]: examples/breakout_ppo.yaml, PpoCnn 84x84x4,
+env_num=32, T=128 (N=4096 samples), BATCH_SIZE=320, NUM_SGD_ITER=4, hidden 256, A=4.
+
+value = env-frames/s = 4 (frame-skip) x env-steps consumed / wall time, whole job over all
+ranks.  N>1: one process per GPU (torchrun), weak scaling: every rank owns env_num=32
+trajectories and a 320-row local minibatch; gradients are summed with one RCCL all-reduce of
+the flat fp32 gradient buffer per SGD step, then every rank applies the identical
+clip+Adam update (grad_scale = 1/N).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+FRAME_SKIP = 4                  # xt/environment/gym/atari_wrappers.py:34
+
+CFG = dict(LR=2.5e-4, LOSS_CLIPPING=0.1, ENTROPY_LOSS=0.003, VF_CLIP=5.0, CRITIC_LOSS_COEF=1.0,
+           MAX_GRAD_NORM=5.0, BATCH_SIZE=320, NUM_SGD_ITER=4)
+ENV_NUM, T_LEN, STATE_DIM, A_DIM, HIDDEN = 32, 128, (84, 84, 4), 4, (256,)
+
+
+def synth_rollout(seed, env_num=ENV_NUM, t_len=T_LEN):
+    rng = np.random.default_rng(seed)
+    n = env_num * t_len
+    obs = rng.integers(0, 256, (n,) + STATE_DIM, dtype=np.uint8)
+    action = rng.integers(0, A_DIM, n).astype(np.int32)
+    logits = rng.standard_normal((n, A_DIM))
+    lsm = logits - np.log(np.exp(logits).sum(-1, keepdims=True))
+    logp = np.take_along_axis(lsm, action[:, None].astype(np.int64), 1).astype(np.float32).reshape(-1)
+    value = rng.standard_normal((env_num, t_len + 1)).astype(np.float32)
+    reward = rng.choice([-1.0, 0.0, 1.0], size=(env_num, t_len), p=[0.05, 0.9, 0.05])
+    done = (rng.random((env_num, t_len)) < 0.01)
+    return obs, action, logp, value, reward, done
+
+
+def host_cores():
+    """cores this process may actually use: min(cpu_count, affinity mask, cgroup cpu quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(obs, action, logp, value, reward, done, max_seconds=20.0):
+    """Oracle (torch-CPU fp32 restatement of the same update, oneDNN, all host cores) timed on a
+    bounded sample: a few B=320 SGD steps + the numpy GAE of the full rollout; extrapolated to the
+    full update.  Checker/baseline only -- never on the product path."""
+    from oracle import nets, returns, torch_ref
+    cores = min(host_cores(), 64)   # oneDNN does not scale past ~64 threads at B=320; count is reported
+    torch.set_num_threads(cores)
+    spec = nets.ppo_cnn_spec(STATE_DIM, A_DIM, HIDDEN, "relu", True)
+    params = nets.init_params(spec, seed=0)
+    learner = torch_ref.TorchPpoLearner(spec, params, CFG, torch.float32)
+    t0 = time.perf_counter()
+    advs = []
+    for i in range(value.shape[0]):
+        a, _, tg = returns.gae(value[i].reshape(-1, 1), reward[i].copy(), done[i])
+        advs.append((a, tg))
+    t_gae = time.perf_counter() - t0
+    n = obs.shape[0]
+    b = CFG["BATCH_SIZE"]
+    adv = np.concatenate([a for a, _ in advs]).astype(np.float32)
+    tgt = np.concatenate([t for _, t in advs]).astype(np.float32)
+    oldv = value[:, :-1].reshape(-1, 1)
+    rng = np.random.default_rng(0)
+    steps, t_steps = 0, 0.0
+    learner.step(obs[:b], action[:b], logp[:b].reshape(-1, 1), adv[:b], oldv[:b], tgt[:b])   # warm-up
+    while t_steps < max_seconds and steps < 24:
+        mb = rng.permutation(n)[:b]
+        t1 = time.perf_counter()
+        learner.step(obs[mb], action[mb], logp[mb].reshape(-1, 1), adv[mb], oldv[mb], tgt[mb])
+        t_steps += time.perf_counter() - t1
+        steps += 1
+    per_step = t_steps / steps
+    nsteps_full = CFG["NUM_SGD_ITER"] * ((n + b - 1) // b)
+    t_full = t_gae + per_step * nsteps_full
+    return {"value": FRAME_SKIP * n / t_full, "unit": "env-frames/s", "cores": cores, "kind": "port",
+            "sample": "{} SGD steps of B={} (fp32 torch-CPU restatement, oneDNN) + numpy GAE of {}x{}; "
+                      "extrapolated to {} steps/update".format(steps, b, value.shape[0], T_LEN, nsteps_full),
+            "ms_per_sgd_step": per_step * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a GPU: the learner path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node {}".format(args.gpus)
+
+    from xingtian_amd import lib as L
+    from xingtian_amd.model import netspec
+    from xingtian_amd.model.hip_net import HipActorCritic
+
+    dev = torch.device("cuda", local_rank)
+    obs, action, logp, value, reward, done = synth_rollout(seed=rank)
+    n = obs.shape[0]
+    spec = netspec.ppo_cnn(STATE_DIM, A_DIM, HIDDEN, "relu", True)
+    net = HipActorCritic(spec, max_batch=CFG["BATCH_SIZE"], device=str(dev), seed=0)   # same seed -> same replica
+    lib = L.load()
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_obs, d_act, d_logp = d(obs), d(action), d(logp)
+    d_value, d_reward, d_done = d(value), d(reward), d(done.astype(np.uint8))
+    d_adv = torch.empty((n,), dtype=torch.float64, device=dev)
+    d_tgt = torch.empty((n,), dtype=torch.float64, device=dev)
+    d_oldv = torch.empty((n,), dtype=torch.float32, device=dev)
+    perm_rng = np.random.default_rng(1234)   # identical on every rank
+    d_perm = torch.empty((CFG["NUM_SGD_ITER"], n), dtype=torch.int32, device=dev)
+    cfg = net.make_ppo_cfg(CFG, grad_scale=1.0 / world, global_batch=0)
+    use_graph = (world == 1) and not args.no_graph
+    bsz = CFG["BATCH_SIZE"]
+
+    def new_perms():
+        inds = np.arange(n)
+        p = np.empty((CFG["NUM_SGD_ITER"], n), np.int32)
+        for ep in range(CFG["NUM_SGD_ITER"]):
+            perm_rng.shuffle(inds)
+            p[ep] = inds
+        d_perm.copy_(torch.from_numpy(p), non_blocking=False)
+
+    def one_update():
+        new_perms()
+        st = L.stream_ptr()
+        L.check(lib.xt_gae_f64(L.ptr(d_value), L.ptr(d_reward), L.ptr(d_done), L.ptr(d_adv), L.ptr(d_tgt),
+                               L.ptr(d_oldv), ENV_NUM, T_LEN, 0.99, 0.95, st), "gae")
+        if world == 1:
+            net.ppo_train(cfg, d_obs, d_perm, d_act, d_logp, d_adv, d_oldv, d_tgt, use_graph=use_graph)
+        else:
+            for ep in range(CFG["NUM_SGD_ITER"]):
+                for start in range(0, n, bsz):
+                    idx = d_perm[ep, start:start + bsz]
+                    net.ppo_step(cfg, d_obs, idx, d_act, d_logp, d_adv, d_oldv, d_tgt, apply=False)
+                    dist.all_reduce(net.grads)                      # RCCL sum over xGMI, flat fp32 buffer
+                    net.apply(CFG["LR"], CFG["MAX_GRAD_NORM"], grad_scale=1.0 / world)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_update()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_update()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(net.params).all(), "non-finite parameters after the benchmark"
+
+    frames = FRAME_SKIP * n * world * args.steps
+    out = {
+        "metric": "learner env-frames/sec (Atari 84x84x4)", "value": frames / elapsed, "unit": "env-frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+        "config": {"workload": "examples/breakout_ppo.yaml PpoCnn 84x84x4 uint8, env_num=32/GPU, T=128, "
+                               "BATCH_SIZE=320/GPU, NUM_SGD_ITER=4, hidden 256, A=4; step = GAE + full PPO update "
+                               "(52 SGD steps) on an HBM-resident rollout",
+                   "env_steps_per_update": n * world, "sgd_steps_per_update": CFG["NUM_SGD_ITER"] * ((n + bsz - 1) // bsz),
+                   "parallelism": "dp{}".format(world), "hip_graph": bool(use_graph)},
+    }
+    if rank == 0:
+        # roofline of the dominant kernels: first-layer (conv 8x8/4, 4->32) forward and weight-gradient
+        idx = d_perm[0, :bsz].contiguous()
+        lay = spec.layers[0]
+        flops = 2.0 * bsz * lay.OH * lay.OW * lay.N * lay.K
+        kern = {}
+        for which, nm in ((0, "igemm_fwd_kernel<128,32,4,1,u8> (conv1 fwd)"), (1, "igemm_wgrad_kernel<128,32,4,1,u8> (conv1 wgrad)")):
+            ms = net.time_layer(0, which, d_obs, idx, bsz, reps=50)
+            kern[nm] = ms
+        dom = max(kern, key=kern.get)
+        ach = flops / (kern[dom] * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                           "flop_per_launch": flops, "avg_launch_ms": kern[dom],
+                           "all_ms": kern}
+        total_flops = 31.313e6 * n * CFG["NUM_SGD_ITER"]
+        out["update_tflops"] = total_flops * args.steps / elapsed / 1e12
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(obs, action, logp, value, reward, done)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

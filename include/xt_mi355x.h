@@ -1,0 +1,260 @@
+/*
+ * xt_mi355x.h -- C ABI of the MI355X-native XingTian learner-update path.
+ *
+ * The reference (huawei-noah/xingtian) is 100 % Python and ships no native
+ * interface: the learner arithmetic is TensorFlow graph ops called from
+ * xt/model/ppo/ppo.py, xt/model/impala/impala_cnn_opt.py, xt/model/impala/vtrace.py
+ * and numpy in xt/agent/ppo/ppo.py.  Each entry point below therefore cites the
+ * reference *call site* whose arithmetic it replaces.  A reference maintainer binds
+ * this library with ctypes (cffi is not installed in the target image); the stub is
+ * shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named host_*; the caller (PyTorch-ROCm
+ *     tensors in our host code) owns all memory, nothing is allocated or freed here
+ *     except inside an xt_net handle's own small descriptor tables;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream);
+ *   - every function returns 0 on success, non-zero on error; xt_last_error() then
+ *     returns a thread-local, NUL-terminated description;
+ *   - layouts are TensorFlow's: activations NHWC, conv kernels HWIO [kh,kw,cin,cout],
+ *     dense kernels [in,out]; a layer's kernel and bias are contiguous
+ *     ([K*N] floats then [N] floats) inside one flat fp32 parameter buffer.
+ */
+#ifndef XT_MI355X_H_
+#define XT_MI355X_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XT_ABI_VERSION 1
+
+#define XT_ACT_NONE 0
+#define XT_ACT_RELU 1
+#define XT_ACT_TANH 2
+
+/* ------------------------------------------------------------------ misc */
+int xt_abi_version(void);
+const char* xt_last_error(void);
+/* name of the gfx target the device code was compiled for ("gfx950") */
+const char* xt_build_arch(void);
+
+/* ------------------------------------------------------------- geometry */
+/* One Conv2D / Dense layer as an implicit GEMM  Y[M,N] = act(im2col(X)[M,K] . W[K,N] + b).
+ * Dense: H=W=KH=KW=S=1, C=in features.  pad_top/pad_left are TensorFlow's
+ * (SAME puts the odd cell at bottom/right, so only top/left are needed).
+ * Replaces keras Conv2D/Dense built in xt/model/model_utils.py:83-97 and
+ * xt/model/impala/impala_cnn_opt.py:119-141. */
+typedef struct xt_conv_geom {
+  int32_t H, W, C;      /* input height, width, channels (NHWC)            */
+  int32_t KH, KW, S;    /* kernel height/width, stride                      */
+  int32_t PT, PL;       /* zero padding before the first row / column       */
+  int32_t OH, OW, N;    /* output height, width, channels                   */
+  int32_t act;          /* XT_ACT_* applied to the output                   */
+} xt_conv_geom;
+
+/* how a uint8 observation becomes fp32: (x - mean) / std ; mean==0 -> x / std
+ * (layer_function xt/model/model_utils.py:187-189, state_transform :192-201) */
+typedef struct xt_input_xform {
+  int32_t is_u8;        /* 1: `in` is uint8, 0: `in` is float32 (no transform) */
+  float mean, std;
+} xt_input_xform;
+
+/* --------------------------------------------------- returns (HBM-bound) */
+/* GAE(gamma, lambda), float64, one GPU thread per trajectory, bit-exact with numpy.
+ * Replaces PPO.data_proc, xt/agent/ppo/ppo.py:87-104.
+ *   value   [n_traj, T+1] f32   reward [n_traj, T] f64   done [n_traj, T] u8 (0/1)
+ *   adv, target_value [n_traj, T] f64     old_value [n_traj, T] f32 */
+int xt_gae_f64(const float* value, const double* reward, const uint8_t* done,
+               double* adv, double* target_value, float* old_value,
+               int32_t n_traj, int32_t T, double gamma, double lam, void* stream);
+
+/* ----------------------------------------------- implicit-GEMM layer ops */
+/* Forward of one layer.  in: [B,H,W,C] (u8 or f32); idx (may be NULL): [B] int32 row
+ * gather -- sample b is read from in[idx[b]] (replaces the numpy fancy-index minibatch
+ * gather state[0][mbinds], xt/model/ppo/ppo.py:123).  w,bias: [K,N],[N]; y: [B*OH*OW,N].
+ * ksplit>1 computes partial sums into `partial` [ksplit, M, N] and finishes (bias+act)
+ * with a second kernel.  Replaces the Conv2D/Dense forward inside sess.run,
+ * xt/model/ppo/ppo.py:129, impala_cnn_opt.py:255. */
+int xt_layer_fwd(const xt_conv_geom* g, const xt_input_xform* xf, int32_t B,
+                 const void* in, const int32_t* idx, const float* w, const float* bias,
+                 float* y, float* partial, int32_t ksplit, void* stream);
+
+/* Weight+bias gradient of one layer: dW[K,N] = im2col(X)^T . dY, db[N] = sum_m dY.
+ * dy is the gradient w.r.t. the PRE-activation output, [M,N].  dwb receives
+ * [(K+1)*N] floats (kernel grad then bias grad).  msplit>1 reduces over M in `msplit`
+ * slabs written to `slabs` [msplit,(K+1)*N] and summed by a second kernel
+ * (deterministic; no atomics).  Replaces tf.gradients inside
+ * AdamOptimizer.compute_gradients, xt/model/ppo/ppo.py:99. */
+int xt_layer_wgrad(const xt_conv_geom* g, const xt_input_xform* xf, int32_t B,
+                   const void* in, const int32_t* idx, const float* dy,
+                   float* dwb, float* slabs, int32_t msplit, void* stream);
+
+/* Input gradient of one layer, fused with the activation gradient of the producer:
+ * dx[b,iy,ix,c] = act'(x)*sum dY.W^T, where x (fp32 [B,H,W,C]) is the producer's
+ * post-activation output and act_prev its activation.  Strided convs are decomposed
+ * into S*S parity classes so that no MAC is spent on structural zeros. */
+int xt_layer_dgrad(const xt_conv_geom* g, int32_t B, const float* dy, const float* w,
+                   const float* x, int32_t act_prev, float* dx, void* stream);
+
+/* --------------------------------------------------------------- heads */
+/* logits[B,A] = f_pi.Wpi + bpi ; value[B] = f_v.Wv + bv.   (pi_latent / output_value
+ * Dense layers, xt/model/model_utils.py:64-65; 1x1 Conv2D policy + dense baseline,
+ * impala_cnn_opt.py:138-152). */
+int xt_heads_fwd(const float* f_pi, const float* f_v, int32_t B, int32_t F, int32_t A,
+                 const float* wpi, const float* bpi, const float* wv, const float* bv,
+                 float* logits, float* value, void* stream);
+
+/* PPO clipped-surrogate + entropy + clipped-critic loss and its gradient w.r.t.
+ * logits and value.  Replaces actor_loss_with_entropy / critic_loss
+ * (xt/model/ppo/__init__.py:4-25), CategoricalDist (xt/model/tf_dist.py:103-113) and
+ * their tf.gradients.  Labels are gathered through idx (may be NULL) like the
+ * observations.  adv/target_v are float64 as the actor produces them and are rounded
+ * to fp32 on load (the reference's float32 placeholders, xt/model/ppo/ppo.py:65-68).
+ * inv_b = 1/(global minibatch size).  loss_terms [B,4]: surr, entropy, vf, 0. */
+int xt_ppo_loss(const float* logits, const float* value, int32_t B, int32_t A,
+                const int32_t* idx, const int32_t* action, const float* old_logp,
+                const double* adv, const float* old_v, const double* target_v,
+                float clip_ratio, float ent_coef, float vf_clip, float critic_coef,
+                float inv_b, float* dlogits, float* dvalue, float* loss_terms,
+                void* stream);
+
+/* loss scalar from the per-sample terms of xt_ppo_loss:
+ * out[0]=loss, out[1]=actor_loss, out[2]=critic_loss, out[3]=mean entropy;
+ * if acc != NULL, acc[0] += loss (running sum for the mean over minibatches,
+ * xt/model/ppo/ppo.py:130-132). */
+int xt_ppo_loss_reduce(const float* loss_terms, int32_t B, float ent_coef, float critic_coef,
+                       float inv_b, float* out, float* acc, void* stream);
+
+/* IMPALA: v-trace targets + loss gradient for one chunk of n_traj trajectories of T
+ * steps (flat env-major index b*T+t).  Replaces split_batches / vtrace_loss
+ * (impala_cnn_opt.py:171-196,299-351) and vtrace.from_logic_outputs (vtrace.py:39-115).
+ * done: u8, reward: f32 (clipped to [-1,1] here).  out[0]=loss (sum form).
+ * vs/pg_adv (optional, may be NULL): [n_traj,T-1] for parity tests. */
+int xt_impala_loss(const float* logits, const float* baseline, const float* bp_logits,
+                   const int32_t* action, const uint8_t* done, const float* reward,
+                   int32_t n_traj, int32_t T, int32_t A, float gamma,
+                   float* dlogits, float* dbaseline, float* out, float* acc,
+                   float* vs, float* pg_adv, void* stream);
+
+/* Backward through the two heads: head weight/bias gradients and the gradient w.r.t.
+ * the trunk features (times the producer's activation gradient).  If f_v == f_pi the
+ * trunk is shared and df_v must equal df_pi (contributions are summed). */
+int xt_heads_bwd(const float* f_pi, const float* f_v, int32_t B, int32_t F, int32_t A,
+                 const float* wpi, const float* wv, const float* dlogits, const float* dvalue,
+                 int32_t act_prev, float* dwpi, float* dbpi, float* dwv, float* dbv,
+                 float* df_pi, float* df_v, void* stream);
+
+/* ----------------------------------------------------------- optimiser */
+/* state[8] floats on the device: [0]=beta1^t [1]=beta2^t [2]=scale [3]=alpha
+ * [4]=global_norm [5]=step(as float) [6..7] reserved.  Initialise with
+ * xt_adam_state_init (beta powers = 1). */
+int xt_adam_state_init(float* state, void* stream);
+
+/* tf.clip_by_global_norm + tf.train.AdamOptimizer.apply_gradients
+ * (xt/model/ppo/ppo.py:97-102, impala_cnn_opt.py:204-217) over one flat buffer:
+ *   g  = grad * grad_scale                       (grad_scale = 1/world for a mean loss)
+ *   g  = g * clip / max(||g||_2, clip)
+ *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m += (g-m)(1-b1); v += (g*g-v)(1-b2)
+ *   p -= lr_t*m/(sqrt(v)+eps)
+ * scratch: >= 1024 floats. */
+int xt_adam_tf_clip(float* param, const float* grad, float* m, float* v, int64_t count,
+                    float lr, float beta1, float beta2, float eps, float clip_norm,
+                    float grad_scale, float* state, float* scratch, void* stream);
+
+/* the two halves of the above, for data-parallel use (all-reduce in between is the
+ * caller's): xt_grad_sqnorm fills state[2..4] from the (already reduced) gradient. */
+int xt_grad_global_norm(const float* grad, int64_t count, float clip_norm, float grad_scale,
+                        float* state, float* scratch, void* stream);
+
+/* ------------------------------------------------------------- network */
+/* A whole actor-critic network + update loop, so that one C call enqueues a complete
+ * Model.train().  Buffers stay caller-owned. */
+typedef struct xt_net xt_net;
+
+typedef struct xt_layer_desc {
+  xt_conv_geom g;
+  int64_t param_off;    /* offset (floats) of this layer's [K*N]+[N] block in the flat buffer */
+  int32_t trunk;        /* 0 = pi (or shared) trunk, 1 = v trunk                                */
+} xt_layer_desc;
+
+typedef struct xt_net_desc {
+  int32_t n_layers;
+  const xt_layer_desc* layers;  /* trunk 0 layers first (in order), then trunk 1 layers */
+  int32_t n_trunks;             /* 1 shared, 2 separate pi/v trunks                      */
+  int32_t feat;                 /* features entering the heads                            */
+  int32_t action_dim;
+  int64_t pi_off, v_off;        /* offsets of [F*A]+[A] and [F]+[1] head blocks           */
+  int64_t n_params;
+  xt_input_xform xf;
+  int32_t in_h, in_w, in_c;     /* observation shape                                      */
+} xt_net_desc;
+
+int xt_net_create(const xt_net_desc* desc, int32_t max_batch, xt_net** out);
+void xt_net_destroy(xt_net* net);
+/* bytes of fp32 workspace xt_net needs for minibatches of up to max_batch rows */
+int64_t xt_net_workspace_bytes(const xt_net* net);
+int xt_net_bind(xt_net* net, float* params, float* grads, float* adam_m, float* adam_v,
+                float* adam_state, void* workspace, int64_t workspace_bytes);
+
+/* forward only (Model.predict, xt/model/ppo/ppo.py:104-109): logits [B,A], value [B] */
+int xt_net_forward(xt_net* net, const void* obs, const int32_t* idx, int32_t B,
+                   float* logits, float* value, void* stream);
+
+typedef struct xt_ppo_cfg {
+  float lr, beta1, beta2, eps;
+  float clip_ratio, ent_coef, vf_clip, critic_coef, max_grad_norm;
+  int32_t batch_size, num_sgd_iter;
+  float grad_scale;             /* 1/world_size for data parallel, else 1             */
+  int32_t global_batch;         /* rows of the GLOBAL minibatch (for the mean); 0 -> local */
+} xt_ppo_cfg;
+
+/* one SGD step on rows idx[0..B) of the rollout: forward, loss, backward -> net grads.
+ * `apply` != 0 also runs clip+Adam (single GPU).  loss_out: 4 floats (see
+ * xt_ppo_loss_reduce); loss_acc optional running sum. */
+int xt_net_ppo_step(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, const int32_t* idx,
+                    int32_t B, const int32_t* action, const float* old_logp, const double* adv,
+                    const float* old_v, const double* target_v, int32_t apply,
+                    float* loss_out, float* loss_acc, void* stream);
+
+/* Model.train of xt/model/ppo/ppo.py:111-132 in one call: NUM_SGD_ITER epochs x
+ * ceil(n/BATCH_SIZE) minibatches; perm [num_sgd_iter, n] int32 holds the epoch
+ * permutations (the reference's np.random.shuffle, injected).  loss_acc[0] receives the
+ * SUM of minibatch losses, loss_acc[1] the number of minibatches.  use_graph != 0
+ * captures the whole call into a hipGraph on first use and replays it afterwards
+ * (pointers and sizes must then stay the same between calls). */
+int xt_net_ppo_train(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, int32_t n,
+                     const int32_t* perm, const int32_t* action, const float* old_logp,
+                     const double* adv, const float* old_v, const double* target_v,
+                     float* loss_acc, int32_t use_graph, void* stream);
+
+typedef struct xt_impala_cfg {
+  float lr, beta1, beta2, eps;
+  float grad_norm_clip, gamma;
+  int32_t sample_batch_step;    /* T */
+  float grad_scale;
+} xt_impala_cfg;
+
+/* ImpalaCnnOpt.train (impala_cnn_opt.py:251-265) on one chunk of n = n_traj*T frames */
+int xt_net_impala_step(xt_net* net, const xt_impala_cfg* cfg, const void* obs, int32_t n,
+                       const float* bp_logits, const int32_t* action, const uint8_t* done,
+                       const float* reward, int32_t apply, float* loss_out, float* loss_acc,
+                       void* stream);
+
+/* clip + Adam on the net's flat gradient (second half of a data-parallel step) */
+int xt_net_apply(xt_net* net, float lr, float beta1, float beta2, float eps, float clip_norm,
+                 float grad_scale, void* stream);
+
+/* kernel-time probe: average duration (ms) of `reps` launches of the dominant kernel
+ * (first-layer forward) on `stream`, measured with HIP events on that stream. */
+int xt_net_time_layer(xt_net* net, int32_t layer, int32_t which /*0 fwd 1 wgrad 2 dgrad*/,
+                      const void* obs, const int32_t* idx, int32_t B, int32_t reps,
+                      float* ms_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XT_MI355X_H_ */

@@ -1,0 +1,354 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every C-ABI kernel entry point against the
+CPU oracle on seeded inputs.  Tolerances: bit-exact for GAE (float64, index/mask ops);
+fp32 kernels vs the float64 oracle <= 1e-4 relative (north_star), in practice ~1e-6."""
+import ctypes
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets, returns
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def L():
+    from xingtian_amd import lib
+    lib.require_gpu()
+    lib.load()
+    return lib
+
+
+_KEEP = []
+
+
+@pytest.fixture(autouse=True)
+def _keepalive():
+    """device temporaries passed as raw pointers must outlive the (asynchronous) kernels"""
+    _KEEP.clear()
+    yield
+    torch.cuda.synchronize()
+    _KEEP.clear()
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    t = t.cuda()
+    _KEEP.append(t)
+    return t
+
+
+def rel_err(got, ref):
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    denom = np.linalg.norm(ref.ravel()) + 1e-30
+    return np.linalg.norm((got - ref).ravel()) / denom
+
+
+def max_err_scaled(got, ref):
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    return np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30)
+
+
+def geom_of(L, lay):
+    g = L.ConvGeom()
+    if lay.kind == "conv":
+        g.H, g.W, g.C, g.KH, g.KW, g.S = lay.in_h, lay.in_w, lay.cin, lay.k, lay.k, lay.s
+        g.PT, g.PL, g.OH, g.OW = lay.pt, lay.pl, lay.out_h, lay.out_w
+    else:
+        g.H = g.W = g.KH = g.KW = g.S = 1
+        g.C = lay.cin
+        g.PT = g.PL = 0
+        g.OH = g.OW = 1
+    g.N = lay.cout
+    g.act = L.ACT[lay.act]
+    return g
+
+
+# ------------------------------------------------------------------ GAE
+def test_gae_goldens_bit_exact(L, golden_dir):
+    from xingtian_amd import ops
+    files = sorted(glob.glob(os.path.join(golden_dir, "gae_*.npz")))
+    assert files
+    for f in files:
+        g = np.load(f)
+        adv, ov, tgt = ops.gae(g["value"].reshape(1, -1), g["reward"].reshape(1, -1), g["done"].reshape(1, -1),
+                               float(g["gamma"]), float(g["lam"]))
+        assert np.array_equal(adv.reshape(-1, 1), g["adv"]), f
+        assert np.array_equal(tgt.reshape(-1, 1), g["target_value"]), f
+        assert np.array_equal(ov.reshape(-1, 1), g["old_value"]), f
+
+
+def test_gae_many_trajectories_bit_exact(L):
+    from xingtian_amd import ops
+    rng = np.random.default_rng(11)
+    n, t = 300, 128
+    value = rng.standard_normal((n, t + 1)).astype(np.float32)
+    reward = rng.choice([-1.0, 0.0, 1.0], size=(n, t), p=[0.05, 0.9, 0.05])
+    reward[::7] = rng.standard_normal((len(reward[::7]), t))   # unclipped rewards too
+    done = rng.random((n, t)) < 0.02
+    adv, ov, tgt = ops.gae(value, reward, done)
+    for i in range(n):
+        a, o, tg = returns.gae(value[i].reshape(-1, 1), reward[i].copy(), done[i])
+        assert np.array_equal(adv[i], a[:, 0])
+        assert np.array_equal(tgt[i], tg[:, 0])
+        assert np.array_equal(ov[i], o[:, 0])
+
+
+# ------------------------------------------------------------------ single layers
+LAYER_CASES = [
+    # name, kind, in_hw, cin, cout, k, s, padding, act, B, u8
+    ("ppo_conv1_u8", "conv", (84, 84), 4, 32, 8, 4, "valid", "relu", 5, True),
+    ("ppo_conv2", "conv", (20, 20), 32, 32, 4, 2, "valid", "relu", 7, False),
+    ("ppo_conv3", "conv", (9, 9), 32, 64, 3, 1, "valid", "relu", 9, False),
+    ("ppo_fc", "dense", (1, 1), 3136, 256, 1, 1, "valid", "relu", 37, False),
+    ("imp_conv1_same_u8", "conv", (84, 84), 4, 16, 8, 4, "same", "relu", 3, True),
+    ("imp_conv2_same", "conv", (21, 21), 16, 32, 4, 2, "same", "relu", 6, False),
+    ("imp_conv3_11", "conv", (11, 11), 32, 256, 11, 1, "valid", "relu", 40, False),
+    ("imp42_conv1_same_u8", "conv", (42, 42), 4, 16, 4, 2, "same", "relu", 4, True),
+    ("mlp_in4_tanh", "dense", (1, 1), 4, 64, 1, 1, "valid", "tanh", 200, False),
+    ("mlp_64_tanh", "dense", (1, 1), 64, 64, 1, 1, "valid", "tanh", 130, False),
+    ("conv5_s1", "conv", (15, 15), 4, 32, 5, 1, "valid", "none", 3, False),
+    ("conv3_s3_same", "conv", (10, 10), 8, 12, 3, 3, "same", "tanh", 3, False),
+]
+
+
+def _layer_data(case, seed=0):
+    name, kind, in_hw, cin, cout, k, s, padding, act, b, u8 = case
+    rng = np.random.default_rng(seed)
+    lay = nets.LayerSpec(name, kind, cin, cout, act if act != "none" else None, k, s, padding, in_hw)
+    shape = (b, in_hw[0], in_hw[1], cin)
+    if u8:
+        x_raw = rng.integers(0, 256, shape).astype(np.uint8)
+        x = x_raw.astype(np.float64) / 255.0
+    else:
+        x_raw = rng.standard_normal(shape).astype(np.float32)
+        x = x_raw.astype(np.float64)
+    kk = k * k * cin if kind == "conv" else cin
+    w = (rng.standard_normal((kk, cout)) / np.sqrt(kk)).astype(np.float32)
+    bias = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+    return lay, x_raw, x, w, bias, rng
+
+
+@pytest.mark.parametrize("case", LAYER_CASES, ids=[c[0] for c in LAYER_CASES])
+@pytest.mark.parametrize("ksplit", [1, 3])
+def test_layer_fwd(L, case, ksplit):
+    lay, x_raw, x, w, bias, rng = _layer_data(case)
+    b = x.shape[0]
+    cols = nets.im2col(x, lay) if lay.kind == "conv" else x.reshape(b, -1)
+    ref = nets.act_fwd(cols @ w.astype(np.float64) + bias, lay.act)
+    g = geom_of(L, lay)
+    u8 = x_raw.dtype == np.uint8
+    xf = L.InputXform(1 if u8 else 0, 0.0, 255.0 if u8 else 1.0)
+    lib = L.load()
+    m = b * lay.out_h * lay.out_w
+    y = torch.full((m, lay.cout), float("nan"), device="cuda")
+    partial = torch.zeros((8, m, lay.cout), device="cuda")
+    L.check(lib.xt_layer_fwd(ctypes.byref(g), ctypes.byref(xf), b, L.ptr(dev(x_raw)), None, L.ptr(dev(w)),
+                             L.ptr(dev(bias)), L.ptr(y), L.ptr(partial), ksplit, None), "fwd")
+    torch.cuda.synchronize()
+    got = y.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_err(got, ref) < 2e-6, case[0]
+    assert max_err_scaled(got, ref) < 1e-5
+
+
+def test_layer_fwd_with_row_gather_and_mean_std(L):
+    case = ("imp42", "conv", (42, 42), 4, 16, 4, 2, "same", "relu", 6, True)
+    lay, x_raw, _, w, bias, rng = _layer_data(case, seed=3)
+    pool = rng.integers(0, 256, (20, 42, 42, 4)).astype(np.uint8)
+    idx = np.array([7, 7, 0, 19, 3, 12], np.int32)
+    x = (pool[idx].astype(np.float64) - 128.0) / 128.0
+    ref = nets.act_fwd(nets.im2col(x, lay) @ w.astype(np.float64) + bias, "relu")
+    g = geom_of(L, lay)
+    xf = L.InputXform(1, 128.0, 128.0)
+    y = torch.zeros((6 * 21 * 21, 16), device="cuda")
+    L.check(L.load().xt_layer_fwd(ctypes.byref(g), ctypes.byref(xf), 6, L.ptr(dev(pool)), L.ptr(dev(idx)),
+                                  L.ptr(dev(w)), L.ptr(dev(bias)), L.ptr(y), None, 1, None), "fwd")
+    assert rel_err(y.cpu().numpy(), ref) < 2e-6
+
+
+@pytest.mark.parametrize("case", LAYER_CASES, ids=[c[0] for c in LAYER_CASES])
+@pytest.mark.parametrize("msplit", [1, 5])
+def test_layer_wgrad(L, case, msplit):
+    lay, x_raw, x, w, bias, rng = _layer_data(case, seed=1)
+    b = x.shape[0]
+    cols = nets.im2col(x, lay) if lay.kind == "conv" else x.reshape(b, -1)
+    m = cols.shape[0]
+    dy = rng.standard_normal((m, lay.cout)).astype(np.float32)
+    ref_w = cols.T @ dy.astype(np.float64)
+    ref_b = dy.astype(np.float64).sum(0)
+    g = geom_of(L, lay)
+    u8 = x_raw.dtype == np.uint8
+    xf = L.InputXform(1 if u8 else 0, 0.0, 255.0 if u8 else 1.0)
+    kk = cols.shape[1]
+    out = torch.full(((kk + 1) * lay.cout,), float("nan"), device="cuda")
+    slabs = torch.zeros((16 * (kk + 1) * lay.cout,), device="cuda")
+    L.check(L.load().xt_layer_wgrad(ctypes.byref(g), ctypes.byref(xf), b, L.ptr(dev(x_raw)), None, L.ptr(dev(dy)),
+                                    L.ptr(out), L.ptr(slabs), msplit, None), "wgrad")
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_err(got[:kk * lay.cout].reshape(kk, lay.cout), ref_w) < 3e-6, case[0]
+    assert rel_err(got[kk * lay.cout:], ref_b) < 3e-6
+
+
+@pytest.mark.parametrize("case", LAYER_CASES, ids=[c[0] for c in LAYER_CASES])
+def test_layer_dgrad(L, case):
+    lay, x_raw, x, w, bias, rng = _layer_data(case, seed=2)
+    if x_raw.dtype == np.uint8:
+        x_raw = rng.standard_normal(x_raw.shape).astype(np.float32)   # dgrad needs an fp32 producer output
+    b = x_raw.shape[0]
+    m = b * lay.out_h * lay.out_w
+    dy = rng.standard_normal((m, lay.cout)).astype(np.float32)
+    dcols = dy.astype(np.float64) @ w.astype(np.float64).T
+    dx = nets.col2im(dcols, lay, b) if lay.kind == "conv" else dcols.reshape(x_raw.shape)
+    for act_prev in ("relu", "tanh"):
+        xp = x_raw if act_prev == "relu" else np.tanh(x_raw).astype(np.float32)
+        ref = nets.act_bwd(dx.reshape(xp.shape), xp.astype(np.float64), act_prev)
+        g = geom_of(L, lay)
+        out = torch.full(xp.shape, float("nan"), device="cuda")
+        L.check(L.load().xt_layer_dgrad(ctypes.byref(g), b, L.ptr(dev(dy)), L.ptr(dev(w)), L.ptr(dev(xp)),
+                                        L.ACT[act_prev], L.ptr(out), None), "dgrad")
+        got = out.cpu().numpy()
+        assert np.isfinite(got).all(), case[0]
+        assert rel_err(got, ref) < 3e-6, (case[0], act_prev)
+
+
+# ------------------------------------------------------------------ heads / losses
+@pytest.mark.parametrize("a_dim,shared", [(4, True), (6, True), (2, False), (18, True)])
+def test_heads_and_ppo_loss(L, a_dim, shared):
+    rng = np.random.default_rng(5)
+    b, f = 77, 256 if shared else 64
+    f_pi = rng.standard_normal((b, f)).astype(np.float32)
+    f_pi[f_pi < -0.5] = 0.0
+    f_v = f_pi if shared else np.tanh(rng.standard_normal((b, f))).astype(np.float32)
+    wpi = (rng.standard_normal((f, a_dim)) * 0.1).astype(np.float32)
+    bpi = (rng.standard_normal(a_dim) * 0.1).astype(np.float32)
+    wv = (rng.standard_normal((f, 1)) * 0.1).astype(np.float32)
+    bv = np.array([0.3], np.float32)
+    lib = L.load()
+    d_fpi, d_fv = dev(f_pi), None
+    d_fv = d_fpi if shared else dev(f_v)
+    logits = torch.zeros((b, a_dim), device="cuda")
+    value = torch.zeros((b,), device="cuda")
+    L.check(lib.xt_heads_fwd(L.ptr(d_fpi), L.ptr(d_fv), b, f, a_dim, L.ptr(dev(wpi)), L.ptr(dev(bpi)), L.ptr(dev(wv)),
+                             L.ptr(dev(bv)), L.ptr(logits), L.ptr(value), None), "heads_fwd")
+    ref_logits = f_pi.astype(np.float64) @ wpi + bpi
+    ref_value = f_v.astype(np.float64) @ wv + bv
+    assert rel_err(logits.cpu().numpy(), ref_logits) < 2e-6
+    assert rel_err(value.cpu().numpy(), ref_value[:, 0]) < 2e-6
+
+    # PPO loss on the oracle's logits (isolates the loss kernel)
+    n_pool = 150
+    idx = rng.permutation(n_pool)[:b].astype(np.int32)
+    action = rng.integers(0, a_dim, n_pool).astype(np.int32)
+    old_logp = (-np.abs(rng.standard_normal(n_pool)) - 0.3).astype(np.float32)
+    adv = rng.standard_normal(n_pool)
+    old_v = rng.standard_normal(n_pool).astype(np.float32)
+    target_v = old_v + rng.standard_normal(n_pool) * 4
+    lg32, v32 = ref_logits.astype(np.float32), ref_value.astype(np.float32)
+    clip, entc, vfc, cc = 0.1, 0.003, 0.5, 0.7
+    loss, dlg, dv, parts = nets.ppo_loss_and_grads(
+        lg32.astype(np.float64), v32.astype(np.float64), action[idx], old_logp[idx].reshape(-1, 1).astype(np.float64),
+        adv[idx].astype(np.float32).reshape(-1, 1).astype(np.float64), old_v[idx].reshape(-1, 1).astype(np.float64),
+        target_v[idx].astype(np.float32).reshape(-1, 1).astype(np.float64), clip, entc, vfc, cc)
+    dlogits = torch.zeros((b, a_dim), device="cuda")
+    dvalue = torch.zeros((b,), device="cuda")
+    terms = torch.zeros((b, 4), device="cuda")
+    out = torch.zeros(8, device="cuda")
+    acc = torch.zeros(8, device="cuda")
+    L.check(lib.xt_ppo_loss(L.ptr(dev(lg32)), L.ptr(dev(v32[:, 0])), b, a_dim, L.ptr(dev(idx)), L.ptr(dev(action)),
+                            L.ptr(dev(old_logp)), L.ptr(dev(adv)), L.ptr(dev(old_v)), L.ptr(dev(target_v)),
+                            clip, entc, vfc, cc, 1.0 / b, L.ptr(dlogits), L.ptr(dvalue), L.ptr(terms), None), "ppo_loss")
+    L.check(lib.xt_ppo_loss_reduce(L.ptr(terms), b, entc, cc, 1.0 / b, L.ptr(out), L.ptr(acc), None), "reduce")
+    o = out.cpu().numpy()
+    assert abs(o[0] - loss) < 1e-5 * max(1.0, abs(loss))
+    assert abs(o[1] - parts["actor_loss"]) < 1e-5 and abs(o[2] - parts["critic_loss"]) < 1e-5 * max(1, parts["critic_loss"])
+    assert rel_err(dlogits.cpu().numpy(), dlg) < 1e-5
+    assert rel_err(dvalue.cpu().numpy(), dv[:, 0]) < 1e-5
+    assert acc.cpu().numpy()[1] == 1.0
+
+    # heads backward
+    for act_prev in ("relu", "tanh"):
+        dl32, dv32 = dlg.astype(np.float32), dv.astype(np.float32)
+        dwpi = torch.zeros((f, a_dim), device="cuda"); dbpi = torch.zeros(a_dim, device="cuda")
+        dwv = torch.zeros((f,), device="cuda"); dbv = torch.zeros(1, device="cuda")
+        df_pi = torch.zeros((b, f), device="cuda")
+        df_v = df_pi if shared else torch.zeros((b, f), device="cuda")
+        L.check(lib.xt_heads_bwd(L.ptr(d_fpi), L.ptr(d_fv), b, f, a_dim, L.ptr(dev(wpi)), L.ptr(dev(wv)),
+                                 L.ptr(dev(dl32)), L.ptr(dev(dv32[:, 0])), L.ACT[act_prev], L.ptr(dwpi), L.ptr(dbpi),
+                                 L.ptr(dwv), L.ptr(dbv), L.ptr(df_pi), L.ptr(df_v), None), "heads_bwd")
+        assert rel_err(dwpi.cpu().numpy(), f_pi.astype(np.float64).T @ dl32) < 3e-6
+        assert rel_err(dbpi.cpu().numpy(), dl32.astype(np.float64).sum(0)) < 3e-6
+        assert rel_err(dwv.cpu().numpy(), (f_v.astype(np.float64).T @ dv32)[:, 0]) < 3e-6
+        assert rel_err(dbv.cpu().numpy(), dv32.astype(np.float64).sum(0)) < 3e-6
+        dpi = dl32.astype(np.float64) @ wpi.T
+        dvf = dv32.astype(np.float64) @ wv.T
+        if shared:
+            ref = nets.act_bwd(dpi + dvf, f_pi.astype(np.float64), act_prev)
+            assert rel_err(df_pi.cpu().numpy(), ref) < 3e-6
+        else:
+            assert rel_err(df_pi.cpu().numpy(), nets.act_bwd(dpi, f_pi.astype(np.float64), act_prev)) < 3e-6
+            assert rel_err(df_v.cpu().numpy(), nets.act_bwd(dvf, f_v.astype(np.float64), act_prev)) < 3e-6
+
+
+@pytest.mark.parametrize("tlen,n_traj,a_dim", [(128, 3, 4), (50, 20, 6), (2, 1, 4), (5, 2, 18)])
+def test_impala_vtrace_loss(L, tlen, n_traj, a_dim):
+    rng = np.random.default_rng(9)
+    n = tlen * n_traj
+    logits = rng.standard_normal((n, a_dim)).astype(np.float32)
+    baseline = rng.standard_normal(n).astype(np.float32)
+    bp = rng.standard_normal((n, a_dim)).astype(np.float32)
+    act = rng.integers(0, a_dim, n).astype(np.int32)
+    done = rng.random(n) < 0.1
+    rew = (rng.standard_normal(n) * 2).astype(np.float32)
+    loss, dlg, dbl, parts = nets.impala_loss_and_grads(logits, baseline, bp, act, done, rew, tlen)
+    dlogits = torch.full((n, a_dim), float("nan"), device="cuda")
+    dbase = torch.full((n,), float("nan"), device="cuda")
+    out = torch.zeros(8 + n_traj, device="cuda")
+    vs = torch.zeros((n_traj, tlen - 1), device="cuda")
+    pg = torch.zeros((n_traj, tlen - 1), device="cuda")
+    L.check(L.load().xt_impala_loss(L.ptr(dev(logits)), L.ptr(dev(baseline)), L.ptr(dev(bp)), L.ptr(dev(act)),
+                                    L.ptr(dev(done.astype(np.uint8))), L.ptr(dev(rew)), n_traj, tlen, a_dim, 0.99,
+                                    L.ptr(dlogits), L.ptr(dbase), L.ptr(out), None, L.ptr(vs), L.ptr(pg), None),
+            "impala_loss")
+    assert rel_err(vs.cpu().numpy(), parts["vs"].T) < 1e-5      # oracle is [T-1, B]
+    assert rel_err(pg.cpu().numpy(), parts["pg_adv"].T) < 1e-5
+    assert abs(out[0].item() - loss) < 2e-5 * max(1.0, abs(loss))
+    assert rel_err(dlogits.cpu().numpy(), dlg) < 1e-5
+    assert rel_err(dbase.cpu().numpy(), dbl) < 1e-5
+    # bit-exact index/mask behaviour: the bootstrap step of every trajectory carries no gradient
+    assert (dlogits.cpu().numpy().reshape(n_traj, tlen, a_dim)[:, -1] == 0).all()
+    assert (dbase.cpu().numpy().reshape(n_traj, tlen)[:, -1] == 0).all()
+
+
+# ------------------------------------------------------------------ optimiser
+@pytest.mark.parametrize("count,clip", [(847496, 5.0), (1003, 0.01), (4, 40.0)])
+def test_adam_tf_clip(L, count, clip):
+    rng = np.random.default_rng(4)
+    p = rng.standard_normal(count).astype(np.float32)
+    params = {"w": p.copy()}
+    opt = nets.AdamTF(params, 2.5e-4)
+    dp, dm, dv_ = dev(p), torch.zeros(count, device="cuda"), torch.zeros(count, device="cuda")
+    state = torch.zeros(8, device="cuda")
+    scratch = torch.zeros(1024, device="cuda")
+    lib = L.load()
+    L.check(lib.xt_adam_state_init(L.ptr(state), None), "init")
+    for it in range(4):
+        g = (rng.standard_normal(count) * (0.01 if it % 2 else 1.0)).astype(np.float32)
+        clipped, gn = nets.clip_by_global_norm({"w": g}, clip)
+        opt.apply(params, clipped)
+        L.check(lib.xt_adam_tf_clip(L.ptr(dp), L.ptr(dev(g)), L.ptr(dm), L.ptr(dv_), count, 2.5e-4, 0.9, 0.999, 1e-8,
+                                    clip, 1.0, L.ptr(state), L.ptr(scratch), None), "adam")
+        st = state.cpu().numpy()
+        assert abs(st[4] - gn) < 1e-5 * gn
+        assert st[5] == it + 1
+        np.testing.assert_allclose(dp.cpu().numpy(), params["w"], rtol=2e-5, atol=2e-7)

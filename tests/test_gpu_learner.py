@@ -1,0 +1,305 @@
+"""GPU parity tests of the whole learner update (network level + plugin classes) against the
+float64 oracle on identical seeded rollout batches.  Bar (north_star): loss and every gradient
+tensor within 1e-4 relative of the reference math."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(got, ref):
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    return np.linalg.norm((got - ref).ravel()) / (np.linalg.norm(ref.ravel()) + 1e-30)
+
+
+def assert_update_close(w_got, w_ref, w_init, lr, tag=""):
+    """post-Adam parity.  The first Adam steps are sign-like (m/(sqrt(v)+eps)), so an element whose
+    gradient is ~eps-sized turns a 1e-11 gradient difference into a visible step difference; compare the
+    UPDATE per tensor in L2 (<=1e-3) and bound every element by a small fraction of one lr step."""
+    for k, ref in w_ref.items():
+        got = np.asarray(w_got[k], np.float64).reshape(ref.shape)
+        init = np.asarray(w_init[k], np.float64).reshape(ref.shape)
+        upd_ref, upd_got = ref - init, got - init
+        if np.linalg.norm(upd_ref) > 0:
+            assert rel_err(upd_got, upd_ref) < 1e-3, (tag, k, rel_err(upd_got, upd_ref))
+        assert np.abs(got - ref).max() <= 0.1 * lr, (tag, k, np.abs(got - ref).max())
+
+
+def synth_ppo_rollout(rng, n, state_dim, a_dim, u8=True):
+    if u8:
+        obs = rng.integers(0, 256, (n,) + tuple(state_dim)).astype(np.uint8)
+    else:
+        obs = rng.uniform(-1, 1, (n,) + tuple(state_dim)).astype(np.float32)
+    action = rng.integers(0, a_dim, n).astype(np.int32)
+    logits = rng.standard_normal((n, a_dim))
+    lsm = logits - np.log(np.exp(logits).sum(-1, keepdims=True))
+    logp = np.take_along_axis(lsm, action[:, None].astype(np.int64), 1).astype(np.float32)
+    adv = rng.standard_normal((n, 1))
+    old_v = rng.standard_normal((n, 1)).astype(np.float32)
+    target_v = old_v.astype(np.float64) + rng.standard_normal((n, 1))
+    return obs, [action, logp, adv, old_v, target_v]
+
+
+def oracle_params_for(net, oracle_spec, seed):
+    """seeded oracle params, copied into the HIP net by TF variable name."""
+    params = nets.init_params(oracle_spec, seed=seed, bias_scale=0.05)
+    w = {}
+    for k, v in params.items():
+        shape = net.spec.names[k][1]
+        w[k] = v.reshape(shape)
+    net.set_weights(w)
+    return params
+
+
+PPO_CFG = dict(LR=2.5e-4, LOSS_CLIPPING=0.1, ENTROPY_LOSS=0.003, VF_CLIP=5.0, CRITIC_LOSS_COEF=1.0,
+               MAX_GRAD_NORM=5.0, BATCH_SIZE=64, NUM_SGD_ITER=2)
+
+
+def _mk(which, batch):
+    from xingtian_amd.model import netspec
+    from xingtian_amd.model.hip_net import HipActorCritic
+    if which == "cnn84":
+        spec = netspec.ppo_cnn((84, 84, 4), 4, (256,), "relu", True)
+        ospec = nets.ppo_cnn_spec((84, 84, 4), 4, (256,), "relu", True)
+        sd, u8 = (84, 84, 4), True
+    elif which == "cnn42_unshared":
+        spec = netspec.ppo_cnn((42, 42, 4), 6, (64,), "tanh", False)
+        ospec = nets.ppo_cnn_spec((42, 42, 4), 6, (64,), "tanh", False)
+        sd, u8 = (42, 42, 4), True
+    else:
+        spec = netspec.ppo_mlp((4,), 2, (64, 64), "tanh", False)
+        ospec = nets.ppo_mlp_spec((4,), 2, (64, 64), "tanh", False)
+        sd, u8 = (4,), False
+    net = HipActorCritic(spec, max_batch=batch, seed=0)
+    return net, ospec, sd, u8
+
+
+@pytest.mark.parametrize("which,b", [("cnn84", 48), ("cnn42_unshared", 33), ("mlp", 200)])
+def test_ppo_step_loss_and_grads_vs_oracle(which, b):
+    net, ospec, sd, u8 = _mk(which, b)
+    params = oracle_params_for(net, ospec, seed=7)
+    rng = np.random.default_rng(0)
+    n = b + 40
+    obs, lab = synth_ppo_rollout(rng, n, sd, ospec["action_dim"], u8)
+    idx = rng.permutation(n)[:b].astype(np.int32)
+    cfg = dict(PPO_CFG, BATCH_SIZE=b)
+    orc = nets.PpoLearnerOracle(ospec, params, cfg, np.float64)
+    out = orc.step(obs[idx], lab[0][idx], lab[1][idx].astype(np.float32), lab[2][idx].astype(np.float32),
+                   lab[3][idx].astype(np.float32), lab[4][idx].astype(np.float32), apply=True)
+    c = net.make_ppo_cfg(cfg)
+    d = lambda a, dt=None: (torch.from_numpy(np.ascontiguousarray(a)).to(dt) if dt else
+                            torch.from_numpy(np.ascontiguousarray(a))).cuda()
+    dobs = net.to_device_obs(obs)
+    lo = net.ppo_step(c, dobs, d(idx), d(lab[0]), d(lab[1].reshape(-1)), d(lab[2].reshape(-1)),
+                      d(lab[3].reshape(-1)), d(lab[4].reshape(-1)), apply=True)
+    torch.cuda.synchronize()
+    loss = lo.cpu().numpy()[0]
+    assert abs(loss - out["loss"]) <= 1e-4 * max(1.0, abs(out["loss"])), (loss, out["loss"])
+    g = net.grads_dict()
+    worst = 0.0
+    for k, ref in out["grads"].items():
+        e = rel_err(g[k].reshape(ref.shape), ref)
+        worst = max(worst, e)
+        assert e < 1e-4, (k, e)
+    st = net.adam_state.cpu().numpy()
+    assert abs(st[4] - out["gnorm"]) < 1e-4 * out["gnorm"]
+    assert_update_close(net.get_weights(), orc.net.params, params, cfg["LR"], which)
+    print("worst grad rel err", which, worst)
+
+
+def test_ppo_train_matches_oracle_and_graph_replay_is_bitwise():
+    """Model.train loop: epochs x minibatches incl. a short last minibatch; the hipGraph replay
+    must reproduce the eager enqueue bit for bit, twice."""
+    from xingtian_amd.model import netspec
+    from xingtian_amd.model.hip_net import HipActorCritic
+    spec = netspec.ppo_cnn((42, 42, 4), 4, (64,), "relu", True)
+    ospec = nets.ppo_cnn_spec((42, 42, 4), 4, (64,), "relu", True)
+    cfg = dict(PPO_CFG, BATCH_SIZE=40, NUM_SGD_ITER=2)
+    rng = np.random.default_rng(3)
+    n = 100   # 40 + 40 + 20
+    obs, lab = synth_ppo_rollout(rng, n, (42, 42, 4), 4)
+    perms = np.stack([rng.permutation(n) for _ in range(2)]).astype(np.int32)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    results = []
+
+    def run(net, bufs, use_graph):
+        params = oracle_params_for(net, ospec, seed=11)
+        net.reset_optimizer()
+        acc = net.ppo_train(net.make_ppo_cfg(cfg), *bufs, use_graph=use_graph)
+        torch.cuda.synchronize()
+        a = acc.cpu().numpy()
+        assert a[1] == 6.0
+        results.append((a[0] / a[1], net.params.cpu().numpy().copy()))
+        return params
+
+    def mkbufs(net):
+        return [net.to_device_obs(obs), d(perms), d(lab[0]), d(lab[1].reshape(-1)), d(lab[2].reshape(-1)),
+                d(lab[3].reshape(-1)), d(lab[4].reshape(-1))]
+
+    net_e = HipActorCritic(spec, max_batch=40, seed=0)
+    params = run(net_e, mkbufs(net_e), False)          # eager enqueue
+    net = HipActorCritic(spec, max_batch=40, seed=0)
+    bufs = mkbufs(net)
+    run(net, bufs, True)                               # capture + first launch
+    run(net, bufs, True)                               # cached graph replay from the same initial state
+    assert np.array_equal(results[0][1], results[1][1])
+    assert np.array_equal(results[1][1], results[2][1])
+    assert results[0][0] == results[1][0] == results[2][0]
+    orc = nets.PpoLearnerOracle(ospec, params, cfg, np.float64)
+    ref_loss = orc.train([obs], lab, perms)
+    assert abs(results[0][0] - ref_loss) < 1e-4 * max(1.0, abs(ref_loss))
+    # 6 SGD steps: every element moved by at most 6 lr-sized steps
+    for k, ref in orc.net.params.items():
+        got = net.get_weights()[k].reshape(ref.shape)
+        assert rel_err(got - params[k], ref - params[k]) < 2e-3, k
+        assert np.abs(got - ref).max() <= 0.2 * cfg["LR"], k
+
+
+@pytest.mark.parametrize("dim,a_dim,tlen,ntraj,mean,std", [(84, 4, 16, 3, 0.0, 255.0), (42, 6, 50, 4, 128.0, 128.0)])
+def test_impala_step_vs_oracle(dim, a_dim, tlen, ntraj, mean, std):
+    from xingtian_amd.model import netspec
+    from xingtian_amd.model.hip_net import HipActorCritic
+    spec = netspec.impala_cnn_opt((dim, dim, 4), a_dim, mean, std)
+    ospec = nets.impala_cnn_opt_spec((dim, dim, 4), a_dim, mean, std)
+    n = tlen * ntraj
+    net = HipActorCritic(spec, max_batch=n, seed=0)
+    params = oracle_params_for(net, ospec, seed=5)
+    rng = np.random.default_rng(1)
+    obs = rng.integers(0, 256, (n, dim, dim, 4)).astype(np.uint8)
+    bp = rng.standard_normal((n, a_dim)).astype(np.float32)
+    act = rng.integers(0, a_dim, n).astype(np.int32)
+    done = rng.random(n) < 0.05
+    rew = rng.choice([-2.0, 0.0, 1.0, 3.0], n).astype(np.float32)
+    cfg = dict(LR=5e-4, grad_norm_clip=40.0, sample_batch_step=tlen, BATCH_SIZE=n)
+    orc = nets.ImpalaLearnerOracle(ospec, params, cfg, np.float64)
+    out = orc.step(obs, bp, act, done, rew, apply=True)
+    c = net.make_impala_cfg(5e-4, 40.0, tlen)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    lo = net.impala_step(c, d(obs), d(bp), d(act), d(done.astype(np.uint8)), d(rew), apply=True)
+    torch.cuda.synchronize()
+    loss = lo.cpu().numpy()[0]
+    assert abs(loss - out["loss"]) <= 1e-4 * max(1.0, abs(out["loss"])), (loss, out["loss"])
+    g = net.grads_dict()
+    for k, ref in out["grads"].items():
+        e = rel_err(g[k].reshape(ref.shape), ref)
+        assert e < 1e-4, (k, e)
+    assert_update_close(net.get_weights(), orc.net.params, params, 5e-4, "impala")
+
+
+# ------------------------------------------------------------------ plugin classes (the drop-in boundary)
+def test_registry_ppo_cnn_algorithm_end_to_end():
+    """alg_builder('PPO') + model 'PpoCnn' from a breakout_ppo.yaml-shaped config; prepare_data x env_num,
+    train(), get_weights()/set_weights()/save/restore round trip."""
+    import os
+    import tempfile
+    from xingtian_amd.algorithm import alg_builder
+    model_info = {"actor": {"model_name": "PpoCnn", "state_dim": [84, 84, 4], "action_dim": 4,
+                            "input_dtype": "uint8",
+                            "model_config": {"BATCH_SIZE": 64, "CRITIC_LOSS_COEF": 1.0, "ENTROPY_LOSS": 0.003,
+                                             "LOSS_CLIPPING": 0.1, "LR": 0.00025, "MAX_GRAD_NORM": 5.0,
+                                             "NUM_SGD_ITER": 2, "SUMMARY": False, "VF_SHARE_LAYERS": True,
+                                             "activation": "relu", "hidden_sizes": [256],
+                                             "action_type": "Categorical", "SEED": 1}}}
+    alg_config = {"instance_num": 3, "agent_num": 1}
+    alg = alg_builder("PPO", model_info, alg_config)
+    assert alg.prepare_data_times == 3 and alg.async_flag is False
+    rng = np.random.default_rng(2)
+    tlen = 32
+    all_obs, all_lab = [], [[] for _ in range(5)]
+    for env in range(3):
+        obs, lab = synth_ppo_rollout(rng, tlen, (84, 84, 4), 4)
+        alg.prepare_data({"cur_state": obs, "action": lab[0], "logp": lab[1], "adv": lab[2], "old_value": lab[3],
+                          "target_value": lab[4]})
+        all_obs.append(obs)
+        for i in range(5):
+            all_lab[i].append(lab[i])
+    w0 = alg.get_weights()
+    assert "shared_conv_layer_0/kernel" in w0 and w0["shared_conv_layer_0/kernel"].shape == (8, 8, 4, 32)
+    assert w0["shared_hidden_mlp_0/kernel"].shape == (3136, 256) and w0["pi_latent/kernel"].shape == (256, 4)
+    perms = np.stack([rng.permutation(3 * tlen) for _ in range(2)]).astype(np.int32)
+    loss = alg.train(perms=perms)
+    assert isinstance(loss, (float, np.floating)) and np.isfinite(loss)
+    assert alg.obs == []
+    ospec = nets.ppo_cnn_spec((84, 84, 4), 4, (256,), "relu", True)
+    cfg = dict(LR=0.00025, LOSS_CLIPPING=0.1, ENTROPY_LOSS=0.003, VF_CLIP=5.0, CRITIC_LOSS_COEF=1.0,
+               MAX_GRAD_NORM=5.0, BATCH_SIZE=64, NUM_SGD_ITER=2)
+    orc = nets.PpoLearnerOracle(ospec, {k: v.reshape(nets.init_params(ospec)[k].shape) for k, v in w0.items()},
+                                cfg, np.float64)
+    ref = orc.train([np.concatenate(all_obs)], [np.concatenate(x) for x in all_lab], perms)
+    assert abs(loss - ref) < 1e-4 * max(1.0, abs(ref))
+    w1 = alg.get_weights()
+    for k, r in orc.net.params.items():
+        assert rel_err(w1[k].reshape(r.shape) - w0[k].reshape(r.shape), r - w0[k].reshape(r.shape)) < 2e-3, k
+        assert np.abs(w1[k].reshape(r.shape) - r).max() <= 0.2 * 0.00025, k
+    # predict contract
+    action, logp, value = alg.predict(all_obs[0][0])
+    assert action.shape == (1,) and action.dtype == np.int32 and logp.shape == (1, 1) and value.shape == (1, 1)
+    # save / restore round trip; unknown names ignored, nothing matching -> KeyError
+    with tempfile.TemporaryDirectory() as tmp:
+        names = alg.save(tmp, 7)
+        assert names == [os.path.join(tmp, "actor_00007.npz")]
+        alg.set_weights({k: v * 0 for k, v in w1.items()})
+        alg.restore(model_name=names[0])
+        w2 = alg.get_weights()
+        assert all(np.array_equal(w1[k], w2[k]) for k in w1)
+    alg.restore(model_weights=dict(w0, **{"not/a/variable": np.zeros(3)}))
+    with pytest.raises(KeyError):
+        alg.set_weights({"nope": np.zeros(1)})
+
+
+def test_registry_impala_opt_end_to_end():
+    from xingtian_amd.algorithm import alg_builder
+    model_info = {"actor": {"model_name": "ImpalaCnnOpt", "state_dim": [42, 42, 4], "input_dtype": "uint8",
+                            "state_mean": 128.0, "state_std": 128.0, "action_dim": 6,
+                            "model_config": {"LR": 0.001, "sample_batch_step": 10, "grad_norm_clip": 40.0, "SEED": 3}}}
+    alg = alg_builder("IMPALAOpt", model_info, {"instance_num": 2, "agent_num": 1, "prepare_times_per_train": 2,
+                                               "BATCH_SIZE": 40, "train_per_checkpoint": 1})
+    rng = np.random.default_rng(4)
+    w0 = alg.get_weights()
+    assert w0["explore_agent/conv2d_3/kernel"].shape == (1, 1, 256, 6)
+    msgs = []
+    for _ in range(2):
+        n = 30   # 3 envs x 10 steps, env-major
+        m = {"cur_state": rng.integers(0, 256, (n, 42, 42, 4)).astype(np.uint8),
+             "logit": rng.standard_normal((n, 6)).astype(np.float32),
+             "action": rng.integers(0, 6, n).astype(np.int32), "done": list(rng.random(n) < 0.1),
+             "reward": list(rng.choice([-1.0, 0.0, 1.0], n))}
+        alg.prepare_data(m)
+        msgs.append(m)
+    loss = alg.train()
+    assert np.isfinite(loss)
+    ospec = nets.impala_cnn_opt_spec((42, 42, 4), 6, 128.0, 128.0)
+    shapes = nets.init_params(ospec)
+    orc = nets.ImpalaLearnerOracle(ospec, {k: v.reshape(shapes[k].shape) for k, v in w0.items()},
+                                   dict(LR=0.001, grad_norm_clip=40.0, sample_batch_step=10, BATCH_SIZE=40), np.float64)
+    cat = lambda key, dt: np.concatenate([np.asarray(m[key], dt) for m in msgs])
+    ref = orc.train(cat("cur_state", np.uint8), cat("logit", np.float32), cat("action", np.int32),
+                    cat("done", bool), cat("reward", np.float32))
+    assert abs(loss - ref) < 1e-4 * max(1.0, abs(ref))
+    logits, baseline, action = alg.predict(msgs[0]["cur_state"][:5])
+    assert logits.shape == (5, 6) and baseline.shape == (5,) and action.shape == (5,)
+
+
+def test_gae_on_learner_path_through_algorithm():
+    """trajectories without 'adv' get GAE on the GPU, identical to the actor-side numpy result."""
+    from oracle import returns
+    from xingtian_amd.algorithm import alg_builder
+    model_info = {"actor": {"model_name": "PpoMlp", "state_dim": [4], "action_dim": 2, "input_dtype": "float32",
+                            "model_config": {"BATCH_SIZE": 50, "NUM_SGD_ITER": 1, "SEED": 0,
+                                             "action_type": "Categorical"}}}
+    alg = alg_builder("PPO", model_info, {"instance_num": 1, "agent_num": 1})
+    rng = np.random.default_rng(6)
+    t = 50
+    value = rng.standard_normal((t + 1, 1)).astype(np.float32)
+    reward = rng.standard_normal(t)
+    done = rng.random(t) < 0.1
+    alg.prepare_data({"cur_state": rng.standard_normal((t, 4)).astype(np.float32),
+                      "action": rng.integers(0, 2, t).astype(np.int32),
+                      "logp": -np.ones((t, 1), np.float32), "value": value, "reward": reward, "done": done})
+    adv, ov, tgt = returns.gae(value, reward.copy(), done)
+    assert np.array_equal(alg.adv[0], adv) and np.array_equal(alg.target_v[0], tgt) and np.array_equal(alg.old_v[0], ov)
+    assert np.isfinite(alg.train())

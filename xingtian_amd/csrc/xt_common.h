@@ -1,0 +1,62 @@
+// Shared host/device helpers for the MI355X (gfx950) learner kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "xt_mi355x.h"
+
+namespace xt {
+
+void set_error(const char* fmt, ...);
+
+#define XT_CHECK_HIP(expr)                                                                  \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      (void)hipGetLastError(); /* do not leave a sticky error for the host framework */      \
+      xt::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return 1;                                                                             \
+    }                                                                                       \
+  } while (0)
+
+#define XT_REQUIRE(cond, ...)          \
+  do {                                 \
+    if (!(cond)) {                     \
+      xt::set_error(__VA_ARGS__);      \
+      return 2;                        \
+    }                                  \
+  } while (0)
+
+#define XT_LAUNCH_CHECK() XT_CHECK_HIP(hipGetLastError())
+
+// n / d for n*d < 2^32 via one v_mul_hi_u32 (magic = floor(2^32/d)+1).
+struct FastDiv {
+  uint32_t d, magic;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  f.magic = (d <= 1) ? 0u : (uint32_t)((1ull << 32) / d) + 1u;
+  return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) {
+  return f.d <= 1 ? n : __umulhi(n, f.magic);
+}
+
+__device__ __forceinline__ float act_apply(float z, int act) {
+  if (act == XT_ACT_RELU) return z > 0.f ? z : 0.f;
+  if (act == XT_ACT_TANH) return tanhf(z);
+  return z;
+}
+// d(pre-activation)/d(post) from the saved OUTPUT y
+__device__ __forceinline__ float act_grad(float y, int act) {
+  if (act == XT_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  if (act == XT_ACT_TANH) return 1.f - y * y;
+  return 1.f;
+}
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace xt

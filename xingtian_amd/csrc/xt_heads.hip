@@ -1,0 +1,408 @@
+// Policy/value heads, PPO and IMPALA(v-trace) losses and their gradients, GAE.
+// All HBM/latency-bound; wave64 shuffles for the reductions, no atomics (deterministic).
+#include "xt_common.h"
+
+namespace xt {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------- heads forward
+// one wave per sample; lanes stride the feature axis
+__global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict__ f_pi, const float* __restrict__ f_v,
+                                                        int B, int F, int A, const float* __restrict__ wpi,
+                                                        const float* __restrict__ bpi, const float* __restrict__ wv,
+                                                        const float* __restrict__ bv, float* __restrict__ logits,
+                                                        float* __restrict__ value) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float* fp = f_pi + (size_t)b * F;
+  const float* fv = f_v + (size_t)b * F;
+  for (int a = 0; a < A; ++a) {
+    float s = 0.f;
+    for (int f = lane; f < F; f += 64) s = fmaf(fp[f], wpi[(size_t)f * A + a], s);
+    s = wave_sum(s);
+    if (lane == 0) logits[(size_t)b * A + a] = s + bpi[a];
+  }
+  float s = 0.f;
+  for (int f = lane; f < F; f += 64) s = fmaf(fv[f], wv[f], s);
+  s = wave_sum(s);
+  if (lane == 0) value[b] = s + bv[0];
+}
+
+// ---------------------------------------------------------------- PPO loss
+// one thread per sample (A is tiny); tf_dist.py:103-113 + model/ppo/__init__.py:4-25
+__global__ __launch_bounds__(256) void ppo_loss_kernel(const float* __restrict__ logits, const float* __restrict__ value,
+                                                       int B, int A, const int32_t* __restrict__ idx,
+                                                       const int32_t* __restrict__ action, const float* __restrict__ old_logp,
+                                                       const double* __restrict__ adv, const float* __restrict__ old_v,
+                                                       const double* __restrict__ target_v, float clip_ratio,
+                                                       float ent_coef, float vf_clip, float critic_coef, float inv_b,
+                                                       float* __restrict__ dlogits, float* __restrict__ dvalue,
+                                                       float* __restrict__ terms) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const int s = idx ? idx[b] : b;
+  const float* lg = logits + (size_t)b * A;
+  float mx = lg[0];
+  for (int a = 1; a < A; ++a) mx = fmaxf(mx, lg[a]);
+  float z = 0.f;
+  for (int a = 0; a < A; ++a) z += expf(lg[a] - mx);
+  const float logz = logf(z);
+  const int act = action[s];
+  float ent = 0.f;
+  for (int a = 0; a < A; ++a) {
+    const float rl = lg[a] - mx;
+    ent += (expf(rl) / z) * (logz - rl);
+  }
+  const float logp = (lg[act] - mx) - logz;
+  const float advf = (float)adv[s];            // float32 placeholder cast (ppo.py:65-68)
+  const float tv = (float)target_v[s];
+  const float ov = old_v[s];
+  const float ratio = expf(logp - old_logp[s]);
+  const float surr1 = ratio * advf;
+  const float rc = fminf(fmaxf(ratio, 1.f - clip_ratio), 1.f + clip_ratio);
+  const float surr2 = rc * advf;
+  const float surr = fminf(surr1, surr2);
+  const bool first = surr1 <= surr2;
+  const bool in_rng = (ratio >= 1.f - clip_ratio) && (ratio <= 1.f + clip_ratio);
+  const float dsurr = (first || in_rng) ? advf : 0.f;
+  const float dlogp = -(dsurr * ratio) * inv_b;
+  const float v = value[b];
+  const float d1 = v - tv;
+  const float vf1 = d1 * d1;
+  const float vcl = ov + fminf(fmaxf(v - ov, -vf_clip), vf_clip);
+  const float d2 = vcl - tv;
+  const float vf2 = d2 * d2;
+  const bool take1 = vf1 >= vf2;
+  const bool in_v = fabsf(v - ov) <= vf_clip;
+  const float dv = take1 ? 2.f * d1 : (in_v ? 2.f * d2 : 0.f);
+  dvalue[b] = critic_coef * 0.5f * inv_b * dv;
+  for (int a = 0; a < A; ++a) {
+    const float rl = lg[a] - mx;
+    const float pa = expf(rl) / z;
+    const float lpa = rl - logz;
+    const float onehot = (a == act) ? 1.f : 0.f;
+    // d(-ent_coef*mean(H))/dlogit = +ent_coef/B * p*(log p + H)
+    dlogits[(size_t)b * A + a] = dlogp * (onehot - pa) + ent_coef * inv_b * (pa * (lpa + ent));
+  }
+  float* tm = terms + (size_t)b * 4;
+  tm[0] = surr; tm[1] = ent; tm[2] = fmaxf(vf1, vf2); tm[3] = 0.f;
+}
+
+// single block, fixed-order tree: loss scalars from the per-sample terms
+__global__ __launch_bounds__(256) void ppo_loss_reduce_kernel(const float* __restrict__ terms, int B, float ent_coef,
+                                                              float critic_coef, float inv_b, float* __restrict__ out,
+                                                              float* __restrict__ acc) {
+  __shared__ float sh[3][256];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    s0 += terms[(size_t)b * 4 + 0]; s1 += terms[(size_t)b * 4 + 1]; s2 += terms[(size_t)b * 4 + 2];
+  }
+  sh[0][threadIdx.x] = s0; sh[1][threadIdx.x] = s1; sh[2][threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+      sh[2][threadIdx.x] += sh[2][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float surr = sh[0][0] * inv_b, ent = sh[1][0] * inv_b, vf = 0.5f * sh[2][0] * inv_b;
+    const float actor = -surr - ent_coef * ent;
+    const float loss = actor + critic_coef * vf;
+    out[0] = loss; out[1] = actor; out[2] = vf; out[3] = ent;
+    if (acc) { acc[0] += loss; acc[1] += 1.f; }
+  }
+}
+
+// ---------------------------------------------------------------- IMPALA v-trace loss
+// one block per trajectory, thread t = time step.  Phases: (1) per-step rho/c/delta in
+// parallel, (2) serial reverse scan by thread 0 over LDS, (3) per-step pg_adv + grads.
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void impala_loss_kernel(const float* __restrict__ logits, const float* __restrict__ baseline,
+                                                           const float* __restrict__ bp_logits, const int32_t* __restrict__ action,
+                                                           const uint8_t* __restrict__ done, const float* __restrict__ reward,
+                                                           int T, int A, float gamma, float* __restrict__ dlogits,
+                                                           float* __restrict__ dbaseline, float* __restrict__ traj_loss,
+                                                           float* __restrict__ vs_out, float* __restrict__ pg_out) {
+  __shared__ float s_delta[MAXT], s_dc[MAXT], s_vs[MAXT + 1], s_red[MAXT];
+  const int t = threadIdx.x;
+  const int traj = blockIdx.x;
+  const int Tm = T - 1;                      // steps that carry loss; step T-1 is the bootstrap only
+  const size_t base = (size_t)traj * T;
+  float rho = 0.f, disc = 0.f, rew = 0.f, val = 0.f, ce = 0.f, ent = 0.f, logz = 0.f, mx = 0.f, z = 1.f;
+  int act = 0;
+  if (t < Tm) {
+    const float* lg = logits + (base + t) * A;
+    const float* bl = bp_logits + (base + t) * A;
+    act = action[base + t];
+    mx = lg[0];
+    float bmx = bl[0];
+    for (int a = 1; a < A; ++a) { mx = fmaxf(mx, lg[a]); bmx = fmaxf(bmx, bl[a]); }
+    z = 0.f;
+    float bz = 0.f;
+    for (int a = 0; a < A; ++a) { z += expf(lg[a] - mx); bz += expf(bl[a] - bmx); }
+    logz = logf(z);
+    const float tlp = (lg[act] - mx) - logz;
+    const float blp = (bl[act] - bmx) - logf(bz);
+    ce = -tlp;
+    rho = expf(tlp - blp);
+    disc = done[base + t] ? 0.f : gamma;
+    rew = fminf(fmaxf(reward[base + t], -1.f), 1.f);
+    val = baseline[base + t];
+    const float nval = baseline[base + t + 1];          // t+1 == T-1 -> bootstrap value
+    const float crho = fminf(1.f, rho);
+    s_delta[t] = crho * (rew + disc * nval - val);
+    s_dc[t] = disc * fminf(1.f, rho);
+    for (int a = 0; a < A; ++a) {
+      const float rl = lg[a] - mx;
+      ent += (expf(rl) / z) * (logz - rl);
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    float acc = 0.f;
+    for (int q = Tm - 1; q >= 0; --q) {
+      acc = s_delta[q] + s_dc[q] * acc;
+      s_vs[q] = acc + baseline[base + q];
+    }
+    s_vs[Tm] = baseline[base + Tm];                     // bootstrap
+  }
+  __syncthreads();
+  float lterm = 0.f;
+  if (t < Tm) {
+    const float vs = s_vs[t], vsn = s_vs[t + 1];
+    const float pg = fminf(1.f, rho) * (rew + disc * vsn - val);
+    const float* lg = logits + (base + t) * A;
+    for (int a = 0; a < A; ++a) {
+      const float rl = lg[a] - mx;
+      const float pa = expf(rl) / z;
+      const float lpa = rl - logz;
+      const float onehot = (a == act) ? 1.f : 0.f;
+      dlogits[(base + t) * A + a] = pg * (pa - onehot) + 0.01f * (pa * (lpa + ent));
+    }
+    dbaseline[base + t] = 0.5f * (val - vs);
+    const float dvv = vs - val;
+    lterm = ce * pg + 0.5f * (0.5f * dvv * dvv) + 0.01f * (-ent);
+    if (vs_out) vs_out[(size_t)traj * Tm + t] = vs;
+    if (pg_out) pg_out[(size_t)traj * Tm + t] = pg;
+  } else if (t == Tm) {
+    for (int a = 0; a < A; ++a) dlogits[(base + t) * A + a] = 0.f;
+    dbaseline[base + t] = 0.f;
+  }
+  s_red[t] = lterm;
+  __syncthreads();
+  if (t == 0) {
+    float s = 0.f;
+    for (int q = 0; q < T; ++q) s += s_red[q];
+    traj_loss[traj] = s;
+  }
+}
+
+__global__ void impala_loss_reduce_kernel(const float* __restrict__ traj_loss, int n, float* __restrict__ out,
+                                          float* __restrict__ acc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += traj_loss[i];
+    out[0] = s;
+    if (acc) { acc[0] += s; acc[1] += 1.f; }
+  }
+}
+
+// ---------------------------------------------------------------- heads backward
+// gradient w.r.t. trunk features, times the producer's activation gradient
+__global__ __launch_bounds__(256) void heads_dfeat_kernel(const float* __restrict__ f_pi, const float* __restrict__ f_v,
+                                                          int B, int F, int A, const float* __restrict__ wpi,
+                                                          const float* __restrict__ wv, const float* __restrict__ dlogits,
+                                                          const float* __restrict__ dvalue, int act_prev, int shared,
+                                                          float* __restrict__ df_pi, float* __restrict__ df_v) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * F) return;
+  const int b = e / F, f = e - b * F;
+  float s = 0.f;
+  for (int a = 0; a < A; ++a) s = fmaf(dlogits[(size_t)b * A + a], wpi[(size_t)f * A + a], s);
+  const float sv = dvalue[b] * wv[f];
+  if (shared) {
+    df_pi[e] = (s + sv) * act_grad(f_pi[e], act_prev);
+  } else {
+    df_pi[e] = s * act_grad(f_pi[e], act_prev);
+    df_v[e] = sv * act_grad(f_v[e], act_prev);
+  }
+}
+
+// head weight gradients: block = 64 features x 4 batch groups; outputs in chunks of 8
+__global__ __launch_bounds__(256) void heads_wgrad_kernel(const float* __restrict__ f_pi, const float* __restrict__ f_v,
+                                                          int B, int F, int A, const float* __restrict__ dlogits,
+                                                          const float* __restrict__ dvalue, float* __restrict__ dwpi,
+                                                          float* __restrict__ dbpi, float* __restrict__ dwv,
+                                                          float* __restrict__ dbv) {
+  __shared__ float red[4][64][9];
+  const int fl = threadIdx.x & 63, bg = threadIdx.x >> 6;
+  const int f = blockIdx.x * 64 + fl;
+  const bool fok = f < F;
+  // outputs 0..A-1: pi columns, output A: value column
+  for (int a0 = 0; a0 <= A; a0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    for (int b = bg; b < B; b += 4) {
+      const float xp = fok ? f_pi[(size_t)b * F + f] : 0.f;
+      const float xv = fok ? f_v[(size_t)b * F + f] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int a = a0 + q;
+        if (a < A) acc[q] = fmaf(xp, dlogits[(size_t)b * A + a], acc[q]);
+        else if (a == A) acc[q] = fmaf(xv, dvalue[b], acc[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) red[bg][fl][q] = acc[q];
+    __syncthreads();
+    if (bg == 0 && fok) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int a = a0 + q;
+        const float s = red[0][fl][q] + red[1][fl][q] + red[2][fl][q] + red[3][fl][q];
+        if (a < A) dwpi[(size_t)f * A + a] = s;
+        else if (a == A) dwv[f] = s;
+      }
+    }
+    __syncthreads();
+  }
+  // bias grads: block 0, wave-parallel over batch
+  if (blockIdx.x == 0) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int a = w; a <= A; a += 4) {
+      float s = 0.f;
+      for (int b = lane; b < B; b += 64) s += (a < A) ? dlogits[(size_t)b * A + a] : dvalue[b];
+      s = wave_sum(s);
+      if (lane == 0) { if (a < A) dbpi[a] = s; else dbv[0] = s; }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- GAE (float64, bit-exact with numpy)
+// one thread per trajectory; same association as xt/agent/ppo/ppo.py:92-104:
+//   discount = (~done)*gamma ; delta = (reward + discount*next_v) - v ;
+//   adv[j] += (adv[j+1]*discount[j])*lam ; target = adv + v.   Compiled with
+//   -ffp-contract=off semantics via explicit __dmul_rn/__dadd_rn.
+__global__ __launch_bounds__(64) void gae_f64_kernel(const float* __restrict__ value, const double* __restrict__ reward,
+                                                     const uint8_t* __restrict__ done, double* __restrict__ adv,
+                                                     double* __restrict__ target, float* __restrict__ old_value,
+                                                     int n_traj, int T, double gamma, double lam) {
+  const int tr = blockIdx.x * 64 + threadIdx.x;
+  if (tr >= n_traj) return;
+  const float* v = value + (size_t)tr * (T + 1);
+  const double* r = reward + (size_t)tr * T;
+  const uint8_t* d = done + (size_t)tr * T;
+  double* ad = adv + (size_t)tr * T;
+  double* tg = target + (size_t)tr * T;
+  float* ov = old_value + (size_t)tr * T;
+  double carry = 0.0;
+  for (int j = T - 1; j >= 0; --j) {
+    const double disc = d[j] ? 0.0 : gamma;               // ~done * GAMMA (bool*float -> 0.0 or GAMMA)
+    const double vj = (double)v[j], vn = (double)v[j + 1];
+    const double delta = __dsub_rn(__dadd_rn(r[j], __dmul_rn(disc, vn)), vj);
+    double a = delta;
+    if (j < T - 1) a = __dadd_rn(delta, __dmul_rn(__dmul_rn(carry, disc), lam));
+    ad[j] = a;
+    tg[j] = __dadd_rn(a, vj);
+    ov[j] = v[j];
+    carry = a;
+  }
+}
+
+}  // namespace xt
+
+extern "C" {
+
+int xt_heads_fwd(const float* f_pi, const float* f_v, int32_t B, int32_t F, int32_t A, const float* wpi,
+                 const float* bpi, const float* wv, const float* bv, float* logits, float* value, void* stream) {
+  XT_REQUIRE(B > 0 && F > 0 && A > 0, "xt_heads_fwd: bad sizes");
+  hipLaunchKernelGGL(xt::heads_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, xt::as_stream(stream), f_pi, f_v, B, F, A,
+                     wpi, bpi, wv, bv, logits, value);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
+int xt_ppo_loss(const float* logits, const float* value, int32_t B, int32_t A, const int32_t* idx,
+                const int32_t* action, const float* old_logp, const double* adv, const float* old_v,
+                const double* target_v, float clip_ratio, float ent_coef, float vf_clip, float critic_coef,
+                float inv_b, float* dlogits, float* dvalue, float* loss_terms, void* stream) {
+  XT_REQUIRE(B > 0 && A > 0, "xt_ppo_loss: bad sizes");
+  hipLaunchKernelGGL(xt::ppo_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, xt::as_stream(stream), logits, value, B, A,
+                     idx, action, old_logp, adv, old_v, target_v, clip_ratio, ent_coef, vf_clip, critic_coef, inv_b,
+                     dlogits, dvalue, loss_terms);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
+int xt_ppo_loss_reduce(const float* loss_terms, int32_t B, float ent_coef, float critic_coef, float inv_b,
+                       float* out, float* acc, void* stream) {
+  hipLaunchKernelGGL(xt::ppo_loss_reduce_kernel, dim3(1), dim3(256), 0, xt::as_stream(stream), loss_terms, B, ent_coef,
+                     critic_coef, inv_b, out, acc);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
+int xt_impala_loss(const float* logits, const float* baseline, const float* bp_logits, const int32_t* action,
+                   const uint8_t* done, const float* reward, int32_t n_traj, int32_t T, int32_t A, float gamma,
+                   float* dlogits, float* dbaseline, float* out, float* acc, float* vs, float* pg_adv,
+                   void* stream) {
+  XT_REQUIRE(n_traj > 0 && T >= 2 && T <= 1024, "xt_impala_loss: need 2 <= T <= 1024 (got %d)", T);
+  XT_REQUIRE(n_traj <= 4096, "xt_impala_loss: n_traj too large");
+  // traj_loss scratch lives in out[4..4+n_traj)
+  float* traj_loss = out + 4;
+  hipStream_t st = xt::as_stream(stream);
+  if (T <= 64)
+    hipLaunchKernelGGL((xt::impala_loss_kernel<64>), dim3(n_traj), dim3(64), 0, st, logits, baseline, bp_logits, action,
+                       done, reward, T, A, gamma, dlogits, dbaseline, traj_loss, vs, pg_adv);
+  else if (T <= 128)
+    hipLaunchKernelGGL((xt::impala_loss_kernel<128>), dim3(n_traj), dim3(128), 0, st, logits, baseline, bp_logits, action,
+                       done, reward, T, A, gamma, dlogits, dbaseline, traj_loss, vs, pg_adv);
+  else if (T <= 256)
+    hipLaunchKernelGGL((xt::impala_loss_kernel<256>), dim3(n_traj), dim3(256), 0, st, logits, baseline, bp_logits, action,
+                       done, reward, T, A, gamma, dlogits, dbaseline, traj_loss, vs, pg_adv);
+  else
+    hipLaunchKernelGGL((xt::impala_loss_kernel<1024>), dim3(n_traj), dim3(1024), 0, st, logits, baseline, bp_logits,
+                       action, done, reward, T, A, gamma, dlogits, dbaseline, traj_loss, vs, pg_adv);
+  XT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(xt::impala_loss_reduce_kernel, dim3(1), dim3(64), 0, st, traj_loss, n_traj, out, acc);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
+int xt_heads_bwd(const float* f_pi, const float* f_v, int32_t B, int32_t F, int32_t A, const float* wpi,
+                 const float* wv, const float* dlogits, const float* dvalue, int32_t act_prev, float* dwpi,
+                 float* dbpi, float* dwv, float* dbv, float* df_pi, float* df_v, void* stream) {
+  XT_REQUIRE(B > 0 && F > 0 && A > 0, "xt_heads_bwd: bad sizes");
+  const int shared = (f_pi == f_v) ? 1 : 0;
+  XT_REQUIRE(!shared || df_pi == df_v, "xt_heads_bwd: shared trunk needs df_pi == df_v");
+  hipStream_t st = xt::as_stream(stream);
+  hipLaunchKernelGGL(xt::heads_dfeat_kernel, dim3((B * F + 255) / 256), dim3(256), 0, st, f_pi, f_v, B, F, A, wpi, wv,
+                     dlogits, dvalue, act_prev, shared, df_pi, df_v);
+  XT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(xt::heads_wgrad_kernel, dim3((F + 63) / 64), dim3(256), 0, st, f_pi, f_v, B, F, A, dlogits, dvalue,
+                     dwpi, dbpi, dwv, dbv);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
+int xt_gae_f64(const float* value, const double* reward, const uint8_t* done, double* adv, double* target_value,
+               float* old_value, int32_t n_traj, int32_t T, double gamma, double lam, void* stream) {
+  XT_REQUIRE(n_traj >= 0 && T >= 0, "xt_gae_f64: bad sizes");
+  if (n_traj == 0 || T == 0) return 0;
+  hipLaunchKernelGGL(xt::gae_f64_kernel, dim3((n_traj + 63) / 64), dim3(64), 0, xt::as_stream(stream), value, reward,
+                     done, adv, target_value, old_value, n_traj, T, gamma, lam);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,597 @@
+// Implicit-GEMM Conv2D/Dense forward, weight-gradient and input-gradient kernels for
+// gfx950 (MI355X, CDNA4), fp32 in / fp32 accumulate on the matrix cores
+// (v_mfma_f32_32x32x2_f32: exact f32, bitwise an fmaf chain, 157 TFLOP/s dense peak).
+//
+// All three kernels share one LDS tile core: As[kk][i] and Bs[kk][j] (kk = reduction
+// index, 32 per step), each wave owning 32x32 output tiles fed by ds_read_b32 that are
+// bank-conflict free (consecutive lanes -> consecutive i / j).  What differs is how the
+// operand tiles are gathered from HBM:
+//   fwd   : A = im2col(X)[m,k] (NHWC gather, uint8->f32 fused, minibatch row gather
+//           fused), B = W[k,n]                      -> Y[m,n] = act(. + bias)
+//   wgrad : A = im2col(X)^T[k,m], B = dY[m,n]       -> dW[k,n] (+ db), split over m
+//   dgrad : A = dY gathered per stride-parity class, B = W^T -> dX * act'(X)
+// Fetches are 16-byte (4-byte for uint8) vectors along the contiguous NHWC channel
+// axis; operands whose contiguous axis is the reduction axis are transposed on the way
+// into LDS (row stride == 1 mod 32 words, conflict-free ds_write_b32).
+//
+// Replaces the TensorFlow Conv2D/Dense forward+backward ops the reference runs inside
+// sess.run (xt/model/ppo/ppo.py:129, xt/model/impala/impala_cnn_opt.py:255).
+#include "xt_common.h"
+
+namespace xt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Geom {
+  int B, H, W, C, KH, KW, S, PT, PL, OH, OW, N, act;
+  int K, KWC, M, OHOW;
+  FastDiv d_ohow, d_ow, d_kwc, d_c, d_n;
+  float mean, std;
+};
+
+static int make_geom(const xt_conv_geom* g, const xt_input_xform* xf, int B, Geom* o) {
+  XT_REQUIRE(g && B > 0, "igemm: bad geometry/batch");
+  o->B = B; o->H = g->H; o->W = g->W; o->C = g->C; o->KH = g->KH; o->KW = g->KW; o->S = g->S;
+  o->PT = g->PT; o->PL = g->PL; o->OH = g->OH; o->OW = g->OW; o->N = g->N; o->act = g->act;
+  o->K = g->KH * g->KW * g->C; o->KWC = g->KW * g->C; o->OHOW = g->OH * g->OW;
+  XT_REQUIRE(g->C % 4 == 0, "igemm: input channels C=%d must be a multiple of 4", g->C);
+  XT_REQUIRE(g->N % 4 == 0, "igemm: output channels N=%d must be a multiple of 4", g->N);
+  XT_REQUIRE(g->S >= 1 && g->KH >= 1 && g->KW >= 1, "igemm: bad kernel/stride");
+  long long m = (long long)B * o->OHOW;
+  XT_REQUIRE(m * (long long)o->OHOW < (1ll << 32) && m < (1ll << 30), "igemm: M=%lld too large", m);
+  XT_REQUIRE((long long)B * g->H * g->W * g->C < (1ll << 31), "igemm: activation tensor too large");
+  o->M = (int)m;
+  o->d_ohow = make_fastdiv(o->OHOW); o->d_ow = make_fastdiv(o->OW);
+  o->d_kwc = make_fastdiv(o->KWC); o->d_c = make_fastdiv(o->C); o->d_n = make_fastdiv(o->N);
+  o->mean = xf ? xf->mean : 0.f; o->std = xf ? xf->std : 1.f;
+  return 0;
+}
+
+template <bool U8>
+__device__ __forceinline__ float4 load_in4(const void* in, size_t off, float mean, float stdv) {
+  if (U8) {
+    const uchar4 u = *reinterpret_cast<const uchar4*>(static_cast<const uint8_t*>(in) + off);
+    float4 f = make_float4((float)u.x, (float)u.y, (float)u.z, (float)u.w);
+    if (fabsf(mean) >= 1e-4f) { f.x -= mean; f.y -= mean; f.z -= mean; f.w -= mean; }
+    f.x /= stdv; f.y /= stdv; f.z /= stdv; f.w /= stdv;
+    return f;
+  } else {
+    return *reinterpret_cast<const float4*>(static_cast<const float*>(in) + off);
+  }
+}
+
+// im2col row m -> sample base offset (elements) and top-left input coordinate
+__device__ __forceinline__ void decode_row(const Geom& g, int m, const int32_t* __restrict__ idx,
+                                           size_t* rowoff, int* iy0, int* ix0) {
+  if (m >= g.M) { *rowoff = 0; *iy0 = -(1 << 28); *ix0 = 0; return; }
+  const uint32_t b = fdiv((uint32_t)m, g.d_ohow);
+  const uint32_t rem = (uint32_t)m - b * (uint32_t)g.OHOW;
+  const uint32_t oy = fdiv(rem, g.d_ow);
+  const uint32_t ox = rem - oy * (uint32_t)g.OW;
+  const size_t s = idx ? (size_t)idx[b] : (size_t)b;
+  *rowoff = s * (size_t)(g.H * g.W * g.C);
+  *iy0 = (int)oy * g.S - g.PT;
+  *ix0 = (int)ox * g.S - g.PL;
+}
+
+// 32 reduction steps of the tile product on the matrix cores
+template <int TI, int TJ, int SA, int SB>
+__device__ __forceinline__ void mma_tile(const float* As, const float* Bs, int a_off, int b_off,
+                                         f32x16 (&acc)[TI][TJ], int lane) {
+  const int kl = lane >> 5, il = lane & 31;
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    float a[TI], b[TJ];
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) a[ti] = As[(kk * 2 + kl) * SA + a_off + ti * 32 + il];
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) b[tj] = Bs[(kk * 2 + kl) * SB + b_off + tj * 32 + il];
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj)
+        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+  }
+}
+
+// ------------------------------------------------------------------ forward
+struct FwdArgs {
+  Geom g;
+  const void* in;
+  const int32_t* idx;
+  const float* w;
+  const float* bias;
+  float* y;        // ksplit==1: final output; else partial [ksplit][M][N]
+  int ksplit, kchunk;
+};
+
+template <int BI, int BJ, int WI, int WJ, bool U8>
+__global__ __launch_bounds__(256) void igemm_fwd_kernel(const FwdArgs p) {
+  constexpr int TI = BI / (32 * WI), TJ = BJ / (32 * WJ);
+  constexpr int SA = BI + 1, SB = BJ;
+  constexpr int NA = BI / 32;            // float4 fetches per thread for A
+  constexpr int CPRB = BJ / 4;           // float4 groups per B row
+  constexpr int RPB = 256 / CPRB;        // B rows per pass
+  constexpr int NB = 32 / RPB;
+  __shared__ __attribute__((aligned(16))) float smem[32 * SA + 32 * SB];
+  float* As = smem;
+  float* Bs = smem + 32 * SA;
+  const Geom& g = p.g;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int i0 = blockIdx.x * BI, j0 = blockIdx.y * BJ;
+  const int kbeg = blockIdx.z * p.kchunk;
+  const int kend = min(g.K, kbeg + p.kchunk);
+
+  const int c4 = t & 7, r0 = t >> 3;
+  size_t rowoff[NA];
+  int iy0[NA], ix0[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) decode_row(g, i0 + r0 + 32 * i, p.idx, &rowoff[i], &iy0[i], &ix0[i]);
+  const int cb = t % CPRB, rb = t / CPRB;
+
+  float4 ra[NA], rbv[NB];
+  auto fetch = [&](int k0) {
+    const int k = k0 + c4 * 4;
+    const uint32_t ky = fdiv((uint32_t)k, g.d_kwc);
+    const uint32_t r = (uint32_t)k - ky * (uint32_t)g.KWC;
+    const uint32_t kx = fdiv(r, g.d_c);
+    const uint32_t c = r - kx * (uint32_t)g.C;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int iy = iy0[i] + (int)ky, ix = ix0[i] + (int)kx;
+      const bool ok = (k < kend) && ((unsigned)iy < (unsigned)g.H) && ((unsigned)ix < (unsigned)g.W);
+      ra[i] = ok ? load_in4<U8>(p.in, rowoff[i] + (size_t)((iy * g.W + ix) * g.C + (int)c), g.mean, g.std)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int kk = k0 + rb + RPB * i, n = j0 + cb * 4;
+      rbv[i] = (kk < kend && n < g.N) ? *reinterpret_cast<const float4*>(p.w + (size_t)kk * g.N + n)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int r = r0 + 32 * i;
+      As[(c4 * 4 + 0) * SA + r] = ra[i].x;
+      As[(c4 * 4 + 1) * SA + r] = ra[i].y;
+      As[(c4 * 4 + 2) * SA + r] = ra[i].z;
+      As[(c4 * 4 + 3) * SA + r] = ra[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      *reinterpret_cast<float4*>(&Bs[(rb + RPB * i) * SB + cb * 4]) = rbv[i];
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+
+  const int wi = wave / WJ, wj = wave % WJ;
+  if (kbeg < kend) fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += 32) {
+    stash();
+    __syncthreads();
+    if (k0 + 32 < kend) fetch(k0 + 32);
+    mma_tile<TI, TJ, SA, SB>(As, Bs, wi * TI * 32, wj * TJ * 32, acc, lane);
+    __syncthreads();
+  }
+
+  const bool final_out = (p.ksplit == 1);
+  float* out = final_out ? p.y : p.y + (size_t)blockIdx.z * (size_t)g.M * g.N;
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      const int n = j0 + (wj * TJ + tj) * 32 + (lane & 31);
+      const float bv = (final_out && n < g.N) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = i0 + (wi * TI + ti) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < g.M && n < g.N) {
+          float v = acc[ti][tj][r];
+          if (final_out) v = act_apply(v + bv, g.act);
+          out[(size_t)m * g.N + n] = v;
+        }
+      }
+    }
+}
+
+// y = act(sum_z partial[z] + bias)
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
+                                                            float* __restrict__ y, int MN, int N, int ksplit, int act) {
+  const int e4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e4 >= MN) return;
+  float4 s = *reinterpret_cast<const float4*>(partial + e4);
+  for (int z = 1; z < ksplit; ++z) {
+    const float4 q = *reinterpret_cast<const float4*>(partial + (size_t)z * MN + e4);
+    s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+  }
+  const int n = e4 % N;
+  const float4 b = *reinterpret_cast<const float4*>(bias + n);
+  s.x = act_apply(s.x + b.x, act); s.y = act_apply(s.y + b.y, act);
+  s.z = act_apply(s.z + b.z, act); s.w = act_apply(s.w + b.w, act);
+  *reinterpret_cast<float4*>(y + e4) = s;
+}
+
+// ------------------------------------------------------------------ wgrad
+struct WgradArgs {
+  Geom g;
+  const void* in;
+  const int32_t* idx;
+  const float* dy;
+  float* out;      // [msplit][(K+1)*N]
+  int msplit, mchunk;
+};
+
+template <int BI, int BJ, int WI, int WJ, bool U8>
+__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs p) {
+  constexpr int TI = BI / (32 * WI), TJ = BJ / (32 * WJ);
+  constexpr int SA = BI, SB = BJ;
+  constexpr int CPRA = BI / 4, RPA = 256 / CPRA, NA = 32 / RPA;
+  constexpr int CPRB = BJ / 4, RPB = 256 / CPRB, NB = 32 / RPB;
+  constexpr int RG = 256 / BJ;           // row groups for the bias column sums
+  __shared__ __attribute__((aligned(16))) float smem[32 * SA + 32 * SB];
+  float* As = smem;
+  float* Bs = smem + 32 * SA;
+  const Geom& g = p.g;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int i0 = blockIdx.x * BI, j0 = blockIdx.y * BJ;     // i = k, j = n
+  const int mbeg = blockIdx.z * p.mchunk;
+  const int mend = min(g.M, mbeg + p.mchunk);
+
+  // this thread's fixed k group
+  const int ca = t % CPRA, rowa = t / CPRA;
+  const int k = i0 + ca * 4;
+  const bool kok = k < g.K;
+  const uint32_t ky = fdiv((uint32_t)k, g.d_kwc);
+  const uint32_t rr = (uint32_t)k - ky * (uint32_t)g.KWC;
+  const uint32_t kx = fdiv(rr, g.d_c);
+  const int kc = (int)(rr - kx * (uint32_t)g.C);
+  const int cb = t % CPRB, rowb = t / CPRB;
+
+  float4 ra[NA], rbv[NB];
+  auto fetch = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int m = m0 + rowa + RPA * i;
+      size_t rowoff; int iy, ix;
+      decode_row(g, m < mend ? m : g.M, p.idx, &rowoff, &iy, &ix);
+      iy += (int)ky; ix += (int)kx;
+      const bool ok = kok && ((unsigned)iy < (unsigned)g.H) && ((unsigned)ix < (unsigned)g.W);
+      ra[i] = ok ? load_in4<U8>(p.in, rowoff + (size_t)((iy * g.W + ix) * g.C + kc), g.mean, g.std)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int m = m0 + rowb + RPB * i, n = j0 + cb * 4;
+      rbv[i] = (m < mend && n < g.N) ? *reinterpret_cast<const float4*>(p.dy + (size_t)m * g.N + n)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      *reinterpret_cast<float4*>(&As[(rowa + RPA * i) * SA + ca * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      *reinterpret_cast<float4*>(&Bs[(rowb + RPB * i) * SB + cb * 4]) = rbv[i];
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+
+  const int wi = wave / WJ, wj = wave % WJ;
+  const bool do_bias = (blockIdx.x == 0);
+  const int bcol = t % BJ, brg = t / BJ;
+  float bsum = 0.f;
+
+  if (mbeg < mend) fetch(mbeg);
+  for (int m0 = mbeg; m0 < mend; m0 += 32) {
+    stash();
+    __syncthreads();
+    if (m0 + 32 < mend) fetch(m0 + 32);
+    if (do_bias) {
+#pragma unroll
+      for (int q = 0; q < 32 / RG; ++q) bsum += Bs[(brg + RG * q) * SB + bcol];
+    }
+    mma_tile<TI, TJ, SA, SB>(As, Bs, wi * TI * 32, wj * TJ * 32, acc, lane);
+    __syncthreads();
+  }
+
+  float* out = p.out + (size_t)blockIdx.z * ((size_t)(g.K + 1) * g.N);
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      const int n = j0 + (wj * TJ + tj) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kr = i0 + (wi * TI + ti) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (kr < g.K && n < g.N) out[(size_t)kr * g.N + n] = acc[ti][tj][r];
+      }
+    }
+  if (do_bias) {
+    smem[brg * BJ + bcol] = bsum;      // safe: last loop iteration ended with a barrier
+    __syncthreads();
+    if (t < BJ) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < RG; ++q) s += smem[q * BJ + t];
+      const int n = j0 + t;
+      if (n < g.N) out[(size_t)g.K * g.N + n] = s;
+    }
+  }
+}
+
+// dst[e] = sum_z src[z][e]
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           int count, int nslab) {
+  const int e4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e4 >= count) return;
+  float4 s = *reinterpret_cast<const float4*>(src + e4);
+  for (int z = 1; z < nslab; ++z) {
+    const float4 q = *reinterpret_cast<const float4*>(src + (size_t)z * count + e4);
+    s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+  }
+  *reinterpret_cast<float4*>(dst + e4) = s;
+}
+
+// ------------------------------------------------------------------ dgrad
+struct DgradArgs {
+  Geom g;
+  const float* dy;
+  const float* w;
+  const float* x;     // producer's post-activation output [B,H,W,C]
+  float* dx;
+  int act_prev;
+};
+
+template <int BI, int BJ, int WI, int WJ>
+__global__ __launch_bounds__(256) void igemm_dgrad_kernel(const DgradArgs p) {
+  constexpr int TI = BI / (32 * WI), TJ = BJ / (32 * WJ);
+  constexpr int SA = BI + 1, SB = BJ + 1;
+  constexpr int NA = BI / 32, NB = BJ / 32;
+  __shared__ __attribute__((aligned(16))) float smem[32 * SA + 32 * SB + BI];
+  float* As = smem;
+  float* Bs = smem + 32 * SA;
+  int* rowOut = reinterpret_cast<int*>(smem + 32 * SA + 32 * SB);
+  const Geom& g = p.g;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+  // stride-parity class of this block
+  const int ry = blockIdx.z / g.S, rx = blockIdx.z % g.S;
+  const int cy0 = ((ry - g.PT) % g.S + g.S) % g.S, cx0 = ((rx - g.PL) % g.S + g.S) % g.S;
+  const int HC = cy0 < g.H ? (g.H - cy0 + g.S - 1) / g.S : 0;
+  const int WC = cx0 < g.W ? (g.W - cx0 + g.S - 1) / g.S : 0;
+  const int Mc = g.B * HC * WC;
+  const int i0 = blockIdx.x * BI, j0 = blockIdx.y * BJ;      // i = class pixel, j = input channel
+  if (i0 >= Mc) return;
+  const int JY = ry < g.KH ? (g.KH - ry + g.S - 1) / g.S : 0;
+  const int JX = rx < g.KW ? (g.KW - rx + g.S - 1) / g.S : 0;
+  const int Kc = JY * JX * g.N;
+  const int qy0 = (cy0 + g.PT) / g.S, qx0 = (cx0 + g.PL) / g.S;
+
+  if (t < BI) {
+    const int mc = i0 + t;
+    int off = -1;
+    if (mc < Mc) {
+      const int b = mc / (HC * WC), rem = mc - b * (HC * WC);
+      const int ty = rem / WC, tx = rem - ty * WC;
+      off = ((b * g.H + cy0 + g.S * ty) * g.W + cx0 + g.S * tx) * g.C;
+    }
+    rowOut[t] = off;
+  }
+
+  const int c4 = t & 7, r0 = t >> 3;
+  int dybase[NA], qy[NA], qx[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int mc = i0 + r0 + 32 * i;
+    if (mc < Mc) {
+      const int b = mc / (HC * WC), rem = mc - b * (HC * WC);
+      const int ty = rem / WC, tx = rem - ty * WC;
+      dybase[i] = b * g.OHOW * g.N; qy[i] = qy0 + ty; qx[i] = qx0 + tx;
+    } else {
+      dybase[i] = 0; qy[i] = -(1 << 28); qx[i] = 0;
+    }
+  }
+
+  float4 ra[NA], rbv[NB];
+  auto fetch = [&](int k0) {
+    const int kk = k0 + c4 * 4;
+    const bool kok = kk < Kc;
+    const uint32_t tap = fdiv((uint32_t)kk, g.d_n);
+    const int n = kk - (int)tap * g.N;
+    const int jy = JX > 0 ? (int)tap / JX : 0, jx = (int)tap - jy * JX;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int oy = qy[i] - jy, ox = qx[i] - jx;
+      const bool ok = kok && ((unsigned)oy < (unsigned)g.OH) && ((unsigned)ox < (unsigned)g.OW);
+      ra[i] = ok ? *reinterpret_cast<const float4*>(p.dy + (size_t)(dybase[i] + (oy * g.OW + ox) * g.N + n))
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int ky = ry + g.S * jy, kx = rx + g.S * jx;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int c = j0 + r0 + 32 * i;
+      rbv[i] = (kok && c < g.C)
+                   ? *reinterpret_cast<const float4*>(p.w + (size_t)(((ky * g.KW + kx) * g.C + c)) * g.N + n)
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int r = r0 + 32 * i;
+      As[(c4 * 4 + 0) * SA + r] = ra[i].x;
+      As[(c4 * 4 + 1) * SA + r] = ra[i].y;
+      As[(c4 * 4 + 2) * SA + r] = ra[i].z;
+      As[(c4 * 4 + 3) * SA + r] = ra[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int r = r0 + 32 * i;
+      Bs[(c4 * 4 + 0) * SB + r] = rbv[i].x;
+      Bs[(c4 * 4 + 1) * SB + r] = rbv[i].y;
+      Bs[(c4 * 4 + 2) * SB + r] = rbv[i].z;
+      Bs[(c4 * 4 + 3) * SB + r] = rbv[i].w;
+    }
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+
+  const int wi = wave / WJ, wj = wave % WJ;
+  if (Kc > 0) fetch(0);
+  for (int k0 = 0; k0 < Kc; k0 += 32) {
+    stash();
+    __syncthreads();
+    if (k0 + 32 < Kc) fetch(k0 + 32);
+    mma_tile<TI, TJ, SA, SB>(As, Bs, wi * TI * 32, wj * TJ * 32, acc, lane);
+    __syncthreads();
+  }
+  if (Kc == 0) __syncthreads();   // rowOut visibility
+
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      const int c = j0 + (wj * TJ + tj) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int il = (wi * TI + ti) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int off = rowOut[il];
+        if (off >= 0 && c < g.C) {
+          const float xv = p.x[(size_t)off + c];
+          p.dx[(size_t)off + c] = acc[ti][tj][r] * act_grad(xv, p.act_prev);
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------ host launchers
+static inline int pick_ksplit_chunk(int K, int split, int* chunk) {
+  int steps = (K + 31) / 32;
+  int per = (steps + split - 1) / split;
+  *chunk = per * 32;
+  return (steps + per - 1) / per;   // effective split count
+}
+
+int launch_fwd(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const void* in, const int32_t* idx,
+               const float* w, const float* bias, float* y, float* partial, int ksplit, hipStream_t st) {
+  FwdArgs a;
+  if (int rc = make_geom(cg, xf, B, &a.g)) return rc;
+  const bool u8 = xf && xf->is_u8;
+  a.in = in; a.idx = idx; a.w = w; a.bias = bias;
+  if (ksplit < 1) ksplit = 1;
+  int chunk;
+  ksplit = pick_ksplit_chunk(a.g.K, ksplit, &chunk);
+  XT_REQUIRE(ksplit == 1 || partial != nullptr, "xt_layer_fwd: ksplit>1 needs a partial buffer");
+  a.ksplit = ksplit; a.kchunk = chunk;
+  a.y = ksplit == 1 ? y : partial;
+  const int M = a.g.M, N = a.g.N;
+  if (N <= 32) {
+    dim3 grid((M + 127) / 128, (N + 31) / 32, ksplit);
+    if (u8) hipLaunchKernelGGL((igemm_fwd_kernel<128, 32, 4, 1, true>), grid, dim3(256), 0, st, a);
+    else    hipLaunchKernelGGL((igemm_fwd_kernel<128, 32, 4, 1, false>), grid, dim3(256), 0, st, a);
+  } else {
+    dim3 grid((M + 63) / 64, (N + 63) / 64, ksplit);
+    if (u8) hipLaunchKernelGGL((igemm_fwd_kernel<64, 64, 2, 2, true>), grid, dim3(256), 0, st, a);
+    else    hipLaunchKernelGGL((igemm_fwd_kernel<64, 64, 2, 2, false>), grid, dim3(256), 0, st, a);
+  }
+  XT_LAUNCH_CHECK();
+  if (ksplit > 1) {
+    const int MN = M * N;
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((MN / 4 + 255) / 256), dim3(256), 0, st,
+                       partial, bias, y, MN, N, ksplit, a.g.act);
+    XT_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int launch_wgrad(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const void* in, const int32_t* idx,
+                 const float* dy, float* dwb, float* slabs, int msplit, hipStream_t st) {
+  WgradArgs a;
+  if (int rc = make_geom(cg, xf, B, &a.g)) return rc;
+  const bool u8 = xf && xf->is_u8;
+  a.in = in; a.idx = idx; a.dy = dy;
+  if (msplit < 1) msplit = 1;
+  int chunk;
+  msplit = pick_ksplit_chunk(a.g.M, msplit, &chunk);
+  XT_REQUIRE(msplit == 1 || slabs != nullptr, "xt_layer_wgrad: msplit>1 needs a slab buffer");
+  a.msplit = msplit; a.mchunk = chunk;
+  a.out = msplit == 1 ? dwb : slabs;
+  const int K = a.g.K, N = a.g.N;
+  if (N <= 32) {
+    dim3 grid((K + 127) / 128, (N + 31) / 32, msplit);
+    if (u8) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 32, 4, 1, true>), grid, dim3(256), 0, st, a);
+    else    hipLaunchKernelGGL((igemm_wgrad_kernel<128, 32, 4, 1, false>), grid, dim3(256), 0, st, a);
+  } else {
+    dim3 grid((K + 63) / 64, (N + 63) / 64, msplit);
+    if (u8) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 2, 2, true>), grid, dim3(256), 0, st, a);
+    else    hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 2, 2, false>), grid, dim3(256), 0, st, a);
+  }
+  XT_LAUNCH_CHECK();
+  if (msplit > 1) {
+    const int count = (K + 1) * N;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((count / 4 + 255) / 256), dim3(256), 0, st, slabs, dwb, count, msplit);
+    XT_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int launch_dgrad(const xt_conv_geom* cg, int B, const float* dy, const float* w, const float* x, int act_prev,
+                 float* dx, hipStream_t st) {
+  DgradArgs a;
+  if (int rc = make_geom(cg, nullptr, B, &a.g)) return rc;
+  a.dy = dy; a.w = w; a.x = x; a.dx = dx; a.act_prev = act_prev;
+  const Geom& g = a.g;
+  const int hc = (g.H + g.S - 1) / g.S, wc = (g.W + g.S - 1) / g.S;   // upper bound on class extent
+  const int mc = B * hc * wc;
+  if (g.C <= 32) {
+    dim3 grid((mc + 127) / 128, (g.C + 31) / 32, g.S * g.S);
+    hipLaunchKernelGGL((igemm_dgrad_kernel<128, 32, 4, 1>), grid, dim3(256), 0, st, a);
+  } else {
+    dim3 grid((mc + 63) / 64, (g.C + 63) / 64, g.S * g.S);
+    hipLaunchKernelGGL((igemm_dgrad_kernel<64, 64, 2, 2>), grid, dim3(256), 0, st, a);
+  }
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace xt
+
+extern "C" {
+
+int xt_layer_fwd(const xt_conv_geom* g, const xt_input_xform* xf, int32_t B, const void* in, const int32_t* idx,
+                 const float* w, const float* bias, float* y, float* partial, int32_t ksplit, void* stream) {
+  return xt::launch_fwd(g, xf, B, in, idx, w, bias, y, partial, ksplit, xt::as_stream(stream));
+}
+
+int xt_layer_wgrad(const xt_conv_geom* g, const xt_input_xform* xf, int32_t B, const void* in, const int32_t* idx,
+                   const float* dy, float* dwb, float* slabs, int32_t msplit, void* stream) {
+  return xt::launch_wgrad(g, xf, B, in, idx, dy, dwb, slabs, msplit, xt::as_stream(stream));
+}
+
+int xt_layer_dgrad(const xt_conv_geom* g, int32_t B, const float* dy, const float* w, const float* x,
+                   int32_t act_prev, float* dx, void* stream) {
+  return xt::launch_dgrad(g, B, dy, w, x, act_prev, dx, xt::as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,153 @@
+// tf.clip_by_global_norm + TF1 AdamOptimizer over one flat fp32 buffer (HBM-bound).
+// Replaces build_train_op, xt/model/ppo/ppo.py:97-102 and impala_cnn_opt.py:204-217.
+// Three launches: per-block sum of squares (fixed order), single-block finalize
+// (norm, clip scale, bias-corrected step size, beta powers), vectorised Adam update.
+#include "xt_common.h"
+
+namespace xt {
+
+constexpr int kNormBlocks = 512;   // partial sums; scratch must hold >= kNormBlocks floats
+
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, long long count,
+                                                             float* __restrict__ partial) {
+  __shared__ float sh[256];
+  const long long n4 = count >> 2;
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (count & 3)) {
+    const float v = g[(n4 << 2) + threadIdx.x];
+    s += v * v;
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+// state: [0]=b1^t [1]=b2^t [2]=scale [3]=alpha [4]=gnorm [5]=step
+__global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restrict__ partial, int nblocks, float clip_norm,
+                                                            float grad_scale, float lr, float beta1, float beta2,
+                                                            int advance, float* __restrict__ state) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) s += (double)partial[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    // norm of (grad*grad_scale)
+    const float gnorm = sqrtf((float)sh[0]) * grad_scale;
+    // tf.clip_by_global_norm: t * clip_norm * min(1/norm, 1/clip_norm)
+    const float sc = clip_norm * fminf(1.f / gnorm, 1.f / clip_norm);
+    state[2] = sc * grad_scale;
+    state[4] = gnorm;
+    if (advance) {
+      const float b1p = state[0] * beta1, b2p = state[1] * beta2;
+      state[0] = b1p; state[1] = b2p;
+      state[3] = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+      state[5] += 1.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                      float* __restrict__ m, float* __restrict__ v, long long count,
+                                                      float beta1, float beta2, float eps, const float* __restrict__ state) {
+  const float scale = state[2], alpha = state[3];
+  const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+  const long long n4 = count >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 mv = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+#define XT_ADAM1(c)                                   \
+    {                                                 \
+      const float gg = gv.c * scale;                  \
+      mv.c += (gg - mv.c) * omb1;                     \
+      vv.c += (gg * gg - vv.c) * omb2;                \
+      pv.c -= (mv.c * alpha) / (sqrtf(vv.c) + eps);   \
+    }
+    XT_ADAM1(x) XT_ADAM1(y) XT_ADAM1(z) XT_ADAM1(w)
+#undef XT_ADAM1
+    reinterpret_cast<float4*>(m)[i] = mv;
+    reinterpret_cast<float4*>(v)[i] = vv;
+    reinterpret_cast<float4*>(p)[i] = pv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (count & 3)) {
+    const long long i = (n4 << 2) + threadIdx.x;
+    const float gg = g[i] * scale;
+    float mm = m[i], vv = v[i];
+    mm += (gg - mm) * omb1;
+    vv += (gg * gg - vv) * omb2;
+    m[i] = mm; v[i] = vv;
+    p[i] -= (mm * alpha) / (sqrtf(vv) + eps);
+  }
+}
+
+__global__ void adam_state_init_kernel(float* state) {
+  if (threadIdx.x < 8) state[threadIdx.x] = (threadIdx.x < 2) ? 1.f : 0.f;
+}
+
+int launch_global_norm(const float* grad, long long count, float clip_norm, float grad_scale, float lr, float beta1,
+                       float beta2, int advance, float* state, float* scratch, hipStream_t st) {
+  XT_REQUIRE(count > 0 && grad && state && scratch, "global_norm: bad arguments");
+  XT_REQUIRE(((uintptr_t)grad & 15) == 0, "global_norm: grad must be 16-byte aligned");
+  int nb = (int)((count / 4 + 255) / 256);
+  if (nb > kNormBlocks) nb = kNormBlocks;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nb), dim3(256), 0, st, grad, count, scratch);
+  XT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, nb, clip_norm, grad_scale, lr, beta1,
+                     beta2, advance, state);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_adam(float* param, const float* grad, float* m, float* v, long long count, float beta1, float beta2,
+                float eps, const float* state, hipStream_t st) {
+  XT_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+             "adam: buffers must be 16-byte aligned");
+  int nb = (int)((count / 4 + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(adam_tf_kernel, dim3(nb), dim3(256), 0, st, param, grad, m, v, count, beta1, beta2, eps, state);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace xt
+
+extern "C" {
+
+int xt_adam_state_init(float* state, void* stream) {
+  hipLaunchKernelGGL(xt::adam_state_init_kernel, dim3(1), dim3(64), 0, xt::as_stream(stream), state);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
+int xt_grad_global_norm(const float* grad, int64_t count, float clip_norm, float grad_scale, float* state,
+                        float* scratch, void* stream) {
+  return xt::launch_global_norm(grad, count, clip_norm, grad_scale, 0.f, 0.f, 0.f, 0, state, scratch,
+                                xt::as_stream(stream));
+}
+
+int xt_adam_tf_clip(float* param, const float* grad, float* m, float* v, int64_t count, float lr, float beta1,
+                    float beta2, float eps, float clip_norm, float grad_scale, float* state, float* scratch,
+                    void* stream) {
+  if (int rc = xt::launch_global_norm(grad, count, clip_norm, grad_scale, lr, beta1, beta2, 1, state, scratch,
+                                      xt::as_stream(stream)))
+    return rc;
+  return xt::launch_adam(param, grad, m, v, count, beta1, beta2, eps, state, xt::as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,127 @@
+"""ctypes binding of ``libxt_mi355x.so`` (the C ABI declared in ``include/xt_mi355x.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C xingtian_amd/csrc``.
+There is NO CPU fallback: if the shared object is missing or a call fails, a
+``RuntimeError`` is raised.  ``import torch`` happens first so that the HIP runtime the
+kernels bind to is the one PyTorch-ROCm already loaded (same streams / context).
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_void_p
+
+import torch  # noqa: F401  (must precede loading the HIP library, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxt_mi355x.so")
+
+ACT = {"none": 0, None: 0, "relu": 1, "tanh": 2}
+
+
+class ConvGeom(Structure):
+    _fields_ = [(n, c_int32) for n in ("H", "W", "C", "KH", "KW", "S", "PT", "PL", "OH", "OW", "N", "act")]
+
+
+class InputXform(Structure):
+    _fields_ = [("is_u8", c_int32), ("mean", c_float), ("std", c_float)]
+
+
+class LayerDesc(Structure):
+    _fields_ = [("g", ConvGeom), ("param_off", c_int64), ("trunk", c_int32)]
+
+
+class NetDesc(Structure):
+    _fields_ = [("n_layers", c_int32), ("layers", POINTER(LayerDesc)), ("n_trunks", c_int32),
+                ("feat", c_int32), ("action_dim", c_int32), ("pi_off", c_int64), ("v_off", c_int64),
+                ("n_params", c_int64), ("xf", InputXform), ("in_h", c_int32), ("in_w", c_int32),
+                ("in_c", c_int32)]
+
+
+class PpoCfg(Structure):
+    _fields_ = [("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
+                ("clip_ratio", c_float), ("ent_coef", c_float), ("vf_clip", c_float),
+                ("critic_coef", c_float), ("max_grad_norm", c_float), ("batch_size", c_int32),
+                ("num_sgd_iter", c_int32), ("grad_scale", c_float), ("global_batch", c_int32)]
+
+
+class ImpalaCfg(Structure):
+    _fields_ = [("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
+                ("grad_norm_clip", c_float), ("gamma", c_float), ("sample_batch_step", c_int32),
+                ("grad_scale", c_float)]
+
+
+_P = c_void_p
+# name -> (restype, argtypes); every symbol include/xt_mi355x.h declares
+SIGNATURES = {
+    "xt_abi_version": (c_int32, []),
+    "xt_last_error": (c_char_p, []),
+    "xt_build_arch": (c_char_p, []),
+    "xt_gae_f64": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_double, c_double, _P]),
+    "xt_layer_fwd": (c_int32, [POINTER(ConvGeom), POINTER(InputXform), c_int32, _P, _P, _P, _P, _P, _P, c_int32, _P]),
+    "xt_layer_wgrad": (c_int32, [POINTER(ConvGeom), POINTER(InputXform), c_int32, _P, _P, _P, _P, _P, c_int32, _P]),
+    "xt_layer_dgrad": (c_int32, [POINTER(ConvGeom), c_int32, _P, _P, _P, c_int32, _P, _P]),
+    "xt_heads_fwd": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "xt_ppo_loss": (c_int32, [_P, _P, c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float,
+                              c_float, _P, _P, _P, _P]),
+    "xt_ppo_loss_reduce": (c_int32, [_P, c_int32, c_float, c_float, c_float, _P, _P, _P]),
+    "xt_impala_loss": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "xt_heads_bwd": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "xt_adam_state_init": (c_int32, [_P, _P]),
+    "xt_adam_tf_clip": (c_int32, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, _P, _P, _P]),
+    "xt_grad_global_norm": (c_int32, [_P, c_int64, c_float, c_float, _P, _P, _P]),
+    "xt_net_create": (c_int32, [POINTER(NetDesc), c_int32, POINTER(c_void_p)]),
+    "xt_net_destroy": (None, [_P]),
+    "xt_net_workspace_bytes": (c_int64, [_P]),
+    "xt_net_bind": (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_int64]),
+    "xt_net_forward": (c_int32, [_P, _P, _P, c_int32, _P, _P, _P]),
+    "xt_net_ppo_step": (c_int32, [_P, POINTER(PpoCfg), _P, _P, c_int32, _P, _P, _P, _P, _P, c_int32, _P, _P, _P]),
+    "xt_net_ppo_train": (c_int32, [_P, POINTER(PpoCfg), _P, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, _P]),
+    "xt_net_impala_step": (c_int32, [_P, POINTER(ImpalaCfg), _P, c_int32, _P, _P, _P, _P, c_int32, _P, _P, _P]),
+    "xt_net_apply": (c_int32, [_P, c_float, c_float, c_float, c_float, c_float, c_float, _P]),
+    "xt_net_time_layer": (c_int32, [_P, c_int32, c_int32, _P, _P, c_int32, c_int32, POINTER(c_float), _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared object (once) and attach prototypes.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "xingtian_amd: HIP library {} is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C xingtian_amd/csrc`). There is no CPU fallback.".format(LIB_PATH))
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the ABI symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.xt_abi_version() != 1:
+        raise RuntimeError("xingtian_amd: ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().xt_last_error()
+        raise RuntimeError("xingtian_amd: {} failed (rc={}): {}".format(what, rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    """The current PyTorch HIP stream as a void* (kernels are enqueued on it)."""
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("xingtian_amd: no HIP device visible -- the learner update path runs only on the GPU "
+                           "(no CPU fallback by design)")

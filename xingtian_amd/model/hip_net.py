@@ -1,0 +1,198 @@
+"""Device-resident actor-critic network driven through the C ABI.
+
+PyTorch-ROCm tensors are storage only (flat parameter / gradient / Adam buffers, the
+activation workspace, the resident rollout); every arithmetic op is a HIP kernel in
+``libxt_mi355x.so``.  Used by the ``PPO`` / ``ImpalaCnnOpt`` model classes.
+"""
+import ctypes
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from xingtian_amd import lib as L
+
+
+def glorot_uniform(rng, shape):
+    """Keras default kernel initialiser (Conv2D/Dense in xt/model/model_utils.py:86-96)."""
+    if len(shape) == 4:
+        rf = shape[0] * shape[1]
+        fan_in, fan_out = rf * shape[2], rf * shape[3]
+    else:
+        fan_in, fan_out = shape
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+class HipActorCritic(object):
+    def __init__(self, spec, max_batch, device="cuda:0", seed=None, init="glorot"):
+        L.require_gpu()
+        self.lib = L.load()
+        self.spec, self.max_batch = spec, int(max_batch)
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        n = spec.n_flat
+        self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.adam_m = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.adam_v = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.adam_state = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self.loss_acc = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self.loss_out = torch.zeros(8, dtype=torch.float32, device=self.device)
+
+        lay_arr = (L.LayerDesc * len(spec.layers))()
+        for i, lay in enumerate(spec.layers):
+            g = lay_arr[i].g
+            g.H, g.W, g.C, g.KH, g.KW, g.S = lay.H, lay.W, lay.C, lay.KH, lay.KW, lay.S
+            g.PT, g.PL, g.OH, g.OW, g.N, g.act = lay.PT, lay.PL, lay.OH, lay.OW, lay.N, L.ACT[lay.act]
+            lay_arr[i].param_off = lay.param_off
+            lay_arr[i].trunk = lay.trunk
+        self._lay_arr = lay_arr
+        d = L.NetDesc()
+        d.n_layers, d.layers, d.n_trunks = len(spec.layers), lay_arr, spec.n_trunks
+        d.feat, d.action_dim, d.pi_off, d.v_off, d.n_params = spec.feat, spec.action_dim, spec.pi_off, spec.v_off, n
+        d.xf = L.InputXform(*spec.input_xform)
+        d.in_h, d.in_w, d.in_c = spec.layers[0].H, spec.layers[0].W, spec.layers[0].C
+        self._desc = d
+        h = ctypes.c_void_p()
+        L.check(self.lib.xt_net_create(ctypes.byref(d), self.max_batch, ctypes.byref(h)), "xt_net_create")
+        self.handle = h
+        ws_bytes = self.lib.xt_net_workspace_bytes(h)
+        self.workspace = torch.empty(ws_bytes // 4, dtype=torch.float32, device=self.device)
+        L.check(self.lib.xt_net_bind(h, L.ptr(self.params), L.ptr(self.grads), L.ptr(self.adam_m), L.ptr(self.adam_v),
+                                     L.ptr(self.adam_state), L.ptr(self.workspace), ws_bytes), "xt_net_bind")
+        L.check(self.lib.xt_adam_state_init(L.ptr(self.adam_state), L.stream_ptr()), "xt_adam_state_init")
+        if init == "glorot":
+            self.init_weights(seed)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.xt_net_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def init_weights(self, seed=None, baseline_norm_std=None):
+        rng = np.random.default_rng(seed)
+        w = OrderedDict()
+        for name, (_, shape) in self.spec.names.items():
+            if name.endswith("/bias"):
+                w[name] = np.zeros(shape, np.float32)
+            else:
+                w[name] = glorot_uniform(rng, shape)
+        if baseline_norm_std is not None:
+            # custom_norm_initializer(std), xt/model/model_utils.py:204-211
+            shape = self.spec.names[self.spec.v_name + "/kernel"][1]
+            out = rng.standard_normal(shape).astype(np.float32)
+            out *= baseline_norm_std / np.sqrt(np.square(out).sum(axis=0, keepdims=True))
+            w[self.spec.v_name + "/kernel"] = out
+        self.set_weights(w)
+
+    def get_weights(self):
+        """dict TF-variable-name -> ndarray (TFVariables.get_weights, xt/model/tf_utils.py:99-102)."""
+        flat = self.params.detach().cpu().numpy()
+        out = OrderedDict()
+        for name, (off, shape) in self.spec.names.items():
+            size = int(np.prod(shape))
+            out[name] = flat[off:off + size].reshape(shape).copy()
+        return out
+
+    def set_weights(self, weights):
+        """Assign by name; unknown names are ignored, KeyError if nothing matches
+        (TFVariables.set_weights, xt/model/tf_utils.py:104-128)."""
+        hit = [k for k in weights.keys() if k in self.spec.names]
+        if not hit:
+            raise KeyError("NO node's weights could assign in self.graph {} vs {}".format(
+                list(self.spec.names.keys()), list(weights.keys())))
+        flat = self.params.detach().cpu().numpy().copy()
+        for name in hit:
+            off, shape = self.spec.names[name]
+            val = np.asarray(weights[name], np.float32)
+            if tuple(val.shape) != tuple(shape):
+                raise KeyError("update {} encounter error: shape {} vs {}".format(name, val.shape, shape))
+            flat[off:off + val.size] = val.reshape(-1)
+        self.params.copy_(torch.from_numpy(flat))
+
+    def reset_optimizer(self):
+        self.adam_m.zero_()
+        self.adam_v.zero_()
+        L.check(self.lib.xt_adam_state_init(L.ptr(self.adam_state), L.stream_ptr()), "xt_adam_state_init")
+
+    # ------------------------------------------------------------------ compute
+    def to_device_obs(self, obs):
+        t = torch.as_tensor(np.ascontiguousarray(obs)) if not torch.is_tensor(obs) else obs
+        want = torch.uint8 if self.spec.input_xform[0] else torch.float32
+        return t.to(device=self.device, dtype=want).contiguous()
+
+    def forward(self, obs):
+        """obs [B, ...] (host or device) -> (logits [B,A], value [B]) device tensors."""
+        x = self.to_device_obs(obs)
+        b = x.shape[0]
+        a = self.spec.action_dim
+        logits = torch.empty((b, a), dtype=torch.float32, device=self.device)
+        value = torch.empty((b,), dtype=torch.float32, device=self.device)
+        for s in range(0, b, self.max_batch):
+            e = min(b, s + self.max_batch)
+            L.check(self.lib.xt_net_forward(self.handle, L.ptr(x[s:e]), None, e - s, L.ptr(logits[s:e]),
+                                            L.ptr(value[s:e]), L.stream_ptr()), "xt_net_forward")
+        return logits, value
+
+    def make_ppo_cfg(self, cfg, grad_scale=1.0, global_batch=0):
+        c = L.PpoCfg()
+        c.lr, c.beta1, c.beta2, c.eps = cfg["LR"], 0.9, 0.999, 1e-8
+        c.clip_ratio, c.ent_coef, c.vf_clip = cfg["LOSS_CLIPPING"], cfg["ENTROPY_LOSS"], cfg["VF_CLIP"]
+        c.critic_coef, c.max_grad_norm = cfg["CRITIC_LOSS_COEF"], cfg["MAX_GRAD_NORM"]
+        c.batch_size, c.num_sgd_iter = int(cfg["BATCH_SIZE"]), int(cfg["NUM_SGD_ITER"])
+        c.grad_scale, c.global_batch = grad_scale, int(global_batch)
+        return c
+
+    def ppo_step(self, c, obs, idx, action, old_logp, adv, old_v, target_v, apply=True):
+        """One SGD step on rows idx (int32 device tensor or None) of device-resident data."""
+        b = int(idx.numel()) if idx is not None else int(obs.shape[0])
+        L.check(self.lib.xt_net_ppo_step(self.handle, ctypes.byref(c), L.ptr(obs), L.ptr(idx), b, L.ptr(action),
+                                         L.ptr(old_logp), L.ptr(adv), L.ptr(old_v), L.ptr(target_v),
+                                         1 if apply else 0, L.ptr(self.loss_out), None, L.stream_ptr()),
+                "xt_net_ppo_step")
+        return self.loss_out
+
+    def ppo_train(self, c, obs, perm, action, old_logp, adv, old_v, target_v, use_graph=False):
+        n = int(obs.shape[0])
+        L.check(self.lib.xt_net_ppo_train(self.handle, ctypes.byref(c), L.ptr(obs), n, L.ptr(perm), L.ptr(action),
+                                          L.ptr(old_logp), L.ptr(adv), L.ptr(old_v), L.ptr(target_v),
+                                          L.ptr(self.loss_acc), 1 if use_graph else 0, L.stream_ptr()),
+                "xt_net_ppo_train")
+        return self.loss_acc
+
+    def make_impala_cfg(self, lr, grad_norm_clip, sample_batch_step, gamma=0.99, grad_scale=1.0):
+        c = L.ImpalaCfg()
+        c.lr, c.beta1, c.beta2, c.eps = lr, 0.9, 0.999, 1e-8
+        c.grad_norm_clip, c.gamma, c.sample_batch_step, c.grad_scale = grad_norm_clip, gamma, int(sample_batch_step), grad_scale
+        return c
+
+    def impala_step(self, c, obs, bp_logits, action, done, reward, apply=True, loss_acc=None):
+        n = int(obs.shape[0])
+        L.check(self.lib.xt_net_impala_step(self.handle, ctypes.byref(c), L.ptr(obs), n, L.ptr(bp_logits),
+                                            L.ptr(action), L.ptr(done), L.ptr(reward), 1 if apply else 0,
+                                            L.ptr(self.loss_out), L.ptr(loss_acc), L.stream_ptr()),
+                "xt_net_impala_step")
+        return self.loss_out
+
+    def apply(self, lr, clip_norm, grad_scale=1.0):
+        L.check(self.lib.xt_net_apply(self.handle, lr, 0.9, 0.999, 1e-8, clip_norm, grad_scale, L.stream_ptr()),
+                "xt_net_apply")
+
+    def time_layer(self, layer, which, obs, idx, b, reps=20):
+        ms = ctypes.c_float()
+        L.check(self.lib.xt_net_time_layer(self.handle, layer, which, L.ptr(obs), L.ptr(idx), b, reps,
+                                           ctypes.byref(ms), L.stream_ptr()), "xt_net_time_layer")
+        return ms.value
+
+    def grads_dict(self):
+        flat = self.grads.detach().cpu().numpy()
+        out = OrderedDict()
+        for name, (off, shape) in self.spec.names.items():
+            size = int(np.prod(shape))
+            out[name] = flat[off:off + size].reshape(shape).copy()
+        return out

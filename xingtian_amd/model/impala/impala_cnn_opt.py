@@ -1,0 +1,73 @@
+"""``ImpalaCnnOpt`` (xt/model/impala/impala_cnn_opt.py:64-296) on HIP kernels.
+
+conv(SAME) -> conv(SAME) -> 11x11 conv (a dense 3872->256) -> 1x1-conv policy + dense
+baseline, v-trace targets (xt/model/impala/vtrace.py) and the sum-form loss
+``pi + 0.5*baseline + 0.01*entropy`` (:299-351), global-norm clip (:213-214) and Adam.
+The reference pins v-trace to the CPU inside the TF graph (:336); here it is one small
+GPU kernel between the forward and backward passes of the same step.
+"""
+import numpy as np
+import torch
+
+from xingtian_amd.model import netspec
+from xingtian_amd.model.hip_net import HipActorCritic
+from xingtian_amd.model.impala.default_config import GAMMA, LR  # noqa: F401
+from xingtian_amd.model.model import XTModel
+from xingtian_amd.register import Registers, import_config
+
+
+@Registers.model
+class ImpalaCnnOpt(XTModel):
+    """Docstring for ActorNetwork (impala_cnn_opt.py:64)."""
+
+    def __init__(self, model_info):
+        model_config = model_info.get("model_config", dict()) or {}
+        import_config(globals(), model_config)
+        self.input_dtype = model_info.get("input_dtype", "float32")
+        self.sta_mean = model_info.get("state_mean", 0.)
+        self.sta_std = model_info.get("state_std", 255.)
+        self.state_dim = model_info["state_dim"]
+        self.action_dim = model_info["action_dim"]
+        self.lr_schedule = model_config.get("lr_schedule", None)
+        self.opt_type = model_config.get("opt_type", "adam")
+        if self.opt_type != "adam":
+            raise KeyError("invalid opt_type: {} (the HIP learner implements adam)".format(self.opt_type))
+        if self.lr_schedule:
+            raise NotImplementedError("lr_schedule (linear_cosine_decay) is not implemented on the HIP learner")
+        self.lr = LR
+        self.grad_norm_clip = model_config.get("grad_norm_clip", 40.0)
+        self.sample_batch_steps = model_config.get("sample_batch_step", 50)
+        self.max_batch = int(model_config.get("MAX_BATCH", model_info.get("max_batch", 1024)))
+        self.seed = model_config.get("SEED")
+        self._rng = np.random.default_rng(self.seed)
+        super().__init__(model_info)
+
+    def create_model(self, model_info):
+        spec = netspec.impala_cnn_opt(tuple(self.state_dim), self.action_dim, self.sta_mean, self.sta_std,
+                                      self.input_dtype)
+        self.net = HipActorCritic(spec, max_batch=self.max_batch, seed=self.seed, init="none")
+        self.net.init_weights(self.seed, baseline_norm_std=0.01)   # custom_norm_initializer(0.01), :149
+        self.actor_var = self.net
+        self._cfg = self.net.make_impala_cfg(self.lr, self.grad_norm_clip, self.sample_batch_steps, GAMMA)
+        return True
+
+    def train(self, state, label):
+        """One chunk: state [n,...], label=[bp_logits, actions, dones, rewards] -> loss
+        (impala_cnn_opt.py:251-265).  n must be a multiple of sample_batch_step."""
+        bp_logic_outs, actions, dones, rewards = label
+        dev = self.net.device
+        obs = self.net.to_device_obs(state)
+        bp = torch.from_numpy(np.ascontiguousarray(bp_logic_outs, dtype=np.float32)).to(dev)
+        act = torch.from_numpy(np.ascontiguousarray(actions, dtype=np.int32).reshape(-1)).to(dev)
+        dn = torch.from_numpy(np.ascontiguousarray(np.asarray(dones, dtype=bool).astype(np.uint8)).reshape(-1)).to(dev)
+        rw = torch.from_numpy(np.ascontiguousarray(rewards, dtype=np.float32).reshape(-1)).to(dev)
+        out = self.net.impala_step(self._cfg, obs, bp, act, dn, rw, apply=True)
+        return np.float32(out[0].item())
+
+    def predict(self, state):
+        """-> [logits [B,A], baseline [B], action [B]] (impala_cnn_opt.py:267-277)."""
+        logits, value = self.net.forward(np.asarray(state))
+        logits = logits.cpu().numpy()
+        u = self._rng.random(logits.shape)
+        action = np.argmax(logits - np.log(-np.log(u)), axis=-1).astype(np.int32)   # tf.multinomial, :153-157
+        return [logits, value.cpu().numpy(), action]

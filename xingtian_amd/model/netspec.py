@@ -1,0 +1,161 @@
+"""Network descriptions (layer geometry + flat parameter layout) for the HIP learner.
+
+Restates the architecture tables of the reference: ``get_default_filters``
+(xt/model/model_utils.py:120-149), ``get_cnn_backbone`` / ``get_mlp_backbone``
+(:22-80), ``get_atari_filter`` (xt/model/atari_model.py:4-23) and
+``ImpalaCnnOpt.create_model`` (xt/model/impala/impala_cnn_opt.py:110-152), with
+TensorFlow's VALID/SAME output-size and (asymmetric) padding rules.
+
+Flat fp32 parameter buffer layout (ours, not TF's creation order): every trunk layer's
+``[K*N] kernel + [N] bias`` block, then the pi head ``[F*A]+[A]``, then the v head
+``[F]+[1]``; every block starts on a 16-byte boundary.  ``names`` maps the reference's TF
+variable names (Keras layer names, model_utils.py:34-36,87,96) onto (offset, shape).
+"""
+from collections import OrderedDict
+
+
+def conv_out(size, k, s, padding):
+    if padding == "valid":
+        return (size - k) // s + 1, 0
+    out = -(-size // s)
+    total = max((out - 1) * s + k - size, 0)
+    return out, total // 2          # TF SAME: the odd cell goes after (bottom/right)
+
+
+def ppo_cnn_filters(state_dim):
+    hw = list(state_dim[:2])
+    if len(state_dim) != 3:
+        raise ValueError("Without default architecture for obs shape {}".format(state_dim))
+    if hw == [84, 84]:
+        return [(32, 8, 4), (32, 4, 2), (64, 3, 1)]
+    if hw == [42, 42]:
+        return [(32, 4, 2), (32, 4, 2), (64, 3, 1)]
+    if hw == [15, 15]:
+        return [(32, 5, 1), (64, 3, 1), (64, 3, 1)]
+    raise ValueError("Without default architecture for obs shape {}".format(state_dim))
+
+
+def impala_filters(state_dim):
+    hw = list(state_dim[:2])
+    if len(state_dim) == 3 and hw == [84, 84]:
+        return [(16, 8, 4), (32, 4, 2), (256, 11, 1)]
+    if len(state_dim) == 3 and hw == [42, 42]:
+        return [(16, 4, 2), (32, 4, 2), (256, 11, 1)]
+    raise ValueError("Without default architecture for obs shape {}".format(state_dim))
+
+
+class Layer(object):
+    __slots__ = ("name", "H", "W", "C", "KH", "KW", "S", "PT", "PL", "OH", "OW", "N", "act", "trunk",
+                 "param_off", "kernel_shape")
+
+    @property
+    def K(self):
+        return self.KH * self.KW * self.C
+
+
+def _conv(name, h, w, c, cout, k, s, padding, act, trunk):
+    lay = Layer()
+    lay.name, lay.H, lay.W, lay.C, lay.KH, lay.KW, lay.S = name, h, w, c, k, k, s
+    lay.OH, lay.PT = conv_out(h, k, s, padding)
+    lay.OW, lay.PL = conv_out(w, k, s, padding)
+    lay.N, lay.act, lay.trunk = cout, act, trunk
+    lay.kernel_shape = (k, k, c, cout)
+    return lay
+
+
+def _dense(name, cin, cout, act, trunk):
+    lay = Layer()
+    lay.name, lay.H, lay.W, lay.C, lay.KH, lay.KW, lay.S = name, 1, 1, cin, 1, 1, 1
+    lay.OH = lay.OW = 1
+    lay.PT = lay.PL = 0
+    lay.N, lay.act, lay.trunk = cout, act, trunk
+    lay.kernel_shape = (cin, cout)
+    return lay
+
+
+class NetSpec(object):
+    """layers (trunk 0 first), heads, flat layout, name map."""
+
+    def __init__(self, layers, n_trunks, feat, action_dim, pi_name, v_name, pi_kernel_shape, input_xform,
+                 state_dim):
+        self.layers, self.n_trunks, self.feat, self.action_dim = layers, n_trunks, feat, action_dim
+        self.pi_name, self.v_name, self.input_xform, self.state_dim = pi_name, v_name, input_xform, tuple(state_dim)
+        off = 0
+        self.names = OrderedDict()
+        for lay in layers:
+            if lay.C % 4 or lay.N % 4:
+                raise ValueError("layer {}: channel counts must be multiples of 4 for the HIP kernels "
+                                 "(C={}, N={})".format(lay.name, lay.C, lay.N))
+            lay.param_off = off
+            self.names[lay.name + "/kernel"] = (off, lay.kernel_shape)
+            self.names[lay.name + "/bias"] = (off + lay.K * lay.N, (lay.N,))
+            off += (lay.K + 1) * lay.N
+            off = (off + 3) & ~3
+        self.pi_off = off
+        self.names[pi_name + "/kernel"] = (off, pi_kernel_shape)
+        self.names[pi_name + "/bias"] = (off + feat * action_dim, (action_dim,))
+        off = (off + feat * action_dim + action_dim + 3) & ~3
+        self.v_off = off
+        self.names[v_name + "/kernel"] = (off, (feat, 1))
+        self.names[v_name + "/bias"] = (off + feat, (1,))
+        off = (off + feat + 1 + 3) & ~3
+        self.n_flat = off
+        self.n_params = sum(int(_prod(s)) for _, s in self.names.values())
+
+
+def _prod(shape):
+    p = 1
+    for s in shape:
+        p *= s
+    return p
+
+
+def _mlp(prefix, cin, hidden_sizes, act, trunk):
+    out = []
+    for i, hs in enumerate(hidden_sizes):
+        out.append(_dense("{}_hidden_mlp_{}".format(prefix, i), cin, hs, act, trunk))
+        cin = hs
+    return out, cin
+
+
+def ppo_cnn(state_dim, action_dim, hidden_sizes=(512,), act="relu", vf_share=True, input_dtype="uint8"):
+    layers, feat = [], None
+    for trunk, prefix in enumerate(["shared"] if vf_share else ["pi", "v"]):
+        h, w, c = state_dim
+        for i, (cout, k, s) in enumerate(ppo_cnn_filters(state_dim)):
+            lay = _conv("{}_conv_layer_{}".format(prefix, i), h, w, c, cout, k, s, "valid", act, trunk)
+            layers.append(lay)
+            h, w, c = lay.OH, lay.OW, cout
+        mlps, feat = _mlp(prefix, h * w * c, hidden_sizes, act, trunk)
+        layers += mlps
+    xf = (1, 0.0, 255.0) if input_dtype == "uint8" else (0, 0.0, 1.0)
+    return NetSpec(layers, 1 if vf_share else 2, feat, action_dim, "pi_latent", "output_value",
+                   (feat, action_dim), xf, state_dim)
+
+
+def ppo_mlp(state_dim, action_dim, hidden_sizes=(64, 64), act="tanh", vf_share=False):
+    layers, feat = [], None
+    for trunk, prefix in enumerate(["shared"] if vf_share else ["pi", "v"]):
+        mlps, feat = _mlp(prefix, int(state_dim[0]), hidden_sizes, act, trunk)
+        layers += mlps
+    return NetSpec(layers, 1 if vf_share else 2, feat, action_dim, "pi_latent", "output_value",
+                   (feat, action_dim), (0, 0.0, 1.0), (1, 1, int(state_dim[0])))
+
+
+def impala_cnn_opt(state_dim, action_dim, state_mean=0.0, state_std=255.0, input_dtype="uint8"):
+    filt = impala_filters(state_dim)
+    names = ["explore_agent/conv2d", "explore_agent/conv2d_1", "explore_agent/conv2d_2"]
+    h, w, c = state_dim
+    layers = []
+    for i, (cout, k, s) in enumerate(filt):
+        lay = _conv(names[i], h, w, c, cout, k, s, "same" if i < len(filt) - 1 else "valid", "relu", 0)
+        layers.append(lay)
+        h, w, c = lay.OH, lay.OW, cout
+    if (h, w) != (1, 1):
+        raise ValueError("ImpalaCnnOpt expects the last conv to collapse to 1x1, got {}x{}".format(h, w))
+    if input_dtype in ("float32", "float", "float64"):
+        xf = (0, 0.0, 1.0)
+    else:
+        xf = (1, float(state_mean), float(state_std))
+    return NetSpec(layers, 1, c, action_dim, "explore_agent/conv2d_3", "explore_agent/dense",
+                   (1, 1, c, action_dim), xf, state_dim)

@@ -1,0 +1,128 @@
+"""PPO model: the reference's ``PPO(XTModel)`` (xt/model/ppo/ppo.py:36-132) on HIP kernels.
+
+Same constructor contract (``model_info`` with ``state_dim/action_dim/input_dtype/
+model_config``), same ``predict`` / ``train`` / ``get_weights`` / ``set_weights`` /
+``save_model`` signatures and return shapes.  ``train`` uploads the rollout once (the
+reference re-feeds every minibatch through ``feed_dict``), keeps it resident in HBM and
+runs all NUM_SGD_ITER x ceil(N/BATCH_SIZE) steps from one C call; the minibatch gather is
+an index indirection inside the first conv kernel.
+"""
+import numpy as np
+import torch
+
+from xingtian_amd.model.model import XTModel
+from xingtian_amd.model.hip_net import HipActorCritic
+from xingtian_amd.model.ppo.default_config import (  # noqa: F401
+    LR, BATCH_SIZE, CRITIC_LOSS_COEF, ENTROPY_LOSS, LOSS_CLIPPING, MAX_GRAD_NORM, NUM_SGD_ITER, SUMMARY, VF_CLIP)
+from xingtian_amd.register import Registers, import_config
+
+
+@Registers.model
+class PPO(XTModel):
+    """Build PPO network (xt/model/ppo/ppo.py:36)."""
+
+    def __init__(self, model_info):
+        model_config = model_info.get("model_config") or {}
+        import_config(globals(), model_config)
+
+        self.state_dim = model_info["state_dim"]
+        self.action_dim = model_info["action_dim"]
+        self.input_dtype = model_info.get("input_dtype", "float32")
+
+        self.action_type = model_config.get("action_type", "Categorical")
+        self._lr = model_config.get("LR", LR)
+        self._batch_size = model_config.get("BATCH_SIZE", BATCH_SIZE)
+        self.critic_loss_coef = model_config.get("CRITIC_LOSS_COEF", CRITIC_LOSS_COEF)
+        self.ent_coef = model_config.get("ENTROPY_LOSS", ENTROPY_LOSS)
+        self.clip_ratio = model_config.get("LOSS_CLIPPING", LOSS_CLIPPING)
+        self._max_grad_norm = model_config.get("MAX_GRAD_NORM", MAX_GRAD_NORM)
+        self.num_sgd_iter = model_config.get("NUM_SGD_ITER", NUM_SGD_ITER)
+        self.verbose = model_config.get("SUMMARY", SUMMARY)
+        self.vf_clip = model_config.get("VF_CLIP", VF_CLIP)
+        self.use_graph = bool(model_config.get("USE_HIP_GRAPH", True))
+        self.seed = model_config.get("SEED")
+        self._rng = np.random.default_rng(self.seed)
+
+        if self.action_type != "Categorical":
+            raise NotImplementedError(
+                "action type: {} not match any implemented distributions.".format(self.action_type))
+        self._resident = None
+        super().__init__(model_info)
+
+    # subclasses provide build_spec(); create_model wires the HIP network
+    def build_spec(self):
+        raise NotImplementedError
+
+    def create_model(self, model_info):
+        spec = self.build_spec()
+        self.net = HipActorCritic(spec, max_batch=self._batch_size, seed=self.seed)
+        self.actor_var = self.net
+        self._cfg = self.net.make_ppo_cfg(dict(
+            LR=self._lr, LOSS_CLIPPING=self.clip_ratio, ENTROPY_LOSS=self.ent_coef, VF_CLIP=self.vf_clip,
+            CRITIC_LOSS_COEF=self.critic_loss_coef, MAX_GRAD_NORM=self._max_grad_norm,
+            BATCH_SIZE=self._batch_size, NUM_SGD_ITER=self.num_sgd_iter))
+        return self.net
+
+    def predict(self, state):
+        """-> (action [B] int32, logp [B,1] f32, value [B,1] f32), xt/model/ppo/ppo.py:104-109."""
+        state = np.asarray(state)
+        logits, value = self.net.forward(state)
+        logits = logits.cpu().numpy()
+        value = value.cpu().numpy().reshape(-1, 1)
+        # tf.random.categorical (tf_dist.py:127-130): Gumbel-max on the host
+        u = self._rng.random(logits.shape)
+        action = np.argmax(logits - np.log(-np.log(u)), axis=-1).astype(np.int32)
+        m = logits.max(axis=-1, keepdims=True)
+        lsm = logits - m - np.log(np.exp(logits - m).sum(axis=-1, keepdims=True))
+        logp = np.take_along_axis(lsm, action[:, None].astype(np.int64), axis=1).astype(np.float32)
+        return action, logp, value
+
+    def _upload(self, state, label):
+        """Keep the rollout resident in HBM; reuse the buffers when the shapes repeat so that a
+        captured hipGraph stays valid."""
+        dev = self.net.device
+        obs = np.ascontiguousarray(state[0])
+        n = obs.shape[0]
+        key = (obs.shape, str(obs.dtype))
+        if self._resident is None or self._resident["key"] != key:
+            odt = torch.uint8 if self.net.spec.input_xform[0] else torch.float32
+            self._resident = dict(
+                key=key,
+                obs=torch.empty(obs.shape, dtype=odt, device=dev),
+                action=torch.empty((n,), dtype=torch.int32, device=dev),
+                old_logp=torch.empty((n,), dtype=torch.float32, device=dev),
+                adv=torch.empty((n,), dtype=torch.float64, device=dev),
+                old_v=torch.empty((n,), dtype=torch.float32, device=dev),
+                target_v=torch.empty((n,), dtype=torch.float64, device=dev),
+                perm=torch.empty((self.num_sgd_iter, n), dtype=torch.int32, device=dev))
+        r = self._resident
+        r["obs"].copy_(torch.from_numpy(obs).to(r["obs"].dtype) if obs.dtype != np.uint8 and r["obs"].dtype == torch.uint8
+                       else torch.from_numpy(obs), non_blocking=True)
+        r["action"].copy_(torch.from_numpy(np.ascontiguousarray(label[0], dtype=np.int32).reshape(-1)))
+        r["old_logp"].copy_(torch.from_numpy(np.ascontiguousarray(label[1], dtype=np.float32).reshape(-1)))
+        r["adv"].copy_(torch.from_numpy(np.ascontiguousarray(label[2], dtype=np.float64).reshape(-1)))
+        r["old_v"].copy_(torch.from_numpy(np.ascontiguousarray(label[3], dtype=np.float32).reshape(-1)))
+        r["target_v"].copy_(torch.from_numpy(np.ascontiguousarray(label[4], dtype=np.float64).reshape(-1)))
+        return r
+
+    def make_perms(self, nbatch):
+        """np.random.shuffle(inds) once per epoch, cumulatively (xt/model/ppo/ppo.py:114-118)."""
+        inds = np.arange(nbatch)
+        perms = np.empty((self.num_sgd_iter, nbatch), np.int32)
+        for ep in range(self.num_sgd_iter):
+            self._rng.shuffle(inds)
+            perms[ep] = inds
+        return perms
+
+    def train(self, state, label, perms=None):
+        """state=[obs], label=[action, old_logp, adv, old_v, target_v] -> mean minibatch loss
+        (xt/model/ppo/ppo.py:111-132).  ``perms`` ([NUM_SGD_ITER, N]) injects the shuffles."""
+        r = self._upload(state, label)
+        nbatch = r["obs"].shape[0]
+        if perms is None:
+            perms = self.make_perms(nbatch)
+        r["perm"].copy_(torch.from_numpy(np.ascontiguousarray(perms, dtype=np.int32)))
+        acc = self.net.ppo_train(self._cfg, r["obs"], r["perm"], r["action"], r["old_logp"], r["adv"], r["old_v"],
+                                 r["target_v"], use_graph=self.use_graph)
+        a = acc.cpu().numpy()
+        return np.float32(a[0] / max(a[1], 1.0))
