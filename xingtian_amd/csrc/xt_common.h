@@ -57,6 +57,40 @@ __device__ __forceinline__ float act_grad(float y, int act) {
   return 1.f;
 }
 
+// ---- argument blocks shared between translation units -------------------------------------
+struct LossArgs {
+  const float* terms;   // [B,4] per-sample surr, entropy, vf ; nullptr -> skip
+  int B;
+  float ent_coef, critic_coef, inv_b;
+  float* out;           // 4 floats (may be null)
+  float* acc;           // running sum / count (may be null)
+};
+
+// One entry per parameter block: sum `nslab` partial slabs (fixed order) into dst and accumulate the
+// squared norm of the result.  nslab == 1 with src == dst only accumulates the norm.
+struct GradEntry {
+  const float* src;
+  float* dst;
+  int count, nslab;
+  long long stride;
+  int zl;               // z lanes per block (power of two <= 32)
+  int blk0, nblk;
+};
+struct GradTable {
+  int n;
+  GradEntry e[12];
+};
+
+struct PpoHeadArgs {
+  const float *f_pi, *f_v, *wpi, *bpi, *wv, *bv;
+  const int32_t *idx, *action;
+  const float *old_logp, *old_v;
+  const double *adv, *target_v;
+  float clip_ratio, ent_coef, vf_clip, critic_coef, inv_b;
+  int B, F, A, act_prev, shared;
+  float *logits, *value, *dlogits, *dvalue, *terms, *df_pi, *df_v;
+};
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace xt

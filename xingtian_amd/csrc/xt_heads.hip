@@ -288,6 +288,175 @@ __global__ __launch_bounds__(256) void heads_wgrad_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------- fused PPO head (one launch per SGD step)
+// heads forward + PPO loss + d(logits,value) + gradient w.r.t. the trunk features, one wave per
+// sample, lane a <-> action a (A <= 64).  Same arithmetic as heads_fwd_kernel / ppo_loss_kernel /
+// heads_dfeat_kernel; the loss scalar is reduced later (norm_finalize_kernel) from `terms`.
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const PpoHeadArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= p.B) return;
+  const int F = p.F, A = p.A;
+  const float* fp = p.f_pi + (size_t)b * F;
+  const float* fv = p.f_v + (size_t)b * F;
+  float mylogit = -INFINITY;
+  for (int a = 0; a < A; ++a) {
+    float s = 0.f;
+    for (int f = lane; f < F; f += 64) s = fmaf(fp[f], p.wpi[(size_t)f * A + a], s);
+    s = wave_sum(s);
+    if (lane == a) mylogit = s + p.bpi[a];
+  }
+  float sv = 0.f;
+  for (int f = lane; f < F; f += 64) sv = fmaf(fv[f], p.wv[f], sv);
+  const float v = wave_sum(sv) + p.bv[0];
+
+  const bool la = lane < A;
+  const float mx = wave_max(mylogit);
+  const float rl = la ? mylogit - mx : 0.f;
+  const float e = la ? expf(rl) : 0.f;
+  const float z = wave_sum(e);
+  const float logz = logf(z);
+  const float pa = e / z;
+  const float ent = wave_sum(la ? pa * (logz - rl) : 0.f);
+  const int s = p.idx ? p.idx[b] : b;
+  const int act = p.action[s];
+  const float lpa = rl - logz;
+  const float logp = __shfl(lpa, act, 64);
+  const float advf = (float)p.adv[s];
+  const float tv = (float)p.target_v[s];
+  const float ov = p.old_v[s];
+  const float ratio = expf(logp - p.old_logp[s]);
+  const float surr1 = ratio * advf;
+  const float rc = fminf(fmaxf(ratio, 1.f - p.clip_ratio), 1.f + p.clip_ratio);
+  const float surr2 = rc * advf;
+  const bool first = surr1 <= surr2;
+  const bool in_rng = (ratio >= 1.f - p.clip_ratio) && (ratio <= 1.f + p.clip_ratio);
+  const float dsurr = (first || in_rng) ? advf : 0.f;
+  const float dlogp = -(dsurr * ratio) * p.inv_b;
+  const float d1 = v - tv, vf1 = d1 * d1;
+  const float vcl = ov + fminf(fmaxf(v - ov, -p.vf_clip), p.vf_clip);
+  const float d2 = vcl - tv, vf2 = d2 * d2;
+  const bool take1 = vf1 >= vf2;
+  const bool in_v = fabsf(v - ov) <= p.vf_clip;
+  const float dvr = take1 ? 2.f * d1 : (in_v ? 2.f * d2 : 0.f);
+  const float dv = p.critic_coef * 0.5f * p.inv_b * dvr;
+  const float onehot = (lane == act) ? 1.f : 0.f;
+  const float dl = la ? dlogp * (onehot - pa) + p.ent_coef * p.inv_b * (pa * (lpa + ent)) : 0.f;
+  if (la) {
+    p.logits[(size_t)b * A + lane] = mylogit;
+    p.dlogits[(size_t)b * A + lane] = dl;
+  }
+  if (lane == 0) {
+    p.value[b] = v;
+    p.dvalue[b] = dv;
+    float* tm = p.terms + (size_t)b * 4;
+    tm[0] = fminf(surr1, surr2); tm[1] = ent; tm[2] = fmaxf(vf1, vf2); tm[3] = 0.f;
+  }
+  // d(features) = dlogits . Wpi^T (+ dvalue . Wv^T), times the producer's activation gradient
+  for (int f = lane; f < F; f += 64) {
+    float acc = 0.f;
+    for (int a = 0; a < A; ++a) acc = fmaf(__shfl(dl, a, 64), p.wpi[(size_t)f * A + a], acc);
+    const float svv = dv * p.wv[f];
+    if (p.shared) {
+      p.df_pi[(size_t)b * F + f] = (acc + svv) * act_grad(fp[f], p.act_prev);
+    } else {
+      p.df_pi[(size_t)b * F + f] = acc * act_grad(fp[f], p.act_prev);
+      p.df_v[(size_t)b * F + f] = svv * act_grad(fv[f], p.act_prev);
+    }
+  }
+}
+
+// head weight-gradient partial slabs: grid (ceil(F/64), nchunk); chunk = 8 samples.
+// slab_pi[chunk][F*A + A], slab_v[chunk][F + 1] (strides passed), summed by grads_finish_kernel.
+__global__ __launch_bounds__(256) void heads_wgrad_partial_kernel(const float* __restrict__ f_pi, const float* __restrict__ f_v,
+                                                                  int B, int F, int A, const float* __restrict__ dlogits,
+                                                                  const float* __restrict__ dvalue, float* __restrict__ slab_pi,
+                                                                  long long stride_pi, float* __restrict__ slab_v,
+                                                                  long long stride_v) {
+  __shared__ float red[4][64][9];
+  const int fl = threadIdx.x & 63, bg = threadIdx.x >> 6;
+  const int f = blockIdx.x * 64 + fl;
+  const bool fok = f < F;
+  const int b0 = blockIdx.y * 8;
+  float* spi = slab_pi + (size_t)blockIdx.y * stride_pi;
+  float* svp = slab_v + (size_t)blockIdx.y * stride_v;
+  for (int a0 = 0; a0 <= A; a0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int b = b0 + bg + 4 * r;
+      if (b < B) {
+        const float xp = fok ? f_pi[(size_t)b * F + f] : 0.f;
+        const float xv = fok ? f_v[(size_t)b * F + f] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int a = a0 + q;
+          if (a < A) acc[q] = fmaf(xp, dlogits[(size_t)b * A + a], acc[q]);
+          else if (a == A) acc[q] = fmaf(xv, dvalue[b], acc[q]);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) red[bg][fl][q] = acc[q];
+    __syncthreads();
+    if (bg == 0 && fok) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int a = a0 + q;
+        const float s = red[0][fl][q] + red[1][fl][q] + red[2][fl][q] + red[3][fl][q];
+        if (a < A) spi[(size_t)f * A + a] = s;
+        else if (a == A) svp[f] = s;
+      }
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x <= A) {
+    const int a = threadIdx.x;
+    float s = 0.f;
+    for (int r = 0; r < 8; ++r) {
+      const int b = b0 + r;
+      if (b < B) s += (a < A) ? dlogits[(size_t)b * A + a] : dvalue[b];
+    }
+    if (a < A) spi[(size_t)F * A + a] = s; else svp[F] = s;
+  }
+}
+
+int launch_ppo_heads_fused(const PpoHeadArgs& a, hipStream_t st) {
+  XT_REQUIRE(a.A <= 64, "ppo_heads_fused: A=%d > 64", a.A);
+  hipLaunchKernelGGL(ppo_heads_fused_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, a);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_heads_dfeat(const float* f_pi, const float* f_v, int B, int F, int A, const float* wpi, const float* wv,
+                       const float* dlogits, const float* dvalue, int act_prev, float* df_pi, float* df_v,
+                       hipStream_t st) {
+  const int shared = (f_pi == f_v) ? 1 : 0;
+  hipLaunchKernelGGL(heads_dfeat_kernel, dim3((B * F + 255) / 256), dim3(256), 0, st, f_pi, f_v, B, F, A, wpi, wv,
+                     dlogits, dvalue, act_prev, shared, df_pi, df_v);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_heads_wgrad_partial(const float* f_pi, const float* f_v, int B, int F, int A, const float* dlogits,
+                               const float* dvalue, float* slab_pi, long long stride_pi, float* slab_v,
+                               long long stride_v, int* nchunk_out, hipStream_t st) {
+  const int nchunk = (B + 7) / 8;
+  hipLaunchKernelGGL(heads_wgrad_partial_kernel, dim3((F + 63) / 64, nchunk), dim3(256), 0, st, f_pi, f_v, B, F, A,
+                     dlogits, dvalue, slab_pi, stride_pi, slab_v, stride_v);
+  XT_LAUNCH_CHECK();
+  *nchunk_out = nchunk;
+  return 0;
+}
+
 // ---------------------------------------------------------------- GAE (float64, bit-exact with numpy)
 // one thread per trajectory; same association as xt/agent/ppo/ppo.py:92-104:
 //   discount = (~done)*gamma ; delta = (reward + discount*next_v) - v ;

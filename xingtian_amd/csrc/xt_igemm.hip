@@ -26,7 +26,8 @@ struct Geom {
   int B, H, W, C, KH, KW, S, PT, PL, OH, OW, N, act;
   int K, KWC, M, OHOW;
   FastDiv d_ohow, d_ow, d_kwc, d_c, d_n;
-  float mean, std;
+  float xs, xb;          // uint8 -> f32 transform: x*xs + xb  (xs = 1/std, xb = -mean/std)
+  int HWC;
 };
 
 static int make_geom(const xt_conv_geom* g, const xt_input_xform* xf, int B, Geom* o) {
@@ -43,35 +44,91 @@ static int make_geom(const xt_conv_geom* g, const xt_input_xform* xf, int B, Geo
   o->M = (int)m;
   o->d_ohow = make_fastdiv(o->OHOW); o->d_ow = make_fastdiv(o->OW);
   o->d_kwc = make_fastdiv(o->KWC); o->d_c = make_fastdiv(o->C); o->d_n = make_fastdiv(o->N);
-  o->mean = xf ? xf->mean : 0.f; o->std = xf ? xf->std : 1.f;
+  const float mean = (xf && fabsf(xf->mean) >= 1e-4f) ? xf->mean : 0.f;   // state_transform: |mean|<1e-4 -> x/std
+  o->xs = xf ? 1.f / xf->std : 1.f;
+  o->xb = -mean * o->xs;
+  o->HWC = g->H * g->W * g->C;
+  XT_REQUIRE(m * (long long)g->N < (1ll << 31), "igemm: output tensor too large");
   return 0;
 }
 
+__device__ __forceinline__ float4 sel4(bool ok, float4 v) {
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
+// Raw 4-element input group as it comes from HBM: one dword (4 x uint8) or four floats.  The uint8->f32
+// transform and the zero-select for padding/tails are applied when the group is written to LDS, NOT when it
+// is loaded, so that the global loads of step s+2 stay in flight behind the MFMAs of step s.
+template <bool U8> struct Raw4;
+template <> struct Raw4<true> { uint32_t v; };
+template <> struct Raw4<false> { float4 v; };
+
 template <bool U8>
-__device__ __forceinline__ float4 load_in4(const void* in, size_t off, float mean, float stdv) {
-  if (U8) {
-    const uchar4 u = *reinterpret_cast<const uchar4*>(static_cast<const uint8_t*>(in) + off);
-    float4 f = make_float4((float)u.x, (float)u.y, (float)u.z, (float)u.w);
-    if (fabsf(mean) >= 1e-4f) { f.x -= mean; f.y -= mean; f.z -= mean; f.w -= mean; }
-    f.x /= stdv; f.y /= stdv; f.z /= stdv; f.w /= stdv;
-    return f;
+__device__ __forceinline__ Raw4<U8> load_raw4(const void* in, long long off) {
+  Raw4<U8> r;
+  if constexpr (U8) r.v = *reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(in) + off);
+  else r.v = *reinterpret_cast<const float4*>(static_cast<const float*>(in) + off);
+  return r;
+}
+// A/B switch for experiments: -DXT_GUARDED_LOADS turns the clamped unconditional loads back into guarded ones
+template <bool U8>
+__device__ __forceinline__ Raw4<U8> load_raw4_ok(const void* in, long long off, bool ok) {
+#ifdef XT_GUARDED_LOADS
+  Raw4<U8> r;
+  if constexpr (U8) r.v = 0u; else r.v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) r = load_raw4<U8>(in, off);
+  return r;
+#else
+  return load_raw4<U8>(in, ok ? off : 0ll);
+#endif
+}
+__device__ __forceinline__ float4 load_f4_ok(const float* base, long long off, bool ok) {
+#ifdef XT_GUARDED_LOADS
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) r = *reinterpret_cast<const float4*>(base + off);
+  return r;
+#else
+  return *reinterpret_cast<const float4*>(base + (ok ? off : 0ll));
+#endif
+}
+
+template <bool U8>
+__device__ __forceinline__ float4 cook4(const Raw4<U8>& r, bool ok, float xs, float xb) {
+  if constexpr (U8) {
+    // v_cvt_f32_ubyteN + one fma per element
+    return sel4(ok, make_float4(fmaf((float)(r.v & 0xffu), xs, xb), fmaf((float)((r.v >> 8) & 0xffu), xs, xb),
+                                fmaf((float)((r.v >> 16) & 0xffu), xs, xb), fmaf((float)(r.v >> 24), xs, xb)));
   } else {
-    return *reinterpret_cast<const float4*>(static_cast<const float*>(in) + off);
+    return sel4(ok, r.v);
   }
 }
 
-// im2col row m -> sample base offset (elements) and top-left input coordinate
-__device__ __forceinline__ void decode_row(const Geom& g, int m, const int32_t* __restrict__ idx,
-                                           size_t* rowoff, int* iy0, int* ix0) {
-  if (m >= g.M) { *rowoff = 0; *iy0 = -(1 << 28); *ix0 = 0; return; }
-  const uint32_t b = fdiv((uint32_t)m, g.d_ohow);
-  const uint32_t rem = (uint32_t)m - b * (uint32_t)g.OHOW;
+// im2col row m -> sample index b and top-left input coordinate (no memory access, branch-free)
+__device__ __forceinline__ void decode_coords(const Geom& g, int m, uint32_t* b, int* iy0, int* ix0) {
+  const bool okm = m < g.M;
+  const uint32_t mm = okm ? (uint32_t)m : 0u;
+  const uint32_t bb = fdiv(mm, g.d_ohow);
+  const uint32_t rem = mm - bb * (uint32_t)g.OHOW;
   const uint32_t oy = fdiv(rem, g.d_ow);
   const uint32_t ox = rem - oy * (uint32_t)g.OW;
-  const size_t s = idx ? (size_t)idx[b] : (size_t)b;
-  *rowoff = s * (size_t)(g.H * g.W * g.C);
-  *iy0 = (int)oy * g.S - g.PT;
+  *b = bb;
+  *iy0 = okm ? (int)oy * g.S - g.PT : -(1 << 28);
   *ix0 = (int)ox * g.S - g.PL;
+}
+// decode N rows -> element offset of the (possibly out-of-image, when padded) top-left input element of the
+// receptive field, relative to the input base.  All minibatch-gather index loads are issued back to back.
+template <int N>
+__device__ __forceinline__ void decode_rows(const Geom& g, const int (&m)[N], const int32_t* __restrict__ idx,
+                                            long long (&rowbase)[N], int (&iy0)[N], int (&ix0)[N]) {
+  uint32_t b[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) decode_coords(g, m[i], &b[i], &iy0[i], &ix0[i]);
+  int32_t sidx[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) sidx[i] = idx ? idx[b[i]] : (int32_t)b[i];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    rowbase[i] = (long long)sidx[i] * g.HWC + (long long)((iy0[i] * g.W + ix0[i]) * g.C);
 }
 
 // 32 reduction steps of the tile product on the matrix cores
@@ -105,17 +162,19 @@ struct FwdArgs {
   int ksplit, kchunk;
 };
 
-template <int BI, int BJ, int WI, int WJ, bool U8>
+// PADDED: the receptive field can leave the image (TF SAME) -> per-element bounds checks; VALID convs and
+// dense layers skip them.  Row base offsets are computed once per block; a k-step costs one (ky,kx,c)
+// decode per thread plus one 64-bit add per row.
+template <int BI, int BJ, int WI, int WJ, bool U8, bool PADDED>
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(const FwdArgs p) {
   constexpr int TI = BI / (32 * WI), TJ = BJ / (32 * WJ);
   constexpr int SA = BI + 1, SB = BJ;
-  constexpr int NA = BI / 32;            // float4 fetches per thread for A
+  constexpr int NA = BI / 32;            // 4-element fetches per thread for A
   constexpr int CPRB = BJ / 4;           // float4 groups per B row
   constexpr int RPB = 256 / CPRB;        // B rows per pass
   constexpr int NB = 32 / RPB;
-  __shared__ __attribute__((aligned(16))) float smem[32 * SA + 32 * SB];
-  float* As = smem;
-  float* Bs = smem + 32 * SA;
+  constexpr int BUF = 32 * SA + 32 * SB; // one LDS stage (A then B); two stages, one barrier per step
+  __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
   const Geom& g = p.g;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i0 = blockIdx.x * BI, j0 = blockIdx.y * BJ;
@@ -123,45 +182,57 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const FwdArgs p) {
   const int kend = min(g.K, kbeg + p.kchunk);
 
   const int c4 = t & 7, r0 = t >> 3;
-  size_t rowoff[NA];
+  long long rowbase[NA];
   int iy0[NA], ix0[NA];
+  uint32_t rowok = 0;
+  {
+    int mrow[NA];
 #pragma unroll
-  for (int i = 0; i < NA; ++i) decode_row(g, i0 + r0 + 32 * i, p.idx, &rowoff[i], &iy0[i], &ix0[i]);
+    for (int i = 0; i < NA; ++i) { mrow[i] = i0 + r0 + 32 * i; rowok |= (mrow[i] < g.M ? 1u : 0u) << i; }
+    decode_rows<NA>(g, mrow, p.idx, rowbase, iy0, ix0);
+  }
   const int cb = t % CPRB, rb = t / CPRB;
+  const int nb = j0 + cb * 4;
+  const bool nok = nb < g.N;
 
-  float4 ra[NA], rbv[NB];
-  auto fetch = [&](int k0) {
+  struct Regs { Raw4<U8> a[NA]; float4 b[NB]; uint32_t ok; };
+  auto fetch = [&](int k0, Regs& R) {
     const int k = k0 + c4 * 4;
+    const bool kv = k < kend;
     const uint32_t ky = fdiv((uint32_t)k, g.d_kwc);
     const uint32_t r = (uint32_t)k - ky * (uint32_t)g.KWC;
     const uint32_t kx = fdiv(r, g.d_c);
-    const uint32_t c = r - kx * (uint32_t)g.C;
+    const int koff = ((int)ky * g.W + (int)kx) * g.C + (int)(r - kx * (uint32_t)g.C);
+    R.ok = 0;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int iy = iy0[i] + (int)ky, ix = ix0[i] + (int)kx;
-      const bool ok = (k < kend) && ((unsigned)iy < (unsigned)g.H) && ((unsigned)ix < (unsigned)g.W);
-      ra[i] = ok ? load_in4<U8>(p.in, rowoff[i] + (size_t)((iy * g.W + ix) * g.C + (int)c), g.mean, g.std)
-                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      bool ok = kv && ((rowok >> i) & 1u);
+      if (PADDED)
+        ok = ok && ((unsigned)(iy0[i] + (int)ky) < (unsigned)g.H) && ((unsigned)(ix0[i] + (int)kx) < (unsigned)g.W);
+      R.a[i] = load_raw4_ok<U8>(p.in, rowbase[i] + koff, ok);
+      R.ok |= (ok ? 1u : 0u) << i;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int kk = k0 + rb + RPB * i, n = j0 + cb * 4;
-      rbv[i] = (kk < kend && n < g.N) ? *reinterpret_cast<const float4*>(p.w + (size_t)kk * g.N + n)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int kk = k0 + rb + RPB * i;
+      const bool okb = nok && kk < kend;
+      R.b[i] = load_f4_ok(p.w, (long long)kk * g.N + nb, okb);
+      R.ok |= (okb ? 1u : 0u) << (8 + i);
     }
   };
-  auto stash = [&]() {
+  auto stash = [&](const Regs& R, float* As, float* Bs) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int r = r0 + 32 * i;
-      As[(c4 * 4 + 0) * SA + r] = ra[i].x;
-      As[(c4 * 4 + 1) * SA + r] = ra[i].y;
-      As[(c4 * 4 + 2) * SA + r] = ra[i].z;
-      As[(c4 * 4 + 3) * SA + r] = ra[i].w;
+      const float4 v = cook4<U8>(R.a[i], (R.ok >> i) & 1u, g.xs, g.xb);
+      As[(c4 * 4 + 0) * SA + r] = v.x;
+      As[(c4 * 4 + 1) * SA + r] = v.y;
+      As[(c4 * 4 + 2) * SA + r] = v.z;
+      As[(c4 * 4 + 3) * SA + r] = v.w;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i)
-      *reinterpret_cast<float4*>(&Bs[(rb + RPB * i) * SB + cb * 4]) = rbv[i];
+      *reinterpret_cast<float4*>(&Bs[(rb + RPB * i) * SB + cb * 4]) = sel4((R.ok >> (8 + i)) & 1u, R.b[i]);
   };
 
   f32x16 acc[TI][TJ];
@@ -173,13 +244,21 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const FwdArgs p) {
       for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
 
   const int wi = wave / WJ, wj = wave % WJ;
-  if (kbeg < kend) fetch(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += 32) {
-    stash();
+  const int nsteps = (kend - kbeg + 31) / 32;
+  Regs R0, R1;
+  if (nsteps > 0) fetch(kbeg, R0);
+  if (nsteps > 1) fetch(kbeg + 32, R1);
+  for (int s = 0; s < nsteps; s += 2) {
+    stash(R0, smem, smem + 32 * SA);
     __syncthreads();
-    if (k0 + 32 < kend) fetch(k0 + 32);
-    mma_tile<TI, TJ, SA, SB>(As, Bs, wi * TI * 32, wj * TJ * 32, acc, lane);
-    __syncthreads();
+    if (s + 2 < nsteps) fetch(kbeg + (s + 2) * 32, R0);
+    mma_tile<TI, TJ, SA, SB>(smem, smem + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+    if (s + 1 < nsteps) {
+      stash(R1, smem + BUF, smem + BUF + 32 * SA);
+      __syncthreads();
+      if (s + 3 < nsteps) fetch(kbeg + (s + 3) * 32, R1);
+      mma_tile<TI, TJ, SA, SB>(smem + BUF, smem + BUF + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+    }
   }
 
   const bool final_out = (p.ksplit == 1);
@@ -229,16 +308,23 @@ struct WgradArgs {
   int msplit, mchunk;
 };
 
-template <int BI, int BJ, int WI, int WJ, bool U8>
+constexpr int kRowTab = 1024;                       // rows decoded at once into the LDS row table
+constexpr long long kRowInvalid = -(1ll << 62);
+
+// Each thread owns a fixed group of 4 k's (its (ky,kx,c) offset is computed once); the rows of the block's
+// m-range are decoded once into an LDS table (base offset [+ coordinates when PADDED]), so a reduction step
+// costs one ds_read + one 64-bit add per row.
+template <int BI, int BJ, int WI, int WJ, bool U8, bool PADDED>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs p) {
   constexpr int TI = BI / (32 * WI), TJ = BJ / (32 * WJ);
   constexpr int SA = BI, SB = BJ;
   constexpr int CPRA = BI / 4, RPA = 256 / CPRA, NA = 32 / RPA;
   constexpr int CPRB = BJ / 4, RPB = 256 / CPRB, NB = 32 / RPB;
   constexpr int RG = 256 / BJ;           // row groups for the bias column sums
-  __shared__ __attribute__((aligned(16))) float smem[32 * SA + 32 * SB];
-  float* As = smem;
-  float* Bs = smem + 32 * SA;
+  constexpr int BUF = 32 * SA + 32 * SB;
+  __shared__ __attribute__((aligned(16))) float smem[2 * BUF + 2 * kRowTab + (PADDED ? kRowTab : 0)];
+  long long* rowtab = reinterpret_cast<long long*>(smem + 2 * BUF);
+  int* rowxy = reinterpret_cast<int*>(smem + 2 * BUF + 2 * kRowTab);
   const Geom& g = p.g;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i0 = blockIdx.x * BI, j0 = blockIdx.y * BJ;     // i = k, j = n
@@ -252,36 +338,10 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs p) {
   const uint32_t ky = fdiv((uint32_t)k, g.d_kwc);
   const uint32_t rr = (uint32_t)k - ky * (uint32_t)g.KWC;
   const uint32_t kx = fdiv(rr, g.d_c);
-  const int kc = (int)(rr - kx * (uint32_t)g.C);
+  const int koff = ((int)ky * g.W + (int)kx) * g.C + (int)(rr - kx * (uint32_t)g.C);
   const int cb = t % CPRB, rowb = t / CPRB;
-
-  float4 ra[NA], rbv[NB];
-  auto fetch = [&](int m0) {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int m = m0 + rowa + RPA * i;
-      size_t rowoff; int iy, ix;
-      decode_row(g, m < mend ? m : g.M, p.idx, &rowoff, &iy, &ix);
-      iy += (int)ky; ix += (int)kx;
-      const bool ok = kok && ((unsigned)iy < (unsigned)g.H) && ((unsigned)ix < (unsigned)g.W);
-      ra[i] = ok ? load_in4<U8>(p.in, rowoff + (size_t)((iy * g.W + ix) * g.C + kc), g.mean, g.std)
-                 : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int m = m0 + rowb + RPB * i, n = j0 + cb * 4;
-      rbv[i] = (m < mend && n < g.N) ? *reinterpret_cast<const float4*>(p.dy + (size_t)m * g.N + n)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto stash = [&]() {
-#pragma unroll
-    for (int i = 0; i < NA; ++i)
-      *reinterpret_cast<float4*>(&As[(rowa + RPA * i) * SA + ca * 4]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-      *reinterpret_cast<float4*>(&Bs[(rowb + RPB * i) * SB + cb * 4]) = rbv[i];
-  };
+  const int nb = j0 + cb * 4;
+  const bool nok = nb < g.N;
 
   f32x16 acc[TI][TJ];
 #pragma unroll
@@ -296,17 +356,78 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs p) {
   const int bcol = t % BJ, brg = t / BJ;
   float bsum = 0.f;
 
-  if (mbeg < mend) fetch(mbeg);
-  for (int m0 = mbeg; m0 < mend; m0 += 32) {
-    stash();
-    __syncthreads();
-    if (m0 + 32 < mend) fetch(m0 + 32);
-    if (do_bias) {
-#pragma unroll
-      for (int q = 0; q < 32 / RG; ++q) bsum += Bs[(brg + RG * q) * SB + bcol];
+  for (int sub = mbeg; sub < mend; sub += kRowTab) {
+    const int sub_end = min(mend, sub + kRowTab);
+    const int nsteps = (sub_end - sub + 31) / 32;
+    // ---- decode the rows of this sub-range once
+    for (int r = t; r < nsteps * 32; r += 256) {
+      int mr[1] = {sub + r < sub_end ? sub + r : g.M};
+      long long base[1];
+      int iy0[1], ix0[1];
+      decode_rows<1>(g, mr, p.idx, base, iy0, ix0);
+      rowtab[r] = (sub + r < sub_end) ? base[0] : kRowInvalid;
+      if (PADDED) rowxy[r] = (iy0[0] << 16) | (ix0[0] & 0xffff);
     }
-    mma_tile<TI, TJ, SA, SB>(As, Bs, wi * TI * 32, wj * TJ * 32, acc, lane);
     __syncthreads();
+
+    struct Regs { Raw4<U8> a[NA]; float4 b[NB]; uint32_t ok; };
+    auto fetch = [&](int s, Regs& R) {
+      R.ok = 0;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int r = s * 32 + rowa + RPA * i;
+        const long long rbse = rowtab[r];
+        bool ok = kok && (rbse > kRowInvalid);
+        if (PADDED) {
+          const int xy = rowxy[r];
+          ok = ok && ((unsigned)((xy >> 16) + (int)ky) < (unsigned)g.H) &&
+               ((unsigned)((int)(short)(xy & 0xffff) + (int)kx) < (unsigned)g.W);
+        }
+        R.a[i] = load_raw4_ok<U8>(p.in, rbse + koff, ok);
+        R.ok |= (ok ? 1u : 0u) << i;
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int m = sub + s * 32 + rowb + RPB * i;
+        const bool okb = nok && m < sub_end;
+        R.b[i] = load_f4_ok(p.dy, (long long)m * g.N + nb, okb);
+        R.ok |= (okb ? 1u : 0u) << (8 + i);
+      }
+    };
+    auto stash = [&](const Regs& R, float* As, float* Bs) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        *reinterpret_cast<float4*>(&As[(rowa + RPA * i) * SA + ca * 4]) =
+            cook4<U8>(R.a[i], (R.ok >> i) & 1u, g.xs, g.xb);
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        *reinterpret_cast<float4*>(&Bs[(rowb + RPB * i) * SB + cb * 4]) = sel4((R.ok >> (8 + i)) & 1u, R.b[i]);
+    };
+    auto colsum = [&](const float* Bs) {
+      if (do_bias) {
+#pragma unroll
+        for (int q = 0; q < 32 / RG; ++q) bsum += Bs[(brg + RG * q) * SB + bcol];
+      }
+    };
+
+    Regs R0, R1;
+    if (nsteps > 0) fetch(0, R0);
+    if (nsteps > 1) fetch(1, R1);
+    for (int s = 0; s < nsteps; s += 2) {
+      stash(R0, smem, smem + 32 * SA);
+      __syncthreads();
+      if (s + 2 < nsteps) fetch(s + 2, R0);
+      colsum(smem + 32 * SA);
+      mma_tile<TI, TJ, SA, SB>(smem, smem + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+      if (s + 1 < nsteps) {
+        stash(R1, smem + BUF, smem + BUF + 32 * SA);
+        __syncthreads();
+        if (s + 3 < nsteps) fetch(s + 3, R1);
+        colsum(smem + BUF + 32 * SA);
+        mma_tile<TI, TJ, SA, SB>(smem + BUF, smem + BUF + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+      }
+    }
+    __syncthreads();   // row table and LDS stages are reused by the next sub-range
   }
 
   float* out = p.out + (size_t)blockIdx.z * ((size_t)(g.K + 1) * g.N);
@@ -322,14 +443,14 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs p) {
       }
     }
   if (do_bias) {
-    smem[brg * BJ + bcol] = bsum;      // safe: last loop iteration ended with a barrier
+    smem[brg * BJ + bcol] = bsum;      // safe: the loop ended with a barrier
     __syncthreads();
     if (t < BJ) {
-      float s = 0.f;
+      float sum = 0.f;
 #pragma unroll
-      for (int q = 0; q < RG; ++q) s += smem[q * BJ + t];
+      for (int q = 0; q < RG; ++q) sum += smem[q * BJ + t];
       const int n = j0 + t;
-      if (n < g.N) out[(size_t)g.K * g.N + n] = s;
+      if (n < g.N) out[(size_t)g.K * g.N + n] = sum;
     }
   }
 }
@@ -362,10 +483,9 @@ __global__ __launch_bounds__(256) void igemm_dgrad_kernel(const DgradArgs p) {
   constexpr int TI = BI / (32 * WI), TJ = BJ / (32 * WJ);
   constexpr int SA = BI + 1, SB = BJ + 1;
   constexpr int NA = BI / 32, NB = BJ / 32;
-  __shared__ __attribute__((aligned(16))) float smem[32 * SA + 32 * SB + BI];
-  float* As = smem;
-  float* Bs = smem + 32 * SA;
-  int* rowOut = reinterpret_cast<int*>(smem + 32 * SA + 32 * SB);
+  constexpr int BUF = 32 * SA + 32 * SB;
+  __shared__ __attribute__((aligned(16))) float smem[2 * BUF + BI];
+  int* rowOut = reinterpret_cast<int*>(smem + 2 * BUF);
   const Geom& g = p.g;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
@@ -394,58 +514,65 @@ __global__ __launch_bounds__(256) void igemm_dgrad_kernel(const DgradArgs p) {
   }
 
   const int c4 = t & 7, r0 = t >> 3;
-  int dybase[NA], qy[NA], qx[NA];
+  int rowbase[NA], qy[NA], qx[NA];       // dY element offset of output pixel (qy,qx) of the row's sample
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int mc = i0 + r0 + 32 * i;
     if (mc < Mc) {
       const int b = mc / (HC * WC), rem = mc - b * (HC * WC);
       const int ty = rem / WC, tx = rem - ty * WC;
-      dybase[i] = b * g.OHOW * g.N; qy[i] = qy0 + ty; qx[i] = qx0 + tx;
+      qy[i] = qy0 + ty; qx[i] = qx0 + tx;
+      rowbase[i] = (b * g.OHOW + qy[i] * g.OW + qx[i]) * g.N;
     } else {
-      dybase[i] = 0; qy[i] = -(1 << 28); qx[i] = 0;
+      rowbase[i] = 0; qy[i] = -(1 << 28); qx[i] = 0;
     }
   }
+  int cN[NB];
+  uint32_t cok = 0;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) { const int c = j0 + r0 + 32 * i; cN[i] = c * g.N; cok |= (c < g.C ? 1u : 0u) << i; }
 
-  float4 ra[NA], rbv[NB];
-  auto fetch = [&](int k0) {
+  struct Regs { float4 a[NA]; float4 b[NB]; uint32_t ok; };
+  auto fetch = [&](int k0, Regs& R) {
     const int kk = k0 + c4 * 4;
     const bool kok = kk < Kc;
+    R.ok = 0;
     const uint32_t tap = fdiv((uint32_t)kk, g.d_n);
     const int n = kk - (int)tap * g.N;
     const int jy = JX > 0 ? (int)tap / JX : 0, jx = (int)tap - jy * JX;
+    const int tapoff = (jy * g.OW + jx) * g.N - n;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int oy = qy[i] - jy, ox = qx[i] - jx;
-      const bool ok = kok && ((unsigned)oy < (unsigned)g.OH) && ((unsigned)ox < (unsigned)g.OW);
-      ra[i] = ok ? *reinterpret_cast<const float4*>(p.dy + (size_t)(dybase[i] + (oy * g.OW + ox) * g.N + n))
-                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = kok && ((unsigned)(qy[i] - jy) < (unsigned)g.OH) && ((unsigned)(qx[i] - jx) < (unsigned)g.OW);
+      R.a[i] = load_f4_ok(p.dy, (long long)(rowbase[i] - tapoff), ok);
+      R.ok |= (ok ? 1u : 0u) << i;
     }
-    const int ky = ry + g.S * jy, kx = rx + g.S * jx;
+    const int wbase = ((ry + g.S * jy) * g.KW + rx + g.S * jx) * g.C * g.N + n;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int c = j0 + r0 + 32 * i;
-      rbv[i] = (kok && c < g.C)
-                   ? *reinterpret_cast<const float4*>(p.w + (size_t)(((ky * g.KW + kx) * g.C + c)) * g.N + n)
-                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool okb = kok && ((cok >> i) & 1u);
+      R.b[i] = load_f4_ok(p.w, (long long)(wbase + cN[i]), okb);
+      R.ok |= (okb ? 1u : 0u) << (8 + i);
     }
   };
-  auto stash = [&]() {
+  auto stash = [&](const Regs& R, float* As, float* Bs) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int r = r0 + 32 * i;
-      As[(c4 * 4 + 0) * SA + r] = ra[i].x;
-      As[(c4 * 4 + 1) * SA + r] = ra[i].y;
-      As[(c4 * 4 + 2) * SA + r] = ra[i].z;
-      As[(c4 * 4 + 3) * SA + r] = ra[i].w;
+      const float4 v = sel4((R.ok >> i) & 1u, R.a[i]);
+      As[(c4 * 4 + 0) * SA + r] = v.x;
+      As[(c4 * 4 + 1) * SA + r] = v.y;
+      As[(c4 * 4 + 2) * SA + r] = v.z;
+      As[(c4 * 4 + 3) * SA + r] = v.w;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int r = r0 + 32 * i;
-      Bs[(c4 * 4 + 0) * SB + r] = rbv[i].x;
-      Bs[(c4 * 4 + 1) * SB + r] = rbv[i].y;
-      Bs[(c4 * 4 + 2) * SB + r] = rbv[i].z;
-      Bs[(c4 * 4 + 3) * SB + r] = rbv[i].w;
+      const float4 v = sel4((R.ok >> (8 + i)) & 1u, R.b[i]);
+      Bs[(c4 * 4 + 0) * SB + r] = v.x;
+      Bs[(c4 * 4 + 1) * SB + r] = v.y;
+      Bs[(c4 * 4 + 2) * SB + r] = v.z;
+      Bs[(c4 * 4 + 3) * SB + r] = v.w;
     }
   };
 
@@ -458,13 +585,21 @@ __global__ __launch_bounds__(256) void igemm_dgrad_kernel(const DgradArgs p) {
       for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
 
   const int wi = wave / WJ, wj = wave % WJ;
-  if (Kc > 0) fetch(0);
-  for (int k0 = 0; k0 < Kc; k0 += 32) {
-    stash();
+  const int nsteps = (Kc + 31) / 32;
+  Regs R0, R1;
+  if (nsteps > 0) fetch(0, R0);
+  if (nsteps > 1) fetch(32, R1);
+  for (int s = 0; s < nsteps; s += 2) {
+    stash(R0, smem, smem + 32 * SA);
     __syncthreads();
-    if (k0 + 32 < Kc) fetch(k0 + 32);
-    mma_tile<TI, TJ, SA, SB>(As, Bs, wi * TI * 32, wj * TJ * 32, acc, lane);
-    __syncthreads();
+    if (s + 2 < nsteps) fetch((s + 2) * 32, R0);
+    mma_tile<TI, TJ, SA, SB>(smem, smem + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+    if (s + 1 < nsteps) {
+      stash(R1, smem + BUF, smem + BUF + 32 * SA);
+      __syncthreads();
+      if (s + 3 < nsteps) fetch((s + 3) * 32, R1);
+      mma_tile<TI, TJ, SA, SB>(smem + BUF, smem + BUF + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+    }
   }
   if (Kc == 0) __syncthreads();   // rowOut visibility
 
@@ -486,6 +621,11 @@ __global__ __launch_bounds__(256) void igemm_dgrad_kernel(const DgradArgs p) {
 }
 
 // ------------------------------------------------------------------ host launchers
+// does the receptive field ever leave the image (TF SAME padding)?
+static inline bool is_padded(const Geom& g) {
+  return g.PT > 0 || g.PL > 0 || (g.OH - 1) * g.S - g.PT + g.KH > g.H || (g.OW - 1) * g.S - g.PL + g.KW > g.W;
+}
+
 static inline int pick_ksplit_chunk(int K, int split, int* chunk) {
   int steps = (K + 31) / 32;
   int per = (steps + split - 1) / split;
@@ -506,15 +646,17 @@ int launch_fwd(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const vo
   a.ksplit = ksplit; a.kchunk = chunk;
   a.y = ksplit == 1 ? y : partial;
   const int M = a.g.M, N = a.g.N;
-  if (N <= 32) {
-    dim3 grid((M + 127) / 128, (N + 31) / 32, ksplit);
-    if (u8) hipLaunchKernelGGL((igemm_fwd_kernel<128, 32, 4, 1, true>), grid, dim3(256), 0, st, a);
-    else    hipLaunchKernelGGL((igemm_fwd_kernel<128, 32, 4, 1, false>), grid, dim3(256), 0, st, a);
-  } else {
-    dim3 grid((M + 63) / 64, (N + 63) / 64, ksplit);
-    if (u8) hipLaunchKernelGGL((igemm_fwd_kernel<64, 64, 2, 2, true>), grid, dim3(256), 0, st, a);
-    else    hipLaunchKernelGGL((igemm_fwd_kernel<64, 64, 2, 2, false>), grid, dim3(256), 0, st, a);
-  }
+  const bool pad = is_padded(a.g);
+#define XT_FWD(BI, BJ, WI, WJ)                                                                              \
+  do {                                                                                                      \
+    dim3 grid((M + BI - 1) / BI, (N + BJ - 1) / BJ, ksplit);                                                \
+    if (u8 && pad) hipLaunchKernelGGL((igemm_fwd_kernel<BI, BJ, WI, WJ, true, true>), grid, dim3(256), 0, st, a);    \
+    else if (u8) hipLaunchKernelGGL((igemm_fwd_kernel<BI, BJ, WI, WJ, true, false>), grid, dim3(256), 0, st, a);     \
+    else if (pad) hipLaunchKernelGGL((igemm_fwd_kernel<BI, BJ, WI, WJ, false, true>), grid, dim3(256), 0, st, a);    \
+    else hipLaunchKernelGGL((igemm_fwd_kernel<BI, BJ, WI, WJ, false, false>), grid, dim3(256), 0, st, a);            \
+  } while (0)
+  if (N <= 32) XT_FWD(128, 32, 4, 1); else XT_FWD(64, 64, 2, 2);
+#undef XT_FWD
   XT_LAUNCH_CHECK();
   if (ksplit > 1) {
     const int MN = M * N;
@@ -526,7 +668,8 @@ int launch_fwd(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const vo
 }
 
 int launch_wgrad(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const void* in, const int32_t* idx,
-                 const float* dy, float* dwb, float* slabs, int msplit, hipStream_t st) {
+                 const float* dy, float* dwb, float* slabs, int msplit, hipStream_t st, int reduce_now,
+                 int* msplit_out) {
   WgradArgs a;
   if (int rc = make_geom(cg, xf, B, &a.g)) return rc;
   const bool u8 = xf && xf->is_u8;
@@ -538,17 +681,20 @@ int launch_wgrad(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const 
   a.msplit = msplit; a.mchunk = chunk;
   a.out = msplit == 1 ? dwb : slabs;
   const int K = a.g.K, N = a.g.N;
-  if (N <= 32) {
-    dim3 grid((K + 127) / 128, (N + 31) / 32, msplit);
-    if (u8) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 32, 4, 1, true>), grid, dim3(256), 0, st, a);
-    else    hipLaunchKernelGGL((igemm_wgrad_kernel<128, 32, 4, 1, false>), grid, dim3(256), 0, st, a);
-  } else {
-    dim3 grid((K + 63) / 64, (N + 63) / 64, msplit);
-    if (u8) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 2, 2, true>), grid, dim3(256), 0, st, a);
-    else    hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 2, 2, false>), grid, dim3(256), 0, st, a);
-  }
+  const bool pad = is_padded(a.g);
+#define XT_WG(BI, BJ, WI, WJ)                                                                               \
+  do {                                                                                                      \
+    dim3 grid((K + BI - 1) / BI, (N + BJ - 1) / BJ, msplit);                                                \
+    if (u8 && pad) hipLaunchKernelGGL((igemm_wgrad_kernel<BI, BJ, WI, WJ, true, true>), grid, dim3(256), 0, st, a);  \
+    else if (u8) hipLaunchKernelGGL((igemm_wgrad_kernel<BI, BJ, WI, WJ, true, false>), grid, dim3(256), 0, st, a);   \
+    else if (pad) hipLaunchKernelGGL((igemm_wgrad_kernel<BI, BJ, WI, WJ, false, true>), grid, dim3(256), 0, st, a);  \
+    else hipLaunchKernelGGL((igemm_wgrad_kernel<BI, BJ, WI, WJ, false, false>), grid, dim3(256), 0, st, a);          \
+  } while (0)
+  if (N <= 32) XT_WG(128, 32, 4, 1); else XT_WG(64, 64, 2, 2);
+#undef XT_WG
   XT_LAUNCH_CHECK();
-  if (msplit > 1) {
+  if (msplit_out) *msplit_out = msplit;
+  if (msplit > 1 && reduce_now) {
     const int count = (K + 1) * N;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((count / 4 + 255) / 256), dim3(256), 0, st, slabs, dwb, count, msplit);
     XT_LAUNCH_CHECK();
@@ -586,7 +732,7 @@ int xt_layer_fwd(const xt_conv_geom* g, const xt_input_xform* xf, int32_t B, con
 
 int xt_layer_wgrad(const xt_conv_geom* g, const xt_input_xform* xf, int32_t B, const void* in, const int32_t* idx,
                    const float* dy, float* dwb, float* slabs, int32_t msplit, void* stream) {
-  return xt::launch_wgrad(g, xf, B, in, idx, dy, dwb, slabs, msplit, xt::as_stream(stream));
+  return xt::launch_wgrad(g, xf, B, in, idx, dy, dwb, slabs, msplit, xt::as_stream(stream), 1, nullptr);
 }
 
 int xt_layer_dgrad(const xt_conv_geom* g, int32_t B, const float* dy, const float* w, const float* x,

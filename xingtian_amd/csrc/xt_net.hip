@@ -5,6 +5,7 @@
 #include <vector>
 #include <string>
 #include <string.h>
+#include <stdlib.h>
 
 #include "xt_common.h"
 
@@ -21,9 +22,16 @@ void set_error(const char* fmt, ...) {
 int launch_fwd(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*, const float*,
                const float*, float*, float*, int, hipStream_t);
 int launch_wgrad(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*, const float*,
-                 float*, float*, int, hipStream_t);
+                 float*, float*, int, hipStream_t, int reduce_now = 1, int* msplit_out = nullptr);
 int launch_dgrad(const xt_conv_geom*, int, const float*, const float*, const float*, int, float*, hipStream_t);
 int launch_global_norm(const float*, long long, float, float, float, float, float, int, float*, float*, hipStream_t);
+int launch_grads_finish(GradTable*, float*, int, int*, hipStream_t);
+int launch_norm_finalize(const float*, int, float, float, float, float, float, int, float*, const LossArgs*, hipStream_t);
+int launch_ppo_heads_fused(const PpoHeadArgs&, hipStream_t);
+int launch_heads_dfeat(const float*, const float*, int, int, int, const float*, const float*, const float*,
+                       const float*, int, float*, float*, hipStream_t);
+int launch_heads_wgrad_partial(const float*, const float*, int, int, int, const float*, const float*, float*,
+                               long long, float*, long long, int*, hipStream_t);
 int launch_adam(float*, const float*, float*, float*, long long, float, float, float, const float*, hipStream_t);
 
 struct Layer {
@@ -32,6 +40,8 @@ struct Layer {
   int trunk;
   int K, OHOW;
   int64_t act_off, dact_off;   // floats into the workspace
+  int64_t slab_off;            // this layer's wgrad slabs
+  int last_msplit;
 };
 
 static inline int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
@@ -51,11 +61,17 @@ struct xt_net {
   float* ws = nullptr;
   int64_t ws_floats = 0;
   // workspace carve (float offsets)
-  int64_t off_partial, off_slabs, off_logits, off_value, off_dlogits, off_dvalue, off_terms, off_loss, off_norm;
-  int64_t partial_floats, slab_floats;
+  int64_t off_partial, off_logits, off_value, off_dlogits, off_dvalue, off_terms, off_loss, off_norm;
+  int64_t off_hslab_pi, off_hslab_v, hstride_pi, hstride_v;
+  int64_t partial_floats;
+  int head_chunks = 0, norm_blocks = 0;
   // graph cache for ppo_train
   hipGraphExec_t gexec = nullptr;
   hipStream_t cap_stream = nullptr;   // capture happens on our own stream: the legacy null stream cannot be captured
+  // fork/join: weight-gradient kernels run on side streams next to the dgrad chain (also inside the graph)
+  hipStream_t side[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork[16] = {}, ev_join[2] = {};
+  bool overlap = true;
   std::string gkey;
 };
 
@@ -79,7 +95,7 @@ static int wgrad_split(const Layer& L, int B) {
   return s < 1 ? 1 : s;
 }
 
-static int net_forward(xt_net* n, const void* obs, const int32_t* idx, int B, hipStream_t st) {
+static int net_forward(xt_net* n, const void* obs, const int32_t* idx, int B, bool with_heads, hipStream_t st) {
   for (int tr = 0; tr < n->n_trunks; ++tr) {
     const void* x = obs;
     for (int l = n->t_begin[tr]; l < n->t_end[tr]; ++l) {
@@ -92,6 +108,7 @@ static int net_forward(xt_net* n, const void* obs, const int32_t* idx, int B, hi
       x = n->ws + L.act_off;
     }
   }
+  if (!with_heads) return 0;
   const float* f_pi = n->ws + n->layers[n->t_end[0] - 1].act_off;
   const float* f_v = n->ws + n->layers[n->t_end[n->n_trunks - 1] - 1].act_off;
   const int F = n->feat, A = n->A;
@@ -99,38 +116,128 @@ static int net_forward(xt_net* n, const void* obs, const int32_t* idx, int B, hi
                       n->params + n->v_off, n->params + n->v_off + F, n->ws + n->off_logits, n->ws + n->off_value, st);
 }
 
-// heads backward + trunk backward (dlogits/dvalue already in the workspace)
-static int net_backward(xt_net* n, const void* obs, const int32_t* idx, int B, hipStream_t st) {
-  const int F = n->feat, A = n->A;
+constexpr int kMaxNormPartials = 16384;
+
+static int ensure_side_streams(xt_net* n) {
+  for (auto& sd : n->side) if (!sd) XT_CHECK_HIP(hipStreamCreateWithFlags(&sd, hipStreamNonBlocking));
+  for (auto& e : n->ev_fork) if (!e) XT_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto& e : n->ev_join) if (!e) XT_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return 0;
+}
+
+static int layer_wgrad(xt_net* n, int l, bool first, const void* obs, const int32_t* idx, int B, hipStream_t st) {
+  Layer& L = n->layers[l];
+  const void* x = first ? obs : (const void*)(n->ws + n->layers[l - 1].act_off);
+  return launch_wgrad(&L.g, first ? &n->xf : nullptr, B, x, first ? idx : nullptr, n->ws + L.dact_off,
+                      n->grads + L.poff, n->ws + L.slab_off, wgrad_split(L, B), st, 0, &L.last_msplit);
+}
+
+static int heads_wgrad(xt_net* n, int B, hipStream_t st) {
   Layer& Lp = n->layers[n->t_end[0] - 1];
   Layer& Lv = n->layers[n->t_end[n->n_trunks - 1] - 1];
-  if (int rc = xt_heads_bwd(n->ws + Lp.act_off, n->ws + Lv.act_off, B, F, A, n->params + n->pi_off,
-                            n->params + n->v_off, n->ws + n->off_dlogits, n->ws + n->off_dvalue, Lp.g.act,
-                            n->grads + n->pi_off, n->grads + n->pi_off + (int64_t)F * A, n->grads + n->v_off,
-                            n->grads + n->v_off + F, n->ws + Lp.dact_off, n->ws + Lv.dact_off, st))
-    return rc;
+  return launch_heads_wgrad_partial(n->ws + Lp.act_off, n->ws + Lv.act_off, B, n->feat, n->A, n->ws + n->off_dlogits,
+                                    n->ws + n->off_dvalue, n->ws + n->off_hslab_pi, n->hstride_pi,
+                                    n->ws + n->off_hslab_v, n->hstride_v, &n->head_chunks, st);
+}
+
+// Backward through the trunks once d(features) sits in the last layer's dact.  The dgrad chain
+// (dact[l] -> dact[l-1]) is the critical path and stays on `st`; every weight-gradient kernel except the
+// first layer's only consumes finished tensors, so it is forked onto a side stream as soon as its dY
+// exists and joined before the gradient reduction.  Works eagerly and under stream capture.
+static int trunk_backward(xt_net* n, const void* obs, const int32_t* idx, int B, hipStream_t st) {
+  if (!n->overlap) {
+    if (int rc = heads_wgrad(n, B, st)) return rc;
+    for (int tr = 0; tr < n->n_trunks; ++tr)
+      for (int l = n->t_end[tr] - 1; l >= n->t_begin[tr]; --l) {
+        const bool first = (l == n->t_begin[tr]);
+        if (int rc = layer_wgrad(n, l, first, obs, idx, B, st)) return rc;
+        if (!first) {
+          Layer& L = n->layers[l];
+          Layer& Lprev = n->layers[l - 1];
+          if (int rc = launch_dgrad(&L.g, B, n->ws + L.dact_off, n->params + L.poff, n->ws + Lprev.act_off,
+                                    Lprev.g.act, n->ws + Lprev.dact_off, st))
+            return rc;
+        }
+      }
+    return 0;
+  }
+  if (int rc = ensure_side_streams(n)) return rc;
+  int nev = 0, which = 0;
+  bool used[2] = {false, false};
+  // head weight gradients + last layers' wgrad as soon as d(features) exists
+  XT_CHECK_HIP(hipEventRecord(n->ev_fork[nev], st));
+  XT_CHECK_HIP(hipStreamWaitEvent(n->side[0], n->ev_fork[nev], 0));
+  XT_CHECK_HIP(hipStreamWaitEvent(n->side[1], n->ev_fork[nev], 0));
+  ++nev;
+  used[0] = used[1] = true;
+  if (int rc = heads_wgrad(n, B, n->side[1])) return rc;
   for (int tr = 0; tr < n->n_trunks; ++tr) {
     for (int l = n->t_end[tr] - 1; l >= n->t_begin[tr]; --l) {
-      Layer& L = n->layers[l];
       const bool first = (l == n->t_begin[tr]);
-      const void* x = first ? obs : (const void*)(n->ws + n->layers[l - 1].act_off);
-      if (int rc = launch_wgrad(&L.g, first ? &n->xf : nullptr, B, x, first ? idx : nullptr, n->ws + L.dact_off,
-                                n->grads + L.poff, n->ws + n->off_slabs, wgrad_split(L, B), st))
-        return rc;
-      if (!first) {
+      Layer& L = n->layers[l];
+      if (first) {
+        if (int rc = layer_wgrad(n, l, true, obs, idx, B, st)) return rc;     // biggest kernel: keep on the main stream
+      } else {
+        hipStream_t sd = n->side[which];
+        which ^= 1;
+        if (int rc = layer_wgrad(n, l, false, obs, idx, B, sd)) return rc;
         Layer& Lprev = n->layers[l - 1];
         if (int rc = launch_dgrad(&L.g, B, n->ws + L.dact_off, n->params + L.poff, n->ws + Lprev.act_off,
                                   Lprev.g.act, n->ws + Lprev.dact_off, st))
           return rc;
+        // dact[l-1] is ready: let both side streams see it
+        XT_REQUIRE(nev < 16, "xt_net: too many layers for the fork events");
+        XT_CHECK_HIP(hipEventRecord(n->ev_fork[nev], st));
+        XT_CHECK_HIP(hipStreamWaitEvent(n->side[0], n->ev_fork[nev], 0));
+        XT_CHECK_HIP(hipStreamWaitEvent(n->side[1], n->ev_fork[nev], 0));
+        ++nev;
       }
     }
+  }
+  for (int q = 0; q < 2; ++q) {
+    if (!used[q]) continue;
+    XT_CHECK_HIP(hipEventRecord(n->ev_join[q], n->side[q]));
+    XT_CHECK_HIP(hipStreamWaitEvent(st, n->ev_join[q], 0));
   }
   return 0;
 }
 
-static int net_apply(xt_net* n, float lr, float b1, float b2, float eps, float clip, float gscale, hipStream_t st) {
-  if (int rc = launch_global_norm(n->grads, n->P, clip, gscale, lr, b1, b2, 1, n->state, n->ws + n->off_norm, st))
-    return rc;
+// ONE kernel: every slab reduction (trunk layers + heads) + the squared-norm partials
+static int grads_finish(xt_net* n, int B, hipStream_t st) {
+  const int F = n->feat, A = n->A;
+  GradTable tab;
+  tab.n = 0;
+  XT_REQUIRE(n->layers.size() + 2 <= 12, "xt_net: too many layers for the gradient table");
+  for (auto& L : n->layers) {
+    GradEntry& E = tab.e[tab.n++];
+    E.count = (L.K + 1) * L.g.N;
+    E.dst = n->grads + L.poff;
+    E.nslab = L.last_msplit;
+    E.src = (L.last_msplit > 1) ? n->ws + L.slab_off : E.dst;
+    E.stride = E.count;
+  }
+  {
+    GradEntry& E = tab.e[tab.n++];
+    E.count = F * A + A; E.dst = n->grads + n->pi_off; E.src = n->ws + n->off_hslab_pi;
+    E.nslab = n->head_chunks; E.stride = n->hstride_pi;
+  }
+  {
+    GradEntry& E = tab.e[tab.n++];
+    E.count = F + 1; E.dst = n->grads + n->v_off; E.src = n->ws + n->off_hslab_v;
+    E.nslab = n->head_chunks; E.stride = n->hstride_v;
+  }
+  return launch_grads_finish(&tab, n->ws + n->off_norm, kMaxNormPartials, &n->norm_blocks, st);
+}
+
+static int net_apply(xt_net* n, float lr, float b1, float b2, float eps, float clip, float gscale, bool use_partials,
+                     const LossArgs* la, hipStream_t st) {
+  if (use_partials) {
+    if (int rc = launch_norm_finalize(n->ws + n->off_norm, n->norm_blocks, clip, gscale, lr, b1, b2, 1, n->state, la, st))
+      return rc;
+  } else {
+    if (int rc = launch_global_norm(n->grads, n->P, clip, gscale, lr, b1, b2, 1, n->state, n->ws + n->off_norm, st))
+      return rc;
+  }
   return launch_adam(n->params, n->grads, n->m, n->v, n->P, b1, b2, eps, n->state, st);
 }
 
@@ -139,19 +246,46 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
                     const double* target_v, int apply, float* loss_out, float* loss_acc, hipStream_t st) {
   XT_REQUIRE(n->params && n->ws, "xt_net: buffers not bound (call xt_net_bind)");
   XT_REQUIRE(B > 0 && B <= n->maxB, "xt_net_ppo_step: batch %d outside (0,%d]", B, n->maxB);
-  if (int rc = net_forward(n, obs, idx, B, st)) return rc;
+  if (int rc = net_forward(n, obs, idx, B, false, st)) return rc;
   const float inv_b = 1.f / (float)(c->global_batch > 0 ? c->global_batch : B);
-  if (int rc = xt_ppo_loss(n->ws + n->off_logits, n->ws + n->off_value, B, n->A, idx, action, old_logp, adv, old_v,
-                           target_v, c->clip_ratio, c->ent_coef, c->vf_clip, c->critic_coef, inv_b,
-                           n->ws + n->off_dlogits, n->ws + n->off_dvalue, n->ws + n->off_terms, st))
-    return rc;
+  Layer& Lp = n->layers[n->t_end[0] - 1];
+  Layer& Lv = n->layers[n->t_end[n->n_trunks - 1] - 1];
+  const int F = n->feat, A = n->A;
   float* lo = loss_out ? loss_out : n->ws + n->off_loss;
-  if (int rc = xt_ppo_loss_reduce(n->ws + n->off_terms, B, c->ent_coef, c->critic_coef, inv_b, lo, loss_acc, st))
-    return rc;
-  if (int rc = net_backward(n, obs, idx, B, st)) return rc;
+  if (A <= 64) {
+    PpoHeadArgs h;
+    h.f_pi = n->ws + Lp.act_off; h.f_v = n->ws + Lv.act_off;
+    h.wpi = n->params + n->pi_off; h.bpi = h.wpi + (int64_t)F * A; h.wv = n->params + n->v_off; h.bv = h.wv + F;
+    h.idx = idx; h.action = action; h.old_logp = old_logp; h.old_v = old_v; h.adv = adv; h.target_v = target_v;
+    h.clip_ratio = c->clip_ratio; h.ent_coef = c->ent_coef; h.vf_clip = c->vf_clip; h.critic_coef = c->critic_coef;
+    h.inv_b = inv_b; h.B = B; h.F = F; h.A = A; h.act_prev = Lp.g.act; h.shared = (n->n_trunks == 1);
+    h.logits = n->ws + n->off_logits; h.value = n->ws + n->off_value; h.dlogits = n->ws + n->off_dlogits;
+    h.dvalue = n->ws + n->off_dvalue; h.terms = n->ws + n->off_terms;
+    h.df_pi = n->ws + Lp.dact_off; h.df_v = n->ws + Lv.dact_off;
+    if (int rc = launch_ppo_heads_fused(h, st)) return rc;
+  } else {
+    if (int rc = xt_heads_fwd(n->ws + Lp.act_off, n->ws + Lv.act_off, B, F, A, n->params + n->pi_off,
+                              n->params + n->pi_off + (int64_t)F * A, n->params + n->v_off, n->params + n->v_off + F,
+                              n->ws + n->off_logits, n->ws + n->off_value, st))
+      return rc;
+    if (int rc = xt_ppo_loss(n->ws + n->off_logits, n->ws + n->off_value, B, A, idx, action, old_logp, adv, old_v,
+                             target_v, c->clip_ratio, c->ent_coef, c->vf_clip, c->critic_coef, inv_b,
+                             n->ws + n->off_dlogits, n->ws + n->off_dvalue, n->ws + n->off_terms, st))
+      return rc;
+    if (int rc = launch_heads_dfeat(n->ws + Lp.act_off, n->ws + Lv.act_off, B, F, A, n->params + n->pi_off,
+                                    n->params + n->v_off, n->ws + n->off_dlogits, n->ws + n->off_dvalue, Lp.g.act,
+                                    n->ws + Lp.dact_off, n->ws + Lv.dact_off, st))
+      return rc;
+  }
+  if (int rc = trunk_backward(n, obs, idx, B, st)) return rc;
+  if (int rc = grads_finish(n, B, st)) return rc;
+  LossArgs la;
+  la.terms = n->ws + n->off_terms; la.B = B; la.ent_coef = c->ent_coef; la.critic_coef = c->critic_coef;
+  la.inv_b = inv_b; la.out = lo; la.acc = loss_acc;
   if (apply)
-    return net_apply(n, c->lr, c->beta1, c->beta2, c->eps, c->max_grad_norm, c->grad_scale, st);
-  return 0;
+    return net_apply(n, c->lr, c->beta1, c->beta2, c->eps, c->max_grad_norm, c->grad_scale, true, &la, st);
+  // gradient only (data parallel): still report the local loss
+  return xt_ppo_loss_reduce(n->ws + n->off_terms, B, c->ent_coef, c->critic_coef, inv_b, lo, loss_acc, st);
 }
 
 }  // namespace xt
@@ -170,8 +304,10 @@ int xt_net_create(const xt_net_desc* d, int32_t max_batch, xt_net** out) {
   n->n_trunks = d->n_trunks; n->feat = d->feat; n->A = d->action_dim;
   n->pi_off = d->pi_off; n->v_off = d->v_off; n->P = d->n_params; n->xf = d->xf;
   n->in_h = d->in_h; n->in_w = d->in_w; n->in_c = d->in_c; n->maxB = max_batch;
+  n->overlap = false;   // measured: fork/join inside the hipGraph costs more than it hides (14.7 vs 13.9 ms/update)
+  if (const char* e = getenv("XT_OVERLAP")) n->overlap = (e[0] == '1');
   int64_t off = 0;
-  int64_t max_partial = 4, max_slab = 4;
+  int64_t max_partial = 4;
   int cur = -1;
   for (int i = 0; i < d->n_layers; ++i) {
     xt::Layer L;
@@ -189,8 +325,9 @@ int xt_net_create(const xt_net_desc* d, int32_t max_batch, xt_net** out) {
     n->layers.push_back(L);
     // wgrad slab bound: msplit <= max(1, 512/tiles) slabs of (K+1)*N floats
     const int tiles = (L.g.N <= 32) ? ((L.K + 127) / 128) : ((L.K + 63) / 64) * ((L.g.N + 63) / 64);
-    const int64_t s = (int64_t)((512 / tiles) < 1 ? 1 : (512 / tiles)) * (int64_t)(L.K + 1) * L.g.N;
-    if (s > max_slab) max_slab = s;
+    const int64_t sl = (int64_t)((512 / tiles) < 1 ? 1 : (512 / tiles)) * (int64_t)(L.K + 1) * L.g.N;
+    n->layers.back().slab_off = off; off += xt::align4(sl);
+    n->layers.back().last_msplit = 1;
   }
   if (d->n_trunks == 2 && n->t_begin[1] == 0) {
     delete n;
@@ -198,16 +335,22 @@ int xt_net_create(const xt_net_desc* d, int32_t max_batch, xt_net** out) {
   }
   // fwd split-K partial bound: ksplit*tiles <= 512 and a tile holds 4096 outputs
   max_partial = (int64_t)512 * 4096;
-  n->partial_floats = xt::align4(max_partial); n->slab_floats = xt::align4(max_slab);
+  n->partial_floats = xt::align4(max_partial);
   n->off_partial = off; off += n->partial_floats;
-  n->off_slabs = off; off += n->slab_floats;
+  {
+    const int chunks = (max_batch + 7) / 8;
+    n->hstride_pi = xt::align4((int64_t)n->feat * n->A + n->A);
+    n->hstride_v = xt::align4((int64_t)n->feat + 1);
+    n->off_hslab_pi = off; off += n->hstride_pi * chunks;
+    n->off_hslab_v = off; off += n->hstride_v * chunks;
+  }
   n->off_logits = off; off += xt::align4((int64_t)max_batch * n->A);
   n->off_value = off; off += xt::align4(max_batch);
   n->off_dlogits = off; off += xt::align4((int64_t)max_batch * n->A);
   n->off_dvalue = off; off += xt::align4(max_batch);
   n->off_terms = off; off += xt::align4((int64_t)max_batch * 4);
   n->off_loss = off; off += xt::align4(8 + max_batch);
-  n->off_norm = off; off += 1024;
+  n->off_norm = off; off += xt::kMaxNormPartials;
   n->ws_floats = off;
   *out = n;
   return 0;
@@ -217,6 +360,9 @@ void xt_net_destroy(xt_net* net) {
   if (!net) return;
   if (net->gexec) hipGraphExecDestroy(net->gexec);
   if (net->cap_stream) hipStreamDestroy(net->cap_stream);
+  for (auto& sd : net->side) if (sd) hipStreamDestroy(sd);
+  for (auto& e : net->ev_fork) if (e) hipEventDestroy(e);
+  for (auto& e : net->ev_join) if (e) hipEventDestroy(e);
   delete net;
 }
 
@@ -240,7 +386,7 @@ int xt_net_forward(xt_net* n, const void* obs, const int32_t* idx, int32_t B, fl
   XT_REQUIRE(n && n->params && n->ws, "xt_net_forward: buffers not bound");
   XT_REQUIRE(B > 0 && B <= n->maxB, "xt_net_forward: batch %d outside (0,%d]", B, n->maxB);
   hipStream_t st = xt::as_stream(stream);
-  if (int rc = xt::net_forward(n, obs, idx, B, st)) return rc;
+  if (int rc = xt::net_forward(n, obs, idx, B, true, st)) return rc;
   if (logits) XT_CHECK_HIP(hipMemcpyAsync(logits, n->ws + n->off_logits, sizeof(float) * B * n->A, hipMemcpyDeviceToDevice, st));
   if (value) XT_CHECK_HIP(hipMemcpyAsync(value, n->ws + n->off_value, sizeof(float) * B, hipMemcpyDeviceToDevice, st));
   return 0;
@@ -315,22 +461,32 @@ int xt_net_impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int32
              nfr, T);
   XT_REQUIRE(nfr <= n->maxB, "xt_net_impala_step: %d frames > max batch %d", nfr, n->maxB);
   hipStream_t st = xt::as_stream(stream);
-  if (int rc = xt::net_forward(n, obs, nullptr, nfr, st)) return rc;
+  if (int rc = xt::net_forward(n, obs, nullptr, nfr, true, st)) return rc;
   float* lo = n->ws + n->off_loss;   // needs 4 + n_traj floats
   if (int rc = xt_impala_loss(n->ws + n->off_logits, n->ws + n->off_value, bp_logits, action, done, reward, nfr / T,
                               T, n->A, c->gamma, n->ws + n->off_dlogits, n->ws + n->off_dvalue, lo, loss_acc,
                               nullptr, nullptr, st))
     return rc;
   if (loss_out) XT_CHECK_HIP(hipMemcpyAsync(loss_out, lo, sizeof(float), hipMemcpyDeviceToDevice, st));
-  if (int rc = xt::net_backward(n, obs, nullptr, nfr, st)) return rc;
-  if (apply) return xt::net_apply(n, c->lr, c->beta1, c->beta2, c->eps, c->grad_norm_clip, c->grad_scale, st);
+  {
+    xt::Layer& Lp = n->layers[n->t_end[0] - 1];
+    xt::Layer& Lv = n->layers[n->t_end[n->n_trunks - 1] - 1];
+    if (int rc = xt::launch_heads_dfeat(n->ws + Lp.act_off, n->ws + Lv.act_off, nfr, n->feat, n->A,
+                                        n->params + n->pi_off, n->params + n->v_off, n->ws + n->off_dlogits,
+                                        n->ws + n->off_dvalue, Lp.g.act, n->ws + Lp.dact_off, n->ws + Lv.dact_off, st))
+      return rc;
+  }
+  if (int rc = xt::trunk_backward(n, obs, nullptr, nfr, st)) return rc;
+  if (int rc = xt::grads_finish(n, nfr, st)) return rc;
+  if (apply)
+    return xt::net_apply(n, c->lr, c->beta1, c->beta2, c->eps, c->grad_norm_clip, c->grad_scale, true, nullptr, st);
   return 0;
 }
 
 int xt_net_apply(xt_net* n, float lr, float beta1, float beta2, float eps, float clip_norm, float grad_scale,
                  void* stream) {
   XT_REQUIRE(n && n->params && n->m && n->v && n->state, "xt_net_apply: buffers not bound");
-  return xt::net_apply(n, lr, beta1, beta2, eps, clip_norm, grad_scale, xt::as_stream(stream));
+  return xt::net_apply(n, lr, beta1, beta2, eps, clip_norm, grad_scale, false, nullptr, xt::as_stream(stream));
 }
 
 int xt_net_time_layer(xt_net* n, int32_t layer, int32_t which, const void* obs, const int32_t* idx, int32_t B,
@@ -355,7 +511,7 @@ int xt_net_time_layer(xt_net* n, int32_t layer, int32_t which, const void* obs, 
                             xt::fwd_split(L, B), st);
     if (which == 1)
       return xt::launch_wgrad(&L.g, first ? &n->xf : nullptr, B, x, first ? idx : nullptr, n->ws + L.dact_off,
-                              n->grads + L.poff, n->ws + n->off_slabs, xt::wgrad_split(L, B), st);
+                              n->grads + L.poff, n->ws + L.slab_off, xt::wgrad_split(L, B), st, 0, &L.last_msplit);
     xt::Layer& Lp = n->layers[layer - 1];
     return xt::launch_dgrad(&L.g, B, n->ws + L.dact_off, n->params + L.poff, n->ws + Lp.act_off, Lp.g.act,
                             n->ws + Lp.dact_off, st);

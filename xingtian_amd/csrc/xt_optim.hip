@@ -8,6 +8,62 @@ namespace xt {
 
 constexpr int kNormBlocks = 512;   // partial sums; scratch must hold >= kNormBlocks floats
 
+__global__ __launch_bounds__(256) void grads_finish_kernel(const GradTable tab, float* __restrict__ partial) {
+  __shared__ float4 sh4[256];
+  __shared__ float shs[256];
+  int ei = 0;
+  for (int q = 1; q < tab.n; ++q)
+    if ((int)blockIdx.x >= tab.e[q].blk0) ei = q;
+  const GradEntry& E = tab.e[ei];
+  const int zl = E.zl, cols = 256 / zl;
+  const int t = threadIdx.x, col = t % cols, z0 = t / cols;
+  const int e0 = ((blockIdx.x - E.blk0) * cols + col) * 4;
+  const bool active = e0 < E.count;
+  const bool full = e0 + 3 < E.count;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active) {
+    for (int z = z0; z < E.nslab; z += zl) {
+      const float* sp = E.src + (size_t)z * E.stride + e0;
+      if (full) {
+        const float4 q = *reinterpret_cast<const float4*>(sp);
+        a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+      } else {
+        a.x += sp[0];
+        if (e0 + 1 < E.count) a.y += sp[1];
+        if (e0 + 2 < E.count) a.z += sp[2];
+      }
+    }
+  }
+  sh4[t] = a;
+  __syncthreads();
+  float sq = 0.f;
+  if (z0 == 0 && active) {
+    float4 r = sh4[col];
+    for (int z = 1; z < zl; ++z) {
+      const float4 q = sh4[z * cols + col];
+      r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+    }
+    float* dp = E.dst + e0;
+    if (full) {
+      if (E.nslab > 1 || E.src != E.dst) *reinterpret_cast<float4*>(dp) = r;
+      sq = r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
+    } else {
+      const bool wr = (E.nslab > 1 || E.src != E.dst);
+      if (wr) dp[0] = r.x;
+      sq = r.x * r.x;
+      if (e0 + 1 < E.count) { if (wr) dp[1] = r.y; sq += r.y * r.y; }
+      if (e0 + 2 < E.count) { if (wr) dp[2] = r.z; sq += r.z * r.z; }
+    }
+  }
+  shs[t] = sq;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) shs[t] += shs[t + o];
+    __syncthreads();
+  }
+  if (t == 0) partial[blockIdx.x] = shs[0];
+}
+
 __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, long long count,
                                                              float* __restrict__ partial) {
   __shared__ float sh[256];
@@ -33,8 +89,34 @@ __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __rest
 // state: [0]=b1^t [1]=b2^t [2]=scale [3]=alpha [4]=gnorm [5]=step
 __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restrict__ partial, int nblocks, float clip_norm,
                                                             float grad_scale, float lr, float beta1, float beta2,
-                                                            int advance, float* __restrict__ state) {
+                                                            int advance, float* __restrict__ state, LossArgs la) {
   __shared__ double sh[256];
+  if (la.terms) {   // PPO loss scalars from the per-sample terms (fixed-order tree), xt/model/ppo/__init__.py
+    double t3[3] = {0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < la.B; b += 256) {
+      t3[0] += (double)la.terms[(size_t)b * 4 + 0];
+      t3[1] += (double)la.terms[(size_t)b * 4 + 1];
+      t3[2] += (double)la.terms[(size_t)b * 4 + 2];
+    }
+    double tot[3];
+    for (int q = 0; q < 3; ++q) {
+      sh[threadIdx.x] = t3[q];
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+      }
+      tot[q] = sh[0];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      const float surr = (float)tot[0] * la.inv_b, ent = (float)tot[1] * la.inv_b, vf = 0.5f * (float)tot[2] * la.inv_b;
+      const float actor = -surr - la.ent_coef * ent;
+      const float loss = actor + la.critic_coef * vf;
+      if (la.out) { la.out[0] = loss; la.out[1] = actor; la.out[2] = vf; la.out[3] = ent; }
+      if (la.acc) { la.acc[0] += loss; la.acc[1] += 1.f; }
+    }
+  }
   double s = 0.0;
   for (int i = threadIdx.x; i < nblocks; i += 256) s += (double)partial[i];
   sh[threadIdx.x] = s;
@@ -98,6 +180,38 @@ __global__ void adam_state_init_kernel(float* state) {
   if (threadIdx.x < 8) state[threadIdx.x] = (threadIdx.x < 2) ? 1.f : 0.f;
 }
 
+// entries: blk0/nblk/zl are filled here.  partial needs room for the returned block count.
+int launch_grads_finish(GradTable* tab, float* partial, int max_partials, int* nblocks_out, hipStream_t st) {
+  int blk = 0;
+  for (int i = 0; i < tab->n; ++i) {
+    GradEntry& E = tab->e[i];
+    int zl = 1;
+    while (zl < E.nslab && zl < 32) zl <<= 1;
+    E.zl = zl;
+    const int cols = 256 / zl;
+    E.blk0 = blk;
+    E.nblk = ((E.count + 3) / 4 + cols - 1) / cols;
+    blk += E.nblk;
+    XT_REQUIRE((((uintptr_t)E.src | (uintptr_t)E.dst) & 15) == 0 && (E.stride % 4) == 0,
+               "grads_finish: entry %d not 16-byte aligned", i);
+  }
+  XT_REQUIRE(blk > 0 && blk <= max_partials, "grads_finish: %d partial blocks > scratch %d", blk, max_partials);
+  hipLaunchKernelGGL(grads_finish_kernel, dim3(blk), dim3(256), 0, st, *tab, partial);
+  XT_LAUNCH_CHECK();
+  *nblocks_out = blk;
+  return 0;
+}
+
+int launch_norm_finalize(const float* partial, int nblocks, float clip_norm, float grad_scale, float lr, float beta1,
+                         float beta2, int advance, float* state, const LossArgs* la, hipStream_t st) {
+  LossArgs l;
+  if (la) l = *la; else { l.terms = nullptr; l.B = 0; l.ent_coef = l.critic_coef = l.inv_b = 0.f; l.out = l.acc = nullptr; }
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblocks, clip_norm, grad_scale, lr, beta1,
+                     beta2, advance, state, l);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_global_norm(const float* grad, long long count, float clip_norm, float grad_scale, float lr, float beta1,
                        float beta2, int advance, float* state, float* scratch, hipStream_t st) {
   XT_REQUIRE(count > 0 && grad && state && scratch, "global_norm: bad arguments");
@@ -107,10 +221,7 @@ int launch_global_norm(const float* grad, long long count, float clip_norm, floa
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nb), dim3(256), 0, st, grad, count, scratch);
   XT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, nb, clip_norm, grad_scale, lr, beta1,
-                     beta2, advance, state);
-  XT_LAUNCH_CHECK();
-  return 0;
+  return launch_norm_finalize(scratch, nb, clip_norm, grad_scale, lr, beta1, beta2, advance, state, nullptr, st);
 }
 
 int launch_adam(float* param, const float* grad, float* m, float* v, long long count, float beta1, float beta2,
