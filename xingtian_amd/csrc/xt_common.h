@@ -89,6 +89,21 @@ struct PpoHeadArgs {
   float clip_ratio, ent_coef, vf_clip, critic_coef, inv_b;
   int B, F, A, act_prev, shared;
   float *logits, *value, *dlogits, *dvalue, *terms, *df_pi, *df_v;
+  // deferred split-K finish of the last trunk layer(s): feature = act(sum_z part[z] + bias); written to
+  // feat_*_w (the layer's activation buffer) by this kernel.  part_* == nullptr -> features are final already.
+  const float *part_pi, *part_v, *tbias_pi, *tbias_v;
+  float *feat_pi_w, *feat_v_w;
+  int ksplit_pi, ksplit_v, act_feat;
+  long long part_stride;
+};
+
+// norm finalisation executed by the last block of grads_finish_kernel (ticket counter)
+struct FinalizeArgs {
+  int enable;
+  unsigned int* counter;     // zero before the first launch; the last block resets it
+  float clip_norm, grad_scale, lr, beta1, beta2;
+  float* state;
+  LossArgs loss;
 };
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

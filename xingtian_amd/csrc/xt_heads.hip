@@ -1,6 +1,7 @@
 // Policy/value heads, PPO and IMPALA(v-trace) losses and their gradients, GAE.
 // All HBM/latency-bound; wave64 shuffles for the reductions, no atomics (deterministic).
 #include "xt_common.h"
+#include "xt_heads_dev.h"
 
 namespace xt {
 
@@ -298,11 +299,41 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// feature[f] = act(sum_z part[z][row+f] + bias[f]) for f = lane, lane+64, ...: 8 slabs in flight per f
+// (clamped unconditional loads; the fixed summation order z = 0..ksplit-1 in groups of 8 is deterministic)
+__device__ __forceinline__ void sum_partials(const float* __restrict__ part, int ksplit, long long stride, size_t row,
+                                             int F, int lane, const float* __restrict__ bias, int act,
+                                             float* __restrict__ out) {
+  for (int f = lane; f < F; f += 64) {
+    float s = 0.f;
+    for (int z0 = 0; z0 < ksplit; z0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int z = z0 + q;
+        const float x = part[(size_t)(z < ksplit ? z : ksplit - 1) * stride + row + f];
+        v[q] = z < ksplit ? x : 0.f;
+      }
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    out[f] = act_apply(s + bias[f], act);
+  }
+}
+
 __global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const PpoHeadArgs p) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= p.B) return;
   const int F = p.F, A = p.A;
+  if (p.part_pi) {      // split-K finish of the pi/shared trunk's last layer, fused here
+    sum_partials(p.part_pi, p.ksplit_pi, p.part_stride, (size_t)b * F, F, lane, p.tbias_pi, p.act_feat,
+                 p.feat_pi_w + (size_t)b * F);
+  }
+  if (p.part_v) {
+    sum_partials(p.part_v, p.ksplit_v, p.part_stride, (size_t)b * F, F, lane, p.tbias_v, p.act_feat,
+                 p.feat_v_w + (size_t)b * F);
+  }
+  // each lane re-reads only feature elements it wrote itself (same f striding) -> program order suffices
   const float* fp = p.f_pi + (size_t)b * F;
   const float* fv = p.f_v + (size_t)b * F;
   float mylogit = -INFINITY;
@@ -372,61 +403,10 @@ __global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const PpoHeadArgs 
   }
 }
 
-// head weight-gradient partial slabs: grid (ceil(F/64), nchunk); chunk = 8 samples.
-// slab_pi[chunk][F*A + A], slab_v[chunk][F + 1] (strides passed), summed by grads_finish_kernel.
-__global__ __launch_bounds__(256) void heads_wgrad_partial_kernel(const float* __restrict__ f_pi, const float* __restrict__ f_v,
-                                                                  int B, int F, int A, const float* __restrict__ dlogits,
-                                                                  const float* __restrict__ dvalue, float* __restrict__ slab_pi,
-                                                                  long long stride_pi, float* __restrict__ slab_v,
-                                                                  long long stride_v) {
-  __shared__ float red[4][64][9];
-  const int fl = threadIdx.x & 63, bg = threadIdx.x >> 6;
-  const int f = blockIdx.x * 64 + fl;
-  const bool fok = f < F;
-  const int b0 = blockIdx.y * 8;
-  float* spi = slab_pi + (size_t)blockIdx.y * stride_pi;
-  float* svp = slab_v + (size_t)blockIdx.y * stride_v;
-  for (int a0 = 0; a0 <= A; a0 += 8) {
-    float acc[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int b = b0 + bg + 4 * r;
-      if (b < B) {
-        const float xp = fok ? f_pi[(size_t)b * F + f] : 0.f;
-        const float xv = fok ? f_v[(size_t)b * F + f] : 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int a = a0 + q;
-          if (a < A) acc[q] = fmaf(xp, dlogits[(size_t)b * A + a], acc[q]);
-          else if (a == A) acc[q] = fmaf(xv, dvalue[b], acc[q]);
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) red[bg][fl][q] = acc[q];
-    __syncthreads();
-    if (bg == 0 && fok) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int a = a0 + q;
-        const float s = red[0][fl][q] + red[1][fl][q] + red[2][fl][q] + red[3][fl][q];
-        if (a < A) spi[(size_t)f * A + a] = s;
-        else if (a == A) svp[f] = s;
-      }
-    }
-    __syncthreads();
-  }
-  if (blockIdx.x == 0 && (int)threadIdx.x <= A) {
-    const int a = threadIdx.x;
-    float s = 0.f;
-    for (int r = 0; r < 8; ++r) {
-      const int b = b0 + r;
-      if (b < B) s += (a < A) ? dlogits[(size_t)b * A + a] : dvalue[b];
-    }
-    if (a < A) spi[(size_t)F * A + a] = s; else svp[F] = s;
-  }
+// head weight-gradient partial slabs: grid (ceil(F/64), nchunk); body in xt_heads_dev.h
+__global__ __launch_bounds__(256) void heads_wgrad_partial_kernel(const HeadWgArgs h) {
+  __shared__ float smem[4 * 64 * 9];
+  heads_wgrad_partial_body(h, blockIdx.x, blockIdx.y, smem);
 }
 
 int launch_ppo_heads_fused(const PpoHeadArgs& a, hipStream_t st) {
@@ -450,8 +430,10 @@ int launch_heads_wgrad_partial(const float* f_pi, const float* f_v, int B, int F
                                const float* dvalue, float* slab_pi, long long stride_pi, float* slab_v,
                                long long stride_v, int* nchunk_out, hipStream_t st) {
   const int nchunk = (B + 7) / 8;
-  hipLaunchKernelGGL(heads_wgrad_partial_kernel, dim3((F + 63) / 64, nchunk), dim3(256), 0, st, f_pi, f_v, B, F, A,
-                     dlogits, dvalue, slab_pi, stride_pi, slab_v, stride_v);
+  HeadWgArgs h;
+  h.f_pi = f_pi; h.f_v = f_v; h.dlogits = dlogits; h.dvalue = dvalue; h.slab_pi = slab_pi; h.slab_v = slab_v;
+  h.stride_pi = stride_pi; h.stride_v = stride_v; h.B = B; h.F = F; h.A = A; h.gx = (F + 63) / 64; h.nchunk = nchunk;
+  hipLaunchKernelGGL(heads_wgrad_partial_kernel, dim3(h.gx, nchunk), dim3(256), 0, st, h);
   XT_LAUNCH_CHECK();
   *nchunk_out = nchunk;
   return 0;

@@ -17,6 +17,7 @@
 // Replaces the TensorFlow Conv2D/Dense forward+backward ops the reference runs inside
 // sess.run (xt/model/ppo/ppo.py:129, xt/model/impala/impala_cnn_opt.py:255).
 #include "xt_common.h"
+#include "xt_heads_dev.h"
 
 namespace xt {
 
@@ -314,21 +315,24 @@ constexpr long long kRowInvalid = -(1ll << 62);
 // Each thread owns a fixed group of 4 k's (its (ky,kx,c) offset is computed once); the rows of the block's
 // m-range are decoded once into an LDS table (base offset [+ coordinates when PADDED]), so a reduction step
 // costs one ds_read + one 64-bit add per row.
+template <int BI, int BJ, bool PADDED>
+constexpr int wgrad_smem_floats() { return 2 * (32 * BI + 32 * BJ) + 2 * kRowTab + (PADDED ? kRowTab : 0); }
+
 template <int BI, int BJ, int WI, int WJ, bool U8, bool PADDED>
-__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs p) {
+__device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int bx, const int by, const int bz,
+                                                 float* smem) {
   constexpr int TI = BI / (32 * WI), TJ = BJ / (32 * WJ);
   constexpr int SA = BI, SB = BJ;
   constexpr int CPRA = BI / 4, RPA = 256 / CPRA, NA = 32 / RPA;
   constexpr int CPRB = BJ / 4, RPB = 256 / CPRB, NB = 32 / RPB;
   constexpr int RG = 256 / BJ;           // row groups for the bias column sums
   constexpr int BUF = 32 * SA + 32 * SB;
-  __shared__ __attribute__((aligned(16))) float smem[2 * BUF + 2 * kRowTab + (PADDED ? kRowTab : 0)];
   long long* rowtab = reinterpret_cast<long long*>(smem + 2 * BUF);
   int* rowxy = reinterpret_cast<int*>(smem + 2 * BUF + 2 * kRowTab);
   const Geom& g = p.g;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int i0 = blockIdx.x * BI, j0 = blockIdx.y * BJ;     // i = k, j = n
-  const int mbeg = blockIdx.z * p.mchunk;
+  const int i0 = bx * BI, j0 = by * BJ;     // i = k, j = n
+  const int mbeg = bz * p.mchunk;
   const int mend = min(g.M, mbeg + p.mchunk);
 
   // this thread's fixed k group
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs p) {
       for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
 
   const int wi = wave / WJ, wj = wave % WJ;
-  const bool do_bias = (blockIdx.x == 0);
+  const bool do_bias = (bx == 0);
   const int bcol = t % BJ, brg = t / BJ;
   float bsum = 0.f;
 
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs p) {
     __syncthreads();   // row table and LDS stages are reused by the next sub-range
   }
 
-  float* out = p.out + (size_t)blockIdx.z * ((size_t)(g.K + 1) * g.N);
+  float* out = p.out + (size_t)bz * ((size_t)(g.K + 1) * g.N);
 #pragma unroll
   for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
@@ -453,6 +457,12 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs p) {
       if (n < g.N) out[(size_t)g.K * g.N + n] = sum;
     }
   }
+}
+
+template <int BI, int BJ, int WI, int WJ, bool U8, bool PADDED>
+__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[wgrad_smem_floats<BI, BJ, PADDED>()];
+  igemm_wgrad_body<BI, BJ, WI, WJ, U8, PADDED>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 // dst[e] = sum_z src[z][e]
@@ -478,24 +488,27 @@ struct DgradArgs {
   int act_prev;
 };
 
+template <int BI, int BJ>
+constexpr int dgrad_smem_floats() { return 2 * (32 * (BI + 1) + 32 * (BJ + 1)) + BI; }
+
 template <int BI, int BJ, int WI, int WJ>
-__global__ __launch_bounds__(256) void igemm_dgrad_kernel(const DgradArgs p) {
+__device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int bx, const int by, const int bz,
+                                                 float* smem) {
   constexpr int TI = BI / (32 * WI), TJ = BJ / (32 * WJ);
   constexpr int SA = BI + 1, SB = BJ + 1;
   constexpr int NA = BI / 32, NB = BJ / 32;
   constexpr int BUF = 32 * SA + 32 * SB;
-  __shared__ __attribute__((aligned(16))) float smem[2 * BUF + BI];
   int* rowOut = reinterpret_cast<int*>(smem + 2 * BUF);
   const Geom& g = p.g;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
   // stride-parity class of this block
-  const int ry = blockIdx.z / g.S, rx = blockIdx.z % g.S;
+  const int ry = bz / g.S, rx = bz % g.S;
   const int cy0 = ((ry - g.PT) % g.S + g.S) % g.S, cx0 = ((rx - g.PL) % g.S + g.S) % g.S;
   const int HC = cy0 < g.H ? (g.H - cy0 + g.S - 1) / g.S : 0;
   const int WC = cx0 < g.W ? (g.W - cx0 + g.S - 1) / g.S : 0;
   const int Mc = g.B * HC * WC;
-  const int i0 = blockIdx.x * BI, j0 = blockIdx.y * BJ;      // i = class pixel, j = input channel
+  const int i0 = bx * BI, j0 = by * BJ;      // i = class pixel, j = input channel
   if (i0 >= Mc) return;
   const int JY = ry < g.KH ? (g.KH - ry + g.S - 1) / g.S : 0;
   const int JX = rx < g.KW ? (g.KW - rx + g.S - 1) / g.S : 0;
@@ -620,6 +633,46 @@ __global__ __launch_bounds__(256) void igemm_dgrad_kernel(const DgradArgs p) {
     }
 }
 
+template <int BI, int BJ, int WI, int WJ>
+__global__ __launch_bounds__(256) void igemm_dgrad_kernel(const DgradArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[dgrad_smem_floats<BI, BJ>()];
+  igemm_dgrad_body<BI, BJ, WI, WJ>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// ------------------------------------------------------------------ fused backward of one layer
+// One launch = weight-gradient blocks + input-gradient blocks (+ the head weight-gradient blocks for the
+// last trunk layer).  All three only consume d(pre-activation) of this layer, so running them side by side
+// removes two dependent-launch start-ups per layer and fills the CUs that a single short kernel leaves idle.
+struct BwdLayerArgs {
+  WgradArgs wg;
+  DgradArgs dg;
+  HeadWgArgs hw;
+  int wg_gx, wg_gy, wg_gz;   // wgrad grid
+  int dg_gx, dg_gy, dg_gz;   // dgrad grid
+  int n_wg, n_dg, n_hw;      // block counts (n_hw may be 0)
+};
+
+template <int WBI, int WBJ, int WWI, int WWJ, bool WPAD, int DBI, int DBJ, int DWI, int DWJ>
+__global__ __launch_bounds__(256) void igemm_bwd_layer_kernel(const BwdLayerArgs p) {
+  constexpr int SM = wgrad_smem_floats<WBI, WBJ, WPAD>() > dgrad_smem_floats<DBI, DBJ>()
+                         ? wgrad_smem_floats<WBI, WBJ, WPAD>() : dgrad_smem_floats<DBI, DBJ>();
+  __shared__ __attribute__((aligned(16))) float smem[SM];
+  int b = blockIdx.x;
+  if (b < p.n_dg) {                       // dgrad first: it is on the critical path of the next layer
+    const int bx = b % p.dg_gx, r = b / p.dg_gx;
+    igemm_dgrad_body<DBI, DBJ, DWI, DWJ>(p.dg, bx, r % p.dg_gy, r / p.dg_gy, smem);
+    return;
+  }
+  b -= p.n_dg;
+  if (b < p.n_wg) {
+    const int bx = b % p.wg_gx, r = b / p.wg_gx;
+    igemm_wgrad_body<WBI, WBJ, WWI, WWJ, false, WPAD>(p.wg, bx, r % p.wg_gy, r / p.wg_gy, smem);
+    return;
+  }
+  b -= p.n_wg;
+  heads_wgrad_partial_body(p.hw, b % p.hw.gx, b / p.hw.gx, smem);
+}
+
 // ------------------------------------------------------------------ host launchers
 // does the receptive field ever leave the image (TF SAME padding)?
 static inline bool is_padded(const Geom& g) {
@@ -634,7 +687,8 @@ static inline int pick_ksplit_chunk(int K, int split, int* chunk) {
 }
 
 int launch_fwd(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const void* in, const int32_t* idx,
-               const float* w, const float* bias, float* y, float* partial, int ksplit, hipStream_t st) {
+               const float* w, const float* bias, float* y, float* partial, int ksplit, hipStream_t st,
+               int* deferred_ksplit) {
   FwdArgs a;
   if (int rc = make_geom(cg, xf, B, &a.g)) return rc;
   const bool u8 = xf && xf->is_u8;
@@ -658,7 +712,8 @@ int launch_fwd(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const vo
   if (N <= 32) XT_FWD(128, 32, 4, 1); else XT_FWD(64, 64, 2, 2);
 #undef XT_FWD
   XT_LAUNCH_CHECK();
-  if (ksplit > 1) {
+  if (deferred_ksplit) *deferred_ksplit = ksplit;     // caller sums the partials itself (fused head kernel)
+  if (ksplit > 1 && !deferred_ksplit) {
     const int MN = M * N;
     hipLaunchKernelGGL(splitk_finish_kernel, dim3((MN / 4 + 255) / 256), dim3(256), 0, st,
                        partial, bias, y, MN, N, ksplit, a.g.act);
@@ -721,13 +776,66 @@ int launch_dgrad(const xt_conv_geom* cg, int B, const float* dy, const float* w,
   return 0;
 }
 
+// wgrad (fp32 input) + dgrad (+ head wgrad) of one non-first layer in ONE launch.
+int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const float* dy, const float* w,
+                     int act_prev, float* dx, float* dwb, float* slabs, int msplit, const HeadWgArgs* hw,
+                     int* msplit_out, hipStream_t st) {
+  BwdLayerArgs a;
+  if (int rc = make_geom(cg, nullptr, B, &a.wg.g)) return rc;
+  a.dg.g = a.wg.g;
+  const Geom& g = a.wg.g;
+  // ---- wgrad part
+  a.wg.in = x_in; a.wg.idx = nullptr; a.wg.dy = dy;
+  if (msplit < 1) msplit = 1;
+  int chunk;
+  msplit = pick_ksplit_chunk(g.M, msplit, &chunk);
+  XT_REQUIRE(msplit == 1 || slabs != nullptr, "bwd_layer: msplit>1 needs a slab buffer");
+  a.wg.msplit = msplit; a.wg.mchunk = chunk;
+  a.wg.out = msplit == 1 ? dwb : slabs;
+  if (msplit_out) *msplit_out = msplit;
+  const bool wsmall = g.N <= 32;
+  a.wg_gx = wsmall ? (g.K + 127) / 128 : (g.K + 63) / 64;
+  a.wg_gy = wsmall ? (g.N + 31) / 32 : (g.N + 63) / 64;
+  a.wg_gz = msplit;
+  a.n_wg = a.wg_gx * a.wg_gy * a.wg_gz;
+  // ---- dgrad part
+  a.dg.dy = dy; a.dg.w = w; a.dg.x = x_in; a.dg.dx = dx; a.dg.act_prev = act_prev;
+  const int hc = (g.H + g.S - 1) / g.S, wc = (g.W + g.S - 1) / g.S;
+  const int mc = B * hc * wc;
+  const bool dsmall = g.C <= 32;
+  a.dg_gx = dsmall ? (mc + 127) / 128 : (mc + 63) / 64;
+  a.dg_gy = dsmall ? (g.C + 31) / 32 : (g.C + 63) / 64;
+  a.dg_gz = g.S * g.S;
+  a.n_dg = a.dg_gx * a.dg_gy * a.dg_gz;
+  // ---- head wgrad part
+  a.n_hw = 0;
+  if (hw) { a.hw = *hw; a.n_hw = hw->gx * hw->nchunk; }
+  else { a.hw.gx = 1; a.hw.nchunk = 0; }
+  const int total = a.n_wg + a.n_dg + a.n_hw;
+  const bool pad = is_padded(g);
+#define XT_BWD(WBI, WBJ, WWI, WWJ, DBI, DBJ, DWI, DWJ)                                                          \
+  do {                                                                                                          \
+    if (pad) hipLaunchKernelGGL((igemm_bwd_layer_kernel<WBI, WBJ, WWI, WWJ, true, DBI, DBJ, DWI, DWJ>),         \
+                                dim3(total), dim3(256), 0, st, a);                                              \
+    else hipLaunchKernelGGL((igemm_bwd_layer_kernel<WBI, WBJ, WWI, WWJ, false, DBI, DBJ, DWI, DWJ>),            \
+                            dim3(total), dim3(256), 0, st, a);                                                  \
+  } while (0)
+  if (wsmall && dsmall) XT_BWD(128, 32, 4, 1, 128, 32, 4, 1);
+  else if (wsmall) XT_BWD(128, 32, 4, 1, 64, 64, 2, 2);
+  else if (dsmall) XT_BWD(64, 64, 2, 2, 128, 32, 4, 1);
+  else XT_BWD(64, 64, 2, 2, 64, 64, 2, 2);
+#undef XT_BWD
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace xt
 
 extern "C" {
 
 int xt_layer_fwd(const xt_conv_geom* g, const xt_input_xform* xf, int32_t B, const void* in, const int32_t* idx,
                  const float* w, const float* bias, float* y, float* partial, int32_t ksplit, void* stream) {
-  return xt::launch_fwd(g, xf, B, in, idx, w, bias, y, partial, ksplit, xt::as_stream(stream));
+  return xt::launch_fwd(g, xf, B, in, idx, w, bias, y, partial, ksplit, xt::as_stream(stream), nullptr);
 }
 
 int xt_layer_wgrad(const xt_conv_geom* g, const xt_input_xform* xf, int32_t B, const void* in, const int32_t* idx,

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 
 #include "xt_common.h"
+#include "xt_heads_dev.h"
 
 namespace xt {
 
@@ -20,12 +21,14 @@ void set_error(const char* fmt, ...) {
 }
 
 int launch_fwd(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*, const float*,
-               const float*, float*, float*, int, hipStream_t);
+               const float*, float*, float*, int, hipStream_t, int* deferred_ksplit = nullptr);
+int launch_bwd_layer(const xt_conv_geom*, int, const float*, const float*, const float*, int, float*, float*, float*,
+                     int, const HeadWgArgs*, int*, hipStream_t);
 int launch_wgrad(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*, const float*,
                  float*, float*, int, hipStream_t, int reduce_now = 1, int* msplit_out = nullptr);
 int launch_dgrad(const xt_conv_geom*, int, const float*, const float*, const float*, int, float*, hipStream_t);
 int launch_global_norm(const float*, long long, float, float, float, float, float, int, float*, float*, hipStream_t);
-int launch_grads_finish(GradTable*, float*, int, int*, hipStream_t);
+int launch_grads_finish(GradTable*, float*, int, int*, const FinalizeArgs*, hipStream_t);
 int launch_norm_finalize(const float*, int, float, float, float, float, float, int, float*, const LossArgs*, hipStream_t);
 int launch_ppo_heads_fused(const PpoHeadArgs&, hipStream_t);
 int launch_heads_dfeat(const float*, const float*, int, int, int, const float*, const float*, const float*,
@@ -41,7 +44,8 @@ struct Layer {
   int K, OHOW;
   int64_t act_off, dact_off;   // floats into the workspace
   int64_t slab_off;            // this layer's wgrad slabs
-  int last_msplit;
+  int64_t part_off;            // split-K partials of a trunk's last layer (deferred finish), else -1
+  int last_msplit, last_ksplit;
 };
 
 static inline int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
@@ -61,6 +65,7 @@ struct xt_net {
   float* ws = nullptr;
   int64_t ws_floats = 0;
   // workspace carve (float offsets)
+  int64_t off_counter;
   int64_t off_partial, off_logits, off_value, off_dlogits, off_dvalue, off_terms, off_loss, off_norm;
   int64_t off_hslab_pi, off_hslab_v, hstride_pi, hstride_v;
   int64_t partial_floats;
@@ -95,15 +100,21 @@ static int wgrad_split(const Layer& L, int B) {
   return s < 1 ? 1 : s;
 }
 
-static int net_forward(xt_net* n, const void* obs, const int32_t* idx, int B, bool with_heads, hipStream_t st) {
+// defer_last: leave the split-K partials of every trunk's LAST layer un-finished (the fused PPO head kernel
+// sums them); each such layer has its own partial region.
+static int net_forward(xt_net* n, const void* obs, const int32_t* idx, int B, bool with_heads, hipStream_t st,
+                       bool defer_last = false) {
   for (int tr = 0; tr < n->n_trunks; ++tr) {
     const void* x = obs;
     for (int l = n->t_begin[tr]; l < n->t_end[tr]; ++l) {
       Layer& L = n->layers[l];
       const bool first = (l == n->t_begin[tr]);
+      const bool defer = defer_last && (l == n->t_end[tr] - 1) && L.part_off >= 0;
+      L.last_ksplit = 1;
       if (int rc = launch_fwd(&L.g, first ? &n->xf : nullptr, B, x, first ? idx : nullptr, n->params + L.poff,
                               n->params + L.poff + (int64_t)L.K * L.g.N, n->ws + L.act_off,
-                              n->ws + n->off_partial, fwd_split(L, B), st))
+                              n->ws + (defer ? L.part_off : n->off_partial), fwd_split(L, B), st,
+                              defer ? &L.last_ksplit : nullptr))
         return rc;
       x = n->ws + L.act_off;
     }
@@ -146,18 +157,36 @@ static int heads_wgrad(xt_net* n, int B, hipStream_t st) {
 // exists and joined before the gradient reduction.  Works eagerly and under stream capture.
 static int trunk_backward(xt_net* n, const void* obs, const int32_t* idx, int B, hipStream_t st) {
   if (!n->overlap) {
-    if (int rc = heads_wgrad(n, B, st)) return rc;
+    // one launch per non-first layer: dgrad + wgrad (+ the head weight gradients with the very first one)
+    bool heads_done = false;
     for (int tr = 0; tr < n->n_trunks; ++tr)
       for (int l = n->t_end[tr] - 1; l >= n->t_begin[tr]; --l) {
         const bool first = (l == n->t_begin[tr]);
-        if (int rc = layer_wgrad(n, l, first, obs, idx, B, st)) return rc;
-        if (!first) {
-          Layer& L = n->layers[l];
-          Layer& Lprev = n->layers[l - 1];
-          if (int rc = launch_dgrad(&L.g, B, n->ws + L.dact_off, n->params + L.poff, n->ws + Lprev.act_off,
-                                    Lprev.g.act, n->ws + Lprev.dact_off, st))
-            return rc;
+        Layer& L = n->layers[l];
+        if (first) {
+          if (!heads_done) { if (int rc = heads_wgrad(n, B, st)) return rc; heads_done = true; }
+          if (int rc = layer_wgrad(n, l, true, obs, idx, B, st)) return rc;
+          continue;
         }
+        Layer& Lprev = n->layers[l - 1];
+        HeadWgArgs hw;
+        const HeadWgArgs* hwp = nullptr;
+        if (!heads_done) {
+          Layer& Lp = n->layers[n->t_end[0] - 1];
+          Layer& Lv = n->layers[n->t_end[n->n_trunks - 1] - 1];
+          hw.f_pi = n->ws + Lp.act_off; hw.f_v = n->ws + Lv.act_off;
+          hw.dlogits = n->ws + n->off_dlogits; hw.dvalue = n->ws + n->off_dvalue;
+          hw.slab_pi = n->ws + n->off_hslab_pi; hw.slab_v = n->ws + n->off_hslab_v;
+          hw.stride_pi = n->hstride_pi; hw.stride_v = n->hstride_v;
+          hw.B = B; hw.F = n->feat; hw.A = n->A; hw.gx = (n->feat + 63) / 64; hw.nchunk = (B + 7) / 8;
+          n->head_chunks = hw.nchunk;
+          hwp = &hw;
+          heads_done = true;
+        }
+        if (int rc = launch_bwd_layer(&L.g, B, n->ws + Lprev.act_off, n->ws + L.dact_off, n->params + L.poff,
+                                      Lprev.g.act, n->ws + Lprev.dact_off, n->grads + L.poff, n->ws + L.slab_off,
+                                      wgrad_split(L, B), hwp, &L.last_msplit, st))
+          return rc;
       }
     return 0;
   }
@@ -203,7 +232,7 @@ static int trunk_backward(xt_net* n, const void* obs, const int32_t* idx, int B,
 }
 
 // ONE kernel: every slab reduction (trunk layers + heads) + the squared-norm partials
-static int grads_finish(xt_net* n, int B, hipStream_t st) {
+static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t st) {
   const int F = n->feat, A = n->A;
   GradTable tab;
   tab.n = 0;
@@ -226,15 +255,17 @@ static int grads_finish(xt_net* n, int B, hipStream_t st) {
     E.count = F + 1; E.dst = n->grads + n->v_off; E.src = n->ws + n->off_hslab_v;
     E.nslab = n->head_chunks; E.stride = n->hstride_v;
   }
-  return launch_grads_finish(&tab, n->ws + n->off_norm, kMaxNormPartials, &n->norm_blocks, st);
+  return launch_grads_finish(&tab, n->ws + n->off_norm, kMaxNormPartials, &n->norm_blocks, fin, st);
 }
 
-static int net_apply(xt_net* n, float lr, float b1, float b2, float eps, float clip, float gscale, bool use_partials,
+// mode 0: gradient was changed after grads_finish (all-reduce) -> recompute the norm;
+// mode 1: squared-norm partials of grads_finish are valid -> finalize kernel;  mode 2: already finalized in-kernel
+static int net_apply(xt_net* n, float lr, float b1, float b2, float eps, float clip, float gscale, int mode,
                      const LossArgs* la, hipStream_t st) {
-  if (use_partials) {
+  if (mode == 1) {
     if (int rc = launch_norm_finalize(n->ws + n->off_norm, n->norm_blocks, clip, gscale, lr, b1, b2, 1, n->state, la, st))
       return rc;
-  } else {
+  } else if (mode == 0) {
     if (int rc = launch_global_norm(n->grads, n->P, clip, gscale, lr, b1, b2, 1, n->state, n->ws + n->off_norm, st))
       return rc;
   }
@@ -246,7 +277,8 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
                     const double* target_v, int apply, float* loss_out, float* loss_acc, hipStream_t st) {
   XT_REQUIRE(n->params && n->ws, "xt_net: buffers not bound (call xt_net_bind)");
   XT_REQUIRE(B > 0 && B <= n->maxB, "xt_net_ppo_step: batch %d outside (0,%d]", B, n->maxB);
-  if (int rc = net_forward(n, obs, idx, B, false, st)) return rc;
+  const bool fused_head = (n->A <= 64);
+  if (int rc = net_forward(n, obs, idx, B, false, st, fused_head)) return rc;
   const float inv_b = 1.f / (float)(c->global_batch > 0 ? c->global_batch : B);
   Layer& Lp = n->layers[n->t_end[0] - 1];
   Layer& Lv = n->layers[n->t_end[n->n_trunks - 1] - 1];
@@ -262,6 +294,16 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
     h.logits = n->ws + n->off_logits; h.value = n->ws + n->off_value; h.dlogits = n->ws + n->off_dlogits;
     h.dvalue = n->ws + n->off_dvalue; h.terms = n->ws + n->off_terms;
     h.df_pi = n->ws + Lp.dact_off; h.df_v = n->ws + Lv.dact_off;
+    h.part_pi = h.part_v = nullptr; h.tbias_pi = h.tbias_v = nullptr; h.feat_pi_w = h.feat_v_w = nullptr;
+    h.ksplit_pi = h.ksplit_v = 1; h.act_feat = Lp.g.act; h.part_stride = (long long)B * F;
+    if (Lp.last_ksplit > 1) {
+      h.part_pi = n->ws + Lp.part_off; h.ksplit_pi = Lp.last_ksplit; h.feat_pi_w = n->ws + Lp.act_off;
+      h.tbias_pi = n->params + Lp.poff + (int64_t)Lp.K * Lp.g.N;
+    }
+    if (n->n_trunks == 2 && Lv.last_ksplit > 1) {
+      h.part_v = n->ws + Lv.part_off; h.ksplit_v = Lv.last_ksplit; h.feat_v_w = n->ws + Lv.act_off;
+      h.tbias_v = n->params + Lv.poff + (int64_t)Lv.K * Lv.g.N;
+    }
     if (int rc = launch_ppo_heads_fused(h, st)) return rc;
   } else {
     if (int rc = xt_heads_fwd(n->ws + Lp.act_off, n->ws + Lv.act_off, B, F, A, n->params + n->pi_off,
@@ -278,12 +320,18 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
       return rc;
   }
   if (int rc = trunk_backward(n, obs, idx, B, st)) return rc;
-  if (int rc = grads_finish(n, B, st)) return rc;
   LossArgs la;
   la.terms = n->ws + n->off_terms; la.B = B; la.ent_coef = c->ent_coef; la.critic_coef = c->critic_coef;
   la.inv_b = inv_b; la.out = lo; la.acc = loss_acc;
-  if (apply)
-    return net_apply(n, c->lr, c->beta1, c->beta2, c->eps, c->max_grad_norm, c->grad_scale, true, &la, st);
+  if (apply) {
+    FinalizeArgs fin;
+    fin.enable = 1; fin.counter = reinterpret_cast<unsigned int*>(n->ws + n->off_counter);
+    fin.clip_norm = c->max_grad_norm; fin.grad_scale = c->grad_scale; fin.lr = c->lr; fin.beta1 = c->beta1;
+    fin.beta2 = c->beta2; fin.state = n->state; fin.loss = la;
+    if (int rc = grads_finish(n, B, &fin, st)) return rc;
+    return net_apply(n, c->lr, c->beta1, c->beta2, c->eps, c->max_grad_norm, c->grad_scale, 2, nullptr, st);
+  }
+  if (int rc = grads_finish(n, B, nullptr, st)) return rc;
   // gradient only (data parallel): still report the local loss
   return xt_ppo_loss_reduce(n->ws + n->off_terms, B, c->ent_coef, c->critic_coef, inv_b, lo, loss_acc, st);
 }
@@ -328,6 +376,12 @@ int xt_net_create(const xt_net_desc* d, int32_t max_batch, xt_net** out) {
     const int64_t sl = (int64_t)((512 / tiles) < 1 ? 1 : (512 / tiles)) * (int64_t)(L.K + 1) * L.g.N;
     n->layers.back().slab_off = off; off += xt::align4(sl);
     n->layers.back().last_msplit = 1;
+    n->layers.back().last_ksplit = 1;
+    n->layers.back().part_off = -1;
+  }
+  for (int tr = 0; tr < d->n_trunks; ++tr) {   // deferred split-K partials of each trunk's last layer
+    xt::Layer& L = n->layers[n->t_end[tr] - 1];
+    L.part_off = off; off += (int64_t)512 * 4096;
   }
   if (d->n_trunks == 2 && n->t_begin[1] == 0) {
     delete n;
@@ -351,6 +405,7 @@ int xt_net_create(const xt_net_desc* d, int32_t max_batch, xt_net** out) {
   n->off_terms = off; off += xt::align4((int64_t)max_batch * 4);
   n->off_loss = off; off += xt::align4(8 + max_batch);
   n->off_norm = off; off += xt::kMaxNormPartials;
+  n->off_counter = off; off += 32 * 66;   // 1 top + 64 sub ticket counters, one 128-B line each
   n->ws_floats = off;
   *out = n;
   return 0;
@@ -377,6 +432,7 @@ int xt_net_bind(xt_net* n, float* params, float* grads, float* adam_m, float* ad
              "xt_net_bind: buffers must be 16-byte aligned");
   n->params = params; n->grads = grads; n->m = adam_m; n->v = adam_v; n->state = adam_state;
   n->ws = static_cast<float*>(workspace);
+  XT_CHECK_HIP(hipMemset(n->ws + n->off_counter, 0, 32 * 66 * 4));   // ticket counter of grads_finish_kernel
   if (n->gexec) { hipGraphExecDestroy(n->gexec); n->gexec = nullptr; n->gkey.clear(); }
   return 0;
 }
@@ -477,16 +533,16 @@ int xt_net_impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int32
       return rc;
   }
   if (int rc = xt::trunk_backward(n, obs, nullptr, nfr, st)) return rc;
-  if (int rc = xt::grads_finish(n, nfr, st)) return rc;
+  if (int rc = xt::grads_finish(n, nfr, nullptr, st)) return rc;
   if (apply)
-    return xt::net_apply(n, c->lr, c->beta1, c->beta2, c->eps, c->grad_norm_clip, c->grad_scale, true, nullptr, st);
+    return xt::net_apply(n, c->lr, c->beta1, c->beta2, c->eps, c->grad_norm_clip, c->grad_scale, 1, nullptr, st);
   return 0;
 }
 
 int xt_net_apply(xt_net* n, float lr, float beta1, float beta2, float eps, float clip_norm, float grad_scale,
                  void* stream) {
   XT_REQUIRE(n && n->params && n->m && n->v && n->state, "xt_net_apply: buffers not bound");
-  return xt::net_apply(n, lr, beta1, beta2, eps, clip_norm, grad_scale, false, nullptr, xt::as_stream(stream));
+  return xt::net_apply(n, lr, beta1, beta2, eps, clip_norm, grad_scale, 0, nullptr, xt::as_stream(stream));
 }
 
 int xt_net_time_layer(xt_net* n, int32_t layer, int32_t which, const void* obs, const int32_t* idx, int32_t B,

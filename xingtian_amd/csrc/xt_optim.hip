@@ -2,15 +2,21 @@
 // Replaces build_train_op, xt/model/ppo/ppo.py:97-102 and impala_cnn_opt.py:204-217.
 // Three launches: per-block sum of squares (fixed order), single-block finalize
 // (norm, clip scale, bias-corrected step size, beta powers), vectorised Adam update.
+#include <string.h>
 #include "xt_common.h"
 
 namespace xt {
 
 constexpr int kNormBlocks = 512;   // partial sums; scratch must hold >= kNormBlocks floats
 
-__global__ __launch_bounds__(256) void grads_finish_kernel(const GradTable tab, float* __restrict__ partial) {
+__device__ void finalize_body(const float* partial, int nblocks, float clip_norm, float grad_scale, float lr,
+                              float beta1, float beta2, int advance, float* state, const LossArgs& la, double* sh);
+
+__global__ __launch_bounds__(256) void grads_finish_kernel(const GradTable tab, float* __restrict__ partial,
+                                                           const FinalizeArgs fin) {
   __shared__ float4 sh4[256];
   __shared__ float shs[256];
+  __shared__ int s_last;
   int ei = 0;
   for (int q = 1; q < tab.n; ++q)
     if ((int)blockIdx.x >= tab.e[q].blk0) ei = q;
@@ -61,7 +67,36 @@ __global__ __launch_bounds__(256) void grads_finish_kernel(const GradTable tab, 
     if (t < o) shs[t] += shs[t + o];
     __syncthreads();
   }
-  if (t == 0) partial[blockIdx.x] = shs[0];
+  if (!fin.enable) {
+    if (t == 0) partial[blockIdx.x] = shs[0];
+    return;
+  }
+  // ---- last block to arrive finalises (norm, clip scale, Adam step size, loss scalars): saves a launch.
+  // Publish/consume per the gfx950 recipe R1: the 4-byte partial is stored WRITE-THROUGH (relaxed agent-scope
+  // atomic store = sc1, no per-block release fence / L2 write-back), drained with vmcnt(0), then a relaxed
+  // agent ticket; only the last arriver does ONE agent acquire, then plain loads.
+  if (t == 0) {
+    __hip_atomic_store(partial + blockIdx.x, shs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // two-level ticket: ~3000 same-address atomics would serialise (~12 ns each); 64 sub-counters (one 128-B line each) + 1 top
+    const unsigned nsub = gridDim.x < 64u ? gridDim.x : 64u;
+    const unsigned sub = blockIdx.x % nsub;
+    const unsigned cnt = (gridDim.x - sub + nsub - 1u) / nsub;
+    int last = 0;
+    if (__hip_atomic_fetch_add(fin.counter + 32u * (1u + sub), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cnt - 1u) {
+      __hip_atomic_store(fin.counter + 32u * (1u + sub), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsub - 1u) {
+        __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        last = 1;
+      }
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  finalize_body(partial, gridDim.x, fin.clip_norm, fin.grad_scale, fin.lr, fin.beta1, fin.beta2, 1, fin.state,
+                fin.loss, reinterpret_cast<double*>(sh4));
 }
 
 __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, long long count,
@@ -87,10 +122,8 @@ __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __rest
 }
 
 // state: [0]=b1^t [1]=b2^t [2]=scale [3]=alpha [4]=gnorm [5]=step
-__global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restrict__ partial, int nblocks, float clip_norm,
-                                                            float grad_scale, float lr, float beta1, float beta2,
-                                                            int advance, float* __restrict__ state, LossArgs la) {
-  __shared__ double sh[256];
+__device__ void finalize_body(const float* partial, int nblocks, float clip_norm, float grad_scale, float lr,
+                              float beta1, float beta2, int advance, float* state, const LossArgs& la, double* sh) {
   if (la.terms) {   // PPO loss scalars from the per-sample terms (fixed-order tree), xt/model/ppo/__init__.py
     double t3[3] = {0.0, 0.0, 0.0};
     for (int b = threadIdx.x; b < la.B; b += 256) {
@@ -141,6 +174,13 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restr
   }
 }
 
+__global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restrict__ partial, int nblocks, float clip_norm,
+                                                            float grad_scale, float lr, float beta1, float beta2,
+                                                            int advance, float* __restrict__ state, LossArgs la) {
+  __shared__ double sh[256];
+  finalize_body(partial, nblocks, clip_norm, grad_scale, lr, beta1, beta2, advance, state, la, sh);
+}
+
 __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                       float* __restrict__ m, float* __restrict__ v, long long count,
                                                       float beta1, float beta2, float eps, const float* __restrict__ state) {
@@ -181,7 +221,8 @@ __global__ void adam_state_init_kernel(float* state) {
 }
 
 // entries: blk0/nblk/zl are filled here.  partial needs room for the returned block count.
-int launch_grads_finish(GradTable* tab, float* partial, int max_partials, int* nblocks_out, hipStream_t st) {
+int launch_grads_finish(GradTable* tab, float* partial, int max_partials, int* nblocks_out, const FinalizeArgs* fin,
+                        hipStream_t st) {
   int blk = 0;
   for (int i = 0; i < tab->n; ++i) {
     GradEntry& E = tab->e[i];
@@ -196,7 +237,9 @@ int launch_grads_finish(GradTable* tab, float* partial, int max_partials, int* n
                "grads_finish: entry %d not 16-byte aligned", i);
   }
   XT_REQUIRE(blk > 0 && blk <= max_partials, "grads_finish: %d partial blocks > scratch %d", blk, max_partials);
-  hipLaunchKernelGGL(grads_finish_kernel, dim3(blk), dim3(256), 0, st, *tab, partial);
+  FinalizeArgs f;
+  if (fin) f = *fin; else { memset(&f, 0, sizeof(f)); }
+  hipLaunchKernelGGL(grads_finish_kernel, dim3(blk), dim3(256), 0, st, *tab, partial, f);
   XT_LAUNCH_CHECK();
   *nblocks_out = blk;
   return 0;
