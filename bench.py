@@ -203,20 +203,35 @@ def main():
                    "parallelism": "dp{}".format(world), "hip_graph": bool(use_graph)},
     }
     if rank == 0:
-        # roofline of the dominant kernels: first-layer (conv 8x8/4, 4->32) forward and weight-gradient
+        # ---- roofline of the dominant kernel: every layer kernel of one SGD step timed live with HIP events on
+        # the launch stream (xt_net_time_layer), algorithmic FLOPs = 2*M*N*K per GEMM
         idx = d_perm[0, :bsz].contiguous()
-        lay = spec.layers[0]
-        flops = 2.0 * bsz * lay.OH * lay.OW * lay.N * lay.K
         kern = {}
-        for which, nm in ((0, "igemm_fwd_kernel<128,32,4,1,u8> (conv1 fwd)"), (1, "igemm_wgrad_kernel<128,32,4,1,u8> (conv1 wgrad)")):
-            ms = net.time_layer(0, which, d_obs, idx, bsz, reps=50)
-            kern[nm] = ms
-        dom = max(kern, key=kern.get)
-        ach = flops / (kern[dom] * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                           "flop_per_launch": flops, "avg_launch_ms": kern[dom],
-                           "all_ms": kern}
+        for li, lay in enumerate(spec.layers):
+            mnk2 = 2.0 * bsz * lay.OH * lay.OW * lay.N * lay.K
+            if li == 0:
+                kern["L0 conv8x8/4 fwd  [conv_u8c4k8_fwd_bf16x3_kernel]"] = (net.time_layer(0, 0, d_obs, idx, bsz, 50), mnk2, "bf16x3")
+                kern["L0 conv8x8/4 wgrad [igemm_wgrad_kernel<128,32,4,1,u8>]"] = (net.time_layer(0, 1, d_obs, idx, bsz, 50), mnk2, "fp32")
+            else:
+                kern["L%d %s fwd  [igemm_fwd_kernel]" % (li, lay.name)] = (net.time_layer(li, 0, d_obs, idx, bsz, 50), mnk2, "fp32")
+                kern["L%d %s dgrad+wgrad [igemm_bwd_layer_kernel]" % (li, lay.name)] = (
+                    net.time_layer(li, 3, d_obs, idx, bsz, 50), 2 * mnk2, "fp32")
+        dom = max(kern, key=lambda k: kern[k][0])
+        ms, flops, kind = kern[dom]
+        # fp32 kernels: v_mfma_f32_32x32x2_f32 dense peak; bf16x3 kernels spend 3 bf16 MFMA flops per algorithmic flop
+        peak = FP32_MFMA_PEAK_TFLOPS if kind == "fp32" else 2500.0 / 3.0
+        ach = flops / (ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except (OSError, ValueError):
+                traffic = None
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                           "frac": ach / peak, "traffic": traffic, "flop_per_launch": flops, "avg_launch_ms": ms,
+                           "kernels_us": {k: round(v[0] * 1e3, 2) for k, v in kern.items()},
+                           "sum_layer_kernels_us": round(sum(v[0] for v in kern.values()) * 1e3, 1)}
         total_flops = 31.313e6 * n * CFG["NUM_SGD_ITER"]
         out["update_tflops"] = total_flops * args.steps / elapsed / 1e12
         if world == 1 and not args.no_cpu_baseline:

@@ -132,7 +132,7 @@ int xt_ppo_loss_reduce(const float* loss_terms, int32_t B, float ent_coef, float
 /* IMPALA: v-trace targets + loss gradient for one chunk of n_traj trajectories of T
  * steps (flat env-major index b*T+t).  Replaces split_batches / vtrace_loss
  * (impala_cnn_opt.py:171-196,299-351) and vtrace.from_logic_outputs (vtrace.py:39-115).
- * done: u8, reward: f32 (clipped to [-1,1] here).  out[0]=loss (sum form).
+ * done: u8, reward: f32 (clipped to [-1,1] here).  out: >= 4+n_traj floats, out[0]=loss (sum form).
  * vs/pg_adv (optional, may be NULL): [n_traj,T-1] for parity tests. */
 int xt_impala_loss(const float* logits, const float* baseline, const float* bp_logits,
                    const int32_t* action, const uint8_t* done, const float* reward,
@@ -250,7 +250,7 @@ int xt_net_apply(xt_net* net, float lr, float beta1, float beta2, float eps, flo
 
 /* kernel-time probe: average duration (ms) of `reps` launches of the dominant kernel
  * (first-layer forward) on `stream`, measured with HIP events on that stream. */
-int xt_net_time_layer(xt_net* net, int32_t layer, int32_t which /*0 fwd 1 wgrad 2 dgrad*/,
+int xt_net_time_layer(xt_net* net, int32_t layer, int32_t which /*0 fwd 1 wgrad 2 dgrad 3 fused dgrad+wgrad*/,
                       const void* obs, const int32_t* idx, int32_t B, int32_t reps,
                       float* ms_out, void* stream);
 

@@ -1,0 +1,197 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every declared symbol, the plugin registry and
+config surface behave like the reference's, network specs agree with the oracle's, and the data-parallel
+plumbing is correct under a 2-process gloo group."""
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import nets
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_library_loads_and_exports_every_header_symbol():
+    from xingtian_amd import lib
+    handle = lib.load()
+    header = open(os.path.join(ROOT, "include", "xt_mi355x.h")).read()
+    declared = set(re.findall(r"\b(xt_[a-z0-9_]+)\s*\(", header))
+    declared -= {"xt_net_desc", "xt_layer_desc"}
+    assert len(declared) >= 20
+    for name in sorted(declared):
+        assert hasattr(handle, name), "missing C-ABI symbol " + name
+        assert name in lib.SIGNATURES, "no ctypes prototype for " + name
+    assert handle.xt_abi_version() == 1
+    assert handle.xt_build_arch() == b"gfx950"
+
+
+def test_product_path_fails_loudly_without_gpu():
+    from xingtian_amd import lib
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        lib.require_gpu()
+    from xingtian_amd.model import model_builder
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        model_builder({"model_name": "PpoMlp", "state_dim": [4], "action_dim": 2,
+                       "model_config": {"action_type": "Categorical"}})
+
+
+def test_product_never_imports_oracle():
+    import subprocess
+    import sys
+    code = ("import sys; import xingtian_amd, xingtian_amd.model, xingtian_amd.algorithm, xingtian_amd.ops, "
+            "xingtian_amd.parallel; assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)")
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "xingtian_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_registry_and_import_config_semantics():
+    from xingtian_amd.register import Registers, import_config
+    import xingtian_amd.model  # noqa: F401
+    import xingtian_amd.algorithm  # noqa: F401
+    for name in ("PpoCnn", "PpoMlp", "ImpalaCnnOpt"):
+        assert name in Registers.model
+    for name in ("PPO", "IMPALAOpt"):
+        assert name in Registers.algorithm
+    with pytest.raises(KeyError):
+        Registers.model["NoSuchModel"]
+    g = {"LR": 1.0, "BATCH_SIZE": 2, "lower": 3}
+    import_config(g, {"LR": 0.5, "UNKNOWN": 9, "lower": 4})
+    assert g == {"LR": 0.5, "BATCH_SIZE": 2, "lower": 4}
+    import_config(g, None)
+    with pytest.raises(RuntimeError):
+        Registers()
+
+
+def test_yaml_surface_of_reference_examples(tmp_path):
+    """the model_para blocks of the reference's example YAMLs parse into our specs (values copied from
+    examples/breakout_ppo.yaml, cartpole_ppo.yaml, breakout_impala.yaml, pong_impala_speedup.yaml)."""
+    import yaml
+    from xingtian_amd.model import netspec
+    cfg = yaml.safe_load("""
+model_para:
+  actor:
+    model_name: PpoCnn
+    state_dim: [84, 84, 4]
+    action_dim: 4
+    input_dtype: uint8
+    model_config: {BATCH_SIZE: 320, NUM_SGD_ITER: 4, VF_SHARE_LAYERS: True, activation: relu, hidden_sizes: [256]}
+""")["model_para"]["actor"]
+    s = netspec.ppo_cnn(tuple(cfg["state_dim"]), cfg["action_dim"], tuple(cfg["model_config"]["hidden_sizes"]),
+                        cfg["model_config"]["activation"], cfg["model_config"]["VF_SHARE_LAYERS"], cfg["input_dtype"])
+    assert s.n_params == 847493 and s.input_xform == (1, 0.0, 255.0)
+
+
+@pytest.mark.parametrize("which", ["ppo_cnn84", "ppo_cnn42_unshared", "ppo_mlp", "impala84", "impala42"])
+def test_netspec_matches_oracle_spec(which):
+    from xingtian_amd.model import netspec
+    if which == "ppo_cnn84":
+        s, o = netspec.ppo_cnn((84, 84, 4), 4, (256,)), nets.ppo_cnn_spec((84, 84, 4), 4, (256,))
+    elif which == "ppo_cnn42_unshared":
+        s = netspec.ppo_cnn((42, 42, 4), 6, (64,), "tanh", False)
+        o = nets.ppo_cnn_spec((42, 42, 4), 6, (64,), "tanh", False)
+    elif which == "ppo_mlp":
+        s, o = netspec.ppo_mlp((4,), 2), nets.ppo_mlp_spec((4,), 2)
+    elif which == "impala84":
+        s, o = netspec.impala_cnn_opt((84, 84, 4), 4), nets.impala_cnn_opt_spec((84, 84, 4), 4)
+    else:
+        s = netspec.impala_cnn_opt((42, 42, 4), 6, 128.0, 128.0)
+        o = nets.impala_cnn_opt_spec((42, 42, 4), 6, 128.0, 128.0)
+    op = nets.init_params(o)
+    assert set(op.keys()) == set(s.names.keys())
+    assert s.n_params == sum(v.size for v in op.values())
+    olayers = [l for tr in o["trunks"] for l in tr]
+    assert len(olayers) == len(s.layers)
+    for a, b in zip(s.layers, olayers):
+        assert (a.OH, a.OW, a.PT, a.PL, a.N, a.C) == (b.out_h, b.out_w, b.pt, b.pl, b.cout, b.cin), a.name
+        assert a.param_off % 4 == 0
+    # flat layout: blocks do not overlap
+    spans = sorted((off, off + int(np.prod(shape))) for off, shape in s.names.values())
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert a1 <= b0
+    assert spans[-1][1] <= s.n_flat
+
+
+def test_shard_helpers():
+    from xingtian_amd import parallel
+    for n, w in [(32, 8), (10, 4), (3, 8), (256, 8)]:
+        got = [parallel.shard_range(n, r, w) for r in range(w)]
+        assert got[0][0] == 0 and got[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(got, got[1:]))
+        sizes = [e - b for b, e in got]
+        assert max(sizes) - min(sizes) <= 1
+    perm = np.random.default_rng(0).permutation(100)
+    parts = [parallel.split_minibatch(perm, 40, 40, r, 2) for r in range(2)]
+    assert np.array_equal(np.concatenate(parts), perm[40:80])
+    assert parallel.grad_scale("mean", 8) == 0.125 and parallel.grad_scale("sum", 8) == 1.0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _dp_worker(rank, world, port, out):
+    """each rank: oracle gradients of ITS shard of a global minibatch (fp64, CPU) -> gloo all-reduce through
+    xingtian_amd.parallel -> clip+Adam; rank 0 compares with the single-process oracle on the full minibatch."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xingtian_amd import parallel
+    try:
+        rng = np.random.default_rng(0)          # identical data on every rank
+        spec = nets.ppo_cnn_spec((15, 15, 4), 3, (8,), "relu", True)
+        params = nets.init_params(spec, seed=1, bias_scale=0.1)
+        b = 12
+        obs = rng.integers(0, 256, (b, 15, 15, 4)).astype(np.uint8)
+        action = rng.integers(0, 3, b).astype(np.int32)
+        old_logp = -np.abs(rng.standard_normal((b, 1))) - 0.5
+        adv = rng.standard_normal((b, 1)); old_v = rng.standard_normal((b, 1))
+        target_v = old_v + rng.standard_normal((b, 1))
+        cfg = dict(LR=1e-3, LOSS_CLIPPING=0.2, ENTROPY_LOSS=0.01, VF_CLIP=1.0, CRITIC_LOSS_COEF=0.5, MAX_GRAD_NORM=0.5,
+                   BATCH_SIZE=b, NUM_SGD_ITER=1)
+        perm = rng.permutation(b)
+        mine = parallel.split_minibatch(perm, 0, b, rank, world)
+        assert parallel.world_info() == (rank, world)
+        # local gradient of the GLOBAL-mean loss restricted to my rows = (|mine|/b) * grad of my local mean
+        orc = nets.PpoLearnerOracle(spec, params, dict(cfg, BATCH_SIZE=len(mine)), np.float64)
+        out_l = orc.step(obs[mine], action[mine], old_logp[mine], adv[mine], old_v[mine], target_v[mine], apply=False)
+        flat = torch.from_numpy(np.concatenate([g.ravel() for g in out_l["grads"].values()]))
+        parallel.allreduce_sum_(flat)                       # SUM over ranks
+        flat *= parallel.grad_scale("mean", world)          # equal shards: mean of local means = global mean
+        ref = nets.PpoLearnerOracle(spec, params, cfg, np.float64).step(
+            obs[perm], action[perm], old_logp[perm], adv[perm], old_v[perm], target_v[perm], apply=False)
+        ref_flat = np.concatenate([g.ravel() for g in ref["grads"].values()])
+        np.testing.assert_allclose(flat.numpy(), ref_flat, rtol=1e-9, atol=1e-13)
+        # replicas stay identical: the reduced buffer is bit-identical on every rank
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert all(torch.equal(gathered[0], g) for g in gathered)
+        w = torch.tensor([float(rank + 1)])
+        parallel.broadcast_weights_(w, src=0)
+        assert w.item() == 1.0
+        out[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_allreduce_gloo_world2():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_worker, args=(world, port, out), nprocs=world, join=True)
+    assert dict(out) == {0: 1, 1: 1}

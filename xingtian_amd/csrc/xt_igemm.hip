@@ -16,6 +16,7 @@
 //
 // Replaces the TensorFlow Conv2D/Dense forward+backward ops the reference runs inside
 // sess.run (xt/model/ppo/ppo.py:129, xt/model/impala/impala_cnn_opt.py:255).
+#include <stdlib.h>
 #include "xt_common.h"
 #include "xt_heads_dev.h"
 
@@ -686,9 +687,24 @@ static inline int pick_ksplit_chunk(int K, int split, int* chunk) {
   return (steps + per - 1) / per;   // effective split count
 }
 
+int launch_conv1_fwd_bf16x3(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*, const float*,
+                            const float*, float*, hipStream_t);
+int launch_conv1_wgrad_bf16x3(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*,
+                              const float*, float*, float*, int, int*, hipStream_t);
+
+static bool use_bf16x3() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("XT_NO_BF16X3"); v = (e && e[0] == '1') ? 0 : 1; }
+  return v == 1;
+}
+
 int launch_fwd(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const void* in, const int32_t* idx,
                const float* w, const float* bias, float* y, float* partial, int ksplit, hipStream_t st,
                int* deferred_ksplit) {
+  if (use_bf16x3()) {     // uint8 first layer: exact 3-way bf16 split on the bf16 matrix cores
+    const int rc = launch_conv1_fwd_bf16x3(cg, xf, B, in, idx, w, bias, y, st);
+    if (rc >= 0) { if (deferred_ksplit) *deferred_ksplit = 1; return rc; }
+  }
   FwdArgs a;
   if (int rc = make_geom(cg, xf, B, &a.g)) return rc;
   const bool u8 = xf && xf->is_u8;

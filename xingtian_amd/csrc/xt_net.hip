@@ -555,7 +555,8 @@ int xt_net_time_layer(xt_net* n, int32_t layer, int32_t which, const void* obs, 
   bool first = false;
   for (int tr = 0; tr < n->n_trunks; ++tr) first |= (layer == n->t_begin[tr]);
   const void* x = first ? obs : (const void*)(n->ws + n->layers[layer - 1].act_off);
-  XT_REQUIRE(which == 0 || which == 1 || (which == 2 && !first), "xt_net_time_layer: bad kernel selector");
+  XT_REQUIRE(which == 0 || which == 1 || ((which == 2 || which == 3) && !first),
+             "xt_net_time_layer: bad kernel selector");
   hipEvent_t e0, e1;
   XT_CHECK_HIP(hipEventCreate(&e0));
   XT_CHECK_HIP(hipEventCreate(&e1));
@@ -569,6 +570,10 @@ int xt_net_time_layer(xt_net* n, int32_t layer, int32_t which, const void* obs, 
       return xt::launch_wgrad(&L.g, first ? &n->xf : nullptr, B, x, first ? idx : nullptr, n->ws + L.dact_off,
                               n->grads + L.poff, n->ws + L.slab_off, xt::wgrad_split(L, B), st, 0, &L.last_msplit);
     xt::Layer& Lp = n->layers[layer - 1];
+    if (which == 3)   // the fused per-layer backward launch (dgrad + wgrad) used by the update loop
+      return xt::launch_bwd_layer(&L.g, B, n->ws + Lp.act_off, n->ws + L.dact_off, n->params + L.poff, Lp.g.act,
+                                  n->ws + Lp.dact_off, n->grads + L.poff, n->ws + L.slab_off, xt::wgrad_split(L, B),
+                                  nullptr, &L.last_msplit, st);
     return xt::launch_dgrad(&L.g, B, n->ws + L.dact_off, n->params + L.poff, n->ws + Lp.act_off, Lp.g.act,
                             n->ws + Lp.dact_off, st);
   };

@@ -1,0 +1,68 @@
+"""Data-parallel learner plumbing: one process per GPU, ``torch.distributed`` (backend "nccl" == RCCL over
+xGMI on ROCm; "gloo" on CPU for tests).
+
+The learner update shards naturally: samples of a minibatch are independent through
+forward/backward and GAE / v-trace recur only along time, so every rank owns whole trajectories and a
+slice of every minibatch; the ONLY exchange is one all-reduce (SUM) of the flat fp32 gradient buffer per SGD
+step, after which every rank applies the identical clip + Adam update (replicas stay bit-identical because
+the reduced buffer is identical on all ranks).  PPO's loss is a mean over the global minibatch -> scale the
+summed gradient by 1/world (``grad_scale``); IMPALA's loss is a sum -> no scaling.
+
+The reference has no working counterpart: its multi-process trainer (xt/framework/trainer.py:32-136) averages
+gradients on the host in float64 through a RawArray and is dead code (no Algorithm implements get_grad).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def world_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous, balanced [begin, end) shard of n_items (trajectories) for ``rank``."""
+    base, rem = divmod(n_items, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def split_minibatch(perm_row, start, batch_size, rank, world):
+    """Rows of the GLOBAL minibatch perm_row[start:start+batch_size] owned by ``rank`` (equal shards; the global
+    permutation is drawn once with a shared seed so that every rank partitions it identically)."""
+    mb = np.asarray(perm_row[start:start + batch_size])
+    b, e = shard_range(len(mb), rank, world)
+    return mb[b:e]
+
+
+def allreduce_sum_(flat_grad):
+    """In-place SUM all-reduce of the flat gradient buffer (no-op for a single process)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    return flat_grad
+
+
+def grad_scale(loss_reduction, world):
+    """Factor applied to the summed gradient: 'mean' losses (PPO) -> 1/world, 'sum' losses (IMPALA) -> 1."""
+    if loss_reduction == "mean":
+        return 1.0 / world
+    if loss_reduction == "sum":
+        return 1.0
+    raise ValueError(loss_reduction)
+
+
+def broadcast_weights_(flat_params, src=0):
+    """Make replicas identical at start-up (random init differs per process unless seeded identically)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(flat_params, src=src)
+    return flat_params
+
+
+def dp_ppo_step(net, cfg_struct, lr, max_grad_norm, obs, idx, action, old_logp, adv, old_v, target_v, world):
+    """One data-parallel PPO SGD step on a HipActorCritic: local fwd/bwd -> RCCL all-reduce of net.grads ->
+    identical clip+Adam on every rank."""
+    net.ppo_step(cfg_struct, obs, idx, action, old_logp, adv, old_v, target_v, apply=False)
+    allreduce_sum_(net.grads)
+    net.apply(lr, max_grad_norm, grad_scale=grad_scale("mean", world))
