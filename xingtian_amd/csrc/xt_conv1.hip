@@ -40,6 +40,24 @@ __device__ __forceinline__ bf16x8 bytes_to_bf16x8(uint32_t d0, uint32_t d1) {
   return r.v;
 }
 
+// global -> LDS copy of one frame stack: 8 x 16-byte loads per thread are issued back to back (one memory
+// latency for the whole image instead of one per loop iteration), then written to LDS
+__device__ __forceinline__ void stage_image(const uint4* __restrict__ src, uint4* dst, int n16, int t) {
+  for (int base = 0; base < n16; base += 256 * 8) {
+    uint4 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = base + t + 256 * q;
+      v[q] = src[i < n16 ? i : 0];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = base + t + 256 * q;
+      if (i < n16) dst[i] = v[q];
+    }
+  }
+}
+
 struct C1FwdArgs {
   const uint8_t* in;
   const int32_t* idx;
@@ -47,7 +65,7 @@ struct C1FwdArgs {
   const float* bias;   // [32]
   float* y;            // [B*OH*OW][32]
   int B, H, W, OH, OW, S, KH, act;
-  float xs, xb;        // y = act(acc*xs + xb*colsum(W) + bias)
+  float xs, xb;        // y = act(acc*xs + bias)   (xb must be 0 for this kernel)
 };
 
 constexpr int kC1MaxTiles = 4;   // 32-pixel tiles per wave -> OH*OW <= 4*4*32 = 512
@@ -57,13 +75,45 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_fwd_bf16x3_kernel(const C1
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int b = blockIdx.x;
   const int HWC = p.H * p.W * 4, Wrow = p.W * 4, OHOW = p.OH * p.OW;
-  // ---- stage the frame stack (coalesced 16-byte loads, minibatch gather fused)
+  const int nsteps = 2 * p.KH;              // 16 reduction elements per step = half a kernel row
+  uint4* wpl = reinterpret_cast<uint4*>(limg + HWC);     // [nsteps][3 planes][64 lanes] x 16 B, MFMA operand order
+  // ---- issue every global load of the block up front: this thread's share of the weights (fp32, split below)
+  // and of the frame stack (minibatch gather fused) -> one memory latency for the whole prologue
+  float wv[4][8];
+  const int nslots = nsteps * 64;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int slot = t + 256 * q;
+    const int sc = slot < nslots ? slot : 0;
+    const float* wl = p.w + (size_t)((sc >> 6) * 16 + 8 * ((sc & 63) >> 5)) * 32 + (sc & 31);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[q][j] = wl[j * 32];
+  }
   {
     const size_t s = p.idx ? (size_t)p.idx[b] : (size_t)b;
     const uint4* src = reinterpret_cast<const uint4*>(p.in + s * (size_t)HWC);
-    uint4* dst = reinterpret_cast<uint4*>(limg);
-    const int n16 = HWC >> 4;
-    for (int i = t; i < n16; i += 256) dst[i] = src[i];
+    stage_image(src, reinterpret_cast<uint4*>(limg), HWC >> 4, t);
+  }
+  // exact 3-way bf16 split of the weights, written once per block in operand order
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int slot = t + 256 * q;
+    if (slot < nslots) {
+      BF8 b1, b2, b3;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float w0 = wv[q][2 * e], w1 = wv[q][2 * e + 1];
+        const float r0 = w0 - trunc_bf16(w0), r1 = w1 - trunc_bf16(w1);
+        const float q0 = r0 - trunc_bf16(r0), q1 = r1 - trunc_bf16(r1);
+        b1.u[e] = pack_hi16(w0, w1);
+        b2.u[e] = pack_hi16(r0, r1);
+        b3.u[e] = pack_hi16(q0, q1);
+      }
+      const int s = slot >> 6, ln = slot & 63;
+      wpl[(s * 3 + 0) * 64 + ln] = make_uint4(b1.u[0], b1.u[1], b1.u[2], b1.u[3]);
+      wpl[(s * 3 + 1) * 64 + ln] = make_uint4(b2.u[0], b2.u[1], b2.u[2], b2.u[3]);
+      wpl[(s * 3 + 2) * 64 + ln] = make_uint4(b3.u[0], b3.u[1], b3.u[2], b3.u[3]);
+    }
   }
   const int ntiles = (OHOW + 31) >> 5;
   const int il = lane & 31, h = lane >> 5;
@@ -81,31 +131,16 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_fwd_bf16x3_kernel(const C1
   for (int ti = 0; ti < kC1MaxTiles; ++ti)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
-
-  const int nsteps = 2 * p.KH;              // 16 reduction elements per step = half a kernel row
-  const float* wl = p.w + (size_t)(8 * h) * 32 + il;   // this lane's column n = il, rows 8h + j
-  float wcur[8], wnext[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) wcur[j] = wl[j * 32];
-  float sumw = 0.f;
+  const float bias = p.bias[il];
   __syncthreads();
 
   for (int s = 0; s < nsteps; ++s) {
-    if (s + 1 < nsteps) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) wnext[j] = wl[(size_t)((s + 1) * 16 + j) * 32];
-    }
-    // exact 3-way bf16 split of the 8 weights of this lane
     BF8 b1, b2, b3;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float w0 = wcur[2 * q], w1 = wcur[2 * q + 1];
-      sumw += w0 + w1;
-      const float r0 = w0 - trunc_bf16(w0), r1 = w1 - trunc_bf16(w1);
-      const float q0 = r0 - trunc_bf16(r0), q1 = r1 - trunc_bf16(r1);
-      b1.u[q] = pack_hi16(w0, w1);
-      b2.u[q] = pack_hi16(r0, r1);
-      b3.u[q] = pack_hi16(q0, q1);
+    {
+      const uint4 x1 = wpl[(s * 3 + 0) * 64 + lane], x2 = wpl[(s * 3 + 1) * 64 + lane], x3 = wpl[(s * 3 + 2) * 64 + lane];
+      b1.u[0] = x1.x; b1.u[1] = x1.y; b1.u[2] = x1.z; b1.u[3] = x1.w;
+      b2.u[0] = x2.x; b2.u[1] = x2.y; b2.u[2] = x2.z; b2.u[3] = x2.w;
+      b3.u[0] = x3.x; b3.u[1] = x3.y; b3.u[2] = x3.z; b3.u[3] = x3.w;
     }
     const int koff = (s >> 1) * Wrow + (s & 1) * 16;
 #pragma unroll
@@ -118,13 +153,9 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_fwd_bf16x3_kernel(const C1
         acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b3.v, acc[ti], 0, 0, 0);
       }
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) wcur[j] = wnext[j];
   }
 
-  // ---- epilogue: input transform on the accumulator, bias, activation
-  const float colsum = sumw + __shfl_xor(sumw, 32, 64);
-  const float cb = fmaf(p.xb, colsum, p.bias[il]);
+  // ---- epilogue: input scale on the accumulator, bias, activation
 #pragma unroll
   for (int ti = 0; ti < kC1MaxTiles; ++ti) {
     if (wave + 4 * ti < ntiles) {
@@ -132,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_fwd_bf16x3_kernel(const C1
       for (int r = 0; r < 16; ++r) {
         const int pix = (wave + 4 * ti) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (pix < OHOW)
-          p.y[((size_t)b * OHOW + pix) * 32 + il] = act_apply(fmaf(acc[ti][r], p.xs, cb), p.act);
+          p.y[((size_t)b * OHOW + pix) * 32 + il] = act_apply(fmaf(acc[ti][r], p.xs, bias), p.act);
       }
     }
   }
@@ -146,19 +177,165 @@ int launch_conv1_fwd_bf16x3(const xt_conv_geom* g, const xt_input_xform* xf, int
   const int HWC = g->H * g->W * 4;
   if (HWC % 16 != 0 || HWC > 64 * 1024 || (g->W * 4) % 8 != 0 || (g->S * 4) % 8 != 0) return -1;
   if (g->OH * g->OW > 32 * 4 * kC1MaxTiles) return -1;
+  if (fabsf(xf->mean) >= 1e-4f || g->KH > 8) return -1;     // the mean term would need colsum(W); 4 weight slots/thread
   C1FwdArgs a;
   a.in = static_cast<const uint8_t*>(in); a.idx = idx; a.w = w; a.bias = bias; a.y = y;
   a.B = B; a.H = g->H; a.W = g->W; a.OH = g->OH; a.OW = g->OW; a.S = g->S; a.KH = g->KH; a.act = g->act;
   const float mean = fabsf(xf->mean) >= 1e-4f ? xf->mean : 0.f;
   a.xs = 1.f / xf->std; a.xb = -mean * a.xs;
-  hipLaunchKernelGGL(conv_u8c4k8_fwd_bf16x3_kernel, dim3(B), dim3(256), HWC, st, a);
+  const size_t lds = (size_t)HWC + (size_t)2 * g->KH * 3 * 64 * 16;
+  hipLaunchKernelGGL(conv_u8c4k8_fwd_bf16x3_kernel, dim3(B), dim3(256), lds, st, a);
   XT_LAUNCH_CHECK();
   return 0;
 }
 
-int launch_conv1_wgrad_bf16x3(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*,
-                              const float*, float*, float*, int, int*, hipStream_t) {
-  return -1;   // not implemented yet
+// ------------------------------------------------------------------ first-layer weight gradient
+// dW[k,n] = sum_pixels x[pixel,k] * dY[pixel,n]  (x uint8 -> exact bf16 A operand, dY split into 3 bf16 planes
+// as the B operand; the reduction index of v_mfma_f32_32x32x16_bf16 is 16 pixels per instruction).
+// One workgroup = one frame stack (staged into LDS like the forward) -> one partial slab [(K+1)*32]; slabs are
+// summed by grads_finish_kernel.  Wave (pg, kh): pixel steps of parity pg, kernel rows [4kh, 4kh+4) (one kernel
+// row = one 32-wide k tile); the two pixel-parity halves are combined through LDS.  dY is read straight from
+// global/L2 (each lane: 8 pixels x its column n, coalesced 128 B rows) and split in registers once per step for
+// all four k tiles; the x operand is gathered with ds_read_u8 (32 consecutive bytes per half-wave: conflict-free).
+struct C1WgArgs {
+  const uint8_t* in;
+  const int32_t* idx;
+  const float* dy;     // [B*OH*OW][32] d(pre-activation)
+  float* out;          // [B][(K+1)*32] partial slabs
+  int B, H, W, OH, OW, S, KH;
+  float xs, xb;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_u8c4k8_wgrad_bf16x3_kernel(const C1WgArgs p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lsm[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int b = blockIdx.x;
+  const int HWC = p.H * p.W * 4, Wrow = p.W * 4, OHOW = p.OH * p.OW;
+  const int nsteps = (OHOW + 15) >> 4;
+  uint8_t* limg = lsm;
+  float* dys = reinterpret_cast<float*>(lsm + HWC);                      // [nsteps*16][32] this sample's dY
+  int* pixoff = reinterpret_cast<int*>(lsm + HWC + nsteps * 16 * 32 * 4); // [nsteps*16]
+  float* red = dys;                                                      // aliases dys after the main loop
+  float* bred = reinterpret_cast<float*>(pixoff);                        // aliases pixoff after the main loop
+  // ---- every global load of the block is issued up front (dY rows of this sample + the frame stack)
+  {
+    const float4* dsrc = reinterpret_cast<const float4*>(p.dy + (size_t)b * OHOW * 32);
+    const int n4 = OHOW * 8, n4pad = nsteps * 16 * 8;
+    float4 dv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int i = t + 256 * q;
+      dv[q] = dsrc[i < n4 ? i : 0];
+    }
+    const size_t s = p.idx ? (size_t)p.idx[b] : (size_t)b;
+    const uint4* src = reinterpret_cast<const uint4*>(p.in + s * (size_t)HWC);
+    stage_image(src, reinterpret_cast<uint4*>(limg), HWC >> 4, t);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int i = t + 256 * q;
+      if (i < n4pad) reinterpret_cast<float4*>(dys)[i] = i < n4 ? dv[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int i = t; i < nsteps * 16; i += 256) {
+      const int pp = i < OHOW ? i : 0;
+      const int oy = pp / p.OW, ox = pp - oy * p.OW;
+      pixoff[i] = (p.S * oy * p.W + p.S * ox) * 4;
+    }
+  }
+  const int il = lane & 31, h = lane >> 5;
+  const int pg = wave >> 1, kh = wave & 1;
+  f32x16 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  float bsum = 0.f;
+  __syncthreads();
+
+  for (int s = pg; s < nsteps; s += 2) {
+    // exact 3-way bf16 split of the 8 dY values of this lane (pixels 16s+8h+e, column il)
+    float dcur[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dcur[e] = dys[(s * 16 + 8 * h + e) * 32 + il];
+    BF8 b1, b2, b3;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float w0 = dcur[2 * q], w1 = dcur[2 * q + 1];
+      bsum += w0 + w1;
+      const float r0 = w0 - trunc_bf16(w0), r1 = w1 - trunc_bf16(w1);
+      const float q0 = r0 - trunc_bf16(r0), q1 = r1 - trunc_bf16(r1);
+      b1.u[q] = pack_hi16(w0, w1);
+      b2.u[q] = pack_hi16(r0, r1);
+      b3.u[q] = pack_hi16(q0, q1);
+    }
+    int po[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) po[e] = pixoff[s * 16 + 8 * h + e];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kb = (kh * 4 + q) * Wrow + il;        // kernel row ky = 4kh+q, byte kx*4+c = il
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = (float)limg[po[e] + kb];
+      BF8 a;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a.u[e] = pack_hi16(f[2 * e], f[2 * e + 1]);
+      acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b1.v, acc[q], 0, 0, 0);
+      acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b2.v, acc[q], 0, 0, 0);
+      acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b3.v, acc[q], 0, 0, 0);
+    }
+  }
+
+  // ---- combine the two pixel-parity halves, bias gradient, store the slab
+  bsum += __shfl_xor(bsum, 32, 64);
+  __syncthreads();                         // dys / pixoff are dead: their LDS is reused for the reduction
+  if (kh == 0 && h == 0) bred[pg * 32 + il] = bsum;
+  if (pg == 1) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((kh * 4 + q) * 16 + r) * 64 + lane] = acc[q][r];
+  }
+  __syncthreads();
+  if (pg == 0) {
+    const float db = bred[il] + bred[32 + il];
+    float* slab = p.out + (size_t)b * ((size_t)(p.KH * 32 + 1) * 32);
+    const float corr = p.xb * db;            // d/dW of the (x*xs + xb) transform: xb * sum_p dY
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[q][r] + red[((kh * 4 + q) * 16 + r) * 64 + lane];
+        const int k = (kh * 4 + q) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        slab[(size_t)k * 32 + il] = fmaf(v, p.xs, corr);
+      }
+    if (kh == 0 && h == 0) slab[(size_t)p.KH * 32 * 32 + il] = db;
+  }
+}
+
+// returns 0 launched (msplit_out = B slabs), 1 error, -1 geometry not handled
+int launch_conv1_wgrad_bf16x3(const xt_conv_geom* g, const xt_input_xform* xf, int B, const void* in,
+                              const int32_t* idx, const float* dy, float* dwb, float* slabs, int max_slabs,
+                              int* msplit_out, hipStream_t st) {
+  if (!xf || !xf->is_u8 || g->C != 4 || g->KW != 8 || g->KH != 8 || g->N != 32 || g->PT != 0 || g->PL != 0) return -1;
+  if ((g->OH - 1) * g->S + g->KH > g->H || (g->OW - 1) * g->S + g->KW > g->W) return -1;
+  const int HWC = g->H * g->W * 4;
+  if (HWC % 16 != 0 || HWC > 64 * 1024) return -1;
+  if (!slabs || B > max_slabs) return -1;
+  C1WgArgs a;
+  a.in = static_cast<const uint8_t*>(in); a.idx = idx; a.dy = dy; a.out = (B == 1) ? dwb : slabs;
+  a.B = B; a.H = g->H; a.W = g->W; a.OH = g->OH; a.OW = g->OW; a.S = g->S; a.KH = g->KH;
+  const float mean = fabsf(xf->mean) >= 1e-4f ? xf->mean : 0.f;
+  a.xs = 1.f / xf->std; a.xb = -mean * a.xs;
+  const int nsteps = (g->OH * g->OW + 15) / 16;
+  if (nsteps * 16 * 8 > 16 * 256) return -1;                 // dY staging: 16 float4 per thread
+  size_t lds = (size_t)HWC + (size_t)nsteps * 16 * 32 * 4 + (size_t)nsteps * 16 * 4;
+  if ((size_t)nsteps * 16 * 32 * 4 < (size_t)2 * 4 * 16 * 64 * 4) return -1;   // `red` aliases the dY region
+  if ((size_t)nsteps * 16 * 4 < 64 * 4) return -1;                              // `bred` aliases pixoff
+  if (lds > 81920) return -1;                                                    // two workgroups per CU
+  hipLaunchKernelGGL(conv_u8c4k8_wgrad_bf16x3_kernel, dim3(B), dim3(256), lds, st, a);
+  XT_LAUNCH_CHECK();
+  if (msplit_out) *msplit_out = B;
+  return 0;
 }
 
 }  // namespace xt

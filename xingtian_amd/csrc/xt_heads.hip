@@ -320,31 +320,108 @@ __device__ __forceinline__ void sum_partials(const float* __restrict__ part, int
   }
 }
 
-__global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const PpoHeadArgs p) {
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (b >= p.B) return;
+// One wave (= one 64-thread workgroup) per sample.  The sample's features stay in registers (F <= 512: up to 8
+// per lane), the A (+1) dot products are accumulated together and reduced with interleaved shuffles, so the
+// dependent chain is: [partials] -> features -> logits/value -> loss -> d-features.
+constexpr int kHeadFPL = 8;     // features per lane held in registers
+constexpr int kHeadAU = 8;      // actions accumulated per pass
+constexpr int kMaxHeadSplit = 16; // split-K partial slabs the fused head kernel can finish
+
+__global__ __launch_bounds__(64) void ppo_heads_fused_kernel(const PpoHeadArgs p) {
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
   const int F = p.F, A = p.A;
-  if (p.part_pi) {      // split-K finish of the pi/shared trunk's last layer, fused here
-    sum_partials(p.part_pi, p.ksplit_pi, p.part_stride, (size_t)b * F, F, lane, p.tbias_pi, p.act_feat,
-                 p.feat_pi_w + (size_t)b * F);
+  const size_t row = (size_t)b * F;
+  // labels first: idx -> label is a two-hop dependent load chain; issue it before everything else so that it
+  // overlaps the feature phase instead of extending the critical path
+  const int s = p.idx ? p.idx[b] : b;
+  const int act = p.action[s];
+  const float advf = (float)p.adv[s];
+  const float tv = (float)p.target_v[s];
+  const float ov = p.old_v[s];
+  const float olp = p.old_logp[s];
+  // ---- features (optionally finishing the split-K partial sums of the last trunk layer).  No stores in this
+  // phase (they would fence the loads of the next feature group); features are written back at the very end.
+  const int nq = (F + 63) >> 6;                 // wave-uniform
+  const float* __restrict__ ppi = p.part_pi;
+  const float* __restrict__ pv = p.part_v;
+  float fpi[kHeadFPL], fvv[kHeadFPL];
+#pragma unroll
+  for (int q = 0; q < kHeadFPL; ++q) {
+    fpi[q] = 0.f; fvv[q] = 0.f;
+    if (q < nq) {
+      const int f = lane + 64 * q;
+      const bool ok = f < F;
+      const int fc = ok ? f : 0;
+      float x;
+      if (ppi) {
+        float v[kMaxHeadSplit];
+#pragma unroll
+        for (int z = 0; z < kMaxHeadSplit; ++z) {
+          const float y = ppi[(size_t)(z < p.ksplit_pi ? z : p.ksplit_pi - 1) * p.part_stride + row + fc];
+          v[z] = z < p.ksplit_pi ? y : 0.f;
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int z = 0; z < kMaxHeadSplit; z += 4) s += (v[z] + v[z + 1]) + (v[z + 2] + v[z + 3]);
+        x = act_apply(s + p.tbias_pi[fc], p.act_feat);
+      } else {
+        x = p.f_pi[row + fc];
+      }
+      fpi[q] = ok ? x : 0.f;
+      float xv = x;
+      if (!p.shared) {
+        if (pv) {
+          float v[kMaxHeadSplit];
+#pragma unroll
+          for (int z = 0; z < kMaxHeadSplit; ++z) {
+            const float y = pv[(size_t)(z < p.ksplit_v ? z : p.ksplit_v - 1) * p.part_stride + row + fc];
+            v[z] = z < p.ksplit_v ? y : 0.f;
+          }
+          float s = 0.f;
+#pragma unroll
+          for (int z = 0; z < kMaxHeadSplit; z += 4) s += (v[z] + v[z + 1]) + (v[z + 2] + v[z + 3]);
+          xv = act_apply(s + p.tbias_v[fc], p.act_feat);
+        } else {
+          xv = p.f_v[row + fc];
+        }
+      }
+      fvv[q] = ok ? xv : 0.f;
+    }
   }
-  if (p.part_v) {
-    sum_partials(p.part_v, p.ksplit_v, p.part_stride, (size_t)b * F, F, lane, p.tbias_v, p.act_feat,
-                 p.feat_v_w + (size_t)b * F);
-  }
-  // each lane re-reads only feature elements it wrote itself (same f striding) -> program order suffices
-  const float* fp = p.f_pi + (size_t)b * F;
-  const float* fv = p.f_v + (size_t)b * F;
+  // ---- logits (lane a keeps logit a) and value
   float mylogit = -INFINITY;
-  for (int a = 0; a < A; ++a) {
-    float s = 0.f;
-    for (int f = lane; f < F; f += 64) s = fmaf(fp[f], p.wpi[(size_t)f * A + a], s);
-    s = wave_sum(s);
-    if (lane == a) mylogit = s + p.bpi[a];
+  for (int a0 = 0; a0 < A; a0 += kHeadAU) {
+    float acc[kHeadAU];
+#pragma unroll
+    for (int u = 0; u < kHeadAU; ++u) acc[u] = 0.f;
+#pragma unroll
+    for (int q = 0; q < kHeadFPL; ++q) {
+      if (q < nq) {
+        const int f = lane + 64 * q;
+        const int fc = f < F ? f : 0;
+#pragma unroll
+        for (int u = 0; u < kHeadAU; ++u) {
+          const int a = a0 + u;
+          if (a < A) acc[u] = fmaf(fpi[q], p.wpi[(size_t)fc * A + a], acc[u]);   // fpi == 0 beyond F; a<A uniform
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kHeadAU; ++u) {
+      const float s = wave_sum(acc[u]);
+      const int a = a0 + u;
+      if (a < A && lane == a) mylogit = s + p.bpi[a];
+    }
   }
   float sv = 0.f;
-  for (int f = lane; f < F; f += 64) sv = fmaf(fv[f], p.wv[f], sv);
+#pragma unroll
+  for (int q = 0; q < kHeadFPL; ++q) {
+    if (q < nq) {
+      const int f = lane + 64 * q;
+      sv = fmaf(fvv[q], p.wv[f < F ? f : 0], sv);
+    }
+  }
   const float v = wave_sum(sv) + p.bv[0];
 
   const bool la = lane < A;
@@ -355,14 +432,9 @@ __global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const PpoHeadArgs 
   const float logz = logf(z);
   const float pa = e / z;
   const float ent = wave_sum(la ? pa * (logz - rl) : 0.f);
-  const int s = p.idx ? p.idx[b] : b;
-  const int act = p.action[s];
   const float lpa = rl - logz;
   const float logp = __shfl(lpa, act, 64);
-  const float advf = (float)p.adv[s];
-  const float tv = (float)p.target_v[s];
-  const float ov = p.old_v[s];
-  const float ratio = expf(logp - p.old_logp[s]);
+  const float ratio = expf(logp - olp);
   const float surr1 = ratio * advf;
   const float rc = fminf(fmaxf(ratio, 1.f - p.clip_ratio), 1.f + p.clip_ratio);
   const float surr2 = rc * advf;
@@ -389,16 +461,33 @@ __global__ __launch_bounds__(256) void ppo_heads_fused_kernel(const PpoHeadArgs 
     float* tm = p.terms + (size_t)b * 4;
     tm[0] = fminf(surr1, surr2); tm[1] = ent; tm[2] = fmaxf(vf1, vf2); tm[3] = 0.f;
   }
-  // d(features) = dlogits . Wpi^T (+ dvalue . Wv^T), times the producer's activation gradient
-  for (int f = lane; f < F; f += 64) {
-    float acc = 0.f;
-    for (int a = 0; a < A; ++a) acc = fmaf(__shfl(dl, a, 64), p.wpi[(size_t)f * A + a], acc);
-    const float svv = dv * p.wv[f];
-    if (p.shared) {
-      p.df_pi[(size_t)b * F + f] = (acc + svv) * act_grad(fp[f], p.act_prev);
-    } else {
-      p.df_pi[(size_t)b * F + f] = acc * act_grad(fp[f], p.act_prev);
-      p.df_v[(size_t)b * F + f] = svv * act_grad(fv[f], p.act_prev);
+  // ---- d(features) = dlogits . Wpi^T (+ dvalue . Wv^T), times the producer's activation gradient
+  float dacc[kHeadFPL];
+#pragma unroll
+  for (int q = 0; q < kHeadFPL; ++q) dacc[q] = 0.f;
+  for (int a = 0; a < A; ++a) {
+    const float dla = __shfl(dl, a, 64);          // every lane active here
+#pragma unroll
+    for (int q = 0; q < kHeadFPL; ++q) {
+      if (q < nq) {
+        const int f = lane + 64 * q;
+        dacc[q] = fmaf(dla, p.wpi[(size_t)(f < F ? f : 0) * A + a], dacc[q]);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kHeadFPL; ++q) {
+    const int f = lane + 64 * q;
+    if (q < nq && f < F) {
+      if (ppi) p.feat_pi_w[row + f] = fpi[q];
+      if (!p.shared && pv) p.feat_v_w[row + f] = fvv[q];
+      const float svv = dv * p.wv[f];
+      if (p.shared) {
+        p.df_pi[row + f] = (dacc[q] + svv) * act_grad(fpi[q], p.act_prev);
+      } else {
+        p.df_pi[row + f] = dacc[q] * act_grad(fpi[q], p.act_prev);
+        p.df_v[row + f] = svv * act_grad(fvv[q], p.act_prev);
+      }
     }
   }
 }
@@ -410,8 +499,8 @@ __global__ __launch_bounds__(256) void heads_wgrad_partial_kernel(const HeadWgAr
 }
 
 int launch_ppo_heads_fused(const PpoHeadArgs& a, hipStream_t st) {
-  XT_REQUIRE(a.A <= 64, "ppo_heads_fused: A=%d > 64", a.A);
-  hipLaunchKernelGGL(ppo_heads_fused_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, a);
+  XT_REQUIRE(a.A <= 64 && a.F <= 64 * kHeadFPL, "ppo_heads_fused: A=%d > 64 or F=%d > %d", a.A, a.F, 64 * kHeadFPL);
+  hipLaunchKernelGGL(ppo_heads_fused_kernel, dim3(a.B), dim3(64), 0, st, a);
   XT_LAUNCH_CHECK();
   return 0;
 }

@@ -167,8 +167,11 @@ struct FwdArgs {
 // PADDED: the receptive field can leave the image (TF SAME) -> per-element bounds checks; VALID convs and
 // dense layers skip them.  Row base offsets are computed once per block; a k-step costs one (ky,kx,c)
 // decode per thread plus one 64-bit add per row.
-template <int BI, int BJ, int WI, int WJ, bool U8, bool PADDED>
-__global__ __launch_bounds__(256) void igemm_fwd_kernel(const FwdArgs p) {
+// KG = 2: the block has two 4-wave groups that split the reduction range in halves, each with its own LDS
+// stages (same barriers), combined through LDS at the end: halves the dependent step chain of kernels that have
+// too few blocks to fill the chip (<= 1 block per CU) without partial buffers or a finish launch.
+template <int BI, int BJ, int WI, int WJ, bool U8, bool PADDED, int KG>
+__global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
   constexpr int TI = BI / (32 * WI), TJ = BJ / (32 * WJ);
   constexpr int SA = BI + 1, SB = BJ;
   constexpr int NA = BI / 32;            // 4-element fetches per thread for A
@@ -176,12 +179,17 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const FwdArgs p) {
   constexpr int RPB = 256 / CPRB;        // B rows per pass
   constexpr int NB = 32 / RPB;
   constexpr int BUF = 32 * SA + 32 * SB; // one LDS stage (A then B); two stages, one barrier per step
-  __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+  __shared__ __attribute__((aligned(16))) float smem_all[2 * BUF * KG];
   const Geom& g = p.g;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int grp = (KG == 1) ? 0 : (int)(threadIdx.x >> 8);
+  float* smem = smem_all + grp * 2 * BUF;
+  const int t = threadIdx.x & 255, lane = t & 63, wave = t >> 6;
   const int i0 = blockIdx.x * BI, j0 = blockIdx.y * BJ;
-  const int kbeg = blockIdx.z * p.kchunk;
-  const int kend = min(g.K, kbeg + p.kchunk);
+  const int kbeg0 = blockIdx.z * p.kchunk;
+  const int kend0 = min(g.K, kbeg0 + p.kchunk);
+  const int nsteps_all = ((kend0 - kbeg0 + 31) / 32 + KG - 1) / KG;     // block-uniform loop length
+  const int kbeg = kbeg0 + grp * nsteps_all * 32;
+  const int kend = min(kend0, kbeg + nsteps_all * 32);
 
   const int c4 = t & 7, r0 = t >> 3;
   long long rowbase[NA];
@@ -246,21 +254,43 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const FwdArgs p) {
       for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
 
   const int wi = wave / WJ, wj = wave % WJ;
-  const int nsteps = (kend - kbeg + 31) / 32;
+  const int nsteps = kend > kbeg ? (kend - kbeg + 31) / 32 : 0;      // this group's steps (<= nsteps_all)
   Regs R0, R1;
   if (nsteps > 0) fetch(kbeg, R0);
   if (nsteps > 1) fetch(kbeg + 32, R1);
-  for (int s = 0; s < nsteps; s += 2) {
-    stash(R0, smem, smem + 32 * SA);
+  for (int s = 0; s < nsteps_all; s += 2) {
+    if (s < nsteps) stash(R0, smem, smem + 32 * SA);
     __syncthreads();
     if (s + 2 < nsteps) fetch(kbeg + (s + 2) * 32, R0);
-    mma_tile<TI, TJ, SA, SB>(smem, smem + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
-    if (s + 1 < nsteps) {
-      stash(R1, smem + BUF, smem + BUF + 32 * SA);
+    if (s < nsteps) mma_tile<TI, TJ, SA, SB>(smem, smem + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+    if (s + 1 < nsteps_all) {
+      if (s + 1 < nsteps) stash(R1, smem + BUF, smem + BUF + 32 * SA);
       __syncthreads();
       if (s + 3 < nsteps) fetch(kbeg + (s + 3) * 32, R1);
-      mma_tile<TI, TJ, SA, SB>(smem + BUF, smem + BUF + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+      if (s + 1 < nsteps)
+        mma_tile<TI, TJ, SA, SB>(smem + BUF, smem + BUF + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
     }
+  }
+  if (KG == 2) {
+    // combine the two groups' accumulators: group 1 -> LDS (its own stage region, idle after a barrier)
+    __syncthreads();
+    float* red = smem_all + 2 * BUF;
+    if (grp == 1) {
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((ti * TJ + tj) * 16 + r) * 256 + t] = acc[ti][tj][r];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ti][tj][r] += red[((ti * TJ + tj) * 16 + r) * 256 + t];
   }
 
   const bool final_out = (p.ksplit == 1);
@@ -617,20 +647,27 @@ __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int b
   }
   if (Kc == 0) __syncthreads();   // rowOut visibility
 
+  // epilogue in two phases: ALL producer activations are loaded first (clamped, unconditional), then the
+  // masked gradients are stored -- interleaving load/store serialised 16 global-load latencies per tile
+  // (x and dx may alias as far as the compiler knows).
 #pragma unroll
   for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
       const int c = j0 + (wj * TJ + tj) * 32 + (lane & 31);
+      const bool cok = c < g.C;
+      int offs[16];
+      float xv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int il = (wi * TI + ti) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int off = rowOut[il];
-        if (off >= 0 && c < g.C) {
-          const float xv = p.x[(size_t)off + c];
-          p.dx[(size_t)off + c] = acc[ti][tj][r] * act_grad(xv, p.act_prev);
-        }
+        offs[r] = rowOut[il];
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xv[r] = p.x[(offs[r] >= 0 && cok) ? (size_t)offs[r] + c : (size_t)0];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (offs[r] >= 0 && cok) p.dx[(size_t)offs[r] + c] = acc[ti][tj][r] * act_grad(xv[r], p.act_prev);
     }
 }
 
@@ -692,6 +729,12 @@ int launch_conv1_fwd_bf16x3(const xt_conv_geom*, const xt_input_xform*, int, con
 int launch_conv1_wgrad_bf16x3(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*,
                               const float*, float*, float*, int, int*, hipStream_t);
 
+static bool use_kg2() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("XT_NO_KG2"); v = (e && e[0] == '1') ? 0 : 1; }
+  return v == 1;
+}
+
 static bool use_bf16x3() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("XT_NO_BF16X3"); v = (e && e[0] == '1') ? 0 : 1; }
@@ -717,16 +760,22 @@ int launch_fwd(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const vo
   a.y = ksplit == 1 ? y : partial;
   const int M = a.g.M, N = a.g.N;
   const bool pad = is_padded(a.g);
-#define XT_FWD(BI, BJ, WI, WJ)                                                                              \
+  // two wave groups per block when the launch cannot fill the chip and the step chain is long
+  const int nblk = (N <= 32 ? ((M + 127) / 128) * ((N + 31) / 32) : ((M + 63) / 64) * ((N + 63) / 64)) * ksplit;
+  const bool kg2 = use_kg2() && nblk <= 320 && chunk >= 8 * 32;
+#define XT_FWD2(BI, BJ, WI, WJ, KGV)                                                                        \
   do {                                                                                                      \
     dim3 grid((M + BI - 1) / BI, (N + BJ - 1) / BJ, ksplit);                                                \
-    if (u8 && pad) hipLaunchKernelGGL((igemm_fwd_kernel<BI, BJ, WI, WJ, true, true>), grid, dim3(256), 0, st, a);    \
-    else if (u8) hipLaunchKernelGGL((igemm_fwd_kernel<BI, BJ, WI, WJ, true, false>), grid, dim3(256), 0, st, a);     \
-    else if (pad) hipLaunchKernelGGL((igemm_fwd_kernel<BI, BJ, WI, WJ, false, true>), grid, dim3(256), 0, st, a);    \
-    else hipLaunchKernelGGL((igemm_fwd_kernel<BI, BJ, WI, WJ, false, false>), grid, dim3(256), 0, st, a);            \
+    dim3 blk(256 * KGV);                                                                                    \
+    if (u8 && pad) hipLaunchKernelGGL((igemm_fwd_kernel<BI, BJ, WI, WJ, true, true, KGV>), grid, blk, 0, st, a);     \
+    else if (u8) hipLaunchKernelGGL((igemm_fwd_kernel<BI, BJ, WI, WJ, true, false, KGV>), grid, blk, 0, st, a);      \
+    else if (pad) hipLaunchKernelGGL((igemm_fwd_kernel<BI, BJ, WI, WJ, false, true, KGV>), grid, blk, 0, st, a);     \
+    else hipLaunchKernelGGL((igemm_fwd_kernel<BI, BJ, WI, WJ, false, false, KGV>), grid, blk, 0, st, a);             \
   } while (0)
+#define XT_FWD(BI, BJ, WI, WJ) do { if (kg2) XT_FWD2(BI, BJ, WI, WJ, 2); else XT_FWD2(BI, BJ, WI, WJ, 1); } while (0)
   if (N <= 32) XT_FWD(128, 32, 4, 1); else XT_FWD(64, 64, 2, 2);
 #undef XT_FWD
+#undef XT_FWD2
   XT_LAUNCH_CHECK();
   if (deferred_ksplit) *deferred_ksplit = ksplit;     // caller sums the partials itself (fused head kernel)
   if (ksplit > 1 && !deferred_ksplit) {
@@ -740,7 +789,12 @@ int launch_fwd(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const vo
 
 int launch_wgrad(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const void* in, const int32_t* idx,
                  const float* dy, float* dwb, float* slabs, int msplit, hipStream_t st, int reduce_now,
-                 int* msplit_out) {
+                 int* msplit_out, int slab_cap) {
+  if (use_bf16x3() && slabs && !reduce_now && slab_cap >= B) {   // uint8 first layer: one slab per frame stack
+    int ms = 0;
+    const int rc = launch_conv1_wgrad_bf16x3(cg, xf, B, in, idx, dy, dwb, slabs, slab_cap, &ms, st);
+    if (rc >= 0) { if (msplit_out) *msplit_out = ms; return rc; }
+  }
   WgradArgs a;
   if (int rc = make_geom(cg, xf, B, &a.g)) return rc;
   const bool u8 = xf && xf->is_u8;
@@ -856,7 +910,7 @@ int xt_layer_fwd(const xt_conv_geom* g, const xt_input_xform* xf, int32_t B, con
 
 int xt_layer_wgrad(const xt_conv_geom* g, const xt_input_xform* xf, int32_t B, const void* in, const int32_t* idx,
                    const float* dy, float* dwb, float* slabs, int32_t msplit, void* stream) {
-  return xt::launch_wgrad(g, xf, B, in, idx, dy, dwb, slabs, msplit, xt::as_stream(stream), 1, nullptr);
+  return xt::launch_wgrad(g, xf, B, in, idx, dy, dwb, slabs, msplit, xt::as_stream(stream), 1, nullptr, 0);
 }
 
 int xt_layer_dgrad(const xt_conv_geom* g, int32_t B, const float* dy, const float* w, const float* x,

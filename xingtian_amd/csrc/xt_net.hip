@@ -25,7 +25,7 @@ int launch_fwd(const xt_conv_geom*, const xt_input_xform*, int, const void*, con
 int launch_bwd_layer(const xt_conv_geom*, int, const float*, const float*, const float*, int, float*, float*, float*,
                      int, const HeadWgArgs*, int*, hipStream_t);
 int launch_wgrad(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*, const float*,
-                 float*, float*, int, hipStream_t, int reduce_now = 1, int* msplit_out = nullptr);
+                 float*, float*, int, hipStream_t, int reduce_now = 1, int* msplit_out = nullptr, int slab_cap = 0);
 int launch_dgrad(const xt_conv_geom*, int, const float*, const float*, const float*, int, float*, hipStream_t);
 int launch_global_norm(const float*, long long, float, float, float, float, float, int, float*, float*, hipStream_t);
 int launch_grads_finish(GradTable*, float*, int, int*, const FinalizeArgs*, hipStream_t);
@@ -46,6 +46,7 @@ struct Layer {
   int64_t slab_off;            // this layer's wgrad slabs
   int64_t part_off;            // split-K partials of a trunk's last layer (deferred finish), else -1
   int last_msplit, last_ksplit;
+  int slab_cap;                // number of slabs the region can hold
 };
 
 static inline int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
@@ -87,15 +88,21 @@ static int fwd_split(const Layer& L, int B) {
   const int tiles = (N <= 32) ? ((M + 127) / 128) * ((N + 31) / 32) : ((M + 63) / 64) * ((N + 63) / 64);
   const int ksteps = (L.K + 31) / 32;
   if (tiles >= 128 || ksteps < 4) return 1;
-  int s = 512 / tiles;
+  // note: the fused PPO head kernel finishes at most 16 partial slabs (kMaxHeadSplit)
+  static int target = -1;
+  if (target < 0) { const char* e = getenv("XT_FWD_SPLIT_TARGET"); target = e ? atoi(e) : 256; }   // measured: 256 beats 512/128 (Dense 3136->256: 16.6 vs 20.7 us)
+  int s = target / tiles;
   if (s > ksteps / 2) s = ksteps / 2;
+  if (s > 16) s = 16;
   return s < 1 ? 1 : s;
 }
 static int wgrad_split(const Layer& L, int B) {
   const int M = B * L.OHOW, N = L.g.N;
   const int tiles = (N <= 32) ? ((L.K + 127) / 128) * ((N + 31) / 32) : ((L.K + 63) / 64) * ((N + 63) / 64);
   const int msteps = (M + 31) / 32;
-  int s = 512 / tiles;
+  static int wtarget = -1;
+  if (wtarget < 0) { const char* e = getenv("XT_WGRAD_SPLIT_TARGET"); wtarget = e ? atoi(e) : 512; }
+  int s = wtarget / tiles;
   if (s > msteps / 4) s = msteps / 4;
   return s < 1 ? 1 : s;
 }
@@ -140,7 +147,7 @@ static int layer_wgrad(xt_net* n, int l, bool first, const void* obs, const int3
   Layer& L = n->layers[l];
   const void* x = first ? obs : (const void*)(n->ws + n->layers[l - 1].act_off);
   return launch_wgrad(&L.g, first ? &n->xf : nullptr, B, x, first ? idx : nullptr, n->ws + L.dact_off,
-                      n->grads + L.poff, n->ws + L.slab_off, wgrad_split(L, B), st, 0, &L.last_msplit);
+                      n->grads + L.poff, n->ws + L.slab_off, wgrad_split(L, B), st, 0, &L.last_msplit, L.slab_cap);
 }
 
 static int heads_wgrad(xt_net* n, int B, hipStream_t st) {
@@ -277,14 +284,14 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
                     const double* target_v, int apply, float* loss_out, float* loss_acc, hipStream_t st) {
   XT_REQUIRE(n->params && n->ws, "xt_net: buffers not bound (call xt_net_bind)");
   XT_REQUIRE(B > 0 && B <= n->maxB, "xt_net_ppo_step: batch %d outside (0,%d]", B, n->maxB);
-  const bool fused_head = (n->A <= 64);
+  const bool fused_head = (n->A <= 64 && n->feat <= 512);
   if (int rc = net_forward(n, obs, idx, B, false, st, fused_head)) return rc;
   const float inv_b = 1.f / (float)(c->global_batch > 0 ? c->global_batch : B);
   Layer& Lp = n->layers[n->t_end[0] - 1];
   Layer& Lv = n->layers[n->t_end[n->n_trunks - 1] - 1];
   const int F = n->feat, A = n->A;
   float* lo = loss_out ? loss_out : n->ws + n->off_loss;
-  if (A <= 64) {
+  if (fused_head) {
     PpoHeadArgs h;
     h.f_pi = n->ws + Lp.act_off; h.f_v = n->ws + Lv.act_off;
     h.wpi = n->params + n->pi_off; h.bpi = h.wpi + (int64_t)F * A; h.wv = n->params + n->v_off; h.bv = h.wv + F;
@@ -373,7 +380,10 @@ int xt_net_create(const xt_net_desc* d, int32_t max_batch, xt_net** out) {
     n->layers.push_back(L);
     // wgrad slab bound: msplit <= max(1, 512/tiles) slabs of (K+1)*N floats
     const int tiles = (L.g.N <= 32) ? ((L.K + 127) / 128) : ((L.K + 63) / 64) * ((L.g.N + 63) / 64);
-    const int64_t sl = (int64_t)((512 / tiles) < 1 ? 1 : (512 / tiles)) * (int64_t)(L.K + 1) * L.g.N;
+    int nsl = (512 / tiles) < 1 ? 1 : (512 / tiles);
+    if (i == n->t_begin[cur] && nsl < max_batch) nsl = max_batch;   // first layer: one slab per sample (bf16x3 wgrad)
+    const int64_t sl = (int64_t)nsl * (int64_t)(L.K + 1) * L.g.N;
+    n->layers.back().slab_cap = nsl;
     n->layers.back().slab_off = off; off += xt::align4(sl);
     n->layers.back().last_msplit = 1;
     n->layers.back().last_ksplit = 1;
@@ -568,7 +578,8 @@ int xt_net_time_layer(xt_net* n, int32_t layer, int32_t which, const void* obs, 
                             xt::fwd_split(L, B), st);
     if (which == 1)
       return xt::launch_wgrad(&L.g, first ? &n->xf : nullptr, B, x, first ? idx : nullptr, n->ws + L.dact_off,
-                              n->grads + L.poff, n->ws + L.slab_off, xt::wgrad_split(L, B), st, 0, &L.last_msplit);
+                              n->grads + L.poff, n->ws + L.slab_off, xt::wgrad_split(L, B), st, 0, &L.last_msplit,
+                              L.slab_cap);
     xt::Layer& Lp = n->layers[layer - 1];
     if (which == 3)   // the fused per-layer backward launch (dgrad + wgrad) used by the update loop
       return xt::launch_bwd_layer(&L.g, B, n->ws + Lp.act_off, n->ws + L.dact_off, n->params + L.poff, Lp.g.act,
