@@ -105,6 +105,51 @@ def cpu_baseline(obs, action, logp, value, reward, done, max_seconds=20.0):
             "ms_per_sgd_step": per_step * 1e3}
 
 
+def main_impala(args):
+    """Secondary workload: examples/breakout_impala.yaml -- one 'step' = 64 learner trains, each on one
+    128-frame message (prepare_times_per_train=1, BATCH_SIZE 512 >= 128), rollout resident in HBM."""
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        raise RuntimeError("--workload impala is a single-GPU measurement")
+    torch.cuda.set_device(0)
+    from xingtian_amd.model import netspec
+    from xingtian_amd.model.hip_net import HipActorCritic
+    n_msg, t_len, a_dim = 64, 128, 4
+    rng = np.random.default_rng(0)
+    n = n_msg * t_len
+    dev = torch.device("cuda", 0)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    obs = d(rng.integers(0, 256, (n,) + STATE_DIM, dtype=np.uint8))
+    bp = d(rng.standard_normal((n, a_dim)).astype(np.float32))
+    act = d(rng.integers(0, a_dim, n).astype(np.int32))
+    done = d((rng.random(n) < 0.01).astype(np.uint8))
+    rew = d(rng.choice([-1.0, 0.0, 1.0], n, p=[0.05, 0.9, 0.05]).astype(np.float32))
+    spec = netspec.impala_cnn_opt(STATE_DIM, a_dim, 0.0, 255.0)
+    net = HipActorCritic(spec, max_batch=t_len, seed=0)
+    cfg = net.make_impala_cfg(5e-4, 40.0, t_len)
+
+    def one_update():
+        for i in range(n_msg):
+            sl = slice(i * t_len, (i + 1) * t_len)
+            net.impala_step(cfg, obs[sl], bp[sl], act[sl], done[sl], rew[sl], apply=True)
+
+    for _ in range(args.warmup):
+        one_update()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_update()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    assert torch.isfinite(net.params).all()
+    print(json.dumps({
+        "metric": "learner env-frames/sec (Atari 84x84x4)", "value": FRAME_SKIP * n * args.steps / el,
+        "unit": "env-frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "fp32", "data": "synthetic",
+        "config": {"workload": "examples/breakout_impala.yaml ImpalaCnnOpt 84x84x4 uint8 + v-trace, 64 messages x "
+                               "T=128 frames per step (one SGD step per message), HBM-resident", "parallelism": "dp1"}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,7 +157,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--workload", default="ppo", choices=["ppo", "impala"],
+                    help="ppo = BASELINE configs[1] (the headline metric, default); impala = configs[2] "
+                         "(breakout_impala.yaml, ImpalaCnnOpt + v-trace, env_num=64 messages of T=128), secondary")
     args = ap.parse_args()
+    if args.workload == "impala":
+        return main_impala(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -211,7 +261,7 @@ def main():
             mnk2 = 2.0 * bsz * lay.OH * lay.OW * lay.N * lay.K
             if li == 0:
                 kern["L0 conv8x8/4 fwd  [conv_u8c4k8_fwd_bf16x3_kernel]"] = (net.time_layer(0, 0, d_obs, idx, bsz, 50), mnk2, "bf16x3")
-                kern["L0 conv8x8/4 wgrad [igemm_wgrad_kernel<128,32,4,1,u8>]"] = (net.time_layer(0, 1, d_obs, idx, bsz, 50), mnk2, "fp32")
+                kern["L0 conv8x8/4 wgrad [conv_u8c4k8_wgrad_bf16x3_kernel]"] = (net.time_layer(0, 1, d_obs, idx, bsz, 50), mnk2, "bf16x3")
             else:
                 kern["L%d %s fwd  [igemm_fwd_kernel]" % (li, lay.name)] = (net.time_layer(li, 0, d_obs, idx, bsz, 50), mnk2, "fp32")
                 kern["L%d %s dgrad+wgrad [igemm_bwd_layer_kernel]" % (li, lay.name)] = (

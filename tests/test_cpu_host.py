@@ -113,7 +113,9 @@ def test_netspec_matches_oracle_spec(which):
     olayers = [l for tr in o["trunks"] for l in tr]
     assert len(olayers) == len(s.layers)
     for a, b in zip(s.layers, olayers):
-        assert (a.OH, a.OW, a.PT, a.PL, a.N, a.C) == (b.out_h, b.out_w, b.pt, b.pl, b.cout, b.cin), a.name
+        assert (a.OH, a.OW, a.PT, a.PL, a.N) == (b.out_h, b.out_w, b.pt, b.pl, b.cout), a.name
+        # a full-image VALID conv is lowered to a dense layer over the flattened input (same K, same memory)
+        assert a.K == (b.k * b.k * b.cin if b.kind == "conv" else b.cin), a.name
         assert a.param_off % 4 == 0
     # flat layout: blocks do not overlap
     spans = sorted((off, off + int(np.prod(shape))) for off, shape in s.names.values())

@@ -14,6 +14,7 @@ from xingtian_amd import lib as L  # noqa: E402
 if len(sys.argv) > 1 and sys.argv[1].endswith(".so"):
     L.LIB_PATH = os.path.abspath(sys.argv[1])
 BS = [int(a) for a in sys.argv[1:] if a.isdigit()] or [320]
+FUSED = "fused" in sys.argv[1:]      # time the fused dgrad+wgrad launch instead of the two separate kernels
 from xingtian_amd.model import netspec  # noqa: E402
 from xingtian_amd.model.hip_net import HipActorCritic  # noqa: E402
 
@@ -31,11 +32,12 @@ for B in BS:
         tot = 0.0
         for li, lay in enumerate(spec.layers):
             flops = 2.0 * B * lay.OH * lay.OW * lay.N * lay.K
-            for which, nm in ((0, "fwd"), (1, "wgrad"), (2, "dgrad")):
+            kinds = ((0, "fwd"), (1, "wgrad"), (2, "dgrad")) if not FUSED else ((0, "fwd"), (3, "bwd") if li else (1, "wgrad"))
+            for which, nm in kinds:
                 if which == 2 and li == 0:
                     continue
                 ms = net.time_layer(li, which, obs, idx, B, reps=50)
                 tot += ms
                 if rep == 1:
-                    print("%-22s %-5s %8.2f us  %6.1f TFLOP/s" % (lay.name, nm, ms * 1e3, flops / ms / 1e9))
+                    print("%-22s %-5s %8.2f us  %6.1f TFLOP/s" % (lay.name, nm, ms * 1e3, (2 * flops if which == 3 else flops) / ms / 1e9))
     print("sum of layer kernels: %.1f us (ideal at 157.3 TF: %.1f us)" % (tot * 1e3, 31.313e6 * B / 157.3e12 * 1e6))

@@ -60,6 +60,13 @@ def _conv(name, h, w, c, cout, k, s, padding, act, trunk):
     lay.OW, lay.PL = conv_out(w, k, s, padding)
     lay.N, lay.act, lay.trunk = cout, act, trunk
     lay.kernel_shape = (k, k, c, cout)
+    if padding == "valid" and k == h == w:
+        # a VALID conv whose kernel covers the whole image (ImpalaCnnOpt's 11x11 -> 1x1x256,
+        # impala_cnn_opt.py:129-136) IS a dense layer on the NHWC-flattened input: HWIO kernel memory
+        # [ky,kx,c][n] == [in,out].  Run it as Dense so that the input gradient is one GEMM instead of a
+        # 121-tap gather of which a single tap is valid per pixel.  The TF kernel shape is kept for naming.
+        lay.H = lay.W = lay.KH = lay.KW = lay.S = 1
+        lay.C = h * w * c
     return lay
 
 
