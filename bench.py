@@ -157,6 +157,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--force-dp-path", action="store_true",
+                    help="run the N>1 code path (step-wise fwd/bwd -> RCCL all-reduce -> clip+Adam) even with one rank: "
+                         "validates the data-parallel plumbing on a single GPU")
     ap.add_argument("--workload", default="ppo", choices=["ppo", "impala"],
                     help="ppo = BASELINE configs[1] (the headline metric, default); impala = configs[2] "
                          "(breakout_impala.yaml, ImpalaCnnOpt + v-trace, env_num=64 messages of T=128), secondary")
@@ -171,9 +174,10 @@ def main():
         raise RuntimeError("bench.py needs a GPU: the learner path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dp_path:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node {}".format(args.gpus)
 
@@ -196,7 +200,8 @@ def main():
     perm_rng = np.random.default_rng(1234)   # identical on every rank
     d_perm = torch.empty((CFG["NUM_SGD_ITER"], n), dtype=torch.int32, device=dev)
     cfg = net.make_ppo_cfg(CFG, grad_scale=1.0 / world, global_batch=0)
-    use_graph = (world == 1) and not args.no_graph
+    dp_path = world > 1 or args.force_dp_path
+    use_graph = (not dp_path) and not args.no_graph
     bsz = CFG["BATCH_SIZE"]
 
     def new_perms():
@@ -212,7 +217,7 @@ def main():
         st = L.stream_ptr()
         L.check(lib.xt_gae_f64(L.ptr(d_value), L.ptr(d_reward), L.ptr(d_done), L.ptr(d_adv), L.ptr(d_tgt),
                                L.ptr(d_oldv), ENV_NUM, T_LEN, 0.99, 0.95, st), "gae")
-        if world == 1:
+        if not dp_path:
             net.ppo_train(cfg, d_obs, d_perm, d_act, d_logp, d_adv, d_oldv, d_tgt, use_graph=use_graph)
         else:
             for ep in range(CFG["NUM_SGD_ITER"]):
@@ -284,6 +289,7 @@ def main():
                            "sum_layer_kernels_us": round(sum(v[0] for v in kern.values()) * 1e3, 1)}
         total_flops = 31.313e6 * n * CFG["NUM_SGD_ITER"]
         out["update_tflops"] = total_flops * args.steps / elapsed / 1e12
+        out["config"]["dp_path"] = bool(dp_path)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(obs, action, logp, value, reward, done)
         print(json.dumps(out))

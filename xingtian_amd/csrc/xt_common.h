@@ -45,9 +45,13 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) {
   return f.d <= 1 ? n : __umulhi(n, f.magic);
 }
 
+// tanhf is ~60 instructions of libdevice code; kept OUT of line so that epilogues that apply the activation to
+// 16..64 accumulator registers do not inline it 64 times (code size = cold instruction-fetch time per launch)
+__device__ __noinline__ static float xt_tanhf(float z) { return tanhf(z); }
+
 __device__ __forceinline__ float act_apply(float z, int act) {
   if (act == XT_ACT_RELU) return z > 0.f ? z : 0.f;
-  if (act == XT_ACT_TANH) return tanhf(z);
+  if (act == XT_ACT_TANH) return xt_tanhf(z);
   return z;
 }
 // d(pre-activation)/d(post) from the saved OUTPUT y

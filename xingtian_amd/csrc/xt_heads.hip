@@ -320,109 +320,108 @@ __device__ __forceinline__ void sum_partials(const float* __restrict__ part, int
   }
 }
 
-// One wave (= one 64-thread workgroup) per sample.  The sample's features stay in registers (F <= 512: up to 8
-// per lane), the A (+1) dot products are accumulated together and reduced with interleaved shuffles, so the
-// dependent chain is: [partials] -> features -> logits/value -> loss -> d-features.
-constexpr int kHeadFPL = 8;     // features per lane held in registers
-constexpr int kHeadAU = 8;      // actions accumulated per pass
-constexpr int kMaxHeadSplit = 16; // split-K partial slabs the fused head kernel can finish
+// One wave (= one 64-thread workgroup) per sample, specialised on NQ = ceil(F/64) features per lane, on whether
+// the split-K partial slabs of the last trunk layer still have to be summed (PART) and on shared/separate trunks.
+// EVERY global load of the wave is issued before the first dependent instruction (the kernel is a pure latency
+// chain: 73 % of its wave cycles were s_waitcnt with the loads interleaved with their uses), the only two-hop
+// chain being idx -> labels.
+constexpr int kHeadMaxA = 8;          // actions handled by the fused kernel (A <= 8)
+constexpr int kMaxHeadSplit = 16;     // split-K partial slabs the fused head kernel can finish
 
+template <int NQ, bool PART, bool SHARED>
 __global__ __launch_bounds__(64) void ppo_heads_fused_kernel(const PpoHeadArgs p) {
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
   const int F = p.F, A = p.A;
   const size_t row = (size_t)b * F;
-  // labels first: idx -> label is a two-hop dependent load chain; issue it before everything else so that it
-  // overlaps the feature phase instead of extending the critical path
+  // ---------------- issue phase (no dependent use in here)
   const int s = p.idx ? p.idx[b] : b;
+  float praw[PART ? NQ : 1][kMaxHeadSplit], vraw[(PART && !SHARED) ? NQ : 1][kMaxHeadSplit];
+  float xin[NQ], xvin[NQ], tb[NQ], tbv[NQ], wvv[NQ], wp[NQ][kHeadMaxA];
+  int fcl[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int f = lane + 64 * q;
+    fcl[q] = f < F ? f : 0;
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    if (PART) {
+#pragma unroll
+      for (int z = 0; z < kMaxHeadSplit; ++z)
+        praw[q][z] = p.part_pi[(size_t)(z < p.ksplit_pi ? z : p.ksplit_pi - 1) * p.part_stride + row + fcl[q]];
+      tb[q] = p.tbias_pi[fcl[q]];
+      if (!SHARED) {
+#pragma unroll
+        for (int z = 0; z < kMaxHeadSplit; ++z)
+          vraw[q][z] = p.part_v[(size_t)(z < p.ksplit_v ? z : p.ksplit_v - 1) * p.part_stride + row + fcl[q]];
+        tbv[q] = p.tbias_v[fcl[q]];
+      }
+    } else {
+      xin[q] = p.f_pi[row + fcl[q]];
+      if (!SHARED) xvin[q] = p.f_v[row + fcl[q]];
+    }
+    wvv[q] = p.wv[fcl[q]];
+#pragma unroll
+    for (int a = 0; a < kHeadMaxA; ++a) wp[q][a] = p.wpi[(size_t)fcl[q] * A + (a < A ? a : 0)];
+  }
+  const float mybias = p.bpi[lane < A ? lane : 0];
+  const float bvv = p.bv[0];
+  // labels (second hop of idx)
   const int act = p.action[s];
   const float advf = (float)p.adv[s];
   const float tv = (float)p.target_v[s];
   const float ov = p.old_v[s];
   const float olp = p.old_logp[s];
-  // ---- features (optionally finishing the split-K partial sums of the last trunk layer).  No stores in this
-  // phase (they would fence the loads of the next feature group); features are written back at the very end.
-  const int nq = (F + 63) >> 6;                 // wave-uniform
-  const float* __restrict__ ppi = p.part_pi;
-  const float* __restrict__ pv = p.part_v;
-  float fpi[kHeadFPL], fvv[kHeadFPL];
+
+  // ---------------- features
+  float fpi[NQ], fvv[NQ];
 #pragma unroll
-  for (int q = 0; q < kHeadFPL; ++q) {
-    fpi[q] = 0.f; fvv[q] = 0.f;
-    if (q < nq) {
-      const int f = lane + 64 * q;
-      const bool ok = f < F;
-      const int fc = ok ? f : 0;
-      float x;
-      if (ppi) {
-        float v[kMaxHeadSplit];
+  for (int q = 0; q < NQ; ++q) {
+    const bool ok = lane + 64 * q < F;
+    float x, xv;
+    if (PART) {
+      float sacc = 0.f;
 #pragma unroll
-        for (int z = 0; z < kMaxHeadSplit; ++z) {
-          const float y = ppi[(size_t)(z < p.ksplit_pi ? z : p.ksplit_pi - 1) * p.part_stride + row + fc];
-          v[z] = z < p.ksplit_pi ? y : 0.f;
-        }
-        float s = 0.f;
+      for (int z = 0; z < kMaxHeadSplit; z += 4)
+        sacc += ((z < p.ksplit_pi ? praw[q][z] : 0.f) + (z + 1 < p.ksplit_pi ? praw[q][z + 1] : 0.f)) +
+                ((z + 2 < p.ksplit_pi ? praw[q][z + 2] : 0.f) + (z + 3 < p.ksplit_pi ? praw[q][z + 3] : 0.f));
+      x = act_apply(sacc + tb[q], p.act_feat);
+      xv = x;
+      if (!SHARED) {
+        float vacc = 0.f;
 #pragma unroll
-        for (int z = 0; z < kMaxHeadSplit; z += 4) s += (v[z] + v[z + 1]) + (v[z + 2] + v[z + 3]);
-        x = act_apply(s + p.tbias_pi[fc], p.act_feat);
-      } else {
-        x = p.f_pi[row + fc];
+        for (int z = 0; z < kMaxHeadSplit; z += 4)
+          vacc += ((z < p.ksplit_v ? vraw[q][z] : 0.f) + (z + 1 < p.ksplit_v ? vraw[q][z + 1] : 0.f)) +
+                  ((z + 2 < p.ksplit_v ? vraw[q][z + 2] : 0.f) + (z + 3 < p.ksplit_v ? vraw[q][z + 3] : 0.f));
+        xv = act_apply(vacc + tbv[q], p.act_feat);
       }
-      fpi[q] = ok ? x : 0.f;
-      float xv = x;
-      if (!p.shared) {
-        if (pv) {
-          float v[kMaxHeadSplit];
-#pragma unroll
-          for (int z = 0; z < kMaxHeadSplit; ++z) {
-            const float y = pv[(size_t)(z < p.ksplit_v ? z : p.ksplit_v - 1) * p.part_stride + row + fc];
-            v[z] = z < p.ksplit_v ? y : 0.f;
-          }
-          float s = 0.f;
-#pragma unroll
-          for (int z = 0; z < kMaxHeadSplit; z += 4) s += (v[z] + v[z + 1]) + (v[z + 2] + v[z + 3]);
-          xv = act_apply(s + p.tbias_v[fc], p.act_feat);
-        } else {
-          xv = p.f_v[row + fc];
-        }
-      }
-      fvv[q] = ok ? xv : 0.f;
+    } else {
+      x = xin[q];
+      xv = SHARED ? x : xvin[q];
     }
+    fpi[q] = ok ? x : 0.f;
+    fvv[q] = ok ? xv : 0.f;
   }
-  // ---- logits (lane a keeps logit a) and value
-  float mylogit = -INFINITY;
-  for (int a0 = 0; a0 < A; a0 += kHeadAU) {
-    float acc[kHeadAU];
+  // ---------------- logits (lane a keeps logit a) and value
+  float acc[kHeadMaxA];
 #pragma unroll
-    for (int u = 0; u < kHeadAU; ++u) acc[u] = 0.f;
+  for (int a = 0; a < kHeadMaxA; ++a) {
+    float t = 0.f;
 #pragma unroll
-    for (int q = 0; q < kHeadFPL; ++q) {
-      if (q < nq) {
-        const int f = lane + 64 * q;
-        const int fc = f < F ? f : 0;
-#pragma unroll
-        for (int u = 0; u < kHeadAU; ++u) {
-          const int a = a0 + u;
-          if (a < A) acc[u] = fmaf(fpi[q], p.wpi[(size_t)fc * A + a], acc[u]);   // fpi == 0 beyond F; a<A uniform
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < kHeadAU; ++u) {
-      const float s = wave_sum(acc[u]);
-      const int a = a0 + u;
-      if (a < A && lane == a) mylogit = s + p.bpi[a];
-    }
+    for (int q = 0; q < NQ; ++q) t = fmaf(fpi[q], wp[q][a], t);
+    acc[a] = t;
   }
   float sv = 0.f;
 #pragma unroll
-  for (int q = 0; q < kHeadFPL; ++q) {
-    if (q < nq) {
-      const int f = lane + 64 * q;
-      sv = fmaf(fvv[q], p.wv[f < F ? f : 0], sv);
-    }
+  for (int q = 0; q < NQ; ++q) sv = fmaf(fvv[q], wvv[q], sv);
+  float mylogit = -INFINITY;
+#pragma unroll
+  for (int a = 0; a < kHeadMaxA; ++a) {
+    const float t = wave_sum(acc[a]);
+    if (a < A && lane == a) mylogit = t + mybias;
   }
-  const float v = wave_sum(sv) + p.bv[0];
+  const float v = wave_sum(sv) + bvv;
 
   const bool la = lane < A;
   const float mx = wave_max(mylogit);
@@ -451,6 +450,17 @@ __global__ __launch_bounds__(64) void ppo_heads_fused_kernel(const PpoHeadArgs p
   const float dv = p.critic_coef * 0.5f * p.inv_b * dvr;
   const float onehot = (lane == act) ? 1.f : 0.f;
   const float dl = la ? dlogp * (onehot - pa) + p.ent_coef * p.inv_b * (pa * (lpa + ent)) : 0.f;
+  // ---------------- d(features) = dlogits . Wpi^T (+ dvalue . Wv^T), times the producer's activation gradient
+  float dacc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) dacc[q] = 0.f;
+#pragma unroll
+  for (int a = 0; a < kHeadMaxA; ++a) {
+    const float dla = __shfl(dl, a, 64);          // dl == 0 for lanes >= A
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) dacc[q] = fmaf(dla, wp[q][a], dacc[q]);
+  }
+  // ---------------- stores
   if (la) {
     p.logits[(size_t)b * A + lane] = mylogit;
     p.dlogits[(size_t)b * A + lane] = dl;
@@ -461,28 +471,16 @@ __global__ __launch_bounds__(64) void ppo_heads_fused_kernel(const PpoHeadArgs p
     float* tm = p.terms + (size_t)b * 4;
     tm[0] = fminf(surr1, surr2); tm[1] = ent; tm[2] = fmaxf(vf1, vf2); tm[3] = 0.f;
   }
-  // ---- d(features) = dlogits . Wpi^T (+ dvalue . Wv^T), times the producer's activation gradient
-  float dacc[kHeadFPL];
 #pragma unroll
-  for (int q = 0; q < kHeadFPL; ++q) dacc[q] = 0.f;
-  for (int a = 0; a < A; ++a) {
-    const float dla = __shfl(dl, a, 64);          // every lane active here
-#pragma unroll
-    for (int q = 0; q < kHeadFPL; ++q) {
-      if (q < nq) {
-        const int f = lane + 64 * q;
-        dacc[q] = fmaf(dla, p.wpi[(size_t)(f < F ? f : 0) * A + a], dacc[q]);
-      }
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < kHeadFPL; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     const int f = lane + 64 * q;
-    if (q < nq && f < F) {
-      if (ppi) p.feat_pi_w[row + f] = fpi[q];
-      if (!p.shared && pv) p.feat_v_w[row + f] = fvv[q];
-      const float svv = dv * p.wv[f];
-      if (p.shared) {
+    if (f < F) {
+      if (PART) {
+        p.feat_pi_w[row + f] = fpi[q];
+        if (!SHARED) p.feat_v_w[row + f] = fvv[q];
+      }
+      const float svv = dv * wvv[q];
+      if (SHARED) {
         p.df_pi[row + f] = (dacc[q] + svv) * act_grad(fpi[q], p.act_prev);
       } else {
         p.df_pi[row + f] = dacc[q] * act_grad(fpi[q], p.act_prev);
@@ -498,9 +496,23 @@ __global__ __launch_bounds__(256) void heads_wgrad_partial_kernel(const HeadWgAr
   heads_wgrad_partial_body(h, blockIdx.x, blockIdx.y, smem);
 }
 
+// returns -1 when the geometry is outside the fused kernel's envelope (caller falls back to the 3 plain kernels)
 int launch_ppo_heads_fused(const PpoHeadArgs& a, hipStream_t st) {
-  XT_REQUIRE(a.A <= 64 && a.F <= 64 * kHeadFPL, "ppo_heads_fused: A=%d > 64 or F=%d > %d", a.A, a.F, 64 * kHeadFPL);
-  hipLaunchKernelGGL(ppo_heads_fused_kernel, dim3(a.B), dim3(64), 0, st, a);
+  if (a.A > kHeadMaxA || a.F > 512) return -1;
+  const bool part = a.part_pi != nullptr;
+  const bool shared = a.shared != 0;
+  if (part && (a.ksplit_pi > kMaxHeadSplit || (!shared && (!a.part_v || a.ksplit_v > kMaxHeadSplit)))) return -1;
+  const int nq = (a.F + 63) / 64;
+  const dim3 grid(a.B), blk(64);
+#define XT_HEAD(NQV)                                                                                         \
+  do {                                                                                                       \
+    if (part && shared) hipLaunchKernelGGL((ppo_heads_fused_kernel<NQV, true, true>), grid, blk, 0, st, a);  \
+    else if (part) hipLaunchKernelGGL((ppo_heads_fused_kernel<NQV, true, false>), grid, blk, 0, st, a);      \
+    else if (shared) hipLaunchKernelGGL((ppo_heads_fused_kernel<NQV, false, true>), grid, blk, 0, st, a);    \
+    else hipLaunchKernelGGL((ppo_heads_fused_kernel<NQV, false, false>), grid, blk, 0, st, a);               \
+  } while (0)
+  if (nq <= 1) XT_HEAD(1); else if (nq <= 2) XT_HEAD(2); else if (nq <= 4) XT_HEAD(4); else XT_HEAD(8);
+#undef XT_HEAD
   XT_LAUNCH_CHECK();
   return 0;
 }

@@ -284,8 +284,10 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
                     const double* target_v, int apply, float* loss_out, float* loss_acc, hipStream_t st) {
   XT_REQUIRE(n->params && n->ws, "xt_net: buffers not bound (call xt_net_bind)");
   XT_REQUIRE(B > 0 && B <= n->maxB, "xt_net_ppo_step: batch %d outside (0,%d]", B, n->maxB);
-  const bool fused_head = (n->A <= 64 && n->feat <= 512);
-  if (int rc = net_forward(n, obs, idx, B, false, st, fused_head)) return rc;
+  bool fused_head = (n->A <= 8 && n->feat <= 512);
+  static int no_defer = -1;
+  if (no_defer < 0) { const char* e = getenv("XT_NO_DEFER"); no_defer = (e && e[0] == '1') ? 1 : 0; }
+  if (int rc = net_forward(n, obs, idx, B, false, st, fused_head && !no_defer)) return rc;
   const float inv_b = 1.f / (float)(c->global_batch > 0 ? c->global_batch : B);
   Layer& Lp = n->layers[n->t_end[0] - 1];
   Layer& Lv = n->layers[n->t_end[n->n_trunks - 1] - 1];
@@ -311,7 +313,11 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
       h.part_v = n->ws + Lv.part_off; h.ksplit_v = Lv.last_ksplit; h.feat_v_w = n->ws + Lv.act_off;
       h.tbias_v = n->params + Lv.poff + (int64_t)Lv.K * Lv.g.N;
     }
-    if (int rc = launch_ppo_heads_fused(h, st)) return rc;
+    XT_REQUIRE(n->n_trunks == 1 || ((Lp.last_ksplit > 1) == (Lv.last_ksplit > 1)),
+               "xt_net: pi and v trunks ended in different split-K states (unequal trunk shapes are not supported)");
+    const int hrc = launch_ppo_heads_fused(h, st);
+    if (hrc > 0) return hrc;
+    XT_REQUIRE(hrc == 0, "xt_net: fused PPO head kernel rejected the geometry (A=%d F=%d)", A, F);
   } else {
     if (int rc = xt_heads_fwd(n->ws + Lp.act_off, n->ws + Lv.act_off, B, F, A, n->params + n->pi_off,
                               n->params + n->pi_off + (int64_t)F * A, n->params + n->v_off, n->params + n->v_off + F,

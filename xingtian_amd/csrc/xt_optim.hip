@@ -2,6 +2,7 @@
 // Replaces build_train_op, xt/model/ppo/ppo.py:97-102 and impala_cnn_opt.py:204-217.
 // Three launches: per-block sum of squares (fixed order), single-block finalize
 // (norm, clip scale, bias-corrected step size, beta powers), vectorised Adam update.
+#include <stdlib.h>
 #include <string.h>
 #include "xt_common.h"
 
@@ -28,12 +29,24 @@ __global__ __launch_bounds__(256) void grads_finish_kernel(const GradTable tab, 
   const bool full = e0 + 3 < E.count;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   if (active) {
-    for (int z = z0; z < E.nslab; z += zl) {
-      const float* sp = E.src + (size_t)z * E.stride + e0;
-      if (full) {
-        const float4 q = *reinterpret_cast<const float4*>(sp);
-        a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
-      } else {
+    if (full) {
+      // 8 slabs in flight per thread (clamped unconditional loads): the plain one-load-per-iteration loop spent
+      // 74 % of its wave cycles in s_waitcnt
+      for (int zb = z0; zb < E.nslab; zb += 8 * zl) {
+        float4 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int z = zb + u * zl;
+          q[u] = *reinterpret_cast<const float4*>(E.src + (size_t)(z < E.nslab ? z : z0) * E.stride + e0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (zb + u * zl < E.nslab) { a.x += q[u].x; a.y += q[u].y; a.z += q[u].z; a.w += q[u].w; }
+        }
+      }
+    } else {
+      for (int z = z0; z < E.nslab; z += zl) {
+        const float* sp = E.src + (size_t)z * E.stride + e0;
         a.x += sp[0];
         if (e0 + 1 < E.count) a.y += sp[1];
         if (e0 + 2 < E.count) a.z += sp[2];
@@ -227,7 +240,9 @@ int launch_grads_finish(GradTable* tab, float* partial, int max_partials, int* n
   for (int i = 0; i < tab->n; ++i) {
     GradEntry& E = tab->e[i];
     int zl = 1;
-    while (zl < E.nslab && zl < 32) zl <<= 1;
+    static int zcap = -1;
+    if (zcap < 0) { const char* e = getenv("XT_ZL_CAP"); zcap = e ? atoi(e) : 8; }
+    while (zl < E.nslab && zl < zcap) zl <<= 1;   // fewer z lanes = longer contiguous runs per wave (512 B at 8)
     E.zl = zl;
     const int cols = 256 / zl;
     E.blk0 = blk;
