@@ -134,36 +134,67 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_fwd_bf16x3_kernel(const C1
   const float bias = p.bias[il];
   __syncthreads();
 
-  for (int s = 0; s < nsteps; ++s) {
-    BF8 b1, b2, b3;
-    {
-      const uint4 x1 = wpl[(s * 3 + 0) * 64 + lane], x2 = wpl[(s * 3 + 1) * 64 + lane], x3 = wpl[(s * 3 + 2) * 64 + lane];
-      b1.u[0] = x1.x; b1.u[1] = x1.y; b1.u[2] = x1.z; b1.u[3] = x1.w;
-      b2.u[0] = x2.x; b2.u[1] = x2.y; b2.u[2] = x2.z; b2.u[3] = x2.w;
-      b3.u[0] = x3.x; b3.u[1] = x3.y; b3.u[2] = x3.z; b3.u[3] = x3.w;
-    }
+  // software-pipelined main loop: the LDS reads of step s+1 (3 weight planes + one 8-byte pixel group per
+  // tile) are issued before the MFMAs of step s; MFMAs are issued plane-major so that consecutive
+  // instructions hit different accumulators (no dependent-accumulator stall).
+  uint4 wq[3];
+  uint2 aq[kC1MaxTiles];
+  auto lds_fetch = [&](int s) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) wq[pl] = wpl[(s * 3 + pl) * 64 + lane];
     const int koff = (s >> 1) * Wrow + (s & 1) * 16;
 #pragma unroll
-    for (int ti = 0; ti < kC1MaxTiles; ++ti) {
-      if (wave + 4 * ti < ntiles) {     // wave-uniform
-        const uint2 d = *reinterpret_cast<const uint2*>(limg + poff[ti] + koff);
-        const bf16x8 a = bytes_to_bf16x8(d.x, d.y);
-        acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1.v, acc[ti], 0, 0, 0);
-        acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2.v, acc[ti], 0, 0, 0);
-        acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b3.v, acc[ti], 0, 0, 0);
-      }
-    }
+    for (int ti = 0; ti < kC1MaxTiles; ++ti)
+      aq[ti] = *reinterpret_cast<const uint2*>(limg + poff[ti] + koff);   // tiles beyond ntiles read pixel 0: harmless
+  };
+  lds_fetch(0);
+#ifdef XT_C1_NOLOOP
+  for (int s = 0; s < 1; ++s) {
+#else
+  for (int s = 0; s < nsteps; ++s) {
+#endif
+    BF8 bp[3];
+    bf16x8 av[kC1MaxTiles];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) { bp[pl].u[0] = wq[pl].x; bp[pl].u[1] = wq[pl].y; bp[pl].u[2] = wq[pl].z; bp[pl].u[3] = wq[pl].w; }
+#pragma unroll
+    for (int ti = 0; ti < kC1MaxTiles; ++ti) av[ti] = bytes_to_bf16x8(aq[ti].x, aq[ti].y);
+    if (s + 1 < nsteps) lds_fetch(s + 1);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int ti = 0; ti < kC1MaxTiles; ++ti)
+        if (wave + 4 * ti < ntiles)       // wave-uniform
+          acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ti], bp[pl].v, acc[ti], 0, 0, 0);
   }
 
-  // ---- epilogue: input scale on the accumulator, bias, activation
+  // ---- epilogue: input scale on the accumulator, bias, activation.  The 32x32 fp32 tile of a wave is ONE
+  // contiguous 4 KB block of the NHWC output (N = 32): transpose it through LDS (the weight-plane region is
+  // dead after a barrier) and write it with 16-byte-per-lane stores (4 per tile instead of 16 scattered
+  // dword stores: the store phase was 8.5 of the kernel's 23 us).
+  __syncthreads();
+  float* tbuf = reinterpret_cast<float*>(limg + HWC) + wave * (32 * 36);      // [32 rows][36] padded, per wave
 #pragma unroll
   for (int ti = 0; ti < kC1MaxTiles; ++ti) {
     if (wave + 4 * ti < ntiles) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int pix = (wave + 4 * ti) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (pix < OHOW)
-          p.y[((size_t)b * OHOW + pix) * 32 + il] = act_apply(fmaf(acc[ti][r], p.xs, bias), p.act);
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        tbuf[row * 36 + il] = act_apply(fmaf(acc[ti][r], p.xs, bias), p.act);
+      }
+      // wave-private region: program order of one wave suffices between its own ds_write and ds_read
+      const int pix0 = (wave + 4 * ti) * 32;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = q * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(&tbuf[row * 36 + c4]);
+#ifdef XT_C1_NOSTORE
+        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+        if (pix0 + row < OHOW && v.x == 12345.678f)
+#else
+        if (pix0 + row < OHOW)
+#endif
+          *reinterpret_cast<float4*>(&p.y[((size_t)b * OHOW + pix0 + row) * 32 + c4]) = v;
       }
     }
   }
@@ -251,38 +282,54 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_wgrad_bf16x3_kernel(const 
   float bsum = 0.f;
   __syncthreads();
 
-  for (int s = pg; s < nsteps; s += 2) {
-    // exact 3-way bf16 split of the 8 dY values of this lane (pixels 16s+8h+e, column il)
-    float dcur[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dcur[e] = dys[(s * 16 + 8 * h + e) * 32 + il];
-    BF8 b1, b2, b3;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float w0 = dcur[2 * q], w1 = dcur[2 * q + 1];
-      bsum += w0 + w1;
-      const float r0 = w0 - trunc_bf16(w0), r1 = w1 - trunc_bf16(w1);
-      const float q0 = r0 - trunc_bf16(r0), q1 = r1 - trunc_bf16(r1);
-      b1.u[q] = pack_hi16(w0, w1);
-      b2.u[q] = pack_hi16(r0, r1);
-      b3.u[q] = pack_hi16(q0, q1);
-    }
-    int po[8];
+  // software-pipelined: LDS reads of this wave's NEXT step (8 dY values, 4 x 8 pixel bytes) are issued before
+  // the MFMAs of the current one; the pixel-offset table is read one step further ahead (the byte addresses
+  // depend on it).  MFMAs are issued plane-major (consecutive instructions hit different accumulators).
+  float dyr[8];
+  uint32_t xr[4][8];
+  int po[8];
+  auto read_po = [&](int s) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) po[e] = pixoff[s * 16 + 8 * h + e];
+  };
+  auto read_ops = [&](int s) {     // uses po[] of step s
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dyr[e] = dys[(s * 16 + 8 * h + e) * 32 + il];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int kb = (kh * 4 + q) * Wrow + il;        // kernel row ky = 4kh+q, byte kx*4+c = il
-      float f[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = (float)limg[po[e] + kb];
-      BF8 a;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) a.u[e] = pack_hi16(f[2 * e], f[2 * e + 1]);
-      acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b1.v, acc[q], 0, 0, 0);
-      acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b2.v, acc[q], 0, 0, 0);
-      acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b3.v, acc[q], 0, 0, 0);
+      for (int e = 0; e < 8; ++e) xr[q][e] = limg[po[e] + kb];
     }
+  };
+  if (pg < nsteps) { read_po(pg); read_ops(pg); }
+  if (pg + 2 < nsteps) read_po(pg + 2);
+  for (int s = pg; s < nsteps; s += 2) {
+    // exact 3-way bf16 split of the 8 dY values of this lane (pixels 16s+8h+e, column il)
+    BF8 bp[3], av[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float w0 = dyr[2 * q], w1 = dyr[2 * q + 1];
+      bsum += w0 + w1;
+      const float r0 = w0 - trunc_bf16(w0), r1 = w1 - trunc_bf16(w1);
+      const float q0 = r0 - trunc_bf16(r0), q1 = r1 - trunc_bf16(r1);
+      bp[0].u[q] = pack_hi16(w0, w1);
+      bp[1].u[q] = pack_hi16(r0, r1);
+      bp[2].u[q] = pack_hi16(q0, q1);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) av[q].u[e] = pack_hi16((float)xr[q][2 * e], (float)xr[q][2 * e + 1]);
+    if (s + 2 < nsteps) {
+      read_ops(s + 2);                       // po[] currently holds step s+2
+      if (s + 4 < nsteps) read_po(s + 4);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q].v, bp[pl].v, acc[q], 0, 0, 0);
   }
 
   // ---- combine the two pixel-parity halves, bias gradient, store the slab
