@@ -34,9 +34,17 @@ class PPO(Algorithm):
         self.adv = list()
         self.old_v = list()
         self.target_v = list()
+        self._streamed = 0
 
     def train(self, **kwargs):
         """Train PPO Agent."""
+        if self._streamed == len(self.obs) and self._streamed > 0:
+            # every trajectory of this rollout was streamed to HBM as it arrived: no concat, no upload
+            loss = self.actor.train_ingested(**kwargs)
+            self._init_train_list()
+            return loss
+        if self._streamed:
+            self.actor._ingest.reset()
         obs = np.concatenate(self.obs)
         behavior_action = np.concatenate(self.behavior_action)
         old_logp = np.concatenate(self.old_logp)
@@ -55,6 +63,9 @@ class PPO(Algorithm):
                                       np.asarray(train_data["done"], bool).reshape(1, -1), GAMMA, LAM)
             train_data = dict(train_data, adv=adv.reshape(-1, 1), old_value=old_v.reshape(-1, 1),
                               target_value=tgt.reshape(-1, 1))
+        if getattr(self.actor, "stream_ingest", False) and hasattr(self.actor, "ingest_trajectory"):
+            self.actor.ingest_trajectory(train_data)
+            self._streamed += 1
         self.obs.append(train_data["cur_state"])
         self.behavior_action.append(train_data["action"])
         self.old_logp.append(train_data["logp"])

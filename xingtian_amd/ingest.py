@@ -1,0 +1,103 @@
+"""Rollout ingest for the learner (SURVEY.md section 8 "next" row f1): trajectories are copied into PINNED host
+staging buffers as they arrive (``Algorithm.prepare_data``) and shipped to HBM with asynchronous copies on a
+dedicated HIP stream, so that by the time ``train()`` is called the rollout is (mostly) resident and the
+reference's ``np.concatenate`` of the whole rollout (xt/algorithm/ppo/ppo.py:66-71) plus the pageable
+host->device upload are gone from the critical path.  Two buffer sets alternate so that the next rollout can
+stream in while the previous update still reads the other set.
+
+Plumbing only (PyTorch-ROCm tensors / streams); no arithmetic happens here.
+"""
+import numpy as np
+import torch
+
+_FIELDS = (("action", torch.int32, np.int32), ("old_logp", torch.float32, np.float32),
+           ("adv", torch.float64, np.float64), ("old_v", torch.float32, np.float32),
+           ("target_v", torch.float64, np.float64))
+
+
+class _BufferSet(object):
+    def __init__(self, cap, obs_tail, obs_dtype, n_epochs, device):
+        self.cap = cap
+        tdt = torch.uint8 if obs_dtype == np.uint8 else torch.float32
+        self.host = {"obs": torch.empty((cap,) + obs_tail, dtype=tdt, pin_memory=True)}
+        self.dev = {"obs": torch.empty((cap,) + obs_tail, dtype=tdt, device=device)}
+        for name, tdt2, _ in _FIELDS:
+            self.host[name] = torch.empty((cap,), dtype=tdt2, pin_memory=True)
+            self.dev[name] = torch.empty((cap,), dtype=tdt2, device=device)
+        self.dev["perm"] = torch.empty((n_epochs, cap), dtype=torch.int32, device=device)
+        self.host_np = {k: v.numpy() for k, v in self.host.items()}
+        self.done = torch.cuda.Event()
+        self.free = None          # recorded on the compute stream after the update that read this set
+
+
+class RolloutIngest(object):
+    def __init__(self, device, n_epochs, initial_capacity=4096):
+        self.device = torch.device(device)
+        self.n_epochs = n_epochs
+        self.initial_capacity = initial_capacity
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.sets = [None, None]
+        self.cur = 0
+        self.n = 0
+        self._sig = None
+
+    # ------------------------------------------------------------------
+    def _ensure(self, need, obs):
+        sig = (tuple(obs.shape[1:]), obs.dtype == np.uint8)
+        s = self.sets[self.cur]
+        if s is not None and self._sig == sig and s.cap >= need:
+            return s
+        cap = max(self.initial_capacity, need)
+        if s is not None and self._sig == sig:
+            cap = max(cap, 2 * s.cap)
+        new = _BufferSet(cap, tuple(obs.shape[1:]), np.uint8 if obs.dtype == np.uint8 else np.float32,
+                         self.n_epochs, self.device)
+        if s is not None and self._sig == sig and self.n > 0:        # grow: keep what was already ingested
+            self.copy_stream.synchronize()
+            for k in new.host:
+                new.host[k][:self.n].copy_(s.host[k][:self.n])
+            with torch.cuda.stream(self.copy_stream):
+                for k in new.host:
+                    new.dev[k][:self.n].copy_(new.host[k][:self.n], non_blocking=True)
+        self._sig = sig
+        self.sets[self.cur] = new
+        return new
+
+    def put(self, obs, action, old_logp, adv, old_v, target_v):
+        """Append one trajectory ([T,...] arrays as the explorer ships them) and start its H2D copy."""
+        obs = np.asarray(obs)
+        t = obs.shape[0]
+        s = self._ensure(self.n + t, obs)
+        if self.n == 0 and s.free is not None:      # do not overwrite a set an enqueued update still reads
+            self.copy_stream.wait_event(s.free)
+        lo, hi = self.n, self.n + t
+        np.copyto(s.host_np["obs"][lo:hi], obs, casting="unsafe")
+        for (name, _, npdt), arr in zip(_FIELDS, (action, old_logp, adv, old_v, target_v)):
+            np.copyto(s.host_np[name][lo:hi], np.asarray(arr).reshape(-1), casting="same_kind")
+        with torch.cuda.stream(self.copy_stream):
+            for k in s.host:
+                s.dev[k][lo:hi].copy_(s.host[k][lo:hi], non_blocking=True)
+        self.n = hi
+
+    def finish(self):
+        """All trajectories are in: make the compute stream wait for the copies, return (n, device buffers) and
+        switch to the other buffer set for the next rollout."""
+        s = self.sets[self.cur]
+        n = self.n
+        if s is None or n == 0:
+            raise RuntimeError("RolloutIngest.finish(): nothing was ingested")
+        s.done.record(self.copy_stream)
+        torch.cuda.current_stream(self.device).wait_event(s.done)
+        self.cur ^= 1
+        self.n = 0
+        self.last = s
+        return n, s.dev
+
+    def mark_consumed(self):
+        """call after the update that reads the last finished set has been enqueued on the compute stream"""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.last.free = ev
+
+    def reset(self):
+        self.n = 0

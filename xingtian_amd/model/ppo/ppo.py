@@ -47,6 +47,9 @@ class PPO(XTModel):
             raise NotImplementedError(
                 "action type: {} not match any implemented distributions.".format(self.action_type))
         self._resident = None
+        self._ingest = None
+        self._perm_dense = None
+        self.stream_ingest = bool(model_config.get("STREAM_INGEST", True))
         super().__init__(model_info)
 
     # subclasses provide build_spec(); create_model wires the HIP network
@@ -104,6 +107,38 @@ class PPO(XTModel):
         r["old_v"].copy_(torch.from_numpy(np.ascontiguousarray(label[3], dtype=np.float32).reshape(-1)))
         r["target_v"].copy_(torch.from_numpy(np.ascontiguousarray(label[4], dtype=np.float64).reshape(-1)))
         return r
+
+    # ---- streaming ingest: trajectories go to HBM as they arrive -------------------
+    def ingest_trajectory(self, train_data):
+        """Called by ``PPO.prepare_data`` for every trajectory; starts its pinned-staging + async H2D copy."""
+        if self._ingest is None:
+            from xingtian_amd.ingest import RolloutIngest
+            self._ingest = RolloutIngest(self.net.device, self.num_sgd_iter)
+        self._ingest.put(train_data["cur_state"], train_data["action"], train_data["logp"], train_data["adv"],
+                         train_data["old_value"], train_data["target_value"])
+
+    def ingested(self):
+        return 0 if self._ingest is None else self._ingest.n
+
+    def train_ingested(self, perms=None):
+        """``train`` on the rollout that was streamed in through ``ingest_trajectory`` (no concat, no upload)."""
+        n, d = self._ingest.finish()
+        if perms is None:
+            perms = self.make_perms(n)
+        perm = d["perm"][:, :n] if d["perm"].shape[1] == n else None
+        if perm is None:
+            # capacity > n: the kernel expects perm as a dense [epochs, n] array
+            if self._perm_dense is None or self._perm_dense.shape[1] != n:
+                self._perm_dense = torch.empty((self.num_sgd_iter, n), dtype=torch.int32, device=self.net.device)
+            perm = self._perm_dense
+        perm.copy_(torch.from_numpy(np.ascontiguousarray(perms, dtype=np.int32)))
+        # eager enqueue: the two alternating buffer sets would re-capture the graph every update, and eager
+        # and graph replay measure the same (the update is GPU-bound)
+        acc = self.net.ppo_train(self._cfg, d["obs"][:n], perm, d["action"][:n], d["old_logp"][:n], d["adv"][:n],
+                                 d["old_v"][:n], d["target_v"][:n], use_graph=False)
+        self._ingest.mark_consumed()
+        a = acc.cpu().numpy()
+        return np.float32(a[0] / max(a[1], 1.0))
 
     def make_perms(self, nbatch):
         """np.random.shuffle(inds) once per epoch, cumulatively (xt/model/ppo/ppo.py:114-118)."""
