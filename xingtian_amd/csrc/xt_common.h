@@ -31,6 +31,42 @@ void set_error(const char* fmt, ...);
 
 #define XT_LAUNCH_CHECK() XT_CHECK_HIP(hipGetLastError())
 
+// ---- per-block timeline instrumentation (diagnostic builds only: make TL=1 -> libxt_mi355x_tl.so).
+// Every block's thread 0 stores the 100 MHz wall clock at up to 6 marks + a role word + HW_ID/XCC_ID into a
+// host-provided buffer [block][8] (tools/timeline.py); compiled out of the product library.
+#ifdef XT_TIMELINE
+static __device__ unsigned long long* xt_tl_ptr;
+#define XT_TL_BLOCK() ((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z))
+#define XT_TL(slot)                                                                                   \
+  do {                                                                                                \
+    if (threadIdx.x == 0 && xt_tl_ptr) xt_tl_ptr[XT_TL_BLOCK() * 8 + (slot)] = wall_clock64();        \
+  } while (0)
+#define XT_TL_DRAIN(slot)                                     \
+  do {                                                        \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          \
+    XT_TL(slot);                                              \
+  } while (0)
+#define XT_TL_ROLE(role)                                                                              \
+  do {                                                                                                \
+    if (threadIdx.x == 0 && xt_tl_ptr) {                                                              \
+      unsigned hw, xcc;                                                                               \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                              \
+      xt_tl_ptr[XT_TL_BLOCK() * 8 + 6] = (unsigned long long)(role);                                  \
+      xt_tl_ptr[XT_TL_BLOCK() * 8 + 7] = ((unsigned long long)xcc << 32) | hw;                        \
+    }                                                                                                 \
+  } while (0)
+#define XT_TL_SETTER(name)                                                                            \
+  extern "C" int xt_tl_set_##name(void* p) {                                                          \
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(xt_tl_ptr), &p, sizeof(p));                              \
+  }
+#else
+#define XT_TL(slot) do {} while (0)
+#define XT_TL_DRAIN(slot) do {} while (0)
+#define XT_TL_ROLE(role) do {} while (0)
+#define XT_TL_SETTER(name)
+#endif
+
 // n / d for n*d < 2^32 via one v_mul_hi_u32 (magic = floor(2^32/d)+1).
 struct FastDiv {
   uint32_t d, magic;

@@ -77,6 +77,8 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_fwd_bf16x3_kernel(const C1
   const int HWC = p.H * p.W * 4, Wrow = p.W * 4, OHOW = p.OH * p.OW;
   const int nsteps = 2 * p.KH;              // 16 reduction elements per step = half a kernel row
   uint4* wpl = reinterpret_cast<uint4*>(limg + HWC);     // [nsteps][3 planes][64 lanes] x 16 B, MFMA operand order
+  XT_TL(0);
+  XT_TL_ROLE(40);
   // ---- issue every global load of the block up front: this thread's share of the weights (fp32, split below)
   // and of the frame stack (minibatch gather fused) -> one memory latency for the whole prologue
   float wv[4][8];
@@ -94,6 +96,7 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_fwd_bf16x3_kernel(const C1
     const uint4* src = reinterpret_cast<const uint4*>(p.in + s * (size_t)HWC);
     stage_image(src, reinterpret_cast<uint4*>(limg), HWC >> 4, t);
   }
+  XT_TL(1);
   // exact 3-way bf16 split of the weights, written once per block in operand order
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -133,6 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_fwd_bf16x3_kernel(const C1
     for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
   const float bias = p.bias[il];
   __syncthreads();
+  XT_TL(2);
 
   // software-pipelined main loop: the LDS reads of step s+1 (3 weight planes + one 8-byte pixel group per
   // tile) are issued before the MFMAs of step s; MFMAs are issued plane-major so that consecutive
@@ -173,6 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_fwd_bf16x3_kernel(const C1
   // dead after a barrier) and write it with 16-byte-per-lane stores (4 per tile instead of 16 scattered
   // dword stores: the store phase was 8.5 of the kernel's 23 us).
   __syncthreads();
+  XT_TL(3);
   float* tbuf = reinterpret_cast<float*>(limg + HWC) + wave * (32 * 36);      // [32 rows][36] padded, per wave
 #pragma unroll
   for (int ti = 0; ti < kC1MaxTiles; ++ti) {
@@ -198,6 +203,8 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_fwd_bf16x3_kernel(const C1
       }
     }
   }
+  XT_TL(4);
+  XT_TL_DRAIN(5);
 }
 
 // returns 0 launched, 1 error, -1 geometry not handled by this kernel
@@ -248,6 +255,8 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_wgrad_bf16x3_kernel(const 
   int* pixoff = reinterpret_cast<int*>(lsm + HWC + nsteps * 16 * 32 * 4); // [nsteps*16]
   float* red = dys;                                                      // aliases dys after the main loop
   float* bred = reinterpret_cast<float*>(pixoff);                        // aliases pixoff after the main loop
+  XT_TL(0);
+  XT_TL_ROLE(50);
   // ---- every global load of the block is issued up front (dY rows of this sample + the frame stack)
   {
     const float4* dsrc = reinterpret_cast<const float4*>(p.dy + (size_t)b * OHOW * 32);
@@ -280,7 +289,9 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_wgrad_bf16x3_kernel(const 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
   float bsum = 0.f;
+  XT_TL(1);
   __syncthreads();
+  XT_TL(2);
 
   // software-pipelined: LDS reads of this wave's NEXT step (8 dY values, 4 x 8 pixel bytes) are issued before
   // the MFMAs of the current one; the pixel-offset table is read one step further ahead (the byte addresses
@@ -334,6 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_wgrad_bf16x3_kernel(const 
 
   // ---- combine the two pixel-parity halves, bias gradient, store the slab
   bsum += __shfl_xor(bsum, 32, 64);
+  XT_TL(3);
   __syncthreads();                         // dys / pixoff are dead: their LDS is reused for the reduction
   if (kh == 0 && h == 0) bred[pg * 32 + il] = bsum;
   if (pg == 1) {
@@ -357,7 +369,11 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_wgrad_bf16x3_kernel(const 
       }
     if (kh == 0 && h == 0) slab[(size_t)p.KH * 32 * 32 + il] = db;
   }
+  XT_TL(4);
+  XT_TL_DRAIN(5);
 }
+
+XT_TL_SETTER(conv1)
 
 // returns 0 launched (msplit_out = B slabs), 1 error, -1 geometry not handled
 int launch_conv1_wgrad_bf16x3(const xt_conv_geom* g, const xt_input_xform* xf, int B, const void* in,

@@ -1,0 +1,476 @@
+// Register-direct implicit GEMM for gfx950 (MI355X, CDNA4): Conv2D/Dense forward, input-gradient and
+// weight-gradient on v_mfma_f32_32x32x2_f32 with NO LDS staging and NO barrier in the reduction loop.
+//
+// Why: the per-block timelines (tools/timeline.py, profiles/r01_timeline.txt) showed that the LDS-tiled kernels
+// of xt_igemm.hip keep the matrix pipe 35-60 % busy inside their reduction loop and not at all during their
+// 1.5-3.7 us prologues / 2.5-5 us epilogues, because every co-resident block runs the same phase at the same
+// time and the waves of a block are chained to each other by a barrier per 32-deep step.  The learner's GEMMs
+// are small (0.5-1.7 GFLOP per launch): what they need is many independent waves, not big shared tiles.
+//
+// How: the reduction order inside a 32-deep step is free as long as both operands agree, so it is chosen such
+// that every lane's share of an MFMA operand is CONTIGUOUS in HBM:
+//   lane (il = lane & 31, kl = lane >> 5) feeds MFMA kk (0..15) of a step with reduction index 16*kl + kk.
+//   fwd   A[m, k]   : 16 consecutive k of one im2col row = 64 contiguous bytes (NHWC, C % 16 == 0) -> 4 x dwordx4
+//         B[k, n]   : W[(16 kl + kk) * N + n]: 32 consecutive n per instruction (two full 128-B lines)
+//   dgrad A = dY    : 16 consecutive output channels of the tap's output pixel            -> 4 x dwordx4
+//         B = W^T   : W[tap][c][16 kl + kk]: contiguous in HWIO                            -> 4 x dwordx4
+//   wgrad A = X^T   : X[row(m0 + 16 kl + kk)][k0 + il]: 32 consecutive channels per instruction
+//         B = dY    : dY[(m0 + 16 kl + kk) * N + n0 + il]
+// Operands go global -> VGPR -> MFMA.  A wave owns a (32 TI) x (32 TJ) output tile over a slice of the
+// reduction range with a two-stage register pipeline; the NW waves of a block own different slices of the
+// same tile and are combined once, through LDS, in a fixed order (deterministic), and then ALL of them take
+// part in the epilogue.  Waves never wait for each other inside the loop, so the 3-5 resident waves of a SIMD
+// drift apart and cover each other's load latency.  Blocks are mapped to tiles XCD-contiguously (the 8 XCDs
+// have private L2s; neighbouring tiles share im2col lines).
+//
+// Same arithmetic as xt_igemm.hip (fp32 products, fp32 accumulate, fixed summation order per launch
+// configuration).  Shapes outside the envelope (uint8 input, C % 16, K % 32, N % 32) stay on xt_igemm.hip /
+// xt_conv1.hip; the launchers return -1 for those.
+#include <stdlib.h>
+#include "xt_common.h"
+#include "xt_igemm.h"
+
+namespace xt {
+
+// block id -> work item such that each XCD (block id mod 8, round-robin dispatch) gets a contiguous range
+__device__ __forceinline__ uint32_t xcd_chunk(uint32_t bid, uint32_t nb) {
+  const uint32_t q = nb >> 3, r = nb & 7u, x = bid & 7u, j = bid >> 3;
+  return x * q + (x < r ? x : r) + j;
+}
+
+__device__ __forceinline__ float zsel(bool ok, float v) { return ok ? v : 0.f; }
+
+// Buffer addressing (SRSRC descriptor in SGPRs + 32-bit lane byte offset + scalar byte offset): no 64-bit VALU
+// address math, immediate-offset folding, and the hardware range check returns 0 for offsets >= num_bytes,
+// which is how padding taps and tail rows are zero-filled for free (kOob).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kOob = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+
+// Fixed-order combine of the NW per-wave partial tiles + distributed epilogue.  red: [NW][R][64] floats.
+// emit(r, v) is called by exactly one wave per accumulator register r (r = tile * 16 + reg).
+template <int R, typename F>
+__device__ __forceinline__ void combine_and_emit(float* red, const float (&flat)[R], int w, int NW, int lane, F emit) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) red[(w * R + r) * 64 + lane] = flat[r];
+  __syncthreads();
+  for (int r = w; r < R; r += NW) {
+    float v = red[r * 64 + lane];
+    for (int q = 1; q < NW; ++q) v += red[(q * R + r) * 64 + lane];
+    emit(r, v);
+  }
+}
+
+// ------------------------------------------------------------------ forward
+struct DFwdArgs {
+  Geom g;
+  const float* in;
+  const float* w;
+  const float* bias;
+  float* y;          // ksplit == 1: output; else partial [ksplit][M][N]
+  int mt, nt;        // tile grid
+  int ksplit;        // cross-block split of the reduction
+  int steps_blk;     // 32-deep steps per block
+  int nsteps;        // K / 32
+};
+
+template <int TI, int TJ, bool PADDED, int MAXT>
+__global__ __launch_bounds__(MAXT) void direct_fwd_kernel(const DFwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const Geom& g = p.g;
+  // the wave index is made explicitly wave-uniform (SGPR): the step loop then runs on the scalar unit
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;
+  const int il = lane & 31, kl = lane >> 5;
+  XT_TL(0);
+  XT_TL_ROLE(70);
+  uint32_t lin = xcd_chunk(blockIdx.x, gridDim.x);
+  const int z = (int)(lin % (uint32_t)p.ksplit);
+  lin /= (uint32_t)p.ksplit;
+  const int tn = (int)(lin % (uint32_t)p.nt), tm = (int)(lin / (uint32_t)p.nt);
+  const int m0 = tm * (32 * TI), n0 = tn * (32 * TJ);
+  const int sb0 = z * p.steps_blk, sb1 = min(p.nsteps, sb0 + p.steps_blk);
+  const int per = (sb1 - sb0 + NW - 1) / NW;
+  const int s0 = sb0 + w * per, s1 = min(sb1, s0 + per);
+
+  int rowbase[TI], iy0[TI], ix0[TI];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti) {
+    const int m = min(m0 + 32 * ti + il, g.M - 1);
+    const uint32_t b = fdiv((uint32_t)m, g.d_ohow);
+    const uint32_t rem = (uint32_t)m - b * (uint32_t)g.OHOW;
+    const uint32_t oy = fdiv(rem, g.d_ow), ox = rem - oy * (uint32_t)g.OW;
+    iy0[ti] = (int)oy * g.S - g.PT;
+    ix0[ti] = (int)ox * g.S - g.PL;
+    rowbase[ti] = (int)b * g.HWC + (iy0[ti] * g.W + ix0[ti]) * g.C;
+  }
+  const uint32_t wvoff = (uint32_t)(16 * kl * g.N + n0 + il) * 4u;     // lane part of the weight address (fixed)
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, (uint32_t)g.B * (uint32_t)g.HWC * 4u);
+  const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (uint32_t)g.K * (uint32_t)g.N * 4u);
+
+  struct Stage { float4 a[TI][4]; float b[TJ][16]; };
+  auto load = [&](Stage& R, int s, bool live) {     // !live: every offset out of range -> zeros, no memory traffic
+    const uint32_t k = (uint32_t)(32 * s + 16 * kl);
+    const uint32_t ky = fdiv(k, g.d_kwc);
+    const uint32_t r = k - ky * (uint32_t)g.KWC;
+    const uint32_t kx = fdiv(r, g.d_c);
+    const int koff = ((int)ky * g.W + (int)kx) * g.C + (int)(r - kx * (uint32_t)g.C);
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) {
+      bool ok = live;
+      if (PADDED)
+        ok = ok && ((unsigned)(iy0[ti] + (int)ky) < (unsigned)g.H) && ((unsigned)(ix0[ti] + (int)kx) < (unsigned)g.W);
+      const uint32_t off = ok ? (uint32_t)(rowbase[ti] + koff) * 4u : kOob;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) R.a[ti][q] = buf_load4(rs_in, off + 16u * q, 0u);
+    }
+    const uint32_t ws = live ? (uint32_t)(32 * s) * (uint32_t)g.N * 4u : kOob;          // uniform
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) R.b[tj][kk] = buf_load1(rs_w, wvoff + 128u * tj, ws + (uint32_t)(kk * g.N) * 4u);
+  };
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+  auto compute = [&](const Stage& R) {
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[TI];
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) {
+        const float4 v = R.a[ti][kk >> 2];
+        a[ti] = (kk & 3) == 0 ? v.x : (kk & 3) == 1 ? v.y : (kk & 3) == 2 ? v.z : v.w;
+      }
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti], R.b[tj][kk], acc[ti][tj], 0, 0, 0);
+    }
+  };
+
+  // Two register stages.  Every load of the loop is UNCONDITIONAL so that the in-order vmcnt bookkeeping is
+  // static (a conditional prefetch makes the compiler wait for everything in flight); prefetches past the end
+  // of the wave's slice are issued out of range (no memory access).
+  Stage R0, R1;
+  load(R0, s0, s0 < s1);
+  load(R1, s0 + 1, s0 + 1 < s1);
+  XT_TL(1);
+  for (int s = s0; s < s1; s += 2) {
+    compute(R0);
+    load(R0, s + 2, s + 2 < s1);
+    compute(R1);                      // an out-of-range stage holds zeros
+    load(R1, s + 3, s + 3 < s1);
+  }
+  XT_TL(3);
+
+  constexpr int R = TI * TJ * 16;
+  float flat[R];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) flat[(ti * TJ + tj) * 16 + r] = acc[ti][tj][r];
+  const bool final_out = (p.ksplit == 1);
+  float* out = final_out ? p.y : p.y + (size_t)z * (size_t)g.M * g.N;
+  combine_and_emit<R>(red, flat, w, NW, lane, [&](int r, float v) {
+    const int t = r >> 4, rr = r & 15;
+    const int ti = t / TJ, tj = t - ti * TJ;
+    const int m = m0 + 32 * ti + (rr & 3) + 8 * (rr >> 2) + 4 * kl;
+    const int n = n0 + 32 * tj + il;
+    if (m < g.M) {
+      if (final_out) v = act_apply(v + p.bias[n], g.act);
+      out[(size_t)m * g.N + n] = v;
+    }
+  });
+  XT_TL(4);
+  XT_TL_DRAIN(5);
+}
+
+// ------------------------------------------------------------------ input gradient
+// Static-NW combine: wave w owns accumulator registers r = w + j*NW (j < R/NW) of the block's tile.
+template <int R, int NW, typename F>
+__device__ __forceinline__ void combine_emit_static(float* red, const float (&flat)[R], int w, int lane, F emit) {
+  if constexpr (NW == 1) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) emit(r, r, flat[r]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) red[(w * R + r) * 64 + lane] = flat[r];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < R / NW; ++j) {
+      const int r = w + j * NW;
+      float v = red[r * 64 + lane];
+#pragma unroll
+      for (int q = 1; q < NW; ++q) v += red[(q * R + r) * 64 + lane];
+      emit(j, r, v);
+    }
+  }
+}
+
+struct DDgradArgs {
+  Geom g;
+  const float* dy;
+  const float* w;
+  const float* x;     // producer's post-activation output [B,H,W,C]
+  float* dx;
+  int act_prev;
+  int mt, ct;         // pixel tiles per stride-parity class (upper bound), channel tiles
+};
+
+template <int TI, int TJ, int NW>
+__global__ __launch_bounds__(64 * NW) void direct_dgrad_kernel(const DDgradArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const Geom& g = p.g;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int il = lane & 31, kl = lane >> 5;
+  XT_TL(0);
+  XT_TL_ROLE(80);
+  // tile-major, class-minor: the S*S classes of one pixel region read the same dY lines
+  uint32_t lin = xcd_chunk(blockIdx.x, gridDim.x);
+  const int nclass = g.S * g.S;
+  const int cls = (int)(lin % (uint32_t)nclass);
+  lin /= (uint32_t)nclass;
+  const int tc = (int)(lin % (uint32_t)p.ct), tm = (int)(lin / (uint32_t)p.ct);
+  const int ry = cls / g.S, rx = cls - ry * g.S;
+  const int cy0 = ((ry - g.PT) % g.S + g.S) % g.S, cx0 = ((rx - g.PL) % g.S + g.S) % g.S;
+  const int HC = cy0 < g.H ? (g.H - cy0 + g.S - 1) / g.S : 0;
+  const int WC = cx0 < g.W ? (g.W - cx0 + g.S - 1) / g.S : 0;
+  const int Mc = g.B * HC * WC;
+  const int i0 = tm * (32 * TI), c0 = tc * (32 * TJ);
+  if (i0 >= Mc) return;
+  const int JY = ry < g.KH ? (g.KH - ry + g.S - 1) / g.S : 0;
+  const int JX = rx < g.KW ? (g.KW - rx + g.S - 1) / g.S : 0;
+  const int nps = g.N >> 5;                        // 32-deep steps per tap
+  const int nsteps = JY * JX * nps;
+  const int qy0 = (cy0 + g.PT) / g.S, qx0 = (cx0 + g.PL) / g.S;
+  const int per = (nsteps + NW - 1) / NW;
+  const int s0 = w * per, s1 = min(nsteps, s0 + per);
+
+  int dybase[TI], qy[TI], qx[TI], outoff[TI];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti) {
+    const int mraw = i0 + 32 * ti + il;
+    const int mc = min(mraw, Mc - 1);
+    const int b = mc / (HC * WC), rem = mc - b * (HC * WC);
+    const int ty = rem / WC, tx = rem - ty * WC;
+    qy[ti] = qy0 + ty; qx[ti] = qx0 + tx;
+    dybase[ti] = ((b * g.OH + qy[ti]) * g.OW + qx[ti]) * g.N;
+    outoff[ti] = mraw < Mc ? ((b * g.H + cy0 + g.S * ty) * g.W + cx0 + g.S * tx) * g.C : -1;
+  }
+  const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(p.dy, (uint32_t)g.M * (uint32_t)g.N * 4u);
+  const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (uint32_t)g.K * (uint32_t)g.N * 4u);
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x, (uint32_t)g.B * (uint32_t)g.HWC * 4u);
+
+  // producer activations of the registers this wave will emit: loaded before the reduction loop
+  constexpr int R = TI * TJ * 16, RJ = R / NW;
+  float xv[RJ];
+  int eoff[RJ];
+#pragma unroll
+  for (int j = 0; j < RJ; ++j) {
+    const int r = w + j * NW;
+    const int t = r >> 4, rr = r & 15;
+    const int ti = t / TJ, tj = t - ti * TJ;
+    const int row = (rr & 3) + 8 * (rr >> 2) + 4 * kl;
+    int o = 0;
+#pragma unroll
+    for (int q = 0; q < TI; ++q) { const int oq = __shfl(outoff[q], row, 64); if (q == ti) o = oq; }
+    eoff[j] = o >= 0 ? o + c0 + 32 * tj + il : -1;
+    xv[j] = buf_load1(rs_x, o >= 0 ? (uint32_t)eoff[j] * 4u : kOob, 0u);
+  }
+
+  const uint32_t wvoff = (uint32_t)((c0 + il) * g.N + 16 * kl) * 4u;
+  struct Stage { float4 a[TI][4]; float4 b[TJ][4]; };
+  auto load = [&](Stage& S_, int s, bool live) {
+    const int tap = s / nps;                       // uniform
+    const int jy = JX > 0 ? tap / JX : 0, jx = tap - jy * JX;
+    const int nofs = (s - tap * nps) * 32;
+    const int tapoff = (jy * g.OW + jx) * g.N - nofs - 16 * kl;
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) {
+      const bool ok = live && ((unsigned)(qy[ti] - jy) < (unsigned)g.OH) && ((unsigned)(qx[ti] - jx) < (unsigned)g.OW);
+      const uint32_t off = ok ? (uint32_t)(dybase[ti] - tapoff) * 4u : kOob;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) S_.a[ti][q] = buf_load4(rs_dy, off + 16u * q, 0u);
+    }
+    const uint32_t ws = live ? (uint32_t)((((ry + g.S * jy) * g.KW + rx + g.S * jx) * g.C) * g.N + nofs) * 4u : kOob;
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) S_.b[tj][q] = buf_load4(rs_w, wvoff + (uint32_t)(32 * tj * g.N) * 4u + 16u * q, ws);
+  };
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+  auto pick = [](const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; };
+  auto compute = [&](const Stage& S_) {
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(pick(S_.a[ti][kk >> 2], kk & 3), pick(S_.b[tj][kk >> 2], kk & 3),
+                                                             acc[ti][tj], 0, 0, 0);
+  };
+  Stage R0, R1;
+  load(R0, s0, s0 < s1);
+  load(R1, s0 + 1, s0 + 1 < s1);
+  XT_TL(1);
+  for (int s = s0; s < s1; s += 2) {
+    compute(R0);
+    load(R0, s + 2, s + 2 < s1);
+    compute(R1);
+    load(R1, s + 3, s + 3 < s1);
+  }
+  XT_TL(3);
+  float flat[R];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) flat[(ti * TJ + tj) * 16 + r] = acc[ti][tj][r];
+  combine_emit_static<R, NW>(red, flat, w, lane, [&](int j, int r, float v) {
+    if (eoff[j] >= 0) p.dx[(size_t)eoff[j]] = v * act_grad(xv[j], p.act_prev);
+  });
+  XT_TL(4);
+  XT_TL_DRAIN(5);
+}
+
+XT_TL_SETTER(direct)
+
+// ------------------------------------------------------------------ host side
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && e[0]) ? atoi(e) : dflt;
+}
+static bool use_direct() {
+  static int v = -1;
+  if (v < 0) v = env_int("XT_NO_DIRECT", 0) ? 0 : 1;
+  return v == 1;
+}
+// Resident-wave target of one launch.  Measured on MI355X (gpurun_out/sweep1.log, profiles/r01_timeline.txt): the
+// register-direct kernels are bounded by the L2->L1 fill rate (~25 B/clk/CU for row-gathered dwordx4), not by
+// latency, so FEW LONG waves (1-2 per SIMD, each streaming its whole reduction slice) beat many short ones.
+static int want_waves() {
+  static int v = -1;
+  if (v < 0) v = env_int("XT_DIRECT_WAVES", 1536);
+  return v;
+}
+// XT_DIRECT_ALL=1 routes every shape inside the envelope to the direct kernels (experiments); by default only
+// the shapes that measured faster than the LDS-tiled kernels are: single-column tiles (N or C not a multiple of
+// 64, where the LDS tile cannot share the A operand between column tiles anyway) with a long reduction.
+static bool direct_all() {
+  static int v = -1;
+  if (v < 0) v = env_int("XT_DIRECT_ALL", 0);
+  return v == 1;
+}
+
+static bool direct_envelope(const Geom& g, const xt_input_xform* xf) {
+  if (xf && (xf->is_u8 || fabsf(g.xs - 1.f) > 0.f || fabsf(g.xb) > 0.f)) return false;
+  return g.C % 16 == 0 && g.K % 32 == 0 && g.N % 32 == 0;
+}
+
+// returns -1 when the shape is outside the envelope (caller falls back to the LDS-tiled kernel)
+int launch_fwd_direct(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const void* in, const int32_t* idx,
+                      const float* w, const float* bias, float* y, float* partial, int ksplit_max, hipStream_t st,
+                      int* ksplit_out) {
+  if (!use_direct() || idx) return -1;
+  DFwdArgs a;
+  if (make_geom(cg, xf, B, &a.g)) return -1;
+  const Geom& g = a.g;
+  if (!direct_envelope(g, xf)) return -1;
+  const int TJ = (g.N % 64 == 0) ? 2 : 1;
+  if (!direct_all() && (TJ != 1 || g.K < 256)) return -1;
+  a.in = static_cast<const float*>(in); a.w = w; a.bias = bias;
+  a.mt = (g.M + 31) / 32; a.nt = g.N / (32 * TJ);
+  a.nsteps = g.K / 32;
+  const int tiles = a.mt * a.nt;
+  // reduction slices: enough waves to fill the chip, each with >= 2 steps
+  int slices = (want_waves() + tiles - 1) / tiles;
+  slices = max(1, min(slices, a.nsteps / 2));
+  int nw = min(slices, env_int("XT_DIRECT_MAXNW", 8));
+  int ks = (slices + nw - 1) / nw;
+  if (!partial || ksplit_max < 1) ksplit_max = 1;
+  ks = max(1, min(ks, ksplit_max));
+  a.steps_blk = (a.nsteps + ks - 1) / ks;
+  ks = (a.nsteps + a.steps_blk - 1) / a.steps_blk;
+  nw = max(1, min(nw, a.steps_blk));
+  a.ksplit = ks;
+  a.y = ks == 1 ? y : partial;
+  const bool pad = is_padded(g);
+  const dim3 grid(tiles * ks), blk(64 * nw);
+  const size_t sm = (size_t)nw * TJ * 16 * 64 * sizeof(float);
+#define XT_DF(TJV)                                                                                          \
+  do {                                                                                                      \
+    if (pad) hipLaunchKernelGGL((direct_fwd_kernel<1, TJV, true, 512>), grid, blk, sm, st, a);              \
+    else hipLaunchKernelGGL((direct_fwd_kernel<1, TJV, false, 512>), grid, blk, sm, st, a);                 \
+  } while (0)
+  if (TJ == 2) XT_DF(2); else XT_DF(1);
+#undef XT_DF
+  XT_LAUNCH_CHECK();
+  *ksplit_out = ks;
+  return 0;
+}
+
+int launch_dgrad_direct(const xt_conv_geom* cg, int B, const float* dy, const float* w, const float* x, int act_prev,
+                        float* dx, hipStream_t st) {
+  if (!use_direct()) return -1;
+  DDgradArgs a;
+  if (make_geom(cg, nullptr, B, &a.g)) return -1;
+  const Geom& g = a.g;
+  if (g.N % 32 != 0 || g.C % 32 != 0) return -1;
+  a.dy = dy; a.w = w; a.x = x; a.dx = dx; a.act_prev = act_prev;
+  const int TJ = (g.C % 64 == 0) ? 2 : 1;
+  const int hc = (g.H + g.S - 1) / g.S, wc = (g.W + g.S - 1) / g.S;   // upper bound on class extent
+  const int mc = B * hc * wc;
+  const int nclass = g.S * g.S;
+  const int jmax = ((g.KH + g.S - 1) / g.S) * ((g.KW + g.S - 1) / g.S);
+  const int nsteps = jmax * (g.N / 32);
+  const int tiles1 = ((mc + 31) / 32) * (g.C / (32 * TJ)) * nclass;
+  const int TI = (tiles1 >= env_int("XT_DIRECT_TI2_TILES", 3072)) ? 2 : 1;
+  if (!direct_all() && (TJ != 1 || TI != 1 || nsteps < 8)) return -1;
+  a.mt = (mc + 32 * TI - 1) / (32 * TI);
+  a.ct = g.C / (32 * TJ);
+  const int tiles = a.mt * a.ct * nclass;
+  int nw = want_waves() / max(1, tiles);
+  nw = min(nw, nsteps / 2);
+  nw = nw >= 4 ? 4 : nw >= 2 ? 2 : 1;
+  const dim3 grid(tiles), blk(64 * nw);
+  const size_t sm = nw > 1 ? (size_t)nw * TI * TJ * 16 * 64 * sizeof(float) : 0;
+#define XT_DD(TIV, TJV)                                                                                     \
+  do {                                                                                                      \
+    if (nw == 4) hipLaunchKernelGGL((direct_dgrad_kernel<TIV, TJV, 4>), grid, blk, sm, st, a);              \
+    else if (nw == 2) hipLaunchKernelGGL((direct_dgrad_kernel<TIV, TJV, 2>), grid, blk, sm, st, a);         \
+    else hipLaunchKernelGGL((direct_dgrad_kernel<TIV, TJV, 1>), grid, blk, sm, st, a);                      \
+  } while (0)
+  if (TI == 2 && TJ == 2) XT_DD(2, 2);
+  else if (TI == 2) XT_DD(2, 1);
+  else if (TJ == 2) XT_DD(1, 2);
+  else XT_DD(1, 1);
+#undef XT_DD
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace xt

@@ -18,41 +18,10 @@
 // sess.run (xt/model/ppo/ppo.py:129, xt/model/impala/impala_cnn_opt.py:255).
 #include <stdlib.h>
 #include "xt_common.h"
+#include "xt_igemm.h"
 #include "xt_heads_dev.h"
 
 namespace xt {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct Geom {
-  int B, H, W, C, KH, KW, S, PT, PL, OH, OW, N, act;
-  int K, KWC, M, OHOW;
-  FastDiv d_ohow, d_ow, d_kwc, d_c, d_n;
-  float xs, xb;          // uint8 -> f32 transform: x*xs + xb  (xs = 1/std, xb = -mean/std)
-  int HWC;
-};
-
-static int make_geom(const xt_conv_geom* g, const xt_input_xform* xf, int B, Geom* o) {
-  XT_REQUIRE(g && B > 0, "igemm: bad geometry/batch");
-  o->B = B; o->H = g->H; o->W = g->W; o->C = g->C; o->KH = g->KH; o->KW = g->KW; o->S = g->S;
-  o->PT = g->PT; o->PL = g->PL; o->OH = g->OH; o->OW = g->OW; o->N = g->N; o->act = g->act;
-  o->K = g->KH * g->KW * g->C; o->KWC = g->KW * g->C; o->OHOW = g->OH * g->OW;
-  XT_REQUIRE(g->C % 4 == 0, "igemm: input channels C=%d must be a multiple of 4", g->C);
-  XT_REQUIRE(g->N % 4 == 0, "igemm: output channels N=%d must be a multiple of 4", g->N);
-  XT_REQUIRE(g->S >= 1 && g->KH >= 1 && g->KW >= 1, "igemm: bad kernel/stride");
-  long long m = (long long)B * o->OHOW;
-  XT_REQUIRE(m * (long long)o->OHOW < (1ll << 32) && m < (1ll << 30), "igemm: M=%lld too large", m);
-  XT_REQUIRE((long long)B * g->H * g->W * g->C < (1ll << 31), "igemm: activation tensor too large");
-  o->M = (int)m;
-  o->d_ohow = make_fastdiv(o->OHOW); o->d_ow = make_fastdiv(o->OW);
-  o->d_kwc = make_fastdiv(o->KWC); o->d_c = make_fastdiv(o->C); o->d_n = make_fastdiv(o->N);
-  const float mean = (xf && fabsf(xf->mean) >= 1e-4f) ? xf->mean : 0.f;   // state_transform: |mean|<1e-4 -> x/std
-  o->xs = xf ? 1.f / xf->std : 1.f;
-  o->xb = -mean * o->xs;
-  o->HWC = g->H * g->W * g->C;
-  XT_REQUIRE(m * (long long)g->N < (1ll << 31), "igemm: output tensor too large");
-  return 0;
-}
 
 __device__ __forceinline__ float4 sel4(bool ok, float4 v) {
   return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
@@ -190,6 +159,8 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
   const int nsteps_all = ((kend0 - kbeg0 + 31) / 32 + KG - 1) / KG;     // block-uniform loop length
   const int kbeg = kbeg0 + grp * nsteps_all * 32;
   const int kend = min(kend0, kbeg + nsteps_all * 32);
+  XT_TL(0);
+  XT_TL_ROLE(10);
 
   const int c4 = t & 7, r0 = t >> 3;
   long long rowbase[NA];
@@ -258,9 +229,11 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
   Regs R0, R1;
   if (nsteps > 0) fetch(kbeg, R0);
   if (nsteps > 1) fetch(kbeg + 32, R1);
+  XT_TL(1);
   for (int s = 0; s < nsteps_all; s += 2) {
     if (s < nsteps) stash(R0, smem, smem + 32 * SA);
     __syncthreads();
+    if (s == 0) XT_TL(2);
     if (s + 2 < nsteps) fetch(kbeg + (s + 2) * 32, R0);
     if (s < nsteps) mma_tile<TI, TJ, SA, SB>(smem, smem + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
     if (s + 1 < nsteps_all) {
@@ -293,6 +266,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
         for (int r = 0; r < 16; ++r) acc[ti][tj][r] += red[((ti * TJ + tj) * 16 + r) * 256 + t];
   }
 
+  XT_TL(3);
   const bool final_out = (p.ksplit == 1);
   float* out = final_out ? p.y : p.y + (size_t)blockIdx.z * (size_t)g.M * g.N;
 #pragma unroll
@@ -311,6 +285,8 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
         }
       }
     }
+  XT_TL(4);
+  XT_TL_DRAIN(5);
 }
 
 // y = act(sum_z partial[z] + bias)
@@ -390,6 +366,8 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
   const bool do_bias = (bx == 0);
   const int bcol = t % BJ, brg = t / BJ;
   float bsum = 0.f;
+  XT_TL(0);
+  XT_TL_ROLE(20);
 
   for (int sub = mbeg; sub < mend; sub += kRowTab) {
     const int sub_end = min(mend, sub + kRowTab);
@@ -448,9 +426,11 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
     Regs R0, R1;
     if (nsteps > 0) fetch(0, R0);
     if (nsteps > 1) fetch(1, R1);
+    if (sub == mbeg) XT_TL(1);
     for (int s = 0; s < nsteps; s += 2) {
       stash(R0, smem, smem + 32 * SA);
       __syncthreads();
+      if (s == 0 && sub == mbeg) XT_TL(2);
       if (s + 2 < nsteps) fetch(s + 2, R0);
       colsum(smem + 32 * SA);
       mma_tile<TI, TJ, SA, SB>(smem, smem + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
@@ -465,6 +445,7 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
     __syncthreads();   // row table and LDS stages are reused by the next sub-range
   }
 
+  XT_TL(3);
   float* out = p.out + (size_t)bz * ((size_t)(g.K + 1) * g.N);
 #pragma unroll
   for (int ti = 0; ti < TI; ++ti)
@@ -488,6 +469,8 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
       if (n < g.N) out[(size_t)g.K * g.N + n] = sum;
     }
   }
+  XT_TL(4);
+  XT_TL_DRAIN(5);
 }
 
 template <int BI, int BJ, int WI, int WJ, bool U8, bool PADDED>
@@ -545,6 +528,8 @@ __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int b
   const int JX = rx < g.KW ? (g.KW - rx + g.S - 1) / g.S : 0;
   const int Kc = JY * JX * g.N;
   const int qy0 = (cy0 + g.PT) / g.S, qx0 = (cx0 + g.PL) / g.S;
+  XT_TL(0);
+  XT_TL_ROLE(30);
 
   if (t < BI) {
     const int mc = i0 + t;
@@ -633,9 +618,11 @@ __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int b
   Regs R0, R1;
   if (nsteps > 0) fetch(0, R0);
   if (nsteps > 1) fetch(32, R1);
+  XT_TL(1);
   for (int s = 0; s < nsteps; s += 2) {
     stash(R0, smem, smem + 32 * SA);
     __syncthreads();
+    if (s == 0) XT_TL(2);
     if (s + 2 < nsteps) fetch((s + 2) * 32, R0);
     mma_tile<TI, TJ, SA, SB>(smem, smem + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
     if (s + 1 < nsteps) {
@@ -646,6 +633,7 @@ __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int b
     }
   }
   if (Kc == 0) __syncthreads();   // rowOut visibility
+  XT_TL(3);
 
   // epilogue in two phases: ALL producer activations are loaded first (clamped, unconditional), then the
   // masked gradients are stored -- interleaving load/store serialised 16 global-load latencies per tile
@@ -669,6 +657,8 @@ __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int b
       for (int r = 0; r < 16; ++r)
         if (offs[r] >= 0 && cok) p.dx[(size_t)offs[r] + c] = acc[ti][tj][r] * act_grad(xv[r], p.act_prev);
     }
+  XT_TL(4);
+  XT_TL_DRAIN(5);
 }
 
 template <int BI, int BJ, int WI, int WJ>
@@ -711,12 +701,9 @@ __global__ __launch_bounds__(256) void igemm_bwd_layer_kernel(const BwdLayerArgs
   heads_wgrad_partial_body(p.hw, b % p.hw.gx, b / p.hw.gx, smem);
 }
 
-// ------------------------------------------------------------------ host launchers
-// does the receptive field ever leave the image (TF SAME padding)?
-static inline bool is_padded(const Geom& g) {
-  return g.PT > 0 || g.PL > 0 || (g.OH - 1) * g.S - g.PT + g.KH > g.H || (g.OW - 1) * g.S - g.PL + g.KW > g.W;
-}
+XT_TL_SETTER(igemm)
 
+// ------------------------------------------------------------------ host launchers
 static inline int pick_ksplit_chunk(int K, int split, int* chunk) {
   int steps = (K + 31) / 32;
   int per = (steps + split - 1) / split;
@@ -728,6 +715,9 @@ int launch_conv1_fwd_bf16x3(const xt_conv_geom*, const xt_input_xform*, int, con
                             const float*, float*, hipStream_t);
 int launch_conv1_wgrad_bf16x3(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*,
                               const float*, float*, float*, int, int*, hipStream_t);
+int launch_dgrad_direct(const xt_conv_geom*, int, const float*, const float*, const float*, int, float*, hipStream_t);
+int launch_fwd_direct(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*, const float*,
+                      const float*, float*, float*, int, hipStream_t, int*);
 
 static bool use_kg2() {
   static int v = -1;
@@ -750,6 +740,21 @@ int launch_fwd(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const vo
   }
   FwdArgs a;
   if (int rc = make_geom(cg, xf, B, &a.g)) return rc;
+  {                       // register-direct kernel (xt_direct.hip) when the shape is inside its envelope
+    int ks = 1;
+    const int rc = launch_fwd_direct(cg, xf, B, in, idx, w, bias, y, partial, ksplit, st, &ks);
+    if (rc > 0) return rc;
+    if (rc == 0) {
+      if (deferred_ksplit) *deferred_ksplit = ks;
+      if (ks > 1 && !deferred_ksplit) {
+        const int MN = a.g.M * a.g.N;
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3((MN / 4 + 255) / 256), dim3(256), 0, st,
+                           partial, bias, y, MN, a.g.N, ks, a.g.act);
+        XT_LAUNCH_CHECK();
+      }
+      return 0;
+    }
+  }
   const bool u8 = xf && xf->is_u8;
   a.in = in; a.idx = idx; a.w = w; a.bias = bias;
   if (ksplit < 1) ksplit = 1;
@@ -829,6 +834,10 @@ int launch_wgrad(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const 
 
 int launch_dgrad(const xt_conv_geom* cg, int B, const float* dy, const float* w, const float* x, int act_prev,
                  float* dx, hipStream_t st) {
+  {
+    const int rc = launch_dgrad_direct(cg, B, dy, w, x, act_prev, dx, st);
+    if (rc >= 0) return rc;
+  }
   DgradArgs a;
   if (int rc = make_geom(cg, nullptr, B, &a.g)) return rc;
   a.dy = dy; a.w = w; a.x = x; a.dx = dx; a.act_prev = act_prev;

@@ -18,6 +18,8 @@ __global__ __launch_bounds__(256) void grads_finish_kernel(const GradTable tab, 
   __shared__ float4 sh4[256];
   __shared__ float shs[256];
   __shared__ int s_last;
+  XT_TL(0);
+  XT_TL_ROLE(60);
   int ei = 0;
   for (int q = 1; q < tab.n; ++q)
     if ((int)blockIdx.x >= tab.e[q].blk0) ei = q;
@@ -75,11 +77,13 @@ __global__ __launch_bounds__(256) void grads_finish_kernel(const GradTable tab, 
     }
   }
   shs[t] = sq;
+  XT_TL(1);
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (t < o) shs[t] += shs[t + o];
     __syncthreads();
   }
+  XT_TL(2);
   if (!fin.enable) {
     if (t == 0) partial[blockIdx.x] = shs[0];
     return;
@@ -107,10 +111,35 @@ __global__ __launch_bounds__(256) void grads_finish_kernel(const GradTable tab, 
     s_last = last;
   }
   __syncthreads();
+  XT_TL(3);
   if (!s_last) return;
   finalize_body(partial, gridDim.x, fin.clip_norm, fin.grad_scale, fin.lr, fin.beta1, fin.beta2, 1, fin.state,
                 fin.loss, reinterpret_cast<double*>(sh4));
+  XT_TL(4);
 }
+
+XT_TL_SETTER(optim)
+#ifdef XT_TIMELINE
+// launch-to-launch period of an (almost) empty kernel: the floor every dependent launch of the step pays
+__global__ __launch_bounds__(256) void null_kernel(float* p, int wr) {
+  if (wr && threadIdx.x == 0) p[blockIdx.x * 32] = 1.f;
+}
+extern "C" int xt_tl_null_period(int reps, int nblocks, int wr, float* scratch, float* ms_out, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  null_kernel<<<nblocks, 256, 0, st>>>(scratch, wr);
+  hipEventRecord(e0, st);
+  for (int i = 0; i < reps; ++i) null_kernel<<<nblocks, 256, 0, st>>>(scratch, wr);
+  hipEventRecord(e1, st);
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  *ms_out = ms / reps;
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  return (int)hipGetLastError();
+}
+#endif
 
 __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, long long count,
                                                              float* __restrict__ partial) {
