@@ -119,6 +119,33 @@ def main():
             lib.xt_tl_null_period(200, nb, wr, ctypes.c_void_p(scratch.data_ptr()), ctypes.byref(ms), L.stream_ptr())
             print("null kernel %5d blocks wr=%d: %.2f us launch-to-launch" % (nb, wr, ms.value * 1e3))
 
+    lib.xt_tl_clock_probe.restype = ctypes.c_int
+    lib.xt_tl_clock_probe.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    cbuf = torch.zeros(2, dtype=torch.int64, device="cuda")
+
+    def clock_mhz(tag):
+        lib.xt_tl_clock_probe(ctypes.c_void_p(cbuf.data_ptr()), L.stream_ptr())
+        torch.cuda.synchronize()
+        r, c = cbuf.cpu().tolist()
+        print("shader clock %-28s %.0f MHz" % (tag, c / (r / 100.0)))
+
+    clock_mhz("(idle)")
+    for _ in range(3):
+        net.time_layer(1, 0, obs, idx, B, reps=200)
+        clock_mhz("(after 200 conv2 fwd)")
+    if os.environ.get("XT_TL_TRAIN"):
+        rngp = np.random.default_rng(1)
+        perm = torch.from_numpy(np.stack([rngp.permutation(N) for _ in range(4)]).astype(np.int32)).cuda()
+        act0 = torch.from_numpy(rngp.integers(0, 4, N).astype(np.int32)).cuda()
+        g0 = lambda: torch.from_numpy(rngp.standard_normal(N).astype(np.float32)).cuda()
+        lp0, ad0, ov0, tg0 = g0() - 1.5, g0(), g0(), g0()
+        cfg0 = net.make_ppo_cfg(dict(LR=2.5e-4, LOSS_CLIPPING=0.1, ENTROPY_LOSS=0.003, VF_CLIP=5.0, CRITIC_LOSS_COEF=0.5,
+                                     MAX_GRAD_NORM=5.0, BATCH_SIZE=B, NUM_SGD_ITER=4))
+        for rep in range(4):
+            for _ in range(10):
+                net.ppo_train(cfg0, obs, perm, act0, lp0, ad0, ov0, tg0, use_graph=True)
+            clock_mhz("(after 10 ppo_train, rep %d)" % rep)
+
     out = {}
     jobs = [("L0_fwd", 0, 0), ("L0_wgrad", 0, 1)]
     for li in range(1, len(spec.layers)):

@@ -618,6 +618,21 @@ __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int b
   Regs R0, R1;
   if (nsteps > 0) fetch(0, R0);
   if (nsteps > 1) fetch(32, R1);
+  // prefetch the producer activations of this thread's output elements (clamped, unconditional): their latency
+  // hides behind the reduction loop instead of being exposed in the epilogue (4.5 of 13.9 us per block before)
+  __syncthreads();                 // rowOut
+  float xv[TI][TJ][16];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      const int c = j0 + (wj * TJ + tj) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int off = rowOut[(wi * TI + ti) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+        xv[ti][tj][r] = p.x[(off >= 0 && c < g.C) ? (size_t)off + c : (size_t)0];
+      }
+    }
   XT_TL(1);
   for (int s = 0; s < nsteps; s += 2) {
     stash(R0, smem, smem + 32 * SA);
@@ -632,30 +647,21 @@ __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int b
       mma_tile<TI, TJ, SA, SB>(smem + BUF, smem + BUF + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
     }
   }
-  if (Kc == 0) __syncthreads();   // rowOut visibility
   XT_TL(3);
 
-  // epilogue in two phases: ALL producer activations are loaded first (clamped, unconditional), then the
-  // masked gradients are stored -- interleaving load/store serialised 16 global-load latencies per tile
-  // (x and dx may alias as far as the compiler knows).
+  // epilogue: the producer activations (for act') were prefetched before the reduction loop (xv), so the
+  // masked gradients are stored without a second exposed memory round trip.
 #pragma unroll
   for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
       const int c = j0 + (wj * TJ + tj) * 32 + (lane & 31);
       const bool cok = c < g.C;
-      int offs[16];
-      float xv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int il = (wi * TI + ti) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        offs[r] = rowOut[il];
+        const int off = rowOut[(wi * TI + ti) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+        if (off >= 0 && cok) p.dx[(size_t)off + c] = acc[ti][tj][r] * act_grad(xv[ti][tj][r], p.act_prev);
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) xv[r] = p.x[(offs[r] >= 0 && cok) ? (size_t)offs[r] + c : (size_t)0];
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (offs[r] >= 0 && cok) p.dx[(size_t)offs[r] + c] = acc[ti][tj][r] * act_grad(xv[r], p.act_prev);
     }
   XT_TL(4);
   XT_TL_DRAIN(5);

@@ -124,6 +124,17 @@ XT_TL_SETTER(optim)
 __global__ __launch_bounds__(256) void null_kernel(float* p, int wr) {
   if (wr && threadIdx.x == 0) p[blockIdx.x * 32] = 1.f;
 }
+// shader clock probe: s_memtime (shader cycles) against s_memrealtime (100 MHz) over a ~20 us spin on one wave
+__global__ void clock_probe_kernel(unsigned long long* out) {
+  const unsigned long long r0 = wall_clock64(), c0 = clock64();
+  while (wall_clock64() - r0 < 2000ull) { }
+  const unsigned long long r1 = wall_clock64(), c1 = clock64();
+  if (threadIdx.x == 0) { out[0] = r1 - r0; out[1] = c1 - c0; }
+}
+extern "C" int xt_tl_clock_probe(unsigned long long* out, void* stream) {
+  clock_probe_kernel<<<1, 64, 0, (hipStream_t)stream>>>(out);
+  return (int)hipGetLastError();
+}
 extern "C" int xt_tl_null_period(int reps, int nblocks, int wr, float* scratch, float* ms_out, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   hipEvent_t e0, e1;
