@@ -344,3 +344,72 @@ def test_streaming_ingest_matches_upload_path_and_is_faster():
     assert np.array_equal(out[False][0][1], out[True][0][1])
     print("train() wall: upload path %.2f ms, streamed %.2f ms" % (out[False][1] * 1e3, out[True][1] * 1e3))
     assert out[True][1] < out[False][1]
+
+
+def test_checkpoint_resume_is_bit_exact_and_reference_loadable():
+    """save after k updates, restore into a FRESH learner, continue -> bit-identical to the
+    uninterrupted run (weights + Adam m/v/beta powers ride in the same actor_XXXXX.npz).  The file keeps the
+    reference's contract: every TF variable name is a key, extra keys use TF1's slot names, and a loader that
+    only knows the variable names (TFVariables.set_weights, tf_utils.py:104-128) still assigns all of them.
+    Without the slots (SAVE_OPTIMIZER False = the reference's behaviour) the continuation differs."""
+    import os
+    import tempfile
+    from xingtian_amd.algorithm import alg_builder
+
+    def mk(save_opt=True):
+        model_info = {"actor": {"model_name": "PpoCnn", "state_dim": [42, 42, 4], "action_dim": 6,
+                                "input_dtype": "uint8", "max_to_keep": 2,
+                                "model_config": {"BATCH_SIZE": 32, "LR": 0.001, "NUM_SGD_ITER": 2, "SEED": 3,
+                                                 "hidden_sizes": [64], "VF_SHARE_LAYERS": True,
+                                                 "SAVE_OPTIMIZER": save_opt}}}
+        return alg_builder("PPO", model_info, {"instance_num": 1, "agent_num": 1})
+
+    rng = np.random.default_rng(11)
+    rollouts = [synth_ppo_rollout(rng, 64, (42, 42, 4), 6) for _ in range(4)]
+    perms = [np.stack([rng.permutation(64) for _ in range(2)]).astype(np.int32) for _ in range(4)]
+
+    def feed(alg, i):
+        obs, lab = rollouts[i]
+        alg.prepare_data({"cur_state": obs, "action": lab[0], "logp": lab[1], "adv": lab[2], "old_value": lab[3],
+                          "target_value": lab[4]})
+        return alg.train(perms=perms[i])
+
+    ref = mk()
+    for i in range(4):
+        feed(ref, i)
+    w_ref = ref.get_weights()
+
+    with tempfile.TemporaryDirectory() as tmp:
+        a = mk()
+        feed(a, 0), feed(a, 1)
+        (name,) = a.save(tmp, 2)
+        z = np.load(name)
+        names = list(a.get_weights().keys())
+        assert all(k in z.files for k in names)
+        assert all(k + "/Adam" in z.files and k + "/Adam_1" in z.files for k in names)
+        assert abs(float(z["beta1_power"]) - 0.9 ** 8) < 1e-6 and int(z["adam_step"]) == 8   # 2 updates x 2 epochs x 2 minibatches
+        only_vars = {k: z[k] for k in names}                       # what the reference's loader would pick up
+        b = mk()
+        assert not all(np.array_equal(b.get_weights()[k], only_vars[k]) for k in names)
+        b.restore(model_name=name)
+        assert b.actor.optimizer_restored is True
+        feed(b, 2), feed(b, 3)
+        w_b = b.get_weights()
+        assert all(np.array_equal(w_ref[k], w_b[k]) for k in names), "resume is not bit-exact"
+        # reference behaviour (weights only): Adam restarts -> a different trajectory
+        c = mk()
+        c.restore(model_weights=only_vars)
+        feed(c, 2), feed(c, 3)
+        assert not all(np.array_equal(w_ref[k], c.get_weights()[k]) for k in names)
+        # rotation (xt/model/model.py:130-136): max_to_keep = 2 newest actor_* files survive the NEXT save
+        for idx in (3, 4, 5):
+            a.save(tmp, idx)
+        kept = sorted(f for f in os.listdir(tmp) if f.startswith("actor"))
+        assert kept[-1] == "actor_00005.npz" and len(kept) == 3, kept
+        # weights-only files
+        d = mk(save_opt=False)
+        (n2,) = d.save(tmp, 9)
+        assert sorted(np.load(n2).files) == sorted(names)
+        e = mk()
+        e.restore(model_name=n2)
+        assert e.actor.optimizer_restored is False

@@ -115,6 +115,50 @@ class HipActorCritic(object):
             flat[off:off + val.size] = val.reshape(-1)
         self.params.copy_(torch.from_numpy(flat))
 
+    # ------------------------------------------------------------------ optimizer state
+    # The reference never checkpoints its AdamOptimizer slots (TFVariables only walks the trainable variables,
+    # xt/model/tf_utils.py:60-97), so a restored run restarts Adam from zero.  For a true resume the slots are
+    # exported under the names TF1 itself gives them ("<var>/Adam" = m, "<var>/Adam_1" = v, "beta1_power",
+    # "beta2_power"), next to the weights: TFVariables.set_weights ignores names it does not know
+    # (tf_utils.py:106-109), so the same .npz still loads in the reference.
+    OPT_M, OPT_V, OPT_B1, OPT_B2, OPT_STEP = "/Adam", "/Adam_1", "beta1_power", "beta2_power", "adam_step"
+
+    def get_optimizer_state(self):
+        m = self.adam_m.detach().cpu().numpy()
+        v = self.adam_v.detach().cpu().numpy()
+        st = self.adam_state.detach().cpu().numpy()
+        out = OrderedDict()
+        for name, (off, shape) in self.spec.names.items():
+            size = int(np.prod(shape))
+            out[name + self.OPT_M] = m[off:off + size].reshape(shape).copy()
+            out[name + self.OPT_V] = v[off:off + size].reshape(shape).copy()
+        out[self.OPT_B1] = np.float32(st[0])
+        out[self.OPT_B2] = np.float32(st[1])
+        out[self.OPT_STEP] = np.int64(round(float(st[5])))
+        return out
+
+    def set_optimizer_state(self, state):
+        """Restore Adam slots saved by get_optimizer_state; returns False (state untouched) unless EVERY slot
+        and both beta powers are present with the right shapes."""
+        need = [n + sfx for n in self.spec.names for sfx in (self.OPT_M, self.OPT_V)] + [self.OPT_B1, self.OPT_B2]
+        if any(k not in state for k in need):
+            return False
+        m = np.zeros(self.spec.n_flat, np.float32)
+        v = np.zeros(self.spec.n_flat, np.float32)
+        for name, (off, shape) in self.spec.names.items():
+            for sfx, dst in ((self.OPT_M, m), (self.OPT_V, v)):
+                val = np.asarray(state[name + sfx], np.float32)
+                if tuple(val.shape) != tuple(shape):
+                    raise KeyError("optimizer slot {} shape {} vs {}".format(name + sfx, val.shape, shape))
+                dst[off:off + val.size] = val.reshape(-1)
+        st = self.adam_state.detach().cpu().numpy().copy()
+        st[0], st[1] = np.float32(state[self.OPT_B1]), np.float32(state[self.OPT_B2])
+        st[5] = np.float32(state[self.OPT_STEP]) if self.OPT_STEP in state else 0.0
+        self.adam_m.copy_(torch.from_numpy(m))
+        self.adam_v.copy_(torch.from_numpy(v))
+        self.adam_state.copy_(torch.from_numpy(st))
+        return True
+
     def reset_optimizer(self):
         self.adam_m.zero_()
         self.adam_v.zero_()
