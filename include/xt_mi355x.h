@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define XT_ABI_VERSION 1
+#define XT_ABI_VERSION 2
 
 #define XT_ACT_NONE 0
 #define XT_ACT_RELU 1
@@ -122,6 +122,19 @@ int xt_ppo_loss(const float* logits, const float* value, int32_t B, int32_t A,
                 float inv_b, float* dlogits, float* dvalue, float* loss_terms,
                 void* stream);
 
+/* The same loss with the continuous-action distribution: DiagGaussianDist
+ * (xt/model/tf_dist.py:47-87) over dist_param = concat([pi_latent, pi_latent*0 + pi_logstd])
+ * (xt/model/ppo/ppo.py:75-79; examples/pendulum_ppo.yaml).  mean [B,A] is the pi_latent
+ * output, log_std [A] the trainable state-independent variable, action float32 [N,A]
+ * (gathered through idx).  dmean [B,A]; dlogstd_rows [B,A] holds every sample's
+ * contribution to d loss / d pi_logstd (their fixed-order sum over B is the gradient). */
+int xt_ppo_loss_gauss(const float* mean, const float* log_std, const float* value, int32_t B,
+                      int32_t A, const int32_t* idx, const float* action, const float* old_logp,
+                      const double* adv, const float* old_v, const double* target_v,
+                      float clip_ratio, float ent_coef, float vf_clip, float critic_coef,
+                      float inv_b, float* dmean, float* dvalue, float* dlogstd_rows,
+                      float* loss_terms, void* stream);
+
 /* loss scalar from the per-sample terms of xt_ppo_loss:
  * out[0]=loss, out[1]=actor_loss, out[2]=critic_loss, out[3]=mean entropy;
  * if acc != NULL, acc[0] += loss (running sum for the mean over minibatches,
@@ -175,6 +188,9 @@ int xt_grad_global_norm(const float* grad, int64_t count, float clip_norm, float
  * Model.train().  Buffers stay caller-owned. */
 typedef struct xt_net xt_net;
 
+#define XT_ACTION_CATEGORICAL 0    /* action: int32 [N]       (CategoricalDist, tf_dist.py:89)  */
+#define XT_ACTION_DIAG_GAUSSIAN 1  /* action: float32 [N, A]  (DiagGaussianDist, tf_dist.py:47) */
+
 typedef struct xt_layer_desc {
   xt_conv_geom g;
   int64_t param_off;    /* offset (floats) of this layer's [K*N]+[N] block in the flat buffer */
@@ -191,6 +207,8 @@ typedef struct xt_net_desc {
   int64_t n_params;
   xt_input_xform xf;
   int32_t in_h, in_w, in_c;     /* observation shape                                      */
+  int32_t action_type;          /* XT_ACTION_CATEGORICAL | XT_ACTION_DIAG_GAUSSIAN (ABI >= 2) */
+  int64_t logstd_off;           /* offset of pi_logstd [A] (DiagGaussian only; multiple of 4) */
 } xt_net_desc;
 
 int xt_net_create(const xt_net_desc* desc, int32_t max_batch, xt_net** out);
@@ -216,7 +234,8 @@ typedef struct xt_ppo_cfg {
  * `apply` != 0 also runs clip+Adam (single GPU).  loss_out: 4 floats (see
  * xt_ppo_loss_reduce); loss_acc optional running sum. */
 int xt_net_ppo_step(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, const int32_t* idx,
-                    int32_t B, const int32_t* action, const float* old_logp, const double* adv,
+                    int32_t B, const void* action /* int32 [N] | float32 [N,A], see XT_ACTION_* */,
+                    const float* old_logp, const double* adv,
                     const float* old_v, const double* target_v, int32_t apply,
                     float* loss_out, float* loss_acc, void* stream);
 
@@ -227,7 +246,7 @@ int xt_net_ppo_step(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, const i
  * captures the whole call into a hipGraph on first use and replays it afterwards
  * (pointers and sizes must then stay the same between calls). */
 int xt_net_ppo_train(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, int32_t n,
-                     const int32_t* perm, const int32_t* action, const float* old_logp,
+                     const int32_t* perm, const void* action, const float* old_logp,
                      const double* adv, const float* old_v, const double* target_v,
                      float* loss_acc, int32_t use_graph, void* stream);
 

@@ -101,14 +101,16 @@ def ppo_cnn_spec(state_dim, action_dim, hidden_sizes=(512,), act="relu", vf_shar
                 v_name="output_value", input_scale=("div", 0.0, 255.0))
 
 
-def ppo_mlp_spec(state_dim, action_dim, hidden_sizes=(64, 64), act="tanh", vf_share=False):
-    """Layer lists for ``get_mlp_backbone`` xt/model/model_utils.py:22-46."""
+def ppo_mlp_spec(state_dim, action_dim, hidden_sizes=(64, 64), act="tanh", vf_share=False,
+                 action_type="Categorical"):
+    """Layer lists for ``get_mlp_backbone`` xt/model/model_utils.py:22-46.  ``action_type`` 'DiagGaussian'
+    adds the state-independent ``pi_logstd`` [1,A] variable of xt/model/ppo/ppo.py:75-79."""
     trunks = []
     for prefix in (["shared"] if vf_share else ["pi", "v"]):
         mlps, feat = _mlp_trunk(prefix, int(state_dim[0]), hidden_sizes, act)
         trunks.append(mlps)
     return dict(trunks=trunks, feat=feat, action_dim=action_dim, pi_name="pi_latent",
-                v_name="output_value", input_scale=None)
+                v_name="output_value", input_scale=None, action_type=action_type)
 
 
 def impala_cnn_opt_spec(state_dim, action_dim, state_mean=0.0, state_std=255.0):
@@ -183,6 +185,9 @@ def init_params(spec, seed=0, dtype=np.float32, bias_scale=0.0):
                             add(lay.name, lay.kernel_shape)
             add(spec["pi_name"], (spec["feat"], spec["action_dim"]))
             add(spec["v_name"], (spec["feat"], 1))
+    if spec.get("action_type") == "DiagGaussian":
+        # tf.get_variable('pi_logstd', (1, A), zeros) is created in build_graph, after the Keras model (ppo.py:78)
+        params["pi_logstd"] = np.zeros((1, spec["action_dim"]), dtype)
     return params
 
 
@@ -279,9 +284,10 @@ class ActorCritic(object):
         value = f_v @ self.params[self.spec["v_name"] + "/kernel"] + self.params[self.spec["v_name"] + "/bias"]
         return logits, value
 
-    def backward(self, dlogits, dvalue):
-        """dlogits [B,A], dvalue [B,1] -> grads dict (same keys as params)."""
-        grads = OrderedDict()
+    def backward(self, dlogits, dvalue, extra=None):
+        """dlogits [B,A], dvalue [B,1] -> grads dict (same keys as params).  ``extra``: gradients of variables
+        outside the layer stack (pi_logstd)."""
+        grads = OrderedDict(extra or {})
         f_pi, f_v = self.feats[0], self.feats[-1]
         wpi = self.params[self.spec["pi_name"] + "/kernel"]
         wv = self.params[self.spec["v_name"] + "/kernel"]
@@ -367,6 +373,48 @@ def ppo_loss_and_grads(logits, value, action, old_logp, adv, old_v, target_v,
     dvalue = (critic_coef * 0.5 / bsz) * dv
     parts = dict(actor_loss=actor_loss, critic_loss=critic, entropy=ent.mean(), logp=logp)
     return dt.type(loss), dlogits.astype(dt), dvalue.astype(dt), parts
+
+
+def gauss_ppo_loss_and_grads(mean, log_std, value, action, old_logp, adv, old_v, target_v,
+                             clip_ratio, ent_coef, vf_clip, critic_coef):
+    """PPO loss with ``DiagGaussianDist`` (xt/model/tf_dist.py:47-87; dist_param = concat([pi_latent,
+    pi_latent*0 + pi_logstd]), xt/model/ppo/ppo.py:75-79).  mean [B,A], log_std [1,A], action [B,A] float.
+    Returns (loss, dmean [B,A], dvalue [B,1], dlog_std [1,A], parts)."""
+    dt = mean.dtype
+    bsz, adim = mean.shape
+    log_std = np.asarray(log_std, dt).reshape(1, adim)
+    std = np.exp(log_std)
+    x = np.asarray(action, dt).reshape(bsz, adim)
+    zz = (x - mean) / std
+    # neglog_prob, tf_dist.py:66-69 (the python-float constant is cast to the tensor dtype)
+    neglogp = dt.type(0.5 * np.log(2.0 * np.pi)) * dt.type(adim) + 0.5 * np.square(zz).sum(-1, keepdims=True) \
+        + (log_std + 0.0 * mean).sum(-1, keepdims=True)
+    logp = -neglogp
+    ent = (log_std + dt.type(0.5 * (np.log(2.0 * np.pi) + 1.0)) + 0.0 * mean).sum(-1, keepdims=True)   # :74-75
+    ratio = np.exp(logp - old_logp)
+    surr1 = ratio * adv
+    clipped = np.clip(ratio, 1.0 - clip_ratio, 1.0 + clip_ratio)
+    surr2 = clipped * adv
+    surr = np.minimum(surr1, surr2)
+    actor_loss = -surr.mean() - ent_coef * ent.mean()
+    vf1 = np.square(value - target_v)
+    vclip = old_v + np.clip(value - old_v, -vf_clip, vf_clip)
+    vf2 = np.square(vclip - target_v)
+    critic = 0.5 * np.maximum(vf1, vf2).mean()
+    loss = actor_loss + critic_coef * critic
+    first = surr1 <= surr2
+    in_rng = (ratio >= 1.0 - clip_ratio) & (ratio <= 1.0 + clip_ratio)
+    dsurr_dratio = np.where(first, adv, np.where(in_rng, adv, 0.0))
+    dlogp = -(dsurr_dratio * ratio) / bsz
+    dmean = dlogp * zz / std
+    dls_rows = dlogp * (np.square(zz) - 1.0) - (ent_coef / bsz)
+    dlog_std = dls_rows.sum(0, keepdims=True)
+    take1 = vf1 >= vf2
+    in_v = np.abs(value - old_v) <= vf_clip
+    dv = np.where(take1, 2.0 * (value - target_v), np.where(in_v, 2.0 * (vclip - target_v), 0.0))
+    dvalue = (critic_coef * 0.5 / bsz) * dv
+    parts = dict(actor_loss=actor_loss, critic_loss=critic, entropy=ent.mean(), logp=logp, dls_rows=dls_rows)
+    return dt.type(loss), dmean.astype(dt), dvalue.astype(dt), dlog_std.astype(dt), parts
 
 
 # ----------------------------------------------------------------------------
@@ -458,11 +506,18 @@ class PpoLearnerOracle(object):
     def step(self, obs, action, old_logp, adv, old_v, target_v, apply=True):
         c, dt = self.cfg, self.dtype
         logits, value = self.net.forward(obs)
-        loss, dlogits, dvalue, parts = ppo_loss_and_grads(
-            logits, value, action, np.asarray(old_logp, dt), np.asarray(adv, dt),
-            np.asarray(old_v, dt), np.asarray(target_v, dt),
-            c["LOSS_CLIPPING"], c["ENTROPY_LOSS"], c["VF_CLIP"], c["CRITIC_LOSS_COEF"])
-        grads = self.net.backward(dlogits, dvalue)
+        if self.net.spec.get("action_type") == "DiagGaussian":
+            loss, dlogits, dvalue, dls, parts = gauss_ppo_loss_and_grads(
+                logits, self.net.params["pi_logstd"], value, action, np.asarray(old_logp, dt), np.asarray(adv, dt),
+                np.asarray(old_v, dt), np.asarray(target_v, dt),
+                c["LOSS_CLIPPING"], c["ENTROPY_LOSS"], c["VF_CLIP"], c["CRITIC_LOSS_COEF"])
+            grads = self.net.backward(dlogits, dvalue, extra={"pi_logstd": dls})
+        else:
+            loss, dlogits, dvalue, parts = ppo_loss_and_grads(
+                logits, value, action, np.asarray(old_logp, dt), np.asarray(adv, dt),
+                np.asarray(old_v, dt), np.asarray(target_v, dt),
+                c["LOSS_CLIPPING"], c["ENTROPY_LOSS"], c["VF_CLIP"], c["CRITIC_LOSS_COEF"])
+            grads = self.net.backward(dlogits, dvalue)
         clipped, gnorm = clip_by_global_norm(grads, c["MAX_GRAD_NORM"])
         if apply:
             self.opt.apply(self.net.params, clipped)

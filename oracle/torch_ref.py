@@ -143,6 +143,26 @@ class TorchAdamTF(object):
         return gn
 
 
+def gauss_ppo_loss_torch(mean, log_std, value, action, old_logp, adv, old_v, target_v,
+                         clip_ratio, ent_coef, vf_clip, critic_coef):
+    """DiagGaussianDist (tf_dist.py:47-87) in the PPO loss, written with torch ops for autograd."""
+    x = torch.as_tensor(np.asarray(action), dtype=mean.dtype).reshape(mean.shape)
+    param_ls = mean * 0.0 + log_std                      # ppo.py:79
+    std = torch.exp(param_ls)
+    neglogp = 0.5 * np.log(2.0 * np.pi) * mean.shape[-1] + 0.5 * (((x - mean) / std) ** 2).sum(-1, keepdim=True) \
+        + param_ls.sum(-1, keepdim=True)
+    logp = -neglogp
+    ent = (param_ls + 0.5 * (np.log(2.0 * np.pi) + 1.0)).sum(-1, keepdim=True)
+    ratio = torch.exp(logp - old_logp)
+    surr = torch.minimum(ratio * adv, torch.clamp(ratio, 1.0 - clip_ratio, 1.0 + clip_ratio) * adv)
+    actor = -surr.mean() - ent_coef * ent.mean()
+    vf1 = (value - target_v) ** 2
+    vclip = old_v + torch.clamp(value - old_v, -vf_clip, vf_clip)
+    vf2 = (vclip - target_v) ** 2
+    critic = 0.5 * torch.maximum(vf1, vf2).mean()
+    return actor + critic_coef * critic
+
+
 class TorchPpoLearner(object):
     """Whole PPO update on CPU; ``train`` mirrors xt/model/ppo/ppo.py:111-132."""
 
@@ -156,9 +176,14 @@ class TorchPpoLearner(object):
         for p in self.net.params.values():
             p.grad = None
         logits, value = self.net.forward(obs)
-        loss = ppo_loss_torch(logits, value, action, _to_t(old_logp, dt), _to_t(adv, dt), _to_t(old_v, dt),
-                              _to_t(target_v, dt), c["LOSS_CLIPPING"], c["ENTROPY_LOSS"], c["VF_CLIP"],
-                              c["CRITIC_LOSS_COEF"])
+        if self.net.spec.get("action_type") == "DiagGaussian":
+            loss = gauss_ppo_loss_torch(logits, self.net.params["pi_logstd"], value, action, _to_t(old_logp, dt),
+                                        _to_t(adv, dt), _to_t(old_v, dt), _to_t(target_v, dt), c["LOSS_CLIPPING"],
+                                        c["ENTROPY_LOSS"], c["VF_CLIP"], c["CRITIC_LOSS_COEF"])
+        else:
+            loss = ppo_loss_torch(logits, value, action, _to_t(old_logp, dt), _to_t(adv, dt), _to_t(old_v, dt),
+                                  _to_t(target_v, dt), c["LOSS_CLIPPING"], c["ENTROPY_LOSS"], c["VF_CLIP"],
+                                  c["CRITIC_LOSS_COEF"])
         loss.backward()
         grads = {k: p.grad.clone() for k, p in self.net.params.items()}
         gn = None

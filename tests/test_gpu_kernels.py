@@ -352,3 +352,44 @@ def test_adam_tf_clip(L, count, clip):
         assert abs(st[4] - gn) < 1e-5 * gn
         assert st[5] == it + 1
         np.testing.assert_allclose(dp.cpu().numpy(), params["w"], rtol=2e-5, atol=2e-7)
+
+
+@pytest.mark.parametrize("b,a_dim", [(37, 1), (200, 3), (64, 6)])
+def test_ppo_loss_gauss_vs_oracle(L, b, a_dim):
+    """xt_ppo_loss_gauss (DiagGaussianDist, tf_dist.py:47-87) against the oracle on the same fp32 inputs:
+    loss scalars, d mean, d value and the per-sample pi_logstd rows (whose column sums are the gradient)."""
+    lib = L.load()
+    rng = np.random.default_rng(100 + b)
+    n_pool = b + 29
+    idx = rng.permutation(n_pool)[:b].astype(np.int32)
+    mean = rng.standard_normal((b, a_dim)).astype(np.float32)
+    log_std = (rng.standard_normal(a_dim) * 0.4).astype(np.float32)
+    value = rng.standard_normal(b).astype(np.float32)
+    action = (rng.standard_normal((n_pool, a_dim)) * 1.3).astype(np.float32)
+    old_logp = (-np.abs(rng.standard_normal(n_pool)) - 0.3 * a_dim).astype(np.float32)
+    adv = rng.standard_normal(n_pool)
+    old_v = rng.standard_normal(n_pool).astype(np.float32)
+    target_v = old_v + rng.standard_normal(n_pool) * 2
+    clip, entc, vfc, cc = 0.2, 0.01, 0.5, 1.0
+    f64 = lambda x: np.asarray(x, np.float32).astype(np.float64)
+    loss, dmean, dv, dls, parts = nets.gauss_ppo_loss_and_grads(
+        f64(mean), f64(log_std).reshape(1, -1), f64(value).reshape(-1, 1), f64(action[idx]),
+        f64(old_logp[idx]).reshape(-1, 1), f64(adv[idx]).reshape(-1, 1), f64(old_v[idx]).reshape(-1, 1),
+        f64(target_v[idx]).reshape(-1, 1), clip, entc, vfc, cc)
+    d_dmean = torch.zeros((b, a_dim), device="cuda")
+    d_dv = torch.zeros(b, device="cuda")
+    d_rows = torch.zeros((b, a_dim), device="cuda")
+    terms = torch.zeros((b, 4), device="cuda")
+    out = torch.zeros(8, device="cuda")
+    L.check(lib.xt_ppo_loss_gauss(L.ptr(dev(mean)), L.ptr(dev(log_std)), L.ptr(dev(value)), b, a_dim, L.ptr(dev(idx)),
+                                  L.ptr(dev(action)), L.ptr(dev(old_logp)), L.ptr(dev(adv)), L.ptr(dev(old_v)),
+                                  L.ptr(dev(target_v)), clip, entc, vfc, cc, 1.0 / b, L.ptr(d_dmean), L.ptr(d_dv),
+                                  L.ptr(d_rows), L.ptr(terms), None), "ppo_loss_gauss")
+    L.check(lib.xt_ppo_loss_reduce(L.ptr(terms), b, entc, cc, 1.0 / b, L.ptr(out), None, None), "reduce")
+    o = out.cpu().numpy()
+    assert abs(o[0] - loss) < 1e-5 * max(1.0, abs(loss))
+    assert abs(o[3] - parts["entropy"]) < 1e-5 * max(1.0, abs(parts["entropy"]))
+    assert rel_err(d_dmean.cpu().numpy(), dmean) < 1e-5
+    assert rel_err(d_dv.cpu().numpy(), dv[:, 0]) < 1e-5
+    assert rel_err(d_rows.cpu().numpy(), parts["dls_rows"]) < 1e-5
+    assert rel_err(d_rows.cpu().numpy().astype(np.float64).sum(0), dls[0]) < 1e-5

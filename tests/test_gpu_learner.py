@@ -413,3 +413,72 @@ def test_checkpoint_resume_is_bit_exact_and_reference_loadable():
         e = mk()
         e.restore(model_name=n2)
         assert e.actor.optimizer_restored is False
+
+
+@pytest.mark.parametrize("sd,ad,hidden,share", [((3,), 1, (64, 64), False), ((5,), 3, (32,), True)])
+def test_gauss_ppo_mlp_update_vs_oracle(sd, ad, hidden, share):
+    """continuous-action PPO (examples/pendulum_ppo.yaml: PpoMlp, state 3, action 1, tanh 64-64,
+    unshared) through the registry: loss, every gradient (incl. pi_logstd) and the post-Adam weights of a
+    multi-minibatch train() against the float64 oracle; predict() contract of DiagGaussianDist."""
+    from xingtian_amd.algorithm import alg_builder
+    cfg = {"BATCH_SIZE": 40, "CRITIC_LOSS_COEF": 1.0, "ENTROPY_LOSS": 0.01, "LR": 0.0003, "LOSS_CLIPPING": 0.2,
+           "MAX_GRAD_NORM": 5.0, "NUM_SGD_ITER": 3, "VF_SHARE_LAYERS": share, "activation": "tanh",
+           "hidden_sizes": list(hidden), "action_type": "DiagGaussian", "SEED": 5, "VF_CLIP": 10.0}
+    model_info = {"actor": {"model_name": "PpoMlp", "state_dim": list(sd), "action_dim": ad,
+                            "input_dtype": "float32", "model_config": cfg}}
+    alg = alg_builder("PPO", model_info, {"instance_num": 2, "agent_num": 1})
+    net = alg.actor.net
+    w0 = alg.get_weights()
+    assert w0["pi_logstd"].shape == (1, ad) and not w0["pi_logstd"].any()
+    assert w0["pi_hidden_mlp_0/kernel" if not share else "shared_hidden_mlp_0/kernel"].shape == (sd[0], hidden[0])
+    w0["pi_logstd"] = (np.random.default_rng(1).standard_normal((1, ad)) * 0.3).astype(np.float32)
+    alg.set_weights(w0)
+    rng = np.random.default_rng(8)
+    n = 100                                            # 40 + 40 + 20: short last minibatch (variable-length episodes)
+    obs = rng.uniform(-1, 1, (n,) + sd).astype(np.float32)
+    action = rng.standard_normal((n, ad)).astype(np.float32)
+    lab = [action, (-np.abs(rng.standard_normal((n, 1))) - 0.5).astype(np.float32), rng.standard_normal((n, 1)),
+           rng.standard_normal((n, 1)).astype(np.float32), rng.standard_normal((n, 1))]
+    ospec = nets.ppo_mlp_spec(sd, ad, hidden, "tanh", share, action_type="DiagGaussian")
+    shapes = nets.init_params(ospec)
+    ocfg = dict(LR=0.0003, LOSS_CLIPPING=0.2, ENTROPY_LOSS=0.01, VF_CLIP=10.0, CRITIC_LOSS_COEF=1.0, MAX_GRAD_NORM=5.0,
+                BATCH_SIZE=40, NUM_SGD_ITER=3)
+    orc = nets.PpoLearnerOracle(ospec, {k: w0[k].reshape(shapes[k].shape) for k in shapes}, ocfg, np.float64)
+    # single step: loss + grads
+    c = net.make_ppo_cfg(dict(ocfg, BATCH_SIZE=40))
+    d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).cuda()
+    idx = d(np.arange(40), np.int32)
+    out = net.ppo_step(c, alg.actor.net.to_device_obs(obs), idx, d(action, np.float32), d(lab[1].reshape(-1), np.float32),
+                       d(lab[2].reshape(-1), np.float64), d(lab[3].reshape(-1), np.float32),
+                       d(lab[4].reshape(-1), np.float64), apply=False).cpu().numpy()
+    ref = orc.step(obs[:40], action[:40], lab[1][:40], lab[2][:40].astype(np.float32), lab[3][:40],
+                   lab[4][:40].astype(np.float32), apply=False)
+    assert abs(out[0] - ref["loss"]) < 1e-5 * max(1.0, abs(ref["loss"]))
+    g = net.grads_dict()
+    for k, r in ref["grads"].items():
+        assert rel_err(g[k].reshape(r.shape), r) < 1e-4, (k, rel_err(g[k].reshape(r.shape), r))
+    # whole train() with injected permutations
+    for i in range(2):
+        alg.prepare_data({"cur_state": obs[i * 50:(i + 1) * 50], "action": action[i * 50:(i + 1) * 50],
+                          "logp": lab[1][i * 50:(i + 1) * 50], "adv": lab[2][i * 50:(i + 1) * 50],
+                          "old_value": lab[3][i * 50:(i + 1) * 50], "target_value": lab[4][i * 50:(i + 1) * 50]})
+    perms = np.stack([rng.permutation(n) for _ in range(3)]).astype(np.int32)
+    loss = alg.train(perms=perms)
+    ref_loss = orc.train([obs], lab, perms)
+    assert abs(loss - ref_loss) < 1e-4 * max(1.0, abs(ref_loss))
+    w1 = alg.get_weights()
+    for k, r in orc.net.params.items():
+        got, init = w1[k].reshape(r.shape), w0[k].reshape(r.shape)
+        assert rel_err(got - init, r - init) < 5e-3, (k, rel_err(got - init, r - init))
+    # zero-padded input rows of the first kernel stay exactly zero
+    if sd[0] % 4:
+        flat = net.params.detach().cpu().numpy()
+        lay0 = net.spec.layers[0]
+        off = lay0.param_off + sd[0] * lay0.N
+        assert not flat[off:off + (lay0.C - sd[0]) * lay0.N].any()
+    a_out, logp, value = alg.predict(obs[0])
+    assert a_out.shape == (1, ad) and a_out.dtype == np.float32 and logp.shape == (1, 1) and value.shape == (1, 1)
+    ls = w1["pi_logstd"].astype(np.float64)
+    mean, _ = net.forward(obs[:1])
+    z = (a_out.astype(np.float64) - mean.cpu().numpy().astype(np.float64)) / np.exp(ls)
+    assert abs(float(logp[0, 0]) + (0.5 * np.log(2 * np.pi) * ad + 0.5 * (z ** 2).sum() + ls.sum())) < 1e-4

@@ -73,6 +73,34 @@ def test_ppo_grads_match_torch_autograd_fp64(which):
             np.testing.assert_allclose(o.net.params[k], t.net.params[k].detach().numpy(), rtol=1e-9, atol=1e-12)
 
 
+def test_gauss_ppo_grads_match_torch_autograd_fp64():
+    """DiagGaussian PPO (pendulum_ppo.yaml shape: state 3, action 1, tanh 64-64 unshared) + a 3-dim action case."""
+    for sd, ad in (((3,), 1), ((5,), 3)):
+        spec = nets.ppo_mlp_spec(sd, ad, (64, 64), "tanh", False, action_type="DiagGaussian")
+        params = nets.init_params(spec, seed=4, dtype=np.float64, bias_scale=0.1)
+        assert list(params)[-1] == "pi_logstd" and params["pi_logstd"].shape == (1, ad)
+        params["pi_logstd"] = np.random.default_rng(5).standard_normal((1, ad)) * 0.3
+        rng = np.random.default_rng(6)
+        b = 48
+        obs = rng.uniform(-1, 1, (b,) + sd).astype(np.float32)
+        act = rng.standard_normal((b, ad))
+        lab = [act, -np.abs(rng.standard_normal((b, 1))) - 0.5, rng.standard_normal((b, 1)),
+               rng.standard_normal((b, 1)), rng.standard_normal((b, 1))]
+        cfg = dict(LR=3e-3, LOSS_CLIPPING=0.2, ENTROPY_LOSS=0.01, VF_CLIP=0.7, CRITIC_LOSS_COEF=1.0,
+                   MAX_GRAD_NORM=0.5, BATCH_SIZE=b, NUM_SGD_ITER=1)
+        o = nets.PpoLearnerOracle(spec, params, cfg, np.float64)
+        t = torch_ref.TorchPpoLearner(spec, params, cfg, torch.float64)
+        for it in range(3):
+            out = o.step(obs, *lab)
+            tl, tg, gn = t.step(obs, *lab)
+            assert abs(out["loss"] - tl) < 1e-10 * max(1, abs(tl))
+            for k in tg:
+                np.testing.assert_allclose(out["grads"][k], tg[k].numpy(), rtol=1e-8, atol=1e-12, err_msg=k)
+            assert abs(out["gnorm"] - gn) < 1e-9
+            for k in tg:
+                np.testing.assert_allclose(o.net.params[k], t.net.params[k].detach().numpy(), rtol=1e-9, atol=1e-12)
+
+
 def test_same_padding_geometry():
     assert nets.conv_out_size(84, 8, 4, "same") == (21, 2, 2)
     assert nets.conv_out_size(21, 4, 2, "same") == (11, 1, 2)

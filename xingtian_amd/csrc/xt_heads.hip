@@ -95,6 +95,68 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* __restrict__
   tm[0] = surr; tm[1] = ent; tm[2] = fmaxf(vf1, vf2); tm[3] = 0.f;
 }
 
+// The same loss over DiagGaussianDist (xt/model/tf_dist.py:47-87; dist_param = concat([pi_latent,
+// pi_latent*0 + pi_logstd]), xt/model/ppo/ppo.py:75-79).  One thread per sample.  dls_rows [B][ldls] gets every
+// sample's share of d loss / d pi_logstd (surrogate part + the -ent_coef * mean(entropy) part); the gradient is
+// their fixed-order sum (grads_finish_kernel treats the rows as B partial slabs).
+__global__ __launch_bounds__(256) void ppo_loss_gauss_kernel(const float* __restrict__ mean, const float* __restrict__ log_std,
+                                                             const float* __restrict__ value, int B, int A,
+                                                             const int32_t* __restrict__ idx,
+                                                             const float* __restrict__ action,
+                                                             const float* __restrict__ old_logp,
+                                                             const double* __restrict__ adv, const float* __restrict__ old_v,
+                                                             const double* __restrict__ target_v, float clip_ratio,
+                                                             float ent_coef, float vf_clip, float critic_coef, float inv_b,
+                                                             float* __restrict__ dmean, float* __restrict__ dvalue,
+                                                             float* __restrict__ dls_rows, int ldls,
+                                                             float* __restrict__ terms) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const int s = idx ? idx[b] : b;
+  const float* mu = mean + (size_t)b * A;
+  const float* x = action + (size_t)s * A;
+  // neglog_prob = 0.5*log(2*pi)*A + 0.5*sum(((x-mean)/std)^2) + sum(log_std)        (tf_dist.py:66-69)
+  float ssq = 0.f, sls = 0.f, ent = 0.f;
+  for (int a = 0; a < A; ++a) {
+    const float ls = log_std[a];
+    const float z = (x[a] - mu[a]) / expf(ls);
+    ssq += z * z;
+    sls += ls;
+    ent += ls + 1.4189385332046727f;               // 0.5*(log(2*pi)+1)                (tf_dist.py:74-75)
+  }
+  const float logp = -(0.9189385332046727f * (float)A + 0.5f * ssq + sls);
+  const float advf = (float)adv[s];
+  const float tv = (float)target_v[s];
+  const float ov = old_v[s];
+  const float ratio = expf(logp - old_logp[s]);
+  const float surr1 = ratio * advf;
+  const float rc = fminf(fmaxf(ratio, 1.f - clip_ratio), 1.f + clip_ratio);
+  const float surr2 = rc * advf;
+  const float surr = fminf(surr1, surr2);
+  const bool first = surr1 <= surr2;
+  const bool in_rng = (ratio >= 1.f - clip_ratio) && (ratio <= 1.f + clip_ratio);
+  const float dsurr = (first || in_rng) ? advf : 0.f;
+  const float dlogp = -(dsurr * ratio) * inv_b;
+  const float v = value[b];
+  const float d1 = v - tv;
+  const float vf1 = d1 * d1;
+  const float vcl = ov + fminf(fmaxf(v - ov, -vf_clip), vf_clip);
+  const float d2 = vcl - tv;
+  const float vf2 = d2 * d2;
+  const bool take1 = vf1 >= vf2;
+  const bool in_v = fabsf(v - ov) <= vf_clip;
+  const float dv = take1 ? 2.f * d1 : (in_v ? 2.f * d2 : 0.f);
+  dvalue[b] = critic_coef * 0.5f * inv_b * dv;
+  for (int a = 0; a < A; ++a) {
+    const float sd = expf(log_std[a]);
+    const float z = (x[a] - mu[a]) / sd;
+    dmean[(size_t)b * A + a] = dlogp * z / sd;                                   // d logp / d mean = (x-mean)/std^2
+    dls_rows[(size_t)b * ldls + a] = dlogp * (z * z - 1.f) - ent_coef * inv_b;   // d logp / d log_std = z^2 - 1; dH/dls = 1
+  }
+  float* tm = terms + (size_t)b * 4;
+  tm[0] = surr; tm[1] = ent; tm[2] = fmaxf(vf1, vf2); tm[3] = 0.f;
+}
+
 // single block, fixed-order tree: loss scalars from the per-sample terms
 __global__ __launch_bounds__(256) void ppo_loss_reduce_kernel(const float* __restrict__ terms, int B, float ent_coef,
                                                               float critic_coef, float inv_b, float* __restrict__ out,
@@ -571,6 +633,19 @@ __global__ __launch_bounds__(64) void gae_f64_kernel(const float* __restrict__ v
   }
 }
 
+int launch_ppo_loss_gauss(const float* mean, const float* log_std, const float* value, int B, int A, const int32_t* idx,
+                          const float* action, const float* old_logp, const double* adv, const float* old_v,
+                          const double* target_v, float clip_ratio, float ent_coef, float vf_clip, float critic_coef,
+                          float inv_b, float* dmean, float* dvalue, float* dls_rows, int ldls, float* terms,
+                          hipStream_t st) {
+  XT_REQUIRE(B > 0 && A > 0 && ldls >= A && mean && log_std && action && dls_rows, "xt_ppo_loss_gauss: bad arguments");
+  hipLaunchKernelGGL(ppo_loss_gauss_kernel, dim3((B + 255) / 256), dim3(256), 0, st, mean, log_std, value, B, A, idx,
+                     action, old_logp, adv, old_v, target_v, clip_ratio, ent_coef, vf_clip, critic_coef, inv_b, dmean,
+                     dvalue, dls_rows, ldls, terms);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace xt
 
 extern "C" {
@@ -594,6 +669,16 @@ int xt_ppo_loss(const float* logits, const float* value, int32_t B, int32_t A, c
                      dlogits, dvalue, loss_terms);
   XT_LAUNCH_CHECK();
   return 0;
+}
+
+int xt_ppo_loss_gauss(const float* mean, const float* log_std, const float* value, int32_t B, int32_t A,
+                      const int32_t* idx, const float* action, const float* old_logp, const double* adv,
+                      const float* old_v, const double* target_v, float clip_ratio, float ent_coef, float vf_clip,
+                      float critic_coef, float inv_b, float* dmean, float* dvalue, float* dlogstd_rows,
+                      float* loss_terms, void* stream) {
+  return xt::launch_ppo_loss_gauss(mean, log_std, value, B, A, idx, action, old_logp, adv, old_v, target_v, clip_ratio,
+                                   ent_coef, vf_clip, critic_coef, inv_b, dmean, dvalue, dlogstd_rows, A, loss_terms,
+                                   xt::as_stream(stream));
 }
 
 int xt_ppo_loss_reduce(const float* loss_terms, int32_t B, float ent_coef, float critic_coef, float inv_b,

@@ -31,6 +31,9 @@ int launch_global_norm(const float*, long long, float, float, float, float, floa
 int launch_grads_finish(GradTable*, float*, int, int*, const FinalizeArgs*, hipStream_t);
 int launch_norm_finalize(const float*, int, float, float, float, float, float, int, float*, const LossArgs*, hipStream_t);
 int launch_ppo_heads_fused(const PpoHeadArgs&, hipStream_t);
+int launch_ppo_loss_gauss(const float*, const float*, const float*, int, int, const int32_t*, const float*, const float*,
+                          const double*, const float*, const double*, float, float, float, float, float, float*, float*,
+                          float*, int, float*, hipStream_t);
 int launch_heads_dfeat(const float*, const float*, int, int, int, const float*, const float*, const float*,
                        const float*, int, float*, float*, hipStream_t);
 int launch_heads_wgrad_partial(const float*, const float*, int, int, int, const float*, const float*, float*,
@@ -68,6 +71,10 @@ struct xt_net {
   // workspace carve (float offsets)
   int64_t off_counter;
   int64_t off_partial, off_logits, off_value, off_dlogits, off_dvalue, off_terms, off_loss, off_norm;
+  int action_type = 0;          // XT_ACTION_*
+  int64_t logstd_off = 0;       // pi_logstd [A] in the flat parameter buffer (DiagGaussian)
+  int64_t off_dls = 0;          // [maxB][align4(A)] per-sample d loss / d pi_logstd rows
+  int dls_rows = 0;
   int64_t off_hslab_pi, off_hslab_v, hstride_pi, hstride_v;
   int64_t partial_floats;
   int head_chunks = 0, norm_blocks = 0;
@@ -243,7 +250,7 @@ static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t s
   const int F = n->feat, A = n->A;
   GradTable tab;
   tab.n = 0;
-  XT_REQUIRE(n->layers.size() + 2 <= 12, "xt_net: too many layers for the gradient table");
+  XT_REQUIRE(n->layers.size() + 3 <= 12, "xt_net: too many layers for the gradient table");
   for (auto& L : n->layers) {
     GradEntry& E = tab.e[tab.n++];
     E.count = (L.K + 1) * L.g.N;
@@ -261,6 +268,11 @@ static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t s
     GradEntry& E = tab.e[tab.n++];
     E.count = F + 1; E.dst = n->grads + n->v_off; E.src = n->ws + n->off_hslab_v;
     E.nslab = n->head_chunks; E.stride = n->hstride_v;
+  }
+  if (n->action_type == XT_ACTION_DIAG_GAUSSIAN) {   // pi_logstd: the per-sample rows are the partial slabs
+    GradEntry& E = tab.e[tab.n++];
+    E.count = A; E.dst = n->grads + n->logstd_off; E.src = n->ws + n->off_dls;
+    E.nslab = n->dls_rows; E.stride = align4(A);
   }
   return launch_grads_finish(&tab, n->ws + n->off_norm, kMaxNormPartials, &n->norm_blocks, fin, st);
 }
@@ -280,11 +292,13 @@ static int net_apply(xt_net* n, float lr, float b1, float b2, float eps, float c
 }
 
 static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32_t* idx, int B,
-                    const int32_t* action, const float* old_logp, const double* adv, const float* old_v,
+                    const void* action_v, const float* old_logp, const double* adv, const float* old_v,
                     const double* target_v, int apply, float* loss_out, float* loss_acc, hipStream_t st) {
   XT_REQUIRE(n->params && n->ws, "xt_net: buffers not bound (call xt_net_bind)");
   XT_REQUIRE(B > 0 && B <= n->maxB, "xt_net_ppo_step: batch %d outside (0,%d]", B, n->maxB);
-  bool fused_head = (n->A <= 8 && n->feat <= 512);
+  const bool gauss = (n->action_type == XT_ACTION_DIAG_GAUSSIAN);
+  const int32_t* action = static_cast<const int32_t*>(action_v);
+  bool fused_head = (!gauss && n->A <= 8 && n->feat <= 512);
   static int no_defer = -1;
   if (no_defer < 0) { const char* e = getenv("XT_NO_DEFER"); no_defer = (e && e[0] == '1') ? 1 : 0; }
   if (int rc = net_forward(n, obs, idx, B, false, st, fused_head && !no_defer)) return rc;
@@ -323,9 +337,17 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
                               n->params + n->pi_off + (int64_t)F * A, n->params + n->v_off, n->params + n->v_off + F,
                               n->ws + n->off_logits, n->ws + n->off_value, st))
       return rc;
-    if (int rc = xt_ppo_loss(n->ws + n->off_logits, n->ws + n->off_value, B, A, idx, action, old_logp, adv, old_v,
-                             target_v, c->clip_ratio, c->ent_coef, c->vf_clip, c->critic_coef, inv_b,
-                             n->ws + n->off_dlogits, n->ws + n->off_dvalue, n->ws + n->off_terms, st))
+    if (gauss) {
+      if (int rc = launch_ppo_loss_gauss(n->ws + n->off_logits, n->params + n->logstd_off, n->ws + n->off_value, B, A,
+                                         idx, static_cast<const float*>(action_v), old_logp, adv, old_v, target_v,
+                                         c->clip_ratio, c->ent_coef, c->vf_clip, c->critic_coef, inv_b,
+                                         n->ws + n->off_dlogits, n->ws + n->off_dvalue, n->ws + n->off_dls,
+                                         (int)align4(A), n->ws + n->off_terms, st))
+        return rc;
+      n->dls_rows = B;
+    } else if (int rc = xt_ppo_loss(n->ws + n->off_logits, n->ws + n->off_value, B, A, idx, action, old_logp, adv,
+                                    old_v, target_v, c->clip_ratio, c->ent_coef, c->vf_clip, c->critic_coef, inv_b,
+                                    n->ws + n->off_dlogits, n->ws + n->off_dvalue, n->ws + n->off_terms, st))
       return rc;
     if (int rc = launch_heads_dfeat(n->ws + Lp.act_off, n->ws + Lv.act_off, B, F, A, n->params + n->pi_off,
                                     n->params + n->v_off, n->ws + n->off_dlogits, n->ws + n->off_dvalue, Lp.g.act,
@@ -365,6 +387,13 @@ int xt_net_create(const xt_net_desc* d, int32_t max_batch, xt_net** out) {
   n->n_trunks = d->n_trunks; n->feat = d->feat; n->A = d->action_dim;
   n->pi_off = d->pi_off; n->v_off = d->v_off; n->P = d->n_params; n->xf = d->xf;
   n->in_h = d->in_h; n->in_w = d->in_w; n->in_c = d->in_c; n->maxB = max_batch;
+  n->action_type = d->action_type; n->logstd_off = d->logstd_off; n->dls_rows = 0;
+  if (d->action_type != XT_ACTION_CATEGORICAL &&
+      (d->action_type != XT_ACTION_DIAG_GAUSSIAN || d->logstd_off < 0 || d->logstd_off % 4 != 0 ||
+       d->logstd_off + d->action_dim > d->n_params)) {
+    delete n;
+    XT_REQUIRE(false, "xt_net_create: bad action_type / logstd_off");
+  }
   n->overlap = false;   // measured: fork/join inside the hipGraph costs more than it hides (14.7 vs 13.9 ms/update)
   if (const char* e = getenv("XT_OVERLAP")) n->overlap = (e[0] == '1');
   int64_t off = 0;
@@ -419,6 +448,7 @@ int xt_net_create(const xt_net_desc* d, int32_t max_batch, xt_net** out) {
   n->off_dlogits = off; off += xt::align4((int64_t)max_batch * n->A);
   n->off_dvalue = off; off += xt::align4(max_batch);
   n->off_terms = off; off += xt::align4((int64_t)max_batch * 4);
+  n->off_dls = off; off += (int64_t)max_batch * xt::align4(n->A);
   n->off_loss = off; off += xt::align4(8 + max_batch);
   n->off_norm = off; off += xt::kMaxNormPartials;
   n->off_counter = off; off += 32 * 66;   // 1 top + 64 sub ticket counters, one 128-B line each
@@ -465,7 +495,7 @@ int xt_net_forward(xt_net* n, const void* obs, const int32_t* idx, int32_t B, fl
 }
 
 int xt_net_ppo_step(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, const int32_t* idx, int32_t B,
-                    const int32_t* action, const float* old_logp, const double* adv, const float* old_v,
+                    const void* action, const float* old_logp, const double* adv, const float* old_v,
                     const double* target_v, int32_t apply, float* loss_out, float* loss_acc, void* stream) {
   XT_REQUIRE(net && cfg, "xt_net_ppo_step: null argument");
   return xt::ppo_step(net, cfg, obs, idx, B, action, old_logp, adv, old_v, target_v, apply, loss_out, loss_acc,
@@ -473,7 +503,7 @@ int xt_net_ppo_step(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, const i
 }
 
 static int ppo_train_enqueue(xt_net* net, const xt_ppo_cfg* c, const void* obs, int32_t n, const int32_t* perm,
-                             const int32_t* action, const float* old_logp, const double* adv, const float* old_v,
+                             const void* action, const float* old_logp, const double* adv, const float* old_v,
                              const double* target_v, float* loss_acc, hipStream_t st) {
   XT_CHECK_HIP(hipMemsetAsync(loss_acc, 0, 2 * sizeof(float), st));
   for (int ep = 0; ep < c->num_sgd_iter; ++ep) {
@@ -491,7 +521,7 @@ static int ppo_train_enqueue(xt_net* net, const xt_ppo_cfg* c, const void* obs, 
 }
 
 int xt_net_ppo_train(xt_net* net, const xt_ppo_cfg* c, const void* obs, int32_t n, const int32_t* perm,
-                     const int32_t* action, const float* old_logp, const double* adv, const float* old_v,
+                     const void* action, const float* old_logp, const double* adv, const float* old_v,
                      const double* target_v, float* loss_acc, int32_t use_graph, void* stream) {
   XT_REQUIRE(net && c && obs && perm && loss_acc, "xt_net_ppo_train: null argument");
   XT_REQUIRE(n > 0 && c->batch_size > 0 && c->batch_size <= net->maxB && c->num_sgd_iter > 0,

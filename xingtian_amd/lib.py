@@ -29,11 +29,15 @@ class LayerDesc(Structure):
     _fields_ = [("g", ConvGeom), ("param_off", c_int64), ("trunk", c_int32)]
 
 
+ABI_VERSION = 2          # XT_ABI_VERSION of include/xt_mi355x.h
+ACTION_TYPE = {"Categorical": 0, "DiagGaussian": 1}
+
+
 class NetDesc(Structure):
     _fields_ = [("n_layers", c_int32), ("layers", POINTER(LayerDesc)), ("n_trunks", c_int32),
                 ("feat", c_int32), ("action_dim", c_int32), ("pi_off", c_int64), ("v_off", c_int64),
                 ("n_params", c_int64), ("xf", InputXform), ("in_h", c_int32), ("in_w", c_int32),
-                ("in_c", c_int32)]
+                ("in_c", c_int32), ("action_type", c_int32), ("logstd_off", c_int64)]
 
 
 class PpoCfg(Structure):
@@ -62,6 +66,8 @@ SIGNATURES = {
     "xt_heads_fwd": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "xt_ppo_loss": (c_int32, [_P, _P, c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float,
                               c_float, _P, _P, _P, _P]),
+    "xt_ppo_loss_gauss": (c_int32, [_P, _P, _P, c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float,
+                                    c_float, c_float, _P, _P, _P, _P, _P]),
     "xt_ppo_loss_reduce": (c_int32, [_P, c_int32, c_float, c_float, c_float, _P, _P, _P]),
     "xt_impala_loss": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "xt_heads_bwd": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P, _P, _P]),
@@ -97,7 +103,7 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the ABI symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.xt_abi_version() != 1:
+    if lib.xt_abi_version() != ABI_VERSION:
         raise RuntimeError("xingtian_amd: ABI version mismatch")
     _lib = lib
     return lib

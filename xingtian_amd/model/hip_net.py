@@ -53,6 +53,8 @@ class HipActorCritic(object):
         d.feat, d.action_dim, d.pi_off, d.v_off, d.n_params = spec.feat, spec.action_dim, spec.pi_off, spec.v_off, n
         d.xf = L.InputXform(*spec.input_xform)
         d.in_h, d.in_w, d.in_c = spec.layers[0].H, spec.layers[0].W, spec.layers[0].C
+        d.action_type = L.ACTION_TYPE[getattr(spec, "action_type", "Categorical")]
+        d.logstd_off = getattr(spec, "logstd_off", 0)
         self._desc = d
         h = ctypes.c_void_p()
         L.check(self.lib.xt_net_create(ctypes.byref(d), self.max_batch, ctypes.byref(h)), "xt_net_create")
@@ -78,7 +80,7 @@ class HipActorCritic(object):
         rng = np.random.default_rng(seed)
         w = OrderedDict()
         for name, (_, shape) in self.spec.names.items():
-            if name.endswith("/bias"):
+            if name.endswith("/bias") or name == "pi_logstd":
                 w[name] = np.zeros(shape, np.float32)
             else:
                 w[name] = glorot_uniform(rng, shape)
@@ -168,7 +170,11 @@ class HipActorCritic(object):
     def to_device_obs(self, obs):
         t = torch.as_tensor(np.ascontiguousarray(obs)) if not torch.is_tensor(obs) else obs
         want = torch.uint8 if self.spec.input_xform[0] else torch.float32
-        return t.to(device=self.device, dtype=want).contiguous()
+        t = t.to(device=self.device, dtype=want)
+        lay0 = self.spec.layers[0]
+        if t.dim() == 2 and lay0.H == lay0.W == 1 and t.shape[1] < lay0.C:      # zero-pad odd feature counts (netspec._mlp)
+            t = torch.nn.functional.pad(t, (0, lay0.C - t.shape[1]))
+        return t.contiguous()
 
     def forward(self, obs):
         """obs [B, ...] (host or device) -> (logits [B,A], value [B]) device tensors."""

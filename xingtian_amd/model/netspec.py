@@ -84,7 +84,11 @@ class NetSpec(object):
     """layers (trunk 0 first), heads, flat layout, name map."""
 
     def __init__(self, layers, n_trunks, feat, action_dim, pi_name, v_name, pi_kernel_shape, input_xform,
-                 state_dim):
+                 state_dim, action_type="Categorical"):
+        if action_type not in ("Categorical", "DiagGaussian"):
+            raise NotImplementedError(
+                "action type: {} not match any implemented distributions.".format(action_type))
+        self.action_type = action_type
         self.layers, self.n_trunks, self.feat, self.action_dim = layers, n_trunks, feat, action_dim
         self.pi_name, self.v_name, self.input_xform, self.state_dim = pi_name, v_name, input_xform, tuple(state_dim)
         off = 0
@@ -106,6 +110,11 @@ class NetSpec(object):
         self.names[v_name + "/kernel"] = (off, (feat, 1))
         self.names[v_name + "/bias"] = (off + feat, (1,))
         off = (off + feat + 1 + 3) & ~3
+        self.logstd_off = 0
+        if action_type == "DiagGaussian":       # tf.get_variable('pi_logstd', (1, A), zeros), xt/model/ppo/ppo.py:78
+            self.logstd_off = off
+            self.names["pi_logstd"] = (off, (1, action_dim))
+            off = (off + action_dim + 3) & ~3
         self.n_flat = off
         self.n_params = sum(int(_prod(s)) for _, s in self.names.values())
 
@@ -120,12 +129,18 @@ def _prod(shape):
 def _mlp(prefix, cin, hidden_sizes, act, trunk):
     out = []
     for i, hs in enumerate(hidden_sizes):
-        out.append(_dense("{}_hidden_mlp_{}".format(prefix, i), cin, hs, act, trunk))
+        lay = _dense("{}_hidden_mlp_{}".format(prefix, i), (cin + 3) & ~3, hs, act, trunk)
+        # a feature count that is not a multiple of 4 (Pendulum: 3) is zero-padded: the observation gets zero
+        # columns (HipActorCritic.to_device_obs) and the [cin,N] TF kernel is the head of a [pad4(cin),N] block
+        # whose extra rows start at 0 and stay 0 (their gradient is sum(0 * dz) = 0, Adam of 0 is 0) -- exact.
+        lay.kernel_shape = (cin, hs)
+        out.append(lay)
         cin = hs
     return out, cin
 
 
-def ppo_cnn(state_dim, action_dim, hidden_sizes=(512,), act="relu", vf_share=True, input_dtype="uint8"):
+def ppo_cnn(state_dim, action_dim, hidden_sizes=(512,), act="relu", vf_share=True, input_dtype="uint8",
+            action_type="Categorical"):
     layers, feat = [], None
     for trunk, prefix in enumerate(["shared"] if vf_share else ["pi", "v"]):
         h, w, c = state_dim
@@ -137,16 +152,16 @@ def ppo_cnn(state_dim, action_dim, hidden_sizes=(512,), act="relu", vf_share=Tru
         layers += mlps
     xf = (1, 0.0, 255.0) if input_dtype == "uint8" else (0, 0.0, 1.0)
     return NetSpec(layers, 1 if vf_share else 2, feat, action_dim, "pi_latent", "output_value",
-                   (feat, action_dim), xf, state_dim)
+                   (feat, action_dim), xf, state_dim, action_type)
 
 
-def ppo_mlp(state_dim, action_dim, hidden_sizes=(64, 64), act="tanh", vf_share=False):
+def ppo_mlp(state_dim, action_dim, hidden_sizes=(64, 64), act="tanh", vf_share=False, action_type="Categorical"):
     layers, feat = [], None
     for trunk, prefix in enumerate(["shared"] if vf_share else ["pi", "v"]):
         mlps, feat = _mlp(prefix, int(state_dim[0]), hidden_sizes, act, trunk)
         layers += mlps
     return NetSpec(layers, 1 if vf_share else 2, feat, action_dim, "pi_latent", "output_value",
-                   (feat, action_dim), (0, 0.0, 1.0), (1, 1, int(state_dim[0])))
+                   (feat, action_dim), (0, 0.0, 1.0), (1, 1, int(state_dim[0])), action_type)
 
 
 def impala_cnn_opt(state_dim, action_dim, state_mean=0.0, state_std=255.0, input_dtype="uint8"):

@@ -43,13 +43,18 @@ class PPO(XTModel):
         self.seed = model_config.get("SEED")
         self._rng = np.random.default_rng(self.seed)
 
-        if self.action_type != "Categorical":
+        if self.action_type is None:            # learner.py:487 injects it from the environment; Atari YAMLs are discrete
+            self.action_type = "Categorical"
+        if self.action_type not in ("Categorical", "DiagGaussian"):     # make_dist, xt/model/tf_dist.py:133-139
             raise NotImplementedError(
                 "action type: {} not match any implemented distributions.".format(self.action_type))
+        self.gauss = self.action_type == "DiagGaussian"
         self._resident = None
         self._ingest = None
         self._perm_dense = None
-        self.stream_ingest = bool(model_config.get("STREAM_INGEST", True))
+        # the streaming ingest stages int32 actions and unpadded observations: discrete, 4-aligned inputs only
+        self.stream_ingest = bool(model_config.get("STREAM_INGEST", True)) and not self.gauss and \
+            (len(self.state_dim) != 1 or int(self.state_dim[0]) % 4 == 0)
         super().__init__(model_info)
 
     # subclasses provide build_spec(); create_model wires the HIP network
@@ -67,11 +72,19 @@ class PPO(XTModel):
         return self.net
 
     def predict(self, state):
-        """-> (action [B] int32, logp [B,1] f32, value [B,1] f32), xt/model/ppo/ppo.py:104-109."""
+        """-> (action [B] int32 | [B,A] f32, logp [B,1] f32, value [B,1] f32), xt/model/ppo/ppo.py:104-109."""
         state = np.asarray(state)
         logits, value = self.net.forward(state)
         logits = logits.cpu().numpy()
         value = value.cpu().numpy().reshape(-1, 1)
+        if self.gauss:
+            # DiagGaussianDist.sample / log_prob (tf_dist.py:66-69,86-87) on the host; `logits` is the mean
+            log_std = self.net.get_weights()["pi_logstd"].reshape(1, -1).astype(np.float32)
+            std = np.exp(log_std)
+            action = (logits + std * self._rng.standard_normal(logits.shape).astype(np.float32)).astype(np.float32)
+            neglogp = np.float32(0.5 * np.log(2.0 * np.pi)) * np.float32(logits.shape[-1]) \
+                + 0.5 * np.square((action - logits) / std).sum(-1, keepdims=True) + log_std.sum(-1, keepdims=True)
+            return action, (-neglogp).astype(np.float32), value
         # tf.random.categorical (tf_dist.py:127-130): Gumbel-max on the host
         u = self._rng.random(logits.shape)
         action = np.argmax(logits - np.log(-np.log(u)), axis=-1).astype(np.int32)
@@ -87,21 +100,30 @@ class PPO(XTModel):
         obs = np.ascontiguousarray(state[0])
         n = obs.shape[0]
         key = (obs.shape, str(obs.dtype))
+        lay0 = self.net.spec.layers[0]
+        pad = lay0.C - obs.shape[1] if (obs.ndim == 2 and lay0.H == lay0.W == 1) else 0   # netspec._mlp zero padding
         if self._resident is None or self._resident["key"] != key:
             odt = torch.uint8 if self.net.spec.input_xform[0] else torch.float32
+            oshape = (n, lay0.C) if pad > 0 else obs.shape
             self._resident = dict(
                 key=key,
-                obs=torch.empty(obs.shape, dtype=odt, device=dev),
-                action=torch.empty((n,), dtype=torch.int32, device=dev),
+                obs=torch.zeros(oshape, dtype=odt, device=dev),
+                action=(torch.empty((n, self.action_dim), dtype=torch.float32, device=dev) if self.gauss
+                        else torch.empty((n,), dtype=torch.int32, device=dev)),
                 old_logp=torch.empty((n,), dtype=torch.float32, device=dev),
                 adv=torch.empty((n,), dtype=torch.float64, device=dev),
                 old_v=torch.empty((n,), dtype=torch.float32, device=dev),
                 target_v=torch.empty((n,), dtype=torch.float64, device=dev),
                 perm=torch.empty((self.num_sgd_iter, n), dtype=torch.int32, device=dev))
         r = self._resident
-        r["obs"].copy_(torch.from_numpy(obs).to(r["obs"].dtype) if obs.dtype != np.uint8 and r["obs"].dtype == torch.uint8
-                       else torch.from_numpy(obs), non_blocking=True)
-        r["action"].copy_(torch.from_numpy(np.ascontiguousarray(label[0], dtype=np.int32).reshape(-1)))
+        src = torch.from_numpy(obs).to(r["obs"].dtype) if obs.dtype != np.uint8 and r["obs"].dtype == torch.uint8 \
+            else torch.from_numpy(obs)
+        (r["obs"][:, :obs.shape[1]] if pad > 0 else r["obs"]).copy_(src, non_blocking=True)
+        if self.gauss:
+            r["action"].copy_(torch.from_numpy(
+                np.ascontiguousarray(label[0], dtype=np.float32).reshape(n, self.action_dim)))
+        else:
+            r["action"].copy_(torch.from_numpy(np.ascontiguousarray(label[0], dtype=np.int32).reshape(-1)))
         r["old_logp"].copy_(torch.from_numpy(np.ascontiguousarray(label[1], dtype=np.float32).reshape(-1)))
         r["adv"].copy_(torch.from_numpy(np.ascontiguousarray(label[2], dtype=np.float64).reshape(-1)))
         r["old_v"].copy_(torch.from_numpy(np.ascontiguousarray(label[3], dtype=np.float32).reshape(-1)))

@@ -22,4 +22,4 @@ class PpoCnn(PPO):
 
     def build_spec(self):
         return netspec.ppo_cnn(tuple(self.state_dim), self.action_dim, tuple(self.hidden_sizes), self.activation,
-                               self.vf_share_layers, self.input_dtype)
+                               self.vf_share_layers, self.input_dtype, self.action_type)

@@ -25,4 +25,4 @@ class PpoMlp(PPO):
             raise ValueError("dtype: {} not supported automatically, please implement it yourself".format(
                 self.input_dtype))
         return netspec.ppo_mlp(tuple(self.state_dim), self.action_dim, tuple(self.hidden_sizes), self.activation,
-                               self.vf_share_layers)
+                               self.vf_share_layers, self.action_type)
