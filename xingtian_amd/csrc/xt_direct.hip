@@ -29,32 +29,9 @@
 #include <stdlib.h>
 #include "xt_common.h"
 #include "xt_igemm.h"
+#include "xt_direct_dev.h"
 
 namespace xt {
-
-// block id -> work item such that each XCD (block id mod 8, round-robin dispatch) gets a contiguous range
-__device__ __forceinline__ uint32_t xcd_chunk(uint32_t bid, uint32_t nb) {
-  const uint32_t q = nb >> 3, r = nb & 7u, x = bid & 7u, j = bid >> 3;
-  return x * q + (x < r ? x : r) + j;
-}
-
-__device__ __forceinline__ float zsel(bool ok, float v) { return ok ? v : 0.f; }
-
-// Buffer addressing (SRSRC descriptor in SGPRs + 32-bit lane byte offset + scalar byte offset): no 64-bit VALU
-// address math, immediate-offset folding, and the hardware range check returns 0 for offsets >= num_bytes,
-// which is how padding taps and tail rows are zero-filled for free (kOob).
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-constexpr uint32_t kOob = 0x80000000u;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
-  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
-  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
-}
 
 // Fixed-order combine of the NW per-wave partial tiles + distributed epilogue.  red: [NW][R][64] floats.
 // emit(r, v) is called by exactly one wave per accumulator register r (r = tile * 16 + reg).
@@ -201,160 +178,11 @@ __global__ __launch_bounds__(MAXT) void direct_fwd_kernel(const DFwdArgs p) {
   XT_TL_DRAIN(5);
 }
 
-// ------------------------------------------------------------------ input gradient
-// Static-NW combine: wave w owns accumulator registers r = w + j*NW (j < R/NW) of the block's tile.
-template <int R, int NW, typename F>
-__device__ __forceinline__ void combine_emit_static(float* red, const float (&flat)[R], int w, int lane, F emit) {
-  if constexpr (NW == 1) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) emit(r, r, flat[r]);
-  } else {
-#pragma unroll
-    for (int r = 0; r < R; ++r) red[(w * R + r) * 64 + lane] = flat[r];
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < R / NW; ++j) {
-      const int r = w + j * NW;
-      float v = red[r * 64 + lane];
-#pragma unroll
-      for (int q = 1; q < NW; ++q) v += red[(q * R + r) * 64 + lane];
-      emit(j, r, v);
-    }
-  }
-}
-
-struct DDgradArgs {
-  Geom g;
-  const float* dy;
-  const float* w;
-  const float* x;     // producer's post-activation output [B,H,W,C]
-  float* dx;
-  int act_prev;
-  int mt, ct;         // pixel tiles per stride-parity class (upper bound), channel tiles
-};
-
+// ------------------------------------------------------------------ input gradient (body: xt_direct_dev.h)
 template <int TI, int TJ, int NW>
 __global__ __launch_bounds__(64 * NW) void direct_dgrad_kernel(const DDgradArgs p) {
   extern __shared__ __attribute__((aligned(16))) float red[];
-  const Geom& g = p.g;
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int il = lane & 31, kl = lane >> 5;
-  XT_TL(0);
-  XT_TL_ROLE(80);
-  // tile-major, class-minor: the S*S classes of one pixel region read the same dY lines
-  uint32_t lin = xcd_chunk(blockIdx.x, gridDim.x);
-  const int nclass = g.S * g.S;
-  const int cls = (int)(lin % (uint32_t)nclass);
-  lin /= (uint32_t)nclass;
-  const int tc = (int)(lin % (uint32_t)p.ct), tm = (int)(lin / (uint32_t)p.ct);
-  const int ry = cls / g.S, rx = cls - ry * g.S;
-  const int cy0 = ((ry - g.PT) % g.S + g.S) % g.S, cx0 = ((rx - g.PL) % g.S + g.S) % g.S;
-  const int HC = cy0 < g.H ? (g.H - cy0 + g.S - 1) / g.S : 0;
-  const int WC = cx0 < g.W ? (g.W - cx0 + g.S - 1) / g.S : 0;
-  const int Mc = g.B * HC * WC;
-  const int i0 = tm * (32 * TI), c0 = tc * (32 * TJ);
-  if (i0 >= Mc) return;
-  const int JY = ry < g.KH ? (g.KH - ry + g.S - 1) / g.S : 0;
-  const int JX = rx < g.KW ? (g.KW - rx + g.S - 1) / g.S : 0;
-  const int nps = g.N >> 5;                        // 32-deep steps per tap
-  const int nsteps = JY * JX * nps;
-  const int qy0 = (cy0 + g.PT) / g.S, qx0 = (cx0 + g.PL) / g.S;
-  const int per = (nsteps + NW - 1) / NW;
-  const int s0 = w * per, s1 = min(nsteps, s0 + per);
-
-  int dybase[TI], qy[TI], qx[TI], outoff[TI];
-#pragma unroll
-  for (int ti = 0; ti < TI; ++ti) {
-    const int mraw = i0 + 32 * ti + il;
-    const int mc = min(mraw, Mc - 1);
-    const int b = mc / (HC * WC), rem = mc - b * (HC * WC);
-    const int ty = rem / WC, tx = rem - ty * WC;
-    qy[ti] = qy0 + ty; qx[ti] = qx0 + tx;
-    dybase[ti] = ((b * g.OH + qy[ti]) * g.OW + qx[ti]) * g.N;
-    outoff[ti] = mraw < Mc ? ((b * g.H + cy0 + g.S * ty) * g.W + cx0 + g.S * tx) * g.C : -1;
-  }
-  const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(p.dy, (uint32_t)g.M * (uint32_t)g.N * 4u);
-  const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (uint32_t)g.K * (uint32_t)g.N * 4u);
-  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x, (uint32_t)g.B * (uint32_t)g.HWC * 4u);
-
-  // producer activations of the registers this wave will emit: loaded before the reduction loop
-  constexpr int R = TI * TJ * 16, RJ = R / NW;
-  float xv[RJ];
-  int eoff[RJ];
-#pragma unroll
-  for (int j = 0; j < RJ; ++j) {
-    const int r = w + j * NW;
-    const int t = r >> 4, rr = r & 15;
-    const int ti = t / TJ, tj = t - ti * TJ;
-    const int row = (rr & 3) + 8 * (rr >> 2) + 4 * kl;
-    int o = 0;
-#pragma unroll
-    for (int q = 0; q < TI; ++q) { const int oq = __shfl(outoff[q], row, 64); if (q == ti) o = oq; }
-    eoff[j] = o >= 0 ? o + c0 + 32 * tj + il : -1;
-    xv[j] = buf_load1(rs_x, o >= 0 ? (uint32_t)eoff[j] * 4u : kOob, 0u);
-  }
-
-  const uint32_t wvoff = (uint32_t)((c0 + il) * g.N + 16 * kl) * 4u;
-  struct Stage { float4 a[TI][4]; float4 b[TJ][4]; };
-  auto load = [&](Stage& S_, int s, bool live) {
-    const int tap = s / nps;                       // uniform
-    const int jy = JX > 0 ? tap / JX : 0, jx = tap - jy * JX;
-    const int nofs = (s - tap * nps) * 32;
-    const int tapoff = (jy * g.OW + jx) * g.N - nofs - 16 * kl;
-#pragma unroll
-    for (int ti = 0; ti < TI; ++ti) {
-      const bool ok = live && ((unsigned)(qy[ti] - jy) < (unsigned)g.OH) && ((unsigned)(qx[ti] - jx) < (unsigned)g.OW);
-      const uint32_t off = ok ? (uint32_t)(dybase[ti] - tapoff) * 4u : kOob;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) S_.a[ti][q] = buf_load4(rs_dy, off + 16u * q, 0u);
-    }
-    const uint32_t ws = live ? (uint32_t)((((ry + g.S * jy) * g.KW + rx + g.S * jx) * g.C) * g.N + nofs) * 4u : kOob;
-#pragma unroll
-    for (int tj = 0; tj < TJ; ++tj)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) S_.b[tj][q] = buf_load4(rs_w, wvoff + (uint32_t)(32 * tj * g.N) * 4u + 16u * q, ws);
-  };
-  f32x16 acc[TI][TJ];
-#pragma unroll
-  for (int ti = 0; ti < TI; ++ti)
-#pragma unroll
-    for (int tj = 0; tj < TJ; ++tj)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
-  auto pick = [](const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; };
-  auto compute = [&](const Stage& S_) {
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk)
-#pragma unroll
-      for (int ti = 0; ti < TI; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < TJ; ++tj)
-          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(pick(S_.a[ti][kk >> 2], kk & 3), pick(S_.b[tj][kk >> 2], kk & 3),
-                                                             acc[ti][tj], 0, 0, 0);
-  };
-  Stage R0, R1;
-  load(R0, s0, s0 < s1);
-  load(R1, s0 + 1, s0 + 1 < s1);
-  XT_TL(1);
-  for (int s = s0; s < s1; s += 2) {
-    compute(R0);
-    load(R0, s + 2, s + 2 < s1);
-    compute(R1);
-    load(R1, s + 3, s + 3 < s1);
-  }
-  XT_TL(3);
-  float flat[R];
-#pragma unroll
-  for (int ti = 0; ti < TI; ++ti)
-#pragma unroll
-    for (int tj = 0; tj < TJ; ++tj)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) flat[(ti * TJ + tj) * 16 + r] = acc[ti][tj][r];
-  combine_emit_static<R, NW>(red, flat, w, lane, [&](int j, int r, float v) {
-    if (eoff[j] >= 0) p.dx[(size_t)eoff[j]] = v * act_grad(xv[j], p.act_prev);
-  });
-  XT_TL(4);
-  XT_TL_DRAIN(5);
+  direct_dgrad_body<TI, TJ, NW>(p, blockIdx.x, gridDim.x, red);
 }
 
 XT_TL_SETTER(direct)
@@ -431,6 +259,25 @@ int launch_fwd_direct(const xt_conv_geom* cg, const xt_input_xform* xf, int B, c
   XT_LAUNCH_CHECK();
   *ksplit_out = ks;
   return 0;
+}
+
+// Plan for the fused per-layer backward launch (256-thread blocks -> NW = 4, one 32x32 tile per block): only the
+// shapes where the direct kernel measured faster (single-column tiles, long reduction, not too many tiles).
+bool plan_dgrad_direct_fused(const Geom& g, DDgradArgs* a, int* nblocks) {
+  if (!use_direct() || g.N % 32 != 0 || g.C % 32 != 0) return false;
+  if (g.C % 64 == 0) return false;                       // TJ = 2 shapes stay on the LDS-tiled kernel
+  const int hc = (g.H + g.S - 1) / g.S, wc = (g.W + g.S - 1) / g.S;
+  const int mc = g.B * hc * wc;
+  const int nclass = g.S * g.S;
+  const int jmax = ((g.KH + g.S - 1) / g.S) * ((g.KW + g.S - 1) / g.S);
+  const int nsteps = jmax * (g.N / 32);
+  const int tiles = ((mc + 31) / 32) * (g.C / 32) * nclass;
+  if (!direct_all() && (nsteps < 8 || tiles >= env_int("XT_DIRECT_TI2_TILES", 3072))) return false;
+  a->g = g;
+  a->mt = (mc + 31) / 32;
+  a->ct = g.C / 32;
+  *nblocks = tiles;
+  return true;
 }
 
 int launch_dgrad_direct(const xt_conv_geom* cg, int B, const float* dy, const float* w, const float* x, int act_prev,

@@ -20,6 +20,7 @@
 #include "xt_common.h"
 #include "xt_igemm.h"
 #include "xt_heads_dev.h"
+#include "xt_direct_dev.h"
 
 namespace xt {
 
@@ -680,6 +681,8 @@ __global__ __launch_bounds__(256) void igemm_dgrad_kernel(const DgradArgs p) {
 struct BwdLayerArgs {
   WgradArgs wg;
   DgradArgs dg;
+  DDgradArgs ddg;            // register-direct input gradient (xt_direct_dev.h), used when dg_direct != 0
+  int dg_direct;
   HeadWgArgs hw;
   int wg_gx, wg_gy, wg_gz;   // wgrad grid
   int dg_gx, dg_gy, dg_gz;   // dgrad grid
@@ -693,6 +696,10 @@ __global__ __launch_bounds__(256) void igemm_bwd_layer_kernel(const BwdLayerArgs
   __shared__ __attribute__((aligned(16))) float smem[SM];
   int b = blockIdx.x;
   if (b < p.n_dg) {                       // dgrad first: it is on the critical path of the next layer
+    if (p.dg_direct) {                    // single-column tiles with a long reduction: 4 independent waves per tile
+      direct_dgrad_body<1, 1, 4>(p.ddg, (uint32_t)b, (uint32_t)p.n_dg, smem);
+      return;
+    }
     const int bx = b % p.dg_gx, r = b / p.dg_gx;
     igemm_dgrad_body<DBI, DBJ, DWI, DWJ>(p.dg, bx, r % p.dg_gy, r / p.dg_gy, smem);
     return;
@@ -721,6 +728,7 @@ int launch_conv1_fwd_bf16x3(const xt_conv_geom*, const xt_input_xform*, int, con
                             const float*, float*, hipStream_t);
 int launch_conv1_wgrad_bf16x3(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*,
                               const float*, float*, float*, int, int*, hipStream_t);
+bool plan_dgrad_direct_fused(const Geom&, DDgradArgs*, int*);
 int launch_dgrad_direct(const xt_conv_geom*, int, const float*, const float*, const float*, int, float*, hipStream_t);
 int launch_fwd_direct(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*, const float*,
                       const float*, float*, float*, int, hipStream_t, int*);
@@ -892,6 +900,15 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
   a.dg_gy = dsmall ? (g.C + 31) / 32 : (g.C + 63) / 64;
   a.dg_gz = g.S * g.S;
   a.n_dg = a.dg_gx * a.dg_gy * a.dg_gz;
+  a.dg_direct = 0;
+  {
+    int nblk = 0;
+    if (plan_dgrad_direct_fused(g, &a.ddg, &nblk)) {
+      a.ddg.dy = dy; a.ddg.w = w; a.ddg.x = x_in; a.ddg.dx = dx; a.ddg.act_prev = act_prev;
+      a.dg_direct = 1;
+      a.n_dg = nblk;
+    }
+  }
   // ---- head wgrad part
   a.n_hw = 0;
   if (hw) { a.hw = *hw; a.n_hw = hw->gx * hw->nchunk; }

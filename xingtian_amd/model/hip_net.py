@@ -92,9 +92,22 @@ class HipActorCritic(object):
             w[self.spec.v_name + "/kernel"] = out
         self.set_weights(w)
 
+    def _flat_to_host(self, dev_flat, tag):
+        """One D2H of a flat device buffer into a persistent PINNED host buffer (the weight publish
+        after every PPO update is on the critical path; a pageable .cpu() bounces through a driver staging copy)."""
+        pin = getattr(self, "_pin", None)
+        if pin is None:
+            pin = self._pin = {}
+        if tag not in pin:
+            pin[tag] = torch.empty(dev_flat.shape, dtype=dev_flat.dtype, pin_memory=True)
+        pin[tag].copy_(dev_flat.detach(), non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return pin[tag].numpy()
+
     def get_weights(self):
-        """dict TF-variable-name -> ndarray (TFVariables.get_weights, xt/model/tf_utils.py:99-102)."""
-        flat = self.params.detach().cpu().numpy()
+        """dict TF-variable-name -> ndarray (TFVariables.get_weights, xt/model/tf_utils.py:99-102).  The flat
+        parameter buffer IS the packed form: one pinned D2H, then per-variable copies (the caller owns them)."""
+        flat = self._flat_to_host(self.params, "params")
         out = OrderedDict()
         for name, (off, shape) in self.spec.names.items():
             size = int(np.prod(shape))
