@@ -269,7 +269,7 @@ int xt_net_apply(xt_net* net, float lr, float beta1, float beta2, float eps, flo
 
 /* kernel-time probe: average duration (ms) of `reps` launches of the dominant kernel
  * (first-layer forward) on `stream`, measured with HIP events on that stream. */
-int xt_net_time_layer(xt_net* net, int32_t layer, int32_t which /*0 fwd 1 wgrad 2 dgrad 3 fused dgrad+wgrad*/,
+int xt_net_time_layer(xt_net* net, int32_t layer, int32_t which /*0 fwd 1 wgrad 2 dgrad 3 fused dgrad+wgrad 4 fused conv-trunk fwd (layer..layer+2)*/,
                       const void* obs, const int32_t* idx, int32_t B, int32_t reps,
                       float* ms_out, void* stream);
 

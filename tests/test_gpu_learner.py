@@ -482,3 +482,33 @@ def test_gauss_ppo_mlp_update_vs_oracle(sd, ad, hidden, share):
     mean, _ = net.forward(obs[:1])
     z = (a_out.astype(np.float64) - mean.cpu().numpy().astype(np.float64)) / np.exp(ls)
     assert abs(float(logp[0, 0]) + (0.5 * np.log(2 * np.pi) * ad + 0.5 * (z ** 2).sum() + ls.sum())) < 1e-4
+
+
+def test_fused_trunk_forward_matches_per_layer_path(monkeypatch):
+    """xt_trunk.hip (opt-in, XT_TRUNK=1): conv1 -> conv2 -> conv3 of one frame stack per workgroup with the
+    intermediate activations in LDS.  Same arithmetic as the per-layer kernels up to the summation order: logits,
+    value and one SGD step's gradients against the default path and against the float64 oracle."""
+    net, ospec, sd, u8 = _mk("cnn84", 96)
+    params = oracle_params_for(net, ospec, 21)
+    rng = np.random.default_rng(22)
+    obs, lab = synth_ppo_rollout(rng, 96, sd, 4)
+    monkeypatch.delenv("XT_TRUNK", raising=False)
+    l0, v0 = [t.cpu().numpy() for t in net.forward(obs)]
+    monkeypatch.setenv("XT_TRUNK", "1")
+    l1, v1 = [t.cpu().numpy() for t in net.forward(obs)]
+    assert not np.array_equal(l0, l1)                      # a different kernel really ran
+    assert rel_err(l1, l0) < 2e-6 and rel_err(v1, v0) < 2e-6
+    oc = nets.ActorCritic(ospec, params, np.float64)
+    ol, ov = oc.forward(obs)
+    assert rel_err(l1, ol) < 1e-5 and rel_err(v1, ov[:, 0]) < 1e-5
+    c = net.make_ppo_cfg(dict(PPO_CFG, BATCH_SIZE=96))
+    d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).cuda()
+    args = (net.to_device_obs(obs), d(np.arange(96), np.int32), d(lab[0], np.int32), d(lab[1].reshape(-1), np.float32),
+            d(lab[2].reshape(-1), np.float64), d(lab[3].reshape(-1), np.float32), d(lab[4].reshape(-1), np.float64))
+    net.ppo_step(c, *args, apply=False)
+    g1 = net.grads_dict()
+    monkeypatch.delenv("XT_TRUNK")
+    net.ppo_step(c, *args, apply=False)
+    g0 = net.grads_dict()
+    for k in g0:
+        assert rel_err(g1[k], g0[k]) < 1e-5, (k, rel_err(g1[k], g0[k]))

@@ -109,11 +109,13 @@ __global__ __launch_bounds__(MAXT) void direct_fwd_kernel(const DFwdArgs p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) R.a[ti][q] = buf_load4(rs_in, off + 16u * q, 0u);
     }
-    const uint32_t ws = live ? (uint32_t)(32 * s) * (uint32_t)g.N * 4u : kOob;          // uniform
+    // dead stage: out of range through the LANE offset (the range check covers voffset + immediate, not soffset)
+    const uint32_t ws = live ? (uint32_t)(32 * s) * (uint32_t)g.N * 4u : 0u;          // uniform
+    const uint32_t vo = live ? wvoff : kOob;
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj)
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) R.b[tj][kk] = buf_load1(rs_w, wvoff + 128u * tj, ws + (uint32_t)(kk * g.N) * 4u);
+      for (int kk = 0; kk < 16; ++kk) R.b[tj][kk] = buf_load1(rs_w, vo + 128u * tj, ws + (uint32_t)(kk * g.N) * 4u);
   };
   f32x16 acc[TI][TJ];
 #pragma unroll

@@ -139,11 +139,13 @@ __device__ __forceinline__ void direct_dgrad_body(const DDgradArgs& p, uint32_t 
 #pragma unroll
       for (int q = 0; q < 4; ++q) S_.a[ti][q] = buf_load4(rs_dy, off + 16u * q, 0u);
     }
-    const uint32_t ws = live ? (uint32_t)((((ry + g.S * jy) * g.KW + rx + g.S * jx) * g.C) * g.N + nofs) * 4u : kOob;
+    // dead stage: out of range through the LANE offset (the range check covers voffset + immediate, not soffset)
+    const uint32_t ws = live ? (uint32_t)((((ry + g.S * jy) * g.KW + rx + g.S * jx) * g.C) * g.N + nofs) * 4u : 0u;
+    const uint32_t vo = live ? wvoff : kOob;
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) S_.b[tj][q] = buf_load4(rs_w, wvoff + (uint32_t)(32 * tj * g.N) * 4u + 16u * q, ws);
+      for (int q = 0; q < 4; ++q) S_.b[tj][q] = buf_load4(rs_w, vo + (uint32_t)(32 * tj * g.N) * 4u + 16u * q, ws);
   };
   f32x16 acc[TI][TJ];
 #pragma unroll

@@ -31,6 +31,9 @@ int launch_global_norm(const float*, long long, float, float, float, float, floa
 int launch_grads_finish(GradTable*, float*, int, int*, const FinalizeArgs*, hipStream_t);
 int launch_norm_finalize(const float*, int, float, float, float, float, float, int, float*, const LossArgs*, hipStream_t);
 int launch_ppo_heads_fused(const PpoHeadArgs&, hipStream_t);
+int launch_trunk_fwd(const xt_conv_geom*, const xt_conv_geom*, const xt_conv_geom*, const xt_input_xform*, int,
+                     const void*, const int32_t*, const float*, const float*, float*, const float*, const float*,
+                     float*, const float*, const float*, float*, hipStream_t, bool);
 int launch_ppo_loss_gauss(const float*, const float*, const float*, int, int, const int32_t*, const float*, const float*,
                           const double*, const float*, const double*, float, float, float, float, float, float*, float*,
                           float*, int, float*, hipStream_t);
@@ -120,7 +123,24 @@ static int net_forward(xt_net* n, const void* obs, const int32_t* idx, int B, bo
                        bool defer_last = false) {
   for (int tr = 0; tr < n->n_trunks; ++tr) {
     const void* x = obs;
-    for (int l = n->t_begin[tr]; l < n->t_end[tr]; ++l) {
+    int l0 = n->t_begin[tr];
+    if (n->t_end[tr] - l0 >= 4) {      // conv1 -> conv2 -> conv3 of one frame stack per workgroup (xt_trunk.hip)
+      Layer& A = n->layers[l0];
+      Layer& Bl = n->layers[l0 + 1];
+      Layer& C = n->layers[l0 + 2];
+      const int rc = launch_trunk_fwd(&A.g, &Bl.g, &C.g, &n->xf, B, obs, idx, n->params + A.poff,
+                                      n->params + A.poff + (int64_t)A.K * A.g.N, n->ws + A.act_off,
+                                      n->params + Bl.poff, n->params + Bl.poff + (int64_t)Bl.K * Bl.g.N,
+                                      n->ws + Bl.act_off, n->params + C.poff,
+                                      n->params + C.poff + (int64_t)C.K * C.g.N, n->ws + C.act_off, st, false);
+      if (rc > 0) return rc;
+      if (rc == 0) {
+        A.last_ksplit = Bl.last_ksplit = C.last_ksplit = 1;
+        x = n->ws + C.act_off;
+        l0 += 3;
+      }
+    }
+    for (int l = l0; l < n->t_end[tr]; ++l) {
       Layer& L = n->layers[l];
       const bool first = (l == n->t_begin[tr]);
       const bool defer = defer_last && (l == n->t_end[tr] - 1) && L.part_off >= 0;
@@ -601,13 +621,26 @@ int xt_net_time_layer(xt_net* n, int32_t layer, int32_t which, const void* obs, 
   bool first = false;
   for (int tr = 0; tr < n->n_trunks; ++tr) first |= (layer == n->t_begin[tr]);
   const void* x = first ? obs : (const void*)(n->ws + n->layers[layer - 1].act_off);
-  XT_REQUIRE(which == 0 || which == 1 || ((which == 2 || which == 3) && !first),
+  XT_REQUIRE(which == 0 || which == 1 || ((which == 2 || which == 3) && !first) || (which == 4 && first),
              "xt_net_time_layer: bad kernel selector");
+  XT_REQUIRE(which != 4 || layer + 2 < (int)n->layers.size(), "xt_net_time_layer: the fused trunk needs 3 layers");
   hipEvent_t e0, e1;
   XT_CHECK_HIP(hipEventCreate(&e0));
   XT_CHECK_HIP(hipEventCreate(&e1));
   int rc = 0;
   auto one = [&]() -> int {
+    if (which == 4) {      // fused conv1 -> conv2 -> conv3 forward (xt_trunk.hip)
+      xt::Layer& A = n->layers[layer];
+      xt::Layer& Bl = n->layers[layer + 1];
+      xt::Layer& C = n->layers[layer + 2];
+      const int rc = xt::launch_trunk_fwd(&A.g, &Bl.g, &C.g, &n->xf, B, obs, idx, n->params + A.poff,
+                                          n->params + A.poff + (int64_t)A.K * A.g.N, n->ws + A.act_off,
+                                          n->params + Bl.poff, n->params + Bl.poff + (int64_t)Bl.K * Bl.g.N,
+                                          n->ws + Bl.act_off, n->params + C.poff,
+                                          n->params + C.poff + (int64_t)C.K * C.g.N, n->ws + C.act_off, st, true);
+      if (rc < 0) { xt::set_error("xt_net_time_layer: the fused trunk rejected the geometry"); return 2; }
+      return rc;
+    }
     if (which == 0)
       return xt::launch_fwd(&L.g, first ? &n->xf : nullptr, B, x, first ? idx : nullptr, n->params + L.poff,
                             n->params + L.poff + (int64_t)L.K * L.g.N, n->ws + L.act_off, n->ws + n->off_partial,
