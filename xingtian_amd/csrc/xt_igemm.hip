@@ -494,6 +494,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------ dgrad
+constexpr int kMaxClasses = 16;      // stride-parity classes (S <= 4)
 struct DgradArgs {
   Geom g;
   const float* dy;
@@ -501,6 +502,7 @@ struct DgradArgs {
   const float* x;     // producer's post-activation output [B,H,W,C]
   float* dx;
   int act_prev;
+  FastDiv d_hw[kMaxClasses], d_w[kMaxClasses];   // per class: divide by HC*WC and by WC (row decode without idiv)
 };
 
 template <int BI, int BJ>
@@ -532,12 +534,13 @@ __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int b
   XT_TL(0);
   XT_TL_ROLE(30);
 
+  const FastDiv dhw = p.d_hw[bz], dw = p.d_w[bz];
   if (t < BI) {
     const int mc = i0 + t;
     int off = -1;
     if (mc < Mc) {
-      const int b = mc / (HC * WC), rem = mc - b * (HC * WC);
-      const int ty = rem / WC, tx = rem - ty * WC;
+      const int b = (int)fdiv((uint32_t)mc, dhw), rem = mc - b * (HC * WC);
+      const int ty = (int)fdiv((uint32_t)rem, dw), tx = rem - ty * WC;
       off = ((b * g.H + cy0 + g.S * ty) * g.W + cx0 + g.S * tx) * g.C;
     }
     rowOut[t] = off;
@@ -549,8 +552,8 @@ __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int b
   for (int i = 0; i < NA; ++i) {
     const int mc = i0 + r0 + 32 * i;
     if (mc < Mc) {
-      const int b = mc / (HC * WC), rem = mc - b * (HC * WC);
-      const int ty = rem / WC, tx = rem - ty * WC;
+      const int b = (int)fdiv((uint32_t)mc, dhw), rem = mc - b * (HC * WC);
+      const int ty = (int)fdiv((uint32_t)rem, dw), tx = rem - ty * WC;
       qy[i] = qy0 + ty; qx[i] = qx0 + tx;
       rowbase[i] = (b * g.OHOW + qy[i] * g.OW + qx[i]) * g.N;
     } else {
@@ -745,6 +748,20 @@ static bool use_bf16x3() {
   return v == 1;
 }
 
+static int fill_class_divs(const Geom& g, DgradArgs* a) {
+  XT_REQUIRE(g.S * g.S <= kMaxClasses, "igemm dgrad: stride %d not supported (max 4)", g.S);
+  for (int cls = 0; cls < g.S * g.S; ++cls) {
+    const int ry = cls / g.S, rx = cls % g.S;
+    const int cy0 = ((ry - g.PT) % g.S + g.S) % g.S, cx0 = ((rx - g.PL) % g.S + g.S) % g.S;
+    const int HC = cy0 < g.H ? (g.H - cy0 + g.S - 1) / g.S : 0;
+    const int WC = cx0 < g.W ? (g.W - cx0 + g.S - 1) / g.S : 0;
+    XT_REQUIRE((long long)g.B * HC * WC * HC * WC < (1ll << 32), "igemm dgrad: class extent too large for the fast divide");
+    a->d_hw[cls] = make_fastdiv((uint32_t)(HC * WC > 0 ? HC * WC : 1));
+    a->d_w[cls] = make_fastdiv((uint32_t)(WC > 0 ? WC : 1));
+  }
+  return 0;
+}
+
 int launch_fwd(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const void* in, const int32_t* idx,
                const float* w, const float* bias, float* y, float* partial, int ksplit, hipStream_t st,
                int* deferred_ksplit) {
@@ -856,6 +873,7 @@ int launch_dgrad(const xt_conv_geom* cg, int B, const float* dy, const float* w,
   if (int rc = make_geom(cg, nullptr, B, &a.g)) return rc;
   a.dy = dy; a.w = w; a.x = x; a.dx = dx; a.act_prev = act_prev;
   const Geom& g = a.g;
+  if (int rc = fill_class_divs(g, &a)) return rc;
   const int hc = (g.H + g.S - 1) / g.S, wc = (g.W + g.S - 1) / g.S;   // upper bound on class extent
   const int mc = B * hc * wc;
   if (g.C <= 32) {
@@ -893,6 +911,7 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
   a.n_wg = a.wg_gx * a.wg_gy * a.wg_gz;
   // ---- dgrad part
   a.dg.dy = dy; a.dg.w = w; a.dg.x = x_in; a.dg.dx = dx; a.dg.act_prev = act_prev;
+  if (int rc = fill_class_divs(g, &a.dg)) return rc;
   const int hc = (g.H + g.S - 1) / g.S, wc = (g.W + g.S - 1) / g.S;
   const int mc = B * hc * wc;
   const bool dsmall = g.C <= 32;
