@@ -239,6 +239,18 @@ int xt_net_ppo_step(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, const i
                     const float* old_v, const double* target_v, int32_t apply,
                     float* loss_out, float* loss_acc, void* stream);
 
+/* The same SGD step (apply = 0) in two halves for data parallelism, so that the all-reduce of the large tail
+ * of the flat gradient (the Dense layer feeding the heads + the heads: 95 % of PpoCnn's parameters) overlaps the
+ * rest of the backward pass.  _begin: forward, loss, backward of the layer that feeds the heads; on return (in
+ * stream order) grads[*tail_off .. n_params) is final.  _end: remaining backward; grads[0 .. *tail_off) final and
+ * the local loss reported.  Networks that cannot be split (two trunks, single layer) do everything in _begin and
+ * return *tail_off = 0.  Replaces the (dead) host-side gradient averaging of xt/framework/trainer.py:89-92. */
+int xt_net_ppo_step_begin(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, const int32_t* idx,
+                          int32_t B, const void* action, const float* old_logp, const double* adv,
+                          const float* old_v, const double* target_v, int64_t* tail_off, void* stream);
+int xt_net_ppo_step_end(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, const int32_t* idx,
+                        int32_t B, float* loss_out, float* loss_acc, void* stream);
+
 /* Model.train of xt/model/ppo/ppo.py:111-132 in one call: NUM_SGD_ITER epochs x
  * ceil(n/BATCH_SIZE) minibatches; perm [num_sgd_iter, n] int32 holds the epoch
  * permutations (the reference's np.random.shuffle, injected).  loss_acc[0] receives the

@@ -512,3 +512,55 @@ def test_fused_trunk_forward_matches_per_layer_path(monkeypatch):
     g0 = net.grads_dict()
     for k in g0:
         assert rel_err(g1[k], g0[k]) < 1e-5, (k, rel_err(g1[k], g0[k]))
+
+
+@pytest.mark.parametrize("which", ["cnn84", "mlp"])
+def test_dp_step_halves_equal_one_shot_step_and_overlapped_allreduce(which):
+    """xt_net_ppo_step_begin/_end (the data-parallel step split so that the all-reduce of the
+    gradient tail overlaps the rest of the backward) produce bit-identical gradients and loss to the one-shot
+    step; the tail starts at the Dense layer feeding the heads (shared trunk) or at 0 (two trunks: nothing to
+    overlap).  With a 1-rank RCCL group the overlapped dp_ppo_step (two async all-reduces on RCCL's stream)
+    equals the single-all-reduce form bit for bit."""
+    import torch.distributed as dist
+    from xingtian_amd import parallel
+    b = 64
+    net, ospec, sd, u8 = _mk(which, b)
+    oracle_params_for(net, ospec, 31)
+    rng = np.random.default_rng(32)
+    a_dim = net.spec.action_dim
+    obs, lab = synth_ppo_rollout(rng, 200, sd, a_dim, u8=u8)
+    c = net.make_ppo_cfg(dict(PPO_CFG, BATCH_SIZE=b))
+    d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).cuda()
+    args = (net.to_device_obs(obs), d(rng.permutation(200)[:b], np.int32), d(lab[0], np.int32),
+            d(lab[1].reshape(-1), np.float32), d(lab[2].reshape(-1), np.float64), d(lab[3].reshape(-1), np.float32),
+            d(lab[4].reshape(-1), np.float64))
+    loss0 = net.ppo_step(c, *args, apply=False).cpu().numpy().copy()
+    g0 = net.grads.cpu().numpy().copy()
+    net.grads.zero_()
+    tail = net.ppo_step_begin(c, *args)
+    torch.cuda.synchronize()
+    g_half = net.grads.cpu().numpy().copy()
+    if which == "cnn84":
+        assert tail == net.spec.layers[3].param_off and tail > 0
+        assert np.array_equal(g_half[tail:], g0[tail:]) and not g_half[:tail].any()
+    else:
+        assert tail == 0 and np.array_equal(g_half, g0)
+    loss1 = net.ppo_step_end(c, args[0], args[1]).cpu().numpy().copy()
+    assert np.array_equal(net.grads.cpu().numpy(), g0) and np.array_equal(loss0[:4], loss1[:4])
+    # overlapped vs plain data-parallel step on a 1-rank RCCL group
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        w0 = net.params.clone()
+        m0, v0, s0 = net.adam_m.clone(), net.adam_v.clone(), net.adam_state.clone()
+        parallel.dp_ppo_step(net, c, PPO_CFG["LR"], PPO_CFG["MAX_GRAD_NORM"], *args, world=1, overlap=False)
+        w_plain = net.params.clone()
+        net.params.copy_(w0); net.adam_m.copy_(m0); net.adam_v.copy_(v0); net.adam_state.copy_(s0)
+        parallel.dp_ppo_step(net, c, PPO_CFG["LR"], PPO_CFG["MAX_GRAD_NORM"], *args, world=1, overlap=True)
+        assert torch.equal(net.params, w_plain) and not torch.equal(w_plain, w0)
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -189,13 +189,19 @@ static int heads_wgrad(xt_net* n, int B, hipStream_t st) {
 // (dact[l] -> dact[l-1]) is the critical path and stays on `st`; every weight-gradient kernel except the
 // first layer's only consumes finished tensors, so it is forked onto a side stream as soon as its dY
 // exists and joined before the gradient reduction.  Works eagerly and under stream capture.
-static int trunk_backward(xt_net* n, const void* obs, const int32_t* idx, int B, hipStream_t st) {
-  if (!n->overlap) {
+// part: 0 = whole backward; 1 = only the layer that feeds the heads (+ the head weight gradients); 2 = the rest
+// (the data-parallel step all-reduces the large tail of the gradient while part 2 runs; see dp_splittable()).
+static bool dp_splittable(const xt_net* n) { return n->n_trunks == 1 && n->t_end[0] - n->t_begin[0] >= 2; }
+
+static int trunk_backward(xt_net* n, const void* obs, const int32_t* idx, int B, hipStream_t st, int part = 0) {
+  if (!n->overlap || part != 0) {
     // one launch per non-first layer: dgrad + wgrad (+ the head weight gradients with the very first one)
-    bool heads_done = false;
+    bool heads_done = (part == 2);
     for (int tr = 0; tr < n->n_trunks; ++tr)
       for (int l = n->t_end[tr] - 1; l >= n->t_begin[tr]; --l) {
         const bool first = (l == n->t_begin[tr]);
+        const bool last = (l == n->t_end[tr] - 1);
+        if ((part == 1 && !last) || (part == 2 && last)) continue;
         Layer& L = n->layers[l];
         if (first) {
           if (!heads_done) { if (int rc = heads_wgrad(n, B, st)) return rc; heads_done = true; }
@@ -266,12 +272,15 @@ static int trunk_backward(xt_net* n, const void* obs, const int32_t* idx, int B,
 }
 
 // ONE kernel: every slab reduction (trunk layers + heads) + the squared-norm partials
-static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t st) {
+static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t st, int part = 0) {
   const int F = n->feat, A = n->A;
   GradTable tab;
   tab.n = 0;
   XT_REQUIRE(n->layers.size() + 3 <= 12, "xt_net: too many layers for the gradient table");
-  for (auto& L : n->layers) {
+  for (size_t li = 0; li < n->layers.size(); ++li) {
+    const bool last = ((int)li == n->t_end[0] - 1);
+    if ((part == 1 && !last) || (part == 2 && last)) continue;
+    Layer& L = n->layers[li];
     GradEntry& E = tab.e[tab.n++];
     E.count = (L.K + 1) * L.g.N;
     E.dst = n->grads + L.poff;
@@ -279,6 +288,7 @@ static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t s
     E.src = (L.last_msplit > 1) ? n->ws + L.slab_off : E.dst;
     E.stride = E.count;
   }
+  if (part == 2) return launch_grads_finish(&tab, n->ws + n->off_norm, kMaxNormPartials, &n->norm_blocks, fin, st);
   {
     GradEntry& E = tab.e[tab.n++];
     E.count = F * A + A; E.dst = n->grads + n->pi_off; E.src = n->ws + n->off_hslab_pi;
@@ -311,10 +321,21 @@ static int net_apply(xt_net* n, float lr, float b1, float b2, float eps, float c
   return launch_adam(n->params, n->grads, n->m, n->v, n->P, b1, b2, eps, n->state, st);
 }
 
+// phase 0: the whole step; phase 1 / 2: the two halves of the data-parallel step (xt_net_ppo_step_begin/_end)
 static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32_t* idx, int B,
                     const void* action_v, const float* old_logp, const double* adv, const float* old_v,
-                    const double* target_v, int apply, float* loss_out, float* loss_acc, hipStream_t st) {
+                    const double* target_v, int apply, float* loss_out, float* loss_acc, hipStream_t st,
+                    int phase = 0) {
   XT_REQUIRE(n->params && n->ws, "xt_net: buffers not bound (call xt_net_bind)");
+  if (phase == 2) {
+    const float inv_b2 = 1.f / (float)(c->global_batch > 0 ? c->global_batch : B);
+    float* lo2 = loss_out ? loss_out : n->ws + n->off_loss;
+    if (dp_splittable(n)) {
+      if (int rc = trunk_backward(n, obs, idx, B, st, 2)) return rc;
+      if (int rc = grads_finish(n, B, nullptr, st, 2)) return rc;
+    }
+    return xt_ppo_loss_reduce(n->ws + n->off_terms, B, c->ent_coef, c->critic_coef, inv_b2, lo2, loss_acc, st);
+  }
   XT_REQUIRE(B > 0 && B <= n->maxB, "xt_net_ppo_step: batch %d outside (0,%d]", B, n->maxB);
   const bool gauss = (n->action_type == XT_ACTION_DIAG_GAUSSIAN);
   const int32_t* action = static_cast<const int32_t*>(action_v);
@@ -373,6 +394,11 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
                                     n->params + n->v_off, n->ws + n->off_dlogits, n->ws + n->off_dvalue, Lp.g.act,
                                     n->ws + Lp.dact_off, n->ws + Lv.dact_off, st))
       return rc;
+  }
+  if (phase == 1) {
+    const int part = dp_splittable(n) ? 1 : 0;
+    if (int rc = trunk_backward(n, obs, idx, B, st, part)) return rc;
+    return grads_finish(n, B, nullptr, st, part);
   }
   if (int rc = trunk_backward(n, obs, idx, B, st)) return rc;
   LossArgs la;
@@ -520,6 +546,22 @@ int xt_net_ppo_step(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, const i
   XT_REQUIRE(net && cfg, "xt_net_ppo_step: null argument");
   return xt::ppo_step(net, cfg, obs, idx, B, action, old_logp, adv, old_v, target_v, apply, loss_out, loss_acc,
                       xt::as_stream(stream));
+}
+
+int xt_net_ppo_step_begin(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, const int32_t* idx, int32_t B,
+                          const void* action, const float* old_logp, const double* adv, const float* old_v,
+                          const double* target_v, int64_t* tail_off, void* stream) {
+  XT_REQUIRE(net && cfg && tail_off, "xt_net_ppo_step_begin: null argument");
+  *tail_off = xt::dp_splittable(net) ? net->layers[net->t_end[0] - 1].poff : 0;
+  return xt::ppo_step(net, cfg, obs, idx, B, action, old_logp, adv, old_v, target_v, 0, nullptr, nullptr,
+                      xt::as_stream(stream), 1);
+}
+
+int xt_net_ppo_step_end(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, const int32_t* idx, int32_t B,
+                        float* loss_out, float* loss_acc, void* stream) {
+  XT_REQUIRE(net && cfg, "xt_net_ppo_step_end: null argument");
+  return xt::ppo_step(net, cfg, obs, idx, B, nullptr, nullptr, nullptr, nullptr, nullptr, 0, loss_out, loss_acc,
+                      xt::as_stream(stream), 2);
 }
 
 static int ppo_train_enqueue(xt_net* net, const xt_ppo_cfg* c, const void* obs, int32_t n, const int32_t* perm,

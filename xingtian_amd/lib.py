@@ -80,6 +80,8 @@ SIGNATURES = {
     "xt_net_bind": (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_int64]),
     "xt_net_forward": (c_int32, [_P, _P, _P, c_int32, _P, _P, _P]),
     "xt_net_ppo_step": (c_int32, [_P, POINTER(PpoCfg), _P, _P, c_int32, _P, _P, _P, _P, _P, c_int32, _P, _P, _P]),
+    "xt_net_ppo_step_begin": (c_int32, [_P, POINTER(PpoCfg), _P, _P, c_int32, _P, _P, _P, _P, _P, POINTER(c_int64), _P]),
+    "xt_net_ppo_step_end": (c_int32, [_P, POINTER(PpoCfg), _P, _P, c_int32, _P, _P, _P]),
     "xt_net_ppo_train": (c_int32, [_P, POINTER(PpoCfg), _P, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, _P]),
     "xt_net_impala_step": (c_int32, [_P, POINTER(ImpalaCfg), _P, c_int32, _P, _P, _P, _P, c_int32, _P, _P, _P]),
     "xt_net_apply": (c_int32, [_P, c_float, c_float, c_float, c_float, c_float, c_float, _P]),

@@ -220,6 +220,23 @@ class HipActorCritic(object):
                 "xt_net_ppo_step")
         return self.loss_out
 
+    def ppo_step_begin(self, c, obs, idx, action, old_logp, adv, old_v, target_v):
+        """First half of a data-parallel step (C ABI xt_net_ppo_step_begin): returns the float offset from which
+        the flat gradient is already final (in stream order) -> that tail can be all-reduced while
+        ``ppo_step_end`` runs the rest of the backward pass."""
+        b = int(idx.numel()) if idx is not None else int(obs.shape[0])
+        tail = ctypes.c_int64()
+        L.check(self.lib.xt_net_ppo_step_begin(self.handle, ctypes.byref(c), L.ptr(obs), L.ptr(idx), b, L.ptr(action),
+                                               L.ptr(old_logp), L.ptr(adv), L.ptr(old_v), L.ptr(target_v),
+                                               ctypes.byref(tail), L.stream_ptr()), "xt_net_ppo_step_begin")
+        return int(tail.value)
+
+    def ppo_step_end(self, c, obs, idx):
+        b = int(idx.numel()) if idx is not None else int(obs.shape[0])
+        L.check(self.lib.xt_net_ppo_step_end(self.handle, ctypes.byref(c), L.ptr(obs), L.ptr(idx), b,
+                                             L.ptr(self.loss_out), None, L.stream_ptr()), "xt_net_ppo_step_end")
+        return self.loss_out
+
     def ppo_train(self, c, obs, perm, action, old_logp, adv, old_v, target_v, use_graph=False):
         n = int(obs.shape[0])
         L.check(self.lib.xt_net_ppo_train(self.handle, ctypes.byref(c), L.ptr(obs), n, L.ptr(perm), L.ptr(action),
