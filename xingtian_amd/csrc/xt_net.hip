@@ -31,6 +31,8 @@ int launch_global_norm(const float*, long long, float, float, float, float, floa
 int launch_grads_finish(GradTable*, float*, int, int*, const FinalizeArgs*, hipStream_t);
 int launch_norm_finalize(const float*, int, float, float, float, float, float, int, float*, const LossArgs*, hipStream_t);
 int launch_ppo_heads_fused(const PpoHeadArgs&, hipStream_t);
+int launch_adam_clip(float*, const float*, float*, float*, long long, float, float, float, float*, const float*, int,
+                     float, float, hipStream_t);
 int launch_trunk_fwd(const xt_conv_geom*, const xt_conv_geom*, const xt_conv_geom*, const xt_input_xform*, int,
                      const void*, const int32_t*, const float*, const float*, float*, const float*, const float*,
                      float*, const float*, const float*, float*, hipStream_t, bool);
@@ -308,9 +310,13 @@ static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t s
 }
 
 // mode 0: gradient was changed after grads_finish (all-reduce) -> recompute the norm;
-// mode 1: squared-norm partials of grads_finish are valid -> finalize kernel;  mode 2: already finalized in-kernel
+// mode 1: squared-norm partials of grads_finish are valid -> finalize kernel;  mode 2: already finalized in-kernel;
+// mode 3: partials valid, loss/step size done by grads_finish's extra block -> Adam derives the clip factor itself
 static int net_apply(xt_net* n, float lr, float b1, float b2, float eps, float clip, float gscale, int mode,
                      const LossArgs* la, hipStream_t st) {
+  if (mode == 3)
+    return launch_adam_clip(n->params, n->grads, n->m, n->v, n->P, b1, b2, eps, n->state, n->ws + n->off_norm,
+                            n->norm_blocks, clip, gscale, st);
   if (mode == 1) {
     if (int rc = launch_norm_finalize(n->ws + n->off_norm, n->norm_blocks, clip, gscale, lr, b1, b2, 1, n->state, la, st))
       return rc;
@@ -405,12 +411,15 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
   la.terms = n->ws + n->off_terms; la.B = B; la.ent_coef = c->ent_coef; la.critic_coef = c->critic_coef;
   la.inv_b = inv_b; la.out = lo; la.acc = loss_acc;
   if (apply) {
+    static int tail_mode = -1;     // XT_FIN_TICKET=1: the old "last block finalises" form (A/B)
+    if (tail_mode < 0) { const char* e = getenv("XT_FIN_TICKET"); tail_mode = (e && e[0] == '1') ? 1 : 2; }
     FinalizeArgs fin;
-    fin.enable = 1; fin.counter = reinterpret_cast<unsigned int*>(n->ws + n->off_counter);
+    fin.enable = tail_mode; fin.counter = reinterpret_cast<unsigned int*>(n->ws + n->off_counter);
     fin.clip_norm = c->max_grad_norm; fin.grad_scale = c->grad_scale; fin.lr = c->lr; fin.beta1 = c->beta1;
     fin.beta2 = c->beta2; fin.state = n->state; fin.loss = la;
     if (int rc = grads_finish(n, B, &fin, st)) return rc;
-    return net_apply(n, c->lr, c->beta1, c->beta2, c->eps, c->max_grad_norm, c->grad_scale, 2, nullptr, st);
+    return net_apply(n, c->lr, c->beta1, c->beta2, c->eps, c->max_grad_norm, c->grad_scale, tail_mode == 1 ? 2 : 3,
+                     nullptr, st);
   }
   if (int rc = grads_finish(n, B, nullptr, st)) return rc;
   // gradient only (data parallel): still report the local loss

@@ -13,6 +13,11 @@ constexpr int kNormBlocks = 512;   // partial sums; scratch must hold >= kNormBl
 __device__ void finalize_body(const float* partial, int nblocks, float clip_norm, float grad_scale, float lr,
                               float beta1, float beta2, int advance, float* state, const LossArgs& la, double* sh);
 
+__device__ void loss_reduce_body(const LossArgs& la, double* sh);
+__device__ __forceinline__ void adam_advance(float* state, float lr, float beta1, float beta2);
+__device__ void finalize_body(const float* partial, int nblocks, float clip_norm, float grad_scale, float lr,
+                              float beta1, float beta2, int advance, float* state, const LossArgs& la, double* sh);
+
 __global__ __launch_bounds__(256) void grads_finish_kernel(const GradTable tab, float* __restrict__ partial,
                                                            const FinalizeArgs fin) {
   __shared__ float4 sh4[256];
@@ -20,6 +25,13 @@ __global__ __launch_bounds__(256) void grads_finish_kernel(const GradTable tab, 
   __shared__ int s_last;
   XT_TL(0);
   XT_TL_ROLE(60);
+  if (fin.enable == 2 && blockIdx.x == gridDim.x - 1) {
+    // extra block of the "Adam computes the clip scale itself" form: everything of the old last-block finalize
+    // that does not depend on the gradient norm (loss scalars, beta powers, step size) -- off the critical path
+    loss_reduce_body(fin.loss, reinterpret_cast<double*>(sh4));
+    if (threadIdx.x == 0) adam_advance(fin.state, fin.lr, fin.beta1, fin.beta2);
+    return;
+  }
   int ei = 0;
   for (int q = 1; q < tab.n; ++q)
     if ((int)blockIdx.x >= tab.e[q].blk0) ei = q;
@@ -84,7 +96,7 @@ __global__ __launch_bounds__(256) void grads_finish_kernel(const GradTable tab, 
     __syncthreads();
   }
   XT_TL(2);
-  if (!fin.enable) {
+  if (fin.enable != 1) {
     if (t == 0) partial[blockIdx.x] = shs[0];
     return;
   }
@@ -175,34 +187,37 @@ __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __rest
 }
 
 // state: [0]=b1^t [1]=b2^t [2]=scale [3]=alpha [4]=gnorm [5]=step
-__device__ void finalize_body(const float* partial, int nblocks, float clip_norm, float grad_scale, float lr,
-                              float beta1, float beta2, int advance, float* state, const LossArgs& la, double* sh) {
-  if (la.terms) {   // PPO loss scalars from the per-sample terms (fixed-order tree), xt/model/ppo/__init__.py
-    double t3[3] = {0.0, 0.0, 0.0};
-    for (int b = threadIdx.x; b < la.B; b += 256) {
-      t3[0] += (double)la.terms[(size_t)b * 4 + 0];
-      t3[1] += (double)la.terms[(size_t)b * 4 + 1];
-      t3[2] += (double)la.terms[(size_t)b * 4 + 2];
-    }
-    double tot[3];
-    for (int q = 0; q < 3; ++q) {
-      sh[threadIdx.x] = t3[q];
-      __syncthreads();
-      for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-        __syncthreads();
-      }
-      tot[q] = sh[0];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-      const float surr = (float)tot[0] * la.inv_b, ent = (float)tot[1] * la.inv_b, vf = 0.5f * (float)tot[2] * la.inv_b;
-      const float actor = -surr - la.ent_coef * ent;
-      const float loss = actor + la.critic_coef * vf;
-      if (la.out) { la.out[0] = loss; la.out[1] = actor; la.out[2] = vf; la.out[3] = ent; }
-      if (la.acc) { la.acc[0] += loss; la.acc[1] += 1.f; }
-    }
+// PPO loss scalars from the per-sample terms (fixed-order tree), xt/model/ppo/__init__.py
+__device__ void loss_reduce_body(const LossArgs& la, double* sh) {
+  if (!la.terms) return;
+  double t3[3] = {0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < la.B; b += 256) {
+    t3[0] += (double)la.terms[(size_t)b * 4 + 0];
+    t3[1] += (double)la.terms[(size_t)b * 4 + 1];
+    t3[2] += (double)la.terms[(size_t)b * 4 + 2];
   }
+  double tot[3];
+  for (int q = 0; q < 3; ++q) {
+    sh[threadIdx.x] = t3[q];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+      __syncthreads();
+    }
+    tot[q] = sh[0];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float surr = (float)tot[0] * la.inv_b, ent = (float)tot[1] * la.inv_b, vf = 0.5f * (float)tot[2] * la.inv_b;
+    const float actor = -surr - la.ent_coef * ent;
+    const float loss = actor + la.critic_coef * vf;
+    if (la.out) { la.out[0] = loss; la.out[1] = actor; la.out[2] = vf; la.out[3] = ent; }
+    if (la.acc) { la.acc[0] += loss; la.acc[1] += 1.f; }
+  }
+}
+
+// sum of the per-block squared-norm partials (double, fixed order: identical in every block that calls it)
+__device__ double sqnorm_total(const float* partial, int nblocks, double* sh) {
   double s = 0.0;
   for (int i = threadIdx.x; i < nblocks; i += 256) s += (double)partial[i];
   sh[threadIdx.x] = s;
@@ -211,19 +226,33 @@ __device__ void finalize_body(const float* partial, int nblocks, float clip_norm
     if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
     __syncthreads();
   }
+  const double tot = sh[0];
+  __syncthreads();
+  return tot;
+}
+// norm of (grad*grad_scale) and tf.clip_by_global_norm's factor: t * clip_norm * min(1/norm, 1/clip_norm)
+__device__ __forceinline__ void clip_scale(double sq, float clip_norm, float grad_scale, float* gnorm, float* scale) {
+  *gnorm = sqrtf((float)sq) * grad_scale;
+  *scale = clip_norm * fminf(1.f / *gnorm, 1.f / clip_norm) * grad_scale;
+}
+// Adam step-size bookkeeping that does not depend on the gradient: beta powers, lr_t, step counter
+__device__ __forceinline__ void adam_advance(float* state, float lr, float beta1, float beta2) {
+  const float b1p = state[0] * beta1, b2p = state[1] * beta2;
+  state[0] = b1p; state[1] = b2p;
+  state[3] = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+  state[5] += 1.f;
+}
+
+__device__ void finalize_body(const float* partial, int nblocks, float clip_norm, float grad_scale, float lr,
+                              float beta1, float beta2, int advance, float* state, const LossArgs& la, double* sh) {
+  loss_reduce_body(la, sh);
+  const double sq = sqnorm_total(partial, nblocks, sh);
   if (threadIdx.x == 0) {
-    // norm of (grad*grad_scale)
-    const float gnorm = sqrtf((float)sh[0]) * grad_scale;
-    // tf.clip_by_global_norm: t * clip_norm * min(1/norm, 1/clip_norm)
-    const float sc = clip_norm * fminf(1.f / gnorm, 1.f / clip_norm);
-    state[2] = sc * grad_scale;
+    float gnorm, sc;
+    clip_scale(sq, clip_norm, grad_scale, &gnorm, &sc);
+    state[2] = sc;
     state[4] = gnorm;
-    if (advance) {
-      const float b1p = state[0] * beta1, b2p = state[1] * beta2;
-      state[0] = b1p; state[1] = b2p;
-      state[3] = lr * sqrtf(1.f - b2p) / (1.f - b1p);
-      state[5] += 1.f;
-    }
+    if (advance) adam_advance(state, lr, beta1, beta2);
   }
 }
 
@@ -238,6 +267,57 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, con
                                                       float* __restrict__ m, float* __restrict__ v, long long count,
                                                       float beta1, float beta2, float eps, const float* __restrict__ state) {
   const float scale = state[2], alpha = state[3];
+  const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+  const long long n4 = count >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 mv = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+#define XT_ADAM1(c)                                   \
+    {                                                 \
+      const float gg = gv.c * scale;                  \
+      mv.c += (gg - mv.c) * omb1;                     \
+      vv.c += (gg * gg - vv.c) * omb2;                \
+      pv.c -= (mv.c * alpha) / (sqrtf(vv.c) + eps);   \
+    }
+    XT_ADAM1(x) XT_ADAM1(y) XT_ADAM1(z) XT_ADAM1(w)
+#undef XT_ADAM1
+    reinterpret_cast<float4*>(m)[i] = mv;
+    reinterpret_cast<float4*>(v)[i] = vv;
+    reinterpret_cast<float4*>(p)[i] = pv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (count & 3)) {
+    const long long i = (n4 << 2) + threadIdx.x;
+    const float gg = g[i] * scale;
+    float mm = m[i], vv = v[i];
+    mm += (gg - mm) * omb1;
+    vv += (gg * gg - vv) * omb2;
+    m[i] = mm; v[i] = vv;
+    p[i] -= (mm * alpha) / (sqrtf(vv) + eps);
+  }
+}
+
+// Adam + global-norm clip where EVERY block derives the clip factor itself from the squared-norm partials of
+// grads_finish_kernel (1920 floats from L2, fixed-order double sum -> bitwise the same factor in every block):
+// removes the serial "last block finalises" tail (ticket + 6 us single-block reduction) from the step.  Block 0
+// also publishes scale / gnorm to state[2] / state[4] (nobody reads them inside this launch).
+__global__ __launch_bounds__(256) void adam_tf_clip_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                           float* __restrict__ m, float* __restrict__ v, long long count,
+                                                           float beta1, float beta2, float eps, float* __restrict__ state,
+                                                           const float* __restrict__ partial, int nblocks,
+                                                           float clip_norm, float grad_scale) {
+  __shared__ double sh[256];
+  __shared__ float s_scale;
+  const double sq = sqnorm_total(partial, nblocks, sh);
+  if (threadIdx.x == 0) {
+    float gnorm, sc;
+    clip_scale(sq, clip_norm, grad_scale, &gnorm, &sc);
+    s_scale = sc;
+    if (blockIdx.x == 0) { state[2] = sc; state[4] = gnorm; }
+  }
+  __syncthreads();
+  const float scale = s_scale, alpha = state[3];
   const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
   const long long n4 = count >> 2;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
@@ -294,9 +374,23 @@ int launch_grads_finish(GradTable* tab, float* partial, int max_partials, int* n
   XT_REQUIRE(blk > 0 && blk <= max_partials, "grads_finish: %d partial blocks > scratch %d", blk, max_partials);
   FinalizeArgs f;
   if (fin) f = *fin; else { memset(&f, 0, sizeof(f)); }
-  hipLaunchKernelGGL(grads_finish_kernel, dim3(blk), dim3(256), 0, st, *tab, partial, f);
+  hipLaunchKernelGGL(grads_finish_kernel, dim3(blk + (f.enable == 2 ? 1 : 0)), dim3(256), 0, st, *tab, partial, f);
   XT_LAUNCH_CHECK();
   *nblocks_out = blk;
+  return 0;
+}
+
+int launch_adam_clip(float* param, const float* grad, float* m, float* v, long long count, float beta1, float beta2,
+                     float eps, float* state, const float* partial, int nblocks, float clip_norm, float grad_scale,
+                     hipStream_t st) {
+  XT_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+             "adam: buffers must be 16-byte aligned");
+  int nb = (int)((count / 4 + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(adam_tf_clip_kernel, dim3(nb), dim3(256), 0, st, param, grad, m, v, count, beta1, beta2, eps, state,
+                     partial, nblocks, clip_norm, grad_scale);
+  XT_LAUNCH_CHECK();
   return 0;
 }
 
