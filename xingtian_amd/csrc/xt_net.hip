@@ -650,10 +650,15 @@ int xt_net_impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int32
       return rc;
   }
   if (int rc = xt::trunk_backward(n, obs, nullptr, nfr, st)) return rc;
-  if (int rc = xt::grads_finish(n, nfr, nullptr, st)) return rc;
-  if (apply)
-    return xt::net_apply(n, c->lr, c->beta1, c->beta2, c->eps, c->grad_norm_clip, c->grad_scale, 1, nullptr, st);
-  return 0;
+  if (!apply) return xt::grads_finish(n, nfr, nullptr, st);
+  // step size bookkeeping in an extra grads_finish block, clip factor inside the Adam kernel: no finalize launch
+  xt::FinalizeArgs fin;
+  fin.enable = 2; fin.counter = nullptr; fin.clip_norm = c->grad_norm_clip; fin.grad_scale = c->grad_scale;
+  fin.lr = c->lr; fin.beta1 = c->beta1; fin.beta2 = c->beta2; fin.state = n->state;
+  fin.loss.terms = nullptr; fin.loss.B = 0; fin.loss.ent_coef = fin.loss.critic_coef = fin.loss.inv_b = 0.f;
+  fin.loss.out = fin.loss.acc = nullptr;
+  if (int rc = xt::grads_finish(n, nfr, &fin, st)) return rc;
+  return xt::net_apply(n, c->lr, c->beta1, c->beta2, c->eps, c->grad_norm_clip, c->grad_scale, 3, nullptr, st);
 }
 
 int xt_net_apply(xt_net* n, float lr, float beta1, float beta2, float eps, float clip_norm, float grad_scale,
