@@ -709,6 +709,10 @@ __global__ __launch_bounds__(256) void igemm_bwd_layer_kernel(const BwdLayerArgs
   }
   b -= p.n_dg;
   if (b < p.n_wg) {
+    // XCD-contiguous order: the k tiles of one m range gather overlapping im2col lines of the same activation
+    // rows; consecutive block ids land on different XCDs (round-robin dispatch, private L2s), which made every
+    // XCD fetch the layer input once per k tile (PMC: FETCH 2x35 MB for a 16 MB input)
+    b = (int)xcd_chunk((uint32_t)b, (uint32_t)p.n_wg);
     const int bx = b % p.wg_gx, r = b / p.wg_gx;
     igemm_wgrad_body<WBI, WBJ, WWI, WWJ, false, WPAD>(p.wg, bx, r % p.wg_gy, r / p.wg_gy, smem);
     return;
