@@ -279,8 +279,8 @@ int xt_net_impala_step(xt_net* net, const xt_impala_cfg* cfg, const void* obs, i
 int xt_net_apply(xt_net* net, float lr, float beta1, float beta2, float eps, float clip_norm,
                  float grad_scale, void* stream);
 
-/* kernel-time probe: average duration (ms) of `reps` launches of the dominant kernel
- * (first-layer forward) on `stream`, measured with HIP events on that stream. */
+/* kernel-time probe: average duration (ms) of `reps` back-to-back launches of ONE layer kernel of the bound
+ * network on `stream`, measured with HIP events on that stream (bench.py's roofline, tools/layer_bench.py). */
 int xt_net_time_layer(xt_net* net, int32_t layer, int32_t which /*0 fwd 1 wgrad 2 dgrad 3 fused dgrad+wgrad 4 fused conv-trunk fwd (layer..layer+2)*/,
                       const void* obs, const int32_t* idx, int32_t B, int32_t reps,
                       float* ms_out, void* stream);

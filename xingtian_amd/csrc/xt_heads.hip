@@ -361,27 +361,6 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// feature[f] = act(sum_z part[z][row+f] + bias[f]) for f = lane, lane+64, ...: 8 slabs in flight per f
-// (clamped unconditional loads; the fixed summation order z = 0..ksplit-1 in groups of 8 is deterministic)
-__device__ __forceinline__ void sum_partials(const float* __restrict__ part, int ksplit, long long stride, size_t row,
-                                             int F, int lane, const float* __restrict__ bias, int act,
-                                             float* __restrict__ out) {
-  for (int f = lane; f < F; f += 64) {
-    float s = 0.f;
-    for (int z0 = 0; z0 < ksplit; z0 += 8) {
-      float v[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int z = z0 + q;
-        const float x = part[(size_t)(z < ksplit ? z : ksplit - 1) * stride + row + f];
-        v[q] = z < ksplit ? x : 0.f;
-      }
-      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-    }
-    out[f] = act_apply(s + bias[f], act);
-  }
-}
-
 // One wave (= one 64-thread workgroup) per sample, specialised on NQ = ceil(F/64) features per lane, on whether
 // the split-K partial slabs of the last trunk layer still have to be summed (PART) and on shared/separate trunks.
 // EVERY global load of the wave is issued before the first dependent instruction (the kernel is a pure latency
