@@ -197,3 +197,20 @@ def test_data_parallel_gradient_allreduce_gloo_world2():
     out = mgr.dict()
     mp.spawn(_dp_worker, args=(world, port, out), nprocs=world, join=True)
     assert dict(out) == {0: 1, 1: 1}
+
+
+def test_linear_cosine_decay_known_answers():
+    """tf.train.linear_cosine_decay as the reference's ImpalaCnnOpt._get_lr uses it (impala_cnn_opt.py:236-249):
+    closed-form values at 0, decay_steps/2, decay_steps and beyond."""
+    import importlib
+    mod = importlib.import_module("xingtian_amd.model.impala.impala_cnn_opt")
+    lcd = mod.linear_cosine_decay
+    lr0, ds = 0.01, 20000.0
+    beta = 1e-6 / ds
+    assert abs(lcd(lr0, 0, ds, beta=beta) - lr0 * (1.0 + beta)) < 1e-9
+    assert abs(lcd(lr0, 10000, ds, beta=beta) - lr0 * (0.5 * 0.5 + beta)) < 1e-8      # linear 0.5, cos(pi/2) -> 0.5
+    assert abs(lcd(lr0, 20000, ds, beta=beta) - lr0 * beta) < 1e-9
+    assert lcd(lr0, 50000, ds, beta=beta) == lcd(lr0, 20000, ds, beta=beta)            # clamped at decay_steps
+    assert lcd(lr0, 5000, ds, beta=beta).dtype == np.float32
+    vals = [float(lcd(lr0, s_, ds, beta=beta)) for s_ in range(0, 20001, 500)]
+    assert all(a > b for a, b in zip(vals, vals[1:]))                                   # monotone decreasing

@@ -564,3 +564,28 @@ def test_dp_step_halves_equal_one_shot_step_and_overlapped_allreduce(which):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_impala_lr_schedule_linear_cosine_decay_drives_the_adam_step_size():
+    """lr_schedule (impala_cnn_opt.py:199-203,236-249): the step size of update k is linear_cosine_decay at
+    global_step k; the device-side lr_t = lr * sqrt(1-b2^t)/(1-b1^t) must follow it."""
+    from xingtian_amd.model import model_builder
+    from xingtian_amd.model.impala.impala_cnn_opt import linear_cosine_decay
+    sched = [[0, 0.01], [20000, 0.000001]]
+    model = model_builder({"model_name": "ImpalaCnnOpt", "state_dim": [42, 42, 4], "input_dtype": "uint8",
+                           "state_mean": 128.0, "state_std": 128.0, "action_dim": 6,
+                           "model_config": {"sample_batch_step": 10, "lr_schedule": sched, "SEED": 3, "MAX_BATCH": 64}})
+    rng = np.random.default_rng(6)
+    n = 20
+    for k in range(3):
+        model._global_step = [0, 7000, 19999][k]
+        want_lr = float(linear_cosine_decay(0.01, model._global_step, 20000.0, beta=1e-6 / 20000.0))
+        assert abs(float(model.current_lr()) - want_lr) < 1e-12
+        state = rng.integers(0, 256, (n, 42, 42, 4)).astype(np.uint8)
+        label = [rng.standard_normal((n, 6)).astype(np.float32), rng.integers(0, 6, n).astype(np.int32),
+                 rng.random(n) < 0.1, rng.choice([-1.0, 0.0, 1.0], n).astype(np.float32)]
+        assert np.isfinite(model.train(state, label))
+        st = model.net.adam_state.cpu().numpy()
+        t = k + 1
+        alpha = want_lr * np.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t)
+        assert abs(st[3] - alpha) < 3e-5 * alpha and int(round(st[5])) == t     # fp32 beta powers on the device

@@ -16,6 +16,16 @@ from xingtian_amd.model.model import XTModel
 from xingtian_amd.register import Registers, import_config
 
 
+def linear_cosine_decay(learning_rate, global_step, decay_steps, num_periods=0.5, alpha=0.0, beta=0.001):
+    """tf.train.linear_cosine_decay in float32 (the reference's ``_get_lr``, impala_cnn_opt.py:236-249, calls it
+    with learning_rate = lr_schedule[0][1], decay_steps = 20000 and beta = lr_schedule[1][1] / decay_steps)."""
+    f = np.float32
+    step = f(min(float(global_step), float(decay_steps)))
+    linear_decayed = (f(decay_steps) - step) / f(decay_steps)
+    cosine_decayed = f(0.5) * (f(1.0) + np.cos(f(np.pi) * f(2.0) * f(num_periods) * step / f(decay_steps), dtype=f))
+    return f(learning_rate) * ((f(alpha) + linear_decayed) * cosine_decayed + f(beta))
+
+
 @Registers.model
 class ImpalaCnnOpt(XTModel):
     """Docstring for ActorNetwork (impala_cnn_opt.py:64)."""
@@ -32,9 +42,11 @@ class ImpalaCnnOpt(XTModel):
         self.opt_type = model_config.get("opt_type", "adam")
         if self.opt_type != "adam":
             raise KeyError("invalid opt_type: {} (the HIP learner implements adam)".format(self.opt_type))
-        if self.lr_schedule:
-            raise NotImplementedError("lr_schedule (linear_cosine_decay) is not implemented on the HIP learner")
+        if self.lr_schedule and len(self.lr_schedule) != 2:
+            raise ValueError("lr_schedule invalid: {} (need 2 elements, like [[0, 0.01], [20000, 0.000001]])".format(
+                self.lr_schedule))
         self.lr = LR
+        self._global_step = 0          # tf.Variable global_step of apply_gradients (impala_cnn_opt.py:198,217)
         self.grad_norm_clip = model_config.get("grad_norm_clip", 40.0)
         self.sample_batch_steps = model_config.get("sample_batch_step", 50)
         self.max_batch = int(model_config.get("MAX_BATCH", model_info.get("max_batch", 1024)))
@@ -61,8 +73,18 @@ class ImpalaCnnOpt(XTModel):
         act = torch.from_numpy(np.ascontiguousarray(actions, dtype=np.int32).reshape(-1)).to(dev)
         dn = torch.from_numpy(np.ascontiguousarray(np.asarray(dones, dtype=bool).astype(np.uint8)).reshape(-1)).to(dev)
         rw = torch.from_numpy(np.ascontiguousarray(rewards, dtype=np.float32).reshape(-1)).to(dev)
+        if self.lr_schedule:           # the step size is a host-side scalar of the C ABI: evaluate the schedule here
+            self._cfg.lr = float(self.current_lr())
         out = self.net.impala_step(self._cfg, obs, bp, act, dn, rw, apply=True)
+        self._global_step += 1
         return np.float32(out[0].item())
+
+    def current_lr(self, decay_step=20000.0):
+        """Learning rate of the NEXT update (``_get_lr``, impala_cnn_opt.py:236-249)."""
+        if not self.lr_schedule:
+            return np.float32(self.lr)
+        return linear_cosine_decay(self.lr_schedule[0][1], self._global_step, decay_step,
+                                   beta=self.lr_schedule[1][1] / float(decay_step))
 
     def predict(self, state):
         """-> [logits [B,A], baseline [B], action [B]] (impala_cnn_opt.py:267-277)."""
