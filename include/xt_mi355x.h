@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define XT_ABI_VERSION 2
+#define XT_ABI_VERSION 3
 
 #define XT_ACT_NONE 0
 #define XT_ACT_RELU 1
@@ -267,7 +267,14 @@ typedef struct xt_impala_cfg {
   float grad_norm_clip, gamma;
   int32_t sample_batch_step;    /* T */
   float grad_scale;
+  int32_t opt_type;             /* XT_OPT_ADAM | XT_OPT_RMSPROP_CENTERED (ABI >= 3)                          */
+  float rms_decay, rms_eps;     /* tf.train.RMSPropOptimizer(LR, decay=0.99, epsilon=0.1, centered=True),    */
+                                /* impala_cnn_opt.py:205-206: uses adam_m as the mean gradient `mg` and       */
+                                /* adam_v as the mean square `ms` (the caller initialises ms to ONES as TF)   */
 } xt_impala_cfg;
+
+#define XT_OPT_ADAM 0
+#define XT_OPT_RMSPROP_CENTERED 1
 
 /* ImpalaCnnOpt.train (impala_cnn_opt.py:251-265) on one chunk of n = n_traj*T frames */
 int xt_net_impala_step(xt_net* net, const xt_impala_cfg* cfg, const void* obs, int32_t n,

@@ -494,6 +494,26 @@ class AdamTF(object):
 # ----------------------------------------------------------------------------
 # whole updates
 # ----------------------------------------------------------------------------
+class RmsPropTF(object):
+    """tf.train.RMSPropOptimizer(lr, decay, momentum=0, epsilon, centered=True) as TF1's
+    apply_centered_rms_prop computes it (slots: rms initialised to ONES, mg and momentum to zeros):
+    ms = d*ms + (1-d)*g^2; mg = d*mg + (1-d)*g; var -= lr*g / sqrt(ms - mg^2 + eps)
+    (the reference's opt_type 'rmsprop', xt/model/impala/impala_cnn_opt.py:205-206)."""
+
+    def __init__(self, params, lr, decay=0.99, eps=0.1):
+        self.lr, self.decay, self.eps = lr, decay, eps
+        self.ms = OrderedDict((k, np.ones_like(v)) for k, v in params.items())
+        self.mg = OrderedDict((k, np.zeros_like(v)) for k, v in params.items())
+
+    def apply(self, params, grads):
+        d = self.decay
+        for k in params:
+            g = grads[k].astype(params[k].dtype)
+            self.ms[k] = d * self.ms[k] + (1.0 - d) * g * g
+            self.mg[k] = d * self.mg[k] + (1.0 - d) * g
+            params[k] -= self.lr * g / np.sqrt(self.ms[k] - self.mg[k] * self.mg[k] + self.eps)
+
+
 class PpoLearnerOracle(object):
     """``PPO.train`` of xt/model/ppo/ppo.py:111-132 with injected permutations."""
 
@@ -548,7 +568,8 @@ class ImpalaLearnerOracle(object):
     def __init__(self, spec, params, cfg, dtype=np.float64):
         self.net = ActorCritic(spec, params, dtype)
         self.cfg = cfg
-        self.opt = AdamTF(self.net.params, cfg["LR"])
+        self.opt = RmsPropTF(self.net.params, cfg["LR"]) if cfg.get("opt_type") == "rmsprop" \
+            else AdamTF(self.net.params, cfg["LR"])
         self.dtype = dtype
 
     def step(self, state, bp_logits, actions, dones, rewards, apply=True):

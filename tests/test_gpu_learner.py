@@ -589,3 +589,37 @@ def test_impala_lr_schedule_linear_cosine_decay_drives_the_adam_step_size():
         t = k + 1
         alpha = want_lr * np.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t)
         assert abs(st[3] - alpha) < 3e-5 * alpha and int(round(st[5])) == t     # fp32 beta powers on the device
+
+
+def test_impala_rmsprop_centered_matches_oracle():
+    """opt_type 'rmsprop' (impala_cnn_opt.py:205-206): tf.train.RMSPropOptimizer(LR, decay=0.99, epsilon=0.1,
+    centered=True) after the global-norm clip, three updates against the float64 oracle; optimizer slots are
+    checkpointed under their own names."""
+    from xingtian_amd.model import model_builder
+    model = model_builder({"model_name": "ImpalaCnnOpt", "state_dim": [42, 42, 4], "input_dtype": "uint8",
+                           "state_mean": 128.0, "state_std": 128.0, "action_dim": 6,
+                           "model_config": {"LR": 0.002, "sample_batch_step": 10, "grad_norm_clip": 40.0,
+                                            "opt_type": "rmsprop", "SEED": 3, "MAX_BATCH": 64}})
+    assert float(model.net.adam_v.min()) == 1.0 and float(model.net.adam_m.abs().max()) == 0.0
+    w0 = model.get_weights()
+    ospec = nets.impala_cnn_opt_spec((42, 42, 4), 6, 128.0, 128.0)
+    shapes = nets.init_params(ospec)
+    orc = nets.ImpalaLearnerOracle(ospec, {k: v.reshape(shapes[k].shape) for k, v in w0.items()},
+                                   dict(LR=0.002, grad_norm_clip=40.0, sample_batch_step=10, BATCH_SIZE=40,
+                                        opt_type="rmsprop"), np.float64)
+    rng = np.random.default_rng(9)
+    n = 40
+    for _ in range(3):
+        state = rng.integers(0, 256, (n, 42, 42, 4)).astype(np.uint8)
+        label = [rng.standard_normal((n, 6)).astype(np.float32), rng.integers(0, 6, n).astype(np.int32),
+                 rng.random(n) < 0.1, rng.choice([-1.0, 0.0, 1.0], n).astype(np.float32)]
+        loss = model.train(state, label)
+        ref = orc.step(state, *label)
+        assert abs(loss - ref["loss"]) < 1e-4 * max(1.0, abs(ref["loss"]))
+    w1 = model.get_weights()
+    for k, r in orc.net.params.items():
+        got, init = w1[k].reshape(r.shape), w0[k].reshape(r.shape)
+        assert rel_err(got - init, r - init) < 2e-4, (k, rel_err(got - init, r - init))
+    st = model.net.get_optimizer_state()
+    assert "explore_agent/conv2d/kernel/RMSProp" in st and "explore_agent/conv2d/kernel/RMSProp_1" in st
+    assert rel_err(st["explore_agent/dense/kernel/RMSProp"], orc.opt.ms["explore_agent/dense/kernel"]) < 1e-5

@@ -33,6 +33,8 @@ int launch_norm_finalize(const float*, int, float, float, float, float, float, i
 int launch_ppo_heads_fused(const PpoHeadArgs&, hipStream_t);
 int launch_adam_clip(float*, const float*, float*, float*, long long, float, float, float, float*, const float*, int,
                      float, float, hipStream_t);
+int launch_rmsprop_clip(float*, const float*, float*, float*, long long, float, float, float, float*, const float*, int,
+                        float, float, hipStream_t);
 int launch_trunk_fwd(const xt_conv_geom*, const xt_conv_geom*, const xt_conv_geom*, const xt_input_xform*, int,
                      const void*, const int32_t*, const float*, const float*, float*, const float*, const float*,
                      float*, const float*, const float*, float*, hipStream_t, bool);
@@ -658,6 +660,10 @@ int xt_net_impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int32
   fin.loss.terms = nullptr; fin.loss.B = 0; fin.loss.ent_coef = fin.loss.critic_coef = fin.loss.inv_b = 0.f;
   fin.loss.out = fin.loss.acc = nullptr;
   if (int rc = xt::grads_finish(n, nfr, &fin, st)) return rc;
+  if (c->opt_type == XT_OPT_RMSPROP_CENTERED)
+    return xt::launch_rmsprop_clip(n->params, n->grads, n->m, n->v, n->P, c->lr, c->rms_decay, c->rms_eps, n->state,
+                                   n->ws + n->off_norm, n->norm_blocks, c->grad_norm_clip, c->grad_scale, st);
+  XT_REQUIRE(c->opt_type == XT_OPT_ADAM, "xt_net_impala_step: unknown opt_type %d", c->opt_type);
   return xt::net_apply(n, c->lr, c->beta1, c->beta2, c->eps, c->grad_norm_clip, c->grad_scale, 3, nullptr, st);
 }
 

@@ -349,6 +349,35 @@ __global__ __launch_bounds__(256) void adam_tf_clip_kernel(float* __restrict__ p
   }
 }
 
+// tf.train.RMSPropOptimizer(centered=True, momentum=0) after tf.clip_by_global_norm, TF1 apply_centered_rms_prop:
+//   ms = decay*ms + (1-decay)*g^2;  mg = decay*mg + (1-decay)*g;  var -= lr * g / sqrt(ms - mg^2 + epsilon)
+// (impala_cnn_opt.py:205-215).  Same structure as adam_tf_clip_kernel: every block derives the clip factor itself.
+__global__ __launch_bounds__(256) void rmsprop_tf_clip_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                              float* __restrict__ mg, float* __restrict__ ms,
+                                                              long long count, float lr, float decay, float eps,
+                                                              float* __restrict__ state, const float* __restrict__ partial,
+                                                              int nblocks, float clip_norm, float grad_scale) {
+  __shared__ double sh[256];
+  __shared__ float s_scale;
+  const double sq = sqnorm_total(partial, nblocks, sh);
+  if (threadIdx.x == 0) {
+    float gnorm, sc;
+    clip_scale(sq, clip_norm, grad_scale, &gnorm, &sc);
+    s_scale = sc;
+    if (blockIdx.x == 0) { state[2] = sc; state[4] = gnorm; }
+  }
+  __syncthreads();
+  const float scale = s_scale, omd = 1.f - decay;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+    const float gg = g[i] * scale;
+    float a = ms[i], b = mg[i];
+    a += (gg * gg - a) * omd;
+    b += (gg - b) * omd;
+    ms[i] = a; mg[i] = b;
+    p[i] -= lr * gg / sqrtf(a - b * b + eps);
+  }
+}
+
 __global__ void adam_state_init_kernel(float* state) {
   if (threadIdx.x < 8) state[threadIdx.x] = (threadIdx.x < 2) ? 1.f : 0.f;
 }
@@ -377,6 +406,18 @@ int launch_grads_finish(GradTable* tab, float* partial, int max_partials, int* n
   hipLaunchKernelGGL(grads_finish_kernel, dim3(blk + (f.enable == 2 ? 1 : 0)), dim3(256), 0, st, *tab, partial, f);
   XT_LAUNCH_CHECK();
   *nblocks_out = blk;
+  return 0;
+}
+
+int launch_rmsprop_clip(float* param, const float* grad, float* mg, float* ms, long long count, float lr, float decay,
+                        float eps, float* state, const float* partial, int nblocks, float clip_norm, float grad_scale,
+                        hipStream_t st) {
+  int nb = (int)((count + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(rmsprop_tf_clip_kernel, dim3(nb), dim3(256), 0, st, param, grad, mg, ms, count, lr, decay, eps,
+                     state, partial, nblocks, clip_norm, grad_scale);
+  XT_LAUNCH_CHECK();
   return 0;
 }
 

@@ -29,7 +29,7 @@ class LayerDesc(Structure):
     _fields_ = [("g", ConvGeom), ("param_off", c_int64), ("trunk", c_int32)]
 
 
-ABI_VERSION = 2          # XT_ABI_VERSION of include/xt_mi355x.h
+ABI_VERSION = 3          # XT_ABI_VERSION of include/xt_mi355x.h
 ACTION_TYPE = {"Categorical": 0, "DiagGaussian": 1}
 
 
@@ -50,9 +50,10 @@ class PpoCfg(Structure):
 class ImpalaCfg(Structure):
     _fields_ = [("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
                 ("grad_norm_clip", c_float), ("gamma", c_float), ("sample_batch_step", c_int32),
-                ("grad_scale", c_float)]
+                ("grad_scale", c_float), ("opt_type", c_int32), ("rms_decay", c_float), ("rms_eps", c_float)]
 
 
+OPT_TYPE = {"adam": 0, "rmsprop": 1}
 _P = c_void_p
 # name -> (restype, argtypes); every symbol include/xt_mi355x.h declares
 SIGNATURES = {

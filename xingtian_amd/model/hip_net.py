@@ -137,6 +137,10 @@ class HipActorCritic(object):
     # "beta2_power"), next to the weights: TFVariables.set_weights ignores names it does not know
     # (tf_utils.py:106-109), so the same .npz still loads in the reference.
     OPT_M, OPT_V, OPT_B1, OPT_B2, OPT_STEP = "/Adam", "/Adam_1", "beta1_power", "beta2_power", "adam_step"
+    opt_kind = "adam"        # "rmsprop": the two slot buffers hold mg / ms; saved as "<var>/RMSProp_1" / "<var>/RMSProp"
+
+    def _slot_suffixes(self):
+        return ("/RMSProp_1", "/RMSProp") if self.opt_kind == "rmsprop" else (self.OPT_M, self.OPT_V)
 
     def get_optimizer_state(self):
         m = self.adam_m.detach().cpu().numpy()
@@ -145,8 +149,9 @@ class HipActorCritic(object):
         out = OrderedDict()
         for name, (off, shape) in self.spec.names.items():
             size = int(np.prod(shape))
-            out[name + self.OPT_M] = m[off:off + size].reshape(shape).copy()
-            out[name + self.OPT_V] = v[off:off + size].reshape(shape).copy()
+            sm, sv = self._slot_suffixes()
+            out[name + sm] = m[off:off + size].reshape(shape).copy()
+            out[name + sv] = v[off:off + size].reshape(shape).copy()
         out[self.OPT_B1] = np.float32(st[0])
         out[self.OPT_B2] = np.float32(st[1])
         out[self.OPT_STEP] = np.int64(round(float(st[5])))
@@ -155,13 +160,13 @@ class HipActorCritic(object):
     def set_optimizer_state(self, state):
         """Restore Adam slots saved by get_optimizer_state; returns False (state untouched) unless EVERY slot
         and both beta powers are present with the right shapes."""
-        need = [n + sfx for n in self.spec.names for sfx in (self.OPT_M, self.OPT_V)] + [self.OPT_B1, self.OPT_B2]
+        need = [n + sfx for n in self.spec.names for sfx in self._slot_suffixes()] + [self.OPT_B1, self.OPT_B2]
         if any(k not in state for k in need):
             return False
         m = np.zeros(self.spec.n_flat, np.float32)
         v = np.zeros(self.spec.n_flat, np.float32)
         for name, (off, shape) in self.spec.names.items():
-            for sfx, dst in ((self.OPT_M, m), (self.OPT_V, v)):
+            for sfx, dst in zip(self._slot_suffixes(), (m, v)):
                 val = np.asarray(state[name + sfx], np.float32)
                 if tuple(val.shape) != tuple(shape):
                     raise KeyError("optimizer slot {} shape {} vs {}".format(name + sfx, val.shape, shape))
@@ -176,7 +181,7 @@ class HipActorCritic(object):
 
     def reset_optimizer(self):
         self.adam_m.zero_()
-        self.adam_v.zero_()
+        self.adam_v.fill_(1.0) if self.opt_kind == "rmsprop" else self.adam_v.zero_()
         L.check(self.lib.xt_adam_state_init(L.ptr(self.adam_state), L.stream_ptr()), "xt_adam_state_init")
 
     # ------------------------------------------------------------------ compute
@@ -245,11 +250,23 @@ class HipActorCritic(object):
                 "xt_net_ppo_train")
         return self.loss_acc
 
-    def make_impala_cfg(self, lr, grad_norm_clip, sample_batch_step, gamma=0.99, grad_scale=1.0):
+    def make_impala_cfg(self, lr, grad_norm_clip, sample_batch_step, gamma=0.99, grad_scale=1.0, opt_type="adam"):
         c = L.ImpalaCfg()
         c.lr, c.beta1, c.beta2, c.eps = lr, 0.9, 0.999, 1e-8
         c.grad_norm_clip, c.gamma, c.sample_batch_step, c.grad_scale = grad_norm_clip, gamma, int(sample_batch_step), grad_scale
+        c.opt_type = L.OPT_TYPE[opt_type]
+        c.rms_decay, c.rms_eps = 0.99, 0.1          # RMSPropOptimizer(LR, decay=0.99, epsilon=0.1, centered=True)
+        if opt_type != self.opt_kind:
+            raise ValueError("call set_optimizer({!r}) before building its config".format(opt_type))
         return c
+
+    def set_optimizer(self, kind):
+        """'adam' (default) or 'rmsprop': the latter reuses the two slot buffers as mean gradient / mean square and
+        initialises them as TF does (rms = ones, mg = zeros)."""
+        if kind not in L.OPT_TYPE:
+            raise KeyError("invalid opt_type: {}".format(kind))
+        self.opt_kind = kind
+        self.reset_optimizer()
 
     def impala_step(self, c, obs, bp_logits, action, done, reward, apply=True, loss_acc=None):
         n = int(obs.shape[0])

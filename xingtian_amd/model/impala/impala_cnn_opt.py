@@ -40,8 +40,8 @@ class ImpalaCnnOpt(XTModel):
         self.action_dim = model_info["action_dim"]
         self.lr_schedule = model_config.get("lr_schedule", None)
         self.opt_type = model_config.get("opt_type", "adam")
-        if self.opt_type != "adam":
-            raise KeyError("invalid opt_type: {} (the HIP learner implements adam)".format(self.opt_type))
+        if self.opt_type not in ("adam", "rmsprop"):
+            raise KeyError("invalid opt_type: {}".format(self.opt_type))
         if self.lr_schedule and len(self.lr_schedule) != 2:
             raise ValueError("lr_schedule invalid: {} (need 2 elements, like [[0, 0.01], [20000, 0.000001]])".format(
                 self.lr_schedule))
@@ -60,7 +60,9 @@ class ImpalaCnnOpt(XTModel):
         self.net = HipActorCritic(spec, max_batch=self.max_batch, seed=self.seed, init="none")
         self.net.init_weights(self.seed, baseline_norm_std=0.01)   # custom_norm_initializer(0.01), :149
         self.actor_var = self.net
-        self._cfg = self.net.make_impala_cfg(self.lr, self.grad_norm_clip, self.sample_batch_steps, GAMMA)
+        self.net.set_optimizer(self.opt_type)
+        self._cfg = self.net.make_impala_cfg(self.lr, self.grad_norm_clip, self.sample_batch_steps, GAMMA,
+                                             opt_type=self.opt_type)
         return True
 
     def train(self, state, label):
@@ -73,7 +75,8 @@ class ImpalaCnnOpt(XTModel):
         act = torch.from_numpy(np.ascontiguousarray(actions, dtype=np.int32).reshape(-1)).to(dev)
         dn = torch.from_numpy(np.ascontiguousarray(np.asarray(dones, dtype=bool).astype(np.uint8)).reshape(-1)).to(dev)
         rw = torch.from_numpy(np.ascontiguousarray(rewards, dtype=np.float32).reshape(-1)).to(dev)
-        if self.lr_schedule:           # the step size is a host-side scalar of the C ABI: evaluate the schedule here
+        if self.lr_schedule and self.opt_type == "adam":   # (the reference's rmsprop branch ignores lr_schedule, :204-206)
+            # the step size is a host-side scalar of the C ABI: evaluate the schedule here
             self._cfg.lr = float(self.current_lr())
         out = self.net.impala_step(self._cfg, obs, bp, act, dn, rw, apply=True)
         self._global_step += 1
