@@ -286,6 +286,11 @@ int xt_net_impala_step(xt_net* net, const xt_impala_cfg* cfg, const void* obs, i
 int xt_net_apply(xt_net* net, float lr, float beta1, float beta2, float eps, float clip_norm,
                  float grad_scale, void* stream);
 
+/* introspection for tests/tools: float offsets inside the bound workspace of layer `layer`'s post-activation
+ * output [B,OH,OW,N] (out4[0]), its d(pre-activation) buffer (out4[1]), its weight-gradient slabs (out4[2]) and
+ * their capacity in slabs (out4[3]) */
+int xt_net_layer_offsets(const xt_net* net, int32_t layer, int64_t* out4);
+
 /* kernel-time probe: average duration (ms) of `reps` back-to-back launches of ONE layer kernel of the bound
  * network on `stream`, measured with HIP events on that stream (bench.py's roofline, tools/layer_bench.py). */
 int xt_net_time_layer(xt_net* net, int32_t layer, int32_t which /*0 fwd 1 wgrad 2 dgrad 3 fused dgrad+wgrad 4 fused conv-trunk fwd (layer..layer+2)*/,

@@ -393,3 +393,34 @@ def test_ppo_loss_gauss_vs_oracle(L, b, a_dim):
     assert rel_err(d_dv.cpu().numpy(), dv[:, 0]) < 1e-5
     assert rel_err(d_rows.cpu().numpy(), parts["dls_rows"]) < 1e-5
     assert rel_err(d_rows.cpu().numpy().astype(np.float64).sum(0), dls[0]) < 1e-5
+
+
+@pytest.mark.parametrize("name,in_hw,cin,cout,k,s", [("ppo_conv2", (20, 20), 32, 32, 4, 2), ("ppo_conv3", (9, 9), 32, 64, 3, 1)])
+@pytest.mark.parametrize("b", [128, 160, 256, 320])
+def test_layer_fwd_and_dgrad_at_benchmark_batches(L, name, in_hw, cin, cout, k, s, b):
+    """The register-direct kernels (xt_direct.hip) are only routed to for large tile counts and pick their
+    wave/reduction split from the batch: cover BASELINE.json's B = 320 and the data-parallel shard sizes of it
+    through the same C-ABI entry points as the small geometry cases above."""
+    case = (name, "conv", in_hw, cin, cout, k, s, "valid", "relu", b, False)
+    lay, x_raw, x, w, bias, rng = _layer_data(case, seed=3)
+    g = geom_of(L, lay)
+    lib = L.load()
+    m = b * lay.out_h * lay.out_w
+    cols = nets.im2col(x.astype(np.float64).reshape(b, lay.in_h, lay.in_w, lay.cin), lay)
+    ref = nets.act_fwd(cols @ w.astype(np.float64).reshape(-1, lay.cout) + bias, lay.act)
+    out = torch.full((m, lay.cout), float("nan"), device="cuda")
+    part = torch.zeros(16 * m * lay.cout, device="cuda")
+    L.check(lib.xt_layer_fwd(ctypes.byref(g), None, b, L.ptr(dev(x_raw)), None, L.ptr(dev(w)),
+                             L.ptr(dev(bias.astype(np.float32))), L.ptr(out), L.ptr(part), 1, None), "fwd")
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all() and rel_err(got, ref) < 3e-6
+    dy = rng.standard_normal((m, lay.cout)).astype(np.float32)
+    dx = nets.col2im(dy.astype(np.float64) @ w.astype(np.float64).reshape(-1, lay.cout).T, lay, b)
+    for act_prev in ("relu", "tanh"):
+        xp = x_raw if act_prev == "relu" else np.tanh(x_raw).astype(np.float32)
+        refd = nets.act_bwd(dx.reshape(xp.shape), xp.astype(np.float64), act_prev)
+        outd = torch.full(xp.shape, float("nan"), device="cuda")
+        L.check(lib.xt_layer_dgrad(ctypes.byref(g), b, L.ptr(dev(dy)), L.ptr(dev(w)), L.ptr(dev(xp)),
+                                   L.ACT[act_prev], L.ptr(outd), None), "dgrad")
+        gotd = outd.cpu().numpy()
+        assert np.isfinite(gotd).all() and rel_err(gotd, refd) < 3e-6, (name, b, act_prev)

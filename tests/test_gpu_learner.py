@@ -66,6 +66,10 @@ def _mk(which, batch):
         spec = netspec.ppo_cnn((84, 84, 4), 4, (256,), "relu", True)
         ospec = nets.ppo_cnn_spec((84, 84, 4), 4, (256,), "relu", True)
         sd, u8 = (84, 84, 4), True
+    elif which == "cnn84_tanh":      # smooth activation: no ReLU-boundary flips between differently ordered fp32 sums
+        spec = netspec.ppo_cnn((84, 84, 4), 4, (256,), "tanh", True)
+        ospec = nets.ppo_cnn_spec((84, 84, 4), 4, (256,), "tanh", True)
+        sd, u8 = (84, 84, 4), True
     elif which == "cnn42_unshared":
         spec = netspec.ppo_cnn((42, 42, 4), 6, (64,), "tanh", False)
         ospec = nets.ppo_cnn_spec((42, 42, 4), 6, (64,), "tanh", False)
@@ -78,8 +82,10 @@ def _mk(which, batch):
     return net, ospec, sd, u8
 
 
-@pytest.mark.parametrize("which,b", [("cnn84", 48), ("cnn42_unshared", 33), ("mlp", 200)])
+@pytest.mark.parametrize("which,b", [("cnn84", 48), ("cnn84", 320), ("cnn42_unshared", 33), ("mlp", 200)])
 def test_ppo_step_loss_and_grads_vs_oracle(which, b):
+    """b = 320 is BASELINE.json's minibatch (breakout_ppo.yaml BATCH_SIZE): the launch configurations of the
+    benchmark (320 first-layer workgroups, two-wave-group forwards, register-direct conv2) against the oracle."""
     net, ospec, sd, u8 = _mk(which, b)
     params = oracle_params_for(net, ospec, seed=7)
     rng = np.random.default_rng(0)
@@ -623,3 +629,39 @@ def test_impala_rmsprop_centered_matches_oracle():
     st = model.net.get_optimizer_state()
     assert "explore_agent/conv2d/kernel/RMSProp" in st and "explore_agent/conv2d/kernel/RMSProp_1" in st
     assert rel_err(st["explore_agent/dense/kernel/RMSProp"], orc.opt.ms["explore_agent/dense/kernel"]) < 1e-5
+
+
+@pytest.mark.parametrize("which", ["cnn84_tanh", "cnn84"])
+def test_full_size_minibatch_gradient_is_the_mean_of_its_shards(which):
+    """Size-independent property at BASELINE.json's full minibatch (B = 320, PpoCnn 84x84x4): with
+    global_batch = 320 the gradient of the whole minibatch equals the SUM of the gradients of any partition into
+    rank shards (what the data-parallel all-reduce relies on) -- here 2 x 160 and 8 x 40 rows, which
+    run DIFFERENT launch configurations (reduction splits, register-direct wave counts) than B = 320.
+    With tanh the match is at fp32 rounding level.  With ReLU a pre-activation within rounding of zero can land on
+    either side of the mask depending on the summation order (seen: one element of 414 720 with z = 3e-8), which
+    moves the two conv gradients below it by ~1e-4 relative: a property of fp32, bounded here, not of a kernel."""
+    b = 320
+    net, ospec, sd, u8 = _mk(which, b)
+    oracle_params_for(net, ospec, 41)
+    rng = np.random.default_rng(42)
+    obs, lab = synth_ppo_rollout(rng, 400, sd, 4)
+    perm = rng.permutation(400)[:b].astype(np.int32)
+    d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).cuda()
+    dobs = net.to_device_obs(obs)
+    labs = (d(lab[0], np.int32), d(lab[1].reshape(-1), np.float32), d(lab[2].reshape(-1), np.float64),
+            d(lab[3].reshape(-1), np.float32), d(lab[4].reshape(-1), np.float64))
+    c = net.make_ppo_cfg(dict(PPO_CFG, BATCH_SIZE=b), global_batch=b)
+    net.ppo_step(c, dobs, d(perm, np.int32), *labs, apply=False)
+    full = {k: v.astype(np.float64) for k, v in net.grads_dict().items()}
+    tol = 1e-5 if which == "cnn84_tanh" else 2e-3        # fp32 sums of up to 8 shard gradients
+    for world in (2, 8):
+        acc = {k: np.zeros_like(v) for k, v in full.items()}
+        for r in range(world):
+            sl = perm[r * (b // world):(r + 1) * (b // world)]
+            net.ppo_step(c, dobs, d(sl, np.int32), *labs, apply=False)
+            for k, v in net.grads_dict().items():
+                acc[k] += v
+        errs = {k: rel_err(acc[k], full[k]) for k in full}
+        assert max(errs.values()) < tol, (world, errs)
+        if which == "cnn84":     # everything above the lowest flipped mask is still at rounding level
+            assert sum(e > 1e-5 for e in errs.values()) <= 4, (world, errs)

@@ -216,6 +216,8 @@ static bool direct_all() {
   return v == 1;
 }
 
+static bool env_off(const char* name) { const char* e = getenv(name); return e && e[0] == '1'; }
+
 static bool direct_envelope(const Geom& g, const xt_input_xform* xf) {
   if (xf && (xf->is_u8 || fabsf(g.xs - 1.f) > 0.f || fabsf(g.xb) > 0.f)) return false;
   return g.C % 16 == 0 && g.K % 32 == 0 && g.N % 32 == 0;
@@ -225,7 +227,7 @@ static bool direct_envelope(const Geom& g, const xt_input_xform* xf) {
 int launch_fwd_direct(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const void* in, const int32_t* idx,
                       const float* w, const float* bias, float* y, float* partial, int ksplit_max, hipStream_t st,
                       int* ksplit_out) {
-  if (!use_direct() || idx) return -1;
+  if (!use_direct() || idx || env_off("XT_NO_DIRECT_FWD")) return -1;
   DFwdArgs a;
   if (make_geom(cg, xf, B, &a.g)) return -1;
   const Geom& g = a.g;
@@ -266,7 +268,7 @@ int launch_fwd_direct(const xt_conv_geom* cg, const xt_input_xform* xf, int B, c
 // Plan for the fused per-layer backward launch (256-thread blocks -> NW = 4, one 32x32 tile per block): only the
 // shapes where the direct kernel measured faster (single-column tiles, long reduction, not too many tiles).
 bool plan_dgrad_direct_fused(const Geom& g, DDgradArgs* a, int* nblocks) {
-  if (!use_direct() || g.N % 32 != 0 || g.C % 32 != 0) return false;
+  if (!use_direct() || env_off("XT_NO_DIRECT_DGRAD") || g.N % 32 != 0 || g.C % 32 != 0) return false;
   if (g.C % 64 == 0) return false;                       // TJ = 2 shapes stay on the LDS-tiled kernel
   const int hc = (g.H + g.S - 1) / g.S, wc = (g.W + g.S - 1) / g.S;
   const int mc = g.B * hc * wc;

@@ -673,6 +673,13 @@ int xt_net_apply(xt_net* n, float lr, float beta1, float beta2, float eps, float
   return xt::net_apply(n, lr, beta1, beta2, eps, clip_norm, grad_scale, 0, nullptr, xt::as_stream(stream));
 }
 
+int xt_net_layer_offsets(const xt_net* n, int32_t layer, int64_t* out4) {
+  XT_REQUIRE(n && out4 && layer >= 0 && layer < (int)n->layers.size(), "xt_net_layer_offsets: bad arguments");
+  const xt::Layer& L = n->layers[layer];
+  out4[0] = L.act_off; out4[1] = L.dact_off; out4[2] = L.slab_off; out4[3] = L.slab_cap;
+  return 0;
+}
+
 int xt_net_time_layer(xt_net* n, int32_t layer, int32_t which, const void* obs, const int32_t* idx, int32_t B,
                       int32_t reps, float* ms_out, void* stream) {
   XT_REQUIRE(n && n->params && n->ws && ms_out, "xt_net_time_layer: bad arguments");

@@ -86,6 +86,7 @@ SIGNATURES = {
     "xt_net_ppo_train": (c_int32, [_P, POINTER(PpoCfg), _P, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, _P]),
     "xt_net_impala_step": (c_int32, [_P, POINTER(ImpalaCfg), _P, c_int32, _P, _P, _P, _P, c_int32, _P, _P, _P]),
     "xt_net_apply": (c_int32, [_P, c_float, c_float, c_float, c_float, c_float, c_float, _P]),
+    "xt_net_layer_offsets": (c_int32, [_P, c_int32, POINTER(c_int64)]),
     "xt_net_time_layer": (c_int32, [_P, c_int32, c_int32, _P, _P, c_int32, c_int32, POINTER(c_float), _P]),
 }
 

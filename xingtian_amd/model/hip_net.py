@@ -280,6 +280,14 @@ class HipActorCritic(object):
         L.check(self.lib.xt_net_apply(self.handle, lr, 0.9, 0.999, 1e-8, clip_norm, grad_scale, L.stream_ptr()),
                 "xt_net_apply")
 
+    def layer_buffers(self, layer, b):
+        """(activation, d-pre-activation) views of the workspace for the first ``b`` samples of ``layer`` (tests)."""
+        off = (ctypes.c_int64 * 4)()
+        L.check(self.lib.xt_net_layer_offsets(self.handle, layer, off), "xt_net_layer_offsets")
+        lay = self.spec.layers[layer]
+        n = b * lay.OH * lay.OW * lay.N
+        return self.workspace[off[0]:off[0] + n], self.workspace[off[1]:off[1] + n]
+
     def time_layer(self, layer, which, obs, idx, b, reps=20):
         ms = ctypes.c_float()
         L.check(self.lib.xt_net_time_layer(self.handle, layer, which, L.ptr(obs), L.ptr(idx), b, reps,
