@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 PHASES = {
     10: ("fwd", ["decode+fetch0/1 issued", "first stash+barrier", "k loop", "epilogue issue", "store drain"]),
     20: ("wgrad", ["rowtab+fetch issued", "first stash+barrier", "m loop", "epilogue issue", "store drain"]),
+    31: ("dgrad (all classes)", ["decode+fetch issued", "first stash+barrier", "k loop", "epilogue (x load + store issue)", "store drain"]),
     30: ("dgrad", ["decode+fetch issued", "first stash+barrier", "k loop", "epilogue (x load + store issue)", "store drain"]),
     40: ("conv1 fwd", ["loads issued", "split+LDS+barrier", "mfma loop", "transpose+store issue", "store drain"]),
     50: ("conv1 wgrad", ["loads issued+LDS", "barrier", "mfma loop", "combine+store issue", "store drain"]),

@@ -671,6 +671,159 @@ __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int b
   XT_TL_DRAIN(5);
 }
 
+// ------------------------------------------------------------------ dgrad, all stride-parity classes per block
+// For a VALID stride-S conv whose kernel and input extents are multiples of S, the S*S parity classes of the
+// same class position (b, ty, tx) gather the SAME dY pixels (ty - jy, tx - jx) and differ only in the weight
+// taps (ky, kx) = (ry + S*jy, rx + S*jx).  One block therefore loads the dY tile of 128 positions ONCE per step and
+// runs S*S = 4 accumulator tiles against 4 weight tiles: a quarter of the A traffic and of the blocks (250
+// instead of 1000 for PpoCnn's 4x4/2 conv2 at B=320 -> the whole fused backward launch is co-resident in one
+// round), four independent MFMA chains per wave, prologue/epilogue amortised over four times the math.
+// Single LDS stage (two barriers per step): a step carries 64 MFMAs per wave, the barrier is noise, and the small
+// footprint (33.5 KB) keeps three blocks per CU next to the weight-gradient blocks.
+constexpr int kD4Classes = 4;
+constexpr int dgrad4_smem_floats() { return 32 * 129 + kD4Classes * 32 * 33 + 128; }
+
+__device__ __forceinline__ void igemm_dgrad4_body(const DgradArgs& p, const int bx, float* smem) {
+  constexpr int BI = 128, SA = BI + 1, SB = 33, NA = 4;
+  float* As = smem;
+  float* Bs = smem + 32 * SA;                       // [class][32 k][SB]
+  int* rowOut = reinterpret_cast<int*>(smem + 32 * SA + kD4Classes * 32 * SB);
+  const Geom& g = p.g;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int HC = g.H / g.S, WC = g.W / g.S;
+  const int Mc = g.B * HC * WC;
+  const int i0 = bx * BI;
+  const int JX = g.KW / g.S;
+  const int nps = g.N >> 5;                         // 32-deep steps per tap
+  const int nsteps = (g.KH / g.S) * JX * nps;
+  const FastDiv dhw = p.d_hw[0], dw = p.d_w[0];
+  XT_TL(0);
+  XT_TL_ROLE(31);
+  if (t < BI) {
+    const int mc = i0 + t;
+    int off = -1;
+    if (mc < Mc) {
+      const int b = (int)fdiv((uint32_t)mc, dhw), rem = mc - b * (HC * WC);
+      const int ty = (int)fdiv((uint32_t)rem, dw), tx = rem - ty * WC;
+      off = ((b * g.H + g.S * ty) * g.W + g.S * tx) * g.C;      // class (0,0) pixel of this position
+    }
+    rowOut[t] = off;
+  }
+  const int c4 = t & 7, r0 = t >> 3;
+  int rowbase[NA], qy[NA], qx[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int mc = i0 + r0 + 32 * i;
+    if (mc < Mc) {
+      const int b = (int)fdiv((uint32_t)mc, dhw), rem = mc - b * (HC * WC);
+      qy[i] = (int)fdiv((uint32_t)rem, dw); qx[i] = rem - qy[i] * WC;
+      rowbase[i] = (b * g.OHOW + qy[i] * g.OW + qx[i]) * g.N;
+    } else {
+      rowbase[i] = 0; qy[i] = -(1 << 28); qx[i] = 0;
+    }
+  }
+  const int cN = r0 * g.N;                          // this thread's weight row (input channel r0 < 32 = C)
+
+  struct Regs { float4 a[NA]; float4 b[kD4Classes]; uint32_t ok; };
+  auto fetch = [&](int s, Regs& R) {
+    const int tap = s / nps, n0 = (s - tap * nps) * 32 + c4 * 4;
+    const int jy = tap / JX, jx = tap - jy * JX;
+    const int tapoff = (jy * g.OW + jx) * g.N - n0;
+    R.ok = 0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const bool ok = ((unsigned)(qy[i] - jy) < (unsigned)g.OH) && ((unsigned)(qx[i] - jx) < (unsigned)g.OW);
+      R.a[i] = load_f4_ok(p.dy, (long long)(rowbase[i] - tapoff), ok);
+      R.ok |= (ok ? 1u : 0u) << i;
+    }
+#pragma unroll
+    for (int cls = 0; cls < kD4Classes; ++cls) {
+      const int ry = cls / g.S, rx = cls - ry * g.S;
+      const int wbase = ((ry + g.S * jy) * g.KW + rx + g.S * jx) * g.C * g.N + n0;
+      R.b[cls] = *reinterpret_cast<const float4*>(p.w + wbase + cN);
+    }
+  };
+  auto stash = [&](const Regs& R) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int r = r0 + 32 * i;
+      const float4 v = sel4((R.ok >> i) & 1u, R.a[i]);
+      As[(c4 * 4 + 0) * SA + r] = v.x;
+      As[(c4 * 4 + 1) * SA + r] = v.y;
+      As[(c4 * 4 + 2) * SA + r] = v.z;
+      As[(c4 * 4 + 3) * SA + r] = v.w;
+    }
+#pragma unroll
+    for (int cls = 0; cls < kD4Classes; ++cls) {
+      float* Bc = Bs + cls * 32 * SB;
+      Bc[(c4 * 4 + 0) * SB + r0] = R.b[cls].x;
+      Bc[(c4 * 4 + 1) * SB + r0] = R.b[cls].y;
+      Bc[(c4 * 4 + 2) * SB + r0] = R.b[cls].z;
+      Bc[(c4 * 4 + 3) * SB + r0] = R.b[cls].w;
+    }
+  };
+  f32x16 acc[kD4Classes];
+#pragma unroll
+  for (int cls = 0; cls < kD4Classes; ++cls)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[cls][r] = 0.f;
+  // one register stage: a step carries 64 MFMAs per wave (4096 cycles), which covers the fetch of the next one
+  Regs R0;
+  fetch(0, R0);
+  XT_TL(1);
+  const int kl = lane >> 5, il = lane & 31;
+  auto mma = [&]() {
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float a = As[(kk * 2 + kl) * SA + wave * 32 + il];
+#pragma unroll
+      for (int cls = 0; cls < kD4Classes; ++cls)
+        acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bs[cls * 32 * SB + (kk * 2 + kl) * SB + il], acc[cls], 0, 0, 0);
+    }
+  };
+  for (int s = 0; s < nsteps; ++s) {
+    stash(R0);
+    __syncthreads();
+    if (s == 0) XT_TL(2);
+    if (s + 1 < nsteps) fetch(s + 1, R0);
+    mma();
+    __syncthreads();
+  }
+  XT_TL(3);
+  // epilogue: class (ry, rx) of position row i writes pixel rowOut[i] + (ry*W + rx)*C; lanes = channels.  The
+  // producer activations of class c+1 are requested before class c is stored (one exposed round trip, not four).
+  const int c = il;
+  const bool cok = c < g.C;
+  auto class_off = [&](int cls) { const int ry = cls / g.S, rx = cls - ry * g.S; return (ry * g.W + rx) * g.C + c; };
+  auto load_x = [&](float (&xv)[16], int cls) {
+    const int coff = class_off(cls);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int off = rowOut[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl];
+      xv[r] = p.x[(off >= 0 && cok) ? (size_t)(off + coff) : (size_t)0];
+    }
+  };
+  auto store_dx = [&](const float (&xv)[16], int cls) {
+    const int coff = class_off(cls);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int off = rowOut[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl];
+      if (off >= 0 && cok) p.dx[(size_t)(off + coff)] = acc[cls][r] * act_grad(xv[r], p.act_prev);
+    }
+  };
+  float xa[16], xb[16];
+  load_x(xa, 0);
+  load_x(xb, 1);
+  store_dx(xa, 0);
+  load_x(xa, 2);
+  store_dx(xb, 1);
+  load_x(xb, 3);
+  store_dx(xa, 2);
+  store_dx(xb, 3);
+  XT_TL(4);
+  XT_TL_DRAIN(5);
+}
+
 template <int BI, int BJ, int WI, int WJ>
 __global__ __launch_bounds__(256) void igemm_dgrad_kernel(const DgradArgs p) {
   __shared__ __attribute__((aligned(16))) float smem[dgrad_smem_floats<BI, BJ>()];
@@ -692,13 +845,18 @@ struct BwdLayerArgs {
   int n_wg, n_dg, n_hw;      // block counts (n_hw may be 0)
 };
 
-template <int WBI, int WBJ, int WWI, int WWJ, bool WPAD, int DBI, int DBJ, int DWI, int DWJ>
-__global__ __launch_bounds__(256) void igemm_bwd_layer_kernel(const BwdLayerArgs p) {
-  constexpr int SM = wgrad_smem_floats<WBI, WBJ, WPAD>() > dgrad_smem_floats<DBI, DBJ>()
-                         ? wgrad_smem_floats<WBI, WBJ, WPAD>() : dgrad_smem_floats<DBI, DBJ>();
+template <int WBI, int WBJ, int WWI, int WWJ, bool WPAD, int DBI, int DBJ, int DWI, int DWJ, bool D4 = false>
+__global__ __launch_bounds__(256, D4 ? 3 : 1) void igemm_bwd_layer_kernel(const BwdLayerArgs p) {
+  constexpr int SM0 = wgrad_smem_floats<WBI, WBJ, WPAD>() > dgrad_smem_floats<DBI, DBJ>()
+                          ? wgrad_smem_floats<WBI, WBJ, WPAD>() : dgrad_smem_floats<DBI, DBJ>();
+  constexpr int SM = (D4 && dgrad4_smem_floats() > SM0) ? dgrad4_smem_floats() : SM0;
   __shared__ __attribute__((aligned(16))) float smem[SM];
   int b = blockIdx.x;
   if (b < p.n_dg) {                       // dgrad first: it is on the critical path of the next layer
+    if constexpr (D4) {                   // stride-2 conv: the four parity classes of a position tile in one block
+      igemm_dgrad4_body(p.dg, b, smem);
+      return;
+    }
     if (p.dg_direct) {                    // single-column tiles with a long reduction: 4 independent waves per tile
       direct_dgrad_body<1, 1, 4>(p.ddg, (uint32_t)b, (uint32_t)p.n_dg, smem);
       return;
@@ -925,6 +1083,15 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
   a.n_dg = a.dg_gx * a.dg_gy * a.dg_gz;
   a.dg_direct = 0;
   {
+    static int no_d4 = -1;
+    if (no_d4 < 0) { const char* e = getenv("XT_NO_DGRAD4"); no_d4 = (e && e[0] == '1') ? 1 : 0; }
+    if (!no_d4 && g.S == 2 && g.KH % 2 == 0 && g.KW % 2 == 0 && g.H % 2 == 0 && g.W % 2 == 0 && g.PT == 0 &&
+        g.PL == 0 && g.C == 32 && g.N % 32 == 0 && (g.OH - 1) * g.S + g.KH <= g.H && (g.OW - 1) * g.S + g.KW <= g.W) {
+      a.dg_direct = 2;
+      a.n_dg = (B * (g.H / 2) * (g.W / 2) + 127) / 128;
+    }
+  }
+  if (a.dg_direct == 0) {
     int nblk = 0;
     if (plan_dgrad_direct_fused(g, &a.ddg, &nblk)) {
       a.ddg.dy = dy; a.ddg.w = w; a.ddg.x = x_in; a.ddg.dx = dx; a.ddg.act_prev = act_prev;
@@ -945,7 +1112,10 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
     else hipLaunchKernelGGL((igemm_bwd_layer_kernel<WBI, WBJ, WWI, WWJ, false, DBI, DBJ, DWI, DWJ>),            \
                             dim3(total), dim3(256), 0, st, a);                                                  \
   } while (0)
-  if (wsmall && dsmall) XT_BWD(128, 32, 4, 1, 128, 32, 4, 1);
+  if (a.dg_direct == 2) {
+    XT_REQUIRE(wsmall && dsmall && !pad, "bwd_layer: the all-classes input gradient needs the small-tile configuration");
+    hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, true>), dim3(total), dim3(256), 0, st, a);
+  } else if (wsmall && dsmall) XT_BWD(128, 32, 4, 1, 128, 32, 4, 1);
   else if (wsmall) XT_BWD(128, 32, 4, 1, 64, 64, 2, 2);
   else if (dsmall) XT_BWD(64, 64, 2, 2, 128, 32, 4, 1);
   else XT_BWD(64, 64, 2, 2, 64, 64, 2, 2);
