@@ -304,12 +304,25 @@ def main():
         # fp32 kernels: v_mfma_f32_32x32x2_f32 dense peak; bf16x3 kernels spend 3 bf16 MFMA flops per algorithmic flop
         peak = FP32_MFMA_PEAK_TFLOPS if kind == "fp32" else 2500.0 / 3.0
         ach = flops / (ms * 1e-3) / 1e12
+        # HBM traffic of the dominant kernel: PMC FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch from the
+        # committed rocprofv3 passes (profiles/r01_pmc_traffic.json holds every layer kernel), matched by kernel name
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        match = {"L0 conv8x8/4 fwd": "conv_u8c4k8_fwd", "L0 conv8x8/4 wgrad": "conv_u8c4k8_wgrad",
+                 "L1 shared_conv_layer_1 fwd": "direct_fwd_kernel", "L2 shared_conv_layer_2 fwd": "igemm_fwd_kernel<64, 64",
+                 "L3 shared_hidden_mlp_0 fwd": "igemm_fwd_kernel<64, 64",
+                 "L1 shared_conv_layer_1 dgrad+wgrad": "igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1",
+                 "L2 shared_conv_layer_2 dgrad+wgrad": "igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1",
+                 "L3 shared_hidden_mlp_0 dgrad+wgrad": "igemm_bwd_layer_kernel<64, 64, 2, 2, false, 64, 64, 2, 2"}
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except (OSError, ValueError):
+                tj = json.load(open(tpath))
+                sub = next((v for k, v in match.items() if dom.startswith(k)), None)
+                for row in tj.get("all_kernels_KB", []):
+                    if sub and sub in row["kernel"]:
+                        traffic = (2.0 * row["FETCH_SIZE_KB"] + row["WRITE_SIZE_KB"]) * 1024.0
+                        break
+            except (OSError, ValueError, KeyError):
                 traffic = None
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                            "frac": ach / peak, "traffic": traffic, "flop_per_launch": flops, "avg_launch_ms": ms,
