@@ -126,10 +126,9 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_fwd_bf16x3_kernel(const C1
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-      for (int ti = 0; ti < kC1MaxTiles; ++ti)
-        if (wave + 4 * ti < ntiles)       // wave-uniform
-          acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ti], bp[pl].v, acc[ti], 0, 0, 0);
-  }
+      for (int ti = 0; ti < kC1MaxTiles; ++ti)      // unconditional: a tile slot beyond ntiles recomputes pixel 0 and is
+        acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ti], bp[pl].v, acc[ti], 0, 0, 0);   // dropped in the epilogue;
+  }                                                  // a (wave-uniform) branch per MFMA breaks their back-to-back issue
 
   // ---- epilogue: input scale on the accumulator, bias, activation.  The 32x32 fp32 tile of a wave is ONE
   // contiguous 4 KB block of the NHWC output (N = 32): transpose it through LDS (the weight-plane region is
