@@ -4,6 +4,7 @@ plumbing is correct under a 2-process gloo group."""
 import os
 import re
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -214,3 +215,59 @@ def test_linear_cosine_decay_known_answers():
     assert lcd(lr0, 5000, ds, beta=beta).dtype == np.float32
     vals = [float(lcd(lr0, s_, ds, beta=beta)) for s_ in range(0, 20001, 500)]
     assert all(a > b for a, b in zip(vals, vals[1:]))                                   # monotone decreasing
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/zeus/common/util/register.py"),
+                    reason="the reference checkout only exists in the authoring container")
+def test_reference_registry_accepts_the_hip_plugins_as_integration_md_says():
+    """INTEGRATION.md section 1 against the reference's REAL registry: zeus/common/util/register.py is loaded
+    unmodified (its two imports that need uninstalled packages are stubbed: `absl.logging` -> stdlib logging and
+    `zeus.set_backend`, which would import TensorFlow, -> no-op) and the drop-in subclasses are
+    registered and resolved by class __name__, which is how alg_para.alg_name / model_name select plugins
+    (register.py:58-69)."""
+    import importlib.util
+    import logging as pylogging
+    import types
+    absl = types.ModuleType("absl")
+    absl.logging = pylogging
+    zeus = types.ModuleType("zeus")
+    zeus.set_backend = lambda **kw: None
+    saved = {k: sys.modules.get(k) for k in ("absl", "absl.logging", "zeus")}
+    sys.modules["absl"], sys.modules["absl.logging"], sys.modules["zeus"] = absl, pylogging, zeus
+    try:
+        spec = importlib.util.spec_from_file_location("_ref_register", "/root/reference/zeus/common/util/register.py")
+        ref = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    from xingtian_amd.algorithm.impala.impala_opt import IMPALAOpt as _IMPALAOpt
+    from xingtian_amd.algorithm.ppo.ppo import PPO as _PPO
+    from xingtian_amd.model.impala.impala_cnn_opt import ImpalaCnnOpt as _ImpalaCnnOpt
+    from xingtian_amd.model.ppo.ppo_cnn import PpoCnn as _PpoCnn
+
+    @ref.Registers.model
+    class PpoCnnHip(_PpoCnn):
+        pass
+
+    @ref.Registers.model
+    class ImpalaCnnOptHip(_ImpalaCnnOpt):
+        pass
+
+    @ref.Registers.algorithm
+    class PPOHip(_PPO):
+        pass
+
+    @ref.Registers.algorithm
+    class IMPALAOptHip(_IMPALAOpt):
+        pass
+
+    assert ref.Registers.model["PpoCnnHip"] is PpoCnnHip and ref.Registers.model["ImpalaCnnOptHip"] is ImpalaCnnOptHip
+    assert ref.Registers.algorithm["PPOHip"] is PPOHip and ref.Registers.algorithm["IMPALAOptHip"] is IMPALAOptHip
+    # same constructor contract as the reference's plugin classes: Algorithm(model_info, alg_config, **kw), Model(model_info)
+    import inspect
+    assert list(inspect.signature(PPOHip.__init__).parameters)[:3] == ["self", "model_info", "alg_config"]
+    assert list(inspect.signature(PpoCnnHip.__init__).parameters)[:2] == ["self", "model_info"]
