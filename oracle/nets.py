@@ -58,7 +58,21 @@ def ppo_cnn_filters(state_dim):
         return [(32, 4, 2), (32, 4, 2), (64, 3, 1)]
     if hw == [15, 15]:
         return [(32, 5, 1), (64, 3, 1), (64, 3, 1)]
-    raise ValueError("no default filters for %r" % (state_dim,))
+    if len(state_dim) != 3 or hw[0] != hw[1] or hw[0] > 64:
+        raise ValueError("no default filters for %r" % (state_dim,))
+    # inferred architecture, model_utils.py:150-176 (sizes <= 64: beyond that the rule's kernel exceeds the image)
+    filters, size, flat, n = [], hw[0], False, 16
+    while not flat:
+        if size <= 3:
+            k, s, flat = 1, 1, True
+        elif size <= 8:
+            k, s, flat = 3, 1, True
+        else:
+            k, s, flat = 5, 2, False
+        filters.append((n, k, s))
+        n *= 2
+        size //= s
+    return filters
 
 
 def impala_filters(state_dim):

@@ -271,3 +271,96 @@ def test_reference_registry_accepts_the_hip_plugins_as_integration_md_says():
     import inspect
     assert list(inspect.signature(PPOHip.__init__).parameters)[:3] == ["self", "model_info", "alg_config"]
     assert list(inspect.signature(PpoCnnHip.__init__).parameters)[:2] == ["self", "model_info"]
+
+
+def _recording_model():
+    from xingtian_amd.register import Registers
+
+    class RecordingModel(object):
+        def __init__(self, model_info):
+            self.model_info = model_info
+            self.calls = []
+
+        def train(self, state, label, **kw):
+            cp = lambda a: [np.array(x, copy=True) for x in a] if isinstance(a, (list, tuple)) else np.array(a, copy=True)
+            self.calls.append((cp(state), cp(label)))
+            return 0.5 + len(self.calls)
+
+    Registers.model(RecordingModel)
+    return RecordingModel
+
+
+def _check_calls_against_golden(calls, z):
+    assert len(calls) == int(z["train_ncalls"])
+    for i, (state, label) in enumerate(calls):
+        assert isinstance(state, list) == bool(z["train_%d_state_is_list" % i])
+        st = state if isinstance(state, list) else [state]
+        assert len(st) == int(z["train_%d_nstate" % i]) and len(label) == int(z["train_%d_nlabel" % i])
+        for j, a in enumerate(st):
+            ref = z["train_%d_state_%d" % (i, j)]
+            assert a.dtype == ref.dtype and a.shape == ref.shape and np.array_equal(a, ref), ("state", i, j)
+        for j, a in enumerate(label):
+            ref = z["train_%d_label_%d" % (i, j)]
+            assert a.dtype == ref.dtype and a.shape == ref.shape and np.array_equal(a, ref), ("label", i, j)
+
+
+def test_algorithm_host_logic_matches_reference_executed_goldens(golden_dir):
+    """What PPO.train / IMPALAOpt.train hand to Model.train -- concatenation order of ragged trajectories, dtypes,
+    sequential BATCH_SIZE chunks (8, 8, 4 of 20 frames), the returned loss (mean of chunk losses), the cleared
+    accumulators -- against fixtures produced by EXECUTING the reference's own classes with a recording model
+    (oracle/gen_golden_alg.py; xt/algorithm/ppo/ppo.py:66-93, xt/algorithm/impala/impala_opt.py:73-147)."""
+    from oracle import gen_golden_alg as G
+    from xingtian_amd.algorithm import alg_builder
+    _recording_model()
+    z = np.load(os.path.join(golden_dir, "alg_ppo.npz"))
+    alg = alg_builder("PPO", *G.PPO_CFG)
+    assert alg.async_flag is False and alg.prepare_data_times == 3
+    for tr in G.ppo_inputs():
+        alg.prepare_data(tr)
+    loss = alg.train()
+    assert float(loss) == float(z["loss"])
+    _check_calls_against_golden(alg.actor.calls, z)
+    assert (alg.obs == [] and alg.adv == []) == bool(z["lists_cleared"])
+    z = np.load(os.path.join(golden_dir, "alg_impala_opt.npz"))
+    alg = alg_builder("IMPALAOpt", *G.IMPALA_CFG)
+    assert alg.async_flag is False and alg.prepare_data_times == 2
+    for m in G.impala_inputs():
+        alg.prepare_data(m)
+    loss = alg.train()
+    assert float(loss) == float(z["loss"])
+    _check_calls_against_golden(alg.actor.calls, z)
+    assert (alg.states == [] and alg.rewards == []) == bool(z["lists_cleared"])
+
+
+def test_architecture_tables_match_reference_executed_goldens(golden_dir):
+    """get_default_filters / get_atari_filter / default hidden sizes + activations and the INFERRED architecture of
+    table-less square observations, against values produced by executing the reference (oracle/gen_golden_arch.py;
+    xt/model/model_utils.py:100-176, xt/model/atari_model.py:4-23) -- for the HIP netspec and for the oracle."""
+    import json
+    from xingtian_amd.model import netspec
+    g = json.load(open(os.path.join(golden_dir, "arch_tables.json")))
+    for key, ref in g["ppo_cnn_filters"].items():
+        h = int(key.split("x")[0])
+        assert [list(f) for f in netspec.ppo_cnn_filters((h, h, 4))] == ref
+        assert [list(f) for f in nets.ppo_cnn_filters((h, h, 4))] == ref
+    for key, ref in g["impala_filters"].items():
+        h = int(key.split("x")[0])
+        assert [list(f) for f in netspec.impala_filters((h, h, 4))] == ref
+        assert [list(f) for f in nets.impala_filters((h, h, 4))] == ref
+    for key, ref in g["ppo_cnn_inferred"].items():
+        h = int(key.split("x")[0])
+        if h <= 64:
+            assert [list(f) for f in netspec.ppo_cnn_filters((h, h, 4))] == ref, key
+            assert [list(f) for f in nets.ppo_cnn_filters((h, h, 4))] == ref, key
+        else:   # the reference's rule gives a kernel larger than the image there: we refuse instead
+            assert ref[0][1] > h
+            with pytest.raises(ValueError):
+                netspec.ppo_cnn_filters((h, h, 4))
+    assert g["ppo_cnn_rank2_raises"]
+    with pytest.raises(ValueError):
+        netspec.ppo_cnn_filters((84, 84))
+    import importlib
+    pc = importlib.import_module("xingtian_amd.model.ppo.ppo_cnn")
+    src = open(pc.__file__).read()
+    assert str(g["cnn_defaults"]["hidden_sizes"]) in src and g["cnn_defaults"]["activation"] == "relu"
+    assert g["mlp_defaults"] == {"hidden_sizes": [64, 64], "activation": "tanh"}

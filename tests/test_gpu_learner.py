@@ -70,6 +70,10 @@ def _mk(which, batch):
         spec = netspec.ppo_cnn((84, 84, 4), 4, (256,), "tanh", True)
         ospec = nets.ppo_cnn_spec((84, 84, 4), 4, (256,), "tanh", True)
         sd, u8 = (84, 84, 4), True
+    elif which == "cnn30_inferred":  # no table: the reference infers 16x5/2, 32x5/2, 64x3/1 (model_utils.py:150-176)
+        spec = netspec.ppo_cnn((30, 30, 4), 3, (64,), "relu", True)
+        ospec = nets.ppo_cnn_spec((30, 30, 4), 3, (64,), "relu", True)
+        sd, u8 = (30, 30, 4), True
     elif which == "cnn42_a18":       # full Atari action set: beyond the fused head kernel's envelope (A <= 8)
         spec = netspec.ppo_cnn((42, 42, 4), 18, (512,), "relu", True)
         ospec = nets.ppo_cnn_spec((42, 42, 4), 18, (512,), "relu", True)
@@ -86,7 +90,7 @@ def _mk(which, batch):
     return net, ospec, sd, u8
 
 
-@pytest.mark.parametrize("which,b", [("cnn84", 48), ("cnn84", 320), ("cnn42_unshared", 33), ("cnn42_a18", 40),
+@pytest.mark.parametrize("which,b", [("cnn84", 48), ("cnn84", 320), ("cnn42_unshared", 33), ("cnn42_a18", 40), ("cnn30_inferred", 50),
                                      ("mlp", 200)])
 def test_ppo_step_loss_and_grads_vs_oracle(which, b):
     """b = 320 is BASELINE.json's minibatch (breakout_ppo.yaml BATCH_SIZE): the launch configurations of the

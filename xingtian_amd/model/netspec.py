@@ -32,7 +32,33 @@ def ppo_cnn_filters(state_dim):
         return [(32, 4, 2), (32, 4, 2), (64, 3, 1)]
     if hw == [15, 15]:
         return [(32, 5, 1), (64, 3, 1), (64, 3, 1)]
-    raise ValueError("Without default architecture for obs shape {}".format(state_dim))
+    if hw[0] != hw[1]:
+        raise ValueError("Without default architecture for non-square obs shape {}".format(state_dim))
+    return infer_filters(hw[0])
+
+
+def _infer_stride_and_kernel(size, flat):
+    """xt/model/model_utils.py:165-176 -> (kernel, stride, flat)."""
+    if flat or size <= 3:
+        return 1, 1, True
+    if size <= 8:
+        return 3, 1, True
+    if size <= 64:
+        return 5, 2, False
+    raise ValueError("Without default architecture for obs shape > 64 (the reference's rule yields a kernel larger "
+                     "than the image there)")
+
+
+def infer_filters(size):
+    """The reference's fallback for square observations without a table (model_utils.py:150-162): 16, 32, 64, ...
+    filters, 5x5/2 while the (floor-divided) size is above 8, then one 3x3/1 (or 1x1/1 at <= 3) layer."""
+    filters, flat, n = [], False, 16
+    while not flat:
+        k, s, flat = _infer_stride_and_kernel(size, flat)
+        filters.append((n, k, s))
+        n *= 2
+        size //= s
+    return filters
 
 
 def impala_filters(state_dim):
