@@ -359,8 +359,9 @@ def test_architecture_tables_match_reference_executed_goldens(golden_dir):
     assert g["ppo_cnn_rank2_raises"]
     with pytest.raises(ValueError):
         netspec.ppo_cnn_filters((84, 84))
-    import importlib
-    pc = importlib.import_module("xingtian_amd.model.ppo.ppo_cnn")
-    src = open(pc.__file__).read()
-    assert str(g["cnn_defaults"]["hidden_sizes"]) in src and g["cnn_defaults"]["activation"] == "relu"
-    assert g["mlp_defaults"] == {"hidden_sizes": [64, 64], "activation": "tanh"}
+    from xingtian_amd.model.ppo.ppo_cnn import PpoCnn
+    from xingtian_amd.model.ppo.ppo_mlp import PpoMlp
+    for cls, want in ((PpoCnn, g["cnn_defaults"]), (PpoMlp, g["mlp_defaults"])):
+        probe = cls.__new__(cls)                       # option parsing only: no GPU, no network
+        probe._read_trunk_options({}, None, *cls.TRUNK_DEFAULTS)
+        assert probe.hidden_sizes == want["hidden_sizes"] and probe.activation == want["activation"]

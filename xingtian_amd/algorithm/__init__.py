@@ -1,16 +1,12 @@
-"""Algorithm module: base class + ``alg_builder`` (xt/algorithm/__init__.py:19-28)."""
+"""Learner-side algorithm plugins.  ``alg_builder(alg_name, model_info, alg_config)`` is the framework's factory
+entry point (xt/algorithm/__init__.py:19-28): the class is chosen by ``alg_para.alg_name``."""
 from xingtian_amd.algorithm.algorithm import Algorithm, AGENT_PREFIX, MODEL_PREFIX  # noqa: F401
 from xingtian_amd.register import Registers
 
 
 def alg_builder(alg_name, model_info, alg_config, **kwargs):
-    """The API to build a algorithm instance (xt/algorithm/__init__.py:19-28)."""
-    return Registers.algorithm[alg_name](model_info, alg_config, **kwargs)
+    return Registers.algorithm.build(alg_name, model_info, alg_config, **kwargs)
 
 
-def _register_defaults():
-    from xingtian_amd.algorithm.ppo import ppo  # noqa: F401
-    from xingtian_amd.algorithm.impala import impala_opt  # noqa: F401
-
-
-_register_defaults()
+from xingtian_amd.algorithm.ppo import ppo  # noqa: E402,F401
+from xingtian_amd.algorithm.impala import impala_opt  # noqa: E402,F401

@@ -1,62 +1,65 @@
-"""Weight-distribution policies with the reference's behaviour (xt/algorithm/alg_utils.py:26-117)."""
-from collections import deque, defaultdict
+"""Which broker / explorers receive the next weights.
+
+Control-plane glue the learner process of the host framework expects on every Algorithm
+(``alg.dist_model_policy.get_dist_info(...)`` / ``.add_processed_ctr_info(...)``, reference behaviour:
+xt/algorithm/alg_utils.py:26-117).  A destination is ``{"broker_id": b, "explorer_id": ids}`` with -1 = everybody.
+"""
+import collections
+
+EVERYBODY = -1
 
 
-def _clip_explorer_id(raw_dist_info, clip_set):
-    if not clip_set:
-        return raw_dist_info
-    elif raw_dist_info["explorer_id"] == -1:
-        raw_dist_info["explorer_id"] = clip_set
-    else:
-        raw_dist_info["explorer_id"] = [_id for _id in raw_dist_info["explorer_id"] if _id in clip_set]
-    return raw_dist_info
+def _destination(broker=EVERYBODY, explorers=EVERYBODY):
+    return {"broker_id": broker, "explorer_id": explorers}
+
+
+def _restrict(dest, allowed):
+    """Narrow a destination to the explorers in ``allowed`` (no-op without a restriction)."""
+    if allowed:
+        current = dest["explorer_id"]
+        dest["explorer_id"] = allowed if current == EVERYBODY else [e for e in current if e in allowed]
+    return dest
 
 
 class DefaultAlgDistPolicy(object):
+    """Broadcast to every explorer of every broker."""
+
     def __init__(self, actor_num, **kwargs):
         self.actor_num = actor_num
-        self.default_policy = {"broker_id": -1, "explorer_id": -1}
-
-    def get_dist_info(self, model_index, explorer_set=None):
-        return _clip_explorer_id(self.default_policy, explorer_set)
+        self.default_policy = _destination()
 
     def add_processed_ctr_info(self, ctr_info):
-        pass
+        """Called by the learner for every consumed rollout message; only the data-driven policies care."""
+
+    def get_dist_info(self, model_index, explorer_set=None):
+        return _restrict(self.default_policy, explorer_set)
 
 
 class DivideDistPolicy(DefaultAlgDistPolicy):
+    """Model k goes to explorer k mod actor_num."""
+
     def get_dist_info(self, model_index, explorer_set=None):
-        if model_index > -1:
-            self.default_policy.update({"explorer_id": model_index % self.actor_num})
-        return _clip_explorer_id(self.default_policy, explorer_set)
-
-
-def _fetch_broker_info(ctr_relation_buf):
-    ctr_list = list()
-    default_policy = {"broker_id": -1, "explorer_id": -1}
-    for _broker, _explorer in ctr_relation_buf.items():
-        default_policy.update({"broker_id": _broker, "explorer_id": list(_explorer)})
-        ctr_list.append(default_policy.copy())
-    return ctr_list
+        if model_index >= 0:
+            self.default_policy["explorer_id"] = model_index % self.actor_num
+        return _restrict(self.default_policy, explorer_set)
 
 
 class FIFODistPolicy(DefaultAlgDistPolicy):
-    """Distribute to whoever submitted explore data."""
+    """Answer exactly the explorers whose data went into the update (IMPALA-style asynchronous actors)."""
 
     def __init__(self, actor_num, prepare_times, **kwargs):
-        super(FIFODistPolicy, self).__init__(actor_num, **kwargs)
-        self._processed_agent = deque()
+        super().__init__(actor_num, **kwargs)
         self.prepare_data_times = prepare_times
+        self._pending = collections.deque()          # (broker_id, explorer_id, ...) of consumed messages
 
     def add_processed_ctr_info(self, ctr_info):
-        self._processed_agent.append(ctr_info)
+        self._pending.append(ctr_info)
 
     def get_dist_info(self, model_index, explorer_set=None):
         if model_index < 0:
             return self.default_policy
-        ctr_relation_buf = defaultdict(set)
-        for _ in range(len(self._processed_agent)):
-            _info = self._processed_agent.popleft()
-            ctr_relation_buf[_info[0]].update((_info[1],))
-        infos = _fetch_broker_info(ctr_relation_buf)
-        return [_clip_explorer_id(i, explorer_set) for i in infos] if explorer_set else infos
+        by_broker = collections.OrderedDict()
+        while self._pending:
+            broker, explorer = self._pending.popleft()[:2]
+            by_broker.setdefault(broker, set()).add(explorer)
+        return [_restrict(_destination(b, list(ids)), explorer_set) for b, ids in by_broker.items()]

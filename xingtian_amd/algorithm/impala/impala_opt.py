@@ -1,10 +1,11 @@
-"""``IMPALAOpt`` (xt/algorithm/impala/impala_opt.py:37-147): concat messages, sequential
-BATCH_SIZE chunks (no shuffle), mean of chunk losses."""
+"""``IMPALAOpt``: the v-trace learner of the reference's IMPALA configurations (xt/algorithm/impala/impala_opt.py:37-147):
+rollout messages are concatenated in arrival order and fed to ``Model.train`` in sequential BATCH_SIZE chunks (no
+shuffling: chunk boundaries must fall on whole trajectories); the reported loss is the mean over the chunks."""
 import os
 
 import numpy as np
 
-from xingtian_amd.algorithm.algorithm import Algorithm
+from xingtian_amd.algorithm.algorithm import Algorithm, RolloutFields
 from xingtian_amd.algorithm.alg_utils import FIFODistPolicy
 from xingtian_amd.algorithm.impala.default_config import BATCH_SIZE
 from xingtian_amd.register import Registers, import_config
@@ -12,68 +13,47 @@ from xingtian_amd.register import Registers, import_config
 
 @Registers.algorithm
 class IMPALAOpt(Algorithm):
-    """Build IMPALA algorithm."""
+    FIELDS = ("cur_state", "logit", "action", "done", "reward")
 
     def __init__(self, model_info, alg_config, **kwargs):
         import_config(globals(), alg_config)
         actor_info = dict(model_info["actor"])
-        actor_info.setdefault("max_batch", BATCH_SIZE)
+        actor_info.setdefault("max_batch", BATCH_SIZE)      # the HIP model sizes its workspace for one chunk
         super().__init__(alg_name="impala", model_info=actor_info, alg_config=alg_config)
-        self.states = list()
-        self.behavior_logits = list()
-        self.actions = list()
-        self.dones = list()
-        self.rewards = list()
         self.async_flag = False
-        self.dist_model_policy = FIFODistPolicy(alg_config["instance_num"],
-                                                prepare_times=self._prepare_times_per_train)
+        self._rollout = RolloutFields(*self.FIELDS)
+        # asynchronous actors: new weights go back to whoever delivered the data of this update
+        self.dist_model_policy = FIFODistPolicy(alg_config["instance_num"], prepare_times=self._prepare_times_per_train)
 
-    def train(self, **kwargs):
-        """Train impala agent."""
-        states = np.concatenate(self.states)
-        behavior_logits = np.concatenate(self.behavior_logits)
-        actions = np.concatenate(self.actions)
-        dones = np.concatenate(self.dones)
-        rewards = np.concatenate(self.rewards)
-        nbatch = len(states)
-        count = (nbatch + BATCH_SIZE - 1) // BATCH_SIZE
-        loss_list = []
-        for start in range(count):
-            start_index = start * BATCH_SIZE
-            env_index = start_index + BATCH_SIZE
-            actor_loss = self.actor.train(
-                states[start_index:env_index],
-                [behavior_logits[start_index:env_index], actions[start_index:env_index],
-                 dones[start_index:env_index], rewards[start_index:env_index]])
-            loss_list.append(actor_loss)
-        self.states.clear()
-        self.behavior_logits.clear()
-        self.actions.clear()
-        self.dones.clear()
-        self.rewards.clear()
-        return np.mean(loss_list)
+    # list-per-field names of the reference (impala_opt.py:43-47)
+    states = property(lambda self: self._rollout.parts["cur_state"])
+    behavior_logits = property(lambda self: self._rollout.parts["logit"])
+    actions = property(lambda self: self._rollout.parts["action"])
+    dones = property(lambda self: self._rollout.parts["done"])
+    rewards = property(lambda self: self._rollout.parts["reward"])
 
-    def save(self, model_path, model_index):
-        actor_name = "actor" + str(model_index).zfill(5)
-        actor_name = self.actor.save_model(os.path.join(model_path, actor_name))
-        return [actor_name.split("/")[-1]]
+    @staticmethod
+    def _data_proc(episode_data):
+        """The agent ships done / reward as python lists: they become bool / float64 arrays here."""
+        return (episode_data["cur_state"], episode_data["logit"], episode_data["action"],
+                np.asarray(episode_data["done"], dtype=bool), np.asarray(episode_data["reward"]))
 
     def prepare_data(self, train_data, **kwargs):
-        state, logit, action, done, reward = self._data_proc(train_data)
-        self.states.append(state)
-        self.behavior_logits.append(logit)
-        self.actions.append(action)
-        self.dones.append(done)
-        self.rewards.append(reward)
+        self._rollout.add(**dict(zip(self.FIELDS, self._data_proc(train_data))))
+
+    def train(self, **kwargs):
+        states, *labels = self._rollout.stacked()
+        losses = []
+        for lo in range(0, len(states), BATCH_SIZE):
+            hi = lo + BATCH_SIZE
+            losses.append(self.actor.train(states[lo:hi], [x[lo:hi] for x in labels]))
+        self._rollout.reset()
+        return np.mean(losses)
 
     def predict(self, state):
         return self.actor.predict(state)
 
-    @staticmethod
-    def _data_proc(episode_data):
-        states = episode_data["cur_state"]
-        behavior_logits = episode_data["logit"]
-        actions = episode_data["action"]
-        dones = np.asarray(episode_data["done"], dtype=bool)
-        rewards = np.asarray(episode_data["reward"])
-        return states, behavior_logits, actions, dones, rewards
+    def save(self, model_path, model_index):
+        """File NAME only, and no underscore in the stem, as the reference's IMPALAOpt (impala_opt.py:108-114)."""
+        saved = self.actor.save_model(os.path.join(model_path, "actor" + str(model_index).zfill(5)))
+        return [saved.split("/")[-1]]

@@ -1,4 +1,4 @@
-"""Static variables of xt/algorithm/ppo/default_config.py."""
-GAMMA = 0.99
-LAM = 0.95
-BATCH_SIZE = 512
+"""Module-level defaults (see xingtian_amd/defaults.py); YAML keys override them via import_config."""
+from xingtian_amd.defaults import publish
+
+publish(globals(), "algorithm/ppo")

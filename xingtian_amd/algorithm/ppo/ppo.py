@@ -9,54 +9,40 @@ comment in the reference).
 """
 import numpy as np
 
-from xingtian_amd.algorithm.algorithm import Algorithm
+from xingtian_amd.algorithm.algorithm import Algorithm, RolloutFields
 from xingtian_amd.algorithm.ppo.default_config import GAMMA, LAM  # noqa: F401
 from xingtian_amd.register import Registers, import_config
 
 
 @Registers.algorithm
 class PPO(Algorithm):
-    """Build PPO algorithm."""
+    """Synchronous PPO learner: collect ``prepare_data_times`` trajectories, one ``Model.train`` per update."""
+
+    FIELDS = ("cur_state", "action", "logp", "adv", "old_value", "target_value")
 
     def __init__(self, model_info, alg_config, **kwargs):
         import_config(globals(), alg_config)
-        super().__init__(alg_name=kwargs.get("name") or "ppo", model_info=model_info["actor"],
-                         alg_config=alg_config)
-        self._init_train_list()
+        super().__init__(alg_name=kwargs.get("name") or "ppo", model_info=model_info["actor"], alg_config=alg_config)
         self.async_flag = False
+        self._rollout = RolloutFields(*self.FIELDS)
+        self._streamed = 0
         if model_info.get("finetune_weight"):
             self.actor.load_model(model_info["finetune_weight"], by_name=True)
 
-    def _init_train_list(self):
-        self.obs = list()
-        self.behavior_action = list()
-        self.old_logp = list()
-        self.adv = list()
-        self.old_v = list()
-        self.target_v = list()
+    # the reference keeps one python list per field under these names (xt/algorithm/ppo/ppo.py:59-65)
+    obs = property(lambda self: self._rollout.parts["cur_state"])
+    behavior_action = property(lambda self: self._rollout.parts["action"])
+    old_logp = property(lambda self: self._rollout.parts["logp"])
+    adv = property(lambda self: self._rollout.parts["adv"])
+    old_v = property(lambda self: self._rollout.parts["old_value"])
+    target_v = property(lambda self: self._rollout.parts["target_value"])
+
+    def _forget_rollout(self):
+        self._rollout.reset()
         self._streamed = 0
 
-    def train(self, **kwargs):
-        """Train PPO Agent."""
-        if self._streamed == len(self.obs) and self._streamed > 0:
-            # every trajectory of this rollout was streamed to HBM as it arrived: no concat, no upload
-            loss = self.actor.train_ingested(**kwargs)
-            self._init_train_list()
-            return loss
-        if self._streamed:
-            self.actor._ingest.reset()
-        obs = np.concatenate(self.obs)
-        behavior_action = np.concatenate(self.behavior_action)
-        old_logp = np.concatenate(self.old_logp)
-        adv = np.concatenate(self.adv)
-        old_v = np.concatenate(self.old_v)
-        target_v = np.concatenate(self.target_v)
-        loss = self.actor.train([obs], [behavior_action, old_logp, adv, old_v, target_v], **kwargs)
-        self._init_train_list()
-        return loss
-
     def prepare_data(self, train_data, **kwargs):
-        if "adv" not in train_data:
+        if "adv" not in train_data:      # raw value/reward/done: GAE on the learner GPU instead of on the actors
             from xingtian_amd import ops
             adv, old_v, tgt = ops.gae(np.asarray(train_data["value"], np.float32).reshape(1, -1),
                                       np.asarray(train_data["reward"], np.float64).reshape(1, -1),
@@ -64,20 +50,27 @@ class PPO(Algorithm):
             train_data = dict(train_data, adv=adv.reshape(-1, 1), old_value=old_v.reshape(-1, 1),
                               target_value=tgt.reshape(-1, 1))
         if getattr(self.actor, "stream_ingest", False) and hasattr(self.actor, "ingest_trajectory"):
-            self.actor.ingest_trajectory(train_data)
+            self.actor.ingest_trajectory(train_data)          # H2D copy starts now
             self._streamed += 1
-        self.obs.append(train_data["cur_state"])
-        self.behavior_action.append(train_data["action"])
-        self.old_logp.append(train_data["logp"])
-        self.adv.append(train_data["adv"])
-        self.old_v.append(train_data["old_value"])
-        self.target_v.append(train_data["target_value"])
+        self._rollout.add(**{k: train_data[k] for k in self.FIELDS})
+
+    def train(self, **kwargs):
+        """No advantage normalisation (a comment in the reference, xt/algorithm/ppo/ppo.py:73)."""
+        streamed_all = self._streamed > 0 and self._streamed == len(self._rollout)
+        if streamed_all:                 # the rollout already sits in HBM: no concat, no upload
+            loss = self.actor.train_ingested(**kwargs)
+        else:
+            if self._streamed:
+                self.actor._ingest.reset()
+            obs, *labels = self._rollout.stacked()
+            loss = self.actor.train([obs], labels, **kwargs)
+        self._forget_rollout()
+        return loss
 
     def predict(self, state):
-        """Overwrite the predict function, owing to the special input."""
-        if not isinstance(state, (list, tuple)):
-            state = state.reshape((1,) + state.shape)
+        """One state (or a list of per-agent states) -> a batch for ``Model.predict``."""
+        if isinstance(state, (list, tuple)):
+            batch = np.vstack([s.reshape((1,) + s.shape) for s in state])
         else:
-            state = list(map(lambda x: x.reshape((1,) + x.shape), state))
-            state = np.vstack(state)
-        return self.actor.predict(state)
+            batch = state.reshape((1,) + state.shape)
+        return self.actor.predict(batch)

@@ -1,18 +1,13 @@
-"""Model module: ``model_builder`` + the HIP-backed model classes (xt/model/__init__.py:43-47)."""
+"""HIP-backed model plugins.  ``model_builder(model_info)`` is the framework's factory entry point
+(xt/model/__init__.py:43-47): the class is chosen by ``model_info["model_name"]``."""
 from xingtian_amd.register import Registers
 from xingtian_amd.model.model import XTModel  # noqa: F401
 
 
 def model_builder(model_info):
-    """Create the interface func for creating model (xt/model/__init__.py:43-47)."""
-    model_name = model_info["model_name"]
-    return Registers.model[model_name](model_info)
+    return Registers.model.build(model_info["model_name"], model_info)
 
 
-def _register_defaults():
-    # the reference auto-imports xt/model/*/*.py (register.py:95-139); we import explicitly
-    from xingtian_amd.model.ppo import ppo_cnn, ppo_mlp  # noqa: F401
-    from xingtian_amd.model.impala import impala_cnn_opt  # noqa: F401
-
-
-_register_defaults()
+# the reference discovers plugins by importing every xt/model/*/*.py (register.py:95-139); here the list is explicit
+from xingtian_amd.model.ppo import ppo_cnn, ppo_mlp  # noqa: E402,F401
+from xingtian_amd.model.impala import impala_cnn_opt  # noqa: E402,F401

@@ -1,6 +1,4 @@
-"""Defaults of xt/model/impala/default_config.py."""
-LR = 0.0003
-ENTROPY_LOSS = 0.01
-HIDDEN_SIZE = 128
-NUM_LAYERS = 1
-GAMMA = 0.99
+"""Module-level defaults (see xingtian_amd/defaults.py); YAML keys override them via import_config."""
+from xingtian_amd.defaults import publish
+
+publish(globals(), "model/impala")

@@ -1,5 +1,10 @@
-"""Model base class with the reference's ``XTModel`` surface (xt/model/model.py:30-136),
-minus the TensorFlow graph/session: the network lives in a ``HipActorCritic``."""
+"""Base class of the HIP learner models.
+
+Same outward contract as the reference's ``XTModel`` (xt/model/model.py:30-136) -- ``Model(model_info)``,
+``create_model`` hook, ``predict`` / ``train``, name-keyed ``get_weights`` / ``set_weights``, ``save_model`` /
+``load_model`` on ``.npz`` files keyed by TF variable name, ``max_to_keep`` rotation, optional ``init_weights`` --
+without a TensorFlow graph or session: the network is a ``HipActorCritic`` held in ``self.net``.
+"""
 import glob
 import os
 from collections import OrderedDict
@@ -7,27 +12,35 @@ from collections import OrderedDict
 import numpy as np
 
 
-class XTModel(object):
-    """Model Base class for model module (xt/model/model.py:30)."""
+def check_keep_model(model_path, keep_num):
+    """Checkpoint rotation: called BEFORE a save, deletes all but the ``keep_num`` newest ``actor*`` files
+    (newest = last in lexicographic order, which the zero-padded index makes chronological)."""
+    files = sorted(glob.glob(os.path.join(model_path, "actor*")))
+    for stale in files[:max(0, len(files) - keep_num)]:
+        os.remove(stale)
 
+
+class XTModel(object):
     def __init__(self, model_info):
+        cfg = model_info.get("model_config") or {}
         self.actor_var = None
-        self._summary = model_info.get("summary", False)
         self.model_format = model_info.get("model_format")
         self.max_to_keep = model_info.get("max_to_keep", 100)
-        # beyond the reference (SURVEY 8(f4)): Adam slots ride along in the .npz so that a restore is a true resume
-        self.save_optimizer = bool((model_info.get("model_config") or {}).get("SAVE_OPTIMIZER", True))
+        self._summary = model_info.get("summary", False)
+        # beyond the reference (SURVEY 8 f4): Adam slots ride along in the .npz so that a restore is a true resume
+        self.save_optimizer = bool(cfg.get("SAVE_OPTIMIZER", True))
+        self.optimizer_restored = False
         self.model = self.create_model(model_info)
-        if "init_weights" in model_info:
-            model_name = model_info["init_weights"]
+        start_from = model_info.get("init_weights")
+        if start_from is not None:
             try:
-                self.load_model(model_name)
-                print("load weight: {} success.".format(model_name))
-            except BaseException:
-                print("load weight: {} failed!".format(model_name))
+                self.load_model(start_from)
+                print("load weight: {} success.".format(start_from))
+            except BaseException:      # the reference also only reports a bad init_weights path
+                print("load weight: {} failed!".format(start_from))
 
+    # ---- hooks of the concrete models
     def create_model(self, model_info):
-        """Abstract method for creating model."""
         raise NotImplementedError
 
     def predict(self, state):
@@ -36,40 +49,31 @@ class XTModel(object):
     def train(self, state, label):
         raise NotImplementedError
 
-    def set_weights(self, weights):
-        """Set weight with memory tensor (name -> ndarray dict)."""
-        self.net.set_weights(weights)
-
+    # ---- weights by TF variable name
     def get_weights(self):
-        """Get the weights (name -> ndarray dict)."""
         return self.net.get_weights()
 
+    def set_weights(self, weights):
+        self.net.set_weights(weights)
+
+    # ---- checkpoints
     def save_model(self, file_name):
-        """np.savez of {tf_var_name: ndarray} (TFVariables.save_weights, tf_utils.py:130-134; rotation
-        xt/model/model.py:104-108).  With SAVE_OPTIMIZER (default) the Adam slots are added under TF1's own slot
-        names; the reference's loader skips names it does not know, so the file stays loadable there."""
+        """``<file_name>.npz`` = {tf_variable_name: ndarray} as ``TFVariables.save_weights`` writes it
+        (xt/model/tf_utils.py:130-134).  With SAVE_OPTIMIZER (default) the optimizer slots are added under TF1's own
+        slot names; the reference's loader skips names it does not know, so the file stays loadable there."""
         if self.max_to_keep > -1:
             check_keep_model(os.path.dirname(file_name), self.max_to_keep)
-        payload = OrderedDict(self.get_weights())
+        arrays = OrderedDict(self.get_weights())
         if self.save_optimizer and hasattr(self.net, "get_optimizer_state"):
-            payload.update(self.net.get_optimizer_state())
-        np.savez(file_name + ".npz", **payload)
-        return file_name + ".npz"
+            arrays.update(self.net.get_optimizer_state())
+        path = file_name + ".npz"
+        np.savez(path, **arrays)
+        return path
 
     def load_model(self, model_name, by_name=False):
-        """Weights by TF variable name (TFVariables.set_weights_with_npz, tf_utils.py:141-144); Adam slots too
-        when the file carries a complete set, else the optimizer is left as it is."""
-        np_file = np.load(model_name)
-        weights = OrderedDict(**np_file)
-        self.set_weights(weights)
+        """Weights by variable name (``set_weights_with_npz``, tf_utils.py:141-144); optimizer slots too when the
+        file carries a complete set (``self.optimizer_restored``), else the optimizer is left as it is."""
+        arrays = OrderedDict(np.load(model_name).items())
+        self.set_weights(arrays)
         if hasattr(self.net, "set_optimizer_state"):
-            self.optimizer_restored = self.net.set_optimizer_state(weights)
-
-
-def check_keep_model(model_path, keep_num):
-    """Check model saved count under path (xt/model/model.py:130-136)."""
-    target_file = glob.glob(os.path.join(model_path, "actor*"))
-    if len(target_file) > keep_num:
-        to_rm_model = sorted(target_file, reverse=True)[keep_num:]
-        for item in to_rm_model:
-            os.remove(item)
+            self.optimizer_restored = self.net.set_optimizer_state(arrays)

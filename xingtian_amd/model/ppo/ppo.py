@@ -57,6 +57,19 @@ class PPO(XTModel):
             (len(self.state_dim) != 1 or int(self.state_dim[0]) % 4 == 0)
         super().__init__(model_info)
 
+    # ---- trunk options shared by the CNN / MLP variants -------------------------------------------------------
+    TRUNK_ACTIVATIONS = ("relu", "tanh")        # what the HIP epilogues implement (the reference's map has more)
+
+    def _read_trunk_options(self, model_config, share_default, hidden_default, act_default):
+        """VF_SHARE_LAYERS / hidden_sizes / activation with the reference's per-variant defaults
+        (get_cnn_default_settings / get_mlp_default_settings, xt/model/model_utils.py:100-117)."""
+        cfg = model_config or {}
+        self.vf_share_layers = cfg.get("VF_SHARE_LAYERS", share_default)
+        self.hidden_sizes = cfg.get("hidden_sizes", list(hidden_default))
+        self.activation = cfg.get("activation", act_default)
+        if self.activation not in self.TRUNK_ACTIVATIONS:
+            raise KeyError("activation {} not implemented.".format(self.activation))
+
     # subclasses provide build_spec(); create_model wires the HIP network
     def build_spec(self):
         raise NotImplementedError

@@ -1,23 +1,16 @@
-"""``PpoCnn`` (xt/model/ppo/ppo_cnn.py:29-50) on the HIP learner."""
+"""``PpoCnn``: PPO on the Atari conv stack (reference class of the same name, xt/model/ppo/ppo_cnn.py:29-50)."""
 from xingtian_amd.model import netspec
 from xingtian_amd.model.ppo.default_config import CNN_SHARE_LAYERS
 from xingtian_amd.model.ppo.ppo import PPO
 from xingtian_amd.register import Registers
 
-ACTIVATIONS = ("relu", "tanh")
-
 
 @Registers.model
 class PpoCnn(PPO):
-    """Build PPO CNN network."""
+    TRUNK_DEFAULTS = ((512,), "relu")          # hidden_sizes, activation (get_cnn_default_settings)
 
     def __init__(self, model_info):
-        model_config = model_info.get("model_config") or {}
-        self.vf_share_layers = model_config.get("VF_SHARE_LAYERS", CNN_SHARE_LAYERS)
-        self.hidden_sizes = model_config.get("hidden_sizes", [512])   # get_cnn_default_settings, model_utils.py:110-114
-        self.activation = model_config.get("activation", "relu")
-        if self.activation not in ACTIVATIONS:
-            raise KeyError("activation {} not implemented.".format(self.activation))
+        self._read_trunk_options(model_info.get("model_config"), CNN_SHARE_LAYERS, *self.TRUNK_DEFAULTS)
         super().__init__(model_info)
 
     def build_spec(self):

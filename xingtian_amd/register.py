@@ -1,57 +1,63 @@
-"""Plugin registry + config import with the reference's semantics.
+"""Name-keyed plugin registries and YAML-over-module-globals configuration.
 
-Mirrors ``zeus/common/util/register.py:39-82`` (``RegisterStub`` / ``Registers``: classes
-are looked up by ``__name__``) and ``zeus/common/util/common.py:32-44``
-(``import_config``: YAML keys override same-named module-level UPPERCASE globals).
+The host framework selects plugins by class ``__name__`` (``alg_para.alg_name``, ``model_para.actor.model_name``)
+through decorator registries and lets YAML sections override UPPERCASE module constants; reference behaviour:
+zeus/common/util/register.py:39-82 and zeus/common/util/common.py:32-44.
 """
 import logging
 
+_log = logging.getLogger(__name__)
 
-class RegisterStub(object):
-    def __init__(self, name):
-        self._dict = dict()
-        self._name = name
 
-    def __getitem__(self, key):
-        try:
-            return self._dict[key]
-        except KeyError as exc:
-            logging.error("module %s not found in registry '%s'", key, self._name)
-            raise exc
+class Registry(object):
+    """``@registry`` registers a class under its name; ``registry[name]`` returns it (KeyError if unknown)."""
 
-    def __contains__(self, key):
-        return key in self._dict
+    def __init__(self, kind):
+        self.kind = kind
+        self._by_name = {}
 
-    def __call__(self, param):
-        if not callable(param):
-            raise Exception("To Registry must be callable, Got: {}.".format(param))
-        register_name = param.__name__
-        if register_name in self._dict:
-            logging.warning("Key:%s is registered, will replace with %s.", register_name, self._name)
-        self._dict[register_name] = param
-        return param
+    def __call__(self, plugin):
+        if not callable(plugin):
+            raise Exception("To Registry must be callable, Got: {}.".format(plugin))
+        if plugin.__name__ in self._by_name:
+            _log.warning("%s plugin %s registered twice: the later one wins", self.kind, plugin.__name__)
+        self._by_name[plugin.__name__] = plugin
+        return plugin
+
+    def __getitem__(self, name):
+        if name not in self._by_name:
+            _log.error("no %s plugin named %s (known: %s)", self.kind, name, sorted(self._by_name))
+        return self._by_name[name]
+
+    def __contains__(self, name):
+        return name in self._by_name
 
     def keys(self):
-        return self._dict.keys()
+        return self._by_name.keys()
+
+    def build(self, name, *args, **kwargs):
+        """Instantiate the plugin called ``name``."""
+        return self[name](*args, **kwargs)
+
+
+RegisterStub = Registry      # the reference's class name
 
 
 class Registers(object):
-    """All module registers (zeus/common/util/register.py:72-82)."""
+    """Namespace of the registries (never instantiated)."""
+
+    agent = Registry("agent")
+    model = Registry("model")
+    algorithm = Registry("algorithm")
+    env = Registry("env")
+    comm = Registry("comm")
 
     def __init__(self):
         raise RuntimeError("Registries prohibit instancing !")
 
-    agent = RegisterStub("agent")
-    model = RegisterStub("model")
-    algorithm = RegisterStub("algorithm")
-    env = RegisterStub("env")
-    comm = RegisterStub("comm")
-
 
 def import_config(global_para, config):
-    """zeus/common/util/common.py:32-44."""
-    if not config:
-        return
-    for key in config.keys():
+    """Override the module-level constants named in ``config`` (keys the module does not define are ignored)."""
+    for key in (config or {}):
         if key in global_para:
             global_para[key] = config[key]
