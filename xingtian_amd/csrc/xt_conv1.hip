@@ -27,11 +27,16 @@ struct C1FwdArgs {
   float xs, xb;        // y = act(acc*xs + bias)   (xb must be 0 for this kernel)
 };
 
-constexpr int kC1MaxTiles = 4;   // 32-pixel tiles per wave -> OH*OW <= 4*4*32 = 512
+constexpr int kC1TileSlots = 16;   // 32-pixel tile slots per workgroup -> OH*OW <= 512
 
-__global__ __launch_bounds__(256, 2) void conv_u8c4k8_fwd_bf16x3_kernel(const C1FwdArgs p) {
+// NW waves per workgroup, 16/NW tile slots per wave.  Two workgroups fit a CU (LDS) for either NW; with NW = 8 a
+// SIMD holds two waves per workgroup, so the LDS reads and byte->bf16 conversions of one wave are issued under the
+// MFMAs of the other (a lone wave issues in order: its step took 1065 cycles for 384 cycles of MFMA).
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void conv_u8c4k8_fwd_bf16x3_kernel(const C1FwdArgs p) {
+  constexpr int NT = 64 * NW, kC1MaxTiles = kC1TileSlots / NW, WQ = 1024 / NT;
   extern __shared__ __attribute__((aligned(16))) uint8_t limg[];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int b = blockIdx.x;
   const int HWC = p.H * p.W * 4, Wrow = p.W * 4, OHOW = p.OH * p.OW;
   const int nsteps = 2 * p.KH;              // 16 reduction elements per step = half a kernel row
@@ -40,11 +45,11 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_fwd_bf16x3_kernel(const C1
   XT_TL_ROLE(40);
   // ---- issue every global load of the block up front: this thread's share of the weights (fp32, split below)
   // and of the frame stack (minibatch gather fused) -> one memory latency for the whole prologue
-  float wv[4][8];
+  float wv[WQ][8];
   const int nslots = nsteps * 64;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int slot = t + 256 * q;
+  for (int q = 0; q < WQ; ++q) {
+    const int slot = t + NT * q;
     const int sc = slot < nslots ? slot : 0;
     const float* wl = p.w + (size_t)((sc >> 6) * 16 + 8 * ((sc & 63) >> 5)) * 32 + (sc & 31);
 #pragma unroll
@@ -53,13 +58,13 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_fwd_bf16x3_kernel(const C1
   {
     const size_t s = p.idx ? (size_t)p.idx[b] : (size_t)b;
     const uint4* src = reinterpret_cast<const uint4*>(p.in + s * (size_t)HWC);
-    stage_image(src, reinterpret_cast<uint4*>(limg), HWC >> 4, t);
+    stage_image<NT>(src, reinterpret_cast<uint4*>(limg), HWC >> 4, t);
   }
   XT_TL(1);
   // exact 3-way bf16 split of the weights, written once per block in operand order
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int slot = t + 256 * q;
+  for (int q = 0; q < WQ; ++q) {
+    const int slot = t + NT * q;
     if (slot < nslots) {
       BF8 b1, b2, b3;
 #pragma unroll
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_fwd_bf16x3_kernel(const C1
   int poff[kC1MaxTiles];
 #pragma unroll
   for (int ti = 0; ti < kC1MaxTiles; ++ti) {
-    const int pix = (wave + 4 * ti) * 32 + il;
+    const int pix = (wave + NW * ti) * 32 + il;
     const int pp = pix < OHOW ? pix : 0;
     const int oy = pp / p.OW, ox = pp - oy * p.OW;
     poff[ti] = (p.S * oy * p.W + p.S * ox) * 4 + 8 * h;
@@ -139,14 +144,14 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_fwd_bf16x3_kernel(const C1
   float* tbuf = reinterpret_cast<float*>(limg + HWC) + wave * (32 * 36);      // [32 rows][36] padded, per wave
 #pragma unroll
   for (int ti = 0; ti < kC1MaxTiles; ++ti) {
-    if (wave + 4 * ti < ntiles) {
+    if (wave + NW * ti < ntiles) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
         tbuf[row * 36 + il] = act_apply(fmaf(acc[ti][r], p.xs, bias), p.act);
       }
       // wave-private region: program order of one wave suffices between its own ds_write and ds_read
-      const int pix0 = (wave + 4 * ti) * 32;
+      const int pix0 = (wave + NW * ti) * 32;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row = q * 8 + (lane >> 3), c4 = (lane & 7) * 4;
@@ -165,6 +170,12 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_fwd_bf16x3_kernel(const C1
   XT_TL_DRAIN(5);
 }
 
+static int c1_waves() {      // XT_C1_WAVES=4: the four-wave forms (A/B switch)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("XT_C1_WAVES"); v = (e && e[0] == '4') ? 4 : 8; }
+  return v;
+}
+
 // returns 0 launched, 1 error, -1 geometry not handled by this kernel
 int launch_conv1_fwd_bf16x3(const xt_conv_geom* g, const xt_input_xform* xf, int B, const void* in,
                             const int32_t* idx, const float* w, const float* bias, float* y, hipStream_t st) {
@@ -172,15 +183,19 @@ int launch_conv1_fwd_bf16x3(const xt_conv_geom* g, const xt_input_xform* xf, int
   if ((g->OH - 1) * g->S + g->KH > g->H || (g->OW - 1) * g->S + g->KW > g->W) return -1;
   const int HWC = g->H * g->W * 4;
   if (HWC % 16 != 0 || HWC > 64 * 1024 || (g->W * 4) % 8 != 0 || (g->S * 4) % 8 != 0) return -1;
-  if (g->OH * g->OW > 32 * 4 * kC1MaxTiles) return -1;
+  if (g->OH * g->OW > 32 * kC1TileSlots) return -1;
   if (fabsf(xf->mean) >= 1e-4f || g->KH > 8) return -1;     // the mean term would need colsum(W); 4 weight slots/thread
   C1FwdArgs a;
   a.in = static_cast<const uint8_t*>(in); a.idx = idx; a.w = w; a.bias = bias; a.y = y;
   a.B = B; a.H = g->H; a.W = g->W; a.OH = g->OH; a.OW = g->OW; a.S = g->S; a.KH = g->KH; a.act = g->act;
   const float mean = fabsf(xf->mean) >= 1e-4f ? xf->mean : 0.f;
   a.xs = 1.f / xf->std; a.xb = -mean * a.xs;
-  const size_t lds = (size_t)HWC + (size_t)2 * g->KH * 3 * 64 * 16;
-  hipLaunchKernelGGL(conv_u8c4k8_fwd_bf16x3_kernel, dim3(B), dim3(256), lds, st, a);
+  const int nw = c1_waves();
+  size_t lds = (size_t)2 * g->KH * 3 * 64 * 16;                    // weight planes, reused by the output transpose
+  if (lds < (size_t)nw * 32 * 36 * 4) lds = (size_t)nw * 32 * 36 * 4;
+  lds += (size_t)HWC;
+  if (nw == 8) hipLaunchKernelGGL(conv_u8c4k8_fwd_bf16x3_kernel<8>, dim3(B), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL(conv_u8c4k8_fwd_bf16x3_kernel<4>, dim3(B), dim3(256), lds, st, a);
   XT_LAUNCH_CHECK();
   return 0;
 }
@@ -202,9 +217,13 @@ struct C1WgArgs {
   float xs, xb;
 };
 
-__global__ __launch_bounds__(256, 2) void conv_u8c4k8_wgrad_bf16x3_kernel(const C1WgArgs p) {
+// NKQ = kernel-row groups per pixel parity: 2 pixel parities x NKQ groups = 2*NKQ waves, 8/NKQ kernel rows (k
+// tiles) per wave.  NKQ = 4 puts two waves of a workgroup on every SIMD (see the forward kernel).
+template <int NKQ>
+__global__ __launch_bounds__(128 * NKQ, NKQ) void conv_u8c4k8_wgrad_bf16x3_kernel(const C1WgArgs p) {
+  constexpr int NT = 128 * NKQ, RQ = 8 / NKQ, DQ = 4096 / NT;
   extern __shared__ __attribute__((aligned(16))) uint8_t lsm[];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int b = blockIdx.x;
   const int HWC = p.H * p.W * 4, Wrow = p.W * 4, OHOW = p.OH * p.OW;
   const int nsteps = (OHOW + 15) >> 4;
@@ -219,31 +238,31 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_wgrad_bf16x3_kernel(const 
   {
     const float4* dsrc = reinterpret_cast<const float4*>(p.dy + (size_t)b * OHOW * 32);
     const int n4 = OHOW * 8, n4pad = nsteps * 16 * 8;
-    float4 dv[16];
+    float4 dv[DQ];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int i = t + 256 * q;
+    for (int q = 0; q < DQ; ++q) {
+      const int i = t + NT * q;
       dv[q] = dsrc[i < n4 ? i : 0];
     }
     const size_t s = p.idx ? (size_t)p.idx[b] : (size_t)b;
     const uint4* src = reinterpret_cast<const uint4*>(p.in + s * (size_t)HWC);
-    stage_image(src, reinterpret_cast<uint4*>(limg), HWC >> 4, t);
+    stage_image<NT>(src, reinterpret_cast<uint4*>(limg), HWC >> 4, t);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int i = t + 256 * q;
+    for (int q = 0; q < DQ; ++q) {
+      const int i = t + NT * q;
       if (i < n4pad) reinterpret_cast<float4*>(dys)[i] = i < n4 ? dv[q] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int i = t; i < nsteps * 16; i += 256) {
+    for (int i = t; i < nsteps * 16; i += NT) {
       const int pp = i < OHOW ? i : 0;
       const int oy = pp / p.OW, ox = pp - oy * p.OW;
       pixoff[i] = (p.S * oy * p.W + p.S * ox) * 4;
     }
   }
   const int il = lane & 31, h = lane >> 5;
-  const int pg = wave >> 1, kh = wave & 1;
-  f32x16 acc[4];
+  const int pg = wave / NKQ, kq = wave - pg * NKQ;
+  f32x16 acc[RQ];
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < RQ; ++q)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
   float bsum = 0.f;
@@ -251,11 +270,11 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_wgrad_bf16x3_kernel(const 
   __syncthreads();
   XT_TL(2);
 
-  // software-pipelined: LDS reads of this wave's NEXT step (8 dY values, 4 x 8 pixel bytes) are issued before
+  // software-pipelined: LDS reads of this wave's NEXT step (8 dY values, RQ x 8 pixel bytes) are issued before
   // the MFMAs of the current one; the pixel-offset table is read one step further ahead (the byte addresses
   // depend on it).  MFMAs are issued plane-major (consecutive instructions hit different accumulators).
   float dyr[8];
-  uint32_t xr[4][8];
+  uint32_t xr[RQ][8];
   int po[8];
   auto read_po = [&](int s) {
 #pragma unroll
@@ -265,8 +284,8 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_wgrad_bf16x3_kernel(const 
 #pragma unroll
     for (int e = 0; e < 8; ++e) dyr[e] = dys[(s * 16 + 8 * h + e) * 32 + il];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int kb = (kh * 4 + q) * Wrow + il;        // kernel row ky = 4kh+q, byte kx*4+c = il
+    for (int q = 0; q < RQ; ++q) {
+      const int kb = (kq * RQ + q) * Wrow + il;       // kernel row ky = RQ*kq+q, byte kx*4+c = il
 #pragma unroll
       for (int e = 0; e < 8; ++e) xr[q][e] = limg[po[e] + kb];
     }
@@ -275,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_wgrad_bf16x3_kernel(const 
   if (pg + 2 < nsteps) read_po(pg + 2);
   for (int s = pg; s < nsteps; s += 2) {
     // exact 3-way bf16 split of the 8 dY values of this lane (pixels 16s+8h+e, column il)
-    BF8 bp[3], av[4];
+    BF8 bp[3], av[RQ];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float w0 = dyr[2 * q], w1 = dyr[2 * q + 1];
@@ -287,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_wgrad_bf16x3_kernel(const 
       bp[2].u[q] = pack_hi16(q0, q1);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < RQ; ++q)
 #pragma unroll
       for (int e = 0; e < 4; ++e) av[q].u[e] = pack_hi16((float)xr[q][2 * e], (float)xr[q][2 * e + 1]);
     if (s + 2 < nsteps) {
@@ -297,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_wgrad_bf16x3_kernel(const 
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < RQ; ++q)
         acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q].v, bp[pl].v, acc[q], 0, 0, 0);
   }
 
@@ -305,12 +324,12 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_wgrad_bf16x3_kernel(const 
   bsum += __shfl_xor(bsum, 32, 64);
   XT_TL(3);
   __syncthreads();                         // dys / pixoff are dead: their LDS is reused for the reduction
-  if (kh == 0 && h == 0) bred[pg * 32 + il] = bsum;
+  if (kq == 0 && h == 0) bred[pg * 32 + il] = bsum;
   if (pg == 1) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < RQ; ++q)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[((kh * 4 + q) * 16 + r) * 64 + lane] = acc[q][r];
+      for (int r = 0; r < 16; ++r) red[((kq * RQ + q) * 16 + r) * 64 + lane] = acc[q][r];
   }
   __syncthreads();
   if (pg == 0) {
@@ -318,14 +337,14 @@ __global__ __launch_bounds__(256, 2) void conv_u8c4k8_wgrad_bf16x3_kernel(const 
     float* slab = p.out + (size_t)b * ((size_t)(p.KH * 32 + 1) * 32);
     const float corr = p.xb * db;            // d/dW of the (x*xs + xb) transform: xb * sum_p dY
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < RQ; ++q)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = acc[q][r] + red[((kh * 4 + q) * 16 + r) * 64 + lane];
-        const int k = (kh * 4 + q) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = acc[q][r] + red[((kq * RQ + q) * 16 + r) * 64 + lane];
+        const int k = (kq * RQ + q) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         slab[(size_t)k * 32 + il] = fmaf(v, p.xs, corr);
       }
-    if (kh == 0 && h == 0) slab[(size_t)p.KH * 32 * 32 + il] = db;
+    if (kq == 0 && h == 0) slab[(size_t)p.KH * 32 * 32 + il] = db;
   }
   XT_TL(4);
   XT_TL_DRAIN(5);
@@ -353,7 +372,8 @@ int launch_conv1_wgrad_bf16x3(const xt_conv_geom* g, const xt_input_xform* xf, i
   if ((size_t)nsteps * 16 * 32 * 4 < (size_t)2 * 4 * 16 * 64 * 4) return -1;   // `red` aliases the dY region
   if ((size_t)nsteps * 16 * 4 < 64 * 4) return -1;                              // `bred` aliases pixoff
   if (lds > 81920) return -1;                                                    // two workgroups per CU
-  hipLaunchKernelGGL(conv_u8c4k8_wgrad_bf16x3_kernel, dim3(B), dim3(256), lds, st, a);
+  if (c1_waves() == 8) hipLaunchKernelGGL(conv_u8c4k8_wgrad_bf16x3_kernel<4>, dim3(B), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL(conv_u8c4k8_wgrad_bf16x3_kernel<2>, dim3(B), dim3(256), lds, st, a);
   XT_LAUNCH_CHECK();
   if (msplit_out) *msplit_out = B;
   return 0;

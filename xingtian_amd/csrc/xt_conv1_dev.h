@@ -30,17 +30,19 @@ __device__ __forceinline__ bf16x8 bytes_to_bf16x8(uint32_t d0, uint32_t d1) {
 
 // global -> LDS copy of one frame stack: 8 x 16-byte loads per thread are issued back to back (one memory
 // latency for the whole image instead of one per loop iteration), then written to LDS
+template <int NT = 256>
 __device__ __forceinline__ void stage_image(const uint4* __restrict__ src, uint4* dst, int n16, int t) {
-  for (int base = 0; base < n16; base += 256 * 8) {
-    uint4 v[8];
+  constexpr int U = 2048 / NT;           // loads in flight per thread: 2048 x 16 B = 32 KB per pass
+  for (int base = 0; base < n16; base += NT * U) {
+    uint4 v[U];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int i = base + t + 256 * q;
+    for (int q = 0; q < U; ++q) {
+      const int i = base + t + NT * q;
       v[q] = src[i < n16 ? i : 0];
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int i = base + t + 256 * q;
+    for (int q = 0; q < U; ++q) {
+      const int i = base + t + NT * q;
       if (i < n16) dst[i] = v[q];
     }
   }
