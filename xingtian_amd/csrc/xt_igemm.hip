@@ -790,28 +790,39 @@ __device__ __forceinline__ void igemm_dgrad4_body(const DgradArgs& p, const int 
     __syncthreads();
   }
   XT_TL(3);
-  // epilogue: class (ry, rx) of position row i writes pixel rowOut[i] + (ry*W + rx)*C; lanes = channels.  The
-  // producer activations of class c+1 are requested before class c is stored (one exposed round trip, not four).
-  const int c = il;
-  const bool cok = c < g.C;
-  auto class_off = [&](int cls) { const int ry = cls / g.S, rx = cls - ry * g.S; return (ry * g.W + rx) * g.C + c; };
-  auto load_x = [&](float (&xv)[16], int cls) {
+  // epilogue: class (ry, rx) of position row i writes pixel rowOut[i] + (ry*W + rx)*C.  A pixel is one contiguous
+  // 128-byte row of C = 32 channels, but the accumulator layout has lanes = channels (dword accesses, 2 rows per
+  // instruction: 64 loads of the producer activation + 64 stores per lane, 6.5 us of the block's 25).  Each class
+  // tile is therefore transposed through LDS (As/Bs are dead after the loop's last barrier; wave-private regions,
+  // program order of one wave suffices) so that every lane moves 16 bytes: 4 loads + 4 stores per class.  The
+  // producer activations of class c+1 are requested before class c is stored.
+  float* tb = smem + wave * (32 * 36);
+  const int tr = lane >> 3, tc4 = (lane & 7) * 4;
+  int roff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) roff[q] = rowOut[wave * 32 + q * 8 + tr];
+  auto class_off = [&](int cls) { const int ry = cls / g.S, rx = cls - ry * g.S; return (ry * g.W + rx) * g.C + tc4; };
+  auto load_x = [&](float4 (&xv)[4], int cls) {
     const int coff = class_off(cls);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int off = rowOut[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl];
-      xv[r] = p.x[(off >= 0 && cok) ? (size_t)(off + coff) : (size_t)0];
-    }
+    for (int q = 0; q < 4; ++q)
+      xv[q] = *reinterpret_cast<const float4*>(p.x + (roff[q] >= 0 ? (size_t)(roff[q] + coff) : (size_t)0));
   };
-  auto store_dx = [&](const float (&xv)[16], int cls) {
+  auto store_dx = [&](const float4 (&xv)[4], int cls) {
     const int coff = class_off(cls);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int off = rowOut[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl];
-      if (off >= 0 && cok) p.dx[(size_t)(off + coff)] = acc[cls][r] * act_grad(xv[r], p.act_prev);
+    for (int r = 0; r < 16; ++r) tb[((r & 3) + 8 * (r >> 2) + 4 * kl) * 36 + il] = acc[cls][r];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 v = *reinterpret_cast<const float4*>(&tb[(q * 8 + tr) * 36 + tc4]);
+      v.x *= act_grad(xv[q].x, p.act_prev);
+      v.y *= act_grad(xv[q].y, p.act_prev);
+      v.z *= act_grad(xv[q].z, p.act_prev);
+      v.w *= act_grad(xv[q].w, p.act_prev);
+      if (roff[q] >= 0) *reinterpret_cast<float4*>(p.dx + (size_t)(roff[q] + coff)) = v;
     }
   };
-  float xa[16], xb[16];
+  float4 xa[4], xb[4];
   load_x(xa, 0);
   load_x(xb, 1);
   store_dx(xa, 0);
