@@ -47,6 +47,27 @@ __device__ __forceinline__ void combine_and_emit(float* red, const float (&flat)
   }
 }
 
+// The same combine, emitted as 16-byte row pieces: red[q][r][kl*32 + il] holds element (row(r, kl), column il) of
+// wave q's partial tile, so four consecutive columns of one row are contiguous in LDS.  Slot e of the R*16 float4
+// slots: columns 4*(e & 7).., kl = (e >> 3) & 1, r = e >> 4 -> eight consecutive lanes cover one 128-byte row of a
+// 32-column tile (the dword form stored two rows per instruction).  Summation order q = 0..NW-1 as above.
+// emit4(r, kl, c4, v): r = tile * 16 + reg.
+template <int R, typename F>
+__device__ __forceinline__ void combine_and_emit4(float* red, const float (&flat)[R], int w, int NW, int lane, F emit4) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) red[(w * R + r) * 64 + lane] = flat[r];
+  __syncthreads();
+  for (int e = w * 64 + lane; e < R * 16; e += NW * 64) {
+    const int c4 = (e & 7) * 4, kl = (e >> 3) & 1, r = e >> 4;
+    float4 v = *reinterpret_cast<const float4*>(&red[r * 64 + kl * 32 + c4]);
+    for (int q = 1; q < NW; ++q) {
+      const float4 u = *reinterpret_cast<const float4*>(&red[(q * R + r) * 64 + kl * 32 + c4]);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    emit4(r, kl, c4, v);
+  }
+}
+
 // ------------------------------------------------------------------ forward
 struct DFwdArgs {
   Geom g;
@@ -166,14 +187,18 @@ __global__ __launch_bounds__(MAXT) void direct_fwd_kernel(const DFwdArgs p) {
       for (int r = 0; r < 16; ++r) flat[(ti * TJ + tj) * 16 + r] = acc[ti][tj][r];
   const bool final_out = (p.ksplit == 1);
   float* out = final_out ? p.y : p.y + (size_t)z * (size_t)g.M * g.N;
-  combine_and_emit<R>(red, flat, w, NW, lane, [&](int r, float v) {
+  combine_and_emit4<R>(red, flat, w, NW, lane, [&](int r, int rkl, int c4, float4 v) {
     const int t = r >> 4, rr = r & 15;
     const int ti = t / TJ, tj = t - ti * TJ;
-    const int m = m0 + 32 * ti + (rr & 3) + 8 * (rr >> 2) + 4 * kl;
-    const int n = n0 + 32 * tj + il;
+    const int m = m0 + 32 * ti + (rr & 3) + 8 * (rr >> 2) + 4 * rkl;
+    const int n = n0 + 32 * tj + c4;
     if (m < g.M) {
-      if (final_out) v = act_apply(v + p.bias[n], g.act);
-      out[(size_t)m * g.N + n] = v;
+      if (final_out) {
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+        v.x = act_apply(v.x + bv.x, g.act); v.y = act_apply(v.y + bv.y, g.act);
+        v.z = act_apply(v.z + bv.z, g.act); v.w = act_apply(v.w + bv.w, g.act);
+      }
+      *reinterpret_cast<float4*>(out + (size_t)m * g.N + n) = v;
     }
   });
   XT_TL(4);
@@ -308,7 +333,7 @@ int launch_dgrad_direct(const xt_conv_geom* cg, int B, const float* dy, const fl
   nw = min(nw, nsteps / 2);
   nw = nw >= 4 ? 4 : nw >= 2 ? 2 : 1;
   const dim3 grid(tiles), blk(64 * nw);
-  const size_t sm = nw > 1 ? (size_t)nw * TI * TJ * 16 * 64 * sizeof(float) : 0;
+  const size_t sm = (size_t)nw * TI * TJ * 16 * 64 * sizeof(float);
 #define XT_DD(TIV, TJV)                                                                                     \
   do {                                                                                                      \
     if (nw == 4) hipLaunchKernelGGL((direct_dgrad_kernel<TIV, TJV, 4>), grid, blk, sm, st, a);              \

@@ -32,24 +32,33 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, uint32_t vo
 }
 
 // ------------------------------------------------------------------ input gradient
-// Static-NW combine: wave w owns accumulator registers r = w + j*NW (j < R/NW) of the block's tile.
+// Static-NW combine of the per-wave partial tiles, emitted as 16-byte row pieces.  red[q][r][kl*32 + il] holds
+// element (row(r, kl), column il) of wave q's partial tile (r = tile*16 + reg), so four consecutive columns of a
+// row are contiguous in LDS.  Float4 slot e (of R*16): columns 4*(e & 7).., kl = (e >> 3) & 1, r = e >> 4; lane
+// `lane` of wave w owns slots e = w*64 + lane + j*NW*64 -> eight consecutive lanes cover one 128-byte row of a
+// 32-column tile.  Fixed summation order q = 0..NW-1.
+template <int R, int NW>
+struct Slot4 { int c4, kl, r; };
+template <int R, int NW>
+__device__ __forceinline__ Slot4<R, NW> slot4(int w, int lane, int j) {
+  const int e = w * 64 + lane + j * NW * 64;
+  return Slot4<R, NW>{(e & 7) * 4, (e >> 3) & 1, e >> 4};
+}
 template <int R, int NW, typename F>
-__device__ __forceinline__ void combine_emit_static(float* red, const float (&flat)[R], int w, int lane, F emit) {
-  if constexpr (NW == 1) {
+__device__ __forceinline__ void combine_emit_static4(float* red, const float (&flat)[R], int w, int lane, F emit) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) emit(r, r, flat[r]);
-  } else {
+  for (int r = 0; r < R; ++r) red[(w * R + r) * 64 + lane] = flat[r];
+  __syncthreads();
 #pragma unroll
-    for (int r = 0; r < R; ++r) red[(w * R + r) * 64 + lane] = flat[r];
-    __syncthreads();
+  for (int j = 0; j < R * 16 / (NW * 64); ++j) {
+    const Slot4<R, NW> sl = slot4<R, NW>(w, lane, j);
+    float4 v = *reinterpret_cast<const float4*>(&red[sl.r * 64 + sl.kl * 32 + sl.c4]);
 #pragma unroll
-    for (int j = 0; j < R / NW; ++j) {
-      const int r = w + j * NW;
-      float v = red[r * 64 + lane];
-#pragma unroll
-      for (int q = 1; q < NW; ++q) v += red[(q * R + r) * 64 + lane];
-      emit(j, r, v);
+    for (int q = 1; q < NW; ++q) {
+      const float4 u = *reinterpret_cast<const float4*>(&red[(q * R + sl.r) * 64 + sl.kl * 32 + sl.c4]);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
     }
+    emit(j, v);
   }
 }
 
@@ -64,7 +73,8 @@ struct DDgradArgs {
 };
 
 // bid / nblocks: this block's index among the launch's input-gradient blocks (the fused per-layer backward
-// launch of xt_igemm.hip runs them next to the weight-gradient blocks); red: >= NW*TI*TJ*1024 floats of LDS.
+// launch of xt_igemm.hip runs them next to the weight-gradient blocks); red: >= NW*TI*TJ*1024 floats of LDS
+// (also for NW = 1: the tile is transposed through it).
 template <int TI, int TJ, int NW>
 __device__ __forceinline__ void direct_dgrad_body(const DDgradArgs& p, uint32_t bid, uint32_t nblocks, float* red) {
   const Geom& g = p.g;
@@ -108,21 +118,22 @@ __device__ __forceinline__ void direct_dgrad_body(const DDgradArgs& p, uint32_t 
   const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (uint32_t)g.K * (uint32_t)g.N * 4u);
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x, (uint32_t)g.B * (uint32_t)g.HWC * 4u);
 
-  // producer activations of the registers this wave will emit: loaded before the reduction loop
-  constexpr int R = TI * TJ * 16, RJ = R / NW;
-  float xv[RJ];
+  // producer activations of the 16-byte pieces this lane will emit: loaded before the reduction loop
+  constexpr int R = TI * TJ * 16, RJ = R * 16 / (NW * 64);
+  static_assert(R * 16 % (NW * 64) == 0, "direct dgrad: tile does not split evenly over the waves");
+  float4 xv[RJ];
   int eoff[RJ];
 #pragma unroll
   for (int j = 0; j < RJ; ++j) {
-    const int r = w + j * NW;
-    const int t = r >> 4, rr = r & 15;
+    const Slot4<R, NW> sl = slot4<R, NW>(w, lane, j);
+    const int t = sl.r >> 4, rr = sl.r & 15;
     const int ti = t / TJ, tj = t - ti * TJ;
-    const int row = (rr & 3) + 8 * (rr >> 2) + 4 * kl;
+    const int row = (rr & 3) + 8 * (rr >> 2) + 4 * sl.kl;
     int o = 0;
 #pragma unroll
     for (int q = 0; q < TI; ++q) { const int oq = __shfl(outoff[q], row, 64); if (q == ti) o = oq; }
-    eoff[j] = o >= 0 ? o + c0 + 32 * tj + il : -1;
-    xv[j] = buf_load1(rs_x, o >= 0 ? (uint32_t)eoff[j] * 4u : kOob, 0u);
+    eoff[j] = o >= 0 ? o + c0 + 32 * tj + sl.c4 : -1;
+    xv[j] = buf_load4(rs_x, o >= 0 ? (uint32_t)eoff[j] * 4u : kOob, 0u);
   }
 
   const uint32_t wvoff = (uint32_t)((c0 + il) * g.N + 16 * kl) * 4u;
@@ -183,8 +194,12 @@ __device__ __forceinline__ void direct_dgrad_body(const DDgradArgs& p, uint32_t 
     for (int tj = 0; tj < TJ; ++tj)
 #pragma unroll
       for (int r = 0; r < 16; ++r) flat[(ti * TJ + tj) * 16 + r] = acc[ti][tj][r];
-  combine_emit_static<R, NW>(red, flat, w, lane, [&](int j, int r, float v) {
-    if (eoff[j] >= 0) p.dx[(size_t)eoff[j]] = v * act_grad(xv[j], p.act_prev);
+  combine_emit_static4<R, NW>(red, flat, w, lane, [&](int j, float4 v) {
+    if (eoff[j] >= 0) {
+      v.x *= act_grad(xv[j].x, p.act_prev); v.y *= act_grad(xv[j].y, p.act_prev);
+      v.z *= act_grad(xv[j].z, p.act_prev); v.w *= act_grad(xv[j].w, p.act_prev);
+      *reinterpret_cast<float4*>(p.dx + (size_t)eoff[j]) = v;
+    }
   });
   XT_TL(4);
   XT_TL_DRAIN(5);
