@@ -170,6 +170,168 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_u8c4k8_fwd_bf16x3_kernel
   XT_TL_DRAIN(5);
 }
 
+// ---- position-flattened forward: one workgroup = PB consecutive output positions of the flattened [B*OH*OW]
+// range instead of one frame stack.  With one frame stack per workgroup, B = 320 on 256 CUs leaves 64 CUs with two
+// co-resident workgroups (13.9 us) while the other 192 finish their single one in 9.9 us (profiles/r01_timeline*);
+// 512 positions per workgroup are exactly 16 tiles = 8 waves x 2 slots (no idle tile slot: 13 tiles of a frame stack
+// occupied 16) and 250 equal workgroups, one per CU.  A position range touches at most NIMG frame stacks; only the
+// input rows its output rows need are staged (same byte offsets inside a per-stack LDS slot).
+template <int SLOTS>
+__global__ __launch_bounds__(512, 2) void conv_u8c4k8_fwd_flat_kernel(const C1FwdArgs p) {
+  constexpr int NW = 8, NT = 512, PB = 32 * NW * SLOTS, NIMG = SLOTS == 2 ? 3 : 2, WQ = 1024 / NT, U = SLOTS == 2 ? 6 : 4;
+  extern __shared__ __attribute__((aligned(16))) uint8_t limg[];
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int HWC = p.H * p.W * 4, Wrow = p.W * 4, OHOW = p.OH * p.OW;
+  const int total = p.B * OHOW;
+  const int p0 = blockIdx.x * PB, p1 = min(total, p0 + PB);
+  const int nsteps = 2 * p.KH;
+  uint4* wpl = reinterpret_cast<uint4*>(limg + NIMG * HWC);
+  XT_TL(0);
+  XT_TL_ROLE(40);
+  float wv[WQ][8];
+  const int nslots = nsteps * 64;
+#pragma unroll
+  for (int q = 0; q < WQ; ++q) {
+    const int slot = t + NT * q;
+    const int sc = slot < nslots ? slot : 0;
+    const float* wl = p.w + (size_t)((sc >> 6) * 16 + 8 * ((sc & 63) >> 5)) * 32 + (sc & 31);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[q][j] = wl[j * 32];
+  }
+  // ---- stage the needed rows of the (up to NIMG) frame stacks this position range touches
+  const int s0 = p0 / OHOW, slast = (p1 - 1) / OHOW;
+  // (offsets relative to p.in, not per-stack pointers: a select between pointers degrades to flat loads)
+  int un[NIMG], dbase[NIMG], srow[NIMG];
+  long long goff[NIMG];
+  int ntot = 0;
+#pragma unroll
+  for (int i = 0; i < NIMG; ++i) {       // the (dependent) row-gather loads first, all in flight together
+    const int sc = min(s0 + i, p.B - 1);
+    srow[i] = p.idx ? p.idx[sc] : sc;
+  }
+#pragma unroll
+  for (int i = 0; i < NIMG; ++i) {
+    const int sidx = s0 + i;
+    un[i] = 0; dbase[i] = 0; goff[i] = 0;
+    if (sidx <= slast) {
+      const int lo = max(p0, sidx * OHOW) - sidx * OHOW, hi = min(p1, (sidx + 1) * OHOW) - 1 - sidx * OHOW;
+      const int blo = p.S * (lo / p.OW) * Wrow, bhi = (p.S * (hi / p.OW) + p.KH) * Wrow;
+      const int ul = blo >> 4;
+      un[i] = ((bhi + 15) >> 4) - ul;
+      goff[i] = (long long)srow[i] * (long long)HWC + (long long)ul * 16;
+      dbase[i] = i * HWC + ul * 16;
+    }
+    ntot += un[i];
+  }
+  for (int base = 0; base < ntot; base += NT * U) {
+    uint4 v[U];
+    int dsto[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      int u = base + t + NT * q;
+      const bool ok = u < ntot;
+      u = ok ? u : 0;
+      long long go = goff[0];
+      int db = dbase[0];
+#pragma unroll
+      for (int j = 0; j + 1 < NIMG; ++j) {
+        int cum = 0;
+#pragma unroll
+        for (int k = 0; k <= j; ++k) cum += un[k];
+        if ((base + t + NT * q) >= cum && ok) { go = goff[j + 1] - (long long)cum * 16; db = dbase[j + 1] - cum * 16; }
+      }
+      v[q] = *reinterpret_cast<const uint4*>(p.in + go + (long long)u * 16);
+      dsto[q] = db + u * 16;       // units past the end re-copy unit 0 (same bytes to the same place): the LDS write
+    }                              // stays unconditional, a guarded one makes hipcc sink each load into its branch
+#pragma unroll
+    for (int q = 0; q < U; ++q) *reinterpret_cast<uint4*>(limg + dsto[q]) = v[q];
+  }
+  XT_TL(1);
+#pragma unroll
+  for (int q = 0; q < WQ; ++q) {
+    const int slot = t + NT * q;
+    if (slot < nslots) {
+      BF8 b1, b2, b3;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float w0 = wv[q][2 * e], w1 = wv[q][2 * e + 1];
+        const float r0 = w0 - trunc_bf16(w0), r1 = w1 - trunc_bf16(w1);
+        const float q0 = r0 - trunc_bf16(r0), q1 = r1 - trunc_bf16(r1);
+        b1.u[e] = pack_hi16(w0, w1);
+        b2.u[e] = pack_hi16(r0, r1);
+        b3.u[e] = pack_hi16(q0, q1);
+      }
+      const int sidx = slot >> 6, ln = slot & 63;
+      wpl[(sidx * 3 + 0) * 64 + ln] = make_uint4(b1.u[0], b1.u[1], b1.u[2], b1.u[3]);
+      wpl[(sidx * 3 + 1) * 64 + ln] = make_uint4(b2.u[0], b2.u[1], b2.u[2], b2.u[3]);
+      wpl[(sidx * 3 + 2) * 64 + ln] = make_uint4(b3.u[0], b3.u[1], b3.u[2], b3.u[3]);
+    }
+  }
+  const int il = lane & 31, h = lane >> 5;
+  int poff[SLOTS];
+#pragma unroll
+  for (int ti = 0; ti < SLOTS; ++ti) {
+    const int pp = min(p0 + (wave + NW * ti) * 32 + il, p1 - 1);      // tail positions recompute the last valid one
+    const int sidx = pp / OHOW, rem = pp - sidx * OHOW;
+    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+    poff[ti] = (sidx - s0) * HWC + (p.S * oy * p.W + p.S * ox) * 4 + 8 * h;
+  }
+  f32x16 acc[SLOTS];
+#pragma unroll
+  for (int ti = 0; ti < SLOTS; ++ti)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
+  const float bias = p.bias[il];
+  __syncthreads();
+  XT_TL(2);
+  uint4 wq[3];
+  uint2 aq[SLOTS];
+  auto lds_fetch = [&](int s) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) wq[pl] = wpl[(s * 3 + pl) * 64 + lane];
+    const int koff = (s >> 1) * Wrow + (s & 1) * 16;
+#pragma unroll
+    for (int ti = 0; ti < SLOTS; ++ti) aq[ti] = *reinterpret_cast<const uint2*>(limg + poff[ti] + koff);
+  };
+  lds_fetch(0);
+  for (int s = 0; s < nsteps; ++s) {
+    BF8 bp[3];
+    bf16x8 av[SLOTS];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) { bp[pl].u[0] = wq[pl].x; bp[pl].u[1] = wq[pl].y; bp[pl].u[2] = wq[pl].z; bp[pl].u[3] = wq[pl].w; }
+#pragma unroll
+    for (int ti = 0; ti < SLOTS; ++ti) av[ti] = bytes_to_bf16x8(aq[ti].x, aq[ti].y);
+    if (s + 1 < nsteps) lds_fetch(s + 1);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int ti = 0; ti < SLOTS; ++ti)
+        acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ti], bp[pl].v, acc[ti], 0, 0, 0);
+  }
+  __syncthreads();
+  XT_TL(3);
+  float* tbuf = reinterpret_cast<float*>(limg + NIMG * HWC) + wave * (32 * 36);
+#pragma unroll
+  for (int ti = 0; ti < SLOTS; ++ti) {
+    const int pix0 = p0 + (wave + NW * ti) * 32;
+    if (pix0 < p1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        tbuf[row * 36 + il] = act_apply(fmaf(acc[ti][r], p.xs, bias), p.act);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = q * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(&tbuf[row * 36 + c4]);
+        if (pix0 + row < p1) *reinterpret_cast<float4*>(&p.y[(size_t)(pix0 + row) * 32 + c4]) = v;
+      }
+    }
+  }
+  XT_TL(4);
+  XT_TL_DRAIN(5);
+}
+
 static int c1_waves() {      // XT_C1_WAVES=4: the four-wave forms (A/B switch)
   static int v = -1;
   if (v < 0) { const char* e = getenv("XT_C1_WAVES"); v = (e && e[0] == '4') ? 4 : 8; }
@@ -194,6 +356,31 @@ int launch_conv1_fwd_bf16x3(const xt_conv_geom* g, const xt_input_xform* xf, int
   size_t lds = (size_t)2 * g->KH * 3 * 64 * 16;                    // weight planes, reused by the output transpose
   if (lds < (size_t)nw * 32 * 36 * 4) lds = (size_t)nw * 32 * 36 * 4;
   lds += (size_t)HWC;
+  static int flat = -1;          // XT_C1_FLAT=0: one frame stack per workgroup (A/B switch)
+  if (flat < 0) { const char* e = getenv("XT_C1_FLAT"); flat = (e && e[0] == '0') ? 0 : 1; }
+  if (flat && nw == 8 && g->KH == 8) {
+    const int total = B * g->OH * g->OW;
+    const bool two = (total + 511) / 512 >= 200;
+    const int pb = two ? 512 : 256, nimg = two ? 3 : 2;
+    if ((pb - 1) / (g->OH * g->OW) + 2 <= nimg) {          // a range of pb positions touches at most nimg frame stacks
+      const size_t fl = (size_t)nimg * HWC + (size_t)2 * g->KH * 3 * 64 * 16;
+      static bool attr_done = false;
+      if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4k8_fwd_flat_kernel<2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4k8_fwd_flat_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        attr_done = true;
+      }
+      if (fl <= 160 * 1024) {
+        if (two) hipLaunchKernelGGL(conv_u8c4k8_fwd_flat_kernel<2>, dim3((total + pb - 1) / pb), dim3(512), fl, st, a);
+        else hipLaunchKernelGGL(conv_u8c4k8_fwd_flat_kernel<1>, dim3((total + pb - 1) / pb), dim3(512), fl, st, a);
+        XT_LAUNCH_CHECK();
+        return 0;
+      }
+    }
+  }
   if (nw == 8) hipLaunchKernelGGL(conv_u8c4k8_fwd_bf16x3_kernel<8>, dim3(B), dim3(512), lds, st, a);
   else hipLaunchKernelGGL(conv_u8c4k8_fwd_bf16x3_kernel<4>, dim3(B), dim3(256), lds, st, a);
   XT_LAUNCH_CHECK();
