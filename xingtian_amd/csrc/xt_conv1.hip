@@ -170,6 +170,62 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_u8c4k8_fwd_bf16x3_kernel
   XT_TL_DRAIN(5);
 }
 
+// Stage the input rows that the output positions [p0, p1) of the flattened [B*OH*OW] range need: the range touches
+// at most NIMG frame stacks (first one = p0 / OHOW); stack i goes to LDS slot i at its own byte offsets.  All loads
+// of a pass are issued back to back (offsets relative to `in`, not per-stack pointers: a select between pointers
+// degrades to flat loads; unconditional LDS writes: a guarded one makes hipcc sink each load into its branch).
+template <int NIMG, int NT, int U>
+__device__ __forceinline__ void stage_position_range(const uint8_t* __restrict__ in, const int32_t* __restrict__ idx,
+                                                     int B, int HWC, int Wrow, int OHOW, int OW, int S, int KH, int p0,
+                                                     int p1, uint8_t* limg, int t) {
+  const int s0 = p0 / OHOW, slast = (p1 - 1) / OHOW;
+  int un[NIMG], dbase[NIMG], srow[NIMG];
+  long long goff[NIMG];
+  int ntot = 0;
+#pragma unroll
+  for (int i = 0; i < NIMG; ++i) {       // the (dependent) row-gather loads first, all in flight together
+    const int sc = min(s0 + i, B - 1);
+    srow[i] = idx ? idx[sc] : sc;
+  }
+#pragma unroll
+  for (int i = 0; i < NIMG; ++i) {
+    const int sidx = s0 + i;
+    un[i] = 0; dbase[i] = 0; goff[i] = 0;
+    if (sidx <= slast) {
+      const int lo = max(p0, sidx * OHOW) - sidx * OHOW, hi = min(p1, (sidx + 1) * OHOW) - 1 - sidx * OHOW;
+      const int blo = S * (lo / OW) * Wrow, bhi = (S * (hi / OW) + KH) * Wrow;
+      const int ul = blo >> 4;
+      un[i] = ((bhi + 15) >> 4) - ul;
+      goff[i] = (long long)srow[i] * (long long)HWC + (long long)ul * 16;
+      dbase[i] = i * HWC + ul * 16;
+    }
+    ntot += un[i];
+  }
+  for (int base = 0; base < ntot; base += NT * U) {
+    uint4 v[U];
+    int dsto[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      int u = base + t + NT * q;
+      const bool ok = u < ntot;
+      u = ok ? u : 0;
+      long long go = goff[0];
+      int db = dbase[0];
+#pragma unroll
+      for (int j = 0; j + 1 < NIMG; ++j) {
+        int cum = 0;
+#pragma unroll
+        for (int k = 0; k <= j; ++k) cum += un[k];
+        if (u >= cum) { go = goff[j + 1] - (long long)cum * 16; db = dbase[j + 1] - cum * 16; }
+      }
+      v[q] = *reinterpret_cast<const uint4*>(in + go + (long long)u * 16);
+      dsto[q] = db + u * 16;       // units past the end re-copy unit 0 (same bytes to the same place)
+    }
+#pragma unroll
+    for (int q = 0; q < U; ++q) *reinterpret_cast<uint4*>(limg + dsto[q]) = v[q];
+  }
+}
+
 // ---- position-flattened forward: one workgroup = PB consecutive output positions of the flattened [B*OH*OW]
 // range instead of one frame stack.  With one frame stack per workgroup, B = 320 on 256 CUs leaves 64 CUs with two
 // co-resident workgroups (13.9 us) while the other 192 finish their single one in 9.9 us (profiles/r01_timeline*);
@@ -198,54 +254,8 @@ __global__ __launch_bounds__(512, 2) void conv_u8c4k8_fwd_flat_kernel(const C1Fw
 #pragma unroll
     for (int j = 0; j < 8; ++j) wv[q][j] = wl[j * 32];
   }
-  // ---- stage the needed rows of the (up to NIMG) frame stacks this position range touches
-  const int s0 = p0 / OHOW, slast = (p1 - 1) / OHOW;
-  // (offsets relative to p.in, not per-stack pointers: a select between pointers degrades to flat loads)
-  int un[NIMG], dbase[NIMG], srow[NIMG];
-  long long goff[NIMG];
-  int ntot = 0;
-#pragma unroll
-  for (int i = 0; i < NIMG; ++i) {       // the (dependent) row-gather loads first, all in flight together
-    const int sc = min(s0 + i, p.B - 1);
-    srow[i] = p.idx ? p.idx[sc] : sc;
-  }
-#pragma unroll
-  for (int i = 0; i < NIMG; ++i) {
-    const int sidx = s0 + i;
-    un[i] = 0; dbase[i] = 0; goff[i] = 0;
-    if (sidx <= slast) {
-      const int lo = max(p0, sidx * OHOW) - sidx * OHOW, hi = min(p1, (sidx + 1) * OHOW) - 1 - sidx * OHOW;
-      const int blo = p.S * (lo / p.OW) * Wrow, bhi = (p.S * (hi / p.OW) + p.KH) * Wrow;
-      const int ul = blo >> 4;
-      un[i] = ((bhi + 15) >> 4) - ul;
-      goff[i] = (long long)srow[i] * (long long)HWC + (long long)ul * 16;
-      dbase[i] = i * HWC + ul * 16;
-    }
-    ntot += un[i];
-  }
-  for (int base = 0; base < ntot; base += NT * U) {
-    uint4 v[U];
-    int dsto[U];
-#pragma unroll
-    for (int q = 0; q < U; ++q) {
-      int u = base + t + NT * q;
-      const bool ok = u < ntot;
-      u = ok ? u : 0;
-      long long go = goff[0];
-      int db = dbase[0];
-#pragma unroll
-      for (int j = 0; j + 1 < NIMG; ++j) {
-        int cum = 0;
-#pragma unroll
-        for (int k = 0; k <= j; ++k) cum += un[k];
-        if ((base + t + NT * q) >= cum && ok) { go = goff[j + 1] - (long long)cum * 16; db = dbase[j + 1] - cum * 16; }
-      }
-      v[q] = *reinterpret_cast<const uint4*>(p.in + go + (long long)u * 16);
-      dsto[q] = db + u * 16;       // units past the end re-copy unit 0 (same bytes to the same place): the LDS write
-    }                              // stays unconditional, a guarded one makes hipcc sink each load into its branch
-#pragma unroll
-    for (int q = 0; q < U; ++q) *reinterpret_cast<uint4*>(limg + dsto[q]) = v[q];
-  }
+  stage_position_range<NIMG, NT, U>(p.in, p.idx, p.B, HWC, Wrow, OHOW, p.OW, p.S, p.KH, p0, p1, limg, t);
+  const int s0 = p0 / OHOW;
   XT_TL(1);
 #pragma unroll
   for (int q = 0; q < WQ; ++q) {
@@ -537,6 +547,141 @@ __global__ __launch_bounds__(128 * NKQ, NKQ) void conv_u8c4k8_wgrad_bf16x3_kerne
   XT_TL_DRAIN(5);
 }
 
+// ---- position-flattened weight gradient: one workgroup = 512 consecutive positions of the flattened [B*OH*OW]
+// range (32 pixel steps of 16) -> ceil(B*OH*OW / 512) equal workgroups, one per CU, and as many partial slabs
+// (250 instead of 320 at B = 320).  Same wave roles as above (2 pixel parities x 4 kernel-row groups).  The dY rows
+// of a position range are one contiguous block; the frame-stack rows are staged as in the flattened forward.
+__global__ __launch_bounds__(512, 2) void conv_u8c4k8_wgrad_flat_kernel(const C1WgArgs p) {
+  constexpr int NKQ = 4, NT = 512, RQ = 2, PB = 512, NIMG = 3, DQ = PB * 8 / NT;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lsm[];
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int HWC = p.H * p.W * 4, Wrow = p.W * 4, OHOW = p.OH * p.OW;
+  const int total = p.B * OHOW;
+  const int p0 = blockIdx.x * PB, p1 = min(total, p0 + PB);
+  uint8_t* limg = lsm;
+  float* dys = reinterpret_cast<float*>(lsm + NIMG * HWC);                        // [PB][32]
+  int* pixoff = reinterpret_cast<int*>(lsm + NIMG * HWC + PB * 32 * 4);            // [PB]
+  float* bred = reinterpret_cast<float*>(pixoff);       // aliases pixoff after the main loop
+  XT_TL(0);
+  XT_TL_ROLE(50);
+  {
+    const float4* dsrc = reinterpret_cast<const float4*>(p.dy + (size_t)p0 * 32);
+    const int n4 = (p1 - p0) * 8;
+    float4 dv[DQ];
+#pragma unroll
+    for (int q = 0; q < DQ; ++q) {
+      const int i = t + NT * q;
+      dv[q] = dsrc[i < n4 ? i : 0];
+    }
+    stage_position_range<NIMG, NT, 6>(p.in, p.idx, p.B, HWC, Wrow, OHOW, p.OW, p.S, p.KH, p0, p1, limg, t);
+#pragma unroll
+    for (int q = 0; q < DQ; ++q) {
+      const int i = t + NT * q;
+      reinterpret_cast<float4*>(dys)[i] = i < n4 ? dv[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int s0 = p0 / OHOW;
+    {
+      const int pp = min(p0 + t, p1 - 1);        // PB == NT: one position per thread; tail positions carry dY = 0
+      const int sidx = pp / OHOW, rem = pp - sidx * OHOW;
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      pixoff[t] = (sidx - s0) * HWC + (p.S * oy * p.W + p.S * ox) * 4;
+    }
+  }
+  const int il = lane & 31, h = lane >> 5;
+  const int pg = wave / NKQ, kq = wave - pg * NKQ;
+  f32x16 acc[RQ];
+#pragma unroll
+  for (int q = 0; q < RQ; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  float bsum = 0.f;
+  XT_TL(1);
+  __syncthreads();
+  XT_TL(2);
+  float dyr[8];
+  uint32_t xr[RQ][8];
+  int po[8];
+  auto read_po = [&](int s) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) po[e] = pixoff[s * 16 + 8 * h + e];
+  };
+  auto read_ops = [&](int s) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dyr[e] = dys[(s * 16 + 8 * h + e) * 32 + il];
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+      const int kb = (kq * RQ + q) * Wrow + il;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xr[q][e] = limg[po[e] + kb];
+    }
+  };
+  const int nsteps = (p1 - p0 + 15) >> 4;      // <= NSTEP
+  if (pg < nsteps) { read_po(pg); read_ops(pg); }
+  if (pg + 2 < nsteps) read_po(pg + 2);
+  for (int s = pg; s < nsteps; s += 2) {
+    BF8 bp[3], av[RQ];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float w0 = dyr[2 * q], w1 = dyr[2 * q + 1];
+      bsum += w0 + w1;
+      const float r0 = w0 - trunc_bf16(w0), r1 = w1 - trunc_bf16(w1);
+      const float q0 = r0 - trunc_bf16(r0), q1 = r1 - trunc_bf16(r1);
+      bp[0].u[q] = pack_hi16(w0, w1);
+      bp[1].u[q] = pack_hi16(r0, r1);
+      bp[2].u[q] = pack_hi16(q0, q1);
+    }
+#pragma unroll
+    for (int q = 0; q < RQ; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) av[q].u[e] = pack_hi16((float)xr[q][2 * e], (float)xr[q][2 * e + 1]);
+    if (s + 2 < nsteps) {
+      read_ops(s + 2);
+      if (s + 4 < nsteps) read_po(s + 4);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int q = 0; q < RQ; ++q)
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q].v, bp[pl].v, acc[q], 0, 0, 0);
+  }
+  bsum += __shfl_xor(bsum, 32, 64);
+  XT_TL(3);
+  __syncthreads();                         // every staged operand is dead: the LDS is reused for the combine
+  // both pixel-parity halves park their tiles as [parity][k row][36]; then all 512 threads add the two copies and
+  // store 16 bytes each: the slab is written as 4 fully coalesced 8 KB passes (the dword form, stored by the four
+  // parity-0 waves only, took 3.7 us of the block's 13.9)
+  float* T = reinterpret_cast<float*>(lsm);
+  if (kq == 0 && h == 0) bred[pg * 32 + il] = bsum;
+#pragma unroll
+  for (int q = 0; q < RQ; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int krow = (kq * RQ + q) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      T[(pg * 256 + krow) * 36 + il] = acc[q][r];
+    }
+  __syncthreads();
+  {
+    float* slab = p.out + (size_t)blockIdx.x * ((size_t)(p.KH * 32 + 1) * 32);
+    const int c4 = (t & 7) * 4;
+    float corr[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) corr[c] = p.xb * (bred[c4 + c] + bred[32 + c4 + c]);   // d/dW of (x*xs + xb): xb * sum_p dY
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int krow = (t >> 3) + 64 * j;
+      const float4 u0 = *reinterpret_cast<const float4*>(&T[krow * 36 + c4]);
+      const float4 u1 = *reinterpret_cast<const float4*>(&T[(256 + krow) * 36 + c4]);
+      float4 v;
+      v.x = fmaf(u0.x + u1.x, p.xs, corr[0]); v.y = fmaf(u0.y + u1.y, p.xs, corr[1]);
+      v.z = fmaf(u0.z + u1.z, p.xs, corr[2]); v.w = fmaf(u0.w + u1.w, p.xs, corr[3]);
+      *reinterpret_cast<float4*>(slab + (size_t)krow * 32 + c4) = v;
+    }
+    if (t < 32) slab[(size_t)p.KH * 32 * 32 + t] = bred[t] + bred[32 + t];
+  }
+  XT_TL(4);
+  XT_TL_DRAIN(5);
+}
+
 XT_TL_SETTER(conv1)
 
 // returns 0 launched (msplit_out = B slabs), 1 error, -1 geometry not handled
@@ -559,6 +704,26 @@ int launch_conv1_wgrad_bf16x3(const xt_conv_geom* g, const xt_input_xform* xf, i
   if ((size_t)nsteps * 16 * 32 * 4 < (size_t)2 * 4 * 16 * 64 * 4) return -1;   // `red` aliases the dY region
   if ((size_t)nsteps * 16 * 4 < 64 * 4) return -1;                              // `bred` aliases pixoff
   if (lds > 81920) return -1;                                                    // two workgroups per CU
+  {
+    static int flat = -1;          // XT_C1_FLAT=0: one frame stack per workgroup (A/B switch)
+    if (flat < 0) { const char* e = getenv("XT_C1_FLAT"); flat = (e && e[0] == '0') ? 0 : 1; }
+    const int total = B * g->OH * g->OW, nblk = (total + 511) / 512;
+    const size_t fl = (size_t)3 * HWC + (size_t)512 * 32 * 4 + (size_t)512 * 4;
+    if (flat && c1_waves() == 8 && nblk >= 200 && nblk <= max_slabs && 511 / (g->OH * g->OW) + 2 <= 3 &&
+        fl <= 160 * 1024 && B > 1) {
+      static bool attr_done = false;
+      if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4k8_wgrad_flat_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        attr_done = true;
+      }
+      hipLaunchKernelGGL(conv_u8c4k8_wgrad_flat_kernel, dim3(nblk), dim3(512), fl, st, a);
+      XT_LAUNCH_CHECK();
+      if (msplit_out) *msplit_out = nblk;
+      return 0;
+    }
+  }
   if (c1_waves() == 8) hipLaunchKernelGGL(conv_u8c4k8_wgrad_bf16x3_kernel<4>, dim3(B), dim3(512), lds, st, a);
   else hipLaunchKernelGGL(conv_u8c4k8_wgrad_bf16x3_kernel<2>, dim3(B), dim3(256), lds, st, a);
   XT_LAUNCH_CHECK();
