@@ -293,8 +293,8 @@ def main():
         for li, lay in enumerate(spec.layers):
             mnk2 = 2.0 * bsz * lay.OH * lay.OW * lay.N * lay.K
             if li == 0:
-                kern["L0 conv8x8/4 fwd  [conv_u8c4k8_fwd_bf16x3_kernel]"] = (net.time_layer(0, 0, d_obs, idx, bsz, 50), mnk2, "bf16x3")
-                kern["L0 conv8x8/4 wgrad [conv_u8c4k8_wgrad_bf16x3_kernel]"] = (net.time_layer(0, 1, d_obs, idx, bsz, 50), mnk2, "bf16x3")
+                kern["L0 conv8x8/4 fwd  [conv_u8c4k8_fwd_flat_kernel]"] = (net.time_layer(0, 0, d_obs, idx, bsz, 50), mnk2, "bf16x3")
+                kern["L0 conv8x8/4 wgrad [conv_u8c4k8_wgrad_flat_kernel]"] = (net.time_layer(0, 1, d_obs, idx, bsz, 50), mnk2, "bf16x3")
             else:
                 kern["L%d %s fwd  [igemm_fwd_kernel | direct_fwd_kernel]" % (li, lay.name)] = (net.time_layer(li, 0, d_obs, idx, bsz, 50), mnk2, "fp32")
                 kern["L%d %s dgrad+wgrad [igemm_bwd_layer_kernel]" % (li, lay.name)] = (
