@@ -205,4 +205,148 @@ __device__ __forceinline__ void direct_dgrad_body(const DDgradArgs& p, uint32_t 
   XT_TL_DRAIN(5);
 }
 
+// ------------------------------------------------------------------ stride-1 input gradient, dY halo in LDS
+// Same tile / wave / combine structure as direct_dgrad_body<2, 1, 4> (64 positions x 32 channels per workgroup,
+// the four waves split the KH*KW*N reduction, weights straight from L2 into registers), but the dY operand is not
+// gathered from global memory per tap: the KH*KW taps of a position re-read the same few dY rows, every wave of
+// the workgroup walks other taps of the SAME rows, and with two or three co-resident workgroups that working set
+// (about 21 KB each) falls out of the 32 KB L1 -- the register-direct form got slower with more co-residency
+// (late-round finding 4).  A 64-position tile of a small stride-1 map touches at most `nsamp` samples;
+// their whole dY ([OH*OW][N] each, one contiguous block) is staged once into LDS with rows padded to N + 4 floats
+// (16-byte reads of 32 consecutive rows then hit all banks), plus one zero row that out-of-range taps point to.
+// Requires S == 1; smem >= max(staged rows + 1 zero row, 4 waves x 2 tiles x 4 KB for the combine).
+__device__ __forceinline__ void halo_dgrad_body(const DDgradArgs& p, uint32_t bid, uint32_t nblocks, float* smem) {
+  constexpr int TI = 2, NW = 4, R = TI * 16, RJ = R * 16 / (NW * 64);
+  const Geom& g = p.g;
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int il = lane & 31, kl = lane >> 5;
+  XT_TL(0);
+  XT_TL_ROLE(80);
+  const uint32_t lin = xcd_chunk(bid, nblocks);
+  const int tc = (int)(lin % (uint32_t)p.ct), tm = (int)(lin / (uint32_t)p.ct);
+  const int HW = g.H * g.W, Mc = g.B * HW;
+  const int i0 = tm * (32 * TI), c0 = tc * 32;
+  if (i0 >= Mc) return;                                   // block-uniform
+  const int sfirst = i0 / HW, slast = min(i0 + 32 * TI - 1, Mc - 1) / HW;
+  const int RS = g.N + 4;
+  const int nrows = (slast - sfirst + 1) * g.OHOW;        // staged dY rows; row `nrows` is the zero row
+  {
+    const float4* src = reinterpret_cast<const float4*>(p.dy + (size_t)sfirst * g.OHOW * g.N);
+    const int n4row = g.N >> 2, total4 = nrows * n4row;
+    for (int base = 0; base < total4; base += 256 * 8) {
+      float4 v[8];
+      int dst[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        int e = base + t + 256 * q;
+        e = e < total4 ? e : 0;                            // past the end: re-copy element 0 (unconditional LDS write)
+        const int row = e / n4row;
+        v[q] = src[e];
+        dst[q] = row * RS + (e - row * n4row) * 4;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(&smem[dst[q]]) = v[q];
+    }
+    for (int e = t; e < RS; e += 256) smem[nrows * RS + e] = 0.f;
+  }
+  const int nps = g.N >> 5;
+  const int nsteps = g.KH * g.KW * nps;
+  const int per = (nsteps + NW - 1) / NW;
+  const int s0 = w * per, s1 = min(nsteps, s0 + per);
+
+  int r0[TI], qy[TI], qx[TI], outoff[TI];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti) {
+    const int mraw = i0 + 32 * ti + il;
+    const int mc = min(mraw, Mc - 1);
+    const int b = mc / HW, rem = mc - b * HW;
+    const int y = rem / g.W, x = rem - y * g.W;
+    qy[ti] = y + g.PT; qx[ti] = x + g.PL;
+    r0[ti] = (b - sfirst) * g.OHOW + qy[ti] * g.OW + qx[ti];
+    outoff[ti] = mraw < Mc ? mc * g.C : -1;
+  }
+  const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (uint32_t)g.K * (uint32_t)g.N * 4u);
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x, (uint32_t)g.B * (uint32_t)g.HWC * 4u);
+  float4 xv[RJ];
+  int eoff[RJ];
+#pragma unroll
+  for (int j = 0; j < RJ; ++j) {
+    const Slot4<R, NW> sl = slot4<R, NW>(w, lane, j);
+    const int ti = sl.r >> 4, rr = sl.r & 15;
+    const int row = (rr & 3) + 8 * (rr >> 2) + 4 * sl.kl;
+    int o = 0;
+#pragma unroll
+    for (int q = 0; q < TI; ++q) { const int oq = __shfl(outoff[q], row, 64); if (q == ti) o = oq; }
+    eoff[j] = o >= 0 ? o + c0 + sl.c4 : -1;
+    xv[j] = buf_load4(rs_x, o >= 0 ? (uint32_t)eoff[j] * 4u : kOob, 0u);
+  }
+  const uint32_t wvoff = (uint32_t)((c0 + il) * g.N + 16 * kl) * 4u;
+  struct StageA { float4 a[TI][4]; };
+  struct StageB { float4 b[4]; };
+  auto loadB = [&](StageB& S_, int s, bool live) {
+    const int tap = s / nps;
+    const uint32_t ws = live ? (uint32_t)((tap * g.C) * g.N + (s - tap * nps) * 32) * 4u : 0u;
+    const uint32_t vo = live ? wvoff : kOob;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) S_.b[q] = buf_load4(rs_w, vo + 16u * q, ws);
+  };
+  auto loadA = [&](StageA& S_, int s, bool live) {
+    const int tap = s / nps;
+    const int jy = tap / g.KW, jx = tap - jy * g.KW;
+    const int nofs = (s - tap * nps) * 32 + 16 * kl;
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) {
+      const bool ok = live && ((unsigned)(qy[ti] - jy) < (unsigned)g.OH) && ((unsigned)(qx[ti] - jx) < (unsigned)g.OW);
+      const int row = ok ? r0[ti] - (jy * g.OW + jx) : nrows;
+      const float* ap = smem + row * RS + nofs;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) S_.a[ti][q] = *reinterpret_cast<const float4*>(ap + 4 * q);
+    }
+  };
+  f32x16 acc[TI];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
+  auto pick = [](const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; };
+  auto compute = [&](const StageA& A_, const StageB& B_) {
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+        acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(pick(A_.a[ti][kk >> 2], kk & 3), pick(B_.b[kk >> 2], kk & 3), acc[ti], 0, 0, 0);
+  };
+  StageB B0, B1;
+  loadB(B0, s0, s0 < s1);
+  loadB(B1, s0 + 1, s0 + 1 < s1);
+  __syncthreads();                                        // staged dY visible
+  XT_TL(1);
+  StageA A0, A1;
+  loadA(A0, s0, s0 < s1);
+  for (int s = s0; s < s1; s += 2) {
+    loadA(A1, s + 1, s + 1 < s1);
+    compute(A0, B0);
+    loadB(B0, s + 2, s + 2 < s1);
+    loadA(A0, s + 2, s + 2 < s1);
+    compute(A1, B1);
+    loadB(B1, s + 3, s + 3 < s1);
+  }
+  XT_TL(3);
+  float flat[R];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) flat[ti * 16 + r] = acc[ti][r];
+  __syncthreads();                                        // every wave is done reading the staged rows: reuse as `red`
+  combine_emit_static4<R, NW>(smem, flat, w, lane, [&](int j, float4 v) {
+    if (eoff[j] >= 0) {
+      v.x *= act_grad(xv[j].x, p.act_prev); v.y *= act_grad(xv[j].y, p.act_prev);
+      v.z *= act_grad(xv[j].z, p.act_prev); v.w *= act_grad(xv[j].w, p.act_prev);
+      *reinterpret_cast<float4*>(p.dx + (size_t)eoff[j]) = v;
+    }
+  });
+  XT_TL(4);
+  XT_TL_DRAIN(5);
+}
+
 }  // namespace xt

@@ -879,16 +879,27 @@ struct BwdLayerArgs {
   int n_wg, n_dg, n_hw;      // block counts (n_hw may be 0)
 };
 
-template <int WBI, int WBJ, int WWI, int WWJ, bool WPAD, int DBI, int DBJ, int DWI, int DWJ, bool D4 = false>
-__global__ __launch_bounds__(256, D4 ? 3 : 1) void igemm_bwd_layer_kernel(const BwdLayerArgs p) {
-  constexpr int SM0 = wgrad_smem_floats<WBI, WBJ, WPAD>() > dgrad_smem_floats<DBI, DBJ>()
-                          ? wgrad_smem_floats<WBI, WBJ, WPAD>() : dgrad_smem_floats<DBI, DBJ>();
+// HALO = true: the input-gradient blocks are halo_dgrad_body, selected at COMPILE time.  The register allocation of
+// a kernel is the maximum over all of its paths: the generic form needs 144 VGPR (LDS-tiled dgrad) + 32 AGPR
+// (register-direct dgrad) = two workgroups per CU, this one three.
+template <int WBI, int WBJ, int WWI, int WWJ, bool WPAD, int DBI, int DBJ, int DWI, int DWJ, bool D4 = false, bool HALO = false>
+__global__ __launch_bounds__(256, (D4 || HALO) ? 3 : 1) void igemm_bwd_layer_kernel(const BwdLayerArgs p) {
+  constexpr int SMD = HALO ? 9 * 1024 : dgrad_smem_floats<DBI, DBJ>();
+  constexpr int SM0 = wgrad_smem_floats<WBI, WBJ, WPAD>() > SMD ? wgrad_smem_floats<WBI, WBJ, WPAD>() : SMD;
   constexpr int SM = (D4 && dgrad4_smem_floats() > SM0) ? dgrad4_smem_floats() : SM0;
   __shared__ __attribute__((aligned(16))) float smem[SM];
   int b = blockIdx.x;
   if (b < p.n_dg) {                       // dgrad first: it is on the critical path of the next layer
     if constexpr (D4) {                   // stride-2 conv: the four parity classes of a position tile in one block
       igemm_dgrad4_body(p.dg, b, smem);
+      return;
+    }
+    if constexpr (HALO) {
+      halo_dgrad_body(p.ddg, (uint32_t)b, (uint32_t)p.n_dg, smem);
+      return;
+    }
+    if (p.dg_direct == 4) {               // stride-1, small map: 64-row tiles with the dY halo staged in LDS
+      halo_dgrad_body(p.ddg, (uint32_t)b, (uint32_t)p.n_dg, smem);
       return;
     }
     if (p.dg_direct == 3) {               // the same with 64-row tiles (weight operand shared by two row tiles)
@@ -1142,6 +1153,10 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
         a.ddg.mt = (mc + 63) / 64;
         a.n_dg = a.ddg.mt * a.ddg.ct;
         a.dg_direct = 3;
+        static int halo = -1;            // XT_DGRAD_HALO=0: register-direct dY gather instead of the LDS halo (A/B)
+        if (halo < 0) { const char* e = getenv("XT_DGRAD_HALO"); halo = (e && e[0] == '0') ? 0 : 1; }
+        const int nsamp = 63 / (g.H * g.W) + 2;
+        if (halo && (size_t)(nsamp * g.OHOW + 1) * (g.N + 4) * 4 <= 36 * 1024 && g.N + 4 <= 256) a.dg_direct = 4;
       }
     }
   }
@@ -1149,6 +1164,28 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
   a.n_hw = 0;
   if (hw) { a.hw = *hw; a.n_hw = hw->gx * hw->nchunk; }
   else { a.hw.gx = 1; a.hw.nchunk = 0; }
+  // The halo input gradient has its own kernel instance (XT_BWD_SPEC=0: the generic one): three workgroups per CU
+  // instead of two.  With it, a launch that is only a little larger than the 768 co-resident workgroups is cut to
+  // one round (XT_BWD_FIT=<slots>, 0 = off): the surplus weight-gradient blocks otherwise start when the first
+  // input-gradient blocks END and the launch takes two block lifetimes.  Measured for conv3 at B=320: generic 26.3,
+  // own instance 24.4, own instance + one round 22.6 us (with the register-direct dY gather both made it SLOWER:
+  // a third co-resident workgroup thrashed the L1 that gather depends on).
+  static int spec = -1, fit = -1;
+  if (spec < 0) { const char* e = getenv("XT_BWD_SPEC"); spec = (e && e[0] == '0') ? 0 : 1; }
+  if (fit < 0) { const char* e = getenv("XT_BWD_FIT"); fit = e ? atoi(e) : 768; }
+  const bool halo_inst = a.dg_direct == 4 && spec && !wsmall && !is_padded(g);
+  if (halo_inst) {
+    const int tiles = a.wg_gx * a.wg_gy;
+    const int room = fit - a.n_dg - a.n_hw;
+    if (fit > 0 && a.n_wg + a.n_dg + a.n_hw > fit && room >= tiles * 8 && a.n_wg <= 2 * room) {
+      msplit = pick_ksplit_chunk(g.M, room / tiles, &chunk);      // effective split <= room / tiles
+      a.wg.msplit = msplit; a.wg.mchunk = chunk;
+      a.wg.out = msplit == 1 ? dwb : slabs;
+      if (msplit_out) *msplit_out = msplit;
+      a.wg_gz = msplit;
+      a.n_wg = tiles * msplit;
+    }
+  }
   const int total = a.n_wg + a.n_dg + a.n_hw;
   const bool pad = is_padded(g);
 #define XT_BWD(WBI, WBJ, WWI, WWJ, DBI, DBJ, DWI, DWJ)                                                          \
@@ -1158,7 +1195,9 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
     else hipLaunchKernelGGL((igemm_bwd_layer_kernel<WBI, WBJ, WWI, WWJ, false, DBI, DBJ, DWI, DWJ>),            \
                             dim3(total), dim3(256), 0, st, a);                                                  \
   } while (0)
-  if (a.dg_direct == 2) {
+  if (halo_inst) {
+    hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1, false, true>), dim3(total), dim3(256), 0, st, a);
+  } else if (a.dg_direct == 2) {
     XT_REQUIRE(wsmall && dsmall && !pad, "bwd_layer: the all-classes input gradient needs the small-tile configuration");
     hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, true>), dim3(total), dim3(256), 0, st, a);
   } else if (wsmall && dsmall) XT_BWD(128, 32, 4, 1, 128, 32, 4, 1);
