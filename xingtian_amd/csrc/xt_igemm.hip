@@ -21,6 +21,7 @@
 #include "xt_igemm.h"
 #include "xt_heads_dev.h"
 #include "xt_direct_dev.h"
+#include "xt_conv1_dev.h"
 
 namespace xt {
 
@@ -703,14 +704,41 @@ __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int b
 // round), four independent MFMA chains per wave, prologue/epilogue amortised over four times the math.
 // Single LDS stage (two barriers per step): a step carries 64 MFMAs per wave, the barrier is noise, and the small
 // footprint (33.5 KB) keeps three blocks per CU next to the weight-gradient blocks.
+//
+// SPLIT = true ("bf16x6"): fp32 x fp32 on the bf16 matrix cores.  Both operands are split into three bf16 planes
+// (x = x1 + x2 + x3, truncation splits: 3 x 8 = 24 significant bits, i.e. all of fp32) when they are written to
+// LDS -- once per element per block -- and each 16-deep chunk is accumulated as the six products
+// x1*w1 + x1*w2 + x2*w1 + x1*w3 + x2*w2 + x3*w1 in fp32 (every bf16 x bf16 product is exact in fp32; the three
+// dropped terms are below 2^-24 relative, the size of fp32's own rounding).  6 x v_mfma_f32_32x32x16_bf16 (32
+// cycles each) replace 8 x v_mfma_f32_32x32x2_f32 (64 cycles each): 2.7x the matrix rate, which is what bounds
+// this loop (73 % MFMA utilisation on its SIMDs, profiles/r01_timeline_late.txt).  LDS layout per operand:
+// [plane][chunk][k half][row][8 bf16] = one ds_read_b128 per MFMA operand, slot stride padded by 32 B so that the
+// 8-byte split writes of the eight k-quads of a row spread over all banks.
 constexpr int kD4Classes = 4;
-constexpr int dgrad4_smem_floats() { return 32 * 129 + kD4Classes * 32 * 33 + 128; }
+constexpr int kD4SlotA = 128 * 16 + 32, kD4SlotB = 32 * 16 + 32;     // bytes per (plane, chunk, k half) slot
+template <bool SPLIT>
+constexpr int dgrad4_smem_floats() {
+  return SPLIT ? (12 * kD4SlotA + kD4Classes * 12 * kD4SlotB) / 4 + 128 : 32 * 129 + kD4Classes * 32 * 33 + 128;
+}
 
+// 4 consecutive-k fp32 values -> three bf16 planes, 8 bytes each, at base + (plane*4 + sub)*slot + byte
+__device__ __forceinline__ void split3_store(uint8_t* base, int slot, int sub, int byte, const float4 v) {
+  const float rx = v.x - trunc_bf16(v.x), ry = v.y - trunc_bf16(v.y), rz = v.z - trunc_bf16(v.z), rw = v.w - trunc_bf16(v.w);
+  const float qx = rx - trunc_bf16(rx), qy = ry - trunc_bf16(ry), qz = rz - trunc_bf16(rz), qw = rw - trunc_bf16(rw);
+  *reinterpret_cast<uint2*>(base + (0 * 4 + sub) * slot + byte) = make_uint2(pack_hi16(v.x, v.y), pack_hi16(v.z, v.w));
+  *reinterpret_cast<uint2*>(base + (1 * 4 + sub) * slot + byte) = make_uint2(pack_hi16(rx, ry), pack_hi16(rz, rw));
+  *reinterpret_cast<uint2*>(base + (2 * 4 + sub) * slot + byte) = make_uint2(pack_hi16(qx, qy), pack_hi16(qz, qw));
+}
+
+template <bool SPLIT>
 __device__ __forceinline__ void igemm_dgrad4_body(const DgradArgs& p, const int bx, float* smem) {
   constexpr int BI = 128, SA = BI + 1, SB = 33, NA = 4;
   float* As = smem;
   float* Bs = smem + 32 * SA;                       // [class][32 k][SB]
-  int* rowOut = reinterpret_cast<int*>(smem + 32 * SA + kD4Classes * 32 * SB);
+  uint8_t* Ap = reinterpret_cast<uint8_t*>(smem);   // SPLIT: [12 slots][128 rows][16 B]
+  uint8_t* Bp = Ap + 12 * kD4SlotA;                 //        [class][12 slots][32 cols][16 B]
+  int* rowOut = SPLIT ? reinterpret_cast<int*>(Bp + kD4Classes * 12 * kD4SlotB)
+                      : reinterpret_cast<int*>(smem + 32 * SA + kD4Classes * 32 * SB);
   const Geom& g = p.g;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int HC = g.H / g.S, WC = g.W / g.S;
@@ -767,6 +795,16 @@ __device__ __forceinline__ void igemm_dgrad4_body(const DgradArgs& p, const int 
     }
   };
   auto stash = [&](const Regs& R) {
+    if constexpr (SPLIT) {
+      const int sub = c4 >> 1, byte = (c4 & 1) * 8;     // k = 4*c4 + e -> chunk = c4 >> 2, k half = (c4 & 3) >> 1
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        split3_store(Ap + (r0 + 32 * i) * 16, kD4SlotA, sub, byte, sel4((R.ok >> i) & 1u, R.a[i]));
+#pragma unroll
+      for (int cls = 0; cls < kD4Classes; ++cls)
+        split3_store(Bp + cls * 12 * kD4SlotB + r0 * 16, kD4SlotB, sub, byte, R.b[cls]);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int r = r0 + 32 * i;
@@ -796,6 +834,30 @@ __device__ __forceinline__ void igemm_dgrad4_body(const DgradArgs& p, const int 
   XT_TL(1);
   const int kl = lane >> 5, il = lane & 31;
   auto mma = [&]() {
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        bf16x8 a[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          a[pl] = *reinterpret_cast<const bf16x8*>(Ap + (pl * 4 + ch * 2 + kl) * kD4SlotA + (wave * 32 + il) * 16);
+#pragma unroll
+        for (int cls = 0; cls < kD4Classes; ++cls) {
+          bf16x8 b[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            b[pl] = *reinterpret_cast<const bf16x8*>(Bp + (cls * 12 + pl * 4 + ch * 2 + kl) * kD4SlotB + il * 16);
+          // smallest terms first
+          acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[cls], 0, 0, 0);
+          acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[cls], 0, 0, 0);
+          acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[cls], 0, 0, 0);
+          acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[cls], 0, 0, 0);
+          acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[cls], 0, 0, 0);
+          acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[cls], 0, 0, 0);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
       const float a = As[(kk * 2 + kl) * SA + wave * 32 + il];
@@ -882,16 +944,16 @@ struct BwdLayerArgs {
 // HALO = true: the input-gradient blocks are halo_dgrad_body, selected at COMPILE time.  The register allocation of
 // a kernel is the maximum over all of its paths: the generic form needs 144 VGPR (LDS-tiled dgrad) + 32 AGPR
 // (register-direct dgrad) = two workgroups per CU, this one three.
-template <int WBI, int WBJ, int WWI, int WWJ, bool WPAD, int DBI, int DBJ, int DWI, int DWJ, bool D4 = false, bool HALO = false>
+template <int WBI, int WBJ, int WWI, int WWJ, bool WPAD, int DBI, int DBJ, int DWI, int DWJ, int D4 = 0, bool HALO = false>
 __global__ __launch_bounds__(256, (D4 || HALO) ? 3 : 1) void igemm_bwd_layer_kernel(const BwdLayerArgs p) {
   constexpr int SMD = HALO ? 9 * 1024 : dgrad_smem_floats<DBI, DBJ>();
   constexpr int SM0 = wgrad_smem_floats<WBI, WBJ, WPAD>() > SMD ? wgrad_smem_floats<WBI, WBJ, WPAD>() : SMD;
-  constexpr int SM = (D4 && dgrad4_smem_floats() > SM0) ? dgrad4_smem_floats() : SM0;
+  constexpr int SM = (D4 && dgrad4_smem_floats<D4 == 2>() > SM0) ? dgrad4_smem_floats<D4 == 2>() : SM0;
   __shared__ __attribute__((aligned(16))) float smem[SM];
   int b = blockIdx.x;
   if (b < p.n_dg) {                       // dgrad first: it is on the critical path of the next layer
-    if constexpr (D4) {                   // stride-2 conv: the four parity classes of a position tile in one block
-      igemm_dgrad4_body(p.dg, b, smem);
+    if constexpr (D4 != 0) {              // stride-2 conv: the four parity classes of a position tile in one block
+      igemm_dgrad4_body<D4 == 2>(p.dg, b, smem);
       return;
     }
     if constexpr (HALO) {
@@ -1196,10 +1258,13 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
                             dim3(total), dim3(256), 0, st, a);                                                  \
   } while (0)
   if (halo_inst) {
-    hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1, false, true>), dim3(total), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1, 0, true>), dim3(total), dim3(256), 0, st, a);
   } else if (a.dg_direct == 2) {
     XT_REQUIRE(wsmall && dsmall && !pad, "bwd_layer: the all-classes input gradient needs the small-tile configuration");
-    hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, true>), dim3(total), dim3(256), 0, st, a);
+    static int x6 = -1;                  // XT_BF16X6=0: fp32 MFMA in the all-classes input gradient (A/B)
+    if (x6 < 0) { const char* e = getenv("XT_BF16X6"); x6 = (e && e[0] == '0') ? 0 : 1; }
+    if (x6) hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, 2>), dim3(total), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, 1>), dim3(total), dim3(256), 0, st, a);
   } else if (wsmall && dsmall) XT_BWD(128, 32, 4, 1, 128, 32, 4, 1);
   else if (wsmall) XT_BWD(128, 32, 4, 1, 64, 64, 2, 2);
   else if (dsmall) XT_BWD(64, 64, 2, 2, 128, 32, 4, 1);
