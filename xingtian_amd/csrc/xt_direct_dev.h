@@ -4,6 +4,7 @@
 #pragma once
 #include "xt_common.h"
 #include "xt_igemm.h"
+#include "xt_conv1_dev.h"
 
 namespace xt {
 
@@ -215,6 +216,11 @@ __device__ __forceinline__ void direct_dgrad_body(const DDgradArgs& p, uint32_t 
 // their whole dY ([OH*OW][N] each, one contiguous block) is staged once into LDS with rows padded to N + 4 floats
 // (16-byte reads of 32 consecutive rows then hit all banks), plus one zero row that out-of-range taps point to.
 // Requires S == 1; smem >= max(staged rows + 1 zero row, 4 waves x 2 tiles x 4 KB for the combine).
+// SPLIT = true: "bf16x6" (see split3_store in xt_conv1_dev.h): dY is split into three bf16 planes when it is
+// staged -- [plane][row][N bf16 + 16 B pad], one ds_read_b128 per MFMA operand -- and the weights, which go
+// global -> VGPR, are split in registers (8 values per 16-deep chunk).  Within a 32-deep step lane (il, kl) owns the
+// reduction indices 16*chunk + 8*kl + j of both operands.
+template <bool SPLIT>
 __device__ __forceinline__ void halo_dgrad_body(const DDgradArgs& p, uint32_t bid, uint32_t nblocks, float* smem) {
   constexpr int TI = 2, NW = 4, R = TI * 16, RJ = R * 16 / (NW * 64);
   const Geom& g = p.g;
@@ -228,8 +234,11 @@ __device__ __forceinline__ void halo_dgrad_body(const DDgradArgs& p, uint32_t bi
   const int i0 = tm * (32 * TI), c0 = tc * 32;
   if (i0 >= Mc) return;                                   // block-uniform
   const int sfirst = i0 / HW, slast = min(i0 + 32 * TI - 1, Mc - 1) / HW;
-  const int RS = g.N + 4;
+  const int RS = g.N + 4;                                 // fp32 form: LDS row stride in floats
+  const int RB = g.N * 2 + 16;                            // split form: bytes per row of one bf16 plane
   const int nrows = (slast - sfirst + 1) * g.OHOW;        // staged dY rows; row `nrows` is the zero row
+  uint8_t* sb = reinterpret_cast<uint8_t*>(smem);
+  const int PS = (nrows + 1) * RB;                        // split form: bytes per plane
   {
     const float4* src = reinterpret_cast<const float4*>(p.dy + (size_t)sfirst * g.OHOW * g.N);
     const int n4row = g.N >> 2, total4 = nrows * n4row;
@@ -242,12 +251,22 @@ __device__ __forceinline__ void halo_dgrad_body(const DDgradArgs& p, uint32_t bi
         e = e < total4 ? e : 0;                            // past the end: re-copy element 0 (unconditional LDS write)
         const int row = e / n4row;
         v[q] = src[e];
-        dst[q] = row * RS + (e - row * n4row) * 4;
+        dst[q] = SPLIT ? row * RB + (e - row * n4row) * 8 : row * RS + (e - row * n4row) * 4;
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(&smem[dst[q]]) = v[q];
+      for (int q = 0; q < 8; ++q) {
+        if constexpr (SPLIT) split3_store(sb + dst[q], PS, v[q]);
+        else *reinterpret_cast<float4*>(&smem[dst[q]]) = v[q];
+      }
     }
-    for (int e = t; e < RS; e += 256) smem[nrows * RS + e] = 0.f;
+    if constexpr (SPLIT) {
+      for (int e = t; e < 3 * (RB >> 2); e += 256) {
+        const int pl = e / (RB >> 2);
+        reinterpret_cast<uint32_t*>(sb + pl * PS + nrows * RB)[e - pl * (RB >> 2)] = 0u;
+      }
+    } else {
+      for (int e = t; e < RS; e += 256) smem[nrows * RS + e] = 0.f;
+    }
   }
   const int nps = g.N >> 5;
   const int nsteps = g.KH * g.KW * nps;
@@ -280,7 +299,7 @@ __device__ __forceinline__ void halo_dgrad_body(const DDgradArgs& p, uint32_t bi
     eoff[j] = o >= 0 ? o + c0 + sl.c4 : -1;
     xv[j] = buf_load4(rs_x, o >= 0 ? (uint32_t)eoff[j] * 4u : kOob, 0u);
   }
-  const uint32_t wvoff = (uint32_t)((c0 + il) * g.N + 16 * kl) * 4u;
+  const uint32_t wvoff = (uint32_t)((c0 + il) * g.N + (SPLIT ? 8 : 16) * kl) * 4u;
   struct StageA { float4 a[TI][4]; };
   struct StageB { float4 b[4]; };
   auto loadB = [&](StageB& S_, int s, bool live) {
@@ -288,7 +307,7 @@ __device__ __forceinline__ void halo_dgrad_body(const DDgradArgs& p, uint32_t bi
     const uint32_t ws = live ? (uint32_t)((tap * g.C) * g.N + (s - tap * nps) * 32) * 4u : 0u;
     const uint32_t vo = live ? wvoff : kOob;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) S_.b[q] = buf_load4(rs_w, vo + 16u * q, ws);
+    for (int q = 0; q < 4; ++q) S_.b[q] = buf_load4(rs_w, vo + (SPLIT ? 64u * (q >> 1) + 16u * (q & 1) : 16u * q), ws);
   };
   auto loadA = [&](StageA& S_, int s, bool live) {
     const int tap = s / nps;
@@ -316,20 +335,52 @@ __device__ __forceinline__ void halo_dgrad_body(const DDgradArgs& p, uint32_t bi
       for (int ti = 0; ti < TI; ++ti)
         acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(pick(A_.a[ti][kk >> 2], kk & 3), pick(B_.b[kk >> 2], kk & 3), acc[ti], 0, 0, 0);
   };
+  // split form: one step = 2 chunks x (TI x 3 plane reads from LDS, weight chunk split in registers, TI x 6 MFMAs)
+  auto step_split = [&](const StageB& B_, int s, bool live) {
+    const int tap = s / nps;
+    const int jy = tap / g.KW, jx = tap - jy * g.KW;
+    const int nofs = (s - tap * nps) * 32;
+    int rowb[TI];
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) {
+      const bool ok = live && ((unsigned)(qy[ti] - jy) < (unsigned)g.OH) && ((unsigned)(qx[ti] - jx) < (unsigned)g.OW);
+      rowb[ti] = (ok ? r0[ti] - (jy * g.OW + jx) : nrows) * RB + (nofs + 8 * kl) * 2;
+    }
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      bf16x8 a[TI][3], b[3];
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) a[ti][pl] = *reinterpret_cast<const bf16x8*>(sb + pl * PS + rowb[ti] + ch * 32);
+      split3_regs(B_.b[2 * ch], B_.b[2 * ch + 1], b);
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) acc[ti] = mfma_bf16x6(a[ti], b, acc[ti]);
+    }
+  };
   StageB B0, B1;
   loadB(B0, s0, s0 < s1);
   loadB(B1, s0 + 1, s0 + 1 < s1);
   __syncthreads();                                        // staged dY visible
   XT_TL(1);
-  StageA A0, A1;
-  loadA(A0, s0, s0 < s1);
-  for (int s = s0; s < s1; s += 2) {
-    loadA(A1, s + 1, s + 1 < s1);
-    compute(A0, B0);
-    loadB(B0, s + 2, s + 2 < s1);
-    loadA(A0, s + 2, s + 2 < s1);
-    compute(A1, B1);
-    loadB(B1, s + 3, s + 3 < s1);
+  if constexpr (SPLIT) {
+    for (int s = s0; s < s1; s += 2) {
+      step_split(B0, s, true);
+      loadB(B0, s + 2, s + 2 < s1);
+      step_split(B1, s + 1, s + 1 < s1);
+      loadB(B1, s + 3, s + 3 < s1);
+    }
+  } else {
+    StageA A0, A1;
+    loadA(A0, s0, s0 < s1);
+    for (int s = s0; s < s1; s += 2) {
+      loadA(A1, s + 1, s + 1 < s1);
+      compute(A0, B0);
+      loadB(B0, s + 2, s + 2 < s1);
+      loadA(A0, s + 2, s + 2 < s1);
+      compute(A1, B1);
+      loadB(B1, s + 3, s + 3 < s1);
+    }
   }
   XT_TL(3);
   float flat[R];

@@ -721,15 +721,6 @@ constexpr int dgrad4_smem_floats() {
   return SPLIT ? (12 * kD4SlotA + kD4Classes * 12 * kD4SlotB) / 4 + 128 : 32 * 129 + kD4Classes * 32 * 33 + 128;
 }
 
-// 4 consecutive-k fp32 values -> three bf16 planes, 8 bytes each, at base + (plane*4 + sub)*slot + byte
-__device__ __forceinline__ void split3_store(uint8_t* base, int slot, int sub, int byte, const float4 v) {
-  const float rx = v.x - trunc_bf16(v.x), ry = v.y - trunc_bf16(v.y), rz = v.z - trunc_bf16(v.z), rw = v.w - trunc_bf16(v.w);
-  const float qx = rx - trunc_bf16(rx), qy = ry - trunc_bf16(ry), qz = rz - trunc_bf16(rz), qw = rw - trunc_bf16(rw);
-  *reinterpret_cast<uint2*>(base + (0 * 4 + sub) * slot + byte) = make_uint2(pack_hi16(v.x, v.y), pack_hi16(v.z, v.w));
-  *reinterpret_cast<uint2*>(base + (1 * 4 + sub) * slot + byte) = make_uint2(pack_hi16(rx, ry), pack_hi16(rz, rw));
-  *reinterpret_cast<uint2*>(base + (2 * 4 + sub) * slot + byte) = make_uint2(pack_hi16(qx, qy), pack_hi16(qz, qw));
-}
-
 template <bool SPLIT>
 __device__ __forceinline__ void igemm_dgrad4_body(const DgradArgs& p, const int bx, float* smem) {
   constexpr int BI = 128, SA = BI + 1, SB = 33, NA = 4;
@@ -799,10 +790,10 @@ __device__ __forceinline__ void igemm_dgrad4_body(const DgradArgs& p, const int 
       const int sub = c4 >> 1, byte = (c4 & 1) * 8;     // k = 4*c4 + e -> chunk = c4 >> 2, k half = (c4 & 3) >> 1
 #pragma unroll
       for (int i = 0; i < NA; ++i)
-        split3_store(Ap + (r0 + 32 * i) * 16, kD4SlotA, sub, byte, sel4((R.ok >> i) & 1u, R.a[i]));
+        split3_store(Ap + (r0 + 32 * i) * 16 + sub * kD4SlotA + byte, 4 * kD4SlotA, sel4((R.ok >> i) & 1u, R.a[i]));
 #pragma unroll
       for (int cls = 0; cls < kD4Classes; ++cls)
-        split3_store(Bp + cls * 12 * kD4SlotB + r0 * 16, kD4SlotB, sub, byte, R.b[cls]);
+        split3_store(Bp + cls * 12 * kD4SlotB + r0 * 16 + sub * kD4SlotB + byte, 4 * kD4SlotB, R.b[cls]);
       return;
     }
 #pragma unroll
@@ -847,13 +838,7 @@ __device__ __forceinline__ void igemm_dgrad4_body(const DgradArgs& p, const int 
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl)
             b[pl] = *reinterpret_cast<const bf16x8*>(Bp + (cls * 12 + pl * 4 + ch * 2 + kl) * kD4SlotB + il * 16);
-          // smallest terms first
-          acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[cls], 0, 0, 0);
-          acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[cls], 0, 0, 0);
-          acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[cls], 0, 0, 0);
-          acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[cls], 0, 0, 0);
-          acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[cls], 0, 0, 0);
-          acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[cls], 0, 0, 0);
+          acc[cls] = mfma_bf16x6(a, b, acc[cls]);
         }
       }
       return;
@@ -944,9 +929,9 @@ struct BwdLayerArgs {
 // HALO = true: the input-gradient blocks are halo_dgrad_body, selected at COMPILE time.  The register allocation of
 // a kernel is the maximum over all of its paths: the generic form needs 144 VGPR (LDS-tiled dgrad) + 32 AGPR
 // (register-direct dgrad) = two workgroups per CU, this one three.
-template <int WBI, int WBJ, int WWI, int WWJ, bool WPAD, int DBI, int DBJ, int DWI, int DWJ, int D4 = 0, bool HALO = false>
+template <int WBI, int WBJ, int WWI, int WWJ, bool WPAD, int DBI, int DBJ, int DWI, int DWJ, int D4 = 0, int HALO = 0>
 __global__ __launch_bounds__(256, (D4 || HALO) ? 3 : 1) void igemm_bwd_layer_kernel(const BwdLayerArgs p) {
-  constexpr int SMD = HALO ? 9 * 1024 : dgrad_smem_floats<DBI, DBJ>();
+  constexpr int SMD = HALO == 2 ? 11 * 1024 : HALO == 1 ? 9 * 1024 : dgrad_smem_floats<DBI, DBJ>();
   constexpr int SM0 = wgrad_smem_floats<WBI, WBJ, WPAD>() > SMD ? wgrad_smem_floats<WBI, WBJ, WPAD>() : SMD;
   constexpr int SM = (D4 && dgrad4_smem_floats<D4 == 2>() > SM0) ? dgrad4_smem_floats<D4 == 2>() : SM0;
   __shared__ __attribute__((aligned(16))) float smem[SM];
@@ -956,12 +941,12 @@ __global__ __launch_bounds__(256, (D4 || HALO) ? 3 : 1) void igemm_bwd_layer_ker
       igemm_dgrad4_body<D4 == 2>(p.dg, b, smem);
       return;
     }
-    if constexpr (HALO) {
-      halo_dgrad_body(p.ddg, (uint32_t)b, (uint32_t)p.n_dg, smem);
+    if constexpr (HALO != 0) {
+      halo_dgrad_body<HALO == 2>(p.ddg, (uint32_t)b, (uint32_t)p.n_dg, smem);
       return;
     }
     if (p.dg_direct == 4) {               // stride-1, small map: 64-row tiles with the dY halo staged in LDS
-      halo_dgrad_body(p.ddg, (uint32_t)b, (uint32_t)p.n_dg, smem);
+      halo_dgrad_body<false>(p.ddg, (uint32_t)b, (uint32_t)p.n_dg, smem);
       return;
     }
     if (p.dg_direct == 3) {               // the same with 64-row tiles (weight operand shared by two row tiles)
@@ -1258,7 +1243,13 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
                             dim3(total), dim3(256), 0, st, a);                                                  \
   } while (0)
   if (halo_inst) {
-    hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1, 0, true>), dim3(total), dim3(256), 0, st, a);
+    static int hx6 = -1;                 // XT_BF16X6=0: fp32 MFMA (A/B)
+    if (hx6 < 0) { const char* e = getenv("XT_BF16X6"); hx6 = (e && e[0] == '0') ? 0 : 1; }
+    const int nsamp = 63 / (g.H * g.W) + 2;
+    if (hx6 && (size_t)3 * (nsamp * g.OHOW + 1) * (g.N * 2 + 16) <= 44 * 1024)
+      hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1, 0, 2>), dim3(total), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1, 0, 1>), dim3(total), dim3(256), 0, st, a);
   } else if (a.dg_direct == 2) {
     XT_REQUIRE(wsmall && dsmall && !pad, "bwd_layer: the all-classes input gradient needs the small-tile configuration");
     static int x6 = -1;                  // XT_BF16X6=0: fp32 MFMA in the all-classes input gradient (A/B)
