@@ -297,12 +297,16 @@ def main():
                 kern["L0 conv8x8/4 wgrad [conv_u8c4k8_wgrad_flat_kernel]"] = (net.time_layer(0, 1, d_obs, idx, bsz, 50), mnk2, "bf16x3")
             else:
                 kern["L%d %s fwd  [igemm_fwd_kernel | direct_fwd_kernel]" % (li, lay.name)] = (net.time_layer(li, 0, d_obs, idx, bsz, 50), mnk2, "fp32")
+                # conv backward launches: the input-gradient half runs bf16x6 (six bf16 MFMAs per 16-deep chunk), the
+                # weight-gradient half fp32 MFMA -> peak of the launch = harmonic mean of the two halves' peaks
+                x6 = os.environ.get("XT_BF16X6", "1") != "0" and lay.KH > 1
                 kern["L%d %s dgrad+wgrad [igemm_bwd_layer_kernel]" % (li, lay.name)] = (
-                    net.time_layer(li, 3, d_obs, idx, bsz, 50), 2 * mnk2, "fp32")
+                    net.time_layer(li, 3, d_obs, idx, bsz, 50), 2 * mnk2, "fp32+bf16x6" if x6 else "fp32")
         dom = max(kern, key=lambda k: kern[k][0])
         ms, flops, kind = kern[dom]
         # fp32 kernels: v_mfma_f32_32x32x2_f32 dense peak; bf16x3 kernels spend 3 bf16 MFMA flops per algorithmic flop
-        peak = FP32_MFMA_PEAK_TFLOPS if kind == "fp32" else 2500.0 / 3.0
+        peak = {"fp32": FP32_MFMA_PEAK_TFLOPS, "bf16x3": 2500.0 / 3.0,
+                "fp32+bf16x6": 2.0 / (1.0 / FP32_MFMA_PEAK_TFLOPS + 6.0 / 2500.0)}[kind]
         ach = flops / (ms * 1e-3) / 1e12
         # HBM traffic of the dominant kernel: PMC FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch from the
         # committed rocprofv3 passes (profiles/r01_pmc_traffic.json holds every layer kernel), matched by kernel name
@@ -324,7 +328,7 @@ def main():
                         break
             except (OSError, ValueError, KeyError):
                 traffic = None
-        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "arith": kind, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                            "frac": ach / peak, "traffic": traffic, "flop_per_launch": flops, "avg_launch_ms": ms,
                            "kernels_us": {k: round(v[0] * 1e3, 2) for k, v in kern.items()},
                            "sum_layer_kernels_us": round(sum(v[0] for v in kern.values()) * 1e3, 1)}
