@@ -90,11 +90,13 @@ def _mk(which, batch):
     return net, ospec, sd, u8
 
 
-@pytest.mark.parametrize("which,b", [("cnn84", 48), ("cnn84", 320), ("cnn42_unshared", 33), ("cnn42_a18", 40), ("cnn30_inferred", 50),
-                                     ("mlp", 200)])
+@pytest.mark.parametrize("which,b", [("cnn84", 48), ("cnn84", 320), ("cnn84", 261), ("cnn42_unshared", 33), ("cnn42_a18", 40),
+                                     ("cnn30_inferred", 50), ("mlp", 200)])
 def test_ppo_step_loss_and_grads_vs_oracle(which, b):
     """b = 320 is BASELINE.json's minibatch (breakout_ppo.yaml BATCH_SIZE): the launch configurations of the
-    benchmark (320 first-layer workgroups, two-wave-group forwards, register-direct conv2) against the oracle."""
+    benchmark (flattened first-layer kernels, two-wave-group forwards, register-direct conv2, bf16x6 input
+    gradients, halo-staged conv3 input gradient) against the oracle; b = 261 is the same set of kernels with ragged
+    last tiles (position ranges, 64-row input-gradient tiles and 128-position class tiles that end mid-tile)."""
     net, ospec, sd, u8 = _mk(which, b)
     params = oracle_params_for(net, ospec, seed=7)
     rng = np.random.default_rng(0)
