@@ -116,11 +116,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_u8c4k8_fwd_bf16x3_kernel
       aq[ti] = *reinterpret_cast<const uint2*>(limg + poff[ti] + koff);   // tiles beyond ntiles read pixel 0: harmless
   };
   lds_fetch(0);
-#ifdef XT_C1_NOLOOP
-  for (int s = 0; s < 1; ++s) {
-#else
   for (int s = 0; s < nsteps; ++s) {
-#endif
     BF8 bp[3];
     bf16x8 av[kC1MaxTiles];
 #pragma unroll
@@ -156,12 +152,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_u8c4k8_fwd_bf16x3_kernel
       for (int q = 0; q < 4; ++q) {
         const int row = q * 8 + (lane >> 3), c4 = (lane & 7) * 4;
         const float4 v = *reinterpret_cast<const float4*>(&tbuf[row * 36 + c4]);
-#ifdef XT_C1_NOSTORE
-        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-        if (pix0 + row < OHOW && v.x == 12345.678f)
-#else
         if (pix0 + row < OHOW)
-#endif
           *reinterpret_cast<float4*>(&p.y[((size_t)b * OHOW + pix0 + row) * 32 + c4]) = v;
       }
     }

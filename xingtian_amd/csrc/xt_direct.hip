@@ -33,24 +33,10 @@
 
 namespace xt {
 
-// Fixed-order combine of the NW per-wave partial tiles + distributed epilogue.  red: [NW][R][64] floats.
-// emit(r, v) is called by exactly one wave per accumulator register r (r = tile * 16 + reg).
-template <int R, typename F>
-__device__ __forceinline__ void combine_and_emit(float* red, const float (&flat)[R], int w, int NW, int lane, F emit) {
-#pragma unroll
-  for (int r = 0; r < R; ++r) red[(w * R + r) * 64 + lane] = flat[r];
-  __syncthreads();
-  for (int r = w; r < R; r += NW) {
-    float v = red[r * 64 + lane];
-    for (int q = 1; q < NW; ++q) v += red[(q * R + r) * 64 + lane];
-    emit(r, v);
-  }
-}
-
-// The same combine, emitted as 16-byte row pieces: red[q][r][kl*32 + il] holds element (row(r, kl), column il) of
-// wave q's partial tile, so four consecutive columns of one row are contiguous in LDS.  Slot e of the R*16 float4
+// Fixed-order combine of the NW per-wave partial tiles (red: [NW][R][64] floats), emitted as 16-byte row pieces:
+// red[q][r][kl*32 + il] holds element (row(r, kl), column il) of wave q's partial tile, so four consecutive columns of one row are contiguous in LDS.  Slot e of the R*16 float4
 // slots: columns 4*(e & 7).., kl = (e >> 3) & 1, r = e >> 4 -> eight consecutive lanes cover one 128-byte row of a
-// 32-column tile (the dword form stored two rows per instruction).  Summation order q = 0..NW-1 as above.
+// 32-column tile (the dword form stored two rows per instruction).  Summation order q = 0..NW-1.
 // emit4(r, kl, c4, v): r = tile * 16 + reg.
 template <int R, typename F>
 __device__ __forceinline__ void combine_and_emit4(float* red, const float (&flat)[R], int w, int NW, int lane, F emit4) {
