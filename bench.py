@@ -182,11 +182,15 @@ def main():
     ap.add_argument("--force-dp-path", action="store_true",
                     help="run the N>1 code path (step-wise fwd/bwd -> RCCL all-reduce -> clip+Adam) even with one rank: "
                          "validates the data-parallel plumbing on a single GPU")
-    ap.add_argument("--dp-overlap", action="store_true",
-                    help="data-parallel path: two-bucket form (Dense+heads gradient all-reduced asynchronously under "
-                         "the conv backward) instead of one all-reduce after the backward pass.  Off by default: on one "
-                         "rank the two extra c10d calls per SGD step make the eager path host-bound (13.2 vs 10.1 ms "
-                         "per update); it pays off once the all-reduce itself costs more than ~60 us")
+    ap.add_argument("--dp-mode", default="eager", choices=["eager", "eager-overlap", "graph", "graph-overlap"],
+                    help="data-parallel path (N>1 or --force-dp-path).  eager (default): step-wise fwd/bwd -> one RCCL "
+                         "all-reduce of the flat gradient -> clip+Adam.  *overlap: two buckets, the Dense+heads gradient "
+                         "(95 %% of the bytes) all-reduced asynchronously under the conv backward.  graph*: the compute "
+                         "segments replayed from hipGraphs (parallel.DpGraphStepper).  Measured with a 1-rank RCCL group "
+                         "(ms per update): eager 8.4, graph 9.4, eager-overlap 11.4, graph-overlap 12.2 -- three small graph "
+                         "launches cost more than the dozen eager launches they replace, and every extra c10d call with "
+                         "its cross-stream events about 25 us; the alternatives are kept for interconnects where the "
+                         "all-reduce itself is the larger term")
     ap.add_argument("--workload", default="ppo", choices=["ppo", "impala"],
                     help="ppo = BASELINE configs[1] (the headline metric, default); impala = configs[2] "
                          "(breakout_impala.yaml, ImpalaCnnOpt + v-trace, env_num=64 messages of T=128), secondary")
@@ -211,7 +215,7 @@ def main():
     from xingtian_amd import lib as L
     from xingtian_amd.model import netspec
     from xingtian_amd.model.hip_net import HipActorCritic
-    from xingtian_amd.parallel import dp_ppo_step
+    from xingtian_amd.parallel import DpGraphStepper, dp_ppo_step
 
     dev = torch.device("cuda", local_rank)
     obs, action, logp, value, reward, done = synth_rollout(seed=rank)
@@ -240,6 +244,11 @@ def main():
             p[ep] = inds
         d_perm.copy_(torch.from_numpy(p), non_blocking=False)
 
+    stepper = None
+    if dp_path and args.dp_mode.startswith("graph"):
+        stepper = DpGraphStepper(net, cfg, CFG["LR"], CFG["MAX_GRAD_NORM"], d_obs, d_act, d_logp, d_adv, d_oldv, d_tgt,
+                                 world, overlap=(args.dp_mode == "graph-overlap"))
+
     def one_update():
         new_perms()
         st = L.stream_ptr()
@@ -252,8 +261,11 @@ def main():
                 for start in range(0, n, bsz):
                     idx = d_perm[ep, start:start + bsz]
                     # fwd/bwd -> RCCL sum over xGMI (Dense+heads bucket overlapped with the conv backward) -> clip+Adam
-                    dp_ppo_step(net, cfg, CFG["LR"], CFG["MAX_GRAD_NORM"], d_obs, idx, d_act, d_logp, d_adv, d_oldv,
-                                d_tgt, world, overlap=args.dp_overlap)
+                    if stepper is not None:
+                        stepper.step(idx)
+                    else:
+                        dp_ppo_step(net, cfg, CFG["LR"], CFG["MAX_GRAD_NORM"], d_obs, idx, d_act, d_logp, d_adv, d_oldv,
+                                    d_tgt, world, overlap=(args.dp_mode == "eager-overlap"))
 
     def barrier():
         if dist is not None:
@@ -335,6 +347,8 @@ def main():
         total_flops = 31.313e6 * n * CFG["NUM_SGD_ITER"]
         out["update_tflops"] = total_flops * args.steps / elapsed / 1e12
         out["config"]["dp_path"] = bool(dp_path)
+        if dp_path:
+            out["config"]["dp_mode"] = args.dp_mode if not (stepper is not None and stepper.failed) else "eager (capture failed)"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(obs, action, logp, value, reward, done)
         _emit(out)

@@ -583,6 +583,48 @@ def test_dp_step_halves_equal_one_shot_step_and_overlapped_allreduce(which):
             dist.destroy_process_group()
 
 
+def test_dp_graph_stepper_is_bitwise_the_eager_data_parallel_step():
+    """parallel.DpGraphStepper (hipGraph-replayed compute segments + c10d all-reduces, two-bucket overlap) against the
+    eager dp_ppo_step on a 1-rank RCCL group: same parameters bit for bit after several steps with two minibatch
+    sizes (each size has its own captured graphs; the minibatch indices go through a fixed staging buffer)."""
+    import torch.distributed as dist
+    from xingtian_amd import parallel
+    b = 64
+    net, ospec, sd, u8 = _mk("cnn84", b)
+    oracle_params_for(net, ospec, 41)
+    rng = np.random.default_rng(42)
+    obs, lab = synth_ppo_rollout(rng, 300, sd, net.spec.action_dim, u8=u8)
+    c = net.make_ppo_cfg(dict(PPO_CFG, BATCH_SIZE=b))
+    d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).cuda()
+    data = (net.to_device_obs(obs), d(lab[0], np.int32), d(lab[1].reshape(-1), np.float32),
+            d(lab[2].reshape(-1), np.float64), d(lab[3].reshape(-1), np.float32), d(lab[4].reshape(-1), np.float64))
+    perm = d(rng.permutation(300), np.int32)
+    batches = [perm[0:64], perm[64:128], perm[128:168], perm[168:232], perm[232:272]]      # sizes 64, 64, 40, 64, 40
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29578", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        w0 = net.params.clone()
+        m0, v0, s0 = net.adam_m.clone(), net.adam_v.clone(), net.adam_state.clone()
+        for idx in batches:
+            parallel.dp_ppo_step(net, c, PPO_CFG["LR"], PPO_CFG["MAX_GRAD_NORM"], data[0], idx, *data[1:], world=1)
+        w_eager = net.params.clone()
+        for overlap in (True, False):
+            net.params.copy_(w0); net.adam_m.copy_(m0); net.adam_v.copy_(v0); net.adam_state.copy_(s0)
+            st = parallel.DpGraphStepper(net, c, PPO_CFG["LR"], PPO_CFG["MAX_GRAD_NORM"], *data, world=1,
+                                         overlap=overlap, warm_steps=0)
+            for idx in batches:
+                st.step(idx)
+            torch.cuda.synchronize()
+            assert not st.failed and sorted(st.graphs) == [40, 64]
+            assert torch.equal(net.params, w_eager) and not torch.equal(w_eager, w0)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_impala_lr_schedule_linear_cosine_decay_drives_the_adam_step_size():
     """lr_schedule (impala_cnn_opt.py:199-203,236-249): the step size of update k is linear_cosine_decay at
     global_step k; the device-side lr_t = lr * sqrt(1-b2^t)/(1-b1^t) must follow it."""

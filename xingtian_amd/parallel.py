@@ -85,3 +85,92 @@ def dp_ppo_step(net, cfg_struct, lr, max_grad_norm, obs, idx, action, old_logp, 
         if w_head is not None:
             w_head.wait()
     net.apply(lr, max_grad_norm, grad_scale=grad_scale("mean", world))
+
+
+class DpGraphStepper(object):
+    """Data-parallel PPO SGD steps with the compute segments replayed from hipGraphs.
+
+    The eager step enqueues ~12 kernels through three ctypes calls plus one or two c10d calls per SGD step; at
+    ~155 us of GPU work per step that leaves the host little slack, and the two-bucket overlap (``dp_ppo_step``,
+    ``overlap=True``) made the eager path host-bound.  Here each compute segment (forward + heads + first backward
+    launch | rest of the backward | clip + Adam) is captured ONCE per minibatch size with ``torch.cuda.graph`` -- the
+    library launches on torch's current stream, so its kernels are captured like torch's own -- and a step is
+    ``copy the minibatch indices into a fixed buffer -> replay -> all-reduce -> replay -> all-reduce -> replay``.
+    The all-reduces stay ordinary c10d calls on RCCL's stream (tied to the replays by c10d's stream events), exactly
+    as in the eager form, so the arithmetic, its order and therefore the replicas' bits are unchanged.
+
+    Any failure while capturing (an unsupported call under capture, a driver refusing it) permanently falls back to
+    the eager ``dp_ppo_step`` -- a benchmark must never die on an optimisation.
+    """
+
+    def __init__(self, net, cfg_struct, lr, max_grad_norm, obs, action, old_logp, adv, old_v, target_v, world,
+                 overlap=True, warm_steps=2):
+        self.net, self.cfg, self.lr, self.clip = net, cfg_struct, lr, max_grad_norm
+        self.data = (obs, action, old_logp, adv, old_v, target_v)
+        self.world, self.overlap = world, bool(overlap)
+        self.grouped = dist.is_available() and dist.is_initialized()
+        self.idx_buf = torch.empty((net.max_batch,), dtype=torch.int32, device=net.params.device)
+        self.graphs = {}
+        self.eager_left = int(warm_steps)     # the first steps run eagerly: one-time host work stays outside captures
+        self.failed = False
+        self.scale = grad_scale("mean", world)
+
+    def _eager(self, idx):
+        obs, action, old_logp, adv, old_v, target_v = self.data
+        dp_ppo_step(self.net, self.cfg, self.lr, self.clip, obs, idx, action, old_logp, adv, old_v, target_v,
+                    self.world, overlap=False)
+
+    def _capture(self, b):
+        net = self.net
+        obs, action, old_logp, adv, old_v, target_v = self.data
+        idx = self.idx_buf[:b]
+        seg = {}
+        g1 = torch.cuda.CUDAGraph()
+        if self.overlap and self.grouped:
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                seg["tail"] = net.ppo_step_begin(self.cfg, obs, idx, action, old_logp, adv, old_v, target_v)
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+                net.ppo_step_end(self.cfg, obs, idx)
+            seg["end"] = g2
+        else:
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                net.ppo_step(self.cfg, obs, idx, action, old_logp, adv, old_v, target_v, apply=False)
+        seg["begin"] = g1
+        g3 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g3, capture_error_mode="thread_local"):
+            net.apply(self.lr, self.clip, grad_scale=self.scale)
+        seg["apply"] = g3
+        return seg
+
+    def step(self, idx):
+        """One SGD step on the rows ``idx`` (int32 device tensor) of the resident rollout."""
+        if self.failed or self.eager_left > 0:
+            self.eager_left -= 1
+            return self._eager(idx)
+        b = int(idx.numel())
+        seg = self.graphs.get(b)
+        if seg is None:
+            try:
+                seg = self._capture(b)
+            except Exception as exc:       # noqa: BLE001 -- fall back, never fail the run
+                import sys
+                print("[xingtian_amd.parallel] hipGraph capture of the data-parallel step failed (%r): eager path"
+                      % (exc,), file=sys.stderr)
+                self.failed = True
+                return self._eager(idx)
+            self.graphs[b] = seg
+        net = self.net
+        self.idx_buf[:b].copy_(idx, non_blocking=True)
+        seg["begin"].replay()
+        if "end" in seg:
+            tail = seg["tail"]
+            w_tail = dist.all_reduce(net.grads[tail:], op=dist.ReduceOp.SUM, async_op=True)
+            seg["end"].replay()
+            w_head = dist.all_reduce(net.grads[:tail], op=dist.ReduceOp.SUM, async_op=True) if tail > 0 else None
+            w_tail.wait()
+            if w_head is not None:
+                w_head.wait()
+        else:
+            allreduce_sum_(net.grads)
+        seg["apply"].replay()
