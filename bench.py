@@ -182,7 +182,7 @@ def main():
     ap.add_argument("--force-dp-path", action="store_true",
                     help="run the N>1 code path (step-wise fwd/bwd -> RCCL all-reduce -> clip+Adam) even with one rank: "
                          "validates the data-parallel plumbing on a single GPU")
-    ap.add_argument("--dp-mode", default="eager", choices=["eager", "eager-overlap", "graph", "graph-overlap"],
+    ap.add_argument("--dp-mode", default="eager", choices=["eager", "eager-overlap", "graph", "graph-overlap", "ingraph"],
                     help="data-parallel path (N>1 or --force-dp-path).  eager (default): step-wise fwd/bwd -> one RCCL "
                          "all-reduce of the flat gradient -> clip+Adam.  *overlap: two buckets, the Dense+heads gradient "
                          "(95 %% of the bytes) all-reduced asynchronously under the conv backward.  graph*: the compute "
@@ -190,7 +190,9 @@ def main():
                          "(ms per update): eager 8.4, graph 9.4, eager-overlap 11.4, graph-overlap 12.2 -- three small graph "
                          "launches cost more than the dozen eager launches they replace, and every extra c10d call with "
                          "its cross-stream events about 25 us; the alternatives are kept for interconnects where the "
-                         "all-reduce itself is the larger term")
+                         "all-reduce itself is the larger term.  ingraph: raw RCCL all-reduces enqueued by the library "
+                         "itself (xt_net_set_grad_exchange) and captured into the hipGraph of the whole update -- no "
+                         "host involvement per step; validated on one rank only, hence opt-in")
     ap.add_argument("--workload", default="ppo", choices=["ppo", "impala"],
                     help="ppo = BASELINE configs[1] (the headline metric, default); impala = configs[2] "
                          "(breakout_impala.yaml, ImpalaCnnOpt + v-trace, env_num=64 messages of T=128), secondary")
@@ -215,7 +217,7 @@ def main():
     from xingtian_amd import lib as L
     from xingtian_amd.model import netspec
     from xingtian_amd.model.hip_net import HipActorCritic
-    from xingtian_amd.parallel import DpGraphStepper, dp_ppo_step
+    from xingtian_amd.parallel import DpGraphStepper, RcclComm, dp_ppo_step
 
     dev = torch.device("cuda", local_rank)
     obs, action, logp, value, reward, done = synth_rollout(seed=rank)
@@ -244,6 +246,12 @@ def main():
             p[ep] = inds
         d_perm.copy_(torch.from_numpy(p), non_blocking=False)
 
+    rccl = None
+    if dp_path and args.dp_mode == "ingraph":
+        rccl = RcclComm(rank, world)
+        rccl.all_reduce_(net.grads.zero_(), L.stream_ptr())      # RCCL's lazy set-up outside any capture
+        torch.cuda.synchronize()
+        rccl.attach(net)
     stepper = None
     if dp_path and args.dp_mode.startswith("graph"):
         stepper = DpGraphStepper(net, cfg, CFG["LR"], CFG["MAX_GRAD_NORM"], d_obs, d_act, d_logp, d_adv, d_oldv, d_tgt,
@@ -254,8 +262,9 @@ def main():
         st = L.stream_ptr()
         L.check(lib.xt_gae_f64(L.ptr(d_value), L.ptr(d_reward), L.ptr(d_done), L.ptr(d_adv), L.ptr(d_tgt),
                                L.ptr(d_oldv), ENV_NUM, T_LEN, 0.99, 0.95, st), "gae")
-        if not dp_path:
-            net.ppo_train(cfg, d_obs, d_perm, d_act, d_logp, d_adv, d_oldv, d_tgt, use_graph=use_graph)
+        if not dp_path or rccl is not None:
+            net.ppo_train(cfg, d_obs, d_perm, d_act, d_logp, d_adv, d_oldv, d_tgt,
+                          use_graph=(use_graph or rccl is not None) and not args.no_graph)
         else:
             for ep in range(CFG["NUM_SGD_ITER"]):
                 for start in range(0, n, bsz):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define XT_ABI_VERSION 3
+#define XT_ABI_VERSION 4
 
 #define XT_ACT_NONE 0
 #define XT_ACT_RELU 1
@@ -261,6 +261,20 @@ int xt_net_ppo_train(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, int32_
                      const int32_t* perm, const void* action, const float* old_logp,
                      const double* adv, const float* old_v, const double* target_v,
                      float* loss_acc, int32_t use_graph, void* stream);
+
+/* Gradient exchange hook of xt_net_ppo_train (ABI >= 4): the reference's learner is single-process
+ * (its grad_communicate host averaging, xt/framework/trainer.py:89-92, is dead code); data parallelism is this
+ * library's own extension.  When a hook is set, every SGD step of xt_net_ppo_train runs as
+ *     gradient-only step -> fn(net.grads, n_params, user, stream) -> global norm of the EXCHANGED gradient,
+ *     clip, Adam
+ * on the same stream, so that with use_graph != 0 the exchange is captured into the hipGraph of the update
+ * together with the kernels (fn is then called at capture time only).  fn must enqueue an in-place SUM
+ * all-reduce of `count` floats at `grads` on `stream` and return 0 -- e.g. a wrapper around
+ * ncclAllReduce(grads, grads, count, ncclFloat, ncclSum, comm, stream) of the RCCL instance the process already
+ * uses (xingtian_amd/parallel.py::RcclComm).  cfg.grad_scale / cfg.global_batch carry the 1/world scaling as in
+ * the step-wise path.  fn == NULL removes the hook. */
+typedef int (*xt_grad_exchange_fn)(float* grads, int64_t count, void* user, void* stream);
+int xt_net_set_grad_exchange(xt_net* net, xt_grad_exchange_fn fn, void* user);
 
 typedef struct xt_impala_cfg {
   float lr, beta1, beta2, eps;

@@ -625,6 +625,48 @@ def test_dp_graph_stepper_is_bitwise_the_eager_data_parallel_step():
             dist.destroy_process_group()
 
 
+def test_gradient_exchange_hook_in_the_update_graph_matches_the_stepwise_data_parallel_path():
+    """C ABI >= 4: xt_net_set_grad_exchange + a raw 1-rank RCCL communicator (parallel.RcclComm).  The whole-update
+    entry point then runs gradient-only step -> ncclAllReduce on the learner's stream -> norm/clip/Adam, captured
+    into ONE hipGraph; two updates (capture + replay) must leave the parameters bit-identical to the step-wise
+    data-parallel path (ppo_step(apply=False) -> all-reduce -> xt_net_apply) over the same minibatches."""
+    from xingtian_amd import lib as L, parallel
+    b = 64
+    net, ospec, sd, u8 = _mk("cnn84", b)
+    oracle_params_for(net, ospec, 51)
+    rng = np.random.default_rng(52)
+    n = 200                                   # 3 full minibatches + one of 8 rows per epoch
+    obs, lab = synth_ppo_rollout(rng, n, sd, net.spec.action_dim, u8=u8)
+    cfgd = dict(PPO_CFG, BATCH_SIZE=b, NUM_SGD_ITER=2)
+    c = net.make_ppo_cfg(cfgd)
+    d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).cuda()
+    data = (net.to_device_obs(obs), d(lab[0], np.int32), d(lab[1].reshape(-1), np.float32),
+            d(lab[2].reshape(-1), np.float64), d(lab[3].reshape(-1), np.float32), d(lab[4].reshape(-1), np.float64))
+    perm = d(np.stack([rng.permutation(n), rng.permutation(n)]), np.int32)
+    w0 = net.params.clone()
+    m0, v0, s0 = net.adam_m.clone(), net.adam_v.clone(), net.adam_state.clone()
+    for _ in range(2):                        # step-wise reference (no process group: the all-reduce is the identity)
+        for ep in range(2):
+            for start in range(0, n, b):
+                parallel.dp_ppo_step(net, c, cfgd["LR"], cfgd["MAX_GRAD_NORM"], data[0], perm[ep, start:start + b],
+                                     *data[1:], world=1)
+    w_ref = net.params.clone()
+    net.params.copy_(w0); net.adam_m.copy_(m0); net.adam_v.copy_(v0); net.adam_state.copy_(s0)
+    comm = parallel.RcclComm(0, 1)
+    try:
+        comm.all_reduce_(net.grads.zero_(), L.stream_ptr())
+        torch.cuda.synchronize()
+        comm.attach(net)
+        for _ in range(2):
+            net.ppo_train(c, data[0], perm, *data[1:], use_graph=True)
+        torch.cuda.synchronize()
+        assert not comm.errors
+        assert torch.equal(net.params, w_ref) and not torch.equal(w_ref, w0)
+    finally:
+        comm.detach(net)
+        comm.destroy()
+
+
 def test_impala_lr_schedule_linear_cosine_decay_drives_the_adam_step_size():
     """lr_schedule (impala_cnn_opt.py:199-203,236-249): the step size of update k is linear_cosine_decay at
     global_step k; the device-side lr_t = lr * sqrt(1-b2^t)/(1-b1^t) must follow it."""

@@ -86,6 +86,8 @@ struct xt_net {
   int64_t partial_floats;
   int head_chunks = 0, norm_blocks = 0;
   // graph cache for ppo_train
+  xt_grad_exchange_fn xchg = nullptr;  // xt_net_set_grad_exchange
+  void* xchg_user = nullptr;
   hipGraphExec_t gexec = nullptr;
   hipStream_t cap_stream = nullptr;   // capture happens on our own stream: the legacy null stream cannot be captured
   // fork/join: weight-gradient kernels run on side streams next to the dgrad chain (also inside the graph)
@@ -585,8 +587,19 @@ static int ppo_train_enqueue(xt_net* net, const xt_ppo_cfg* c, const void* obs, 
       xt_ppo_cfg cc = *c;
       if (cc.global_batch > 0 && B != c->batch_size)   // short last minibatch: keep the local/global ratio
         cc.global_batch = (int)((long long)cc.global_batch * B / c->batch_size);
+      if (!net->xchg) {
+        if (int rc = xt::ppo_step(net, &cc, obs, perm + (size_t)ep * n + start, B, action, old_logp, adv, old_v,
+                                  target_v, 1, nullptr, loss_acc, st))
+          return rc;
+        continue;
+      }
+      // data parallel: local gradient -> exchange (SUM over the replicas, on this stream) -> norm of the exchanged
+      // gradient, clip, Adam
       if (int rc = xt::ppo_step(net, &cc, obs, perm + (size_t)ep * n + start, B, action, old_logp, adv, old_v,
-                                target_v, 1, nullptr, loss_acc, st))
+                                target_v, 0, nullptr, loss_acc, st))
+        return rc;
+      XT_REQUIRE(net->xchg(net->grads, net->P, net->xchg_user, st) == 0, "xt_net_ppo_train: gradient exchange hook failed");
+      if (int rc = xt::net_apply(net, cc.lr, cc.beta1, cc.beta2, cc.eps, cc.max_grad_norm, cc.grad_scale, 0, nullptr, st))
         return rc;
     }
   }
@@ -603,7 +616,8 @@ int xt_net_ppo_train(xt_net* net, const xt_ppo_cfg* c, const void* obs, int32_t 
   if (!use_graph)
     return ppo_train_enqueue(net, c, obs, n, perm, action, old_logp, adv, old_v, target_v, loss_acc, st);
   char key[512];
-  snprintf(key, sizeof(key), "%p|%d|%p|%p|%p|%p|%p|%p|%p|%g|%g|%g|%g|%g|%g|%g|%g|%g|%d|%d|%g|%d", obs, n,
+  snprintf(key, sizeof(key), "%p|%p|%p|%d|%p|%p|%p|%p|%p|%p|%p|%g|%g|%g|%g|%g|%g|%g|%g|%g|%d|%d|%g|%d",
+           (void*)net->xchg, net->xchg_user, obs, n,
            (const void*)perm, (const void*)action, (const void*)old_logp, (const void*)adv, (const void*)old_v,
            (const void*)target_v, (void*)loss_acc, c->lr, c->beta1, c->beta2, c->eps, c->clip_ratio, c->ent_coef,
            c->vf_clip, c->critic_coef, c->max_grad_norm, c->batch_size, c->num_sgd_iter, c->grad_scale,
@@ -665,6 +679,13 @@ int xt_net_impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int32
                                    n->ws + n->off_norm, n->norm_blocks, c->grad_norm_clip, c->grad_scale, st);
   XT_REQUIRE(c->opt_type == XT_OPT_ADAM, "xt_net_impala_step: unknown opt_type %d", c->opt_type);
   return xt::net_apply(n, c->lr, c->beta1, c->beta2, c->eps, c->grad_norm_clip, c->grad_scale, 3, nullptr, st);
+}
+
+int xt_net_set_grad_exchange(xt_net* net, xt_grad_exchange_fn fn, void* user) {
+  XT_REQUIRE(net, "xt_net_set_grad_exchange: null net");
+  net->xchg = fn;
+  net->xchg_user = fn ? user : nullptr;
+  return 0;
 }
 
 int xt_net_apply(xt_net* n, float lr, float beta1, float beta2, float eps, float clip_norm, float grad_scale,

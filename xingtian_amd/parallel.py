@@ -174,3 +174,79 @@ class DpGraphStepper(object):
         else:
             allreduce_sum_(net.grads)
         seg["apply"].replay()
+
+
+class RcclComm(object):
+    """A raw RCCL communicator for the gradient-exchange hook of ``xt_net_ppo_train`` (C ABI >= 4).
+
+    ``torch.distributed`` owns its communicator and issues collectives on its own stream from Python, one call per
+    SGD step.  The hook form instead enqueues ``ncclAllReduce`` on the stream the learner kernels run on, from inside
+    ``xt_net_ppo_train`` -- so the 52 all-reduces of an update are captured into the update's hipGraph and replayed
+    without any host involvement.  The communicator is created with ctypes on the ``librccl.so`` that torch ships
+    (already loaded in the process); the 128-byte unique id travels through the existing ``torch.distributed`` group.
+
+    Opt-in (``bench.py --dp-mode ingraph``): validated with a 1-rank communicator on one GPU (bit-identical to the
+    step-wise path); multi-rank runs were not possible in the round that added it.
+    """
+    NCCL_FLOAT32, NCCL_SUM = 7, 0
+
+    def __init__(self, rank, world):
+        import ctypes
+        import os
+        self._ct = ctypes
+        self.rank, self.world = int(rank), int(world)
+        self.lib = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+        class UniqueId(ctypes.Structure):
+            _fields_ = [("internal", ctypes.c_byte * 128)]
+
+        uid = UniqueId()
+        if self.rank == 0:
+            self._check(self.lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+        if self.world > 1:
+            t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device="cuda")
+            dist.broadcast(t, src=0)
+            ctypes.memmove(ctypes.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+        self.comm = ctypes.c_void_p()
+        self.lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+        self.lib.ncclCommInitRank.restype = ctypes.c_int
+        self._check(self.lib.ncclCommInitRank(ctypes.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
+        self.lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_void_p, ctypes.c_void_p]
+        self.lib.ncclAllReduce.restype = ctypes.c_int
+        self.errors = []
+
+        def _exchange(grads, count, user, stream):
+            rc = self.lib.ncclAllReduce(grads, grads, count, self.NCCL_FLOAT32, self.NCCL_SUM, self.comm, stream)
+            if rc != 0:
+                self.errors.append(rc)
+            return rc
+
+        self._cb_type = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p)
+        self._cb = self._cb_type(_exchange)          # keep alive: the library stores the raw pointer
+
+    @staticmethod
+    def _check(rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed with ncclResult %d" % (what, rc))
+
+    def all_reduce_(self, flat, stream_ptr):
+        """Eager in-place SUM all-reduce of a float32 device tensor on the given stream (also warms RCCL up before
+        the first capture: its lazy allocations must not happen under stream capture)."""
+        self._check(self.lib.ncclAllReduce(flat.data_ptr(), flat.data_ptr(), flat.numel(), self.NCCL_FLOAT32,
+                                           self.NCCL_SUM, self.comm, stream_ptr), "ncclAllReduce")
+
+    def attach(self, net):
+        from xingtian_amd import lib as L
+        L.check(net.lib.xt_net_set_grad_exchange(net.handle, self._ct.cast(self._cb, self._ct.c_void_p), None),
+                "xt_net_set_grad_exchange")
+
+    def detach(self, net):
+        from xingtian_amd import lib as L
+        L.check(net.lib.xt_net_set_grad_exchange(net.handle, None, None), "xt_net_set_grad_exchange")
+
+    def destroy(self):
+        if self.comm:
+            self.lib.ncclCommDestroy.argtypes = [self._ct.c_void_p]
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = self._ct.c_void_p()
