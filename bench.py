@@ -304,7 +304,7 @@ def main():
                                "BATCH_SIZE=320/GPU, NUM_SGD_ITER=4, hidden 256, A=4; step = GAE + full PPO update "
                                "(52 SGD steps) on an HBM-resident rollout",
                    "env_steps_per_update": n * world, "sgd_steps_per_update": CFG["NUM_SGD_ITER"] * ((n + bsz - 1) // bsz),
-                   "parallelism": "dp{}".format(world), "hip_graph": bool(use_graph)},
+                   "parallelism": "dp{}".format(world), "hip_graph": bool((use_graph or rccl is not None) and not args.no_graph)},
     }
     if rank == 0:
         # ---- roofline of the dominant kernel: every layer kernel of one SGD step timed live with HIP events on
