@@ -1,7 +1,8 @@
 """Oracle (test infrastructure): golden vectors of the reference's ALGORITHM-level host logic, produced by
 EXECUTING the reference.
 
-``xt/algorithm/ppo/ppo.py::PPO`` and ``xt/algorithm/impala/impala_opt.py::IMPALAOpt`` (with their real base class
+``xt/algorithm/ppo/ppo.py::PPO``, ``xt/algorithm/impala/impala_opt.py::IMPALAOpt`` and
+``xt/algorithm/impala/impala.py::IMPALA`` (with their real base class
 ``xt/algorithm/algorithm.py``, ``xt/algorithm/alg_utils.py``, ``zeus/common/util/common.py::import_config`` and
 ``xt/algorithm/impala/default_config.py``) are loaded from /root/reference with importlib.  Only what cannot be
 imported here is stubbed: ``absl.logging`` (-> stdlib logging), ``zeus.common.util.register.Registers``
@@ -12,7 +13,8 @@ fixture pins what the framework hands to ``Model.train`` -- concatenation order 
 IMPALA's sequential BATCH_SIZE chunking, the loss it returns.  One numpy alias is restored (``np.bool``, removed in
 numpy 1.24, used by impala_opt.py:144).
 
-Writes tests/golden/alg_ppo.npz and tests/golden/alg_impala_opt.npz; nothing at test time reads /root/reference.
+Writes tests/golden/alg_ppo.npz, alg_impala_opt.npz and alg_impala.npz (the non-opt ``IMPALA``: actor forward over all
+stored states, numpy v-trace on probabilities, BATCH_SIZE chunks); nothing at test time reads /root/reference.
 
 Usage:  python oracle/gen_golden_alg.py
 """
@@ -39,6 +41,17 @@ class RecordingModel(object):
         cp = lambda a: [np.array(x, copy=True) for x in a] if isinstance(a, (list, tuple)) else np.array(a, copy=True)
         self.calls.append((cp(state), cp(label)))
         return 0.5 + len(self.calls)
+
+    def predict(self, state):
+        """IMPALA (non-opt) runs the actor over every stored state before its numpy v-trace: deterministic
+        probabilities / values, kept so that the test's stand-in model can return the very same arrays."""
+        n, a_dim = len(state[0]), self.model_info["action_dim"]
+        rng = np.random.default_rng(4242 + n)
+        logits = rng.standard_normal((n, a_dim))
+        p = np.exp(logits - logits.max(-1, keepdims=True))
+        self.pred = [(p / p.sum(-1, keepdims=True)).astype(np.float32), rng.standard_normal((n, 1)).astype(np.float32)]
+        self.pred_state = np.array(state[0], copy=True)
+        return self.pred
 
 
 def _load(name, path):
@@ -89,7 +102,8 @@ def load_reference_algorithms():
     _load("xt.algorithm.impala.default_config", "xt/algorithm/impala/default_config.py")
     ppo = _load("xt.algorithm.ppo.ppo", "xt/algorithm/ppo/ppo.py")
     imp = _load("xt.algorithm.impala.impala_opt", "xt/algorithm/impala/impala_opt.py")
-    return ppo.PPO, imp.IMPALAOpt
+    imp0 = _load("xt.algorithm.impala.impala", "xt/algorithm/impala/impala.py")
+    return ppo.PPO, imp.IMPALAOpt, imp0.IMPALA
 
 
 def ppo_inputs(seed=0):
@@ -118,6 +132,25 @@ def impala_inputs(seed=1):
     return msgs
 
 
+def impala_plain_inputs(seed=2, episode_len=6, a_dim=3):
+    """Two fragments of episode_len transitions (episode_len + 1 states each) as the IMPALA agent ships them:
+    one-hot ``real_action``, behaviour probabilities in ``action``."""
+    rng = np.random.default_rng(seed)
+    msgs = []
+    for _ in range(2):
+        t = episode_len
+        beh = rng.random((t, a_dim)) + 0.1
+        msgs.append({"cur_state": rng.integers(0, 256, (t + 1, 6, 6, 2)).astype(np.uint8),
+                     "real_action": np.eye(a_dim, dtype=np.float32)[rng.integers(0, a_dim, t)],
+                     "reward": [float(x) for x in rng.choice([-1.0, 0.0, 1.0], t)],
+                     "done": [bool(x) for x in (rng.random(t) < 0.25)],
+                     "action": (beh / beh.sum(-1, keepdims=True)).astype(np.float32)})
+    return msgs
+
+
+IMPALA_PLAIN_CFG = ({"actor": {"model_name": "RecordingModel", "state_dim": [6, 6, 2], "action_dim": 3}},
+                    {"instance_num": 2, "agent_num": 1, "prepare_times_per_train": 2, "BATCH_SIZE": 5,
+                     "episode_len": 6})
 PPO_CFG = ({"actor": {"model_name": "RecordingModel", "state_dim": [6, 6, 2], "action_dim": 4}},
            {"instance_num": 3, "agent_num": 1})
 IMPALA_CFG = ({"actor": {"model_name": "RecordingModel", "state_dim": [6, 6, 2], "action_dim": 3}},
@@ -138,7 +171,7 @@ def pack_calls(calls, prefix, out):
 
 
 def main():
-    PPO, IMPALAOpt = load_reference_algorithms()
+    PPO, IMPALAOpt, IMPALA = load_reference_algorithms()
     os.makedirs(OUT, exist_ok=True)
     out = {}
     alg = PPO(*PPO_CFG)
@@ -160,6 +193,19 @@ def main():
     np.savez_compressed(os.path.join(OUT, "alg_impala_opt.npz"), **out)
     print("wrote alg_ppo.npz (%d train call) and alg_impala_opt.npz (%d train calls)"
           % (1, int(out["train_ncalls"])))
+    out = {}
+    alg = IMPALA(*IMPALA_PLAIN_CFG)
+    assert alg.async_flag is False and alg.episode_len == 6
+    for m in impala_plain_inputs():
+        alg.prepare_data(m)
+    out["loss"] = np.float64(alg.train())
+    pack_calls(alg.actor.calls, "train", out)
+    out["pred_p"], out["pred_v"], out["pred_state"] = alg.actor.pred[0], alg.actor.pred[1], alg.actor.pred_state
+    out["lists_cleared"] = np.bool_(alg.state == [] and alg.rewards == [])
+    single = alg.predict(np.zeros((6, 6, 2), np.uint8))
+    out["single_pred_p"], out["single_pred_v"] = single[0], single[1]
+    np.savez_compressed(os.path.join(OUT, "alg_impala.npz"), **out)
+    print("wrote alg_impala.npz (%d train calls)" % int(out["train_ncalls"]))
 
 
 if __name__ == "__main__":

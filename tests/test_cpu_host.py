@@ -332,6 +332,42 @@ def test_algorithm_host_logic_matches_reference_executed_goldens(golden_dir):
     assert (alg.states == [] and alg.rewards == []) == bool(z["lists_cleared"])
 
 
+def test_plain_impala_host_vtrace_matches_reference_executed_goldens(golden_dir):
+    """The non-opt IMPALA (xt/algorithm/impala/impala.py:31-190): actor forward over every stored state, numpy v-trace
+    on PROBABILITIES with the reference's own index convention, (state, pg_adv) / (one-hot, target) in sequential
+    BATCH_SIZE chunks of 5, 5, 2 -- against what the EXECUTED reference class handed to its model for the same
+    fragments and the same model outputs (oracle/gen_golden_alg.py)."""
+    from oracle import gen_golden_alg as G
+    from xingtian_amd.algorithm import alg_builder
+    from xingtian_amd.algorithm.impala.impala import vtrace_from_probs
+    z = np.load(os.path.join(golden_dir, "alg_impala.npz"))
+    rec = _recording_model()
+
+    def predict(self, state):
+        if len(state[0]) == 1:
+            return [z["single_pred_p"], z["single_pred_v"]]
+        assert np.array_equal(state[0], z["pred_state"]) and state[1].shape == (len(state[0]), 1)
+        return [z["pred_p"], z["pred_v"]]
+
+    rec.predict = predict
+    alg = alg_builder("IMPALA", *G.IMPALA_PLAIN_CFG)
+    assert alg.async_flag is False and alg.episode_len == 6 and alg.prepare_data_times == 2
+    for m in G.impala_plain_inputs():
+        alg.prepare_data(m)
+    loss = alg.train()
+    assert float(loss) == float(z["loss"])
+    _check_calls_against_golden(alg.actor.calls, z)
+    assert (alg.state == [] and alg.rewards == []) == bool(z["lists_cleared"])
+    single = alg.predict(np.zeros((6, 6, 2), np.uint8))
+    assert np.array_equal(single[0], z["single_pred_p"]) and np.array_equal(single[1], z["single_pred_v"])
+    # the recursion itself on a hand-checkable case: one fragment, T = 2, rho = 1, no terminal
+    p = np.full((1, 2, 2), 0.5)
+    onehot = np.array([[[1.0, 0.0], [0.0, 1.0]]])
+    pg, tgt = vtrace_from_probs(p, p, onehot, np.ones((1, 2, 1)), np.zeros((1, 2, 1), bool), np.zeros((1, 2, 1)),
+                                np.zeros((1, 2, 1)), 0.5)
+    assert np.allclose(tgt[0, :, 0], [1.5, 1.0]) and np.allclose(pg[0, :, 0], [1.5, 1.0])
+
+
 def test_architecture_tables_match_reference_executed_goldens(golden_dir):
     """get_default_filters / get_atari_filter / default hidden sizes + activations and the INFERRED architecture of
     table-less square observations, against values produced by executing the reference (oracle/gen_golden_arch.py;

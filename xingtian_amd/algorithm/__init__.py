@@ -9,4 +9,4 @@ def alg_builder(alg_name, model_info, alg_config, **kwargs):
 
 
 from xingtian_amd.algorithm.ppo import ppo  # noqa: E402,F401
-from xingtian_amd.algorithm.impala import impala_opt  # noqa: E402,F401
+from xingtian_amd.algorithm.impala import impala, impala_opt  # noqa: E402,F401
