@@ -149,6 +149,34 @@ def impala_cnn_opt_spec(state_dim, action_dim, state_mean=0.0, state_std=255.0):
                 input_scale=("affine", float(state_mean), float(state_std)))
 
 
+def impala_cnn_spec(state_dim, action_dim):
+    """Keras ``ImpalaCnn.create_model`` (xt/model/impala/impala_cnn.py:44-57): Conv2D 32@8x8/4, 64@4x4/2, 64@3x3/1
+    (valid, relu) on uint8/255, Dense 256 relu, then a SOFTMAX policy head ``output_actions`` and ``output_value`` on
+    the same features.  Keras auto-names: conv2d, conv2d_1, conv2d_2, dense."""
+    filt = [(32, 8, 4), (64, 4, 2), (64, 3, 1)]
+    names = ["conv2d", "conv2d_1", "conv2d_2"]
+    h, w, c = state_dim
+    layers = []
+    for (cout, k, s), name in zip(filt, names):
+        spec = LayerSpec(name, "conv", c, cout, "relu", k, s, "valid", (h, w))
+        layers.append(spec)
+        h, w, c = spec.out_h, spec.out_w, cout
+    layers.append(LayerSpec("dense", "dense", h * w * c, 256, "relu"))
+    return dict(trunks=[layers], feat=256, action_dim=action_dim, pi_name="output_actions", v_name="output_value",
+                input_scale=("div", 0.0, 255.0))
+
+
+def impala_mlp_spec(state_dim, action_dim, hidden_size=128, num_layers=1):
+    """Keras ``ImpalaMlp.create_model`` (xt/model/impala/impala_mlp.py:42-53): NUM_LAYERS x Dense(HIDDEN_SIZE, relu)
+    named dense, dense_1, ...; softmax policy + value heads."""
+    layers, cin = [], int(state_dim[0])
+    for i in range(num_layers):
+        layers.append(LayerSpec("dense" if i == 0 else "dense_%d" % i, "dense", cin, hidden_size, "relu"))
+        cin = hidden_size
+    return dict(trunks=[layers], feat=hidden_size, action_dim=action_dim, pi_name="output_actions",
+                v_name="output_value", input_scale=None)
+
+
 # ----------------------------------------------------------------------------
 # initialisers (Keras defaults) -- only used to make seeded test weights
 # ----------------------------------------------------------------------------
@@ -526,6 +554,101 @@ class RmsPropTF(object):
             self.ms[k] = d * self.ms[k] + (1.0 - d) * g * g
             self.mg[k] = d * self.mg[k] + (1.0 - d) * g
             params[k] -= self.lr * g / np.sqrt(self.ms[k] - self.mg[k] * self.mg[k] + self.eps)
+
+
+def keras_impala_loss_and_grads(logits, value, adv, onehot, target_v, ent_coef, eps=1e-10):
+    """Loss of the non-opt IMPALA models (impala_cnn.py:94-108 / impala_mlp.py:83-93 + ``model.compile``):
+
+        p = softmax(logits)
+        L_pi = mean_{b,a}( adv_b * (-y_ba * log(p_ba + 1e-10)) - ENT * (-p_ba * log(p_ba + 1e-10)) )
+        L_v  = mean_b (v_b - target_b)^2          (Keras 'mse')
+        L    = 1.0 * L_pi + 0.5 * L_v             (loss_weights)
+
+    -> (L, dL/dlogits [B,A], dL/dvalue [B], (L_pi, L_v)).  adv / target_v: [B] or [B,1]; onehot: [B,A]."""
+    dt = logits.dtype
+    b, a = logits.shape
+    adv = np.asarray(adv, dt).reshape(b, 1)
+    tv = np.asarray(target_v, dt).reshape(b)
+    y = np.asarray(onehot, dt)
+    z = logits - logits.max(axis=1, keepdims=True)
+    e = np.exp(z)
+    p = e / e.sum(axis=1, keepdims=True)
+    lp = np.log(p + dt.type(eps))
+    per = adv * (-y * lp) + dt.type(ent_coef) * (p * lp)
+    l_pi = per.mean()
+    diff = value.reshape(b) - tv
+    l_v = (diff * diff).mean()
+    # d per / d p = -adv*y/(p+eps) + ENT*(log(p+eps) + p/(p+eps)), then through the softmax
+    g = (-adv * y / (p + dt.type(eps)) + dt.type(ent_coef) * (lp + p / (p + dt.type(eps)))) / dt.type(b * a)
+    dlogits = p * (g - (p * g).sum(axis=1, keepdims=True))
+    dvalue = (dt.type(0.5) * dt.type(2.0) * diff / dt.type(b)).reshape(b, 1)
+    return l_pi + dt.type(0.5) * l_v, dlogits, dvalue, (l_pi, l_v)
+
+
+class AdamKeras(object):
+    """``tf.keras.optimizers.Adam(lr, clipnorm=..., decay=...)`` (OptimizerV2, epsilon = 1e-7):
+    every gradient TENSOR is clipped to ``clipnorm`` on its own (clip_by_norm, not the global norm);
+    lr_t = lr / (1 + decay * iterations) * sqrt(1 - b2^t) / (1 - b1^t) with t = iterations + 1;
+    m, v as usual; theta -= lr_t * m / (sqrt(v) + eps)."""
+
+    def __init__(self, params, lr, clipnorm=None, decay=0.0, beta1=0.9, beta2=0.999, eps=1e-7):
+        self.lr, self.clipnorm, self.decay, self.b1, self.b2, self.eps = lr, clipnorm, decay, beta1, beta2, eps
+        self.iterations = 0
+        self.m = OrderedDict((k, np.zeros_like(v)) for k, v in params.items())
+        self.v = OrderedDict((k, np.zeros_like(v)) for k, v in params.items())
+
+    def clip(self, grads):
+        if self.clipnorm is None:
+            return grads
+        out = OrderedDict()
+        for k, g in grads.items():
+            n = np.sqrt(np.square(g.astype(np.float64)).sum())
+            out[k] = g * (self.clipnorm / n) if n > self.clipnorm else g
+        return out
+
+    def apply(self, params, grads):
+        dt = next(iter(params.values())).dtype.type
+        grads = self.clip(grads)
+        t = self.iterations + 1
+        lr = dt(self.lr) / (dt(1.0) + dt(self.decay) * dt(self.iterations))
+        lr_t = lr * np.sqrt(dt(1.0) - dt(self.b2) ** t) / (dt(1.0) - dt(self.b1) ** t)
+        for k in params:
+            g = grads[k]
+            self.m[k] += (g - self.m[k]) * dt(1.0 - self.b1)
+            self.v[k] += (g * g - self.v[k]) * dt(1.0 - self.b2)
+            params[k] -= lr_t * self.m[k] / (np.sqrt(self.v[k]) + dt(self.eps))
+        self.iterations += 1
+
+
+class KerasImpalaOracle(object):
+    """``ImpalaCnn.train`` / ``ImpalaMlp.train``: one ``model.fit`` epoch in minibatches of 128 (injected order)."""
+
+    def __init__(self, spec, params, lr, ent_coef, clipnorm=None, decay=0.0, dtype=np.float64):
+        self.net = ActorCritic(spec, params, dtype)
+        self.ent_coef, self.dtype = ent_coef, dtype
+        self.opt = AdamKeras(self.net.params, lr, clipnorm, decay)
+
+    def predict(self, obs):
+        logits, value = self.net.forward(obs)
+        z = logits - logits.max(axis=1, keepdims=True)
+        e = np.exp(z)
+        return e / e.sum(axis=1, keepdims=True), value
+
+    def step(self, obs, adv, onehot, target_v, apply=True):
+        logits, value = self.net.forward(obs)
+        loss, dlogits, dvalue, parts = keras_impala_loss_and_grads(logits, value, adv, onehot, target_v, self.ent_coef)
+        grads = self.net.backward(dlogits, dvalue)
+        if apply:
+            self.opt.apply(self.net.params, grads)
+        return dict(loss=loss, grads=grads, parts=parts, logits=logits, value=value, dlogits=dlogits, dvalue=dvalue)
+
+    def fit(self, obs, adv, onehot, target_v, order, batch_size=128):
+        """-> sample-weighted mean loss of the epoch (what Keras' History reports)."""
+        tot = 0.0
+        for lo in range(0, len(order), batch_size):
+            idx = order[lo:lo + batch_size]
+            tot += float(self.step(obs[idx], adv[idx], onehot[idx], target_v[idx])["loss"]) * len(idx)
+        return tot / len(order)
 
 
 class PpoLearnerOracle(object):

@@ -225,3 +225,49 @@ class TorchImpalaLearner(object):
         if apply:
             gn = self.opt.apply(grads, c["grad_norm_clip"])
         return loss.item(), grads, gn
+
+
+def keras_impala_loss_torch(logits, value, adv, onehot, target_v, ent_coef):
+    """impala_cnn.py:94-108 + compile(loss_weights) in torch ops (independent of oracle/nets.py):
+    mean over [B,A] of adv*(-y*log(p+1e-10)) - ENT*(-p*log(p+1e-10)), plus 0.5 * mse(value, target)."""
+    p = torch.softmax(logits, dim=-1)
+    logp = torch.log(p + 1e-10)
+    pi = (adv.reshape(-1, 1) * (-onehot * logp) - ent_coef * (-p * logp)).mean()
+    mse = ((value.reshape(-1) - target_v.reshape(-1)) ** 2).mean()
+    return pi + 0.5 * mse
+
+
+class TorchKerasImpalaLearner(object):
+    """Keras-form IMPALA update with torch autograd; optimizer = tf.keras Adam written out (per-tensor clip_by_norm,
+    time-decayed lr, eps 1e-7 outside the square root)."""
+
+    def __init__(self, spec, params, lr, ent_coef, clipnorm=None, decay=0.0, dtype=torch.float64):
+        self.net = TorchActorCritic(spec, params, dtype)
+        self.lr, self.ent, self.clipnorm, self.decay, self.dtype = lr, ent_coef, clipnorm, decay, dtype
+        self.it = 0
+        self.m = {k: torch.zeros_like(p) for k, p in self.net.params.items()}
+        self.v = {k: torch.zeros_like(p) for k, p in self.net.params.items()}
+
+    def step(self, obs, adv, onehot, target_v):
+        dt = self.dtype
+        for p in self.net.params.values():
+            p.grad = None
+        logits, value = self.net.forward(obs)
+        loss = keras_impala_loss_torch(logits, value, _to_t(adv, dt), _to_t(onehot, dt), _to_t(target_v, dt), self.ent)
+        loss.backward()
+        grads = {k: p.grad.clone() for k, p in self.net.params.items()}
+        lr = self.lr / (1.0 + self.decay * self.it)
+        t = self.it + 1
+        lr_t = lr * (1.0 - 0.999 ** t) ** 0.5 / (1.0 - 0.9 ** t)
+        with torch.no_grad():
+            for k, p in self.net.params.items():
+                g = grads[k]
+                if self.clipnorm is not None:
+                    n = torch.linalg.vector_norm(g)
+                    if n > self.clipnorm:
+                        g = g * (self.clipnorm / n)
+                self.m[k] = 0.9 * self.m[k] + 0.1 * g
+                self.v[k] = 0.999 * self.v[k] + 0.001 * g * g
+                p -= lr_t * self.m[k] / (torch.sqrt(self.v[k]) + 1e-7)
+        self.it += 1
+        return loss.item(), grads
