@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define XT_ABI_VERSION 4
+#define XT_ABI_VERSION 5
 
 #define XT_ACT_NONE 0
 #define XT_ACT_RELU 1
@@ -152,6 +152,28 @@ int xt_impala_loss(const float* logits, const float* baseline, const float* bp_l
                    int32_t n_traj, int32_t T, int32_t A, float gamma,
                    float* dlogits, float* dbaseline, float* out, float* acc,
                    float* vs, float* pg_adv, void* stream);
+
+/* Loss of the non-opt IMPALA models (ABI >= 5): Keras `impala_loss` on the SOFTMAX output plus 0.5 * mse of
+ * the value head (xt/model/impala/impala_cnn.py:94-108 + model.compile(loss_weights), impala_mlp.py:83-93):
+ *     p = softmax(logits);  L_pi = mean_{b,a}( adv_b * (-y_ba * log(p_ba + 1e-10)) - ent * (-p_ba * log(p_ba + 1e-10)) )
+ *     L = L_pi + 0.5 * mean_b (value_b - target_b)^2
+ * idx (may be NULL) gathers the rows of adv [N], onehot [N,A], target_v [N] that belong to this minibatch (the
+ * logits / value rows are already in minibatch order).  out: >= 4 + 2*B floats; out[0] = L, out[1] = L_pi,
+ * out[2] = mse, the rest is scratch.  acc (may be NULL): acc[0] += L * B, acc[1] += B (Keras reports the
+ * sample-weighted mean of an epoch).  A <= 64. */
+int xt_keras_impala_loss(const float* logits, const float* value, int32_t B, int32_t A, const int32_t* idx,
+                         const float* adv, const float* onehot, const float* target_v, float ent_coef,
+                         float* dlogits, float* dvalue, float* out, float* acc, void* stream);
+
+/* tf.keras.optimizers.Adam(lr, clipnorm, decay) on a flat parameter buffer made of n_seg tensors
+ * [seg_off[i], seg_off[i] + seg_size[i]) (ABI >= 5; impala_cnn.py:60 `Adam(lr=LR, clipnorm=40., decay=...)`):
+ * every gradient TENSOR is clipped to clipnorm by its own norm (clip_by_norm; clipnorm <= 0: no clipping), then
+ *     m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  theta -= lr_t * m / (sqrt(v) + eps)
+ * with lr_t = lr / (1 + decay * iterations) * sqrt(1 - b2^t) / (1 - b1^t), t = iterations + 1, computed by the
+ * caller (eps = 1e-7 in tf.keras).  scratch: >= 16 * n_seg floats.  n_seg <= 32. */
+int xt_adam_keras(float* param, const float* grad, float* m, float* v, int32_t n_seg, const int64_t* seg_off,
+                  const int64_t* seg_size, float clipnorm, float lr_t, float beta1, float beta2, float eps,
+                  float* scratch, void* stream);
 
 /* Backward through the two heads: head weight/bias gradients and the gradient w.r.t.
  * the trunk features (times the producer's activation gradient).  If f_v == f_pi the
@@ -275,6 +297,13 @@ int xt_net_ppo_train(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, int32_
  * the step-wise path.  fn == NULL removes the hook. */
 typedef int (*xt_grad_exchange_fn)(float* grads, int64_t count, void* user, void* stream);
 int xt_net_set_grad_exchange(xt_net* net, xt_grad_exchange_fn fn, void* user);
+
+/* One minibatch of Keras `model.fit` for the non-opt IMPALA models (ABI >= 5): forward, xt_keras_impala_loss,
+ * backward; the flat gradient is left in the net's gradient buffer for xt_adam_keras.  obs rows are gathered with
+ * idx like the label rows (idx may be NULL: rows 0..B-1). */
+int xt_net_keras_impala_step(xt_net* net, const void* obs, const int32_t* idx, int32_t B, const float* adv,
+                             const float* onehot, const float* target_v, float ent_coef, float* loss_out,
+                             float* loss_acc, void* stream);
 
 typedef struct xt_impala_cfg {
   float lr, beta1, beta2, eps;

@@ -424,3 +424,37 @@ def test_layer_fwd_and_dgrad_at_benchmark_batches(L, name, in_hw, cin, cout, k, 
                                    L.ACT[act_prev], L.ptr(outd), None), "dgrad")
         gotd = outd.cpu().numpy()
         assert np.isfinite(gotd).all() and rel_err(gotd, refd) < 3e-6, (name, b, act_prev)
+
+
+@pytest.mark.parametrize("b,a_dim", [(128, 4), (44, 18), (1, 3)])
+def test_keras_impala_loss_vs_oracle(L, b, a_dim):
+    """xt_keras_impala_loss (softmax + Keras impala_loss + 0.5 mse, label rows gathered through idx) against the
+    float64 oracle: loss terms, d/dlogits, d/dvalue."""
+    rng = np.random.default_rng(70 + b)
+    n = b + 30
+    logits = rng.standard_normal((b, a_dim)).astype(np.float32) * 2
+    value = rng.standard_normal(b).astype(np.float32)
+    adv = rng.standard_normal(n).astype(np.float32)
+    onehot = np.eye(a_dim, dtype=np.float32)[rng.integers(0, a_dim, n)]
+    tv = rng.standard_normal(n).astype(np.float32)
+    idx = rng.permutation(n)[:b].astype(np.int32)
+    loss, dl, dv, parts = nets.keras_impala_loss_and_grads(logits.astype(np.float64), value.astype(np.float64).reshape(b, 1),
+                                                           adv[idx].astype(np.float64), onehot[idx].astype(np.float64),
+                                                           tv[idx].astype(np.float64), 0.01)
+    d = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    d_dl = torch.empty((b, a_dim), dtype=torch.float32, device="cuda")
+    d_dv = torch.empty((b,), dtype=torch.float32, device="cuda")
+    out = torch.zeros((4 + 2 * b,), dtype=torch.float32, device="cuda")
+    acc = torch.zeros((2,), dtype=torch.float32, device="cuda")
+    lib = L.load()
+    dev = [d(x) for x in (logits, value, idx, adv, onehot, tv)]        # keep the uploads alive across the launch
+    L.check(lib.xt_keras_impala_loss(L.ptr(dev[0]), L.ptr(dev[1]), b, a_dim, L.ptr(dev[2]), L.ptr(dev[3]),
+                                     L.ptr(dev[4]), L.ptr(dev[5]), 0.01, L.ptr(d_dl), L.ptr(d_dv), L.ptr(out), L.ptr(acc),
+                                     L.stream_ptr()), "xt_keras_impala_loss")
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    assert abs(o[0] - loss) < 1e-5 * max(1, abs(loss)) and abs(o[1] - parts[0]) < 1e-5 * max(1, abs(parts[0]))
+    assert abs(o[2] - parts[1]) < 1e-5 * max(1, abs(parts[1]))
+    assert np.allclose(acc.cpu().numpy(), [o[0] * b, b], rtol=1e-6)
+    assert np.linalg.norm(d_dl.cpu().numpy() - dl) <= 1e-5 * np.linalg.norm(dl)
+    assert np.linalg.norm(d_dv.cpu().numpy() - dv.reshape(-1)) <= 1e-5 * np.linalg.norm(dv)

@@ -667,6 +667,81 @@ def test_gradient_exchange_hook_in_the_update_graph_matches_the_stepwise_data_pa
         comm.destroy()
 
 
+@pytest.mark.parametrize("which", ["cnn", "mlp"])
+def test_keras_impala_models_fit_vs_oracle(which):
+    """ImpalaCnn / ImpalaMlp (softmax policy head, Keras impala_loss + 0.5 mse, tf.keras Adam with
+    per-tensor clipnorm and lr decay, model.fit in minibatches of 128) against the float64 oracle over one epoch of
+    300 samples (128 + 128 + 44) in an injected order: epoch loss, every gradient of the last minibatch, the
+    parameters after the three updates; clipnorm lowered so that it clips some tensors and not others."""
+    from xingtian_amd.model import model_builder
+    rng = np.random.default_rng(61)
+    n = 300
+    if which == "cnn":
+        sd, a = (36, 36, 4), 5
+        info = {"model_name": "ImpalaCnn", "state_dim": list(sd), "action_dim": a, "model_config": {"SEED": 3}}
+        ospec = nets.impala_cnn_spec(sd, a)
+        obs = rng.integers(0, 256, (n,) + sd).astype(np.uint8)
+    else:
+        sd, a = (6,), 3
+        info = {"model_name": "ImpalaMlp", "state_dim": list(sd), "action_dim": a,
+                "model_config": {"SEED": 3, "NUM_LAYERS": 2, "HIDDEN_SIZE": 128}}
+        ospec = nets.impala_mlp_spec(sd, a, 128, 2)
+        obs = rng.uniform(-1, 1, (n,) + sd).astype(np.float32)
+    model = model_builder(info)
+    params = oracle_params_for(model.net, ospec, seed=62)
+    clip, decay = (0.05, 0.01) if which == "cnn" else (0.0, 0.0)
+    model.CLIPNORM, model.DECAY = clip, decay
+    adv = rng.standard_normal((n, 1))
+    onehot = np.eye(a, dtype=np.float32)[rng.integers(0, a, n)]
+    tv = rng.standard_normal((n, 1))
+    order = rng.permutation(n)
+    orc = nets.KerasImpalaOracle(ospec, params, lr=3e-4, ent_coef=0.01, clipnorm=clip if clip > 0 else None, decay=decay,
+                                 dtype=np.float64)
+    # predict parity before any update
+    p_ref, v_ref = orc.predict(obs[:40])
+    p_got, v_got = model.predict([obs[:40], np.zeros((40, 1))])
+    assert p_got.dtype == np.float32 and p_got.shape == (40, a) and v_got.shape == (40, 1)
+    assert rel_err(p_got, p_ref) < 1e-5 and rel_err(v_got, v_ref) < 1e-5
+    f32 = lambda x: np.asarray(x, np.float32).astype(np.float64)          # Keras feeds float32 placeholders
+    loss_ref = orc.fit(obs, f32(adv), onehot.astype(np.float64), f32(tv), order)
+    w_init = {k: v.copy() for k, v in params.items()}
+    loss = model.fit_in_order(obs, adv, onehot, tv, order)
+    assert model.iterations == 3 and orc.opt.iterations == 3
+    assert abs(loss - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref)), (loss, loss_ref)
+    # three Adam steps: per-tensor update parity (the per-tensor clip decides the step of every clipped tensor)
+    assert_update_close(model.net.get_weights(), orc.net.params, w_init, 3e-4, which)
+    if which == "cnn":          # the clip was active on some tensors and inactive on others in the last minibatch
+        norms = [np.linalg.norm(g) for g in model.net.grads_dict().values()]
+        assert max(norms) > clip > min(norms)
+
+
+def test_registry_plain_impala_end_to_end():
+    """alg_builder("IMPALA") + ImpalaCnn on the GPU: two fragments of episode_len transitions go through the host
+    v-trace (pinned on CPU against the executed reference) and three model.fit calls (BATCH_SIZE chunks); shapes,
+    dtypes, a finite loss and moving weights."""
+    from xingtian_amd.algorithm import alg_builder
+    rng = np.random.default_rng(63)
+    t, a = 20, 4
+    alg = alg_builder("IMPALA", {"actor": {"model_name": "ImpalaCnn", "state_dim": [36, 36, 4], "action_dim": a,
+                                           "model_config": {"SEED": 5}}},
+                      {"instance_num": 2, "agent_num": 1, "prepare_times_per_train": 2, "BATCH_SIZE": 16,
+                       "episode_len": t})
+    w0 = {k: v.copy() for k, v in alg.actor.get_weights().items()}
+    for _ in range(2):
+        beh = rng.random((t, a)) + 0.1
+        alg.prepare_data({"cur_state": rng.integers(0, 256, (t + 1, 36, 36, 4)).astype(np.uint8),
+                          "real_action": np.eye(a, dtype=np.float32)[rng.integers(0, a, t)],
+                          "reward": [float(x) for x in rng.choice([-1.0, 0.0, 1.0], t)],
+                          "done": [bool(x) for x in (rng.random(t) < 0.1)],
+                          "action": (beh / beh.sum(-1, keepdims=True)).astype(np.float32)})
+    loss = alg.train()
+    assert np.isfinite(loss) and alg.actor.iterations == 3            # 40 rows in chunks of 16, 16, 8: one fit each
+    w1 = alg.actor.get_weights()
+    assert any(not np.array_equal(w0[k], w1[k]) for k in w0)
+    p, v = alg.predict(np.zeros((36, 36, 4), np.uint8))
+    assert p.shape == (1, a) and v.shape == (1, 1) and abs(float(p.sum()) - 1.0) < 1e-5
+
+
 def test_impala_lr_schedule_linear_cosine_decay_drives_the_adam_step_size():
     """lr_schedule (impala_cnn_opt.py:199-203,236-249): the step size of update k is linear_cosine_decay at
     global_step k; the device-side lr_t = lr * sqrt(1-b2^t)/(1-b1^t) must follow it."""

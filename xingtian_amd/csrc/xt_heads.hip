@@ -660,6 +660,81 @@ int xt_ppo_loss_gauss(const float* mean, const float* log_std, const float* valu
                                    xt::as_stream(stream));
 }
 
+namespace xt {
+// One thread per sample (the minibatch of model.fit is 128 rows): softmax, the two loss terms of the sample and
+// d loss / d logits through the softmax, d loss / d value.  terms[b] = (sum_a per-element policy loss, squared error).
+__global__ __launch_bounds__(256) void keras_impala_loss_kernel(const float* __restrict__ logits, const float* __restrict__ value,
+                                                                int B, int A, const int32_t* __restrict__ idx,
+                                                                const float* __restrict__ adv, const float* __restrict__ onehot,
+                                                                const float* __restrict__ target_v, float ent,
+                                                                float* __restrict__ dlogits, float* __restrict__ dvalue,
+                                                                float2* __restrict__ terms) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const long long row = idx ? (long long)idx[b] : (long long)b;
+  const float* z = logits + (size_t)b * A;
+  const float* y = onehot + (size_t)row * A;
+  const float ad = adv[row];
+  float mx = z[0];
+  for (int a = 1; a < A; ++a) mx = fmaxf(mx, z[a]);
+  float den = 0.f;
+  for (int a = 0; a < A; ++a) den += expf(z[a] - mx);
+  const float inv_den = 1.f / den, eps = 1e-10f, inv_ba = 1.f / ((float)B * (float)A);
+  float lsum = 0.f, pg = 0.f;
+  for (int a = 0; a < A; ++a) {
+    const float p = expf(z[a] - mx) * inv_den;
+    const float lp = logf(p + eps);
+    lsum += ad * (-y[a] * lp) + ent * (p * lp);
+    const float g = (-ad * y[a] / (p + eps) + ent * (lp + p / (p + eps))) * inv_ba;
+    pg += p * g;
+  }
+  for (int a = 0; a < A; ++a) {
+    const float p = expf(z[a] - mx) * inv_den;
+    const float lp = logf(p + eps);
+    const float g = (-ad * y[a] / (p + eps) + ent * (lp + p / (p + eps))) * inv_ba;
+    dlogits[(size_t)b * A + a] = p * (g - pg);
+  }
+  const float diff = value[b] - target_v[row];
+  dvalue[b] = diff / (float)B;
+  terms[b] = make_float2(lsum, diff * diff);
+}
+
+// fixed-order reduction of the per-sample terms by one block
+__global__ __launch_bounds__(256) void keras_impala_loss_reduce_kernel(const float2* __restrict__ terms, int B, int A,
+                                                                       float* __restrict__ out, float* __restrict__ acc) {
+  __shared__ double sp[256], sv[256];
+  double p = 0.0, v = 0.0;
+  for (int b = threadIdx.x; b < B; b += 256) { p += (double)terms[b].x; v += (double)terms[b].y; }
+  sp[threadIdx.x] = p; sv[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { sp[threadIdx.x] += sp[threadIdx.x + o]; sv[threadIdx.x] += sv[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float lpi = (float)(sp[0] / ((double)B * (double)A)), mse = (float)(sv[0] / (double)B);
+    const float l = lpi + 0.5f * mse;
+    out[0] = l; out[1] = lpi; out[2] = mse;
+    if (acc) { acc[0] += l * (float)B; acc[1] += (float)B; }
+  }
+}
+}  // namespace xt
+
+int xt_keras_impala_loss(const float* logits, const float* value, int32_t B, int32_t A, const int32_t* idx,
+                         const float* adv, const float* onehot, const float* target_v, float ent_coef,
+                         float* dlogits, float* dvalue, float* out, float* acc, void* stream) {
+  XT_REQUIRE(logits && value && adv && onehot && target_v && dlogits && dvalue && out, "xt_keras_impala_loss: null argument");
+  XT_REQUIRE(B > 0 && A > 0 && A <= 64, "xt_keras_impala_loss: bad sizes (B=%d A=%d)", B, A);
+  hipStream_t st = xt::as_stream(stream);
+  float2* terms = reinterpret_cast<float2*>(out + 4);       // out: >= 4 + 2*B floats
+  hipLaunchKernelGGL(xt::keras_impala_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, st, logits, value, B, A, idx, adv,
+                     onehot, target_v, ent_coef, dlogits, dvalue, terms);
+  XT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(xt::keras_impala_loss_reduce_kernel, dim3(1), dim3(256), 0, st, terms, B, A, out, acc);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
 int xt_ppo_loss_reduce(const float* loss_terms, int32_t B, float ent_coef, float critic_coef, float inv_b,
                        float* out, float* acc, void* stream) {
   hipLaunchKernelGGL(xt::ppo_loss_reduce_kernel, dim3(1), dim3(256), 0, xt::as_stream(stream), loss_terms, B, ent_coef,

@@ -1182,7 +1182,7 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
     static int no_d4 = -1;
     if (no_d4 < 0) { const char* e = getenv("XT_NO_DGRAD4"); no_d4 = (e && e[0] == '1') ? 1 : 0; }
     if (!no_d4 && g.S == 2 && g.KH % 2 == 0 && g.KW % 2 == 0 && g.H % 2 == 0 && g.W % 2 == 0 && g.PT == 0 &&
-        g.PL == 0 && g.C == 32 && g.N % 32 == 0 && (g.OH - 1) * g.S + g.KH <= g.H && (g.OW - 1) * g.S + g.KW <= g.W) {
+        g.PL == 0 && g.C == 32 && g.N == 32 && (g.OH - 1) * g.S + g.KH <= g.H && (g.OW - 1) * g.S + g.KW <= g.W) {
       a.dg_direct = 2;
       a.n_dg = (B * (g.H / 2) * (g.W / 2) + 127) / 128;
     }

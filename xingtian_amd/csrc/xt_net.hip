@@ -508,7 +508,7 @@ int xt_net_create(const xt_net_desc* d, int32_t max_batch, xt_net** out) {
   n->off_dvalue = off; off += xt::align4(max_batch);
   n->off_terms = off; off += xt::align4((int64_t)max_batch * 4);
   n->off_dls = off; off += (int64_t)max_batch * xt::align4(n->A);
-  n->off_loss = off; off += xt::align4(8 + max_batch);
+  n->off_loss = off; off += xt::align4(8 + 2 * max_batch);     // 4 + n_traj (v-trace) / 4 + 2 B (Keras loss terms)
   n->off_norm = off; off += xt::kMaxNormPartials;
   n->off_counter = off; off += 32 * 66;   // 1 top + 64 sub ticket counters, one 128-B line each
   n->ws_floats = off;
@@ -679,6 +679,29 @@ int xt_net_impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int32
                                    n->ws + n->off_norm, n->norm_blocks, c->grad_norm_clip, c->grad_scale, st);
   XT_REQUIRE(c->opt_type == XT_OPT_ADAM, "xt_net_impala_step: unknown opt_type %d", c->opt_type);
   return xt::net_apply(n, c->lr, c->beta1, c->beta2, c->eps, c->grad_norm_clip, c->grad_scale, 3, nullptr, st);
+}
+
+int xt_net_keras_impala_step(xt_net* n, const void* obs, const int32_t* idx, int32_t B, const float* adv,
+                             const float* onehot, const float* target_v, float ent_coef, float* loss_out,
+                             float* loss_acc, void* stream) {
+  XT_REQUIRE(n && n->params && n->ws && obs && adv && onehot && target_v, "xt_net_keras_impala_step: null argument / unbound buffers");
+  XT_REQUIRE(B > 0 && B <= n->maxB, "xt_net_keras_impala_step: batch %d outside (0,%d]", B, n->maxB);
+  XT_REQUIRE(n->action_type == XT_ACTION_CATEGORICAL, "xt_net_keras_impala_step: categorical heads only");
+  hipStream_t st = xt::as_stream(stream);
+  if (int rc = xt::net_forward(n, obs, idx, B, true, st)) return rc;
+  float* lo = n->ws + n->off_loss;
+  if (int rc = xt_keras_impala_loss(n->ws + n->off_logits, n->ws + n->off_value, B, n->A, idx, adv, onehot, target_v,
+                                    ent_coef, n->ws + n->off_dlogits, n->ws + n->off_dvalue, lo, loss_acc, st))
+    return rc;
+  if (loss_out) XT_CHECK_HIP(hipMemcpyAsync(loss_out, lo, 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  xt::Layer& Lp = n->layers[n->t_end[0] - 1];
+  xt::Layer& Lv = n->layers[n->t_end[n->n_trunks - 1] - 1];
+  if (int rc = xt::launch_heads_dfeat(n->ws + Lp.act_off, n->ws + Lv.act_off, B, n->feat, n->A, n->params + n->pi_off,
+                                      n->params + n->v_off, n->ws + n->off_dlogits, n->ws + n->off_dvalue, Lp.g.act,
+                                      n->ws + Lp.dact_off, n->ws + Lv.dact_off, st))
+    return rc;
+  if (int rc = xt::trunk_backward(n, obs, idx, B, st)) return rc;
+  return xt::grads_finish(n, B, nullptr, st);
 }
 
 int xt_net_set_grad_exchange(xt_net* net, xt_grad_exchange_fn fn, void* user) {

@@ -435,6 +435,83 @@ int launch_adam_clip(float* param, const float* grad, float* m, float* v, long l
   return 0;
 }
 
+}  // namespace xt
+
+// ------------------------------------------------------------------ tf.keras Adam with per-tensor clipnorm
+namespace xt {
+constexpr int kKerasSlices = 16;      // squared-norm partials per tensor (fixed-order sum -> reproducible)
+constexpr int kKerasMaxSeg = 32;
+struct KerasSegs {
+  int n;
+  long long off[kKerasMaxSeg], size[kKerasMaxSeg];
+};
+
+// block (slice, tensor): sum of squares of its slice of the tensor's gradient
+__global__ __launch_bounds__(256) void keras_seg_sqnorm_kernel(const float* __restrict__ g, const KerasSegs segs,
+                                                               float* __restrict__ partial) {
+  __shared__ double sh[256];
+  const int sg = blockIdx.y, sl = blockIdx.x;
+  const long long n = segs.size[sg], per = (n + kKerasSlices - 1) / kKerasSlices;
+  const long long lo = sl * per, hi = lo + per < n ? lo + per : n;
+  const float* p = g + segs.off[sg];
+  double acc = 0.0;
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) { const double x = (double)p[i]; acc += x * x; }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[sg * kKerasSlices + sl] = (float)sh[0];
+}
+
+// grid.y = tensor: every block first derives its tensor's clip factor from the 16 partials (same order everywhere)
+__global__ __launch_bounds__(256) void adam_keras_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v, const KerasSegs segs,
+                                                         const float* __restrict__ partial, float clipnorm, float lr_t,
+                                                         float beta1, float beta2, float eps) {
+  const int sg = blockIdx.y;
+  double sq = 0.0;
+#pragma unroll
+  for (int j = 0; j < kKerasSlices; ++j) sq += (double)partial[sg * kKerasSlices + j];
+  const float norm = (float)sqrt(sq);
+  const float scale = (clipnorm > 0.f && norm > clipnorm) ? clipnorm / norm : 1.f;
+  const long long n = segs.size[sg], base = segs.off[sg];
+  const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long e = base + i;
+    const float gg = g[e] * scale;
+    float mm = m[e], vv = v[e];
+    mm += (gg - mm) * omb1;
+    vv += (gg * gg - vv) * omb2;
+    m[e] = mm; v[e] = vv;
+    p[e] -= lr_t * mm / (sqrtf(vv) + eps);
+  }
+}
+
+int launch_adam_keras(float* param, const float* grad, float* m, float* v, int n_seg, const int64_t* seg_off,
+                      const int64_t* seg_size, float clipnorm, float lr_t, float beta1, float beta2, float eps,
+                      float* scratch, hipStream_t st) {
+  XT_REQUIRE(param && grad && m && v && seg_off && seg_size && scratch, "xt_adam_keras: null argument");
+  XT_REQUIRE(n_seg > 0 && n_seg <= kKerasMaxSeg, "xt_adam_keras: n_seg %d outside (0,%d]", n_seg, kKerasMaxSeg);
+  KerasSegs segs;
+  segs.n = n_seg;
+  long long biggest = 1;
+  for (int i = 0; i < n_seg; ++i) {
+    XT_REQUIRE(seg_off[i] >= 0 && seg_size[i] > 0, "xt_adam_keras: bad segment %d", i);
+    segs.off[i] = seg_off[i]; segs.size[i] = seg_size[i];
+    if (seg_size[i] > biggest) biggest = seg_size[i];
+  }
+  hipLaunchKernelGGL(keras_seg_sqnorm_kernel, dim3(kKerasSlices, n_seg), dim3(256), 0, st, grad, segs, scratch);
+  XT_LAUNCH_CHECK();
+  int gx = (int)((biggest + 255) / 256);
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(adam_keras_kernel, dim3(gx, n_seg), dim3(256), 0, st, param, grad, m, v, segs, scratch, clipnorm, lr_t,
+                     beta1, beta2, eps);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_norm_finalize(const float* partial, int nblocks, float clip_norm, float grad_scale, float lr, float beta1,
                          float beta2, int advance, float* state, const LossArgs* la, hipStream_t st) {
   LossArgs l;
@@ -483,6 +560,13 @@ int xt_grad_global_norm(const float* grad, int64_t count, float clip_norm, float
                         float* scratch, void* stream) {
   return xt::launch_global_norm(grad, count, clip_norm, grad_scale, 0.f, 0.f, 0.f, 0, state, scratch,
                                 xt::as_stream(stream));
+}
+
+int xt_adam_keras(float* param, const float* grad, float* m, float* v, int32_t n_seg, const int64_t* seg_off,
+                  const int64_t* seg_size, float clipnorm, float lr_t, float beta1, float beta2, float eps,
+                  float* scratch, void* stream) {
+  return xt::launch_adam_keras(param, grad, m, v, n_seg, seg_off, seg_size, clipnorm, lr_t, beta1, beta2, eps, scratch,
+                               xt::as_stream(stream));
 }
 
 int xt_adam_tf_clip(float* param, const float* grad, float* m, float* v, int64_t count, float lr, float beta1,

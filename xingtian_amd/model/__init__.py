@@ -10,4 +10,4 @@ def model_builder(model_info):
 
 # the reference discovers plugins by importing every xt/model/*/*.py (register.py:95-139); here the list is explicit
 from xingtian_amd.model.ppo import ppo_cnn, ppo_mlp  # noqa: E402,F401
-from xingtian_amd.model.impala import impala_cnn_opt  # noqa: E402,F401
+from xingtian_amd.model.impala import impala_cnn, impala_cnn_opt  # noqa: E402,F401

@@ -276,6 +276,36 @@ class HipActorCritic(object):
                 "xt_net_impala_step")
         return self.loss_out
 
+    def keras_impala_step(self, obs, idx, adv, onehot, target_v, ent_coef, loss_acc=None):
+        """One ``model.fit`` minibatch of the non-opt IMPALA models (C ABI xt_net_keras_impala_step): forward, Keras
+        impala_loss + 0.5 mse, backward; the gradient stays in ``self.grads`` for ``adam_keras``.  Returns the device
+        tensor [loss, policy loss, mse]."""
+        b = int(idx.numel()) if idx is not None else int(obs.shape[0])
+        L.check(self.lib.xt_net_keras_impala_step(self.handle, L.ptr(obs), L.ptr(idx), b, L.ptr(adv), L.ptr(onehot),
+                                                  L.ptr(target_v), float(ent_coef), L.ptr(self.loss_out),
+                                                  L.ptr(loss_acc) if loss_acc is not None else None, L.stream_ptr()),
+                "xt_net_keras_impala_step")
+        return self.loss_out
+
+    def adam_keras(self, lr, iterations, clipnorm=0.0, decay=0.0, beta1=0.9, beta2=0.999, eps=1e-7):
+        """tf.keras Adam on the flat buffers: per-TENSOR clip_by_norm (kernel and bias are separate tensors), time-decayed
+        learning rate; ``iterations`` = number of updates applied so far."""
+        if not hasattr(self, "_keras_segs"):
+            offs, sizes = [], []
+            for _, (off, shape) in self.spec.names.items():
+                offs.append(int(off))
+                sizes.append(int(np.prod(shape)))
+            dev = self.device
+            self._keras_segs = (torch.tensor(offs, dtype=torch.int64), torch.tensor(sizes, dtype=torch.int64), len(offs))
+            self._keras_scratch = torch.zeros((16 * len(offs),), dtype=torch.float32, device=dev)
+        offs, sizes, n = self._keras_segs
+        t = iterations + 1
+        lr_t = np.float32(lr) / (np.float32(1.0) + np.float32(decay) * np.float32(iterations))
+        lr_t = lr_t * np.sqrt(np.float32(1.0) - np.float32(beta2) ** t) / (np.float32(1.0) - np.float32(beta1) ** t)
+        L.check(self.lib.xt_adam_keras(L.ptr(self.params), L.ptr(self.grads), L.ptr(self.adam_m), L.ptr(self.adam_v), n,
+                                       offs.data_ptr(), sizes.data_ptr(), float(clipnorm), float(lr_t), beta1, beta2,
+                                       eps, L.ptr(self._keras_scratch), L.stream_ptr()), "xt_adam_keras")
+
     def apply(self, lr, clip_norm, grad_scale=1.0):
         L.check(self.lib.xt_net_apply(self.handle, lr, 0.9, 0.999, 1e-8, clip_norm, grad_scale, L.stream_ptr()),
                 "xt_net_apply")

@@ -207,3 +207,31 @@ def impala_cnn_opt(state_dim, action_dim, state_mean=0.0, state_std=255.0, input
         xf = (1, float(state_mean), float(state_std))
     return NetSpec(layers, 1, c, action_dim, "explore_agent/conv2d_3", "explore_agent/dense",
                    (1, 1, c, action_dim), xf, state_dim)
+
+
+def impala_cnn(state_dim, action_dim):
+    """Keras ``ImpalaCnn`` (xt/model/impala/impala_cnn.py:44-57): Conv2D 32@8x8/4, 64@4x4/2, 64@3x3/1 (valid, relu) on
+    uint8 / 255, Dense 256 relu; a softmax policy head and a value head on the same features.  Variable names are
+    Keras' automatic layer names (conv2d, conv2d_1, conv2d_2, dense) and the two named output layers."""
+    h, w, c = state_dim
+    layers = []
+    for name, (cout, k, s) in zip(("conv2d", "conv2d_1", "conv2d_2"), ((32, 8, 4), (64, 4, 2), (64, 3, 1))):
+        lay = _conv(name, h, w, c, cout, k, s, "valid", "relu", 0)
+        layers.append(lay)
+        h, w, c = lay.OH, lay.OW, cout
+    layers.append(_dense("dense", h * w * c, 256, "relu", 0))
+    return NetSpec(layers, 1, 256, action_dim, "output_actions", "output_value", (256, action_dim), (1, 0.0, 255.0),
+                   state_dim)
+
+
+def impala_mlp(state_dim, action_dim, hidden_size=128, num_layers=1):
+    """Keras ``ImpalaMlp`` (xt/model/impala/impala_mlp.py:42-53): NUM_LAYERS x Dense(HIDDEN_SIZE, relu) named dense,
+    dense_1, ...; softmax policy + value heads.  An input width that is not a multiple of 4 is zero-padded (see _mlp)."""
+    layers, cin = [], int(state_dim[0])
+    for i in range(int(num_layers)):
+        lay = _dense("dense" if i == 0 else "dense_%d" % i, (cin + 3) & ~3, hidden_size, "relu", 0)
+        lay.kernel_shape = (cin, hidden_size)
+        layers.append(lay)
+        cin = hidden_size
+    return NetSpec(layers, 1, hidden_size, action_dim, "output_actions", "output_value", (hidden_size, action_dim),
+                   (0, 0.0, 1.0), (1, 1, int(state_dim[0])))
