@@ -715,6 +715,28 @@ def test_keras_impala_models_fit_vs_oracle(which):
         assert max(norms) > clip > min(norms)
 
 
+def test_keras_impala_checkpoint_resume_is_bit_exact(tmp_path):
+    """ImpalaMlp: fit, save (weights + Adam slots + tf.keras Adam's ``iterations``), load into a fresh model, fit again
+    on both: identical parameters bit for bit (the time-decayed step size depends on ``iterations``)."""
+    from xingtian_amd.model import model_builder
+    info = {"model_name": "ImpalaMlp", "state_dim": [6], "action_dim": 3, "model_config": {"SEED": 4}}
+    rng = np.random.default_rng(64)
+    n, a = 200, 3
+    data = [(rng.uniform(-1, 1, (n, 6)).astype(np.float32), rng.standard_normal((n, 1)),
+             np.eye(a, dtype=np.float32)[rng.integers(0, a, n)], rng.standard_normal((n, 1)), rng.permutation(n))
+            for _ in range(2)]
+    m1 = model_builder(info)
+    m1.DECAY = 0.05
+    m1.fit_in_order(*data[0])
+    path = m1.save_model(str(tmp_path / "actor_00001"))
+    m2 = model_builder(dict(info, model_config={"SEED": 99}))
+    m2.DECAY = 0.05
+    m2.load_model(path)
+    assert m2.optimizer_restored and m2.iterations == m1.iterations == 2
+    l1, l2 = m1.fit_in_order(*data[1]), m2.fit_in_order(*data[1])
+    assert l1 == l2 and torch.equal(m1.net.params, m2.net.params)
+
+
 def test_registry_plain_impala_end_to_end():
     """alg_builder("IMPALA") + ImpalaCnn on the GPU: two fragments of episode_len transitions go through the host
     v-trace (pinned on CPU against the executed reference) and three model.fit calls (BATCH_SIZE chunks); shapes,

@@ -40,6 +40,13 @@ class _KerasImpalaModel(XTModel):
         self._acc = torch.zeros((2,), dtype=torch.float32, device=self.net.device)
         return True
 
+    def extra_optimizer_state(self):
+        return {"keras_adam_iterations": np.int64(self.iterations)}
+
+    def restore_extra_optimizer_state(self, arrays):
+        if "keras_adam_iterations" in arrays:
+            self.iterations = int(arrays["keras_adam_iterations"])
+
     def predict(self, state):
         """-> [softmax probabilities [N,A], value [N,1]] (numpy float32); ``state`` = [observations, dummy adv]."""
         logits, value = self.net.forward(np.asarray(state[0]))

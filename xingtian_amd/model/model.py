@@ -66,6 +66,7 @@ class XTModel(object):
         arrays = OrderedDict(self.get_weights())
         if self.save_optimizer and hasattr(self.net, "get_optimizer_state"):
             arrays.update(self.net.get_optimizer_state())
+            arrays.update(self.extra_optimizer_state())
         path = file_name + ".npz"
         np.savez(path, **arrays)
         return path
@@ -77,3 +78,12 @@ class XTModel(object):
         self.set_weights(arrays)
         if hasattr(self.net, "set_optimizer_state"):
             self.optimizer_restored = self.net.set_optimizer_state(arrays)
+            if self.optimizer_restored:
+                self.restore_extra_optimizer_state(arrays)
+
+    # ---- optimizer state that lives on the host side of a concrete model (e.g. tf.keras Adam's ``iterations``)
+    def extra_optimizer_state(self):
+        return {}
+
+    def restore_extra_optimizer_state(self, arrays):
+        pass
