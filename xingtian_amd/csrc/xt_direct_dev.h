@@ -364,11 +364,17 @@ __device__ __forceinline__ void halo_dgrad_body(const DDgradArgs& p, uint32_t bi
   __syncthreads();                                        // staged dY visible
   XT_TL(1);
   if constexpr (SPLIT) {
-    for (int s = s0; s < s1; s += 2) {
+    // three weight stages in flight (the split form has the registers for it: 120 -> 136 VGPRs): a wave's whole slice
+    // is at most ceil(KH*KW*N/32 / 4) steps, so most of its weight loads are issued before the first MFMA
+    StageB B2;
+    loadB(B2, s0 + 2, s0 + 2 < s1);
+    for (int s = s0; s < s1; s += 3) {
       step_split(B0, s, true);
-      loadB(B0, s + 2, s + 2 < s1);
+      loadB(B0, s + 3, s + 3 < s1);
       step_split(B1, s + 1, s + 1 < s1);
-      loadB(B1, s + 3, s + 3 < s1);
+      loadB(B1, s + 4, s + 4 < s1);
+      step_split(B2, s + 2, s + 2 < s1);
+      loadB(B2, s + 5, s + 5 < s1);
     }
   } else {
     StageA A0, A1;
