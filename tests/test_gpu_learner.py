@@ -780,7 +780,10 @@ model_para:
 env_num: 10
 """)
     alg_cfg = dict(cfg["alg_para"]["alg_config"], instance_num=cfg["env_num"], agent_num=1)
-    info = {"actor": dict(cfg["model_para"]["actor"], model_config={"SEED": 6})}
+    # import_config(globals(), ...) overrides MODULE globals for the rest of the process (the reference's mechanism; one
+    # model per process there), so a test process that built other ImpalaMlp variants before restates the defaults
+    info = {"actor": dict(cfg["model_para"]["actor"], model_config={"SEED": 6, "NUM_LAYERS": 1, "HIDDEN_SIZE": 128,
+                                                                    "LR": 3e-4, "ENTROPY_LOSS": 0.01})}
     alg = alg_builder(cfg["alg_para"]["alg_name"], info, alg_cfg)
     assert alg.prepare_data_times == 2 and alg.episode_len == 200
     ospec = nets.impala_mlp_spec((4,), 2, 128, 1)
