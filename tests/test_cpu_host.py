@@ -206,6 +206,53 @@ def test_data_parallel_gradient_allreduce_gloo_world2():
     assert dict(out) == {0: 1, 1: 1}
 
 
+def _dp_impala_worker(rank, world, port, out):
+    """IMPALA's loss is a SUM over trajectories (impala_cnn_opt.py:299-351): every rank owns whole trajectories, the
+    all-reduced gradient needs NO 1/world scaling (parallel.grad_scale("sum")), and equals the single-process gradient
+    of all trajectories."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xingtian_amd import parallel
+    try:
+        rng = np.random.default_rng(3)          # identical data on every rank
+        spec = nets.impala_cnn_opt_spec((42, 42, 2), 3)
+        params = nets.init_params(spec, seed=4, bias_scale=0.1)
+        t, ntraj = 5, 6
+        n = t * ntraj                            # env-major flat batch [traj * T + step]
+        states = rng.integers(0, 256, (n, 42, 42, 2)).astype(np.uint8)
+        bp = rng.standard_normal((n, 3)).astype(np.float32)
+        act = rng.integers(0, 3, n).astype(np.int32)
+        dones = rng.random(n) < 0.15
+        rew = rng.choice([-1.0, 0.0, 1.0], n).astype(np.float32)
+        cfg = dict(LR=1e-3, grad_norm_clip=40.0, sample_batch_step=t)
+        lo, hi = parallel.shard_range(ntraj, rank, world)
+        rows = slice(lo * t, hi * t)             # whole trajectories
+        orc = nets.ImpalaLearnerOracle(spec, params, cfg, np.float64)
+        mine = orc.step(states[rows], bp[rows], act[rows], dones[rows], rew[rows], apply=False)
+        flat = torch.from_numpy(np.concatenate([g.ravel() for g in mine["grads"].values()]))
+        parallel.allreduce_sum_(flat)
+        flat *= parallel.grad_scale("sum", world)
+        ref = nets.ImpalaLearnerOracle(spec, params, cfg, np.float64).step(states, bp, act, dones, rew, apply=False)
+        ref_flat = np.concatenate([g.ravel() for g in ref["grads"].values()])
+        np.testing.assert_allclose(flat.numpy(), ref_flat, rtol=1e-9, atol=1e-12)
+        loss = torch.tensor([float(mine["loss"])], dtype=torch.float64)
+        dist.all_reduce(loss)
+        assert abs(loss.item() - float(ref["loss"])) < 1e-9 * max(1.0, abs(float(ref["loss"])))
+        out[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_impala_sum_loss_gloo_world2():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_impala_worker, args=(world, port, out), nprocs=world, join=True)
+    assert dict(out) == {0: 1, 1: 1}
+
+
 def test_linear_cosine_decay_known_answers():
     """tf.train.linear_cosine_decay as the reference's ImpalaCnnOpt._get_lr uses it (impala_cnn_opt.py:236-249):
     closed-form values at 0, decay_steps/2, decay_steps and beyond."""
