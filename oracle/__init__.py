@@ -12,8 +12,13 @@ Parity status
   reference's own numpy implementation (``xt/agent/ppo/ppo.py:77-106``) executed
   under import stubs; the resulting vectors are committed in
   ``tests/golden/gae_*.npz`` together with ``oracle/gen_golden.py``.
+* Host logic of the algorithm classes (``PPO``, ``IMPALAOpt``, the non-opt ``IMPALA`` with its numpy v-trace on
+  probabilities) and the architecture tables: **pinned** -- ``oracle/gen_golden_alg.py`` / ``gen_golden_arch.py``
+  EXECUTE the reference's own classes / functions under import stubs and commit what they produce
+  (``tests/golden/alg_*.npz``, ``arch_tables.json``); the product's classes are tested against those fixtures.
 * Everything the reference delegates to TensorFlow (conv/dense fwd+bwd, the PPO
-  and v-trace losses, clip_by_global_norm, AdamOptimizer): **parity unpinned**.
+  and v-trace losses, the Keras ``impala_loss``, clip_by_global_norm, AdamOptimizer / RMSProp / tf.keras Adam):
+  **parity unpinned**.
   TensorFlow (1.15 / 2.3.1, un-vendored, not installable here) holds the
   arithmetic and the reference's tests pin no numbers for it, so this package
   restates TF's published semantics (VALID/SAME padding, NHWC/HWIO layouts,
