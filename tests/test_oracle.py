@@ -198,3 +198,61 @@ def test_split_batches_env_major():
     s = returns.split_batches(x, 4)
     assert s.shape == (4, 3) and s[1, 2] == 2 * 4 + 1
     assert returns.split_batches(x, 4, drop_last=True).shape == (3, 3)
+
+
+# ----------------------------------------------------------------------------------------------
+# the TensorFlow-side formulas: oracle restatement vs the reference's own sources EXECUTED under the
+# torch-float64 tf stand-in (oracle/gen_golden_tf.py -> tests/golden/tf_*.npz)
+# ----------------------------------------------------------------------------------------------
+def _close(got, ref, tol=1e-11):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()), np.abs(got - ref).max()
+
+
+def test_ppo_categorical_loss_matches_executed_reference(golden_dir):
+    files = sorted(glob.glob(os.path.join(golden_dir, "tf_ppo_cat_*.npz")))
+    assert len(files) == 4
+    for f in files:
+        g = np.load(f)
+        loss, dlg, dv, parts = nets.ppo_loss_and_grads(
+            g["logits"].astype(np.float64), g["value"].astype(np.float64), g["action"], g["old_logp"],
+            g["adv"].astype(np.float64), g["old_v"].astype(np.float64), g["target_v"].astype(np.float64),
+            float(g["clip"]), float(g["ent_coef"]), float(g["vf_clip"]), float(g["critic_coef"]))
+        _close(loss, g["loss"]); _close(parts["actor_loss"], g["actor_loss"]); _close(parts["critic_loss"], g["critic_loss"])
+        _close(parts["logp"], g["logp"]); _close(dlg, g["dlogits"]); _close(dv, g["dvalue"])
+        p, logp_all, ent = nets.softmax_stats(g["logits"].astype(np.float64))
+        _close(ent, g["entropy"])
+        # the fixture really contains the tie rows it claims: ratio == 1 and |v - old_v| == VF_CLIP exactly
+        assert np.array_equal(parts["logp"][:4], g["old_logp"][:4])
+        assert (np.abs(g["value"][4:8].astype(np.float64) - g["old_v"][4:8]) == float(g["vf_clip"])).all()
+
+
+def test_ppo_gaussian_loss_matches_executed_reference(golden_dir):
+    files = sorted(glob.glob(os.path.join(golden_dir, "tf_ppo_gauss_*.npz")))
+    assert len(files) == 3
+    for f in files:
+        g = np.load(f)
+        loss, dm, dv, dls, parts = nets.gauss_ppo_loss_and_grads(
+            g["mean"].astype(np.float64), g["log_std"].astype(np.float64), g["value"].astype(np.float64),
+            g["action"].astype(np.float64), g["old_logp"], g["adv"].astype(np.float64), g["old_v"].astype(np.float64),
+            g["target_v"].astype(np.float64), float(g["clip"]), float(g["ent_coef"]), float(g["vf_clip"]),
+            float(g["critic_coef"]))
+        _close(loss, g["loss"]); _close(parts["logp"], g["logp"]); _close(dm, g["dmean"]); _close(dv, g["dvalue"])
+        _close(dls, g["dlog_std"]); _close(parts["actor_loss"], g["actor_loss"])
+
+
+def test_impala_vtrace_and_loss_match_executed_reference(golden_dir):
+    files = sorted(glob.glob(os.path.join(golden_dir, "tf_impala_*.npz")))
+    assert len(files) == 8
+    for f in files:
+        g = np.load(f)
+        loss, dlg, dbl, parts = nets.impala_loss_and_grads(
+            g["logits"], g["baseline"], g["bp_logits"], g["actions"], g["dones"], g["rewards"], int(g["batch_step"]),
+            gamma=float(g["gamma"]))
+        _close(parts["vs"], g["vs"]); _close(parts["pg_adv"], g["pg_adv"])
+        _close(loss, g["loss"], 1e-10); _close(dlg, g["dlogits"]); _close(dbl, g["dbaseline"])
+        # split_batches index behaviour: the bootstrap row of every trajectory gets exactly zero gradient
+        t = int(g["batch_step"])
+        assert (g["dlogits"].reshape(-1, t, g["dlogits"].shape[-1])[:, -1] == 0).all()
+        assert (g["dbaseline"].reshape(-1, t)[:, -1] == 0).all()
