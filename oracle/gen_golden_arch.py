@@ -67,3 +67,25 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def dump_defaults():
+    """tests/golden/defaults.json: the module constants of the reference's four default_config files, read by
+    EXECUTING them (xt/model/{ppo,impala}/default_config.py, xt/algorithm/{ppo,impala}/default_config.py)."""
+    import json
+    out = {}
+    for key, rel in [("model/ppo", "xt/model/ppo/default_config.py"), ("model/impala", "xt/model/impala/default_config.py"),
+                     ("algorithm/ppo", "xt/algorithm/ppo/default_config.py"),
+                     ("algorithm/impala", "xt/algorithm/impala/default_config.py")]:
+        ns = {}
+        with open(os.path.join("/root/reference", rel)) as f:
+            exec(f.read(), ns)
+        out[key] = {k: v for k, v in ns.items() if k.isupper()}
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "defaults.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    dump_defaults()

@@ -454,3 +454,43 @@ def test_architecture_tables_match_reference_executed_goldens(golden_dir):
         probe = cls.__new__(cls)                       # option parsing only: no GPU, no network
         probe._read_trunk_options({}, None, *cls.TRUNK_DEFAULTS)
         assert probe.hidden_sizes == want["hidden_sizes"] and probe.activation == want["activation"]
+
+
+def test_defaults_are_the_reference_module_constants(golden_dir):
+    """xingtian_amd/defaults.py against tests/golden/defaults.json (oracle/gen_golden_arch.py executes the
+    reference's four default_config files)."""
+    import json
+    from xingtian_amd import defaults
+    with open(os.path.join(golden_dir, "defaults.json")) as f:
+        ref = json.load(f)
+    assert set(ref) == set(defaults.DEFAULTS)
+    for key, vals in ref.items():
+        assert defaults.DEFAULTS[key] == vals, key
+
+
+def test_ppo_train_accepts_the_learner_threads_kwargs():
+    """learner.py:348 calls ``alg.train(episode_num=...)``; only ``perms`` may reach the model."""
+    from xingtian_amd.algorithm.ppo.ppo import PPO
+
+    class _Actor(object):
+        stream_ingest = False
+
+        def train(self, state, label, perms=None):
+            self.got = (state[0].shape, perms)
+            return np.float32(0.5)
+
+    alg = PPO.__new__(PPO)
+    from xingtian_amd.algorithm.algorithm import RolloutFields
+    alg._rollout, alg._streamed, alg.actor = RolloutFields(*PPO.FIELDS), 0, _Actor()
+    t = 5
+    alg.prepare_data({"cur_state": np.zeros((t, 4), np.float32), "action": np.zeros(t, np.int32),
+                      "logp": np.zeros((t, 1), np.float32), "adv": np.zeros((t, 1)), "old_value": np.zeros((t, 1), np.float32),
+                      "target_value": np.zeros((t, 1))})
+    assert alg.train(episode_num=3) == np.float32(0.5)
+    assert alg.actor.got == ((t, 4), None)
+
+
+def test_ppo_cnn_netspec_rejects_unknown_input_dtype():
+    from xingtian_amd.model import netspec
+    with pytest.raises(ValueError):
+        netspec.ppo_cnn((84, 84, 4), 4, (256,), "relu", True, input_dtype="uint16")

@@ -55,15 +55,18 @@ class PPO(Algorithm):
         self._rollout.add(**{k: train_data[k] for k in self.FIELDS})
 
     def train(self, **kwargs):
-        """No advantage normalisation (a comment in the reference, xt/algorithm/ppo/ppo.py:73)."""
+        """No advantage normalisation (a comment in the reference, xt/algorithm/ppo/ppo.py:73).  The learner thread
+        calls ``train(episode_num=...)`` (xt/framework/learner.py:348); the reference ignores its kwargs, here only
+        ``perms`` (injected epoch shuffles, for tests) is understood by the model."""
+        perms = kwargs.get("perms")
         streamed_all = self._streamed > 0 and self._streamed == len(self._rollout)
         if streamed_all:                 # the rollout already sits in HBM: no concat, no upload
-            loss = self.actor.train_ingested(**kwargs)
+            loss = self.actor.train_ingested(perms=perms)
         else:
             if self._streamed:
                 self.actor._ingest.reset()
             obs, *labels = self._rollout.stacked()
-            loss = self.actor.train([obs], labels, **kwargs)
+            loss = self.actor.train([obs], labels, perms=perms)
         self._forget_rollout()
         return loss
 

@@ -16,9 +16,10 @@ _FIELDS = (("action", torch.int32, np.int32), ("old_logp", torch.float32, np.flo
 
 
 class _BufferSet(object):
-    def __init__(self, cap, obs_tail, obs_dtype, n_epochs, device):
+    def __init__(self, cap, obs_tail, obs_u8, n_epochs, device, sig):
         self.cap = cap
-        tdt = torch.uint8 if obs_dtype == np.uint8 else torch.float32
+        self.sig = sig
+        tdt = torch.uint8 if obs_u8 else torch.float32
         self.host = {"obs": torch.empty((cap,) + obs_tail, dtype=tdt, pin_memory=True)}
         self.dev = {"obs": torch.empty((cap,) + obs_tail, dtype=tdt, device=device)}
         for name, tdt2, _ in _FIELDS:
@@ -31,7 +32,11 @@ class _BufferSet(object):
 
 
 class RolloutIngest(object):
-    def __init__(self, device, n_epochs, initial_capacity=4096):
+    def __init__(self, device, n_epochs, initial_capacity=4096, obs_u8=None):
+        """``obs_u8``: the observation type the NETWORK reads (``spec.input_xform[0]``: uint8 frames vs float32);
+        arriving arrays of another dtype are cast into the staging buffer like the upload path casts them.  None
+        = take the dtype of the first array (stand-alone use)."""
+        self.obs_u8 = obs_u8
         self.device = torch.device(device)
         self.n_epochs = n_epochs
         self.initial_capacity = initial_capacity
@@ -39,27 +44,26 @@ class RolloutIngest(object):
         self.sets = [None, None]
         self.cur = 0
         self.n = 0
-        self._sig = None
 
     # ------------------------------------------------------------------
     def _ensure(self, need, obs):
-        sig = (tuple(obs.shape[1:]), obs.dtype == np.uint8)
+        u8 = (obs.dtype == np.uint8) if self.obs_u8 is None else bool(self.obs_u8)
+        sig = (tuple(obs.shape[1:]), u8)
         s = self.sets[self.cur]
-        if s is not None and self._sig == sig and s.cap >= need:
+        same = s is not None and s.sig == sig          # every buffer set remembers the layout it was built for
+        if same and s.cap >= need:
             return s
         cap = max(self.initial_capacity, need)
-        if s is not None and self._sig == sig:
+        if same:
             cap = max(cap, 2 * s.cap)
-        new = _BufferSet(cap, tuple(obs.shape[1:]), np.uint8 if obs.dtype == np.uint8 else np.float32,
-                         self.n_epochs, self.device)
-        if s is not None and self._sig == sig and self.n > 0:        # grow: keep what was already ingested
+        new = _BufferSet(cap, tuple(obs.shape[1:]), u8, self.n_epochs, self.device, sig)
+        if same and self.n > 0:                        # grow: keep what was already ingested
             self.copy_stream.synchronize()
             for k in new.host:
                 new.host[k][:self.n].copy_(s.host[k][:self.n])
             with torch.cuda.stream(self.copy_stream):
                 for k in new.host:
                     new.dev[k][:self.n].copy_(new.host[k][:self.n], non_blocking=True)
-        self._sig = sig
         self.sets[self.cur] = new
         return new
 

@@ -82,6 +82,14 @@ class ImpalaCnnOpt(XTModel):
         self._global_step += 1
         return np.float32(out[0].item())
 
+    def extra_optimizer_state(self):
+        """``global_step`` drives ``lr_schedule`` (impala_cnn_opt.py:198-203): it belongs to a true resume."""
+        return {"global_step": np.int64(self._global_step)}
+
+    def restore_extra_optimizer_state(self, arrays):
+        if "global_step" in arrays:
+            self._global_step = int(arrays["global_step"])
+
     def current_lr(self, decay_step=20000.0):
         """Learning rate of the NEXT update (``_get_lr``, impala_cnn_opt.py:236-249)."""
         if not self.lr_schedule:

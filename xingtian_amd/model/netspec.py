@@ -167,6 +167,8 @@ def _mlp(prefix, cin, hidden_sizes, act, trunk):
 
 def ppo_cnn(state_dim, action_dim, hidden_sizes=(512,), act="relu", vf_share=True, input_dtype="uint8",
             action_type="Categorical"):
+    if input_dtype not in ("uint8", "float32"):      # get_cnn_backbone, xt/model/model_utils.py:53-58
+        raise ValueError("dtype: {} not supported automatically, please implement it yourself".format(input_dtype))
     layers, feat = [], None
     for trunk, prefix in enumerate(["shared"] if vf_share else ["pi", "v"]):
         h, w, c = state_dim

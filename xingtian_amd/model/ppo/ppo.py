@@ -148,7 +148,8 @@ class PPO(XTModel):
         """Called by ``PPO.prepare_data`` for every trajectory; starts its pinned-staging + async H2D copy."""
         if self._ingest is None:
             from xingtian_amd.ingest import RolloutIngest
-            self._ingest = RolloutIngest(self.net.device, self.num_sgd_iter)
+            self._ingest = RolloutIngest(self.net.device, self.num_sgd_iter,
+                                         obs_u8=bool(self.net.spec.input_xform[0]))
         self._ingest.put(train_data["cur_state"], train_data["action"], train_data["logp"], train_data["adv"],
                          train_data["old_value"], train_data["target_value"])
 
