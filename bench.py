@@ -1,22 +1,35 @@
 #!/usr/bin/env python
-"""Learner-throughput benchmark of the MI355X-native PPO update (BASELINE.json metric).
+"""Learner-throughput benchmark of the MI355X-native PPO / IMPALA update (BASELINE.json metric).
 
-One "step" = one complete learner update on one synthetic rollout batch that is already
-resident in HBM: GAE over env_num x T transitions (xt/agent/ppo/ppo.py:77-106 moved to the
-learner) followed by Model.train (xt/model/ppo/ppo.py:111-132): NUM_SGD_ITER epochs x
-ceil(N/BATCH_SIZE) minibatch SGD steps (forward, PPO loss, backward, global-norm clip,
-Adam).  Workload = BASELINE.json configs[1]: examples/breakout_ppo.yaml, PpoCnn 84x84x4,
-env_num=32, T=128 (N=4096 samples), BATCH_SIZE=320, NUM_SGD_ITER=4, hidden 256, A=4.
+Headline (``value``): BASELINE.json configs[1] = examples/breakout_ppo.yaml, PpoCnn 84x84x4 uint8, env_num=32,
+T=128 (N=4096 samples), BATCH_SIZE=320, NUM_SGD_ITER=4, hidden 256, A=4.  One "step" = one complete learner update
+on one synthetic rollout that is already resident in HBM: GAE over env_num x T transitions
+(xt/agent/ppo/ppo.py:77-106 moved to the learner) + Model.train (xt/model/ppo/ppo.py:111-132): 52 minibatch SGD
+steps (forward, PPO loss, backward, global-norm clip, Adam).  value = env-frames/s = 4 (frame-skip) x env-steps
+consumed / wall time, whole job over all ranks.
 
-value = env-frames/s = 4 (frame-skip) x env-steps consumed / wall time, whole job over all
-ranks.  N>1: one process per GPU (torchrun), weak scaling: every rank owns env_num=32
-trajectories and a 320-row local minibatch; gradients are summed with one RCCL all-reduce of
-the flat fp32 gradient buffer per SGD step, then every rank applies the identical
-clip+Adam update (grad_scale = 1/N).
+The same JSON line also carries (rank 0, one GPU):
+  roofline      dominant kernel of an SGD step, timed live with HIP events on the launch stream
+  e2e           SURVEY 8(d)'s metric through the PLUGIN classes: alg.prepare_data x env_num (host numpy ->
+                pinned staging -> async H2D) + alg.train() + alg.get_weights() (D2H), env_num 32 and the YAML's 10
+  secondary     configs[2] breakout_impala.yaml (ImpalaCnnOpt 84x84, T=128, one SGD step per message) and
+                configs[4] pong_impala_speedup.yaml (42x42, A=6, 1000-frame steps), HBM-resident and through
+                IMPALAOpt, each with its own roofline and cpu_baseline
+  cpu_baseline  the torch-CPU fp32 restatement of the same update on the host cores (all cores and 1 thread) and the
+                numpy GAE per trajectory (bit-for-bit the reference's PPO.data_proc)
+  sustained     the headline loop repeated for >= 2 s
+
+N > 1: ``python bench.py --gpus N`` spawns N ranks itself (torch.distributed.run, one process per GPU, RCCL) when it
+is not already running under a launcher, and FAILS if it cannot.  Two data-parallel modes are measured in the same
+run: ``value`` = weak scaling (every rank owns env_num=32 trajectories and a 320-row local minibatch, one all-reduce
+of the flat fp32 gradient per SGD step, grad_scale 1/N); ``strict`` = the reference's global minibatch of 320 rows
+split into N shards (40 rows per GPU at N=8), shared permutation, means over the global minibatch.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,128 +41,26 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16
 FRAME_SKIP = 4                  # xt/environment/gym/atari_wrappers.py:34
 
 CFG = dict(LR=2.5e-4, LOSS_CLIPPING=0.1, ENTROPY_LOSS=0.003, VF_CLIP=5.0, CRITIC_LOSS_COEF=1.0,
            MAX_GRAD_NORM=5.0, BATCH_SIZE=320, NUM_SGD_ITER=4)
 ENV_NUM, T_LEN, STATE_DIM, A_DIM, HIDDEN = 32, 128, (84, 84, 4), 4, (256,)
+PPO_MFLOP_PER_SAMPLE_PASS = 31.313
+IMPALA = {   # MFLOP per sample (fwd + bwd, one pass)
+    "breakout_impala": dict(dim=84, a_dim=4, t_len=128, frames_per_train=128, mean=0.0, std=255.0, lr=5e-4,
+                            mflop=19.128, trains=64,
+                            name="examples/breakout_impala.yaml ImpalaCnnOpt 84x84x4 uint8 + v-trace, T=128, "
+                                 "vector_env_size=1, prepare_times_per_train=1 (one 128-frame SGD step per message)"),
+    "pong_impala_speedup": dict(dim=42, a_dim=6, t_len=50, frames_per_train=1000, mean=128.0, std=128.0, lr=1e-3,
+                                mflop=13.712, trains=16,
+                                name="examples/pong_impala_speedup.yaml ImpalaCnnOpt 42x42x4 uint8 (mean 128 / std 128) "
+                                     "A=6, T=50, 4 messages x 5 envs per train (one 1000-frame SGD step)"),
+}
 
 
-def synth_rollout(seed, env_num=ENV_NUM, t_len=T_LEN):
-    rng = np.random.default_rng(seed)
-    n = env_num * t_len
-    obs = rng.integers(0, 256, (n,) + STATE_DIM, dtype=np.uint8)
-    action = rng.integers(0, A_DIM, n).astype(np.int32)
-    logits = rng.standard_normal((n, A_DIM))
-    lsm = logits - np.log(np.exp(logits).sum(-1, keepdims=True))
-    logp = np.take_along_axis(lsm, action[:, None].astype(np.int64), 1).astype(np.float32).reshape(-1)
-    value = rng.standard_normal((env_num, t_len + 1)).astype(np.float32)
-    reward = rng.choice([-1.0, 0.0, 1.0], size=(env_num, t_len), p=[0.05, 0.9, 0.05])
-    done = (rng.random((env_num, t_len)) < 0.01)
-    return obs, action, logp, value, reward, done
-
-
-def host_cores():
-    """cores this process may actually use: min(cpu_count, affinity mask, cgroup cpu quota)."""
-    n = os.cpu_count() or 1
-    try:
-        n = min(n, len(os.sched_getaffinity(0)))
-    except AttributeError:
-        pass
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            quota, period = f.read().split()
-        if quota != "max":
-            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
-    except (OSError, ValueError):
-        pass
-    return n
-
-
-def cpu_baseline(obs, action, logp, value, reward, done, max_seconds=20.0):
-    """Oracle (torch-CPU fp32 restatement of the same update, oneDNN, all host cores) timed on a
-    bounded sample: a few B=320 SGD steps + the numpy GAE of the full rollout; extrapolated to the
-    full update.  Checker/baseline only -- never on the product path."""
-    from oracle import nets, returns, torch_ref
-    cores = min(host_cores(), 64)   # oneDNN does not scale past ~64 threads at B=320; count is reported
-    torch.set_num_threads(cores)
-    spec = nets.ppo_cnn_spec(STATE_DIM, A_DIM, HIDDEN, "relu", True)
-    params = nets.init_params(spec, seed=0)
-    learner = torch_ref.TorchPpoLearner(spec, params, CFG, torch.float32)
-    t0 = time.perf_counter()
-    advs = []
-    for i in range(value.shape[0]):
-        a, _, tg = returns.gae(value[i].reshape(-1, 1), reward[i].copy(), done[i])
-        advs.append((a, tg))
-    t_gae = time.perf_counter() - t0
-    n = obs.shape[0]
-    b = CFG["BATCH_SIZE"]
-    adv = np.concatenate([a for a, _ in advs]).astype(np.float32)
-    tgt = np.concatenate([t for _, t in advs]).astype(np.float32)
-    oldv = value[:, :-1].reshape(-1, 1)
-    rng = np.random.default_rng(0)
-    steps, t_steps = 0, 0.0
-    learner.step(obs[:b], action[:b], logp[:b].reshape(-1, 1), adv[:b], oldv[:b], tgt[:b])   # warm-up
-    while t_steps < max_seconds and steps < 24:
-        mb = rng.permutation(n)[:b]
-        t1 = time.perf_counter()
-        learner.step(obs[mb], action[mb], logp[mb].reshape(-1, 1), adv[mb], oldv[mb], tgt[mb])
-        t_steps += time.perf_counter() - t1
-        steps += 1
-    per_step = t_steps / steps
-    nsteps_full = CFG["NUM_SGD_ITER"] * ((n + b - 1) // b)
-    t_full = t_gae + per_step * nsteps_full
-    return {"value": FRAME_SKIP * n / t_full, "unit": "env-frames/s", "cores": cores, "kind": "port",
-            "sample": "{} SGD steps of B={} (fp32 torch-CPU restatement, oneDNN) + numpy GAE of {}x{}; "
-                      "extrapolated to {} steps/update".format(steps, b, value.shape[0], T_LEN, nsteps_full),
-            "ms_per_sgd_step": per_step * 1e3}
-
-
-def main_impala(args):
-    """Secondary workload: examples/breakout_impala.yaml -- one 'step' = 64 learner trains, each on one
-    128-frame message (prepare_times_per_train=1, BATCH_SIZE 512 >= 128), rollout resident in HBM."""
-    if int(os.environ.get("WORLD_SIZE", "1")) != 1:
-        raise RuntimeError("--workload impala is a single-GPU measurement")
-    torch.cuda.set_device(0)
-    from xingtian_amd.model import netspec
-    from xingtian_amd.model.hip_net import HipActorCritic
-    n_msg, t_len, a_dim = 64, 128, 4
-    rng = np.random.default_rng(0)
-    n = n_msg * t_len
-    dev = torch.device("cuda", 0)
-    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    obs = d(rng.integers(0, 256, (n,) + STATE_DIM, dtype=np.uint8))
-    bp = d(rng.standard_normal((n, a_dim)).astype(np.float32))
-    act = d(rng.integers(0, a_dim, n).astype(np.int32))
-    done = d((rng.random(n) < 0.01).astype(np.uint8))
-    rew = d(rng.choice([-1.0, 0.0, 1.0], n, p=[0.05, 0.9, 0.05]).astype(np.float32))
-    spec = netspec.impala_cnn_opt(STATE_DIM, a_dim, 0.0, 255.0)
-    net = HipActorCritic(spec, max_batch=t_len, seed=0)
-    cfg = net.make_impala_cfg(5e-4, 40.0, t_len)
-
-    def one_update():
-        for i in range(n_msg):
-            sl = slice(i * t_len, (i + 1) * t_len)
-            net.impala_step(cfg, obs[sl], bp[sl], act[sl], done[sl], rew[sl], apply=True)
-
-    for _ in range(args.warmup):
-        one_update()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_update()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    assert torch.isfinite(net.params).all()
-    _emit({
-        "metric": "learner env-frames/sec (Atari 84x84x4)", "value": FRAME_SKIP * n * args.steps / el,
-        "unit": "env-frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "fp32", "data": "synthetic",
-        "config": {"workload": "examples/breakout_impala.yaml ImpalaCnnOpt 84x84x4 uint8 + v-trace, 64 messages x "
-                               "T=128 frames per step (one SGD step per message), HBM-resident", "parallelism": "dp1"}})
-
-
+# ------------------------------------------------------------------------------------------------ plumbing
 _REAL_STDOUT = None
 
 
@@ -171,131 +82,474 @@ def _emit(obj):
     out.flush()
 
 
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """cores this process may actually use: min(cpu_count, affinity mask, cgroup cpu quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_spawn(args):
+    """``python bench.py --gpus N`` outside a launcher: re-exec under torch.distributed.run with N ranks on this
+    node.  Never falls back to fewer ranks."""
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        raise RuntimeError("bench.py --gpus {} needs {} visible GPUs, found {}".format(args.gpus, args.gpus, have))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log("spawning", args.gpus, "ranks:", " ".join(cmd))
+    proc = subprocess.run(cmd, env=env, stdout=_claim_stdout())
+    if proc.returncode != 0:
+        raise RuntimeError("bench.py: the {}-rank run failed with exit code {}".format(args.gpus, proc.returncode))
+
+
+# ------------------------------------------------------------------------------------------------ synthetic data
+def synth_rollout(seed, env_num=ENV_NUM, t_len=T_LEN):
+    """uint8 frames ~ U{0..255}, actions ~ U{0..3}, logp = log-softmax of N(0,1) logits at the
+    action, value ~ N(0,1), reward in {-1,0,1} (p .05/.9/.05), done ~ Bernoulli(0.01)."""
+    rng = np.random.default_rng(seed)
+    n = env_num * t_len
+    obs = rng.integers(0, 256, (n,) + STATE_DIM, dtype=np.uint8)
+    action = rng.integers(0, A_DIM, n).astype(np.int32)
+    logits = rng.standard_normal((n, A_DIM))
+    lsm = logits - np.log(np.exp(logits).sum(-1, keepdims=True))
+    logp = np.take_along_axis(lsm, action[:, None].astype(np.int64), 1).astype(np.float32).reshape(-1)
+    value = rng.standard_normal((env_num, t_len + 1)).astype(np.float32)
+    reward = rng.choice([-1.0, 0.0, 1.0], size=(env_num, t_len), p=[0.05, 0.9, 0.05])
+    done = (rng.random((env_num, t_len)) < 0.01)
+    return obs, action, logp, value, reward, done
+
+
+def synth_impala(seed, n, dim, a_dim):
+    rng = np.random.default_rng(seed)
+    return dict(obs=rng.integers(0, 256, (n, dim, dim, 4), dtype=np.uint8),
+                logit=rng.standard_normal((n, a_dim)).astype(np.float32),
+                action=rng.integers(0, a_dim, n).astype(np.int32),
+                done=(rng.random(n) < 0.01),
+                reward=rng.choice([-1.0, 0.0, 1.0], n, p=[0.05, 0.9, 0.05]))
+
+
+# ------------------------------------------------------------------------------------------------ CPU baselines
+def cpu_baseline_ppo(obs, action, logp, value, reward, done, max_seconds=14.0):
+    """Oracle (torch-CPU fp32 restatement of the same update, oneDNN) timed on a bounded sample: B=320 SGD steps
+    with all host cores and with one thread + the numpy GAE of the full rollout (oracle.returns.gae is bit-for-bit
+    the reference's PPO.data_proc, tests/golden/gae_*.npz); extrapolated to the full update.  Checker/baseline only
+    -- never on the product path."""
+    from oracle import nets, returns, torch_ref
+    cores = min(host_cores(), 64)   # oneDNN does not scale past ~64 threads at B=320; the count is reported
+    spec = nets.ppo_cnn_spec(STATE_DIM, A_DIM, HIDDEN, "relu", True)
+    params = nets.init_params(spec, seed=0)
+    t0 = time.perf_counter()
+    advs = []
+    for i in range(value.shape[0]):
+        a, _, tg = returns.gae(value[i].reshape(-1, 1), reward[i].copy(), done[i])
+        advs.append((a, tg))
+    t_gae = time.perf_counter() - t0
+    n = obs.shape[0]
+    b = CFG["BATCH_SIZE"]
+    adv = np.concatenate([a for a, _ in advs]).astype(np.float32)
+    tgt = np.concatenate([t for _, t in advs]).astype(np.float32)
+    oldv = value[:, :-1].reshape(-1, 1)
+    nsteps_full = CFG["NUM_SGD_ITER"] * ((n + b - 1) // b)
+
+    def timed(threads, budget, max_steps):
+        torch.set_num_threads(threads)
+        learner = torch_ref.TorchPpoLearner(spec, params, CFG, torch.float32)
+        rng = np.random.default_rng(0)
+        learner.step(obs[:b], action[:b], logp[:b].reshape(-1, 1), adv[:b], oldv[:b], tgt[:b])   # warm-up
+        steps, t_steps = 0, 0.0
+        while t_steps < budget and steps < max_steps:
+            mb = rng.permutation(n)[:b]      # the reference's fancy-index minibatch gather is part of the step
+            t1 = time.perf_counter()
+            learner.step(obs[mb], action[mb], logp[mb].reshape(-1, 1), adv[mb], oldv[mb], tgt[mb])
+            t_steps += time.perf_counter() - t1
+            steps += 1
+        return t_steps / steps, steps
+
+    per_step, steps = timed(cores, max_seconds, 24)
+    per_step_1, steps_1 = timed(1, 6.0, 4)
+    torch.set_num_threads(cores)
+    t_full = t_gae + per_step * nsteps_full
+    t_full_1 = t_gae + per_step_1 * nsteps_full
+    return {"value": FRAME_SKIP * n / t_full, "unit": "env-frames/s", "cores": cores, "kind": "port",
+            "sample": "{} SGD steps of B={} (fp32 torch-CPU restatement, oneDNN) + numpy GAE of {}x{}; "
+                      "extrapolated to {} steps/update".format(steps, b, value.shape[0], T_LEN, nsteps_full),
+            "ms_per_sgd_step": per_step * 1e3,
+            "one_thread": {"value": FRAME_SKIP * n / t_full_1, "ms_per_sgd_step": per_step_1 * 1e3, "steps": steps_1},
+            "gae_numpy_ms_per_trajectory": 1e3 * t_gae / value.shape[0]}
+
+
+def cpu_baseline_impala(w, data, max_seconds=5.0):
+    from oracle import nets, torch_ref
+    cores = min(host_cores(), 64)
+    torch.set_num_threads(cores)
+    spec = nets.impala_cnn_opt_spec((w["dim"], w["dim"], 4), w["a_dim"], w["mean"], w["std"])
+    params = nets.init_params(spec, seed=0)
+    learner = torch_ref.TorchImpalaLearner(spec, params, dict(LR=w["lr"], grad_norm_clip=40.0,
+                                                              sample_batch_step=w["t_len"]), torch.float32)
+    f = w["frames_per_train"]
+    sl = slice(0, f)
+    call = lambda: learner.step(data["obs"][sl], data["logit"][sl], data["action"][sl], data["done"][sl],
+                                data["reward"][sl].astype(np.float32))
+    call()
+    steps, t = 0, 0.0
+    while t < max_seconds and steps < 24:
+        t1 = time.perf_counter()
+        call()
+        t += time.perf_counter() - t1
+        steps += 1
+    return {"value": FRAME_SKIP * f * steps / t, "unit": "env-frames/s", "cores": cores, "kind": "port",
+            "sample": "{} SGD steps of {} frames (fp32 torch-CPU restatement incl. v-trace)".format(steps, f),
+            "ms_per_sgd_step": 1e3 * t / steps}
+
+
+# ------------------------------------------------------------------------------------------------ GPU measurements
+def layer_rooflines(net, spec, rows, obs, idx, x6=True):
+    """Every layer kernel of one SGD step timed live with HIP events on the launch stream (xt_net_time_layer);
+    algorithmic FLOPs = 2*M*N*K per GEMM.  Returns {label: (ms, flops, arithmetic kind)}."""
+    kern = {}
+    for li, lay in enumerate(spec.layers):
+        mnk2 = 2.0 * rows * lay.OH * lay.OW * lay.N * lay.K
+        first = li == 0
+        # the bf16x3 first-layer kernels (xt_conv1.hip: uint8 NHWC C=4, 8x8 VALID -> 32 channels, mean 0)
+        u8c4 = bool(first and spec.input_xform[0] and lay.C == 4 and lay.KH == 8 and lay.N == 32 and lay.PT == 0
+                    and spec.input_xform[1] == 0.0)
+        kern["L%d %s fwd" % (li, lay.name)] = (net.time_layer(li, 0, obs, idx, rows, 50), mnk2, "bf16x3" if u8c4 else "fp32")
+        if first:
+            kern["L0 %s wgrad" % lay.name] = (net.time_layer(0, 1, obs, idx, rows, 50), mnk2, "bf16x3" if u8c4 else "fp32")
+        else:
+            # conv backward launches: the input-gradient half runs bf16x6 (six bf16 MFMAs per 16-deep chunk), the
+            # weight-gradient half fp32 MFMA -> peak of the launch = harmonic mean of the two halves' peaks
+            # (xt_igemm.hip launch_bwd_layer: the all-classes stride-2 form needs VALID, C = N = 32 and even extents;
+            # the halo-staged stride-1 form a small map)
+            valid = lay.PT == 0 and lay.PL == 0 and (lay.OH - 1) * lay.S + lay.KH <= lay.H
+            s2 = lay.S == 2 and lay.C == 32 and lay.N == 32 and lay.H % 2 == 0 and lay.KH % 2 == 0
+            s1 = lay.S == 1 and lay.KH > 1 and lay.H * lay.W <= 128 and rows * lay.H * lay.W > 512 * 64
+            kind = "fp32+bf16x6" if (x6 and valid and (s2 or s1)) else "fp32"
+            kern["L%d %s dgrad+wgrad" % (li, lay.name)] = (net.time_layer(li, 3, obs, idx, rows, 50), 2 * mnk2, kind)
+    return kern
+
+
+PEAK = {"fp32": FP32_MFMA_PEAK_TFLOPS, "bf16x3": BF16_MFMA_PEAK_TFLOPS / 3.0,
+        "fp32+bf16x6": 2.0 / (1.0 / FP32_MFMA_PEAK_TFLOPS + 6.0 / BF16_MFMA_PEAK_TFLOPS)}
+
+
+def roofline_of(kern, traffic_json=None, prefix=""):
+    dom = max(kern, key=lambda k: kern[k][0])
+    ms, flops, kind = kern[dom]
+    ach = flops / (ms * 1e-3) / 1e12
+    traffic = None
+    if traffic_json and os.path.exists(traffic_json):
+        try:
+            tj = json.load(open(traffic_json))
+            row = tj.get("by_label", {}).get(prefix + dom)
+            if row:
+                traffic = (2.0 * row["FETCH_SIZE_KB"] + row["WRITE_SIZE_KB"]) * 1024.0   # gfx950: FETCH_SIZE counts 64 B units as 32
+        except (OSError, ValueError, KeyError):
+            traffic = None
+    return {"bound": "mfma", "kernel": dom, "arith": kind, "achieved": ach, "peak": PEAK[kind], "unit": "TFLOP/s",
+            "frac": ach / PEAK[kind], "traffic": traffic, "flop_per_launch": flops, "avg_launch_ms": ms,
+            "kernels_us": {k: round(v[0] * 1e3, 2) for k, v in kern.items()},
+            "sum_layer_kernels_us": round(sum(v[0] for v in kern.values()) * 1e3, 1)}
+
+
+def bench_e2e_ppo(env_num, min_seconds=1.0, max_updates=40):
+    """(rollout samples consumed by one Algorithm.train()) / (wall time of prepare_data x env_num +
+    train() incl. the H2D of the uint8 rollout + get_weights D2H), through the plugin classes exactly as
+    xt/framework/learner.py:306-313,346-348,361-363 drives them.  Host arrays are plain (pageable) numpy."""
+    from xingtian_amd.algorithm import alg_builder
+    from oracle import returns      # baseline-side helper only: the actors' GAE (not timed, not the product path)
+    model_info = {"actor": {"model_name": "PpoCnn", "state_dim": list(STATE_DIM), "action_dim": A_DIM,
+                            "input_dtype": "uint8",
+                            "model_config": dict(CFG, SUMMARY=False, VF_SHARE_LAYERS=True, activation="relu",
+                                                 hidden_sizes=list(HIDDEN), action_type="Categorical", SEED=0)}}
+    alg = alg_builder("PPO", model_info, {"instance_num": env_num, "agent_num": 1})
+    obs, action, logp, value, reward, done = synth_rollout(100 + env_num, env_num)
+    trajs = []
+    for i in range(env_num):
+        a, ov, tg = returns.gae(value[i].reshape(-1, 1), reward[i].copy(), done[i])
+        sl = slice(i * T_LEN, (i + 1) * T_LEN)
+        trajs.append({"cur_state": obs[sl], "action": action[sl], "logp": logp[sl].reshape(-1, 1), "adv": a,
+                      "old_value": ov, "target_value": tg})
+    t_prep = t_train = t_w = 0.0
+    updates = 0
+
+    def one(timed):
+        nonlocal t_prep, t_train, t_w, updates
+        t0 = time.perf_counter()
+        for tr in trajs:
+            alg.prepare_data(tr)
+        t1 = time.perf_counter()
+        loss = alg.train(episode_num=updates)
+        t2 = time.perf_counter()
+        w = alg.get_weights()
+        t3 = time.perf_counter()
+        assert np.isfinite(loss) and len(w) == 12
+        if timed:
+            t_prep += t1 - t0; t_train += t2 - t1; t_w += t3 - t2; updates += 1
+
+    for _ in range(3):
+        one(False)
+    t_begin = time.perf_counter()
+    while updates < max_updates and (updates < 5 or time.perf_counter() - t_begin < min_seconds):
+        one(True)
+    total = t_prep + t_train + t_w
+    n = env_num * T_LEN
+    bytes_h2d = n * (int(np.prod(STATE_DIM)) + 4 + 4 + 8 + 4 + 8)
+    return {"env_num": env_num, "env_steps_per_update": n, "updates": updates,
+            "value": FRAME_SKIP * n * updates / total, "unit": "env-frames/s", "ms_per_update": 1e3 * total / updates,
+            "prepare_data_ms": 1e3 * t_prep / updates, "train_ms": 1e3 * t_train / updates,
+            "get_weights_ms": 1e3 * t_w / updates, "h2d_bytes_per_update": bytes_h2d,
+            "h2d_ms_at_55GBps": 1e3 * bytes_h2d / 55e9, "stream_ingest": bool(alg.actor.stream_ingest),
+            "path": "alg_builder('PPO') -> prepare_data x {} (pageable numpy -> pinned staging -> async H2D) -> "
+                    "train() -> get_weights() (one pinned D2H)".format(env_num)}
+
+
+def bench_impala(key, steps, warmup, with_cpu):
+    """HBM-resident and plugin-path measurements of one IMPALA configuration (secondary workloads)."""
+    from xingtian_amd.algorithm import alg_builder
+    from xingtian_amd.model import netspec
+    from xingtian_amd.model.hip_net import HipActorCritic
+    w = IMPALA[key]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    f, trains = w["frames_per_train"], w["trains"]
+    n = f * trains
+    data = synth_impala(7, n, w["dim"], w["a_dim"])
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    dobs, dbp, dact = d(data["obs"]), d(data["logit"]), d(data["action"])
+    ddone, drew = d(data["done"].astype(np.uint8)), d(data["reward"].astype(np.float32))
+    spec = netspec.impala_cnn_opt((w["dim"], w["dim"], 4), w["a_dim"], w["mean"], w["std"], "uint8")
+    net = HipActorCritic(spec, max_batch=f, seed=0)
+    cfg = net.make_impala_cfg(w["lr"], 40.0, w["t_len"])
+
+    def one_step():      # `trains` learner trains (one BATCH_SIZE chunk each) enqueued by ONE C call, hipGraph replay
+        net.impala_train(cfg, dobs, f, dbp, dact, ddone, drew, use_graph=True)
+
+    for _ in range(warmup):
+        one_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    assert torch.isfinite(net.params).all()
+    us_per_train = 1e6 * el / (steps * trains)
+    kern = layer_rooflines(net, spec, f, dobs, None, x6=True)
+    roof = roofline_of(kern, os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"), prefix=key + ": ")
+    out = {"workload": w["name"], "metric": "learner env-frames/sec", "unit": "env-frames/s", "dtype": "fp32",
+           "value": FRAME_SKIP * n * steps / el, "us_per_train": us_per_train, "frames_per_train": f,
+           "trains_per_step": trains, "steps": steps,
+           "update_tflops": w["mflop"] * 1e6 * f / (us_per_train * 1e-6) / 1e12,
+           "update_frac_of_fp32_mfma_peak": w["mflop"] * 1e6 * f / (us_per_train * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+           "hip_graph": True, "roofline": roof}
+    del net
+    # ---- plugin path: IMPALAOpt.prepare_data x k -> train() -> get_weights(), host numpy in, per learner train
+    msgs_per_train = 1 if key == "breakout_impala" else 4
+    fm = f // msgs_per_train
+    model_info = {"actor": {"model_name": "ImpalaCnnOpt", "state_dim": [w["dim"], w["dim"], 4], "input_dtype": "uint8",
+                            "state_mean": w["mean"], "state_std": w["std"], "action_dim": w["a_dim"],
+                            "model_config": {"LR": w["lr"], "sample_batch_step": w["t_len"], "grad_norm_clip": 40.0,
+                                             "SEED": 0}}}
+    alg = alg_builder("IMPALAOpt", model_info, {"instance_num": 32, "agent_num": 1,
+                                               "prepare_times_per_train": msgs_per_train,
+                                               "BATCH_SIZE": max(f, 512) if key == "breakout_impala" else f})
+    msgs = []
+    for i in range(min(trains, 8) * msgs_per_train):
+        sl = slice(i * fm, (i + 1) * fm)
+        msgs.append({"cur_state": data["obs"][sl], "logit": data["logit"][sl], "action": data["action"][sl],
+                     "done": list(data["done"][sl]), "reward": list(data["reward"][sl])})
+    t_prep = t_train = t_w = 0.0
+    cnt = 0
+
+    def one_train(i, timed):
+        nonlocal t_prep, t_train, t_w, cnt
+        t0 = time.perf_counter()
+        for k in range(msgs_per_train):
+            alg.prepare_data(msgs[(i * msgs_per_train + k) % len(msgs)])
+        t1 = time.perf_counter()
+        loss = alg.train(episode_num=i)
+        t2 = time.perf_counter()
+        wts = alg.get_weights()
+        t3 = time.perf_counter()
+        assert np.isfinite(loss) and len(wts) >= 8
+        if timed:
+            t_prep += t1 - t0; t_train += t2 - t1; t_w += t3 - t2; cnt += 1
+
+    for i in range(6):
+        one_train(i, False)
+    tb = time.perf_counter()
+    i = 0
+    while cnt < 400 and (cnt < 20 or time.perf_counter() - tb < 1.0):
+        one_train(i, True)
+        i += 1
+    tot = t_prep + t_train + t_w
+    out["e2e"] = {"value": FRAME_SKIP * f * cnt / tot, "unit": "env-frames/s", "trains": cnt,
+                  "ms_per_train": 1e3 * tot / cnt, "prepare_data_ms": 1e3 * t_prep / cnt, "train_ms": 1e3 * t_train / cnt,
+                  "get_weights_ms": 1e3 * t_w / cnt,
+                  "path": "alg_builder('IMPALAOpt') -> prepare_data x {} -> train() -> get_weights()".format(msgs_per_train)}
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline_impala(w, data)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the IMPALA workloads and the plugin-path (e2e) runs")
+    ap.add_argument("--quick", action="store_true", help="headline + roofline only (profiling runs)")
     ap.add_argument("--force-dp-path", action="store_true",
-                    help="run the N>1 code path (step-wise fwd/bwd -> RCCL all-reduce -> clip+Adam) even with one rank: "
-                         "validates the data-parallel plumbing on a single GPU")
-    ap.add_argument("--dp-mode", default="eager", choices=["eager", "eager-overlap", "graph", "graph-overlap", "ingraph"],
+                    help="run the N>1 code path (step-wise fwd/bwd -> all-reduce -> clip+Adam) even with one rank")
+    ap.add_argument("--dp-mode", default="eager", choices=["eager", "ingraph"],
                     help="data-parallel path (N>1 or --force-dp-path).  eager (default): step-wise fwd/bwd -> one RCCL "
-                         "all-reduce of the flat gradient -> clip+Adam.  *overlap: two buckets, the Dense+heads gradient "
-                         "(95 %% of the bytes) all-reduced asynchronously under the conv backward.  graph*: the compute "
-                         "segments replayed from hipGraphs (parallel.DpGraphStepper).  Measured with a 1-rank RCCL group "
-                         "(ms per update): eager 8.4, graph 9.4, eager-overlap 11.4, graph-overlap 12.2 -- three small graph "
-                         "launches cost more than the dozen eager launches they replace, and every extra c10d call with "
-                         "its cross-stream events about 25 us; the alternatives are kept for interconnects where the "
-                         "all-reduce itself is the larger term.  ingraph: raw RCCL all-reduces enqueued by the library "
-                         "itself (xt_net_set_grad_exchange) and captured into the hipGraph of the whole update -- no "
-                         "host involvement per step; validated on one rank only, hence opt-in")
-    ap.add_argument("--workload", default="ppo", choices=["ppo", "impala"],
-                    help="ppo = BASELINE configs[1] (the headline metric, default); impala = configs[2] "
-                         "(breakout_impala.yaml, ImpalaCnnOpt + v-trace, env_num=64 messages of T=128), secondary")
+                         "all-reduce of the flat gradient (torch.distributed) -> clip+Adam.  ingraph: raw RCCL all-reduces "
+                         "enqueued by the library itself (xt_net_set_grad_exchange) and captured into the hipGraph of the "
+                         "whole update -- no host involvement per step; validated on one rank only, hence opt-in")
+    ap.add_argument("--workload", default="ppo", choices=["ppo", "breakout_impala", "pong_impala_speedup"],
+                    help="ppo = BASELINE configs[1] (the headline metric, default; its JSON line carries the IMPALA "
+                         "workloads as `secondary`); the IMPALA names print that workload's own line (profiling)")
     args = ap.parse_args()
-    if args.workload == "impala":
-        return main_impala(args)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return self_spawn(args)
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise RuntimeError("bench.py --gpus {} is running under a launcher with WORLD_SIZE={}".format(args.gpus, world))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU: the learner path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+
+    if args.workload != "ppo":
+        if world != 1:
+            raise RuntimeError("--workload {} is a single-GPU measurement".format(args.workload))
+        out = bench_impala(args.workload, args.steps, args.warmup, not args.no_cpu_baseline)
+        out.update({"n_gpus": 1, "warmup": args.warmup, "higher_is_better": True, "data": "synthetic"})
+        return _emit(out)
+
     dist = None
     if world > 1 or args.force_dp_path:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node {}".format(args.gpus)
 
     from xingtian_amd import lib as L
     from xingtian_amd.model import netspec
     from xingtian_amd.model.hip_net import HipActorCritic
-    from xingtian_amd.parallel import DpGraphStepper, RcclComm, dp_ppo_step
+    from xingtian_amd.parallel import RcclComm, dp_ppo_update
 
     dev = torch.device("cuda", local_rank)
-    obs, action, logp, value, reward, done = synth_rollout(seed=rank)
-    n = obs.shape[0]
     spec = netspec.ppo_cnn(STATE_DIM, A_DIM, HIDDEN, "relu", True)
-    net = HipActorCritic(spec, max_batch=CFG["BATCH_SIZE"], device=str(dev), seed=0)   # same seed -> same replica
     lib = L.load()
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    d_obs, d_act, d_logp = d(obs), d(action), d(logp)
-    d_value, d_reward, d_done = d(value), d(reward), d(done.astype(np.uint8))
-    d_adv = torch.empty((n,), dtype=torch.float64, device=dev)
-    d_tgt = torch.empty((n,), dtype=torch.float64, device=dev)
-    d_oldv = torch.empty((n,), dtype=torch.float32, device=dev)
-    perm_rng = np.random.default_rng(1234)   # identical on every rank
-    d_perm = torch.empty((CFG["NUM_SGD_ITER"], n), dtype=torch.int32, device=dev)
-    cfg = net.make_ppo_cfg(CFG, grad_scale=1.0 / world, global_batch=0)
     dp_path = world > 1 or args.force_dp_path
     use_graph = (not dp_path) and not args.no_graph
     bsz = CFG["BATCH_SIZE"]
-
-    def new_perms():
-        inds = np.arange(n)
-        p = np.empty((CFG["NUM_SGD_ITER"], n), np.int32)
-        for ep in range(CFG["NUM_SGD_ITER"]):
-            perm_rng.shuffle(inds)
-            p[ep] = inds
-        d_perm.copy_(torch.from_numpy(p), non_blocking=False)
-
-    rccl = None
-    if dp_path and args.dp_mode == "ingraph":
-        rccl = RcclComm(rank, world)
-        rccl.all_reduce_(net.grads.zero_(), L.stream_ptr())      # RCCL's lazy set-up outside any capture
-        torch.cuda.synchronize()
-        rccl.attach(net)
-    stepper = None
-    if dp_path and args.dp_mode.startswith("graph"):
-        stepper = DpGraphStepper(net, cfg, CFG["LR"], CFG["MAX_GRAD_NORM"], d_obs, d_act, d_logp, d_adv, d_oldv, d_tgt,
-                                 world, overlap=(args.dp_mode == "graph-overlap"))
-
-    def one_update():
-        new_perms()
-        st = L.stream_ptr()
-        L.check(lib.xt_gae_f64(L.ptr(d_value), L.ptr(d_reward), L.ptr(d_done), L.ptr(d_adv), L.ptr(d_tgt),
-                               L.ptr(d_oldv), ENV_NUM, T_LEN, 0.99, 0.95, st), "gae")
-        if not dp_path or rccl is not None:
-            net.ppo_train(cfg, d_obs, d_perm, d_act, d_logp, d_adv, d_oldv, d_tgt,
-                          use_graph=(use_graph or rccl is not None) and not args.no_graph)
-        else:
-            for ep in range(CFG["NUM_SGD_ITER"]):
-                for start in range(0, n, bsz):
-                    idx = d_perm[ep, start:start + bsz]
-                    # fwd/bwd -> RCCL sum over xGMI (Dense+heads bucket overlapped with the conv backward) -> clip+Adam
-                    if stepper is not None:
-                        stepper.step(idx)
-                    else:
-                        dp_ppo_step(net, cfg, CFG["LR"], CFG["MAX_GRAD_NORM"], d_obs, idx, d_act, d_logp, d_adv, d_oldv,
-                                    d_tgt, world, overlap=(args.dp_mode == "eager-overlap"))
+    perm_rng = np.random.default_rng(1234)   # identical on every rank
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_update()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_update()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.isfinite(net.params).all(), "non-finite parameters after the benchmark"
+    def run_mode(mode):
+        """mode 'weak': rollout seed = rank (own trajectories), full local minibatches; 'strict': the SAME rollout on
+        every rank, shards of the global minibatch."""
+        obs, action, logp, value, reward, done = synth_rollout(seed=rank if mode == "weak" else 0)
+        n = obs.shape[0]
+        net = HipActorCritic(spec, max_batch=bsz, device=str(dev), seed=0)   # same seed -> same replica
+        d_obs, d_act, d_logp = d(obs), d(action), d(logp)
+        d_value, d_reward, d_done = d(value), d(reward), d(done.astype(np.uint8))
+        d_adv = torch.empty((n,), dtype=torch.float64, device=dev)
+        d_tgt = torch.empty((n,), dtype=torch.float64, device=dev)
+        d_oldv = torch.empty((n,), dtype=torch.float32, device=dev)
+        d_perm = torch.empty((CFG["NUM_SGD_ITER"], n), dtype=torch.int32, device=dev)
+        cfg = net.make_ppo_cfg(CFG, grad_scale=1.0 / world, global_batch=0)
+        rccl = None
+        if dp_path and args.dp_mode == "ingraph" and mode == "weak":
+            rccl = RcclComm(rank, world)
+            rccl.all_reduce_(net.grads.zero_(), L.stream_ptr())      # RCCL's lazy set-up outside any capture
+            torch.cuda.synchronize()
+            rccl.attach(net)
 
+        def new_perms():
+            inds = np.arange(n)
+            p = np.empty((CFG["NUM_SGD_ITER"], n), np.int32)
+            for ep in range(CFG["NUM_SGD_ITER"]):
+                perm_rng.shuffle(inds)
+                p[ep] = inds
+            d_perm.copy_(torch.from_numpy(p), non_blocking=False)
+
+        def one_update():
+            new_perms()
+            L.check(lib.xt_gae_f64(L.ptr(d_value), L.ptr(d_reward), L.ptr(d_done), L.ptr(d_adv), L.ptr(d_tgt),
+                                   L.ptr(d_oldv), ENV_NUM, T_LEN, 0.99, 0.95, L.stream_ptr()), "gae")
+            if not dp_path or rccl is not None:
+                net.ppo_train(cfg, d_obs, d_perm, d_act, d_logp, d_adv, d_oldv, d_tgt,
+                              use_graph=(use_graph or rccl is not None) and not args.no_graph)
+            else:
+                dp_ppo_update(net, CFG, d_obs, d_perm, d_act, d_logp, d_adv, d_oldv, d_tgt, rank, world, mode=mode)
+
+        for _ in range(args.warmup):
+            one_update()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_update()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        assert torch.isfinite(net.params).all(), "non-finite parameters after the benchmark"
+        if dist is not None and world > 1:       # replicas must still be bit-identical
+            chk = net.params.double().sum().reshape(1)
+            lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            assert float(lo) == float(hi), "data-parallel replicas diverged"
+        keep = dict(net=net, obs=obs, action=action, logp=logp, value=value, reward=reward, done=done, d_obs=d_obs,
+                    d_perm=d_perm, one_update=one_update, rccl=rccl)
+        return elapsed, n, keep
+
+    elapsed, n, keep = run_mode("weak")
     frames = FRAME_SKIP * n * world * args.steps
+    sgd_steps = CFG["NUM_SGD_ITER"] * ((n + bsz - 1) // bsz)
+    graph_on = bool((use_graph or keep["rccl"] is not None) and not args.no_graph)
     out = {
         "metric": "learner env-frames/sec (Atari 84x84x4)", "value": frames / elapsed, "unit": "env-frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -303,64 +557,68 @@ def main():
         "config": {"workload": "examples/breakout_ppo.yaml PpoCnn 84x84x4 uint8, env_num=32/GPU, T=128, "
                                "BATCH_SIZE=320/GPU, NUM_SGD_ITER=4, hidden 256, A=4; step = GAE + full PPO update "
                                "(52 SGD steps) on an HBM-resident rollout",
-                   "env_steps_per_update": n * world, "sgd_steps_per_update": CFG["NUM_SGD_ITER"] * ((n + bsz - 1) // bsz),
-                   "parallelism": "dp{}".format(world), "hip_graph": bool((use_graph or rccl is not None) and not args.no_graph)},
+                   "env_steps_per_update": n * world, "sgd_steps_per_update": sgd_steps,
+                   "global_batch": bsz * world, "parallelism": "dp{}".format(world), "hip_graph": graph_on,
+                   "dp_path": bool(dp_path)},
     }
-    if rank == 0:
-        # ---- roofline of the dominant kernel: every layer kernel of one SGD step timed live with HIP events on
-        # the launch stream (xt_net_time_layer), algorithmic FLOPs = 2*M*N*K per GEMM
-        idx = d_perm[0, :bsz].contiguous()
-        kern = {}
-        for li, lay in enumerate(spec.layers):
-            mnk2 = 2.0 * bsz * lay.OH * lay.OW * lay.N * lay.K
-            if li == 0:
-                kern["L0 conv8x8/4 fwd  [conv_u8c4k8_fwd_flat_kernel]"] = (net.time_layer(0, 0, d_obs, idx, bsz, 50), mnk2, "bf16x3")
-                kern["L0 conv8x8/4 wgrad [conv_u8c4k8_wgrad_flat_kernel]"] = (net.time_layer(0, 1, d_obs, idx, bsz, 50), mnk2, "bf16x3")
-            else:
-                kern["L%d %s fwd  [igemm_fwd_kernel | direct_fwd_kernel]" % (li, lay.name)] = (net.time_layer(li, 0, d_obs, idx, bsz, 50), mnk2, "fp32")
-                # conv backward launches: the input-gradient half runs bf16x6 (six bf16 MFMAs per 16-deep chunk), the
-                # weight-gradient half fp32 MFMA -> peak of the launch = harmonic mean of the two halves' peaks
-                x6 = os.environ.get("XT_BF16X6", "1") != "0" and lay.KH > 1
-                kern["L%d %s dgrad+wgrad [igemm_bwd_layer_kernel]" % (li, lay.name)] = (
-                    net.time_layer(li, 3, d_obs, idx, bsz, 50), 2 * mnk2, "fp32+bf16x6" if x6 else "fp32")
-        dom = max(kern, key=lambda k: kern[k][0])
-        ms, flops, kind = kern[dom]
-        # fp32 kernels: v_mfma_f32_32x32x2_f32 dense peak; bf16x3 kernels spend 3 bf16 MFMA flops per algorithmic flop
-        peak = {"fp32": FP32_MFMA_PEAK_TFLOPS, "bf16x3": 2500.0 / 3.0,
-                "fp32+bf16x6": 2.0 / (1.0 / FP32_MFMA_PEAK_TFLOPS + 6.0 / 2500.0)}[kind]
-        ach = flops / (ms * 1e-3) / 1e12
-        # HBM traffic of the dominant kernel: PMC FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch from the
-        # committed rocprofv3 passes (profiles/r01_pmc_traffic.json holds every layer kernel), matched by kernel name
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        match = {"L0 conv8x8/4 fwd": "conv_u8c4k8_fwd", "L0 conv8x8/4 wgrad": "conv_u8c4k8_wgrad",
-                 "L1 shared_conv_layer_1 fwd": "direct_fwd_kernel", "L2 shared_conv_layer_2 fwd": "igemm_fwd_kernel<64, 64",
-                 "L3 shared_hidden_mlp_0 fwd": "igemm_fwd_kernel<64, 64",
-                 "L1 shared_conv_layer_1 dgrad+wgrad": "igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1",
-                 "L2 shared_conv_layer_2 dgrad+wgrad": "igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1",
-                 "L3 shared_hidden_mlp_0 dgrad+wgrad": "igemm_bwd_layer_kernel<64, 64, 2, 2, false, 64, 64, 2, 2"}
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                sub = next((v for k, v in match.items() if dom.startswith(k)), None)
-                for row in tj.get("all_kernels_KB", []):
-                    if sub and sub in row["kernel"]:
-                        traffic = (2.0 * row["FETCH_SIZE_KB"] + row["WRITE_SIZE_KB"]) * 1024.0
-                        break
-            except (OSError, ValueError, KeyError):
-                traffic = None
-        out["roofline"] = {"bound": "mfma", "kernel": dom, "arith": kind, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                           "frac": ach / peak, "traffic": traffic, "flop_per_launch": flops, "avg_launch_ms": ms,
-                           "kernels_us": {k: round(v[0] * 1e3, 2) for k, v in kern.items()},
-                           "sum_layer_kernels_us": round(sum(v[0] for v in kern.values()) * 1e3, 1)}
-        total_flops = 31.313e6 * n * CFG["NUM_SGD_ITER"]
-        out["update_tflops"] = total_flops * args.steps / elapsed / 1e12
-        out["config"]["dp_path"] = bool(dp_path)
-        if dp_path:
-            out["config"]["dp_mode"] = args.dp_mode if not (stepper is not None and stepper.failed) else "eager (capture failed)"
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(obs, action, logp, value, reward, done)
-        _emit(out)
+    if dp_path:
+        out["config"]["dp_mode"] = args.dp_mode
+        out["config"]["collective"] = "one all-reduce (SUM) of the flat fp32 gradient ({} floats) per SGD step, {}".format(
+            spec.n_flat, "torch.distributed nccl (RCCL)" if args.dp_mode == "eager" else "raw RCCL inside the hipGraph")
+        if dist is not None:
+            out["config"]["ranks_in_group"] = dist.get_world_size()
+    out["update_tflops"] = PPO_MFLOP_PER_SAMPLE_PASS * 1e6 * n * CFG["NUM_SGD_ITER"] * world * args.steps / elapsed / 1e12
+
+    if world > 1:
+        # ---- strict data parallelism: the reference's global minibatch of 320 rows sharded over the ranks
+        keep_weak = keep
+        del keep
+        keep_weak.pop("one_update"); keep_weak.pop("net")
+        torch.cuda.empty_cache()
+        el_s, n_s, keep_s = run_mode("strict")
+        out["strict"] = {"value": FRAME_SKIP * n_s * args.steps / el_s, "unit": "env-frames/s", "scaling": "strong",
+                         "ms_per_step": 1e3 * el_s / args.steps, "global_batch": bsz,
+                         "rows_per_gpu": bsz // world, "env_steps_per_update": n_s, "sgd_steps_per_update": sgd_steps,
+                         "note": "same rollout + same permutations on every rank, rank r takes rows "
+                                 "[r*B/N, (r+1)*B/N) of every global minibatch; loss means over the global minibatch; "
+                                 "arithmetic of the single-GPU update up to fp32 summation order"}
+        if rank == 0:
+            _emit(out)
+        dist.destroy_process_group()
+        return
+
+    # ------------------------------------------------------------------ single GPU: the rest of the line (rank 0)
+    net, d_obs, d_perm = keep["net"], keep["d_obs"], keep["d_perm"]
+    idx = d_perm[0, :bsz].contiguous()
+    kern = layer_rooflines(net, spec, bsz, d_obs, idx, x6=True)
+    out["roofline"] = roofline_of(kern, os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"), prefix="ppo: ")
+    if not args.quick:
+        # sustained: the same loop for >= 2 s (the K-step region above is ~0.16 s at K=20)
+        one_update = keep["one_update"]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 2.0:
+            for _ in range(10):
+                one_update()
+            torch.cuda.synchronize()
+            reps += 10
+        el = time.perf_counter() - t0
+        out["sustained"] = {"seconds": el, "updates": reps, "value": FRAME_SKIP * n * reps / el,
+                            "ms_per_step": 1e3 * el / reps}
+    obs, action, logp, value, reward, done = (keep[k] for k in ("obs", "action", "logp", "value", "reward", "done"))
+    del keep, net
+    torch.cuda.empty_cache()
+    if not (args.quick or args.no_secondary):
+        out["e2e"] = {"definition": "SURVEY 8(d): env-steps of one Algorithm.train() / wall time of prepare_data x k + "
+                                    "train() (incl. H2D of the uint8 rollout) + get_weights() (D2H), plugin classes",
+                      "env_num_32": bench_e2e_ppo(32), "env_num_10_yaml": bench_e2e_ppo(10)}
+        out["value_e2e"] = out["e2e"]["env_num_32"]["value"]
+        out["secondary"] = [bench_impala(k, 10, 3, not args.no_cpu_baseline)
+                            for k in ("breakout_impala", "pong_impala_speedup")]
+    if not (args.no_cpu_baseline or args.quick):
+        out["cpu_baseline"] = cpu_baseline_ppo(obs, action, logp, value, reward, done)
+    _emit(out)
     if dist is not None:
         dist.destroy_process_group()
 

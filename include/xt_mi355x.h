@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define XT_ABI_VERSION 5
+#define XT_ABI_VERSION 6
 
 #define XT_ACT_NONE 0
 #define XT_ACT_RELU 1
@@ -261,18 +261,6 @@ int xt_net_ppo_step(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, const i
                     const float* old_v, const double* target_v, int32_t apply,
                     float* loss_out, float* loss_acc, void* stream);
 
-/* The same SGD step (apply = 0) in two halves for data parallelism, so that the all-reduce of the large tail
- * of the flat gradient (the Dense layer feeding the heads + the heads: 95 % of PpoCnn's parameters) overlaps the
- * rest of the backward pass.  _begin: forward, loss, backward of the layer that feeds the heads; on return (in
- * stream order) grads[*tail_off .. n_params) is final.  _end: remaining backward; grads[0 .. *tail_off) final and
- * the local loss reported.  Networks that cannot be split (two trunks, single layer) do everything in _begin and
- * return *tail_off = 0.  Replaces the (dead) host-side gradient averaging of xt/framework/trainer.py:89-92. */
-int xt_net_ppo_step_begin(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, const int32_t* idx,
-                          int32_t B, const void* action, const float* old_logp, const double* adv,
-                          const float* old_v, const double* target_v, int64_t* tail_off, void* stream);
-int xt_net_ppo_step_end(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, const int32_t* idx,
-                        int32_t B, float* loss_out, float* loss_acc, void* stream);
-
 /* Model.train of xt/model/ppo/ppo.py:111-132 in one call: NUM_SGD_ITER epochs x
  * ceil(n/BATCH_SIZE) minibatches; perm [num_sgd_iter, n] int32 holds the epoch
  * permutations (the reference's np.random.shuffle, injected).  loss_acc[0] receives the
@@ -325,6 +313,21 @@ int xt_net_impala_step(xt_net* net, const xt_impala_cfg* cfg, const void* obs, i
                        const float* reward, int32_t apply, float* loss_out, float* loss_acc,
                        void* stream);
 
+/* IMPALAOpt.train of xt/algorithm/impala/impala_opt.py:73-106 in one call (ABI >= 6): the n frames of the
+ * concatenated rollout messages are consumed in sequential chunks of batch_size frames (no shuffling; n and
+ * batch_size must be multiples of sample_batch_step because split_batches, impala_cnn_opt.py:171-186, reshapes every
+ * chunk to [B, T]), one ImpalaCnnOpt.train (forward, v-trace, sum-form loss, backward, clip, optimiser) per chunk.
+ * lr_steps (device, may be NULL): step size of every chunk ([ceil(n/batch_size)] floats; the caller evaluates
+ * lr_schedule / linear_cosine_decay, impala_cnn_opt.py:234-249, per global_step) -- read on the device so that a
+ * replayed hipGraph sees new values; NULL -> cfg->lr.  loss_acc[0] receives the SUM of the chunk losses, loss_acc[1]
+ * the number of chunks (the algorithm returns their mean, impala_opt.py:106).  use_graph != 0 captures the call into
+ * a hipGraph on first use and replays it while pointers and sizes repeat (a small cache of graphs is kept, so that
+ * alternating ingest buffer sets do not re-capture).  A gradient-exchange hook (xt_net_set_grad_exchange) makes every
+ * chunk data parallel: local gradient -> exchange (SUM; the loss is a sum, grad_scale = 1) -> clip + Adam. */
+int xt_net_impala_train(xt_net* net, const xt_impala_cfg* cfg, const void* obs, int32_t n, int32_t batch_size,
+                        const float* bp_logits, const int32_t* action, const uint8_t* done, const float* reward,
+                        const float* lr_steps, float* loss_acc, int32_t use_graph, void* stream);
+
 /* clip + Adam on the net's flat gradient (second half of a data-parallel step) */
 int xt_net_apply(xt_net* net, float lr, float beta1, float beta2, float eps, float clip_norm,
                  float grad_scale, void* stream);
@@ -336,7 +339,7 @@ int xt_net_layer_offsets(const xt_net* net, int32_t layer, int64_t* out4);
 
 /* kernel-time probe: average duration (ms) of `reps` back-to-back launches of ONE layer kernel of the bound
  * network on `stream`, measured with HIP events on that stream (bench.py's roofline, tools/layer_bench.py). */
-int xt_net_time_layer(xt_net* net, int32_t layer, int32_t which /*0 fwd 1 wgrad 2 dgrad 3 fused dgrad+wgrad 4 fused conv-trunk fwd (layer..layer+2)*/,
+int xt_net_time_layer(xt_net* net, int32_t layer, int32_t which /* 0 fwd, 1 wgrad, 2 dgrad, 3 fused dgrad+wgrad */,
                       const void* obs, const int32_t* idx, int32_t B, int32_t reps,
                       float* ms_out, void* stream);
 

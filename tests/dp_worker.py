@@ -1,0 +1,83 @@
+"""Rank program of the multi-process data-parallel GPU tests (launched by tests/test_gpu_dp.py through
+torch.distributed.run).  Every rank builds the same HipActorCritic replica on the ONE visible GPU and runs the
+PRODUCT data-parallel path (xingtian_amd.parallel.dp_ppo_update / dp_impala_step); the gradient all-reduce goes through
+``gloo`` (RCCL refuses two ranks on one device; gloo accepts device tensors), so everything but the transport is what
+``bench.py --gpus N`` runs.  Rank r writes its final parameters to <outdir>/params_<mode>_r<r>.npy."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def ppo_case():
+    """shared by the worker and the single-process reference in the test"""
+    from xingtian_amd.model import netspec
+    spec = netspec.ppo_cnn((42, 42, 4), 4, (64,), "relu", True)
+    cfg = dict(LR=2.5e-4, LOSS_CLIPPING=0.1, ENTROPY_LOSS=0.003, VF_CLIP=5.0, CRITIC_LOSS_COEF=1.0,
+               MAX_GRAD_NORM=5.0, BATCH_SIZE=32, NUM_SGD_ITER=2)
+    return spec, cfg, 80        # 80 rows: 32 + 32 + 16 (short last minibatch: 8 rows per rank)
+
+
+def ppo_rollout(seed, n):
+    from test_gpu_learner import synth_ppo_rollout
+    rng = np.random.default_rng(seed)
+    obs, lab = synth_ppo_rollout(rng, n, (42, 42, 4), 4)
+    perms = np.stack([rng.permutation(n) for _ in range(2)]).astype(np.int32)
+    return obs, lab, perms
+
+
+def impala_case():
+    from xingtian_amd.model import netspec
+    spec = netspec.impala_cnn_opt((42, 42, 4), 6, 128.0, 128.0)
+    rng = np.random.default_rng(77)
+    tlen, ntraj = 10, 5          # 5 trajectories over 2 ranks: shards of 3 and 2
+    n = tlen * ntraj
+    data = dict(obs=rng.integers(0, 256, (n, 42, 42, 4)).astype(np.uint8),
+                bp=rng.standard_normal((n, 6)).astype(np.float32), act=rng.integers(0, 6, n).astype(np.int32),
+                done=(rng.random(n) < 0.1).astype(np.uint8), rew=rng.choice([-1.0, 0.0, 1.0], n).astype(np.float32))
+    return spec, data, tlen, ntraj
+
+
+def main():
+    outdir, mode = sys.argv[1], sys.argv[2]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from xingtian_amd import parallel
+    from xingtian_amd.model.hip_net import HipActorCritic
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    if mode in ("strict", "weak"):
+        spec, cfg, n = ppo_case()
+        net = HipActorCritic(spec, max_batch=cfg["BATCH_SIZE"], seed=5)
+        parallel.broadcast_weights_(net.params)
+        obs, lab, perms = ppo_rollout(100 if mode == "strict" else 200 + rank, n)
+        if mode == "weak":
+            _, _, perms = ppo_rollout(100, n)          # the SAME permutation of local row numbers on every rank
+        steps = parallel.dp_ppo_update(net, cfg, net.to_device_obs(obs), d(perms), d(lab[0]), d(lab[1].reshape(-1)),
+                                       d(lab[2].reshape(-1)), d(lab[3].reshape(-1)), d(lab[4].reshape(-1)), rank, world,
+                                       mode=mode)
+        assert steps == 6
+    elif mode == "impala":
+        spec, data, tlen, ntraj = impala_case()
+        net = HipActorCritic(spec, max_batch=tlen * ntraj, seed=5)
+        parallel.broadcast_weights_(net.params)
+        c = net.make_impala_cfg(1e-3, 40.0, tlen)
+        for _ in range(2):
+            parallel.dp_impala_step(net, c, 1e-3, 40.0, d(data["obs"]), d(data["bp"]), d(data["act"]), d(data["done"]),
+                                    d(data["rew"]), ntraj, tlen, rank, world)
+    else:
+        raise SystemExit("unknown mode " + mode)
+    torch.cuda.synchronize()
+    np.save(os.path.join(outdir, "params_{}_r{}.npy".format(mode, rank)), net.params.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

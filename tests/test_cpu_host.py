@@ -27,20 +27,111 @@ def test_cabi_library_loads_and_exports_every_header_symbol():
     for name in sorted(declared):
         assert hasattr(handle, name), "missing C-ABI symbol " + name
         assert name in lib.SIGNATURES, "no ctypes prototype for " + name
-    assert handle.xt_abi_version() == 5
+    assert handle.xt_abi_version() == lib.ABI_VERSION == 6
     assert handle.xt_build_arch() == b"gfx950"
 
 
 def test_product_path_fails_loudly_without_gpu():
+    """The LEARNER (model_info type 'learner', xt/framework/learner.py:544) has no CPU fallback; a model built in an
+    explorer / evaluator process (no GPU visible, no 'type') is the inference-only numpy replica: it predicts and
+    takes weights by name but refuses to train."""
     from xingtian_amd import lib
     if torch.cuda.is_available():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError, match="no HIP device"):
         lib.require_gpu()
     from xingtian_amd.model import model_builder
+    info = {"model_name": "PpoMlp", "state_dim": [4], "action_dim": 2, "model_config": {"action_type": "Categorical"}}
     with pytest.raises(RuntimeError, match="no HIP device"):
-        model_builder({"model_name": "PpoMlp", "state_dim": [4], "action_dim": 2,
-                       "model_config": {"action_type": "Categorical"}})
+        model_builder(dict(info, type="learner"))
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        model_builder(dict(info, model_config={"action_type": "Categorical", "DEVICE": "gpu"}))
+    from xingtian_amd.algorithm import alg_builder
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        alg_builder("PPO", {"actor": dict(info, type="learner")}, {"instance_num": 1, "agent_num": 1})
+    actor = model_builder(info)
+    assert actor.net.inference_only
+    state = np.zeros((3, 4), np.float32)
+    action, logp, value = actor.predict(state)
+    assert action.shape == (3,) and action.dtype == np.int32 and logp.shape == (3, 1) and value.shape == (3, 1)
+    with pytest.raises(RuntimeError, match="inference-only"):
+        actor.train([state], [action, logp, value, value, value])
+
+
+@pytest.mark.parametrize("which", ["ppo_cnn84", "ppo_cnn42_unshared", "ppo_mlp", "impala84", "impala42", "pendulum"])
+def test_cpu_replica_forward_matches_the_oracle_and_keeps_the_weight_contract(which):
+    """the numpy replica explorers run (xingtian_amd/model/cpu_net.py -- product code, no oracle
+    import) against the float64 oracle forward: NHWC im2col, VALID and TensorFlow's asymmetric SAME padding, Flatten
+    in (H, W, C) order, the 11x11 conv as a dense layer, zero-padded odd feature counts; weights go in and out by TF
+    variable name with TFVariables' error behaviour."""
+    from xingtian_amd.model import netspec
+    from xingtian_amd.model.cpu_net import CpuActorCritic
+    rng = np.random.default_rng(5)
+    if which == "ppo_cnn84":
+        spec, ospec = netspec.ppo_cnn((84, 84, 4), 4, (256,), "relu", True), nets.ppo_cnn_spec((84, 84, 4), 4, (256,), "relu", True)
+        obs = rng.integers(0, 256, (5, 84, 84, 4)).astype(np.uint8)
+    elif which == "ppo_cnn42_unshared":
+        spec, ospec = netspec.ppo_cnn((42, 42, 4), 6, (64,), "tanh", False), nets.ppo_cnn_spec((42, 42, 4), 6, (64,), "tanh", False)
+        obs = rng.integers(0, 256, (4, 42, 42, 4)).astype(np.uint8)
+    elif which == "ppo_mlp":
+        spec, ospec = netspec.ppo_mlp((4,), 2, (64, 64), "tanh", False), nets.ppo_mlp_spec((4,), 2, (64, 64), "tanh", False)
+        obs = rng.standard_normal((7, 4)).astype(np.float32)
+    elif which == "pendulum":
+        spec = netspec.ppo_mlp((3,), 1, (64, 64), "tanh", False, action_type="DiagGaussian")
+        ospec = nets.ppo_mlp_spec((3,), 1, (64, 64), "tanh", False, action_type="DiagGaussian")
+        obs = rng.standard_normal((6, 3)).astype(np.float32)
+    else:
+        dim, a, mean, std = (84, 4, 0.0, 255.0) if which == "impala84" else (42, 6, 128.0, 128.0)
+        spec, ospec = netspec.impala_cnn_opt((dim, dim, 4), a, mean, std), nets.impala_cnn_opt_spec((dim, dim, 4), a, mean, std)
+        obs = rng.integers(0, 256, (3, dim, dim, 4)).astype(np.uint8)
+    net = CpuActorCritic(spec, seed=0)
+    params = nets.init_params(ospec, seed=3, bias_scale=0.05)
+    net.set_weights({k: v.reshape(spec.names[k][1]) for k, v in params.items()})
+    logits, value = net.forward(obs)
+    ol, ov = nets.ActorCritic(ospec, params, np.float64).forward(obs)
+    rel = lambda a, b: np.linalg.norm(np.asarray(a, np.float64) - b) / (np.linalg.norm(b) + 1e-30)
+    assert logits.dtype == np.float32 and logits.shape == ol.shape and value.shape == (len(obs),)
+    assert rel(logits, ol) < 1e-5 and rel(value, ov[:, 0]) < 1e-5, (rel(logits, ol), rel(value, ov[:, 0]))
+    got = net.get_weights()
+    assert list(got) == list(spec.names) and all(np.array_equal(got[k].reshape(-1), params[k].reshape(-1).astype(np.float32))
+                                                  for k in params)
+    with pytest.raises(KeyError):
+        net.set_weights({"no_such_variable": np.zeros(3)})
+    net.set_weights({"no_such_variable": np.zeros(3), spec.pi_name + "/bias": np.ones(spec.action_dim, np.float32)})
+    assert np.array_equal(net.get_weights()[spec.pi_name + "/bias"], np.ones(spec.action_dim, np.float32))
+
+
+def test_explorer_side_models_predict_on_cpu_with_learner_weights(tmp_path):
+    """Every registered model class builds as the CPU replica in a GPU-less process (explorer.py:60), accepts a
+    weights dict / .npz published by a learner of the same configuration and returns ``predict`` in the reference's
+    shapes (ppo.py:104-109, impala_cnn_opt.py:267-277, impala_cnn.py predict)."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: explorer processes run with CUDA_VISIBLE_DEVICES=-1")
+    from xingtian_amd.model import model_builder
+    m = model_builder({"model_name": "PpoCnn", "state_dim": [84, 84, 4], "action_dim": 4, "input_dtype": "uint8",
+                       "model_config": {"VF_SHARE_LAYERS": True, "hidden_sizes": [256], "activation": "relu", "SEED": 1}})
+    a, lp, v = m.predict(np.zeros((2, 84, 84, 4), np.uint8))
+    assert a.shape == (2,) and lp.shape == (2, 1) and v.shape == (2, 1) and lp.dtype == v.dtype == np.float32
+    w = m.get_weights()
+    w["pi_latent/bias"] = np.array([50.0, 0.0, 0.0, 0.0], np.float32)
+    m.set_weights(w)
+    a, lp, _ = m.predict(np.zeros((64, 84, 84, 4), np.uint8))
+    assert (a == 0).all() and np.allclose(lp, 0.0, atol=1e-6)
+    path = m.save_model(os.path.join(str(tmp_path), "actor_00001"))
+    m2 = model_builder({"model_name": "PpoCnn", "state_dim": [84, 84, 4], "action_dim": 4, "input_dtype": "uint8",
+                        "model_config": {"VF_SHARE_LAYERS": True, "hidden_sizes": [256], "activation": "relu", "SEED": 2}})
+    m2.load_model(path)
+    assert all(np.array_equal(m2.get_weights()[k], w[k]) for k in w)
+    imp = model_builder({"model_name": "ImpalaCnnOpt", "state_dim": [42, 42, 4], "action_dim": 6, "input_dtype": "uint8",
+                         "state_mean": 128.0, "state_std": 128.0, "model_config": {"sample_batch_step": 50, "SEED": 1}})
+    logits, baseline, action = imp.predict(np.zeros((5, 42, 42, 4), np.uint8))
+    assert logits.shape == (5, 6) and baseline.shape == (5,) and action.shape == (5,) and action.dtype == np.int32
+    with pytest.raises(RuntimeError, match="inference-only"):
+        imp.train(np.zeros((50, 42, 42, 4), np.uint8), [np.zeros((50, 6), np.float32), np.zeros(50, np.int32),
+                                                        np.zeros(50, bool), np.zeros(50, np.float32)])
+    ker = model_builder({"model_name": "ImpalaMlp", "state_dim": [6], "action_dim": 3, "model_config": {"SEED": 3}})
+    p, val = ker.predict([np.zeros((4, 6), np.float32), np.zeros((4, 1), np.float32)])
+    assert p.shape == (4, 3) and val.shape == (4, 1) and np.allclose(p.sum(-1), 1.0, atol=1e-6)
 
 
 def test_product_never_imports_oracle():

@@ -1,0 +1,114 @@
+"""Multi-RANK data-parallel tests of the product path: two processes, one replica each, on
+the one GPU of the test box; gradients are exchanged through a real 2-rank ``torch.distributed`` group (gloo, because
+RCCL refuses two ranks on one device).  The result is compared with the single-process update on the same data:
+strict sharding reproduces the single-GPU update up to fp32 summation order, the replicas stay bit-identical."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_two_ranks(tmp_path, mode):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path), mode]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+    assert proc.returncode == 0, proc.stdout.decode()[-3000:]
+    p0 = np.load(os.path.join(str(tmp_path), "params_{}_r0.npy".format(mode)))
+    p1 = np.load(os.path.join(str(tmp_path), "params_{}_r1.npy".format(mode)))
+    assert np.array_equal(p0, p1), "replicas diverged"
+    return p0
+
+
+def _delta_err(got, ref, start):
+    return np.linalg.norm((got - start) - (ref - start)) / (np.linalg.norm(ref - start) + 1e-30)
+
+
+def test_strict_sharding_two_ranks_equals_the_single_gpu_update(tmp_path):
+    """Global minibatch of 32 rows -> 16 rows per rank (8 in the short last minibatch), shared permutations, loss
+    means over the global minibatch: 6 SGD steps must reproduce ``xt_net_ppo_train`` of one process."""
+    import dp_worker
+    from xingtian_amd.model.hip_net import HipActorCritic
+    got = _run_two_ranks(tmp_path, "strict")
+    spec, cfg, n = dp_worker.ppo_case()
+    obs, lab, perms = dp_worker.ppo_rollout(100, n)
+    net = HipActorCritic(spec, max_batch=cfg["BATCH_SIZE"], seed=5)
+    start = net.params.cpu().numpy().copy()
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    net.ppo_train(net.make_ppo_cfg(cfg), net.to_device_obs(obs), d(perms), d(lab[0]), d(lab[1].reshape(-1)),
+                  d(lab[2].reshape(-1)), d(lab[3].reshape(-1)), d(lab[4].reshape(-1)), use_graph=False)
+    torch.cuda.synchronize()
+    ref = net.params.cpu().numpy()
+    assert not np.array_equal(ref, start)
+    # same arithmetic up to the fp32 summation order of the two shard gradients; Adam's sign-like first steps
+    # amplify ~eps gradients (cf. test_ppo_train_matches_oracle_and_graph_replay_is_bitwise: 5e-3 over 6 steps)
+    assert _delta_err(got, ref, start) < 5e-3, _delta_err(got, ref, start)
+    assert np.abs(got - ref).max() <= 2 * 6 * cfg["LR"]
+
+
+def test_weak_scaling_two_ranks_equals_one_process_on_the_union_minibatch(tmp_path):
+    """Weak mode: rank r owns its own 80-row rollout and full 32-row local minibatches, grad_scale 1/2 -> the update
+    of ONE process whose minibatch is the union (64 rows: the means of two equal halves average to the mean of the
+    union)."""
+    import dp_worker
+    from xingtian_amd.model.hip_net import HipActorCritic
+    got = _run_two_ranks(tmp_path, "weak")
+    spec, cfg, n = dp_worker.ppo_case()
+    rolls = [dp_worker.ppo_rollout(200 + r, n) for r in range(2)]
+    _, _, perms = dp_worker.ppo_rollout(100, n)
+    obs = np.concatenate([r[0] for r in rolls])
+    lab = [np.concatenate([r[1][i] for r in rolls]) for i in range(5)]
+    # minibatch k of the union = rank 0's rows of its minibatch k followed by rank 1's
+    b = cfg["BATCH_SIZE"]
+    uperm = []
+    for ep in range(2):
+        row = []
+        for s in range(0, n, b):
+            row += list(perms[ep, s:s + b]) + list(n + perms[ep, s:s + b])
+        uperm.append(row)
+    uperm = np.asarray(uperm, np.int32)
+    cfg2 = dict(cfg, BATCH_SIZE=2 * b)
+    net = HipActorCritic(spec, max_batch=2 * b, seed=5)
+    start = net.params.cpu().numpy().copy()
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    net.ppo_train(net.make_ppo_cfg(cfg2), net.to_device_obs(obs), d(uperm), d(lab[0]), d(lab[1].reshape(-1)),
+                  d(lab[2].reshape(-1)), d(lab[3].reshape(-1)), d(lab[4].reshape(-1)), use_graph=False)
+    torch.cuda.synchronize()
+    ref = net.params.cpu().numpy()
+    assert _delta_err(got, ref, start) < 5e-3, _delta_err(got, ref, start)
+
+
+def test_impala_sum_loss_two_ranks_whole_trajectory_shards(tmp_path):
+    """IMPALA's loss is a SUM over (T-1) x B (impala_cnn_opt.py:299-318,351): 5 trajectories as shards of 3 + 2,
+    gradients summed without scaling, two updates == the single-process updates on all 5 trajectories."""
+    import dp_worker
+    from xingtian_amd.model.hip_net import HipActorCritic
+    got = _run_two_ranks(tmp_path, "impala")
+    spec, data, tlen, ntraj = dp_worker.impala_case()
+    net = HipActorCritic(spec, max_batch=tlen * ntraj, seed=5)
+    start = net.params.cpu().numpy().copy()
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    c = net.make_impala_cfg(1e-3, 40.0, tlen)
+    for _ in range(2):
+        net.impala_step(c, d(data["obs"]), d(data["bp"]), d(data["act"]), d(data["done"]), d(data["rew"]), apply=True)
+    torch.cuda.synchronize()
+    ref = net.params.cpu().numpy()
+    assert _delta_err(got, ref, start) < 5e-3, _delta_err(got, ref, start)

@@ -180,7 +180,8 @@ def test_ppo_train_matches_oracle_and_graph_replay_is_bitwise():
     (84, 4, 16, 3, 0.0, 255.0), (42, 6, 50, 4, 128.0, 128.0),
     (84, 4, 128, 1, 0.0, 255.0),      # BASELINE configs[2] breakout_impala.yaml: one 128-step trajectory per SGD step
     (84, 4, 128, 4, 0.0, 255.0),      # ... and BATCH_SIZE 512 = four trajectories in one step
-    (42, 6, 50, 20, 128.0, 128.0)])   # BASELINE configs[4] pong_impala_speedup.yaml: 1000 rows = 20 trajectories of 50
+    (42, 6, 50, 20, 128.0, 128.0),    # BASELINE configs[4] pong_impala_speedup.yaml: 1000 rows = 20 trajectories of 50
+    (42, 18, 8, 3, 128.0, 128.0)])    # A = 18 (full Atari action set): outside the fused head kernels -> unfused launches
 def test_impala_step_vs_oracle(dim, a_dim, tlen, ntraj, mean, std):
     from xingtian_amd.model import netspec
     from xingtian_amd.model.hip_net import HipActorCritic
@@ -553,130 +554,6 @@ def test_gauss_ppo_mlp_update_vs_oracle(sd, ad, hidden, share):
     assert abs(float(logp[0, 0]) + (0.5 * np.log(2 * np.pi) * ad + 0.5 * (z ** 2).sum() + ls.sum())) < 1e-4
 
 
-def test_fused_trunk_forward_matches_per_layer_path(monkeypatch):
-    """xt_trunk.hip (opt-in, XT_TRUNK=1): conv1 -> conv2 -> conv3 of one frame stack per workgroup with the
-    intermediate activations in LDS.  Same arithmetic as the per-layer kernels up to the summation order: logits,
-    value and one SGD step's gradients against the default path and against the float64 oracle."""
-    net, ospec, sd, u8 = _mk("cnn84", 96)
-    params = oracle_params_for(net, ospec, 21)
-    rng = np.random.default_rng(22)
-    obs, lab = synth_ppo_rollout(rng, 96, sd, 4)
-    monkeypatch.delenv("XT_TRUNK", raising=False)
-    l0, v0 = [t.cpu().numpy() for t in net.forward(obs)]
-    monkeypatch.setenv("XT_TRUNK", "1")
-    l1, v1 = [t.cpu().numpy() for t in net.forward(obs)]
-    assert not np.array_equal(l0, l1)                      # a different kernel really ran
-    assert rel_err(l1, l0) < 2e-6 and rel_err(v1, v0) < 2e-6
-    oc = nets.ActorCritic(ospec, params, np.float64)
-    ol, ov = oc.forward(obs)
-    assert rel_err(l1, ol) < 1e-5 and rel_err(v1, ov[:, 0]) < 1e-5
-    c = net.make_ppo_cfg(dict(PPO_CFG, BATCH_SIZE=96))
-    d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).cuda()
-    args = (net.to_device_obs(obs), d(np.arange(96), np.int32), d(lab[0], np.int32), d(lab[1].reshape(-1), np.float32),
-            d(lab[2].reshape(-1), np.float64), d(lab[3].reshape(-1), np.float32), d(lab[4].reshape(-1), np.float64))
-    net.ppo_step(c, *args, apply=False)
-    g1 = net.grads_dict()
-    monkeypatch.delenv("XT_TRUNK")
-    net.ppo_step(c, *args, apply=False)
-    g0 = net.grads_dict()
-    for k in g0:
-        assert rel_err(g1[k], g0[k]) < 1e-5, (k, rel_err(g1[k], g0[k]))
-
-
-@pytest.mark.parametrize("which", ["cnn84", "mlp"])
-def test_dp_step_halves_equal_one_shot_step_and_overlapped_allreduce(which):
-    """xt_net_ppo_step_begin/_end (the data-parallel step split so that the all-reduce of the
-    gradient tail overlaps the rest of the backward) produce bit-identical gradients and loss to the one-shot
-    step; the tail starts at the Dense layer feeding the heads (shared trunk) or at 0 (two trunks: nothing to
-    overlap).  With a 1-rank RCCL group the overlapped dp_ppo_step (two async all-reduces on RCCL's stream)
-    equals the single-all-reduce form bit for bit."""
-    import torch.distributed as dist
-    from xingtian_amd import parallel
-    b = 64
-    net, ospec, sd, u8 = _mk(which, b)
-    oracle_params_for(net, ospec, 31)
-    rng = np.random.default_rng(32)
-    a_dim = net.spec.action_dim
-    obs, lab = synth_ppo_rollout(rng, 200, sd, a_dim, u8=u8)
-    c = net.make_ppo_cfg(dict(PPO_CFG, BATCH_SIZE=b))
-    d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).cuda()
-    args = (net.to_device_obs(obs), d(rng.permutation(200)[:b], np.int32), d(lab[0], np.int32),
-            d(lab[1].reshape(-1), np.float32), d(lab[2].reshape(-1), np.float64), d(lab[3].reshape(-1), np.float32),
-            d(lab[4].reshape(-1), np.float64))
-    loss0 = net.ppo_step(c, *args, apply=False).cpu().numpy().copy()
-    g0 = net.grads.cpu().numpy().copy()
-    net.grads.zero_()
-    tail = net.ppo_step_begin(c, *args)
-    torch.cuda.synchronize()
-    g_half = net.grads.cpu().numpy().copy()
-    if which == "cnn84":
-        assert tail == net.spec.layers[3].param_off and tail > 0
-        assert np.array_equal(g_half[tail:], g0[tail:]) and not g_half[:tail].any()
-    else:
-        assert tail == 0 and np.array_equal(g_half, g0)
-    loss1 = net.ppo_step_end(c, args[0], args[1]).cpu().numpy().copy()
-    assert np.array_equal(net.grads.cpu().numpy(), g0) and np.array_equal(loss0[:4], loss1[:4])
-    # overlapped vs plain data-parallel step on a 1-rank RCCL group
-    created = False
-    if not dist.is_initialized():
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1,
-                                device_id=torch.device("cuda", 0))
-        created = True
-    try:
-        w0 = net.params.clone()
-        m0, v0, s0 = net.adam_m.clone(), net.adam_v.clone(), net.adam_state.clone()
-        parallel.dp_ppo_step(net, c, PPO_CFG["LR"], PPO_CFG["MAX_GRAD_NORM"], *args, world=1, overlap=False)
-        w_plain = net.params.clone()
-        net.params.copy_(w0); net.adam_m.copy_(m0); net.adam_v.copy_(v0); net.adam_state.copy_(s0)
-        parallel.dp_ppo_step(net, c, PPO_CFG["LR"], PPO_CFG["MAX_GRAD_NORM"], *args, world=1, overlap=True)
-        assert torch.equal(net.params, w_plain) and not torch.equal(w_plain, w0)
-    finally:
-        if created:
-            dist.destroy_process_group()
-
-
-def test_dp_graph_stepper_is_bitwise_the_eager_data_parallel_step():
-    """parallel.DpGraphStepper (hipGraph-replayed compute segments + c10d all-reduces, two-bucket overlap) against the
-    eager dp_ppo_step on a 1-rank RCCL group: same parameters bit for bit after several steps with two minibatch
-    sizes (each size has its own captured graphs; the minibatch indices go through a fixed staging buffer)."""
-    import torch.distributed as dist
-    from xingtian_amd import parallel
-    b = 64
-    net, ospec, sd, u8 = _mk("cnn84", b)
-    oracle_params_for(net, ospec, 41)
-    rng = np.random.default_rng(42)
-    obs, lab = synth_ppo_rollout(rng, 300, sd, net.spec.action_dim, u8=u8)
-    c = net.make_ppo_cfg(dict(PPO_CFG, BATCH_SIZE=b))
-    d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).cuda()
-    data = (net.to_device_obs(obs), d(lab[0], np.int32), d(lab[1].reshape(-1), np.float32),
-            d(lab[2].reshape(-1), np.float64), d(lab[3].reshape(-1), np.float32), d(lab[4].reshape(-1), np.float64))
-    perm = d(rng.permutation(300), np.int32)
-    batches = [perm[0:64], perm[64:128], perm[128:168], perm[168:232], perm[232:272]]      # sizes 64, 64, 40, 64, 40
-    created = False
-    if not dist.is_initialized():
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29578", rank=0, world_size=1,
-                                device_id=torch.device("cuda", 0))
-        created = True
-    try:
-        w0 = net.params.clone()
-        m0, v0, s0 = net.adam_m.clone(), net.adam_v.clone(), net.adam_state.clone()
-        for idx in batches:
-            parallel.dp_ppo_step(net, c, PPO_CFG["LR"], PPO_CFG["MAX_GRAD_NORM"], data[0], idx, *data[1:], world=1)
-        w_eager = net.params.clone()
-        for overlap in (True, False):
-            net.params.copy_(w0); net.adam_m.copy_(m0); net.adam_v.copy_(v0); net.adam_state.copy_(s0)
-            st = parallel.DpGraphStepper(net, c, PPO_CFG["LR"], PPO_CFG["MAX_GRAD_NORM"], *data, world=1,
-                                         overlap=overlap, warm_steps=0)
-            for idx in batches:
-                st.step(idx)
-            torch.cuda.synchronize()
-            assert not st.failed and sorted(st.graphs) == [40, 64]
-            assert torch.equal(net.params, w_eager) and not torch.equal(w_eager, w0)
-    finally:
-        if created:
-            dist.destroy_process_group()
-
-
 def test_gradient_exchange_hook_in_the_update_graph_matches_the_stepwise_data_parallel_path():
     """C ABI >= 4: xt_net_set_grad_exchange + a raw 1-rank RCCL communicator (parallel.RcclComm).  The whole-update
     entry point then runs gradient-only step -> ncclAllReduce on the learner's stream -> norm/clip/Adam, captured
@@ -952,3 +829,94 @@ def test_full_size_minibatch_gradient_is_the_mean_of_its_shards(which):
         assert max(errs.values()) < tol, (world, errs)
         if which == "cnn84":     # everything above the lowest flipped mask is still at rounding level
             assert sum(e > 1e-5 for e in errs.values()) <= 4, (world, errs)
+
+
+def test_impala_train_entry_chunks_graph_replay_bitwise_and_device_step_sizes():
+    """xt_net_impala_train: IMPALAOpt.train's sequential BATCH_SIZE chunks (impala_opt.py:90-99) in one call incl. a
+    shorter last chunk, per-chunk step sizes read from device memory (lr_schedule), hipGraph replay bit-identical to
+    the eager enqueue, everything against the float64 oracle stepped chunk by chunk."""
+    from xingtian_amd.model import netspec
+    from xingtian_amd.model.hip_net import HipActorCritic
+    tlen, ntraj, a_dim, bs = 10, 5, 6, 20
+    n = tlen * ntraj
+    spec = netspec.impala_cnn_opt((42, 42, 4), a_dim, 128.0, 128.0)
+    ospec = nets.impala_cnn_opt_spec((42, 42, 4), a_dim, 128.0, 128.0)
+    rng = np.random.default_rng(21)
+    obs = rng.integers(0, 256, (n, 42, 42, 4)).astype(np.uint8)
+    bp = rng.standard_normal((n, a_dim)).astype(np.float32)
+    act = rng.integers(0, a_dim, n).astype(np.int32)
+    done = rng.random(n) < 0.1
+    rew = rng.choice([-2.0, 0.0, 1.0], n).astype(np.float32)
+    lrs = np.array([1e-3, 5e-4, 2e-4], np.float32)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    bufs = [d(obs), d(bp), d(act), d(done.astype(np.uint8)), d(rew)]
+    d_lr = d(lrs)
+    results = []
+    params = None
+    for use_graph, fresh in ((False, True), (True, True), (True, False)):
+        if fresh:
+            net = HipActorCritic(spec, max_batch=bs, seed=0)
+        params = oracle_params_for(net, ospec, seed=9)
+        net.reset_optimizer()
+        c = net.make_impala_cfg(7e-4, 40.0, tlen)
+        acc = net.impala_train(c, bufs[0], bs, *bufs[1:], lr_steps=d_lr, use_graph=use_graph)
+        torch.cuda.synchronize()
+        a = acc.cpu().numpy()
+        assert a[1] == 3.0
+        results.append((a[0] / a[1], net.params.cpu().numpy().copy(), net.adam_state.cpu().numpy().copy()))
+    assert np.array_equal(results[0][1], results[1][1]) and np.array_equal(results[1][1], results[2][1])
+    assert results[0][0] == results[1][0] == results[2][0]
+    orc = nets.ImpalaLearnerOracle(ospec, params, dict(LR=7e-4, grad_norm_clip=40.0, sample_batch_step=tlen,
+                                                       BATCH_SIZE=bs), np.float64)
+    losses = []
+    for i, lo in enumerate(range(0, n, bs)):
+        orc.opt.lr = float(lrs[i])
+        sl = slice(lo, lo + bs)
+        losses.append(orc.step(obs[sl], bp[sl], act[sl], done[sl], rew[sl])["loss"])
+    ref = np.mean(losses)
+    assert abs(results[0][0] - ref) < 1e-4 * max(1.0, abs(ref)), (results[0][0], ref)
+    alpha3 = lrs[2] * np.sqrt(1.0 - 0.999 ** 3) / (1.0 - 0.9 ** 3)
+    assert abs(results[0][2][3] - alpha3) < 3e-5 * alpha3 and int(round(results[0][2][5])) == 3
+    got = net.get_weights()
+    for k, r in orc.net.params.items():
+        assert rel_err(got[k].reshape(r.shape) - params[k], r - params[k]) < 5e-3, k
+    # no step sizes -> cfg.lr; a chunk size that is not a whole number of trajectories is refused
+    net.impala_train(c, bufs[0], bs, *bufs[1:], lr_steps=None, use_graph=False)
+    with pytest.raises(RuntimeError):
+        net.impala_train(c, bufs[0], 15, *bufs[1:], use_graph=False)
+
+
+def test_impala_opt_streaming_ingest_is_bitwise_the_upload_path():
+    """IMPALAOpt.prepare_data streams every message into HBM as it arrives (pinned staging + async H2D, two
+    alternating buffer sets, hipGraph cached per set); the update must equal the concat + chunk-by-chunk upload path
+    bit for bit over several trains."""
+    from xingtian_amd.algorithm import alg_builder
+    algs = []
+    for stream in (True, False):
+        model_info = {"actor": {"model_name": "ImpalaCnnOpt", "state_dim": [42, 42, 4], "input_dtype": "uint8",
+                                "state_mean": 128.0, "state_std": 128.0, "action_dim": 6,
+                                "model_config": {"LR": 0.001, "sample_batch_step": 10, "grad_norm_clip": 40.0, "SEED": 3,
+                                                 "STREAM_INGEST": stream,
+                                                 "lr_schedule": [[0, 0.001], [20000, 0.000001]]}}}
+        algs.append(alg_builder("IMPALAOpt", model_info, {"instance_num": 3, "agent_num": 1,
+                                                         "prepare_times_per_train": 3, "BATCH_SIZE": 40}))
+    assert algs[0].actor.stream_ingest and not algs[1].actor.stream_ingest
+    rng = np.random.default_rng(8)
+    for it in range(4):
+        msgs = []
+        for _ in range(3):
+            n = 20
+            msgs.append({"cur_state": rng.integers(0, 256, (n, 42, 42, 4)).astype(np.uint8),
+                         "logit": rng.standard_normal((n, 6)).astype(np.float32),
+                         "action": rng.integers(0, 6, n).astype(np.int32), "done": list(rng.random(n) < 0.1),
+                         "reward": list(rng.choice([-1.0, 0.0, 1.0], n))})
+        losses = []
+        for alg in algs:
+            for m in msgs:
+                alg.prepare_data(m)
+            losses.append(alg.train(episode_num=it))
+        assert losses[0] == losses[1], (it, losses)
+        w0, w1 = algs[0].get_weights(), algs[1].get_weights()
+        for k in w0:
+            assert np.array_equal(w0[k], w1[k]), (it, k)
+    assert algs[0].actor._global_step == algs[1].actor._global_step == 8      # 60 frames = chunks of 40 + 20, 4 trains

@@ -28,7 +28,6 @@ PHASES = {
     50: ("conv1 wgrad", ["loads issued+LDS", "barrier", "mfma loop", "combine+store issue", "store drain"]),
     70: ("direct fwd", ["decode+2 stages issued", "", "reduction loop", "combine+store issue", "store drain"]),
     80: ("direct dgrad", ["decode+x+2 stages issued", "", "reduction loop", "combine+store issue", "store drain"]),
-    90: ("trunk fwd", ["frame stack staged", "conv1 (bf16x3) -> act1 in LDS", "conv2 (+act1 copy-out)", "conv3", "store drain"]),
     60: ("grads_finish", ["slab loads+sum", "block reduce", "ticket", "finalize (last block)", ""]),
 }
 
@@ -100,7 +99,7 @@ def main():
     net.forward(obs[:B])
     cap = 8192
     buf = torch.zeros((cap, 8), dtype=torch.int64, device="cuda")
-    setters = [getattr(lib, "xt_tl_set_" + n) for n in ("igemm", "conv1", "optim", "direct", "trunk")]
+    setters = [getattr(lib, "xt_tl_set_" + n) for n in ("igemm", "conv1", "optim", "direct")]
     for s in setters:
         s.restype = ctypes.c_int
         s.argtypes = [ctypes.c_void_p]
@@ -149,9 +148,8 @@ def main():
             clock_mhz("(after 10 ppo_train, rep %d)" % rep)
 
     out = {}
-    only_trunk = bool(os.environ.get("XT_TL_ONLY_TRUNK"))
-    jobs = [] if only_trunk else [("L0_fwd", 0, 0), ("L0_wgrad", 0, 1)]
-    for li in range(1, 0 if only_trunk else len(spec.layers)):
+    jobs = [("L0_fwd", 0, 0), ("L0_wgrad", 0, 1)]
+    for li in range(1, len(spec.layers)):
         jobs += [("L%d_fwd" % li, li, 0), ("L%d_bwd" % li, li, 3), ("L%d_dgrad" % li, li, 2)]
     for name, li, which in jobs:
         arm(False)
@@ -162,23 +160,6 @@ def main():
         arm(False)
         out[name] = buf.cpu().numpy().copy()
         out[name + "_ms"] = np.float64(ms)
-    # fused trunk forward (xt_trunk.hip)
-    arm(False)
-    ms = net.time_layer(0, 4, obs, idx, B, reps=50)
-    buf.zero_()
-    arm(True)
-    net.time_layer(0, 4, obs, idx, B, reps=1)
-    arm(False)
-    raw = buf.cpu().numpy().copy()
-    raw[raw[:, 6] != 90] = 0
-    out["trunk_fwd"] = raw
-    out["trunk_fwd_ms"] = np.float64(ms)
-    if os.environ.get("XT_TL_CLK"):
-        u = raw[raw[:, 6] == 90].astype(np.float64)
-        us = (u[:, 4] - u[:, 2]) / 100.0
-        mhz = (u[:, 5] - u[:, 3]) / us
-        print("conv2 phase of wave 0: %.2f us median, %.0f cycles median -> shader clock %.0f MHz (min %.0f max %.0f)"
-              % (np.median(us), np.median(u[:, 5] - u[:, 3]), np.median(mhz), mhz.min(), mhz.max()))
     # one whole SGD step: later kernels overwrite earlier ones' rows; the grads_finish rows (role 60) survive
     act = torch.from_numpy(rng.integers(0, 4, N).astype(np.int32)).cuda()
     f = lambda: torch.from_numpy(rng.standard_normal(N).astype(np.float32)).cuda()

@@ -22,6 +22,7 @@ class IMPALAOpt(Algorithm):
         super().__init__(alg_name="impala", model_info=actor_info, alg_config=alg_config)
         self.async_flag = False
         self._rollout = RolloutFields(*self.FIELDS)
+        self._streamed = 0
         # asynchronous actors: new weights go back to whoever delivered the data of this update
         self.dist_model_policy = FIFODistPolicy(alg_config["instance_num"], prepare_times=self._prepare_times_per_train)
 
@@ -39,16 +40,28 @@ class IMPALAOpt(Algorithm):
                 np.asarray(episode_data["done"], dtype=bool), np.asarray(episode_data["reward"]))
 
     def prepare_data(self, train_data, **kwargs):
-        self._rollout.add(**dict(zip(self.FIELDS, self._data_proc(train_data))))
+        fields = self._data_proc(train_data)
+        if getattr(self.actor, "stream_ingest", False) and hasattr(self.actor, "ingest_message"):
+            self.actor.ingest_message(*fields)            # pinned staging + async H2D start now
+            self._streamed += 1
+        self._rollout.add(**dict(zip(self.FIELDS, fields)))
 
     def train(self, **kwargs):
-        states, *labels = self._rollout.stacked()
-        losses = []
-        for lo in range(0, len(states), BATCH_SIZE):
-            hi = lo + BATCH_SIZE
-            losses.append(self.actor.train(states[lo:hi], [x[lo:hi] for x in labels]))
+        if self._streamed > 0 and self._streamed == len(self._rollout):
+            # the whole rollout already sits in HBM: every BATCH_SIZE chunk in one C call, no concat, no upload
+            loss = self.actor.train_ingested(BATCH_SIZE)
+        else:
+            if self._streamed:
+                self.actor._ingest.reset()
+            states, *labels = self._rollout.stacked()
+            losses = []
+            for lo in range(0, len(states), BATCH_SIZE):
+                hi = lo + BATCH_SIZE
+                losses.append(self.actor.train(states[lo:hi], [x[lo:hi] for x in labels]))
+            loss = np.mean(losses)
         self._rollout.reset()
-        return np.mean(losses)
+        self._streamed = 0
+        return loss
 
     def predict(self, state):
         return self.actor.predict(state)

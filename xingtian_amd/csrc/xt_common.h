@@ -104,6 +104,10 @@ struct LossArgs {
   float ent_coef, critic_coef, inv_b;
   float* out;           // 4 floats (may be null)
   float* acc;           // running sum / count (may be null)
+  // IMPALA's sum-form loss (impala_cnn_opt.py:351): per-trajectory sums written by the v-trace kernel, added up
+  // in trajectory order; used when terms == nullptr and traj_loss != nullptr
+  const float* traj_loss;
+  int n_traj;
 };
 
 // One entry per parameter block: sum `nslab` partial slabs (fixed order) into dst and accumulate the
@@ -137,6 +141,29 @@ struct PpoHeadArgs {
   long long part_stride;
 };
 
+// IMPALA (ImpalaCnnOpt, one shared trunk): heads forward with the deferred split-K finish of the last trunk layer
+struct ImpalaHeadArgs {
+  const float *feat, *wpi, *bpi, *wv, *bv;
+  const float *part, *tbias;   // part != nullptr: feature = act(sum_z part[z] + tbias), written to feat_w
+  float* feat_w;
+  int ksplit, act_feat;
+  long long part_stride;
+  int B, F, A;
+  float *logits, *value;
+};
+// v-trace targets + sum-form loss + d(logits, baseline) + d(features) of one chunk, one workgroup per trajectory
+struct ImpalaLossArgs {
+  const float *logits, *baseline, *bp_logits;
+  const int32_t* action;
+  const uint8_t* done;
+  const float* reward;
+  int T, A, F, act_prev;
+  float gamma;
+  float *dlogits, *dbaseline, *traj_loss, *vs_out, *pg_out;
+  const float *feat, *wpi, *wv;
+  float* dfeat;
+};
+
 // norm finalisation executed by the last block of grads_finish_kernel (ticket counter)
 struct FinalizeArgs {
   int enable;
@@ -144,6 +171,7 @@ struct FinalizeArgs {
   float clip_norm, grad_scale, lr, beta1, beta2;
   float* state;
   LossArgs loss;
+  const float* lr_dev;       // != nullptr: the step size is read from device memory (lr_schedule inside a replayed hipGraph)
 };
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

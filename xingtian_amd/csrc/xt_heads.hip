@@ -581,6 +581,238 @@ int launch_heads_wgrad_partial(const float* f_pi, const float* f_v, int B, int F
   return 0;
 }
 
+// ---------------------------------------------------------------- fused IMPALA heads (ImpalaCnnOpt: one shared trunk)
+// K1: split-K finish of the 11x11 conv (a dense 3872->256) + 1x1-conv policy + dense baseline, one wave per frame --
+// the first half of ppo_heads_fused_kernel (same issue-everything-first structure, same arithmetic as
+// splitk_finish + heads_fwd_kernel).  impala_cnn_opt.py:131-152.
+template <int NQ, bool PART>
+__global__ __launch_bounds__(64) void impala_heads_fwd_kernel(const ImpalaHeadArgs p) {
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  const int F = p.F, A = p.A;
+  const size_t row = (size_t)b * F;
+  float praw[PART ? NQ : 1][kMaxHeadSplit];
+  float xin[NQ], tb[NQ], wvv[NQ], wp[NQ][kHeadMaxA];
+  int fcl[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int f = lane + 64 * q;
+    fcl[q] = f < F ? f : 0;
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    if (PART) {
+#pragma unroll
+      for (int z = 0; z < kMaxHeadSplit; ++z)
+        praw[q][z] = p.part[(size_t)(z < p.ksplit ? z : p.ksplit - 1) * p.part_stride + row + fcl[q]];
+      tb[q] = p.tbias[fcl[q]];
+    } else {
+      xin[q] = p.feat[row + fcl[q]];
+    }
+    wvv[q] = p.wv[fcl[q]];
+#pragma unroll
+    for (int a = 0; a < kHeadMaxA; ++a) wp[q][a] = p.wpi[(size_t)fcl[q] * A + (a < A ? a : 0)];
+  }
+  const float mybias = p.bpi[lane < A ? lane : 0];
+  const float bvv = p.bv[0];
+  float fx[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const bool ok = lane + 64 * q < F;
+    float x;
+    if (PART) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int z = 0; z < kMaxHeadSplit; z += 4)
+        sacc += ((z < p.ksplit ? praw[q][z] : 0.f) + (z + 1 < p.ksplit ? praw[q][z + 1] : 0.f)) +
+                ((z + 2 < p.ksplit ? praw[q][z + 2] : 0.f) + (z + 3 < p.ksplit ? praw[q][z + 3] : 0.f));
+      x = act_apply(sacc + tb[q], p.act_feat);
+    } else {
+      x = xin[q];
+    }
+    fx[q] = ok ? x : 0.f;
+  }
+  float acc[kHeadMaxA];
+#pragma unroll
+  for (int a = 0; a < kHeadMaxA; ++a) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) t = fmaf(fx[q], wp[q][a], t);
+    acc[a] = t;
+  }
+  float sv = 0.f;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) sv = fmaf(fx[q], wvv[q], sv);
+  float mylogit = 0.f;
+#pragma unroll
+  for (int a = 0; a < kHeadMaxA; ++a) {
+    const float t = wave_sum(acc[a]);
+    if (a < A && lane == a) mylogit = t + mybias;
+  }
+  const float v = wave_sum(sv) + bvv;
+  if (lane < A) p.logits[(size_t)b * A + lane] = mylogit;
+  if (lane == 0) p.value[b] = v;
+  if (PART) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int f = lane + 64 * q;
+      if (f < F) p.feat_w[row + f] = fx[q];
+    }
+  }
+}
+
+int launch_impala_heads_fwd(const ImpalaHeadArgs& a, hipStream_t st) {
+  if (a.A > kHeadMaxA || a.F > 512) return -1;
+  const bool part = a.part != nullptr;
+  if (part && a.ksplit > kMaxHeadSplit) return -1;
+  const int nq = (a.F + 63) / 64;
+  const dim3 grid(a.B), blk(64);
+#define XT_IH(NQV)                                                                                   \
+  do {                                                                                               \
+    if (part) hipLaunchKernelGGL((impala_heads_fwd_kernel<NQV, true>), grid, blk, 0, st, a);         \
+    else hipLaunchKernelGGL((impala_heads_fwd_kernel<NQV, false>), grid, blk, 0, st, a);             \
+  } while (0)
+  if (nq <= 1) XT_IH(1); else if (nq <= 2) XT_IH(2); else if (nq <= 4) XT_IH(4); else XT_IH(8);
+#undef XT_IH
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
+// K2: v-trace + loss + d(logits, baseline) (the arithmetic of impala_loss_kernel, statement for statement) followed
+// by the gradient w.r.t. the trunk features of the trajectory's rows (the arithmetic of heads_dfeat_kernel), one
+// 256-thread workgroup per trajectory.  The reverse scan stays SERIAL in time (tf.scan, vtrace.py:94-106) but runs
+// from registers: thread 0 pulls delta / discount*c / V in chunks of 16 from LDS, then a pure FMA chain.
+template <int AM>
+__global__ __launch_bounds__(256) void impala_vtrace_bwd_kernel(const ImpalaLossArgs p) {
+  constexpr int MAXT = 256;
+  __shared__ float s_delta[MAXT], s_dc[MAXT], s_val[MAXT + 1], s_vs[MAXT + 1], s_red[MAXT], s_dv[MAXT];
+  __shared__ float s_dl[MAXT * AM];
+  const int t = threadIdx.x;
+  const int traj = blockIdx.x;
+  const int T = p.T, A = p.A, F = p.F;
+  const int Tm = T - 1;
+  const size_t base = (size_t)traj * T;
+  float rho = 0.f, disc = 0.f, rew = 0.f, val = 0.f, ce = 0.f, ent = 0.f, logz = 0.f, mx = 0.f, z = 1.f;
+  int act = 0;
+  if (t < T) s_val[t] = p.baseline[base + t];
+  if (t < Tm) {
+    const float* lg = p.logits + (base + t) * A;
+    const float* bl = p.bp_logits + (base + t) * A;
+    act = p.action[base + t];
+    mx = lg[0];
+    float bmx = bl[0];
+    for (int a = 1; a < A; ++a) { mx = fmaxf(mx, lg[a]); bmx = fmaxf(bmx, bl[a]); }
+    z = 0.f;
+    float bz = 0.f;
+    for (int a = 0; a < A; ++a) { z += expf(lg[a] - mx); bz += expf(bl[a] - bmx); }
+    logz = logf(z);
+    const float tlp = (lg[act] - mx) - logz;
+    const float blp = (bl[act] - bmx) - logf(bz);
+    ce = -tlp;
+    rho = expf(tlp - blp);
+    disc = p.done[base + t] ? 0.f : p.gamma;
+    rew = fminf(fmaxf(p.reward[base + t], -1.f), 1.f);
+    val = p.baseline[base + t];
+    const float nval = p.baseline[base + t + 1];
+    const float crho = fminf(1.f, rho);
+    s_delta[t] = crho * (rew + disc * nval - val);
+    s_dc[t] = disc * fminf(1.f, rho);
+    for (int a = 0; a < A; ++a) {
+      const float rl = lg[a] - mx;
+      ent += (expf(rl) / z) * (logz - rl);
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    float acc = 0.f;
+    for (int q0 = Tm; q0 > 0; q0 -= 16) {         // rows q0-1 .. q0-16, newest first
+      float d[16], c[16], v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int q = q0 - 1 - u;
+        const int qc = q >= 0 ? q : 0;
+        d[u] = s_delta[qc]; c[u] = s_dc[qc]; v[u] = s_val[qc];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int q = q0 - 1 - u;
+        if (q >= 0) {
+          acc = d[u] + c[u] * acc;
+          s_vs[q] = acc + v[u];
+        }
+      }
+    }
+    s_vs[Tm] = s_val[Tm];
+  }
+  __syncthreads();
+  float lterm = 0.f;
+  if (t < Tm) {
+    const float vs = s_vs[t], vsn = s_vs[t + 1];
+    const float pg = fminf(1.f, rho) * (rew + disc * vsn - val);
+    const float* lg = p.logits + (base + t) * A;
+    for (int a = 0; a < A; ++a) {
+      const float rl = lg[a] - mx;
+      const float pa = expf(rl) / z;
+      const float lpa = rl - logz;
+      const float onehot = (a == act) ? 1.f : 0.f;
+      const float dl = pg * (pa - onehot) + 0.01f * (pa * (lpa + ent));
+      p.dlogits[(base + t) * A + a] = dl;
+      s_dl[t * AM + a] = dl;
+    }
+    const float dvl = 0.5f * (val - vs);
+    p.dbaseline[base + t] = dvl;
+    s_dv[t] = dvl;
+    const float dvv = vs - val;
+    lterm = ce * pg + 0.5f * (0.5f * dvv * dvv) + 0.01f * (-ent);
+    if (p.vs_out) p.vs_out[(size_t)traj * Tm + t] = vs;
+    if (p.pg_out) p.pg_out[(size_t)traj * Tm + t] = pg;
+  } else if (t == Tm) {
+    for (int a = 0; a < A; ++a) { p.dlogits[(base + t) * A + a] = 0.f; s_dl[t * AM + a] = 0.f; }
+    p.dbaseline[base + t] = 0.f;
+    s_dv[t] = 0.f;
+  }
+  if (t < MAXT) s_red[t] = lterm;
+  __syncthreads();
+  if (t == 64) {                                  // lane 0 of the second wave: the others go on with d(features)
+    float s = 0.f;
+    for (int q = 0; q < T; ++q) s += s_red[q];
+    p.traj_loss[traj] = s;
+  }
+  // d(features)[r, f] = (sum_a dlogits[r,a] Wpi[f,a] + dbaseline[r] Wv[f]) * act'(feature)   (heads_dfeat_kernel)
+  for (int f = t; f < F; f += 256) {
+    float w[AM];
+#pragma unroll
+    for (int a = 0; a < AM; ++a) w[a] = p.wpi[(size_t)f * A + (a < A ? a : 0)];
+    const float wvf = p.wv[f];
+    const float* fr = p.feat + base * F + f;
+    float* dr = p.dfeat + base * F + f;
+#pragma unroll 4
+    for (int r = 0; r < T; ++r) {
+      const float x = fr[(size_t)r * F];
+      float s = 0.f;
+#pragma unroll
+      for (int a = 0; a < AM; ++a)
+        if (a < A) s = fmaf(s_dl[r * AM + a], w[a], s);
+      const float sv = s_dv[r] * wvf;
+      dr[(size_t)r * F] = (s + sv) * act_grad(x, p.act_prev);
+    }
+  }
+}
+
+int launch_impala_vtrace_bwd(const ImpalaLossArgs& a, int n_traj, hipStream_t st) {
+  if (a.T > 256 || a.A > 32 || n_traj < 1) return -1;
+  if (a.A <= 8) hipLaunchKernelGGL((impala_vtrace_bwd_kernel<8>), dim3(n_traj), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((impala_vtrace_bwd_kernel<32>), dim3(n_traj), dim3(256), 0, st, a);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_impala_loss_reduce(const float* traj_loss, int n, float* out, float* acc, hipStream_t st) {
+  hipLaunchKernelGGL(impala_loss_reduce_kernel, dim3(1), dim3(64), 0, st, traj_loss, n, out, acc);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---------------------------------------------------------------- GAE (float64, bit-exact with numpy)
 // one thread per trajectory; same association as xt/agent/ppo/ppo.py:92-104:
 //   discount = (~done)*gamma ; delta = (reward + discount*next_v) - v ;

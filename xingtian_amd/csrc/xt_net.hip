@@ -34,10 +34,10 @@ int launch_ppo_heads_fused(const PpoHeadArgs&, hipStream_t);
 int launch_adam_clip(float*, const float*, float*, float*, long long, float, float, float, float*, const float*, int,
                      float, float, hipStream_t);
 int launch_rmsprop_clip(float*, const float*, float*, float*, long long, float, float, float, float*, const float*, int,
-                        float, float, hipStream_t);
-int launch_trunk_fwd(const xt_conv_geom*, const xt_conv_geom*, const xt_conv_geom*, const xt_input_xform*, int,
-                     const void*, const int32_t*, const float*, const float*, float*, const float*, const float*,
-                     float*, const float*, const float*, float*, hipStream_t, bool);
+                        float, float, hipStream_t, const float* lr_dev = nullptr);
+int launch_impala_heads_fwd(const ImpalaHeadArgs&, hipStream_t);
+int launch_impala_vtrace_bwd(const ImpalaLossArgs&, int, hipStream_t);
+int launch_impala_loss_reduce(const float*, int, float*, float*, hipStream_t);
 int launch_ppo_loss_gauss(const float*, const float*, const float*, int, int, const int32_t*, const float*, const float*,
                           const double*, const float*, const double*, float, float, float, float, float, float*, float*,
                           float*, int, float*, hipStream_t);
@@ -88,13 +88,12 @@ struct xt_net {
   // graph cache for ppo_train
   xt_grad_exchange_fn xchg = nullptr;  // xt_net_set_grad_exchange
   void* xchg_user = nullptr;
-  hipGraphExec_t gexec = nullptr;
+  // hipGraph cache of the whole-update entry points: a few slots, because the streaming ingest alternates between
+  // two rollout buffer sets (two pointer sets -> two graphs), least recently used replaced
+  struct GraphSlot { std::string key; hipGraphExec_t exec = nullptr; unsigned long long used = 0; };
+  GraphSlot gslots[4];
+  unsigned long long gclock = 0;
   hipStream_t cap_stream = nullptr;   // capture happens on our own stream: the legacy null stream cannot be captured
-  // fork/join: weight-gradient kernels run on side streams next to the dgrad chain (also inside the graph)
-  hipStream_t side[2] = {nullptr, nullptr};
-  hipEvent_t ev_fork[16] = {}, ev_join[2] = {};
-  bool overlap = true;
-  std::string gkey;
 };
 
 namespace xt {
@@ -129,23 +128,7 @@ static int net_forward(xt_net* n, const void* obs, const int32_t* idx, int B, bo
                        bool defer_last = false) {
   for (int tr = 0; tr < n->n_trunks; ++tr) {
     const void* x = obs;
-    int l0 = n->t_begin[tr];
-    if (n->t_end[tr] - l0 >= 4) {      // conv1 -> conv2 -> conv3 of one frame stack per workgroup (xt_trunk.hip)
-      Layer& A = n->layers[l0];
-      Layer& Bl = n->layers[l0 + 1];
-      Layer& C = n->layers[l0 + 2];
-      const int rc = launch_trunk_fwd(&A.g, &Bl.g, &C.g, &n->xf, B, obs, idx, n->params + A.poff,
-                                      n->params + A.poff + (int64_t)A.K * A.g.N, n->ws + A.act_off,
-                                      n->params + Bl.poff, n->params + Bl.poff + (int64_t)Bl.K * Bl.g.N,
-                                      n->ws + Bl.act_off, n->params + C.poff,
-                                      n->params + C.poff + (int64_t)C.K * C.g.N, n->ws + C.act_off, st, false);
-      if (rc > 0) return rc;
-      if (rc == 0) {
-        A.last_ksplit = Bl.last_ksplit = C.last_ksplit = 1;
-        x = n->ws + C.act_off;
-        l0 += 3;
-      }
-    }
+    const int l0 = n->t_begin[tr];
     for (int l = l0; l < n->t_end[tr]; ++l) {
       Layer& L = n->layers[l];
       const bool first = (l == n->t_begin[tr]);
@@ -169,13 +152,6 @@ static int net_forward(xt_net* n, const void* obs, const int32_t* idx, int B, bo
 
 constexpr int kMaxNormPartials = 16384;
 
-static int ensure_side_streams(xt_net* n) {
-  for (auto& sd : n->side) if (!sd) XT_CHECK_HIP(hipStreamCreateWithFlags(&sd, hipStreamNonBlocking));
-  for (auto& e : n->ev_fork) if (!e) XT_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  for (auto& e : n->ev_join) if (!e) XT_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  return 0;
-}
-
 static int layer_wgrad(xt_net* n, int l, bool first, const void* obs, const int32_t* idx, int B, hipStream_t st) {
   Layer& L = n->layers[l];
   const void* x = first ? obs : (const void*)(n->ws + n->layers[l - 1].act_off);
@@ -191,101 +167,51 @@ static int heads_wgrad(xt_net* n, int B, hipStream_t st) {
                                     n->ws + n->off_hslab_v, n->hstride_v, &n->head_chunks, st);
 }
 
-// Backward through the trunks once d(features) sits in the last layer's dact.  The dgrad chain
-// (dact[l] -> dact[l-1]) is the critical path and stays on `st`; every weight-gradient kernel except the
-// first layer's only consumes finished tensors, so it is forked onto a side stream as soon as its dY
-// exists and joined before the gradient reduction.  Works eagerly and under stream capture.
-// part: 0 = whole backward; 1 = only the layer that feeds the heads (+ the head weight gradients); 2 = the rest
-// (the data-parallel step all-reduces the large tail of the gradient while part 2 runs; see dp_splittable()).
-static bool dp_splittable(const xt_net* n) { return n->n_trunks == 1 && n->t_end[0] - n->t_begin[0] >= 2; }
-
-static int trunk_backward(xt_net* n, const void* obs, const int32_t* idx, int B, hipStream_t st, int part = 0) {
-  if (!n->overlap || part != 0) {
-    // one launch per non-first layer: dgrad + wgrad (+ the head weight gradients with the very first one)
-    bool heads_done = (part == 2);
-    for (int tr = 0; tr < n->n_trunks; ++tr)
-      for (int l = n->t_end[tr] - 1; l >= n->t_begin[tr]; --l) {
-        const bool first = (l == n->t_begin[tr]);
-        const bool last = (l == n->t_end[tr] - 1);
-        if ((part == 1 && !last) || (part == 2 && last)) continue;
-        Layer& L = n->layers[l];
-        if (first) {
-          if (!heads_done) { if (int rc = heads_wgrad(n, B, st)) return rc; heads_done = true; }
-          if (int rc = layer_wgrad(n, l, true, obs, idx, B, st)) return rc;
-          continue;
-        }
-        Layer& Lprev = n->layers[l - 1];
-        HeadWgArgs hw;
-        const HeadWgArgs* hwp = nullptr;
-        if (!heads_done) {
-          Layer& Lp = n->layers[n->t_end[0] - 1];
-          Layer& Lv = n->layers[n->t_end[n->n_trunks - 1] - 1];
-          hw.f_pi = n->ws + Lp.act_off; hw.f_v = n->ws + Lv.act_off;
-          hw.dlogits = n->ws + n->off_dlogits; hw.dvalue = n->ws + n->off_dvalue;
-          hw.slab_pi = n->ws + n->off_hslab_pi; hw.slab_v = n->ws + n->off_hslab_v;
-          hw.stride_pi = n->hstride_pi; hw.stride_v = n->hstride_v;
-          hw.B = B; hw.F = n->feat; hw.A = n->A; hw.gx = (n->feat + 63) / 64; hw.nchunk = (B + 7) / 8;
-          n->head_chunks = hw.nchunk;
-          hwp = &hw;
-          heads_done = true;
-        }
-        if (int rc = launch_bwd_layer(&L.g, B, n->ws + Lprev.act_off, n->ws + L.dact_off, n->params + L.poff,
-                                      Lprev.g.act, n->ws + Lprev.dact_off, n->grads + L.poff, n->ws + L.slab_off,
-                                      wgrad_split(L, B), hwp, &L.last_msplit, st))
-          return rc;
-      }
-    return 0;
-  }
-  if (int rc = ensure_side_streams(n)) return rc;
-  int nev = 0, which = 0;
-  bool used[2] = {false, false};
-  // head weight gradients + last layers' wgrad as soon as d(features) exists
-  XT_CHECK_HIP(hipEventRecord(n->ev_fork[nev], st));
-  XT_CHECK_HIP(hipStreamWaitEvent(n->side[0], n->ev_fork[nev], 0));
-  XT_CHECK_HIP(hipStreamWaitEvent(n->side[1], n->ev_fork[nev], 0));
-  ++nev;
-  used[0] = used[1] = true;
-  if (int rc = heads_wgrad(n, B, n->side[1])) return rc;
-  for (int tr = 0; tr < n->n_trunks; ++tr) {
+// Backward through the trunks once d(features) sits in the last layer's dact: one launch per non-first layer
+// (input gradient + weight gradient [+ the head weight gradients with the very first one]), then the first layer's
+// weight gradient.  (Forking the weight-gradient kernels onto side streams inside the hipGraph measured SLOWER
+// than this chain -- 14.7 vs 13.9 ms per update -- and was removed.)
+static int trunk_backward(xt_net* n, const void* obs, const int32_t* idx, int B, hipStream_t st) {
+  bool heads_done = false;
+  for (int tr = 0; tr < n->n_trunks; ++tr)
     for (int l = n->t_end[tr] - 1; l >= n->t_begin[tr]; --l) {
       const bool first = (l == n->t_begin[tr]);
       Layer& L = n->layers[l];
       if (first) {
-        if (int rc = layer_wgrad(n, l, true, obs, idx, B, st)) return rc;     // biggest kernel: keep on the main stream
-      } else {
-        hipStream_t sd = n->side[which];
-        which ^= 1;
-        if (int rc = layer_wgrad(n, l, false, obs, idx, B, sd)) return rc;
-        Layer& Lprev = n->layers[l - 1];
-        if (int rc = launch_dgrad(&L.g, B, n->ws + L.dact_off, n->params + L.poff, n->ws + Lprev.act_off,
-                                  Lprev.g.act, n->ws + Lprev.dact_off, st))
-          return rc;
-        // dact[l-1] is ready: let both side streams see it
-        XT_REQUIRE(nev < 16, "xt_net: too many layers for the fork events");
-        XT_CHECK_HIP(hipEventRecord(n->ev_fork[nev], st));
-        XT_CHECK_HIP(hipStreamWaitEvent(n->side[0], n->ev_fork[nev], 0));
-        XT_CHECK_HIP(hipStreamWaitEvent(n->side[1], n->ev_fork[nev], 0));
-        ++nev;
+        if (!heads_done) { if (int rc = heads_wgrad(n, B, st)) return rc; heads_done = true; }
+        if (int rc = layer_wgrad(n, l, true, obs, idx, B, st)) return rc;
+        continue;
       }
+      Layer& Lprev = n->layers[l - 1];
+      HeadWgArgs hw;
+      const HeadWgArgs* hwp = nullptr;
+      if (!heads_done) {
+        Layer& Lp = n->layers[n->t_end[0] - 1];
+        Layer& Lv = n->layers[n->t_end[n->n_trunks - 1] - 1];
+        hw.f_pi = n->ws + Lp.act_off; hw.f_v = n->ws + Lv.act_off;
+        hw.dlogits = n->ws + n->off_dlogits; hw.dvalue = n->ws + n->off_dvalue;
+        hw.slab_pi = n->ws + n->off_hslab_pi; hw.slab_v = n->ws + n->off_hslab_v;
+        hw.stride_pi = n->hstride_pi; hw.stride_v = n->hstride_v;
+        hw.B = B; hw.F = n->feat; hw.A = n->A; hw.gx = (n->feat + 63) / 64; hw.nchunk = (B + 7) / 8;
+        n->head_chunks = hw.nchunk;
+        hwp = &hw;
+        heads_done = true;
+      }
+      if (int rc = launch_bwd_layer(&L.g, B, n->ws + Lprev.act_off, n->ws + L.dact_off, n->params + L.poff,
+                                    Lprev.g.act, n->ws + Lprev.dact_off, n->grads + L.poff, n->ws + L.slab_off,
+                                    wgrad_split(L, B), hwp, &L.last_msplit, st))
+        return rc;
     }
-  }
-  for (int q = 0; q < 2; ++q) {
-    if (!used[q]) continue;
-    XT_CHECK_HIP(hipEventRecord(n->ev_join[q], n->side[q]));
-    XT_CHECK_HIP(hipStreamWaitEvent(st, n->ev_join[q], 0));
-  }
   return 0;
 }
 
 // ONE kernel: every slab reduction (trunk layers + heads) + the squared-norm partials
-static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t st, int part = 0) {
+static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t st) {
   const int F = n->feat, A = n->A;
   GradTable tab;
   tab.n = 0;
   XT_REQUIRE(n->layers.size() + 3 <= 12, "xt_net: too many layers for the gradient table");
   for (size_t li = 0; li < n->layers.size(); ++li) {
-    const bool last = ((int)li == n->t_end[0] - 1);
-    if ((part == 1 && !last) || (part == 2 && last)) continue;
     Layer& L = n->layers[li];
     GradEntry& E = tab.e[tab.n++];
     E.count = (L.K + 1) * L.g.N;
@@ -294,7 +220,6 @@ static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t s
     E.src = (L.last_msplit > 1) ? n->ws + L.slab_off : E.dst;
     E.stride = E.count;
   }
-  if (part == 2) return launch_grads_finish(&tab, n->ws + n->off_norm, kMaxNormPartials, &n->norm_blocks, fin, st);
   {
     GradEntry& E = tab.e[tab.n++];
     E.count = F * A + A; E.dst = n->grads + n->pi_off; E.src = n->ws + n->off_hslab_pi;
@@ -331,21 +256,10 @@ static int net_apply(xt_net* n, float lr, float b1, float b2, float eps, float c
   return launch_adam(n->params, n->grads, n->m, n->v, n->P, b1, b2, eps, n->state, st);
 }
 
-// phase 0: the whole step; phase 1 / 2: the two halves of the data-parallel step (xt_net_ppo_step_begin/_end)
 static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32_t* idx, int B,
                     const void* action_v, const float* old_logp, const double* adv, const float* old_v,
-                    const double* target_v, int apply, float* loss_out, float* loss_acc, hipStream_t st,
-                    int phase = 0) {
+                    const double* target_v, int apply, float* loss_out, float* loss_acc, hipStream_t st) {
   XT_REQUIRE(n->params && n->ws, "xt_net: buffers not bound (call xt_net_bind)");
-  if (phase == 2) {
-    const float inv_b2 = 1.f / (float)(c->global_batch > 0 ? c->global_batch : B);
-    float* lo2 = loss_out ? loss_out : n->ws + n->off_loss;
-    if (dp_splittable(n)) {
-      if (int rc = trunk_backward(n, obs, idx, B, st, 2)) return rc;
-      if (int rc = grads_finish(n, B, nullptr, st, 2)) return rc;
-    }
-    return xt_ppo_loss_reduce(n->ws + n->off_terms, B, c->ent_coef, c->critic_coef, inv_b2, lo2, loss_acc, st);
-  }
   XT_REQUIRE(B > 0 && B <= n->maxB, "xt_net_ppo_step: batch %d outside (0,%d]", B, n->maxB);
   const bool gauss = (n->action_type == XT_ACTION_DIAG_GAUSSIAN);
   const int32_t* action = static_cast<const int32_t*>(action_v);
@@ -405,19 +319,14 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
                                     n->ws + Lp.dact_off, n->ws + Lv.dact_off, st))
       return rc;
   }
-  if (phase == 1) {
-    const int part = dp_splittable(n) ? 1 : 0;
-    if (int rc = trunk_backward(n, obs, idx, B, st, part)) return rc;
-    return grads_finish(n, B, nullptr, st, part);
-  }
   if (int rc = trunk_backward(n, obs, idx, B, st)) return rc;
-  LossArgs la;
+  LossArgs la{};
   la.terms = n->ws + n->off_terms; la.B = B; la.ent_coef = c->ent_coef; la.critic_coef = c->critic_coef;
   la.inv_b = inv_b; la.out = lo; la.acc = loss_acc;
   if (apply) {
     static int tail_mode = -1;     // XT_FIN_TICKET=1: the old "last block finalises" form (A/B)
     if (tail_mode < 0) { const char* e = getenv("XT_FIN_TICKET"); tail_mode = (e && e[0] == '1') ? 1 : 2; }
-    FinalizeArgs fin;
+    FinalizeArgs fin{};
     fin.enable = tail_mode; fin.counter = reinterpret_cast<unsigned int*>(n->ws + n->off_counter);
     fin.clip_norm = c->max_grad_norm; fin.grad_scale = c->grad_scale; fin.lr = c->lr; fin.beta1 = c->beta1;
     fin.beta2 = c->beta2; fin.state = n->state; fin.loss = la;
@@ -428,6 +337,111 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
   if (int rc = grads_finish(n, B, nullptr, st)) return rc;
   // gradient only (data parallel): still report the local loss
   return xt_ppo_loss_reduce(n->ws + n->off_terms, B, c->ent_coef, c->critic_coef, inv_b, lo, loss_acc, st);
+}
+
+// Replay the hipGraph cached under `key`, capturing `enqueue` (on the net's private stream) on a miss.
+template <typename F>
+static int graph_run(xt_net* net, const char* key, hipStream_t st, F enqueue) {
+  xt_net::GraphSlot* slot = nullptr;
+  for (auto& g : net->gslots) if (g.exec && g.key == key) slot = &g;
+  if (!slot) {
+    slot = &net->gslots[0];
+    for (auto& g : net->gslots) {
+      if (!g.exec) { slot = &g; break; }
+      if (g.used < slot->used) slot = &g;
+    }
+    if (slot->exec) { hipGraphExecDestroy(slot->exec); slot->exec = nullptr; slot->key.clear(); }
+    hipGraph_t graph = nullptr;
+    if (!net->cap_stream) XT_CHECK_HIP(hipStreamCreateWithFlags(&net->cap_stream, hipStreamNonBlocking));
+    hipStream_t cs = net->cap_stream;
+    XT_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
+    int rc = enqueue(cs);
+    hipError_t e = hipStreamEndCapture(cs, &graph);
+    if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+    XT_CHECK_HIP(e);
+    e = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    XT_CHECK_HIP(e);
+    slot->key = key;
+  }
+  slot->used = ++net->gclock;
+  XT_CHECK_HIP(hipGraphLaunch(slot->exec, st));
+  return 0;
+}
+
+// ImpalaCnnOpt.train (impala_cnn_opt.py:251-265) on one chunk of nfr = n_traj * T frames.  lr_dev (may be null): the
+// step size in device memory (lr_schedule evaluated by the caller; lets a replayed hipGraph see a new value).
+static int impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int nfr, const float* bp_logits,
+                       const int32_t* action, const uint8_t* done, const float* reward, int apply, const float* lr_dev,
+                       float* loss_out, float* loss_acc, hipStream_t st) {
+  const int T = c->sample_batch_step;
+  XT_REQUIRE(T >= 2 && nfr > 0 && nfr % T == 0, "xt_net_impala_step: n=%d must be a multiple of sample_batch_step=%d",
+             nfr, T);
+  XT_REQUIRE(nfr <= n->maxB, "xt_net_impala_step: %d frames > max batch %d", nfr, n->maxB);
+  const int ntraj = nfr / T, F = n->feat, A = n->A;
+  Layer& Lp = n->layers[n->t_end[0] - 1];
+  Layer& Lv = n->layers[n->t_end[n->n_trunks - 1] - 1];
+  float* lo = n->ws + n->off_loss;   // [0] = loss, [4 .. 4 + n_traj) per-trajectory sums
+  // fused form (ImpalaCnnOpt: one trunk, A <= 8, T <= 256): split-K finish + heads in one launch, v-trace + loss +
+  // d(heads) + d(features) in the next, loss scalar in the gradient-reduction launch
+  const bool fused = (n->n_trunks == 1 && A <= 8 && F <= 512 && T <= 256);
+  bool loss_pending = false;
+  if (fused) {
+    if (int rc = net_forward(n, obs, nullptr, nfr, false, st, true)) return rc;
+    ImpalaHeadArgs h{};
+    h.feat = n->ws + Lp.act_off; h.wpi = n->params + n->pi_off; h.bpi = h.wpi + (int64_t)F * A;
+    h.wv = n->params + n->v_off; h.bv = h.wv + F; h.B = nfr; h.F = F; h.A = A;
+    h.logits = n->ws + n->off_logits; h.value = n->ws + n->off_value; h.act_feat = Lp.g.act;
+    h.ksplit = 1; h.part_stride = (long long)nfr * F;
+    if (Lp.last_ksplit > 1) {
+      h.part = n->ws + Lp.part_off; h.ksplit = Lp.last_ksplit; h.feat_w = n->ws + Lp.act_off;
+      h.tbias = n->params + Lp.poff + (int64_t)Lp.K * Lp.g.N;
+    }
+    int rc = launch_impala_heads_fwd(h, st);
+    if (rc > 0) return rc;
+    XT_REQUIRE(rc == 0, "xt_net_impala_step: fused head kernel rejected the geometry (A=%d F=%d)", A, F);
+    ImpalaLossArgs q{};
+    q.logits = n->ws + n->off_logits; q.baseline = n->ws + n->off_value; q.bp_logits = bp_logits; q.action = action;
+    q.done = done; q.reward = reward; q.T = T; q.A = A; q.F = F; q.act_prev = Lp.g.act; q.gamma = c->gamma;
+    q.dlogits = n->ws + n->off_dlogits; q.dbaseline = n->ws + n->off_dvalue; q.traj_loss = lo + 4;
+    q.feat = n->ws + Lp.act_off; q.wpi = n->params + n->pi_off; q.wv = n->params + n->v_off;
+    q.dfeat = n->ws + Lp.dact_off;
+    rc = launch_impala_vtrace_bwd(q, ntraj, st);
+    if (rc > 0) return rc;
+    XT_REQUIRE(rc == 0, "xt_net_impala_step: fused v-trace kernel rejected the geometry (T=%d A=%d)", T, A);
+    loss_pending = true;
+  } else {
+    if (int rc = net_forward(n, obs, nullptr, nfr, true, st)) return rc;
+    if (int rc = xt_impala_loss(n->ws + n->off_logits, n->ws + n->off_value, bp_logits, action, done, reward, ntraj, T,
+                                A, c->gamma, n->ws + n->off_dlogits, n->ws + n->off_dvalue, lo, loss_acc, nullptr,
+                                nullptr, st))
+      return rc;
+    if (loss_out) XT_CHECK_HIP(hipMemcpyAsync(loss_out, lo, sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (int rc = launch_heads_dfeat(n->ws + Lp.act_off, n->ws + Lv.act_off, nfr, F, A, n->params + n->pi_off,
+                                    n->params + n->v_off, n->ws + n->off_dlogits, n->ws + n->off_dvalue, Lp.g.act,
+                                    n->ws + Lp.dact_off, n->ws + Lv.dact_off, st))
+      return rc;
+  }
+  if (int rc = trunk_backward(n, obs, nullptr, nfr, st)) return rc;
+  if (!apply) {
+    if (int rc = grads_finish(n, nfr, nullptr, st)) return rc;
+    if (loss_pending) return launch_impala_loss_reduce(lo + 4, ntraj, loss_out ? loss_out : lo, loss_acc, st);
+    return 0;
+  }
+  // step size bookkeeping (and the fused form's loss scalar) in an extra grads_finish block, clip factor inside the
+  // Adam kernel: no finalize launch
+  FinalizeArgs fin{};
+  fin.enable = 2; fin.counter = nullptr; fin.clip_norm = c->grad_norm_clip; fin.grad_scale = c->grad_scale;
+  fin.lr = c->lr; fin.beta1 = c->beta1; fin.beta2 = c->beta2; fin.state = n->state; fin.lr_dev = lr_dev;
+  if (loss_pending) {
+    fin.loss.traj_loss = lo + 4; fin.loss.n_traj = ntraj; fin.loss.out = loss_out ? loss_out : lo; fin.loss.acc = loss_acc;
+  }
+  if (int rc = grads_finish(n, nfr, &fin, st)) return rc;
+  if (c->opt_type == XT_OPT_RMSPROP_CENTERED)
+    return launch_rmsprop_clip(n->params, n->grads, n->m, n->v, n->P, c->lr, c->rms_decay, c->rms_eps, n->state,
+                               n->ws + n->off_norm, n->norm_blocks, c->grad_norm_clip, c->grad_scale, st, lr_dev);
+  XT_REQUIRE(c->opt_type == XT_OPT_ADAM, "xt_net_impala_step: unknown opt_type %d", c->opt_type);
+  return net_apply(n, c->lr, c->beta1, c->beta2, c->eps, c->grad_norm_clip, c->grad_scale, 3, nullptr, st);
 }
 
 }  // namespace xt
@@ -453,8 +467,6 @@ int xt_net_create(const xt_net_desc* d, int32_t max_batch, xt_net** out) {
     delete n;
     XT_REQUIRE(false, "xt_net_create: bad action_type / logstd_off");
   }
-  n->overlap = false;   // measured: fork/join inside the hipGraph costs more than it hides (14.7 vs 13.9 ms/update)
-  if (const char* e = getenv("XT_OVERLAP")) n->overlap = (e[0] == '1');
   int64_t off = 0;
   int64_t max_partial = 4;
   int cur = -1;
@@ -518,11 +530,8 @@ int xt_net_create(const xt_net_desc* d, int32_t max_batch, xt_net** out) {
 
 void xt_net_destroy(xt_net* net) {
   if (!net) return;
-  if (net->gexec) hipGraphExecDestroy(net->gexec);
+  for (auto& g : net->gslots) if (g.exec) hipGraphExecDestroy(g.exec);
   if (net->cap_stream) hipStreamDestroy(net->cap_stream);
-  for (auto& sd : net->side) if (sd) hipStreamDestroy(sd);
-  for (auto& e : net->ev_fork) if (e) hipEventDestroy(e);
-  for (auto& e : net->ev_join) if (e) hipEventDestroy(e);
   delete net;
 }
 
@@ -538,7 +547,7 @@ int xt_net_bind(xt_net* n, float* params, float* grads, float* adam_m, float* ad
   n->params = params; n->grads = grads; n->m = adam_m; n->v = adam_v; n->state = adam_state;
   n->ws = static_cast<float*>(workspace);
   XT_CHECK_HIP(hipMemset(n->ws + n->off_counter, 0, 32 * 66 * 4));   // ticket counter of grads_finish_kernel
-  if (n->gexec) { hipGraphExecDestroy(n->gexec); n->gexec = nullptr; n->gkey.clear(); }
+  for (auto& g : n->gslots) if (g.exec) { hipGraphExecDestroy(g.exec); g.exec = nullptr; g.key.clear(); }
   return 0;
 }
 
@@ -559,22 +568,6 @@ int xt_net_ppo_step(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, const i
   XT_REQUIRE(net && cfg, "xt_net_ppo_step: null argument");
   return xt::ppo_step(net, cfg, obs, idx, B, action, old_logp, adv, old_v, target_v, apply, loss_out, loss_acc,
                       xt::as_stream(stream));
-}
-
-int xt_net_ppo_step_begin(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, const int32_t* idx, int32_t B,
-                          const void* action, const float* old_logp, const double* adv, const float* old_v,
-                          const double* target_v, int64_t* tail_off, void* stream) {
-  XT_REQUIRE(net && cfg && tail_off, "xt_net_ppo_step_begin: null argument");
-  *tail_off = xt::dp_splittable(net) ? net->layers[net->t_end[0] - 1].poff : 0;
-  return xt::ppo_step(net, cfg, obs, idx, B, action, old_logp, adv, old_v, target_v, 0, nullptr, nullptr,
-                      xt::as_stream(stream), 1);
-}
-
-int xt_net_ppo_step_end(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, const int32_t* idx, int32_t B,
-                        float* loss_out, float* loss_acc, void* stream) {
-  XT_REQUIRE(net && cfg, "xt_net_ppo_step_end: null argument");
-  return xt::ppo_step(net, cfg, obs, idx, B, nullptr, nullptr, nullptr, nullptr, nullptr, 0, loss_out, loss_acc,
-                      xt::as_stream(stream), 2);
 }
 
 static int ppo_train_enqueue(xt_net* net, const xt_ppo_cfg* c, const void* obs, int32_t n, const int32_t* perm,
@@ -616,69 +609,79 @@ int xt_net_ppo_train(xt_net* net, const xt_ppo_cfg* c, const void* obs, int32_t 
   if (!use_graph)
     return ppo_train_enqueue(net, c, obs, n, perm, action, old_logp, adv, old_v, target_v, loss_acc, st);
   char key[512];
-  snprintf(key, sizeof(key), "%p|%p|%p|%d|%p|%p|%p|%p|%p|%p|%p|%g|%g|%g|%g|%g|%g|%g|%g|%g|%d|%d|%g|%d",
+  snprintf(key, sizeof(key), "P|%p|%p|%p|%d|%p|%p|%p|%p|%p|%p|%p|%g|%g|%g|%g|%g|%g|%g|%g|%g|%d|%d|%g|%d",
            (void*)net->xchg, net->xchg_user, obs, n,
            (const void*)perm, (const void*)action, (const void*)old_logp, (const void*)adv, (const void*)old_v,
            (const void*)target_v, (void*)loss_acc, c->lr, c->beta1, c->beta2, c->eps, c->clip_ratio, c->ent_coef,
            c->vf_clip, c->critic_coef, c->max_grad_norm, c->batch_size, c->num_sgd_iter, c->grad_scale,
            c->global_batch);
-  if (!net->gexec || net->gkey != key) {
-    if (net->gexec) { hipGraphExecDestroy(net->gexec); net->gexec = nullptr; }
-    hipGraph_t graph = nullptr;
-    if (!net->cap_stream) XT_CHECK_HIP(hipStreamCreateWithFlags(&net->cap_stream, hipStreamNonBlocking));
-    hipStream_t cs = net->cap_stream;
-    XT_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
-    int rc = ppo_train_enqueue(net, c, obs, n, perm, action, old_logp, adv, old_v, target_v, loss_acc, cs);
-    hipError_t e = hipStreamEndCapture(cs, &graph);
-    if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
-    XT_CHECK_HIP(e);
-    e = hipGraphInstantiate(&net->gexec, graph, nullptr, nullptr, 0);
-    hipGraphDestroy(graph);
-    XT_CHECK_HIP(e);
-    net->gkey = key;
-  }
-  XT_CHECK_HIP(hipGraphLaunch(net->gexec, st));
-  return 0;
+  return xt::graph_run(net, key, st, [&](hipStream_t cs) {
+    return ppo_train_enqueue(net, c, obs, n, perm, action, old_logp, adv, old_v, target_v, loss_acc, cs);
+  });
 }
 
 int xt_net_impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int32_t nfr, const float* bp_logits,
                        const int32_t* action, const uint8_t* done, const float* reward, int32_t apply,
                        float* loss_out, float* loss_acc, void* stream) {
   XT_REQUIRE(n && c && n->params && n->ws, "xt_net_impala_step: null argument / unbound buffers");
-  const int T = c->sample_batch_step;
-  XT_REQUIRE(T >= 2 && nfr > 0 && nfr % T == 0, "xt_net_impala_step: n=%d must be a multiple of sample_batch_step=%d",
-             nfr, T);
-  XT_REQUIRE(nfr <= n->maxB, "xt_net_impala_step: %d frames > max batch %d", nfr, n->maxB);
-  hipStream_t st = xt::as_stream(stream);
-  if (int rc = xt::net_forward(n, obs, nullptr, nfr, true, st)) return rc;
-  float* lo = n->ws + n->off_loss;   // needs 4 + n_traj floats
-  if (int rc = xt_impala_loss(n->ws + n->off_logits, n->ws + n->off_value, bp_logits, action, done, reward, nfr / T,
-                              T, n->A, c->gamma, n->ws + n->off_dlogits, n->ws + n->off_dvalue, lo, loss_acc,
-                              nullptr, nullptr, st))
-    return rc;
-  if (loss_out) XT_CHECK_HIP(hipMemcpyAsync(loss_out, lo, sizeof(float), hipMemcpyDeviceToDevice, st));
-  {
-    xt::Layer& Lp = n->layers[n->t_end[0] - 1];
-    xt::Layer& Lv = n->layers[n->t_end[n->n_trunks - 1] - 1];
-    if (int rc = xt::launch_heads_dfeat(n->ws + Lp.act_off, n->ws + Lv.act_off, nfr, n->feat, n->A,
-                                        n->params + n->pi_off, n->params + n->v_off, n->ws + n->off_dlogits,
-                                        n->ws + n->off_dvalue, Lp.g.act, n->ws + Lp.dact_off, n->ws + Lv.dact_off, st))
+  return xt::impala_step(n, c, obs, nfr, bp_logits, action, done, reward, apply, nullptr, loss_out, loss_acc,
+                         xt::as_stream(stream));
+}
+
+static int impala_train_enqueue(xt_net* net, const xt_impala_cfg* c, const void* obs, int32_t n, int32_t batch_size,
+                                const float* bp_logits, const int32_t* action, const uint8_t* done, const float* reward,
+                                const float* lr_steps, float* loss_acc, hipStream_t st) {
+  XT_CHECK_HIP(hipMemsetAsync(loss_acc, 0, 2 * sizeof(float), st));
+  const size_t frame = (size_t)net->in_h * net->in_w * net->in_c * (net->xf.is_u8 ? 1 : 4);
+  int chunk = 0;
+  for (int lo = 0; lo < n; lo += batch_size, ++chunk) {
+    const int nfr = (n - lo) < batch_size ? (n - lo) : batch_size;
+    const float* lr_dev = lr_steps ? lr_steps + chunk : nullptr;
+    const void* o = static_cast<const char*>(obs) + frame * lo;
+    if (!net->xchg) {
+      if (int rc = xt::impala_step(net, c, o, nfr, bp_logits + (size_t)lo * net->A, action + lo, done + lo, reward + lo, 1,
+                                   lr_dev, nullptr, loss_acc, st))
+        return rc;
+      continue;
+    }
+    // data parallel: local gradient of this rank's trajectories -> SUM over the replicas (the loss is a sum:
+    // grad_scale = 1) -> norm of the exchanged gradient, clip, optimiser
+    XT_REQUIRE(c->opt_type == XT_OPT_ADAM && !lr_dev,
+               "xt_net_impala_train: the gradient exchange path supports Adam with a fixed step size");
+    if (int rc = xt::impala_step(net, c, o, nfr, bp_logits + (size_t)lo * net->A, action + lo, done + lo, reward + lo, 0,
+                                 lr_dev, nullptr, loss_acc, st))
+      return rc;
+    XT_REQUIRE(net->xchg(net->grads, net->P, net->xchg_user, st) == 0, "xt_net_impala_train: gradient exchange hook failed");
+    if (int rc = xt::net_apply(net, c->lr, c->beta1, c->beta2, c->eps, c->grad_norm_clip, c->grad_scale, 0, nullptr, st))
       return rc;
   }
-  if (int rc = xt::trunk_backward(n, obs, nullptr, nfr, st)) return rc;
-  if (!apply) return xt::grads_finish(n, nfr, nullptr, st);
-  // step size bookkeeping in an extra grads_finish block, clip factor inside the Adam kernel: no finalize launch
-  xt::FinalizeArgs fin;
-  fin.enable = 2; fin.counter = nullptr; fin.clip_norm = c->grad_norm_clip; fin.grad_scale = c->grad_scale;
-  fin.lr = c->lr; fin.beta1 = c->beta1; fin.beta2 = c->beta2; fin.state = n->state;
-  fin.loss.terms = nullptr; fin.loss.B = 0; fin.loss.ent_coef = fin.loss.critic_coef = fin.loss.inv_b = 0.f;
-  fin.loss.out = fin.loss.acc = nullptr;
-  if (int rc = xt::grads_finish(n, nfr, &fin, st)) return rc;
-  if (c->opt_type == XT_OPT_RMSPROP_CENTERED)
-    return xt::launch_rmsprop_clip(n->params, n->grads, n->m, n->v, n->P, c->lr, c->rms_decay, c->rms_eps, n->state,
-                                   n->ws + n->off_norm, n->norm_blocks, c->grad_norm_clip, c->grad_scale, st);
-  XT_REQUIRE(c->opt_type == XT_OPT_ADAM, "xt_net_impala_step: unknown opt_type %d", c->opt_type);
-  return xt::net_apply(n, c->lr, c->beta1, c->beta2, c->eps, c->grad_norm_clip, c->grad_scale, 3, nullptr, st);
+  return 0;
+}
+
+int xt_net_impala_train(xt_net* net, const xt_impala_cfg* c, const void* obs, int32_t n, int32_t batch_size,
+                        const float* bp_logits, const int32_t* action, const uint8_t* done, const float* reward,
+                        const float* lr_steps, float* loss_acc, int32_t use_graph, void* stream) {
+  XT_REQUIRE(net && c && obs && bp_logits && action && done && reward && loss_acc, "xt_net_impala_train: null argument");
+  XT_REQUIRE(net->params && net->ws, "xt_net_impala_train: buffers not bound");
+  const int T = c->sample_batch_step;
+  XT_REQUIRE(n > 0 && batch_size > 0 && T >= 2, "xt_net_impala_train: bad sizes (n=%d batch=%d T=%d)", n, batch_size, T);
+  // impala_opt.py:90-99 slices BATCH_SIZE rows at a time and split_batches reshapes each slice to [B, T]: every chunk
+  // (including the last, shorter one) must hold whole trajectories
+  XT_REQUIRE(batch_size % T == 0 && n % T == 0,
+             "xt_net_impala_train: n=%d and BATCH_SIZE=%d must be multiples of sample_batch_step=%d", n, batch_size, T);
+  XT_REQUIRE(batch_size <= net->maxB || n <= net->maxB, "xt_net_impala_train: chunk of %d frames > max batch %d",
+             batch_size < n ? batch_size : n, net->maxB);
+  hipStream_t st = xt::as_stream(stream);
+  if (!use_graph)
+    return impala_train_enqueue(net, c, obs, n, batch_size, bp_logits, action, done, reward, lr_steps, loss_acc, st);
+  char key[512];
+  snprintf(key, sizeof(key), "I|%p|%p|%p|%d|%d|%p|%p|%p|%p|%p|%p|%g|%g|%g|%g|%g|%g|%d|%g|%d|%g|%g",
+           (void*)net->xchg, net->xchg_user, obs, n, batch_size, (const void*)bp_logits, (const void*)action,
+           (const void*)done, (const void*)reward, (const void*)lr_steps, (void*)loss_acc, c->lr, c->beta1, c->beta2,
+           c->eps, c->grad_norm_clip, c->gamma, c->sample_batch_step, c->grad_scale, c->opt_type, c->rms_decay, c->rms_eps);
+  return xt::graph_run(net, key, st, [&](hipStream_t cs) {
+    return impala_train_enqueue(net, c, obs, n, batch_size, bp_logits, action, done, reward, lr_steps, loss_acc, cs);
+  });
 }
 
 int xt_net_keras_impala_step(xt_net* n, const void* obs, const int32_t* idx, int32_t B, const float* adv,
@@ -734,26 +737,12 @@ int xt_net_time_layer(xt_net* n, int32_t layer, int32_t which, const void* obs, 
   bool first = false;
   for (int tr = 0; tr < n->n_trunks; ++tr) first |= (layer == n->t_begin[tr]);
   const void* x = first ? obs : (const void*)(n->ws + n->layers[layer - 1].act_off);
-  XT_REQUIRE(which == 0 || which == 1 || ((which == 2 || which == 3) && !first) || (which == 4 && first),
-             "xt_net_time_layer: bad kernel selector");
-  XT_REQUIRE(which != 4 || layer + 2 < (int)n->layers.size(), "xt_net_time_layer: the fused trunk needs 3 layers");
+  XT_REQUIRE(which == 0 || which == 1 || ((which == 2 || which == 3) && !first), "xt_net_time_layer: bad kernel selector");
   hipEvent_t e0, e1;
   XT_CHECK_HIP(hipEventCreate(&e0));
   XT_CHECK_HIP(hipEventCreate(&e1));
   int rc = 0;
   auto one = [&]() -> int {
-    if (which == 4) {      // fused conv1 -> conv2 -> conv3 forward (xt_trunk.hip)
-      xt::Layer& A = n->layers[layer];
-      xt::Layer& Bl = n->layers[layer + 1];
-      xt::Layer& C = n->layers[layer + 2];
-      const int rc = xt::launch_trunk_fwd(&A.g, &Bl.g, &C.g, &n->xf, B, obs, idx, n->params + A.poff,
-                                          n->params + A.poff + (int64_t)A.K * A.g.N, n->ws + A.act_off,
-                                          n->params + Bl.poff, n->params + Bl.poff + (int64_t)Bl.K * Bl.g.N,
-                                          n->ws + Bl.act_off, n->params + C.poff,
-                                          n->params + C.poff + (int64_t)C.K * C.g.N, n->ws + C.act_off, st, true);
-      if (rc < 0) { xt::set_error("xt_net_time_layer: the fused trunk rejected the geometry"); return 2; }
-      return rc;
-    }
     if (which == 0)
       return xt::launch_fwd(&L.g, first ? &n->xf : nullptr, B, x, first ? idx : nullptr, n->params + L.poff,
                             n->params + L.poff + (int64_t)L.K * L.g.N, n->ws + L.act_off, n->ws + n->off_partial,

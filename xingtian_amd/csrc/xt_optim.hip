@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void grads_finish_kernel(const GradTable tab, 
     // extra block of the "Adam computes the clip scale itself" form: everything of the old last-block finalize
     // that does not depend on the gradient norm (loss scalars, beta powers, step size) -- off the critical path
     loss_reduce_body(fin.loss, reinterpret_cast<double*>(sh4));
-    if (threadIdx.x == 0) adam_advance(fin.state, fin.lr, fin.beta1, fin.beta2);
+    if (threadIdx.x == 0) adam_advance(fin.state, fin.lr_dev ? fin.lr_dev[0] : fin.lr, fin.beta1, fin.beta2);
     return;
   }
   int ei = 0;
@@ -125,8 +125,8 @@ __global__ __launch_bounds__(256) void grads_finish_kernel(const GradTable tab, 
   __syncthreads();
   XT_TL(3);
   if (!s_last) return;
-  finalize_body(partial, gridDim.x, fin.clip_norm, fin.grad_scale, fin.lr, fin.beta1, fin.beta2, 1, fin.state,
-                fin.loss, reinterpret_cast<double*>(sh4));
+  finalize_body(partial, gridDim.x, fin.clip_norm, fin.grad_scale, fin.lr_dev ? fin.lr_dev[0] : fin.lr, fin.beta1, fin.beta2,
+                1, fin.state, fin.loss, reinterpret_cast<double*>(sh4));
   XT_TL(4);
 }
 
@@ -189,7 +189,15 @@ __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __rest
 // state: [0]=b1^t [1]=b2^t [2]=scale [3]=alpha [4]=gnorm [5]=step
 // PPO loss scalars from the per-sample terms (fixed-order tree), xt/model/ppo/__init__.py
 __device__ void loss_reduce_body(const LossArgs& la, double* sh) {
-  if (!la.terms) return;
+  if (!la.terms) {
+    if (la.traj_loss && threadIdx.x == 0) {     // IMPALA: sum of the per-trajectory sums, trajectory order (float, as
+      float s = 0.f;                            // impala_loss_reduce_kernel)
+      for (int i = 0; i < la.n_traj; ++i) s += la.traj_loss[i];
+      if (la.out) la.out[0] = s;
+      if (la.acc) { la.acc[0] += s; la.acc[1] += 1.f; }
+    }
+    return;
+  }
   double t3[3] = {0.0, 0.0, 0.0};
   for (int b = threadIdx.x; b < la.B; b += 256) {
     t3[0] += (double)la.terms[(size_t)b * 4 + 0];
@@ -354,11 +362,13 @@ __global__ __launch_bounds__(256) void adam_tf_clip_kernel(float* __restrict__ p
 // (impala_cnn_opt.py:205-215).  Same structure as adam_tf_clip_kernel: every block derives the clip factor itself.
 __global__ __launch_bounds__(256) void rmsprop_tf_clip_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                               float* __restrict__ mg, float* __restrict__ ms,
-                                                              long long count, float lr, float decay, float eps,
+                                                              long long count, float lr_arg, float decay, float eps,
                                                               float* __restrict__ state, const float* __restrict__ partial,
-                                                              int nblocks, float clip_norm, float grad_scale) {
+                                                              int nblocks, float clip_norm, float grad_scale,
+                                                              const float* __restrict__ lr_dev) {
   __shared__ double sh[256];
   __shared__ float s_scale;
+  const float lr = lr_dev ? lr_dev[0] : lr_arg;
   const double sq = sqnorm_total(partial, nblocks, sh);
   if (threadIdx.x == 0) {
     float gnorm, sc;
@@ -411,12 +421,12 @@ int launch_grads_finish(GradTable* tab, float* partial, int max_partials, int* n
 
 int launch_rmsprop_clip(float* param, const float* grad, float* mg, float* ms, long long count, float lr, float decay,
                         float eps, float* state, const float* partial, int nblocks, float clip_norm, float grad_scale,
-                        hipStream_t st) {
+                        hipStream_t st, const float* lr_dev) {
   int nb = (int)((count + 255) / 256);
   if (nb > 2048) nb = 2048;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(rmsprop_tf_clip_kernel, dim3(nb), dim3(256), 0, st, param, grad, mg, ms, count, lr, decay, eps,
-                     state, partial, nblocks, clip_norm, grad_scale);
+                     state, partial, nblocks, clip_norm, grad_scale, lr_dev);
   XT_LAUNCH_CHECK();
   return 0;
 }
@@ -514,8 +524,8 @@ int launch_adam_keras(float* param, const float* grad, float* m, float* v, int n
 
 int launch_norm_finalize(const float* partial, int nblocks, float clip_norm, float grad_scale, float lr, float beta1,
                          float beta2, int advance, float* state, const LossArgs* la, hipStream_t st) {
-  LossArgs l;
-  if (la) l = *la; else { l.terms = nullptr; l.B = 0; l.ent_coef = l.critic_coef = l.inv_b = 0.f; l.out = l.acc = nullptr; }
+  LossArgs l{};
+  if (la) l = *la;
   hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblocks, clip_norm, grad_scale, lr, beta1,
                      beta2, advance, state, l);
   XT_LAUNCH_CHECK();

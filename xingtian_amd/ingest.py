@@ -10,33 +10,46 @@ Plumbing only (PyTorch-ROCm tensors / streams); no arithmetic happens here.
 import numpy as np
 import torch
 
-_FIELDS = (("action", torch.int32, np.int32), ("old_logp", torch.float32, np.float32),
-           ("adv", torch.float64, np.float64), ("old_v", torch.float32, np.float32),
-           ("target_v", torch.float64, np.float64))
+# label fields of a PPO trajectory (xt/algorithm/ppo/ppo.py:79-85): name, device dtype, per-row width (0 = scalar)
+PPO_FIELDS = (("action", torch.int32, 0), ("old_logp", torch.float32, 0), ("adv", torch.float64, 0),
+              ("old_v", torch.float32, 0), ("target_v", torch.float64, 0))
+
+
+def impala_fields(action_dim):
+    """label fields of an IMPALAOpt rollout message (xt/algorithm/impala/impala_opt.py:116-147): behaviour logits
+    [n, A] f32, actions i32, dones (bool -> u8), rewards (float64 on the wire, float32 at the placeholder)."""
+    return (("logit", torch.float32, int(action_dim)), ("action", torch.int32, 0), ("done", torch.uint8, 0),
+            ("reward", torch.float32, 0))
+
+
 
 
 class _BufferSet(object):
-    def __init__(self, cap, obs_tail, obs_u8, n_epochs, device, sig):
+    def __init__(self, cap, obs_tail, obs_u8, n_epochs, device, sig, fields=PPO_FIELDS):
         self.cap = cap
         self.sig = sig
         tdt = torch.uint8 if obs_u8 else torch.float32
         self.host = {"obs": torch.empty((cap,) + obs_tail, dtype=tdt, pin_memory=True)}
         self.dev = {"obs": torch.empty((cap,) + obs_tail, dtype=tdt, device=device)}
-        for name, tdt2, _ in _FIELDS:
-            self.host[name] = torch.empty((cap,), dtype=tdt2, pin_memory=True)
-            self.dev[name] = torch.empty((cap,), dtype=tdt2, device=device)
-        self.dev["perm"] = torch.empty((n_epochs, cap), dtype=torch.int32, device=device)
+        for name, tdt2, width in fields:
+            shape = (cap, width) if width else (cap,)
+            self.host[name] = torch.empty(shape, dtype=tdt2, pin_memory=True)
+            self.dev[name] = torch.empty(shape, dtype=tdt2, device=device)
+        if n_epochs > 0:
+            self.dev["perm"] = torch.empty((n_epochs, cap), dtype=torch.int32, device=device)
         self.host_np = {k: v.numpy() for k, v in self.host.items()}
         self.done = torch.cuda.Event()
         self.free = None          # recorded on the compute stream after the update that read this set
 
 
 class RolloutIngest(object):
-    def __init__(self, device, n_epochs, initial_capacity=4096, obs_u8=None):
+    def __init__(self, device, n_epochs, initial_capacity=4096, obs_u8=None, fields=PPO_FIELDS):
         """``obs_u8``: the observation type the NETWORK reads (``spec.input_xform[0]``: uint8 frames vs float32);
         arriving arrays of another dtype are cast into the staging buffer like the upload path casts them.  None
-        = take the dtype of the first array (stand-alone use)."""
+        = take the dtype of the first array (stand-alone use).  ``fields``: the label arrays that travel with the
+        observations (``PPO_FIELDS`` / ``impala_fields(A)``); ``n_epochs`` = 0: no permutation buffer."""
         self.obs_u8 = obs_u8
+        self.fields = tuple(fields)
         self.device = torch.device(device)
         self.n_epochs = n_epochs
         self.initial_capacity = initial_capacity
@@ -56,7 +69,7 @@ class RolloutIngest(object):
         cap = max(self.initial_capacity, need)
         if same:
             cap = max(cap, 2 * s.cap)
-        new = _BufferSet(cap, tuple(obs.shape[1:]), u8, self.n_epochs, self.device, sig)
+        new = _BufferSet(cap, tuple(obs.shape[1:]), u8, self.n_epochs, self.device, sig, self.fields)
         if same and self.n > 0:                        # grow: keep what was already ingested
             self.copy_stream.synchronize()
             for k in new.host:
@@ -67,8 +80,9 @@ class RolloutIngest(object):
         self.sets[self.cur] = new
         return new
 
-    def put(self, obs, action, old_logp, adv, old_v, target_v):
-        """Append one trajectory ([T,...] arrays as the explorer ships them) and start its H2D copy."""
+    def put(self, obs, *labels):
+        """Append one trajectory / rollout message ([T,...] arrays as the explorer ships them, labels in the order
+        of ``fields``) and start its H2D copy."""
         obs = np.asarray(obs)
         t = obs.shape[0]
         s = self._ensure(self.n + t, obs)
@@ -76,8 +90,14 @@ class RolloutIngest(object):
             self.copy_stream.wait_event(s.free)
         lo, hi = self.n, self.n + t
         np.copyto(s.host_np["obs"][lo:hi], obs, casting="unsafe")
-        for (name, _, npdt), arr in zip(_FIELDS, (action, old_logp, adv, old_v, target_v)):
-            np.copyto(s.host_np[name][lo:hi], np.asarray(arr).reshape(-1), casting="same_kind")
+        if len(labels) != len(self.fields):
+            raise ValueError("RolloutIngest.put: {} label arrays for fields {}".format(
+                len(labels), [f[0] for f in self.fields]))
+        for (name, _, width), arr in zip(self.fields, labels):
+            arr = np.asarray(arr)
+            dst = s.host_np[name][lo:hi]
+            # bool -> uint8 and float64 -> float32 are the casts the reference's placeholders apply
+            np.copyto(dst, arr.reshape(dst.shape), casting="unsafe" if arr.dtype == np.bool_ else "same_kind")
         with torch.cuda.stream(self.copy_stream):
             for k in s.host:
                 s.dev[k][lo:hi].copy_(s.host[k][lo:hi], non_blocking=True)

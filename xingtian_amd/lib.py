@@ -29,7 +29,7 @@ class LayerDesc(Structure):
     _fields_ = [("g", ConvGeom), ("param_off", c_int64), ("trunk", c_int32)]
 
 
-ABI_VERSION = 5          # XT_ABI_VERSION of include/xt_mi355x.h
+ABI_VERSION = 6          # XT_ABI_VERSION of include/xt_mi355x.h
 ACTION_TYPE = {"Categorical": 0, "DiagGaussian": 1}
 
 
@@ -81,14 +81,13 @@ SIGNATURES = {
     "xt_net_bind": (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_int64]),
     "xt_net_forward": (c_int32, [_P, _P, _P, c_int32, _P, _P, _P]),
     "xt_net_ppo_step": (c_int32, [_P, POINTER(PpoCfg), _P, _P, c_int32, _P, _P, _P, _P, _P, c_int32, _P, _P, _P]),
-    "xt_net_ppo_step_begin": (c_int32, [_P, POINTER(PpoCfg), _P, _P, c_int32, _P, _P, _P, _P, _P, POINTER(c_int64), _P]),
-    "xt_net_ppo_step_end": (c_int32, [_P, POINTER(PpoCfg), _P, _P, c_int32, _P, _P, _P]),
     "xt_net_ppo_train": (c_int32, [_P, POINTER(PpoCfg), _P, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, _P]),
     "xt_net_set_grad_exchange": (c_int32, [_P, _P, _P]),
     "xt_keras_impala_loss": (c_int32, [_P, _P, c_int32, c_int32, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P]),
     "xt_adam_keras": (c_int32, [_P, _P, _P, _P, c_int32, _P, _P, c_float, c_float, c_float, c_float, c_float, _P, _P]),
     "xt_net_keras_impala_step": (c_int32, [_P, _P, _P, c_int32, _P, _P, _P, c_float, _P, _P, _P]),
     "xt_net_impala_step": (c_int32, [_P, POINTER(ImpalaCfg), _P, c_int32, _P, _P, _P, _P, c_int32, _P, _P, _P]),
+    "xt_net_impala_train": (c_int32, [_P, POINTER(ImpalaCfg), _P, c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_int32, _P]),
     "xt_net_apply": (c_int32, [_P, c_float, c_float, c_float, c_float, c_float, c_float, _P]),
     "xt_net_layer_offsets": (c_int32, [_P, c_int32, POINTER(c_int64)]),
     "xt_net_time_layer": (c_int32, [_P, c_int32, c_int32, _P, _P, c_int32, c_int32, POINTER(c_float), _P]),

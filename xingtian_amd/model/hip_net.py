@@ -11,17 +11,7 @@ import numpy as np
 import torch
 
 from xingtian_amd import lib as L
-
-
-def glorot_uniform(rng, shape):
-    """Keras default kernel initialiser (Conv2D/Dense in xt/model/model_utils.py:86-96)."""
-    if len(shape) == 4:
-        rf = shape[0] * shape[1]
-        fan_in, fan_out = rf * shape[2], rf * shape[3]
-    else:
-        fan_in, fan_out = shape
-    lim = np.sqrt(6.0 / (fan_in + fan_out))
-    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+from xingtian_amd.model.cpu_net import initial_weights
 
 
 class HipActorCritic(object):
@@ -76,21 +66,10 @@ class HipActorCritic(object):
             pass
 
     # ------------------------------------------------------------------ weights
+    inference_only = False
+
     def init_weights(self, seed=None, baseline_norm_std=None):
-        rng = np.random.default_rng(seed)
-        w = OrderedDict()
-        for name, (_, shape) in self.spec.names.items():
-            if name.endswith("/bias") or name == "pi_logstd":
-                w[name] = np.zeros(shape, np.float32)
-            else:
-                w[name] = glorot_uniform(rng, shape)
-        if baseline_norm_std is not None:
-            # custom_norm_initializer(std), xt/model/model_utils.py:204-211
-            shape = self.spec.names[self.spec.v_name + "/kernel"][1]
-            out = rng.standard_normal(shape).astype(np.float32)
-            out *= baseline_norm_std / np.sqrt(np.square(out).sum(axis=0, keepdims=True))
-            w[self.spec.v_name + "/kernel"] = out
-        self.set_weights(w)
+        self.set_weights(initial_weights(self.spec, seed, baseline_norm_std))
 
     def _flat_to_host(self, dev_flat, tag):
         """One D2H of a flat device buffer into a persistent PINNED host buffer (the weight publish
@@ -225,23 +204,6 @@ class HipActorCritic(object):
                 "xt_net_ppo_step")
         return self.loss_out
 
-    def ppo_step_begin(self, c, obs, idx, action, old_logp, adv, old_v, target_v):
-        """First half of a data-parallel step (C ABI xt_net_ppo_step_begin): returns the float offset from which
-        the flat gradient is already final (in stream order) -> that tail can be all-reduced while
-        ``ppo_step_end`` runs the rest of the backward pass."""
-        b = int(idx.numel()) if idx is not None else int(obs.shape[0])
-        tail = ctypes.c_int64()
-        L.check(self.lib.xt_net_ppo_step_begin(self.handle, ctypes.byref(c), L.ptr(obs), L.ptr(idx), b, L.ptr(action),
-                                               L.ptr(old_logp), L.ptr(adv), L.ptr(old_v), L.ptr(target_v),
-                                               ctypes.byref(tail), L.stream_ptr()), "xt_net_ppo_step_begin")
-        return int(tail.value)
-
-    def ppo_step_end(self, c, obs, idx):
-        b = int(idx.numel()) if idx is not None else int(obs.shape[0])
-        L.check(self.lib.xt_net_ppo_step_end(self.handle, ctypes.byref(c), L.ptr(obs), L.ptr(idx), b,
-                                             L.ptr(self.loss_out), None, L.stream_ptr()), "xt_net_ppo_step_end")
-        return self.loss_out
-
     def ppo_train(self, c, obs, perm, action, old_logp, adv, old_v, target_v, use_graph=False):
         n = int(obs.shape[0])
         L.check(self.lib.xt_net_ppo_train(self.handle, ctypes.byref(c), L.ptr(obs), n, L.ptr(perm), L.ptr(action),
@@ -275,6 +237,17 @@ class HipActorCritic(object):
                                             L.ptr(self.loss_out), L.ptr(loss_acc), L.stream_ptr()),
                 "xt_net_impala_step")
         return self.loss_out
+
+    def impala_train(self, c, obs, batch_size, bp_logits, action, done, reward, lr_steps=None, use_graph=False):
+        """IMPALAOpt.train in one call (C ABI xt_net_impala_train): sequential BATCH_SIZE chunks of the resident
+        rollout; ``lr_steps`` (float32 device tensor, one step size per chunk) or None.  Returns the device tensor
+        [sum of chunk losses, number of chunks]."""
+        n = int(obs.shape[0])
+        L.check(self.lib.xt_net_impala_train(self.handle, ctypes.byref(c), L.ptr(obs), n, int(batch_size),
+                                             L.ptr(bp_logits), L.ptr(action), L.ptr(done), L.ptr(reward),
+                                             L.ptr(lr_steps), L.ptr(self.loss_acc), 1 if use_graph else 0,
+                                             L.stream_ptr()), "xt_net_impala_train")
+        return self.loss_acc
 
     def keras_impala_step(self, obs, idx, adv, onehot, target_v, ent_coef, loss_acc=None):
         """One ``model.fit`` minibatch of the non-opt IMPALA models (C ABI xt_net_keras_impala_step): forward, Keras

@@ -10,9 +10,8 @@ import numpy as np
 import torch
 
 from xingtian_amd.model import netspec
-from xingtian_amd.model.hip_net import HipActorCritic
 from xingtian_amd.model.impala.default_config import GAMMA, LR  # noqa: F401
-from xingtian_amd.model.model import XTModel
+from xingtian_amd.model.model import XTModel, as_numpy, build_net
 from xingtian_amd.register import Registers, import_config
 
 
@@ -52,35 +51,83 @@ class ImpalaCnnOpt(XTModel):
         self.max_batch = int(model_config.get("MAX_BATCH", model_info.get("max_batch", 1024)))
         self.seed = model_config.get("SEED")
         self._rng = np.random.default_rng(self.seed)
+        self.use_graph = bool(model_config.get("USE_HIP_GRAPH", True))
+        self.stream_ingest = bool(model_config.get("STREAM_INGEST", True))
+        self._ingest = None
+        self._lr_host = self._lr_dev = None
         super().__init__(model_info)
 
     def create_model(self, model_info):
         spec = netspec.impala_cnn_opt(tuple(self.state_dim), self.action_dim, self.sta_mean, self.sta_std,
                                       self.input_dtype)
-        self.net = HipActorCritic(spec, max_batch=self.max_batch, seed=self.seed, init="none")
+        self.net = build_net(model_info, spec, self.max_batch, self.seed, init="none")
         self.net.init_weights(self.seed, baseline_norm_std=0.01)   # custom_norm_initializer(0.01), :149
         self.actor_var = self.net
+        if self.net.inference_only:
+            self.stream_ingest = False
+            return True
         self.net.set_optimizer(self.opt_type)
         self._cfg = self.net.make_impala_cfg(self.lr, self.grad_norm_clip, self.sample_batch_steps, GAMMA,
                                              opt_type=self.opt_type)
         return True
 
+    # ---- resident rollout: every train goes pinned staging -> async H2D -> ONE C call (hipGraph replay) -------
+    def _ingest_obj(self):
+        if self._ingest is None:
+            from xingtian_amd.ingest import RolloutIngest, impala_fields
+            self._ingest = RolloutIngest(self.net.device, 0, initial_capacity=self.max_batch,
+                                         obs_u8=bool(self.net.spec.input_xform[0]),
+                                         fields=impala_fields(self.action_dim))
+        return self._ingest
+
+    def ingest_message(self, states, bp_logic_outs, actions, dones, rewards):
+        """Called by ``IMPALAOpt.prepare_data`` for every rollout message: its pinned-staging + asynchronous H2D
+        copy starts now, so ``train`` finds the rollout resident."""
+        self._ingest_obj().put(states, bp_logic_outs, actions, dones, rewards)
+
+    def ingested(self):
+        return 0 if self._ingest is None else self._ingest.n
+
+    def _lr_steps(self, n_chunks):
+        """Step size of the next ``n_chunks`` updates as a device array, or None when it is the constant LR (the
+        reference's rmsprop branch ignores lr_schedule, impala_cnn_opt.py:204-206)."""
+        if not (self.lr_schedule and self.opt_type == "adam"):
+            return None
+        if self._lr_host is None or self._lr_host.numel() < n_chunks:
+            self._lr_host = torch.empty((max(n_chunks, 16),), dtype=torch.float32, pin_memory=True)
+            self._lr_dev = torch.empty((max(n_chunks, 16),), dtype=torch.float32, device=self.net.device)
+        step0 = self._global_step
+        for i in range(n_chunks):
+            self._global_step = step0 + i
+            self._lr_host[i] = float(self.current_lr())
+        self._global_step = step0
+        self._lr_dev[:n_chunks].copy_(self._lr_host[:n_chunks], non_blocking=True)
+        return self._lr_dev
+
+    def train_ingested(self, batch_size):
+        """``IMPALAOpt.train`` (impala_opt.py:73-106) on the rollout streamed in through ``ingest_message``: all
+        sequential BATCH_SIZE chunks in one C call -> mean of the chunk losses."""
+        self._require_learner()
+        n, d = self._ingest.finish()
+        n_chunks = (n + batch_size - 1) // batch_size
+        lr_steps = self._lr_steps(n_chunks)
+        acc = self.net.impala_train(self._cfg, d["obs"][:n], batch_size, d["logit"][:n], d["action"][:n], d["done"][:n],
+                                    d["reward"][:n], lr_steps=lr_steps, use_graph=self.use_graph)
+        self._ingest.mark_consumed()
+        self._global_step += n_chunks
+        a = acc.cpu().numpy()
+        return np.float32(a[0] / max(a[1], 1.0))
+
     def train(self, state, label):
         """One chunk: state [n,...], label=[bp_logits, actions, dones, rewards] -> loss
         (impala_cnn_opt.py:251-265).  n must be a multiple of sample_batch_step."""
+        self._require_learner()
         bp_logic_outs, actions, dones, rewards = label
-        dev = self.net.device
-        obs = self.net.to_device_obs(state)
-        bp = torch.from_numpy(np.ascontiguousarray(bp_logic_outs, dtype=np.float32)).to(dev)
-        act = torch.from_numpy(np.ascontiguousarray(actions, dtype=np.int32).reshape(-1)).to(dev)
-        dn = torch.from_numpy(np.ascontiguousarray(np.asarray(dones, dtype=bool).astype(np.uint8)).reshape(-1)).to(dev)
-        rw = torch.from_numpy(np.ascontiguousarray(rewards, dtype=np.float32).reshape(-1)).to(dev)
-        if self.lr_schedule and self.opt_type == "adam":   # (the reference's rmsprop branch ignores lr_schedule, :204-206)
-            # the step size is a host-side scalar of the C ABI: evaluate the schedule here
-            self._cfg.lr = float(self.current_lr())
-        out = self.net.impala_step(self._cfg, obs, bp, act, dn, rw, apply=True)
-        self._global_step += 1
-        return np.float32(out[0].item())
+        ing = self._ingest_obj()
+        ing.reset()
+        ing.put(state, bp_logic_outs, np.asarray(actions).reshape(-1), np.asarray(dones, dtype=bool).reshape(-1),
+                np.asarray(rewards).reshape(-1))
+        return self.train_ingested(int(np.asarray(state).shape[0]))
 
     def extra_optimizer_state(self):
         """``global_step`` drives ``lr_schedule`` (impala_cnn_opt.py:198-203): it belongs to a true resume."""
@@ -100,7 +147,7 @@ class ImpalaCnnOpt(XTModel):
     def predict(self, state):
         """-> [logits [B,A], baseline [B], action [B]] (impala_cnn_opt.py:267-277)."""
         logits, value = self.net.forward(np.asarray(state))
-        logits = logits.cpu().numpy()
+        logits = as_numpy(logits)
         u = self._rng.random(logits.shape)
         action = np.argmax(logits - np.log(-np.log(u)), axis=-1).astype(np.int32)   # tf.multinomial, :153-157
-        return [logits, value.cpu().numpy(), action]
+        return [logits, as_numpy(value), action]

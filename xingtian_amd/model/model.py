@@ -20,6 +20,37 @@ def check_keep_model(model_path, keep_num):
         os.remove(stale)
 
 
+def wants_cpu_replica(model_info):
+    """True in the processes that only ever call ``predict``: explorers, evaluators and the predictor are started
+    with ``CUDA_VISIBLE_DEVICES=-1`` (xt/framework/explorer.py:60, predictor.py:88) and only the learner marks its
+    model ``type: learner`` (xt/framework/learner.py:544).  There the model is the numpy replica
+    (``cpu_net.CpuActorCritic``: same names, same flat layout, no ``train``).  The LEARNER never takes this route:
+    without a GPU it fails loudly in ``HipActorCritic``.  ``model_config.DEVICE`` ("cpu" | "gpu") overrides."""
+    dev = (model_info.get("model_config") or {}).get("DEVICE")
+    if dev is not None:
+        if dev not in ("cpu", "gpu"):
+            raise ValueError("model_config.DEVICE must be 'cpu' or 'gpu', got {!r}".format(dev))
+        return dev == "cpu"
+    if model_info.get("type") == "learner":
+        return False
+    import torch
+    return not torch.cuda.is_available()
+
+
+def build_net(model_info, spec, max_batch, seed, init="glorot"):
+    """The network object behind a model: HIP learner network, or the inference-only CPU replica (see above)."""
+    if wants_cpu_replica(model_info):
+        from xingtian_amd.model.cpu_net import CpuActorCritic
+        return CpuActorCritic(spec, seed=seed, init=init)
+    from xingtian_amd.model.hip_net import HipActorCritic
+    return HipActorCritic(spec, max_batch=max_batch, seed=seed, init=init)
+
+
+def as_numpy(x):
+    """device tensor or ndarray -> ndarray (``predict`` post-processing is shared by both network kinds)"""
+    return x if isinstance(x, np.ndarray) else x.cpu().numpy()
+
+
 class XTModel(object):
     def __init__(self, model_info):
         cfg = model_info.get("model_config") or {}
@@ -48,6 +79,11 @@ class XTModel(object):
 
     def train(self, state, label):
         raise NotImplementedError
+
+    def _require_learner(self):
+        if getattr(self.net, "inference_only", False):
+            raise RuntimeError("{}: this is the inference-only CPU replica (explorer / evaluator process); the learner "
+                               "update runs only on the GPU (model_info['type'] == 'learner')".format(type(self).__name__))
 
     # ---- weights by TF variable name
     def get_weights(self):

@@ -1,12 +1,25 @@
 """Data-parallel learner plumbing: one process per GPU, ``torch.distributed`` (backend "nccl" == RCCL over
-xGMI on ROCm; "gloo" on CPU for tests).
+xGMI on ROCm; "gloo" for the multi-process tests, which also accepts device tensors).
 
 The learner update shards naturally: samples of a minibatch are independent through
 forward/backward and GAE / v-trace recur only along time, so every rank owns whole trajectories and a
 slice of every minibatch; the ONLY exchange is one all-reduce (SUM) of the flat fp32 gradient buffer per SGD
 step, after which every rank applies the identical clip + Adam update (replicas stay bit-identical because
-the reduced buffer is identical on all ranks).  PPO's loss is a mean over the global minibatch -> scale the
-summed gradient by 1/world (``grad_scale``); IMPALA's loss is a sum -> no scaling.
+the reduced buffer is identical on all ranks).
+
+Two PPO modes (``dp_ppo_update``):
+
+* ``strict`` -- what north_star / SURVEY 8(e) specify: the reference's GLOBAL minibatch of BATCH_SIZE rows
+  (xt/model/ppo/ppo.py:119-124) is split into ``world`` equal shards (320 -> 40 rows per GPU at 8 GPUs), every rank
+  walks the SAME epoch permutations, the loss means (xt/model/ppo/__init__.py:13,24) run over the global minibatch
+  (``cfg.global_batch``), so the summed gradient IS the single-GPU gradient (up to fp32 summation order) and
+  ``grad_scale`` = 1.
+* ``weak`` -- every rank owns its own env_num trajectories and a full BATCH_SIZE local minibatch (global minibatch
+  BATCH_SIZE * world: a flagged deviation that keeps the per-GPU work constant); the local means are averaged:
+  ``grad_scale`` = 1 / world.
+
+IMPALA's loss is a SUM over (T-1) x B (impala_cnn_opt.py:299-318,351): ranks own whole trajectories of a chunk,
+the gradients are summed, no scaling.
 
 The reference has no working counterpart: its multi-process trainer (xt/framework/trainer.py:32-136) averages
 gradients on the host in float64 through a RawArray and is dead code (no Algorithm implements get_grad).
@@ -23,18 +36,19 @@ def world_info():
 
 
 def shard_range(n_items, rank, world):
-    """Contiguous, balanced [begin, end) shard of n_items (trajectories) for ``rank``."""
+    """Contiguous, balanced [begin, end) shard of n_items (trajectories / minibatch rows) for ``rank``."""
     base, rem = divmod(n_items, world)
     begin = rank * base + min(rank, rem)
     return begin, begin + base + (1 if rank < rem else 0)
 
 
 def split_minibatch(perm_row, start, batch_size, rank, world):
-    """Rows of the GLOBAL minibatch perm_row[start:start+batch_size] owned by ``rank`` (equal shards; the global
-    permutation is drawn once with a shared seed so that every rank partitions it identically)."""
-    mb = np.asarray(perm_row[start:start + batch_size])
-    b, e = shard_range(len(mb), rank, world)
-    return mb[b:e]
+    """Rows of the GLOBAL minibatch perm_row[start:start+batch_size] owned by ``rank`` (balanced contiguous shards;
+    the global permutation is drawn once with a shared seed so that every rank partitions it identically).  Works on
+    numpy arrays and on (device) tensors; a tensor slice is a view, i.e. an index indirection without a copy."""
+    stop = min(start + batch_size, len(perm_row))
+    b, e = shard_range(stop - start, rank, world)
+    return perm_row[start + b:start + e]
 
 
 def allreduce_sum_(flat_grad):
@@ -45,10 +59,11 @@ def allreduce_sum_(flat_grad):
 
 
 def grad_scale(loss_reduction, world):
-    """Factor applied to the summed gradient: 'mean' losses (PPO) -> 1/world, 'sum' losses (IMPALA) -> 1."""
+    """Factor applied to the summed gradient: 'mean' losses averaged over equal local minibatches (PPO, weak mode)
+    -> 1/world; 'sum' losses (IMPALA) and means already taken over the global minibatch (PPO, strict mode) -> 1."""
     if loss_reduction == "mean":
         return 1.0 / world
-    if loss_reduction == "sum":
+    if loss_reduction in ("sum", "global_mean"):
         return 1.0
     raise ValueError(loss_reduction)
 
@@ -61,119 +76,64 @@ def broadcast_weights_(flat_params, src=0):
 
 
 def dp_ppo_step(net, cfg_struct, lr, max_grad_norm, obs, idx, action, old_logp, adv, old_v, target_v, world,
-                overlap=False):
-    """One data-parallel PPO SGD step on a HipActorCritic: local fwd/bwd -> RCCL all-reduce (SUM) of net.grads ->
-    identical clip+Adam on every rank.
+                scale=None):
+    """One data-parallel PPO SGD step on a HipActorCritic: local fwd/bwd on this rank's rows ``idx`` -> all-reduce
+    (SUM) of net.grads -> identical clip+Adam on every rank.  ``scale`` multiplies the summed gradient
+    (default: 1/world, the weak mode; strict mode passes 1 with ``cfg_struct.global_batch`` = the global rows)."""
+    net.ppo_step(cfg_struct, obs, idx, action, old_logp, adv, old_v, target_v, apply=False)
+    allreduce_sum_(net.grads)
+    net.apply(lr, max_grad_norm, grad_scale=grad_scale("mean", world) if scale is None else scale)
+    return net.loss_out
 
-    ``overlap``: two buckets.  The tail of the flat gradient (the Dense layer feeding the heads + the heads, 95 %
-    of PpoCnn's 3.39 MB) is final after the first backward launch, so its all-reduce is issued asynchronously
-    (RCCL's own stream; xGMI rings are per-link bound, >= 40 us for 3.2 MB at 8 GPUs) and overlaps the conv
-    backward (~85 us); only the 170 KB head of the buffer is reduced after it.  Each bucket is summed by RCCL in
-    a fixed order, so replicas stay bit-identical.  Costs two more c10d calls per step (~60 us of host time, measured
-    with a 1-rank RCCL group: the eager step becomes host-bound), hence opt-in: worth it when the all-reduce
-    itself is slower than that (more ranks / slower links)."""
-    grouped = dist.is_available() and dist.is_initialized()
-    if not overlap or not grouped:
-        net.ppo_step(cfg_struct, obs, idx, action, old_logp, adv, old_v, target_v, apply=False)
-        allreduce_sum_(net.grads)
+
+def dp_ppo_update(net, cfg, obs, perm, action, old_logp, adv, old_v, target_v, rank, world, mode="strict"):
+    """One whole ``Model.train`` (xt/model/ppo/ppo.py:111-132) data parallel over ``world`` ranks.
+
+    ``cfg``: the reference's model_config keys (LR, BATCH_SIZE, NUM_SGD_ITER, ...); ``perm`` int32 DEVICE tensor
+    [NUM_SGD_ITER, n] with the epoch permutations (identical on every rank in strict mode); the rollout tensors are
+    device resident.  strict: every rank holds the same n-row rollout and processes its shard of every global
+    minibatch; weak: every rank holds its own rollout and processes full local minibatches.
+    Returns the number of SGD steps."""
+    bsz, epochs = int(cfg["BATCH_SIZE"]), int(cfg["NUM_SGD_ITER"])
+    n = int(perm.shape[1])
+    steps = 0
+    structs = {}
+    for ep in range(epochs):
+        for start in range(0, n, bsz):
+            rows = min(bsz, n - start)
+            if mode == "strict":
+                idx = split_minibatch(perm[ep], start, bsz, rank, world)
+                if idx.numel() == 0:
+                    raise ValueError("strict sharding: minibatch of {} rows over {} ranks leaves rank {} empty".format(
+                        rows, world, rank))
+                key, scale = rows, grad_scale("global_mean", world)
+                if key not in structs:
+                    structs[key] = net.make_ppo_cfg(cfg, grad_scale=scale, global_batch=rows)
+            elif mode == "weak":
+                idx = perm[ep, start:start + rows]
+                key, scale = 0, grad_scale("mean", world)
+                if key not in structs:
+                    structs[key] = net.make_ppo_cfg(cfg, grad_scale=scale, global_batch=0)
+            else:
+                raise ValueError(mode)
+            dp_ppo_step(net, structs[key], cfg["LR"], cfg["MAX_GRAD_NORM"], obs, idx, action, old_logp, adv, old_v,
+                        target_v, world, scale=scale)
+            steps += 1
+    return steps
+
+
+def dp_impala_step(net, cfg_struct, lr, grad_norm_clip, obs, bp_logits, action, done, reward, n_traj, t_len, rank,
+                   world):
+    """One data-parallel ImpalaCnnOpt step: the chunk's ``n_traj`` trajectories (flat env-major rows b*T+t) are
+    split into whole-trajectory shards, gradients of the sum-form loss are SUMMED, no scaling."""
+    b, e = shard_range(n_traj, rank, world)
+    if e > b:
+        sl = slice(b * t_len, e * t_len)
+        net.impala_step(cfg_struct, obs[sl], bp_logits[sl], action[sl], done[sl], reward[sl], apply=False)
     else:
-        tail = net.ppo_step_begin(cfg_struct, obs, idx, action, old_logp, adv, old_v, target_v)
-        w_tail = dist.all_reduce(net.grads[tail:], op=dist.ReduceOp.SUM, async_op=True)
-        net.ppo_step_end(cfg_struct, obs, idx)
-        w_head = dist.all_reduce(net.grads[:tail], op=dist.ReduceOp.SUM, async_op=True) if tail > 0 else None
-        w_tail.wait()
-        if w_head is not None:
-            w_head.wait()
-    net.apply(lr, max_grad_norm, grad_scale=grad_scale("mean", world))
-
-
-class DpGraphStepper(object):
-    """Data-parallel PPO SGD steps with the compute segments replayed from hipGraphs.
-
-    The eager step enqueues ~12 kernels through three ctypes calls plus one or two c10d calls per SGD step; at
-    ~155 us of GPU work per step that leaves the host little slack, and the two-bucket overlap (``dp_ppo_step``,
-    ``overlap=True``) made the eager path host-bound.  Here each compute segment (forward + heads + first backward
-    launch | rest of the backward | clip + Adam) is captured ONCE per minibatch size with ``torch.cuda.graph`` -- the
-    library launches on torch's current stream, so its kernels are captured like torch's own -- and a step is
-    ``copy the minibatch indices into a fixed buffer -> replay -> all-reduce -> replay -> all-reduce -> replay``.
-    The all-reduces stay ordinary c10d calls on RCCL's stream (tied to the replays by c10d's stream events), exactly
-    as in the eager form, so the arithmetic, its order and therefore the replicas' bits are unchanged.
-
-    Any failure while capturing (an unsupported call under capture, a driver refusing it) permanently falls back to
-    the eager ``dp_ppo_step`` -- a benchmark must never die on an optimisation.
-    """
-
-    def __init__(self, net, cfg_struct, lr, max_grad_norm, obs, action, old_logp, adv, old_v, target_v, world,
-                 overlap=True, warm_steps=2):
-        self.net, self.cfg, self.lr, self.clip = net, cfg_struct, lr, max_grad_norm
-        self.data = (obs, action, old_logp, adv, old_v, target_v)
-        self.world, self.overlap = world, bool(overlap)
-        self.grouped = dist.is_available() and dist.is_initialized()
-        self.idx_buf = torch.empty((net.max_batch,), dtype=torch.int32, device=net.params.device)
-        self.graphs = {}
-        self.eager_left = int(warm_steps)     # the first steps run eagerly: one-time host work stays outside captures
-        self.failed = False
-        self.scale = grad_scale("mean", world)
-
-    def _eager(self, idx):
-        obs, action, old_logp, adv, old_v, target_v = self.data
-        dp_ppo_step(self.net, self.cfg, self.lr, self.clip, obs, idx, action, old_logp, adv, old_v, target_v,
-                    self.world, overlap=False)
-
-    def _capture(self, b):
-        net = self.net
-        obs, action, old_logp, adv, old_v, target_v = self.data
-        idx = self.idx_buf[:b]
-        seg = {}
-        g1 = torch.cuda.CUDAGraph()
-        if self.overlap and self.grouped:
-            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
-                seg["tail"] = net.ppo_step_begin(self.cfg, obs, idx, action, old_logp, adv, old_v, target_v)
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, capture_error_mode="thread_local"):
-                net.ppo_step_end(self.cfg, obs, idx)
-            seg["end"] = g2
-        else:
-            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
-                net.ppo_step(self.cfg, obs, idx, action, old_logp, adv, old_v, target_v, apply=False)
-        seg["begin"] = g1
-        g3 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g3, capture_error_mode="thread_local"):
-            net.apply(self.lr, self.clip, grad_scale=self.scale)
-        seg["apply"] = g3
-        return seg
-
-    def step(self, idx):
-        """One SGD step on the rows ``idx`` (int32 device tensor) of the resident rollout."""
-        if self.failed or self.eager_left > 0:
-            self.eager_left -= 1
-            return self._eager(idx)
-        b = int(idx.numel())
-        seg = self.graphs.get(b)
-        if seg is None:
-            try:
-                seg = self._capture(b)
-            except Exception as exc:       # noqa: BLE001 -- fall back, never fail the run
-                import sys
-                print("[xingtian_amd.parallel] hipGraph capture of the data-parallel step failed (%r): eager path"
-                      % (exc,), file=sys.stderr)
-                self.failed = True
-                return self._eager(idx)
-            self.graphs[b] = seg
-        net = self.net
-        self.idx_buf[:b].copy_(idx, non_blocking=True)
-        seg["begin"].replay()
-        if "end" in seg:
-            tail = seg["tail"]
-            w_tail = dist.all_reduce(net.grads[tail:], op=dist.ReduceOp.SUM, async_op=True)
-            seg["end"].replay()
-            w_head = dist.all_reduce(net.grads[:tail], op=dist.ReduceOp.SUM, async_op=True) if tail > 0 else None
-            w_tail.wait()
-            if w_head is not None:
-                w_head.wait()
-        else:
-            allreduce_sum_(net.grads)
-        seg["apply"].replay()
+        net.grads.zero_()
+    allreduce_sum_(net.grads)
+    net.apply(lr, grad_norm_clip, grad_scale=grad_scale("sum", world))
 
 
 class RcclComm(object):
@@ -186,7 +146,7 @@ class RcclComm(object):
     (already loaded in the process); the 128-byte unique id travels through the existing ``torch.distributed`` group.
 
     Opt-in (``bench.py --dp-mode ingraph``): validated with a 1-rank communicator on one GPU (bit-identical to the
-    step-wise path); multi-rank runs were not possible in the round that added it.
+    step-wise path); it has not met a second rank yet, so the default data-parallel path is the step-wise one.
     """
     NCCL_FLOAT32, NCCL_SUM = 7, 0
 
