@@ -679,9 +679,12 @@ int launch_impala_heads_fwd(const ImpalaHeadArgs& a, hipStream_t st) {
 }
 
 // K2: v-trace + loss + d(logits, baseline) (the arithmetic of impala_loss_kernel, statement for statement) followed
-// by the gradient w.r.t. the trunk features of the trajectory's rows (the arithmetic of heads_dfeat_kernel), one
-// 256-thread workgroup per trajectory.  The reverse scan stays SERIAL in time (tf.scan, vtrace.py:94-106) but runs
+// by the gradient w.r.t. the trunk features (the arithmetic of heads_dfeat_kernel).  Grid (trajectory, row block):
+// every workgroup of a trajectory repeats the (cheap, LDS-resident) v-trace of the whole trajectory and then
+// produces d(features) of its own kVtRows rows -- one workgroup per trajectory walking all T rows was a chain of
+// T/4 dependent global-load round trips (47 us at T = 128 for breakout_impala's single trajectory).  The reverse scan stays SERIAL in time (tf.scan, vtrace.py:94-106) but runs
 // from registers: thread 0 pulls delta / discount*c / V in chunks of 16 from LDS, then a pure FMA chain.
+constexpr int kVtRows = 8;
 template <int AM>
 __global__ __launch_bounds__(256) void impala_vtrace_bwd_kernel(const ImpalaLossArgs p) {
   constexpr int MAXT = 256;
@@ -692,6 +695,7 @@ __global__ __launch_bounds__(256) void impala_vtrace_bwd_kernel(const ImpalaLoss
   const int T = p.T, A = p.A, F = p.F;
   const int Tm = T - 1;
   const size_t base = (size_t)traj * T;
+  const bool lead = blockIdx.y == 0;             // the trajectory's first row block publishes d(heads) and the loss
   float rho = 0.f, disc = 0.f, rew = 0.f, val = 0.f, ce = 0.f, ent = 0.f, logz = 0.f, mx = 0.f, z = 1.f;
   int act = 0;
   if (t < T) s_val[t] = p.baseline[base + t];
@@ -756,29 +760,31 @@ __global__ __launch_bounds__(256) void impala_vtrace_bwd_kernel(const ImpalaLoss
       const float lpa = rl - logz;
       const float onehot = (a == act) ? 1.f : 0.f;
       const float dl = pg * (pa - onehot) + 0.01f * (pa * (lpa + ent));
-      p.dlogits[(base + t) * A + a] = dl;
+      if (lead) p.dlogits[(base + t) * A + a] = dl;
       s_dl[t * AM + a] = dl;
     }
     const float dvl = 0.5f * (val - vs);
-    p.dbaseline[base + t] = dvl;
+    if (lead) p.dbaseline[base + t] = dvl;
     s_dv[t] = dvl;
     const float dvv = vs - val;
     lterm = ce * pg + 0.5f * (0.5f * dvv * dvv) + 0.01f * (-ent);
-    if (p.vs_out) p.vs_out[(size_t)traj * Tm + t] = vs;
-    if (p.pg_out) p.pg_out[(size_t)traj * Tm + t] = pg;
+    if (lead && p.vs_out) p.vs_out[(size_t)traj * Tm + t] = vs;
+    if (lead && p.pg_out) p.pg_out[(size_t)traj * Tm + t] = pg;
   } else if (t == Tm) {
-    for (int a = 0; a < A; ++a) { p.dlogits[(base + t) * A + a] = 0.f; s_dl[t * AM + a] = 0.f; }
-    p.dbaseline[base + t] = 0.f;
+    for (int a = 0; a < A; ++a) { if (lead) p.dlogits[(base + t) * A + a] = 0.f; s_dl[t * AM + a] = 0.f; }
+    if (lead) p.dbaseline[base + t] = 0.f;
     s_dv[t] = 0.f;
   }
   if (t < MAXT) s_red[t] = lterm;
   __syncthreads();
-  if (t == 64) {                                  // lane 0 of the second wave: the others go on with d(features)
+  if (t == 64 && blockIdx.y == 0) {               // lane 0 of the second wave: the others go on with d(features)
     float s = 0.f;
     for (int q = 0; q < T; ++q) s += s_red[q];
     p.traj_loss[traj] = s;
   }
   // d(features)[r, f] = (sum_a dlogits[r,a] Wpi[f,a] + dbaseline[r] Wv[f]) * act'(feature)   (heads_dfeat_kernel)
+  // for this block's kVtRows rows: every row's feature load is issued before the first use
+  const int r0 = blockIdx.y * kVtRows;
   for (int f = t; f < F; f += 256) {
     float w[AM];
 #pragma unroll
@@ -786,23 +792,32 @@ __global__ __launch_bounds__(256) void impala_vtrace_bwd_kernel(const ImpalaLoss
     const float wvf = p.wv[f];
     const float* fr = p.feat + base * F + f;
     float* dr = p.dfeat + base * F + f;
-#pragma unroll 4
-    for (int r = 0; r < T; ++r) {
-      const float x = fr[(size_t)r * F];
-      float s = 0.f;
+    float x[kVtRows];
 #pragma unroll
-      for (int a = 0; a < AM; ++a)
-        if (a < A) s = fmaf(s_dl[r * AM + a], w[a], s);
-      const float sv = s_dv[r] * wvf;
-      dr[(size_t)r * F] = (s + sv) * act_grad(x, p.act_prev);
+    for (int u = 0; u < kVtRows; ++u) {
+      const int r = r0 + u < T ? r0 + u : T - 1;
+      x[u] = fr[(size_t)r * F];
+    }
+#pragma unroll
+    for (int u = 0; u < kVtRows; ++u) {
+      const int r = r0 + u;
+      if (r < T) {
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < AM; ++a)
+          if (a < A) s = fmaf(s_dl[r * AM + a], w[a], s);
+        const float sv = s_dv[r] * wvf;
+        dr[(size_t)r * F] = (s + sv) * act_grad(x[u], p.act_prev);
+      }
     }
   }
 }
 
 int launch_impala_vtrace_bwd(const ImpalaLossArgs& a, int n_traj, hipStream_t st) {
   if (a.T > 256 || a.A > 32 || n_traj < 1) return -1;
-  if (a.A <= 8) hipLaunchKernelGGL((impala_vtrace_bwd_kernel<8>), dim3(n_traj), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((impala_vtrace_bwd_kernel<32>), dim3(n_traj), dim3(256), 0, st, a);
+  const dim3 grid(n_traj, (a.T + kVtRows - 1) / kVtRows);
+  if (a.A <= 8) hipLaunchKernelGGL((impala_vtrace_bwd_kernel<8>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((impala_vtrace_bwd_kernel<32>), grid, dim3(256), 0, st, a);
   XT_LAUNCH_CHECK();
   return 0;
 }
