@@ -258,21 +258,45 @@ PEAK = {"fp32": FP32_MFMA_PEAK_TFLOPS, "bf16x3": BF16_MFMA_PEAK_TFLOPS / 3.0,
         "fp32+bf16x6": 2.0 / (1.0 / FP32_MFMA_PEAK_TFLOPS + 6.0 / BF16_MFMA_PEAK_TFLOPS)}
 
 
-def roofline_of(kern, traffic_json=None, prefix=""):
+# kernel symbol (substring) behind every roofline label, per workload: joins the live timings with the committed
+# rocprofv3 --pmc summaries (profiles/r02_pmc_<workload>.json, tools/profile_round.sh)
+KERNEL_OF = {
+    "ppo": {"L0 shared_conv_layer_0 fwd": "conv_u8c4k8_fwd_flat_kernel", "L0 shared_conv_layer_0 wgrad": "conv_u8c4k8_wgrad_flat_kernel",
+            "L1 shared_conv_layer_1 fwd": "direct_fwd_kernel<1, 1, false, 512>",
+            "L1 shared_conv_layer_1 dgrad+wgrad": "igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, 2, 0>",
+            "L2 shared_conv_layer_2 fwd": "igemm_fwd_kernel<64, 64, 2, 2, false, false, 2>",
+            "L2 shared_conv_layer_2 dgrad+wgrad": "igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1, 0, 2>",
+            "L3 shared_hidden_mlp_0 fwd": "igemm_fwd_kernel<64, 64, 2, 2, false, false, 2>",
+            "L3 shared_hidden_mlp_0 dgrad+wgrad": "igemm_bwd_layer_kernel<64, 64, 2, 2, false, 64, 64, 2, 2, 0, 0>"},
+    "impala": {"L0 explore_agent/conv2d fwd": "igemm_fwd_kernel<128, 32, 4, 1, true, true, 1>",
+               "L0 explore_agent/conv2d wgrad": "igemm_wgrad_kernel<128, 32, 4, 1, true, true>",
+               "L1 explore_agent/conv2d_1 fwd": "direct_fwd_kernel<1, 1, true, 512>",
+               "L1 explore_agent/conv2d_1 dgrad+wgrad": "igemm_bwd_layer_kernel<128, 32, 4, 1, true, 128, 32, 4, 1, 0, 0>",
+               "L2 explore_agent/conv2d_2 fwd": "igemm_fwd_kernel<64, 64, 2, 2, false, false",
+               "L2 explore_agent/conv2d_2 dgrad+wgrad": "igemm_bwd_layer_kernel<64, 64, 2, 2, false, 64, 64, 2, 2, 0, 0>"},
+}
+
+
+def roofline_of(kern, workload="ppo"):
     dom = max(kern, key=lambda k: kern[k][0])
     ms, flops, kind = kern[dom]
     ach = flops / (ms * 1e-3) / 1e12
-    traffic = None
-    if traffic_json and os.path.exists(traffic_json):
+    traffic = mfma_util = None
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_{}.json".format(workload))
+    sym = KERNEL_OF["ppo" if workload == "ppo" else "impala"].get(dom)
+    if sym and os.path.exists(pmc):
         try:
-            tj = json.load(open(traffic_json))
-            row = tj.get("by_label", {}).get(prefix + dom)
-            if row:
-                traffic = (2.0 * row["FETCH_SIZE_KB"] + row["WRITE_SIZE_KB"]) * 1024.0   # gfx950: FETCH_SIZE counts 64 B units as 32
+            for row in json.load(open(pmc)).get("kernels", []):
+                if sym in row["kernel"]:
+                    if row.get("hbm_side_MB") is not None:
+                        traffic = row["hbm_side_MB"] * 1048576.0    # 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction), per launch
+                    mfma_util = row.get("mfma_pipe_util")
+                    break
         except (OSError, ValueError, KeyError):
-            traffic = None
-    return {"bound": "mfma", "kernel": dom, "arith": kind, "achieved": ach, "peak": PEAK[kind], "unit": "TFLOP/s",
-            "frac": ach / PEAK[kind], "traffic": traffic, "flop_per_launch": flops, "avg_launch_ms": ms,
+            traffic = mfma_util = None
+    return {"bound": "mfma", "kernel": dom, "kernel_symbol": sym, "arith": kind, "achieved": ach, "peak": PEAK[kind],
+            "unit": "TFLOP/s", "frac": ach / PEAK[kind], "traffic": traffic, "mfma_pipe_util_pmc": mfma_util,
+            "flop_per_launch": flops, "avg_launch_ms": ms,
             "kernels_us": {k: round(v[0] * 1e3, 2) for k, v in kern.items()},
             "sum_layer_kernels_us": round(sum(v[0] for v in kern.values()) * 1e3, 1)}
 
@@ -360,7 +384,7 @@ def bench_impala(key, steps, warmup, with_cpu):
     assert torch.isfinite(net.params).all()
     us_per_train = 1e6 * el / (steps * trains)
     kern = layer_rooflines(net, spec, f, dobs, None, x6=True)
-    roof = roofline_of(kern, os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"), prefix=key + ": ")
+    roof = roofline_of(kern, key)
     out = {"workload": w["name"], "metric": "learner env-frames/sec", "unit": "env-frames/s", "dtype": "fp32",
            "value": FRAME_SKIP * n * steps / el, "us_per_train": us_per_train, "frames_per_train": f,
            "trains_per_step": trains, "steps": steps,
@@ -591,7 +615,7 @@ def main():
     net, d_obs, d_perm = keep["net"], keep["d_obs"], keep["d_perm"]
     idx = d_perm[0, :bsz].contiguous()
     kern = layer_rooflines(net, spec, bsz, d_obs, idx, x6=True)
-    out["roofline"] = roofline_of(kern, os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"), prefix="ppo: ")
+    out["roofline"] = roofline_of(kern, "ppo")
     if not args.quick:
         # sustained: the same loop for >= 2 s (the K-step region above is ~0.16 s at K=20)
         one_update = keep["one_update"]

@@ -42,6 +42,39 @@ const char* xt_last_error(void);
 /* name of the gfx target the device code was compiled for ("gfx950") */
 const char* xt_build_arch(void);
 
+/* --------------------------------------------------------------- tuning */
+/* Process-wide kernel-selection knobs (ABI >= 6).  The defaults (xt_tuning_get on a fresh process) are the forms
+ * that measured fastest on MI355X for the BASELINE.json shapes; the alternatives are kept
+ * for A/B measurements (tools/) and as fallbacks.  Set them BEFORE creating networks: captured hipGraphs and the
+ * split counts cached in a net are not revisited.  Every form computes the same arithmetic up to fp32 summation
+ * order; `bf16x6 = 0` / `conv1_bf16x3 = 0` select plain fp32 MFMA. */
+typedef struct xt_tuning {
+  int32_t bf16x6;             /* 1: conv input gradients as six bf16 MFMAs per 16-deep chunk (exact split)      */
+  int32_t dgrad_all_classes;  /* 1: stride-2 VALID conv: all four parity classes of a position tile per block   */
+  int32_t dgrad_tile64;       /* 1: stride-1 register-direct input gradient with 64-row tiles                   */
+  int32_t dgrad_halo;         /* 1: ... with the dY halo of the tile staged in LDS                              */
+  int32_t bwd_own_instance;   /* 1: halo input gradient in its own kernel instance (3 workgroups per CU)        */
+  int32_t bwd_fit_slots;      /* co-resident workgroup slots a fused backward launch is cut to (0 = off)        */
+  int32_t conv1_bf16x3;       /* 1: uint8 first layer on the bf16 matrix cores (exact three-way split)          */
+  int32_t conv1_flat;         /* 1: first layer over the flattened position range (512-position workgroups)     */
+  int32_t conv1_waves;        /* 8 | 4 waves per first-layer workgroup                                          */
+  int32_t fwd_two_groups;     /* 1: two wave groups per forward block when the launch cannot fill the chip      */
+  int32_t direct;             /* 1: register-direct kernels (xt_direct.hip) where they measured faster          */
+  int32_t direct_fwd;         /* 1: ... for forwards                                                            */
+  int32_t direct_dgrad;       /* 1: ... for input gradients                                                     */
+  int32_t direct_all;         /* 1: ... for every shape inside their envelope (experiments)                     */
+  int32_t direct_waves;       /* resident-wave target of a register-direct launch                               */
+  int32_t direct_max_waves;   /* waves per register-direct workgroup (<= 8)                                     */
+  int32_t direct_tile64_tiles;/* tile count from which the register-direct input gradient uses 64-row tiles     */
+  int32_t fwd_split_target;   /* split-K forward: target block count                                            */
+  int32_t wgrad_split_target; /* split-M weight gradient: target block count                                    */
+  int32_t reduce_z_lanes;     /* gradient reduction: slab lanes per block (power of two <= 32)                  */
+  int32_t defer_splitk;       /* 1: the fused head kernel finishes the last trunk layer's split-K partials      */
+  int32_t finalize_ticket;    /* 1: last-block finalize of the norm instead of the clip factor inside Adam      */
+} xt_tuning;
+int xt_tuning_get(xt_tuning* out);
+int xt_tuning_set(const xt_tuning* in);
+
 /* ------------------------------------------------------------- geometry */
 /* One Conv2D / Dense layer as an implicit GEMM  Y[M,N] = act(im2col(X)[M,K] . W[K,N] + b).
  * Dense: H=W=KH=KW=S=1, C=in features.  pad_top/pad_left are TensorFlow's

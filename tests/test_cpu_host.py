@@ -31,6 +31,30 @@ def test_cabi_library_loads_and_exports_every_header_symbol():
     assert handle.xt_build_arch() == b"gfx950"
 
 
+def test_tuning_struct_replaces_the_environment_switches():
+    """Kernel-selection knobs live in ONE struct on the C ABI (xt_tuning_get / xt_tuning_set), defaults = the
+    measured-best forms; the shipped library reads no environment variable."""
+    from xingtian_amd import lib
+    t = lib.get_tuning()
+    assert t["bf16x6"] == 1 and t["conv1_bf16x3"] == 1 and t["conv1_waves"] == 8 and t["bwd_fit_slots"] == 768
+    assert t["fwd_split_target"] == 256 and t["wgrad_split_target"] == 512 and t["finalize_ticket"] == 0
+    old = lib.set_tuning(bf16x6=0, direct_waves=1024)
+    try:
+        assert old == {"bf16x6": 1, "direct_waves": 1536}
+        t2 = lib.get_tuning()
+        assert t2["bf16x6"] == 0 and t2["direct_waves"] == 1024 and t2["conv1_flat"] == t["conv1_flat"]
+        with pytest.raises(RuntimeError, match="conv1_waves"):
+            lib.set_tuning(conv1_waves=5)
+        with pytest.raises(KeyError):
+            lib.set_tuning(no_such_knob=1)
+    finally:
+        lib.set_tuning(**old)
+    assert lib.get_tuning() == t
+    for f in os.listdir(os.path.join(ROOT, "xingtian_amd", "csrc")):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(ROOT, "xingtian_amd", "csrc", f)).read(), f
+
+
 def test_product_path_fails_loudly_without_gpu():
     """The LEARNER (model_info type 'learner', xt/framework/learner.py:544) has no CPU fallback; a model built in an
     explorer / evaluator process (no GPU visible, no 'type') is the inference-only numpy replica: it predicts and
@@ -585,3 +609,92 @@ def test_ppo_cnn_netspec_rejects_unknown_input_dtype():
     from xingtian_amd.model import netspec
     with pytest.raises(ValueError):
         netspec.ppo_cnn((84, 84, 4), 4, (256,), "relu", True, input_dtype="uint16")
+
+
+# ---------------------------------------------------------------------------------------------- transport (f1)
+def _ppo_message(rng, t=16):
+    return {"cur_state": rng.integers(0, 256, (t, 84, 84, 4)).astype(np.uint8), "action": rng.integers(0, 4, t).astype(np.int32),
+            "logp": rng.standard_normal((t, 1)).astype(np.float32), "adv": rng.standard_normal((t, 1)),
+            "old_value": rng.standard_normal((t, 1)).astype(np.float32), "target_value": rng.standard_normal((t, 1)),
+            "reward": [float(x) for x in rng.choice([-1.0, 0.0, 1.0], t)], "done": [bool(x) for x in rng.random(t) < 0.1],
+            "info": [{"real_done": bool(i % 3 == 0), "eval_reward": float(i)} for i in range(t)]}
+
+
+def test_transport_codec_round_trips_the_reference_payloads():
+    """The wire payloads of the learner path (SURVEY 8b ``train_data``; the weights dict of get_weights) through
+    xingtian_amd.transport: dtypes, shapes, field order, python lists (reward / done / info) and numpy scalars survive;
+    arrays come back as zero-copy views into the message buffer."""
+    from collections import OrderedDict
+    from xingtian_amd import transport
+    rng = np.random.default_rng(0)
+    msg = _ppo_message(rng)
+    ctr = {"cmd": "train", "broker_id": 0, "explorer_id": 3, "agent_id": -1}
+    buf = transport.encode(ctr, msg)
+    ctr2, out = transport.decode(buf)
+    assert ctr2 == ctr and list(out) == list(msg)
+    for k, v in msg.items():
+        if isinstance(v, np.ndarray):
+            assert out[k].dtype == v.dtype and out[k].shape == v.shape and np.array_equal(out[k], v)
+            assert not out[k].flags.owndata                      # a view into buf, not a copy
+        else:
+            assert out[k] == v
+    imp = {"cur_state": rng.integers(0, 256, (250, 42, 42, 4)).astype(np.uint8), "logit": rng.standard_normal((250, 6)).astype(np.float32),
+           "action": rng.integers(0, 6, 250).astype(np.int32), "reward": list(rng.choice([-1.0, 0.0, 1.0], 250)),
+           "done": list(rng.random(250) < 0.1), "info": [{} for _ in range(250)]}
+    _, out = transport.decode(transport.encode({"cmd": "train"}, imp))
+    assert out["done"] == [bool(x) for x in imp["done"]] and out["reward"] == [float(x) for x in imp["reward"]]
+    assert np.array_equal(out["logit"], imp["logit"])
+    weights = OrderedDict((("shared_conv_layer_0/kernel", rng.standard_normal((8, 8, 4, 32)).astype(np.float32)),
+                           ("shared_conv_layer_0/bias", np.zeros(32, np.float32)), ("pi_latent/kernel", np.zeros((256, 4), np.float32))))
+    _, w2 = transport.decode(transport.encode({"cmd": "explore"}, weights))
+    assert list(w2) == list(weights) and all(np.array_equal(w2[k], weights[k]) for k in weights)
+    with pytest.raises(ValueError):
+        transport.decode(b"nope" + bytes(60))
+    seen = []
+    transport.decode_into(buf, lambda data, ctr_info=None: seen.append((ctr_info["cmd"], data["cur_state"].sum())))
+    assert seen == [("train", msg["cur_state"].sum())]
+
+
+def _ring_producer(name, n_msgs, seed):
+    from xingtian_amd import transport
+    ring = transport.ShmRing(name=name, create=False, slots=4, slot_bytes=4 << 20)
+    rng = np.random.default_rng(seed)
+    for i in range(n_msgs):
+        assert ring.send({"cmd": "train", "seq": i}, _ppo_message(rng), timeout=30.0)
+    ring.close()
+
+
+def test_shared_memory_ring_carries_rollouts_between_processes():
+    """ShmRing (the plasma-free intra-node channel): a producer PROCESS pushes 12 trajectories of 16 x 84x84x4 frames
+    through a 4-slot ring (it wraps three times and blocks when full); the consumer receives them in order, bit for
+    bit, half of them zero-copy (recv_into) and half as copies (recv)."""
+    from xingtian_amd import transport
+    ring = transport.ShmRing(slots=4, slot_bytes=4 << 20)
+    ctx = mp.get_context("spawn")
+    proc = ctx.Process(target=_ring_producer, args=(ring.name, 12, 5))
+    proc.start()
+    try:
+        rng = np.random.default_rng(5)
+        for i in range(12):
+            want = _ppo_message(rng)
+            if i % 2:
+                got = ring.recv(timeout=60.0)
+                assert got is not None
+                ctr, data = got
+                assert data["cur_state"].flags.owndata or data["cur_state"].base is not None
+            else:
+                box = {}
+                ctr = ring.recv_into(lambda d, ctr_info=None: box.update({k: (v.copy() if isinstance(v, np.ndarray) else v)
+                                                                           for k, v in d.items()}), timeout=60.0)
+                assert ctr is not None
+                data = box
+            assert ctr == {"cmd": "train", "seq": i}
+            for k, v in want.items():
+                assert np.array_equal(data[k], v) if isinstance(v, np.ndarray) else data[k] == v, (i, k)
+        assert ring.pending() == 0 and ring.recv(block=False) is None
+        proc.join(30)
+        assert proc.exitcode == 0
+    finally:
+        if proc.is_alive():
+            proc.terminate()
+        ring.close()

@@ -359,9 +359,9 @@ def test_gae_on_learner_path_through_algorithm():
     from oracle import returns
     from xingtian_amd.algorithm import alg_builder
     model_info = {"actor": {"model_name": "PpoMlp", "state_dim": [4], "action_dim": 2, "input_dtype": "float32",
-                            "model_config": {"BATCH_SIZE": 50, "NUM_SGD_ITER": 1, "SEED": 0,
-                                             "action_type": "Categorical"}}}
-    alg = alg_builder("PPO", model_info, {"instance_num": 1, "agent_num": 1})
+                            "model_config": {"BATCH_SIZE": 50, "NUM_SGD_ITER": 1, "SEED": 0, "STREAM_INGEST": False,
+                                             "action_type": "Categorical"}}}     # not streamed: the per-field lists
+    alg = alg_builder("PPO", model_info, {"instance_num": 1, "agent_num": 1})    # of the reference keep the arrays
     rng = np.random.default_rng(6)
     t = 50
     value = rng.standard_normal((t + 1, 1)).astype(np.float32)
@@ -920,3 +920,71 @@ def test_impala_opt_streaming_ingest_is_bitwise_the_upload_path():
         for k in w0:
             assert np.array_equal(w0[k], w1[k]), (it, k)
     assert algs[0].actor._global_step == algs[1].actor._global_step == 8      # 60 frames = chunks of 40 + 20, 4 trains
+
+
+def test_tuning_fp32_mfma_forms_are_selectable_and_closer_to_the_oracle():
+    """xt_tuning.bf16x6 = 0 / conv1_bf16x3 = 0 route the conv input gradients and the first layer to plain fp32 MFMA
+    (the A/B forms behind INTEGRATION.md section 5's numerics statement): different bits, both inside the 1e-5 bar."""
+    from xingtian_amd import lib as L
+    rng = np.random.default_rng(0)
+    errs = {}
+    for name, knobs in (("default", {}), ("fp32", dict(bf16x6=0, conv1_bf16x3=0))):
+        old = L.set_tuning(**knobs)
+        try:
+            net, ospec, sd, u8 = _mk("cnn84", 96)
+            params = oracle_params_for(net, ospec, seed=7)
+            if name == "default":
+                obs, lab = synth_ppo_rollout(rng, 96, sd, 4, u8)
+                cfg = dict(PPO_CFG, BATCH_SIZE=96)
+                out = nets.PpoLearnerOracle(ospec, params, cfg, np.float64).step(
+                    obs, lab[0], lab[1].astype(np.float32), lab[2].astype(np.float32), lab[3].astype(np.float32),
+                    lab[4].astype(np.float32), apply=False)
+            d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+            net.ppo_step(net.make_ppo_cfg(cfg), net.to_device_obs(obs), None, d(lab[0]), d(lab[1].reshape(-1)),
+                         d(lab[2].reshape(-1)), d(lab[3].reshape(-1)), d(lab[4].reshape(-1)), apply=False)
+            torch.cuda.synchronize()
+            g = net.grads_dict()
+            errs[name] = {k: rel_err(g[k].reshape(r.shape), r) for k, r in out["grads"].items()}
+            errs[name + "_bits"] = net.grads.cpu().numpy().copy()
+        finally:
+            L.set_tuning(**old)
+    assert max(errs["default"].values()) < 1e-5 and max(errs["fp32"].values()) < 1e-5, errs
+    assert not np.array_equal(errs["default_bits"], errs["fp32_bits"])
+
+
+def test_rollouts_through_the_transport_ring_feed_the_ingest_bit_identically():
+    """SURVEY 8(f1) end to end: trajectories encoded by xingtian_amd.transport, carried by a ShmRing and handed to
+    ``PPO.prepare_data`` as zero-copy views (wire -> pinned staging -> HBM, one host copy) give the same update, bit
+    for bit, as the dicts handed over directly."""
+    from xingtian_amd import transport
+    from xingtian_amd.algorithm import alg_builder
+    model_info = {"actor": {"model_name": "PpoCnn", "state_dim": [84, 84, 4], "action_dim": 4, "input_dtype": "uint8",
+                            "model_config": {"BATCH_SIZE": 64, "NUM_SGD_ITER": 2, "hidden_sizes": [256],
+                                             "VF_SHARE_LAYERS": True, "activation": "relu", "SEED": 4}}}
+    rng = np.random.default_rng(33)
+    trajs = []
+    for _ in range(4):
+        obs, lab = synth_ppo_rollout(rng, 32, (84, 84, 4), 4)
+        trajs.append({"cur_state": obs, "action": lab[0], "logp": lab[1], "adv": lab[2], "old_value": lab[3],
+                      "target_value": lab[4], "reward": [0.0] * 32, "done": [False] * 32, "info": [{}] * 32})
+    perms = np.stack([rng.permutation(128) for _ in range(2)]).astype(np.int32)
+    results = []
+    for via_ring in (False, True):
+        alg = alg_builder("PPO", model_info, {"instance_num": 4, "agent_num": 1})
+        if via_ring:
+            ring = transport.ShmRing(slots=4, slot_bytes=2 << 20)
+            try:
+                for i, tr in enumerate(trajs):
+                    assert ring.send({"cmd": "train", "explorer_id": i}, tr)
+                for _ in trajs:
+                    assert ring.recv_into(alg.prepare_data)["cmd"] == "train"
+            finally:
+                ring.close()
+        else:
+            for tr in trajs:
+                alg.prepare_data(tr)
+        loss = alg.train(perms=perms)
+        results.append((loss, alg.get_weights()))
+    assert results[0][0] == results[1][0]
+    for k in results[0][1]:
+        assert np.array_equal(results[0][1][k], results[1][1][k]), k

@@ -1,14 +1,26 @@
 #!/bin/bash
-# One GPU-box call that refreshes the judged profile artifacts (run from the repo root on the GPU box):
-#   gpurun_out/prof_stats  rocprofv3 --kernel-trace --stats of `python bench.py`
-#   gpurun_out/pmc_fetch, gpurun_out/pmc_write  separate --pmc passes over tools/layer_bench.py
-#   gpurun_out/bench.json  the bench line
+# One GPU-box call that refreshes the judged profile artifacts (run from the repo root on the GPU box).  Counter
+# passes are separate rocprofv3 runs with --pmc only (no trace domains), as MI355X_MICROARCH.md prescribes.
+#   gpurun_out/<tag>_bench.json                 the default `python bench.py` line
+#   gpurun_out/<tag>_kernel_stats_<workload>.csv rocprofv3 --kernel-trace --stats of bench.py --quick (in-graph averages)
+#   gpurun_out/<tag>_pmc_<workload>.json         tools/pmc_summary.py of three --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*) over
+#                                                tools/step_probe.py <workload> (eager updates: every kernel of a step)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${1:-r02}
+mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py > $R/gpurun_out/bench.json 2> $R/gpurun_out/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $R/gpurun_out/bench_prof.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -- python $R/tools/layer_bench.py fused > $R/gpurun_out/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -- python $R/tools/layer_bench.py fused > $R/gpurun_out/pmc_write.log 2>&1
-cd $R && python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_traffic.json | tail -20
-find gpurun_out/prof_stats -name "*kernel_stats.csv" | head -2
-tail -1 gpurun_out/bench.json | cut -c1-200
+python $R/bench.py > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err
+for W in ppo breakout_impala pong_impala_speedup; do
+  rm -rf /tmp/ks; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $R/bench.py --workload $W --steps 8 --warmup 2 --no-cpu-baseline --quick > /tmp/ks.log 2>&1
+  cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $R/gpurun_out/${TAG}_kernel_stats_$W.csv
+done
+for W in ppo breakout_impala pong_impala_speedup; do
+  for P in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+    set -- $P; name=$1; shift
+    rm -rf /tmp/pmc_${W}_$name
+    rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_${W}_$name -- python $R/tools/step_probe.py $W > /tmp/pmc_${W}_$name.log 2>&1
+  done
+  (cd $R && python tools/pmc_summary.py /tmp/pmc_${W}_fetch /tmp/pmc_${W}_write /tmp/pmc_${W}_sq gpurun_out/${TAG}_pmc_$W.json gpurun_out/${TAG}_kernel_stats_$W.csv | tail -16)
+done
+cd $R
+tail -1 gpurun_out/${TAG}_bench.json | cut -c1-300

@@ -44,6 +44,8 @@ class IMPALAOpt(Algorithm):
         if getattr(self.actor, "stream_ingest", False) and hasattr(self.actor, "ingest_message"):
             self.actor.ingest_message(*fields)            # pinned staging + async H2D start now
             self._streamed += 1
+            self._rollout.add(**{k: None for k in self.FIELDS})   # no reference kept: the arrays may be transport views
+            return
         self._rollout.add(**dict(zip(self.FIELDS, fields)))
 
     def train(self, **kwargs):
@@ -52,7 +54,7 @@ class IMPALAOpt(Algorithm):
             loss = self.actor.train_ingested(BATCH_SIZE)
         else:
             if self._streamed:
-                self.actor._ingest.reset()
+                raise RuntimeError("IMPALAOpt.train: the rollout was only partly streamed to the device")
             states, *labels = self._rollout.stacked()
             losses = []
             for lo in range(0, len(states), BATCH_SIZE):

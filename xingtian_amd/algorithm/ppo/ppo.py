@@ -52,6 +52,10 @@ class PPO(Algorithm):
         if getattr(self.actor, "stream_ingest", False) and hasattr(self.actor, "ingest_trajectory"):
             self.actor.ingest_trajectory(train_data)          # H2D copy starts now
             self._streamed += 1
+            # the staging buffers hold the copy: keep no reference to the arriving arrays (they may be zero-copy views
+            # into a transport slot that is recycled as soon as this call returns, xingtian_amd/transport.py)
+            self._rollout.add(**{k: None for k in self.FIELDS})
+            return
         self._rollout.add(**{k: train_data[k] for k in self.FIELDS})
 
     def train(self, **kwargs):
@@ -64,7 +68,7 @@ class PPO(Algorithm):
             loss = self.actor.train_ingested(perms=perms)
         else:
             if self._streamed:
-                self.actor._ingest.reset()
+                raise RuntimeError("PPO.train: the rollout was only partly streamed to the device")
             obs, *labels = self._rollout.stacked()
             loss = self.actor.train([obs], labels, perms=perms)
         self._forget_rollout()

@@ -333,11 +333,7 @@ __global__ __launch_bounds__(512, 2) void conv_u8c4k8_fwd_flat_kernel(const C1Fw
   XT_TL_DRAIN(5);
 }
 
-static int c1_waves() {      // XT_C1_WAVES=4: the four-wave forms (A/B switch)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("XT_C1_WAVES"); v = (e && e[0] == '4') ? 4 : 8; }
-  return v;
-}
+static int c1_waves() { return tuning().conv1_waves == 4 ? 4 : 8; }      // 4: the four-wave forms (A/B)
 
 // returns 0 launched, 1 error, -1 geometry not handled by this kernel
 int launch_conv1_fwd_bf16x3(const xt_conv_geom* g, const xt_input_xform* xf, int B, const void* in,
@@ -357,8 +353,7 @@ int launch_conv1_fwd_bf16x3(const xt_conv_geom* g, const xt_input_xform* xf, int
   size_t lds = (size_t)2 * g->KH * 3 * 64 * 16;                    // weight planes, reused by the output transpose
   if (lds < (size_t)nw * 32 * 36 * 4) lds = (size_t)nw * 32 * 36 * 4;
   lds += (size_t)HWC;
-  static int flat = -1;          // XT_C1_FLAT=0: one frame stack per workgroup (A/B switch)
-  if (flat < 0) { const char* e = getenv("XT_C1_FLAT"); flat = (e && e[0] == '0') ? 0 : 1; }
+  const int flat = tuning().conv1_flat;     // 0: one frame stack per workgroup (A/B)
   if (flat && nw == 8 && g->KH == 8) {
     const int total = B * g->OH * g->OW;
     const bool two = (total + 511) / 512 >= 200;
@@ -696,8 +691,7 @@ int launch_conv1_wgrad_bf16x3(const xt_conv_geom* g, const xt_input_xform* xf, i
   if ((size_t)nsteps * 16 * 4 < 64 * 4) return -1;                              // `bred` aliases pixoff
   if (lds > 81920) return -1;                                                    // two workgroups per CU
   {
-    static int flat = -1;          // XT_C1_FLAT=0: one frame stack per workgroup (A/B switch)
-    if (flat < 0) { const char* e = getenv("XT_C1_FLAT"); flat = (e && e[0] == '0') ? 0 : 1; }
+    const int flat = tuning().conv1_flat;
     const int total = B * g->OH * g->OW, nblk = (total + 511) / 512;
     const size_t fl = (size_t)3 * HWC + (size_t)512 * 32 * 4 + (size_t)512 * 4;
     if (flat && c1_waves() == 8 && nblk >= 200 && nblk <= max_slabs && 511 / (g->OH * g->OW) + 2 <= 3 &&

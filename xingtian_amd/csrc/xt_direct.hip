@@ -201,33 +201,15 @@ __global__ __launch_bounds__(64 * NW) void direct_dgrad_kernel(const DDgradArgs 
 XT_TL_SETTER(direct)
 
 // ------------------------------------------------------------------ host side
-static int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return (e && e[0]) ? atoi(e) : dflt;
-}
-static bool use_direct() {
-  static int v = -1;
-  if (v < 0) v = env_int("XT_NO_DIRECT", 0) ? 0 : 1;
-  return v == 1;
-}
-// Resident-wave target of one launch.  Measured on MI355X (gpurun_out/sweep1.log, profiles/r01_timeline.txt): the
+static bool use_direct() { return tuning().direct != 0; }
+// Resident-wave target of one launch.  Measured on MI355X (profiles/r01_direct_sweep.txt, r01_timeline.txt): the
 // register-direct kernels are bounded by the L2->L1 fill rate (~25 B/clk/CU for row-gathered dwordx4), not by
 // latency, so FEW LONG waves (1-2 per SIMD, each streaming its whole reduction slice) beat many short ones.
-static int want_waves() {
-  static int v = -1;
-  if (v < 0) v = env_int("XT_DIRECT_WAVES", 1536);
-  return v;
-}
-// XT_DIRECT_ALL=1 routes every shape inside the envelope to the direct kernels (experiments); by default only
+static int want_waves() { return tuning().direct_waves; }
+// direct_all routes every shape inside the envelope to the direct kernels (experiments); by default only
 // the shapes that measured faster than the LDS-tiled kernels are: single-column tiles (N or C not a multiple of
 // 64, where the LDS tile cannot share the A operand between column tiles anyway) with a long reduction.
-static bool direct_all() {
-  static int v = -1;
-  if (v < 0) v = env_int("XT_DIRECT_ALL", 0);
-  return v == 1;
-}
-
-static bool env_off(const char* name) { const char* e = getenv(name); return e && e[0] == '1'; }
+static bool direct_all() { return tuning().direct_all != 0; }
 
 static bool direct_envelope(const Geom& g, const xt_input_xform* xf) {
   if (xf && (xf->is_u8 || fabsf(g.xs - 1.f) > 0.f || fabsf(g.xb) > 0.f)) return false;
@@ -238,7 +220,7 @@ static bool direct_envelope(const Geom& g, const xt_input_xform* xf) {
 int launch_fwd_direct(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const void* in, const int32_t* idx,
                       const float* w, const float* bias, float* y, float* partial, int ksplit_max, hipStream_t st,
                       int* ksplit_out) {
-  if (!use_direct() || idx || env_off("XT_NO_DIRECT_FWD")) return -1;
+  if (!use_direct() || idx || !tuning().direct_fwd) return -1;
   DFwdArgs a;
   if (make_geom(cg, xf, B, &a.g)) return -1;
   const Geom& g = a.g;
@@ -252,7 +234,7 @@ int launch_fwd_direct(const xt_conv_geom* cg, const xt_input_xform* xf, int B, c
   // reduction slices: enough waves to fill the chip, each with >= 2 steps
   int slices = (want_waves() + tiles - 1) / tiles;
   slices = max(1, min(slices, a.nsteps / 2));
-  int nw = min(slices, env_int("XT_DIRECT_MAXNW", 8));
+  int nw = min(slices, tuning().direct_max_waves);
   int ks = (slices + nw - 1) / nw;
   if (!partial || ksplit_max < 1) ksplit_max = 1;
   ks = max(1, min(ks, ksplit_max));
@@ -279,7 +261,7 @@ int launch_fwd_direct(const xt_conv_geom* cg, const xt_input_xform* xf, int B, c
 // Plan for the fused per-layer backward launch (256-thread blocks -> NW = 4, one 32x32 tile per block): only the
 // shapes where the direct kernel measured faster (single-column tiles, long reduction, not too many tiles).
 bool plan_dgrad_direct_fused(const Geom& g, DDgradArgs* a, int* nblocks) {
-  if (!use_direct() || env_off("XT_NO_DIRECT_DGRAD") || g.N % 32 != 0 || g.C % 32 != 0) return false;
+  if (!use_direct() || !tuning().direct_dgrad || g.N % 32 != 0 || g.C % 32 != 0) return false;
   if (g.C % 64 == 0) return false;                       // TJ = 2 shapes stay on the LDS-tiled kernel
   const int hc = (g.H + g.S - 1) / g.S, wc = (g.W + g.S - 1) / g.S;
   const int mc = g.B * hc * wc;
@@ -287,7 +269,7 @@ bool plan_dgrad_direct_fused(const Geom& g, DDgradArgs* a, int* nblocks) {
   const int jmax = ((g.KH + g.S - 1) / g.S) * ((g.KW + g.S - 1) / g.S);
   const int nsteps = jmax * (g.N / 32);
   const int tiles = ((mc + 31) / 32) * (g.C / 32) * nclass;
-  if (!direct_all() && (nsteps < 8 || tiles >= env_int("XT_DIRECT_TI2_TILES", 3072))) return false;
+  if (!direct_all() && (nsteps < 8 || tiles >= tuning().direct_tile64_tiles)) return false;
   a->g = g;
   a->mt = (mc + 31) / 32;
   a->ct = g.C / 32;
@@ -310,7 +292,7 @@ int launch_dgrad_direct(const xt_conv_geom* cg, int B, const float* dy, const fl
   const int jmax = ((g.KH + g.S - 1) / g.S) * ((g.KW + g.S - 1) / g.S);
   const int nsteps = jmax * (g.N / 32);
   const int tiles1 = ((mc + 31) / 32) * (g.C / (32 * TJ)) * nclass;
-  const int TI = (tiles1 >= env_int("XT_DIRECT_TI2_TILES", 3072)) ? 2 : 1;
+  const int TI = (tiles1 >= tuning().direct_tile64_tiles) ? 2 : 1;
   if (!direct_all() && (TJ != 1 || TI != 1 || nsteps < 8)) return -1;
   a.mt = (mc + 32 * TI - 1) / (32 * TI);
   a.ct = g.C / (32 * TJ);

@@ -994,17 +994,8 @@ int launch_dgrad_direct(const xt_conv_geom*, int, const float*, const float*, co
 int launch_fwd_direct(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*, const float*,
                       const float*, float*, float*, int, hipStream_t, int*);
 
-static bool use_kg2() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("XT_NO_KG2"); v = (e && e[0] == '1') ? 0 : 1; }
-  return v == 1;
-}
-
-static bool use_bf16x3() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("XT_NO_BF16X3"); v = (e && e[0] == '1') ? 0 : 1; }
-  return v == 1;
-}
+static bool use_kg2() { return tuning().fwd_two_groups != 0; }
+static bool use_bf16x3() { return tuning().conv1_bf16x3 != 0; }
 
 static int fill_class_divs(const Geom& g, DgradArgs* a) {
   XT_REQUIRE(g.S * g.S <= kMaxClasses, "igemm dgrad: stride %d not supported (max 4)", g.S);
@@ -1179,8 +1170,7 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
   a.n_dg = a.dg_gx * a.dg_gy * a.dg_gz;
   a.dg_direct = 0;
   {
-    static int no_d4 = -1;
-    if (no_d4 < 0) { const char* e = getenv("XT_NO_DGRAD4"); no_d4 = (e && e[0] == '1') ? 1 : 0; }
+    const int no_d4 = tuning().dgrad_all_classes ? 0 : 1;
     if (!no_d4 && g.S == 2 && g.KH % 2 == 0 && g.KW % 2 == 0 && g.H % 2 == 0 && g.W % 2 == 0 && g.PT == 0 &&
         g.PL == 0 && g.C == 32 && g.N == 32 && (g.OH - 1) * g.S + g.KH <= g.H && (g.OW - 1) * g.S + g.KW <= g.W) {
       a.dg_direct = 2;
@@ -1193,15 +1183,13 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
       a.ddg.dy = dy; a.ddg.w = w; a.ddg.x = x_in; a.ddg.dx = dx; a.ddg.act_prev = act_prev;
       a.dg_direct = 1;
       a.n_dg = nblk;
-      static int ti2 = -1;               // XT_DGRAD_TI2=0: 32-row tiles (A/B; measured 30.4 vs 27.7 us for conv3 at B=320)
-      if (ti2 < 0) { const char* e = getenv("XT_DGRAD_TI2"); ti2 = (e && e[0] == '0') ? 0 : 1; }
+      const int ti2 = tuning().dgrad_tile64;   // 0: 32-row tiles (A/B; measured 30.4 vs 27.7 us for conv3 at B=320)
       if (ti2 && g.S == 1 && nblk > 512) { // 64-row tiles: half the blocks, the weight operand shared by two row tiles
         const int mc = B * g.H * g.W;
         a.ddg.mt = (mc + 63) / 64;
         a.n_dg = a.ddg.mt * a.ddg.ct;
         a.dg_direct = 3;
-        static int halo = -1;            // XT_DGRAD_HALO=0: register-direct dY gather instead of the LDS halo (A/B)
-        if (halo < 0) { const char* e = getenv("XT_DGRAD_HALO"); halo = (e && e[0] == '0') ? 0 : 1; }
+        const int halo = tuning().dgrad_halo;   // 0: register-direct dY gather instead of the LDS halo (A/B)
         const int nsamp = 63 / (g.H * g.W) + 2;
         if (halo && (size_t)(nsamp * g.OHOW + 1) * (g.N + 4) * 4 <= 36 * 1024 && g.N + 4 <= 256) a.dg_direct = 4;
       }
@@ -1211,15 +1199,13 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
   a.n_hw = 0;
   if (hw) { a.hw = *hw; a.n_hw = hw->gx * hw->nchunk; }
   else { a.hw.gx = 1; a.hw.nchunk = 0; }
-  // The halo input gradient has its own kernel instance (XT_BWD_SPEC=0: the generic one): three workgroups per CU
+  // The halo input gradient has its own kernel instance (tuning.bwd_own_instance = 0: the generic one): three workgroups per CU
   // instead of two.  With it, a launch that is only a little larger than the 768 co-resident workgroups is cut to
-  // one round (XT_BWD_FIT=<slots>, 0 = off): the surplus weight-gradient blocks otherwise start when the first
+  // one round (tuning.bwd_fit_slots, 0 = off): the surplus weight-gradient blocks otherwise start when the first
   // input-gradient blocks END and the launch takes two block lifetimes.  Measured for conv3 at B=320: generic 26.3,
   // own instance 24.4, own instance + one round 22.6 us (with the register-direct dY gather both made it SLOWER:
   // a third co-resident workgroup thrashed the L1 that gather depends on).
-  static int spec = -1, fit = -1;
-  if (spec < 0) { const char* e = getenv("XT_BWD_SPEC"); spec = (e && e[0] == '0') ? 0 : 1; }
-  if (fit < 0) { const char* e = getenv("XT_BWD_FIT"); fit = e ? atoi(e) : 768; }
+  const int spec = tuning().bwd_own_instance, fit = tuning().bwd_fit_slots;
   const bool halo_inst = a.dg_direct == 4 && spec && !wsmall && !is_padded(g);
   if (halo_inst) {
     const int tiles = a.wg_gx * a.wg_gy;
@@ -1243,8 +1229,7 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
                             dim3(total), dim3(256), 0, st, a);                                                  \
   } while (0)
   if (halo_inst) {
-    static int hx6 = -1;                 // XT_BF16X6=0: fp32 MFMA (A/B)
-    if (hx6 < 0) { const char* e = getenv("XT_BF16X6"); hx6 = (e && e[0] == '0') ? 0 : 1; }
+    const int hx6 = tuning().bf16x6;     // 0: fp32 MFMA (A/B)
     const int nsamp = 63 / (g.H * g.W) + 2;
     if (hx6 && (size_t)3 * (nsamp * g.OHOW + 1) * (g.N * 2 + 16) <= 44 * 1024)
       hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1, 0, 2>), dim3(total), dim3(256), 0, st, a);
@@ -1252,8 +1237,7 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
       hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1, 0, 1>), dim3(total), dim3(256), 0, st, a);
   } else if (a.dg_direct == 2) {
     XT_REQUIRE(wsmall && dsmall && !pad, "bwd_layer: the all-classes input gradient needs the small-tile configuration");
-    static int x6 = -1;                  // XT_BF16X6=0: fp32 MFMA in the all-classes input gradient (A/B)
-    if (x6 < 0) { const char* e = getenv("XT_BF16X6"); x6 = (e && e[0] == '0') ? 0 : 1; }
+    const int x6 = tuning().bf16x6;      // 0: fp32 MFMA in the all-classes input gradient (A/B)
     if (x6) hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, 2>), dim3(total), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, 1>), dim3(total), dim3(256), 0, st, a);
   } else if (wsmall && dsmall) XT_BWD(128, 32, 4, 1, 128, 32, 4, 1);

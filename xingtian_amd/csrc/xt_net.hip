@@ -20,6 +20,16 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+xt_tuning& tuning() {
+  static xt_tuning t = {/*bf16x6*/ 1, /*dgrad_all_classes*/ 1, /*dgrad_tile64*/ 1, /*dgrad_halo*/ 1, /*bwd_own_instance*/ 1,
+                        /*bwd_fit_slots*/ 768, /*conv1_bf16x3*/ 1, /*conv1_flat*/ 1, /*conv1_waves*/ 8,
+                        /*fwd_two_groups*/ 1, /*direct*/ 1, /*direct_fwd*/ 1, /*direct_dgrad*/ 1, /*direct_all*/ 0,
+                        /*direct_waves*/ 1536, /*direct_max_waves*/ 8, /*direct_tile64_tiles*/ 3072,
+                        /*fwd_split_target*/ 256, /*wgrad_split_target*/ 512, /*reduce_z_lanes*/ 8,
+                        /*defer_splitk*/ 1, /*finalize_ticket*/ 0};
+  return t;
+}
+
 int launch_fwd(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*, const float*,
                const float*, float*, float*, int, hipStream_t, int* deferred_ksplit = nullptr);
 int launch_bwd_layer(const xt_conv_geom*, int, const float*, const float*, const float*, int, float*, float*, float*,
@@ -104,8 +114,7 @@ static int fwd_split(const Layer& L, int B) {
   const int ksteps = (L.K + 31) / 32;
   if (tiles >= 128 || ksteps < 4) return 1;
   // note: the fused PPO head kernel finishes at most 16 partial slabs (kMaxHeadSplit)
-  static int target = -1;
-  if (target < 0) { const char* e = getenv("XT_FWD_SPLIT_TARGET"); target = e ? atoi(e) : 256; }   // measured: 256 beats 512/128 (Dense 3136->256: 16.6 vs 20.7 us)
+  const int target = tuning().fwd_split_target;    // measured: 256 beats 512/128 (Dense 3136->256: 16.6 vs 20.7 us)
   int s = target / tiles;
   if (s > ksteps / 2) s = ksteps / 2;
   if (s > 16) s = 16;
@@ -115,8 +124,7 @@ static int wgrad_split(const Layer& L, int B) {
   const int M = B * L.OHOW, N = L.g.N;
   const int tiles = (N <= 32) ? ((L.K + 127) / 128) * ((N + 31) / 32) : ((L.K + 63) / 64) * ((N + 63) / 64);
   const int msteps = (M + 31) / 32;
-  static int wtarget = -1;
-  if (wtarget < 0) { const char* e = getenv("XT_WGRAD_SPLIT_TARGET"); wtarget = e ? atoi(e) : 512; }
+  const int wtarget = tuning().wgrad_split_target;
   int s = wtarget / tiles;
   if (s > msteps / 4) s = msteps / 4;
   return s < 1 ? 1 : s;
@@ -264,8 +272,7 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
   const bool gauss = (n->action_type == XT_ACTION_DIAG_GAUSSIAN);
   const int32_t* action = static_cast<const int32_t*>(action_v);
   bool fused_head = (!gauss && n->A <= 8 && n->feat <= 512);
-  static int no_defer = -1;
-  if (no_defer < 0) { const char* e = getenv("XT_NO_DEFER"); no_defer = (e && e[0] == '1') ? 1 : 0; }
+  const int no_defer = tuning().defer_splitk ? 0 : 1;
   if (int rc = net_forward(n, obs, idx, B, false, st, fused_head && !no_defer)) return rc;
   const float inv_b = 1.f / (float)(c->global_batch > 0 ? c->global_batch : B);
   Layer& Lp = n->layers[n->t_end[0] - 1];
@@ -324,8 +331,7 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
   la.terms = n->ws + n->off_terms; la.B = B; la.ent_coef = c->ent_coef; la.critic_coef = c->critic_coef;
   la.inv_b = inv_b; la.out = lo; la.acc = loss_acc;
   if (apply) {
-    static int tail_mode = -1;     // XT_FIN_TICKET=1: the old "last block finalises" form (A/B)
-    if (tail_mode < 0) { const char* e = getenv("XT_FIN_TICKET"); tail_mode = (e && e[0] == '1') ? 1 : 2; }
+    const int tail_mode = tuning().finalize_ticket ? 1 : 2;     // 1: the old "last block finalises" form (A/B)
     FinalizeArgs fin{};
     fin.enable = tail_mode; fin.counter = reinterpret_cast<unsigned int*>(n->ws + n->off_counter);
     fin.clip_norm = c->max_grad_norm; fin.grad_scale = c->grad_scale; fin.lr = c->lr; fin.beta1 = c->beta1;
@@ -449,6 +455,22 @@ static int impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int n
 extern "C" {
 
 int xt_abi_version(void) { return XT_ABI_VERSION; }
+int xt_tuning_get(xt_tuning* out) {
+  XT_REQUIRE(out, "xt_tuning_get: null argument");
+  *out = xt::tuning();
+  return 0;
+}
+int xt_tuning_set(const xt_tuning* in) {
+  XT_REQUIRE(in, "xt_tuning_set: null argument");
+  XT_REQUIRE(in->conv1_waves == 4 || in->conv1_waves == 8, "xt_tuning_set: conv1_waves must be 4 or 8");
+  XT_REQUIRE(in->direct_max_waves >= 1 && in->direct_max_waves <= 8, "xt_tuning_set: direct_max_waves outside [1,8]");
+  XT_REQUIRE(in->reduce_z_lanes >= 1 && in->reduce_z_lanes <= 32 && (in->reduce_z_lanes & (in->reduce_z_lanes - 1)) == 0,
+             "xt_tuning_set: reduce_z_lanes must be a power of two <= 32");
+  XT_REQUIRE(in->fwd_split_target >= 1 && in->wgrad_split_target >= 1 && in->direct_waves >= 1 && in->bwd_fit_slots >= 0,
+             "xt_tuning_set: block-count targets must be positive");
+  xt::tuning() = *in;
+  return 0;
+}
 const char* xt_last_error(void) { return xt::g_err; }
 const char* xt_build_arch(void) { return "gfx950"; }
 

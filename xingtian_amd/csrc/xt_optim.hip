@@ -399,8 +399,7 @@ int launch_grads_finish(GradTable* tab, float* partial, int max_partials, int* n
   for (int i = 0; i < tab->n; ++i) {
     GradEntry& E = tab->e[i];
     int zl = 1;
-    static int zcap = -1;
-    if (zcap < 0) { const char* e = getenv("XT_ZL_CAP"); zcap = e ? atoi(e) : 8; }
+    const int zcap = tuning().reduce_z_lanes;
     while (zl < E.nslab && zl < zcap) zl <<= 1;   // fewer z lanes = longer contiguous runs per wave (512 B at 8)
     E.zl = zl;
     const int cols = 256 / zl;

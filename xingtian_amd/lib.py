@@ -53,6 +53,15 @@ class ImpalaCfg(Structure):
                 ("grad_scale", c_float), ("opt_type", c_int32), ("rms_decay", c_float), ("rms_eps", c_float)]
 
 
+class Tuning(Structure):
+    """xt_tuning of include/xt_mi355x.h: process-wide kernel-selection knobs (defaults = measured best)."""
+    _fields_ = [(n, c_int32) for n in (
+        "bf16x6", "dgrad_all_classes", "dgrad_tile64", "dgrad_halo", "bwd_own_instance", "bwd_fit_slots",
+        "conv1_bf16x3", "conv1_flat", "conv1_waves", "fwd_two_groups", "direct", "direct_fwd", "direct_dgrad",
+        "direct_all", "direct_waves", "direct_max_waves", "direct_tile64_tiles", "fwd_split_target",
+        "wgrad_split_target", "reduce_z_lanes", "defer_splitk", "finalize_ticket")]
+
+
 OPT_TYPE = {"adam": 0, "rmsprop": 1}
 _P = c_void_p
 # name -> (restype, argtypes); every symbol include/xt_mi355x.h declares
@@ -60,6 +69,8 @@ SIGNATURES = {
     "xt_abi_version": (c_int32, []),
     "xt_last_error": (c_char_p, []),
     "xt_build_arch": (c_char_p, []),
+    "xt_tuning_get": (c_int32, [POINTER(Tuning)]),
+    "xt_tuning_set": (c_int32, [POINTER(Tuning)]),
     "xt_gae_f64": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_double, c_double, _P]),
     "xt_layer_fwd": (c_int32, [POINTER(ConvGeom), POINTER(InputXform), c_int32, _P, _P, _P, _P, _P, _P, c_int32, _P]),
     "xt_layer_wgrad": (c_int32, [POINTER(ConvGeom), POINTER(InputXform), c_int32, _P, _P, _P, _P, _P, c_int32, _P]),
@@ -114,6 +125,29 @@ def load():
         raise RuntimeError("xingtian_amd: ABI version mismatch")
     _lib = lib
     return lib
+
+
+def get_tuning():
+    """dict of the library's current kernel-selection knobs (xt_tuning_get)."""
+    t = Tuning()
+    check(load().xt_tuning_get(ctypes.byref(t)), "xt_tuning_get")
+    return {n: getattr(t, n) for n, _ in Tuning._fields_}
+
+
+def set_tuning(**knobs):
+    """Change knobs by name (xt_tuning_set); returns the previous values of the ones changed.  Set them before
+    networks are created: captured hipGraphs are not revisited."""
+    t = Tuning()
+    lib = load()
+    check(lib.xt_tuning_get(ctypes.byref(t)), "xt_tuning_get")
+    old = {}
+    for k, v in knobs.items():
+        if not hasattr(t, k):
+            raise KeyError("unknown tuning knob {!r}".format(k))
+        old[k] = getattr(t, k)
+        setattr(t, k, int(v))
+    check(lib.xt_tuning_set(ctypes.byref(t)), "xt_tuning_set")
+    return old
 
 
 def check(rc, what=""):

@@ -1,0 +1,195 @@
+"""Payload codec + shared-memory channel for rollout messages (transport half).
+
+The reference moves every message as ``pyarrow.serialize(obj).to_buffer()`` (+ ``lz4.frame`` above 1 MB) through a
+plasma object store between processes of one node (zeus/common/ipc/share_by_plasma.py:49-95) and through zmq
+multipart frames between nodes (zeus/common/ipc/comm_by_zmq.py:69-97; broker.py:97-119 unpacks them).  Neither
+survives a modern stack: pyarrow >= 2 has no ``serialize`` and no plasma (this image ships pyarrow 25), and ``lz4``
+is not installed.  This module is the plasma-free replacement for the two message kinds on the learner path --
+rollout batches to the learner (``cmd: train``) and weight dicts back to the explorers:
+
+* ``encode(ctr_info, data)`` -> one contiguous buffer: a msgpack header (control dict, python-object fields such as
+  the ``reward`` / ``done`` / ``info`` lists, and for every ndarray its dtype / shape / byte range) followed by the
+  raw array bytes, each 64-byte aligned.  No compression: a uint8 Atari rollout is incompressible enough that the
+  reference's lz4 pass costs more than the memcpy it saves on an intra-node hop.
+* ``decode(buf)`` -> ``(ctr_info, data)`` with the arrays as ZERO-COPY views into ``buf``.
+* ``decode_into(buf, sink)`` -> hands the views straight to an ingest callback (``Algorithm.prepare_data``), so that a
+  trajectory goes wire -> pinned staging -> HBM with exactly one host copy (``RolloutIngest.put``).
+* ``ShmRing`` -- a single-producer / single-consumer ring of fixed-size slots in ``multiprocessing.shared_memory``
+  carrying encoded messages between an explorer-side process and the learner process: the role of plasma's
+  ``put_raw_buffer`` / ``get_buffers`` pair plus its control queue, without a server process.  ``send`` / ``recv``
+  keep the reference channel's ``(ctr_info, data)`` contract.
+
+Plumbing only: no arithmetic, no GPU.  The zmq socket itself (inter-node) is out of scope; its frames would carry the
+same encoded buffer (``send_bytes`` / ``recv_bytes``, comm_by_zmq.py:87-97).
+"""
+import struct
+import time
+from multiprocessing import shared_memory
+
+import msgpack
+import numpy as np
+
+MAGIC = b"XTM1"
+_ALIGN = 64
+
+
+def _pad(n):
+    return (n + _ALIGN - 1) // _ALIGN * _ALIGN
+
+
+def _plain(obj):
+    """numpy scalars / bool_ inside python containers -> msgpack-able python objects"""
+    if isinstance(obj, dict):
+        return {k: _plain(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_plain(v) for v in obj]
+    if isinstance(obj, np.generic):
+        return obj.item()
+    return obj
+
+
+def encode(ctr_info, data):
+    """``data``: dict field -> ndarray | python object (the reference's train_data / weights dict).  Returns a
+    ``bytearray``: MAGIC | u32 header length | msgpack header | padding | array bytes (64-byte aligned each)."""
+    arrays, objects, metas = [], {}, []
+    off = 0
+    for key, val in data.items():
+        if isinstance(val, np.ndarray) and val.dtype != object:
+            arr = np.ascontiguousarray(val)
+            metas.append([key, arr.dtype.str, list(arr.shape), off, arr.nbytes])
+            arrays.append(arr)
+            off += _pad(arr.nbytes)
+        else:
+            objects[key] = _plain(val)
+    header = msgpack.packb({"ctr": _plain(ctr_info), "obj": objects, "arr": metas, "order": list(data.keys())},
+                           use_bin_type=True)
+    base = _pad(8 + len(header))
+    buf = bytearray(base + off)
+    buf[0:4] = MAGIC
+    struct.pack_into("<I", buf, 4, len(header))
+    buf[8:8 + len(header)] = header
+    view = memoryview(buf)
+    for (_, _, _, aoff, nbytes), arr in zip(metas, arrays):
+        if nbytes:
+            view[base + aoff:base + aoff + nbytes] = arr.reshape(-1).view(np.uint8)
+    return buf
+
+
+def _header(buf):
+    view = memoryview(buf)
+    if bytes(view[0:4]) != MAGIC:
+        raise ValueError("transport.decode: not an XTM1 message")
+    hlen = struct.unpack_from("<I", view, 4)[0]
+    head = msgpack.unpackb(bytes(view[8:8 + hlen]), raw=False, strict_map_key=False)
+    return view, head, _pad(8 + hlen)
+
+
+def decode(buf):
+    """-> (ctr_info, data); ndarray fields are zero-copy (read-only when ``buf`` is) views into ``buf``."""
+    view, head, base = _header(buf)
+    fields = dict(head["obj"])
+    for key, dt, shape, off, nbytes in head["arr"]:
+        fields[key] = np.frombuffer(view[base + off:base + off + nbytes], dtype=np.dtype(dt)).reshape(shape)
+    return head["ctr"], {k: fields[k] for k in head["order"]}
+
+
+def decode_into(buf, sink):
+    """Decode and hand the message to ``sink(data, ctr_info=...)`` (``Algorithm.prepare_data``'s signature,
+    xt/framework/learner.py:313) while the views are still backed by ``buf``: the sink copies what it keeps (the
+    streaming ingest copies into pinned staging), after which the slot can be released."""
+    ctr, data = decode(buf)
+    sink(data, ctr_info=ctr)
+    return ctr
+
+
+class ShmRing(object):
+    """Single-producer / single-consumer ring of ``slots`` x ``slot_bytes`` in POSIX shared memory.
+
+    Layout: 64-byte control block {head u64 (next slot to write), tail u64 (next slot to read)} + per-slot u64
+    payload length + the slots.  Only the producer writes ``head`` / lengths / slot bytes, only the consumer writes
+    ``tail``; 8-byte aligned stores are atomic on x86-64 and the payload is complete before ``head`` advances."""
+
+    def __init__(self, name=None, slots=8, slot_bytes=8 << 20, create=True):
+        self.slots, self.slot_bytes = int(slots), int(_pad(slot_bytes))
+        size = _ALIGN + 8 * self.slots + self.slots * self.slot_bytes
+        if create:
+            self.shm = shared_memory.SharedMemory(name=name, create=True, size=size)
+            self.shm.buf[:_ALIGN + 8 * self.slots] = bytes(_ALIGN + 8 * self.slots)
+        else:
+            self.shm = shared_memory.SharedMemory(name=name)
+        self.owner = bool(create)
+        self.name = self.shm.name
+        self._ctl = np.ndarray((2,), dtype=np.uint64, buffer=self.shm.buf, offset=0)
+        self._len = np.ndarray((self.slots,), dtype=np.uint64, buffer=self.shm.buf, offset=_ALIGN)
+        self._base = _ALIGN + 8 * self.slots
+
+    # ---- producer side
+    def send(self, ctr_info, data, block=True, timeout=None):
+        """Encode straight into the next free slot (ShareByPlasma.send / CommByZmq.send contract)."""
+        msg = encode(ctr_info, data)
+        return self.send_bytes(msg, block=block, timeout=timeout)
+
+    def send_bytes(self, msg, block=True, timeout=None):
+        n = len(msg)
+        if n > self.slot_bytes:
+            raise ValueError("message of {} bytes exceeds the slot size {}".format(n, self.slot_bytes))
+        t0 = time.monotonic()
+        while int(self._ctl[0]) - int(self._ctl[1]) >= self.slots:           # ring full
+            if not block or (timeout is not None and time.monotonic() - t0 > timeout):
+                return False
+            time.sleep(0.0002)
+        slot = int(self._ctl[0]) % self.slots
+        off = self._base + slot * self.slot_bytes
+        self.shm.buf[off:off + n] = msg
+        self._len[slot] = n
+        self._ctl[0] = int(self._ctl[0]) + 1
+        return True
+
+    # ---- consumer side
+    def recv_view(self, block=True, timeout=None):
+        """-> memoryview of the oldest unread message (valid until ``release``) or None."""
+        t0 = time.monotonic()
+        while int(self._ctl[0]) == int(self._ctl[1]):
+            if not block or (timeout is not None and time.monotonic() - t0 > timeout):
+                return None
+            time.sleep(0.0002)
+        slot = int(self._ctl[1]) % self.slots
+        off = self._base + slot * self.slot_bytes
+        return self.shm.buf[off:off + int(self._len[slot])]
+
+    def release(self):
+        self._ctl[1] = int(self._ctl[1]) + 1
+
+    def recv(self, block=True, timeout=None):
+        """-> (ctr_info, data) with the arrays COPIED out of the slot (the reference channel's contract)."""
+        view = self.recv_view(block, timeout)
+        if view is None:
+            return None
+        ctr, data = decode(view)
+        data = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in data.items()}
+        del view
+        self.release()
+        return ctr, data
+
+    def recv_into(self, sink, block=True, timeout=None):
+        """Zero-copy receive: ``sink(data, ctr_info=...)`` sees views into the slot; the slot is released after it
+        returns (``decode_into``)."""
+        view = self.recv_view(block, timeout)
+        if view is None:
+            return None
+        ctr = decode_into(view, sink)
+        del view
+        self.release()
+        return ctr
+
+    def pending(self):
+        return int(self._ctl[0]) - int(self._ctl[1])
+
+    def close(self):
+        self._ctl = self._len = None
+        try:
+            self.shm.close()
+            if self.owner:
+                self.shm.unlink()
+        except (BufferError, FileNotFoundError):
+            pass
