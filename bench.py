@@ -301,7 +301,7 @@ def roofline_of(kern, workload="ppo"):
             "sum_layer_kernels_us": round(sum(v[0] for v in kern.values()) * 1e3, 1)}
 
 
-def bench_e2e_ppo(env_num, min_seconds=1.0, max_updates=40):
+def bench_e2e_ppo(env_num, min_seconds=1.0, max_updates=40, via_ring=False):
     """(rollout samples consumed by one Algorithm.train()) / (wall time of prepare_data x env_num +
     train() incl. the H2D of the uint8 rollout + get_weights D2H), through the plugin classes exactly as
     xt/framework/learner.py:306-313,346-348,361-363 drives them.  Host arrays are plain (pageable) numpy."""
@@ -321,13 +321,41 @@ def bench_e2e_ppo(env_num, min_seconds=1.0, max_updates=40):
                       "old_value": ov, "target_value": tg})
     t_prep = t_train = t_w = 0.0
     updates = 0
+    ring, wire = None, None
+    if via_ring:
+        # the trajectories arrive as encoded messages in a PINNED shared-memory ring (xingtian_amd/transport.py): what the
+        # learner process sees when explorers feed it; the explorer-side copy INTO the ring is not learner time
+        from xingtian_amd import transport
+        ring = transport.ShmRing(slots=8, slot_bytes=4 << 20)
+        if not ring.pin():
+            ring.close()
+            return {"skipped": "hipHostRegister of the shared-memory ring failed"}
+        wire = [bytes(transport.encode({"cmd": "train", "explorer_id": i}, dict(tr, reward=[0.0] * T_LEN, done=[False] * T_LEN)))
+                for i, tr in enumerate(trajs)]
+
+    def feed():
+        """-> learner-side seconds spent in prepare_data for the whole rollout"""
+        if ring is None:
+            t0 = time.perf_counter()
+            for tr in trajs:
+                alg.prepare_data(tr)
+            return time.perf_counter() - t0
+        spent = 0.0
+        for lo in range(0, len(wire), ring.slots):
+            chunk = wire[lo:lo + ring.slots]
+            for m in chunk:
+                ring.send_bytes(m)                      # explorer side
+            t0 = time.perf_counter()
+            for _ in chunk:
+                ring.recv_into(alg.prepare_data)        # learner side: decode -> DMA out of the pinned slot
+            spent += time.perf_counter() - t0
+        return spent
 
     def one(timed):
         nonlocal t_prep, t_train, t_w, updates
-        t0 = time.perf_counter()
-        for tr in trajs:
-            alg.prepare_data(tr)
+        dt_prep = feed()
         t1 = time.perf_counter()
+        t0 = t1 - dt_prep
         loss = alg.train(episode_num=updates)
         t2 = time.perf_counter()
         w = alg.get_weights()
@@ -344,13 +372,18 @@ def bench_e2e_ppo(env_num, min_seconds=1.0, max_updates=40):
     total = t_prep + t_train + t_w
     n = env_num * T_LEN
     bytes_h2d = n * (int(np.prod(STATE_DIM)) + 4 + 4 + 8 + 4 + 8)
+    if ring is not None:
+        ring.close()
     return {"env_num": env_num, "env_steps_per_update": n, "updates": updates,
             "value": FRAME_SKIP * n * updates / total, "unit": "env-frames/s", "ms_per_update": 1e3 * total / updates,
             "prepare_data_ms": 1e3 * t_prep / updates, "train_ms": 1e3 * t_train / updates,
             "get_weights_ms": 1e3 * t_w / updates, "h2d_bytes_per_update": bytes_h2d,
             "h2d_ms_at_55GBps": 1e3 * bytes_h2d / 55e9, "stream_ingest": bool(alg.actor.stream_ingest),
-            "path": "alg_builder('PPO') -> prepare_data x {} (pageable numpy -> pinned staging -> async H2D) -> "
-                    "train() -> get_weights() (one pinned D2H)".format(env_num)}
+            "path": ("alg_builder('PPO') -> ShmRing.recv_into(prepare_data) x {} (encoded messages in a hipHostRegister'ed "
+                     "shared-memory ring -> DMA straight to HBM, no learner-side host copy) -> train() -> get_weights()"
+                     if via_ring else
+                     "alg_builder('PPO') -> prepare_data x {} (pageable numpy -> pinned staging -> async H2D) -> "
+                     "train() -> get_weights() (one pinned D2H)").format(env_num)}
 
 
 def bench_impala(key, steps, warmup, with_cpu):
@@ -636,7 +669,8 @@ def main():
     if not (args.quick or args.no_secondary):
         out["e2e"] = {"definition": "SURVEY 8(d): env-steps of one Algorithm.train() / wall time of prepare_data x k + "
                                     "train() (incl. H2D of the uint8 rollout) + get_weights() (D2H), plugin classes",
-                      "env_num_32": bench_e2e_ppo(32), "env_num_10_yaml": bench_e2e_ppo(10)}
+                      "env_num_32": bench_e2e_ppo(32), "env_num_10_yaml": bench_e2e_ppo(10),
+                      "env_num_32_pinned_ring": bench_e2e_ppo(32, via_ring=True)}
         out["value_e2e"] = out["e2e"]["env_num_32"]["value"]
         out["secondary"] = [bench_impala(k, 10, 3, not args.no_cpu_baseline)
                             for k in ("breakout_impala", "pong_impala_speedup")]

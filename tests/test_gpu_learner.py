@@ -969,10 +969,12 @@ def test_rollouts_through_the_transport_ring_feed_the_ingest_bit_identically():
                       "target_value": lab[4], "reward": [0.0] * 32, "done": [False] * 32, "info": [{}] * 32})
     perms = np.stack([rng.permutation(128) for _ in range(2)]).astype(np.int32)
     results = []
-    for via_ring in (False, True):
+    for via_ring in (False, True, "pinned"):
         alg = alg_builder("PPO", model_info, {"instance_num": 4, "agent_num": 1})
         if via_ring:
             ring = transport.ShmRing(slots=4, slot_bytes=2 << 20)
+            if via_ring == "pinned":      # hipHostRegister'ed ring: the frames are DMA-copied straight out of the slot
+                assert ring.pin() and ring.pinned
             try:
                 for i, tr in enumerate(trajs):
                     assert ring.send({"cmd": "train", "explorer_id": i}, tr)
@@ -985,6 +987,6 @@ def test_rollouts_through_the_transport_ring_feed_the_ingest_bit_identically():
                 alg.prepare_data(tr)
         loss = alg.train(perms=perms)
         results.append((loss, alg.get_weights()))
-    assert results[0][0] == results[1][0]
+    assert results[0][0] == results[1][0] == results[2][0]
     for k in results[0][1]:
-        assert np.array_equal(results[0][1][k], results[1][1][k]), k
+        assert np.array_equal(results[0][1][k], results[1][1][k]) and np.array_equal(results[0][1][k], results[2][1][k]), k

@@ -696,6 +696,21 @@ __global__ __launch_bounds__(256) void impala_vtrace_bwd_kernel(const ImpalaLoss
   const int Tm = T - 1;
   const size_t base = (size_t)traj * T;
   const bool lead = blockIdx.y == 0;             // the trajectory's first row block publishes d(heads) and the loss
+  // the d(features) operands of this thread's first feature column do not depend on the v-trace: request them now,
+  // their latency hides behind it
+  const int r0 = blockIdx.y * kVtRows;
+  float wpre[AM], xpre[kVtRows], wvpre;
+  {
+    const int f = t < F ? t : 0;
+#pragma unroll
+    for (int a = 0; a < AM; ++a) wpre[a] = p.wpi[(size_t)f * A + (a < A ? a : 0)];
+    wvpre = p.wv[f];
+#pragma unroll
+    for (int u = 0; u < kVtRows; ++u) {
+      const int r = r0 + u < T ? r0 + u : T - 1;
+      xpre[u] = p.feat[(base + r) * F + f];
+    }
+  }
   float rho = 0.f, disc = 0.f, rew = 0.f, val = 0.f, ce = 0.f, ent = 0.f, logz = 0.f, mx = 0.f, z = 1.f;
   int act = 0;
   if (t < T) s_val[t] = p.baseline[base + t];
@@ -784,20 +799,26 @@ __global__ __launch_bounds__(256) void impala_vtrace_bwd_kernel(const ImpalaLoss
   }
   // d(features)[r, f] = (sum_a dlogits[r,a] Wpi[f,a] + dbaseline[r] Wv[f]) * act'(feature)   (heads_dfeat_kernel)
   // for this block's kVtRows rows: every row's feature load is issued before the first use
-  const int r0 = blockIdx.y * kVtRows;
   for (int f = t; f < F; f += 256) {
-    float w[AM];
+    float w[AM], x[kVtRows];
+    float wvf;
+    if (f == t) {                                 // first feature column: loads issued at kernel entry
 #pragma unroll
-    for (int a = 0; a < AM; ++a) w[a] = p.wpi[(size_t)f * A + (a < A ? a : 0)];
-    const float wvf = p.wv[f];
-    const float* fr = p.feat + base * F + f;
-    float* dr = p.dfeat + base * F + f;
-    float x[kVtRows];
+      for (int a = 0; a < AM; ++a) w[a] = wpre[a];
 #pragma unroll
-    for (int u = 0; u < kVtRows; ++u) {
-      const int r = r0 + u < T ? r0 + u : T - 1;
-      x[u] = fr[(size_t)r * F];
+      for (int u = 0; u < kVtRows; ++u) x[u] = xpre[u];
+      wvf = wvpre;
+    } else {
+#pragma unroll
+      for (int a = 0; a < AM; ++a) w[a] = p.wpi[(size_t)f * A + (a < A ? a : 0)];
+      wvf = p.wv[f];
+#pragma unroll
+      for (int u = 0; u < kVtRows; ++u) {
+        const int r = r0 + u < T ? r0 + u : T - 1;
+        x[u] = p.feat[(base + r) * F + f];
+      }
     }
+    float* dr = p.dfeat + base * F + f;
 #pragma unroll
     for (int u = 0; u < kVtRows; ++u) {
       const int r = r0 + u;

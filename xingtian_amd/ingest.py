@@ -80,27 +80,36 @@ class RolloutIngest(object):
         self.sets[self.cur] = new
         return new
 
-    def put(self, obs, *labels):
+    def put(self, obs, *labels, pinned=False):
         """Append one trajectory / rollout message ([T,...] arrays as the explorer ships them, labels in the order
-        of ``fields``) and start its H2D copy."""
+        of ``fields``) and start its H2D copy.  ``pinned``: the arrays are views into page-locked memory (a pinned
+        transport ring): fields whose dtype already is the device dtype are DMA-copied straight from the source, and
+        the call returns only when those copies have landed (the caller recycles the slot right after)."""
         obs = np.asarray(obs)
         t = obs.shape[0]
         s = self._ensure(self.n + t, obs)
         if self.n == 0 and s.free is not None:      # do not overwrite a set an enqueued update still reads
             self.copy_stream.wait_event(s.free)
         lo, hi = self.n, self.n + t
-        np.copyto(s.host_np["obs"][lo:hi], obs, casting="unsafe")
         if len(labels) != len(self.fields):
             raise ValueError("RolloutIngest.put: {} label arrays for fields {}".format(
                 len(labels), [f[0] for f in self.fields]))
-        for (name, _, width), arr in zip(self.fields, labels):
-            arr = np.asarray(arr)
+        direct = {}
+        named = [("obs", obs)] + [(f[0], np.asarray(a)) for f, a in zip(self.fields, labels)]
+        for name, arr in named:
             dst = s.host_np[name][lo:hi]
-            # bool -> uint8 and float64 -> float32 are the casts the reference's placeholders apply
-            np.copyto(dst, arr.reshape(dst.shape), casting="unsafe" if arr.dtype == np.bool_ else "same_kind")
+            if pinned and isinstance(arr, np.ndarray) and arr.dtype == dst.dtype and arr.flags.c_contiguous \
+                    and arr.flags.writeable and arr.size == dst.size:
+                direct[name] = torch.from_numpy(arr.reshape(dst.shape))     # DMA source = the pinned transport slot
+            else:
+                # bool -> uint8 and float64 -> float32 are the casts the reference's placeholders apply
+                np.copyto(dst, arr.reshape(dst.shape), casting="unsafe" if (name == "obs" or arr.dtype == np.bool_)
+                          else "same_kind")
         with torch.cuda.stream(self.copy_stream):
             for k in s.host:
-                s.dev[k][lo:hi].copy_(s.host[k][lo:hi], non_blocking=True)
+                s.dev[k][lo:hi].copy_(direct[k] if k in direct else s.host[k][lo:hi], non_blocking=True)
+        if direct:
+            self.copy_stream.synchronize()
         self.n = hi
 
     def finish(self):

@@ -17,9 +17,11 @@ rollout batches to the learner (``cmd: train``) and weight dicts back to the exp
 * ``ShmRing`` -- a single-producer / single-consumer ring of fixed-size slots in ``multiprocessing.shared_memory``
   carrying encoded messages between an explorer-side process and the learner process: the role of plasma's
   ``put_raw_buffer`` / ``get_buffers`` pair plus its control queue, without a server process.  ``send`` / ``recv``
-  keep the reference channel's ``(ctr_info, data)`` contract.
+  keep the reference channel's ``(ctr_info, data)`` contract.  ``pin()`` (learner side) page-locks the ring with
+  ``hipHostRegister``: the ingest then DMA-copies the uint8 frames to HBM straight out of the slot -- wire -> HBM with
+  NO host copy on the learner side.
 
-Plumbing only: no arithmetic, no GPU.  The zmq socket itself (inter-node) is out of scope; its frames would carry the
+Plumbing only: no arithmetic; the only GPU-runtime call is the optional ``hipHostRegister`` of ``pin()``.  The zmq socket itself (inter-node) is out of scope; its frames would carry the
 same encoded buffer (``send_bytes`` / ``recv_bytes``, comm_by_zmq.py:87-97).
 """
 import struct
@@ -122,6 +124,28 @@ class ShmRing(object):
         self._ctl = np.ndarray((2,), dtype=np.uint64, buffer=self.shm.buf, offset=0)
         self._len = np.ndarray((self.slots,), dtype=np.uint64, buffer=self.shm.buf, offset=_ALIGN)
         self._base = _ALIGN + 8 * self.slots
+        self.pinned = False
+
+    def pin(self):
+        """Learner side, optional: page-lock the ring with the HIP runtime (``hipHostRegister``) so that the arrays
+        of a received message can be DMA-copied to HBM straight out of the slot -- no staging copy at all
+        (``recv_into`` then tells the sink that its views are pinned).  Needs a GPU process; returns True on success."""
+        import ctypes
+        if self.pinned:
+            return True
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            self._hip = hip
+            probe = np.frombuffer(self.shm.buf, dtype=np.uint8)
+            self._pin_addr = int(probe.ctypes.data)
+            del probe
+            hip.hipHostRegister.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint]
+            hip.hipHostRegister.restype = ctypes.c_int
+            rc = hip.hipHostRegister(ctypes.c_void_p(self._pin_addr), ctypes.c_size_t(self.shm.size), 0)
+        except OSError:
+            return False
+        self.pinned = (rc == 0)
+        return self.pinned
 
     # ---- producer side
     def send(self, ctr_info, data, block=True, timeout=None):
@@ -177,7 +201,12 @@ class ShmRing(object):
         view = self.recv_view(block, timeout)
         if view is None:
             return None
-        ctr = decode_into(view, sink)
+        if self.pinned:
+            ctr, data = decode(view)
+            sink(data, ctr_info=dict(ctr, _pinned_views=True))      # the sink may DMA straight out of the slot
+            del data
+        else:
+            ctr = decode_into(view, sink)
         del view
         self.release()
         return ctr
@@ -187,6 +216,10 @@ class ShmRing(object):
 
     def close(self):
         self._ctl = self._len = None
+        if self.pinned:
+            self._hip.hipHostUnregister.argtypes = [__import__("ctypes").c_void_p]
+            self._hip.hipHostUnregister(__import__("ctypes").c_void_p(self._pin_addr))
+            self.pinned = False
         try:
             self.shm.close()
             if self.owner:
