@@ -115,7 +115,7 @@ def self_spawn(args):
     """``python bench.py --gpus N`` outside a launcher: re-exec under torch.distributed.run with N ranks on this
     node.  Never falls back to fewer ranks."""
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have < args.gpus:
+    if have < args.gpus and not (args.test_backend and have >= 1):
         raise RuntimeError("bench.py --gpus {} needs {} visible GPUs, found {}".format(args.gpus, args.gpus, have))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -474,6 +474,53 @@ def bench_impala(key, steps, warmup, with_cpu):
     return out
 
 
+def bench_impala_dp(key, rank, world, dev, dist, trains=40, warmup=5):
+    """IMPALA data parallel (BASELINE configs[4] direction): the sum-form loss -> gradients are SUMMED, no scaling.
+    strict: the chunk's trajectories are split into whole-trajectory shards (same chunk on every rank); weak: every
+    rank trains on its own full chunk (global chunk = world x BATCH_SIZE frames: flagged semantic change).  A chunk of
+    one trajectory (breakout_impala) cannot be sharded: weak only."""
+    from xingtian_amd.model import netspec
+    from xingtian_amd.model.hip_net import HipActorCritic
+    from xingtian_amd.parallel import allreduce_sum_, dp_impala_step
+    w = IMPALA[key]
+    f, t_len = w["frames_per_train"], w["t_len"]
+    ntraj = f // t_len
+    spec = netspec.impala_cnn_opt((w["dim"], w["dim"], 4), w["a_dim"], w["mean"], w["std"], "uint8")
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    res = {"workload": w["name"], "unit": "env-frames/s", "n_gpus": world}
+    for mode in (("strict", "weak") if ntraj >= world else ("weak",)):
+        data = synth_impala(7 if mode == "strict" else 70 + rank, f, w["dim"], w["a_dim"])
+        obs, bp, act = d(data["obs"]), d(data["logit"]), d(data["action"])
+        done, rew = d(data["done"].astype(np.uint8)), d(data["reward"].astype(np.float32))
+        net = HipActorCritic(spec, max_batch=f, device=str(dev), seed=0)
+        cfg = net.make_impala_cfg(w["lr"], 40.0, t_len)
+
+        def one():
+            if mode == "strict":
+                dp_impala_step(net, cfg, w["lr"], 40.0, obs, bp, act, done, rew, ntraj, t_len, rank, world)
+            else:
+                net.impala_step(cfg, obs, bp, act, done, rew, apply=False)
+                allreduce_sum_(net.grads)
+                net.apply(w["lr"], 40.0, grad_scale=1.0)
+
+        for _ in range(warmup):
+            one()
+        dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(trains):
+            one()
+        dist.barrier(); torch.cuda.synchronize()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        frames = f * (world if mode == "weak" else 1) * trains
+        res[mode] = {"value": FRAME_SKIP * frames / float(el.item()), "us_per_train": 1e6 * float(el.item()) / trains,
+                     "frames_per_train_global": f * (world if mode == "weak" else 1),
+                     "trajectories_per_rank": ntraj if mode == "weak" else "{}..{}".format(ntraj // world, -(-ntraj // world))}
+        assert torch.isfinite(net.params).all()
+        del net
+    return res
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     _claim_stdout()
@@ -492,6 +539,10 @@ def main():
                          "all-reduce of the flat gradient (torch.distributed) -> clip+Adam.  ingraph: raw RCCL all-reduces "
                          "enqueued by the library itself (xt_net_set_grad_exchange) and captured into the hipGraph of the "
                          "whole update -- no host involvement per step; validated on one rank only, hence opt-in")
+    ap.add_argument("--test-backend", default=None, choices=["gloo"],
+                    help="DIAGNOSTIC (numbers are meaningless): run the N ranks on however many GPUs are visible (ranks share "
+                         "devices, round robin) and exchange gradients through gloo -- exercises the self-spawn and the whole "
+                         "N>1 code path on a 1-GPU box, where RCCL refuses two ranks on one device")
     ap.add_argument("--workload", default="ppo", choices=["ppo", "breakout_impala", "pong_impala_speedup"],
                     help="ppo = BASELINE configs[1] (the headline metric, default; its JSON line carries the IMPALA "
                          "workloads as `secondary`); the IMPALA names print that workload's own line (profiling)")
@@ -507,6 +558,8 @@ def main():
         raise RuntimeError("bench.py --gpus {} is running under a launcher with WORLD_SIZE={}".format(args.gpus, world))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU: the learner path has no CPU fallback")
+    if args.test_backend:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
 
     if args.workload != "ppo":
@@ -521,7 +574,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.test_backend:
+            dist.init_process_group(args.test_backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from xingtian_amd import lib as L
     from xingtian_amd.model import netspec
@@ -618,10 +674,13 @@ def main():
                    "global_batch": bsz * world, "parallelism": "dp{}".format(world), "hip_graph": graph_on,
                    "dp_path": bool(dp_path)},
     }
+    if args.test_backend:
+        out["config"]["DIAGNOSTIC"] = "ranks share GPUs, gradients through {}: not a measurement".format(args.test_backend)
     if dp_path:
         out["config"]["dp_mode"] = args.dp_mode
         out["config"]["collective"] = "one all-reduce (SUM) of the flat fp32 gradient ({} floats) per SGD step, {}".format(
-            spec.n_flat, "torch.distributed nccl (RCCL)" if args.dp_mode == "eager" else "raw RCCL inside the hipGraph")
+            spec.n_flat, ("torch.distributed " + (args.test_backend or "nccl (RCCL)")) if args.dp_mode == "eager"
+            else "raw RCCL inside the hipGraph")
         if dist is not None:
             out["config"]["ranks_in_group"] = dist.get_world_size()
     out["update_tflops"] = PPO_MFLOP_PER_SAMPLE_PASS * 1e6 * n * CFG["NUM_SGD_ITER"] * world * args.steps / elapsed / 1e12
@@ -632,13 +691,22 @@ def main():
         del keep
         keep_weak.pop("one_update"); keep_weak.pop("net")
         torch.cuda.empty_cache()
-        el_s, n_s, keep_s = run_mode("strict")
-        out["strict"] = {"value": FRAME_SKIP * n_s * args.steps / el_s, "unit": "env-frames/s", "scaling": "strong",
-                         "ms_per_step": 1e3 * el_s / args.steps, "global_batch": bsz,
-                         "rows_per_gpu": bsz // world, "env_steps_per_update": n_s, "sgd_steps_per_update": sgd_steps,
-                         "note": "same rollout + same permutations on every rank, rank r takes rows "
-                                 "[r*B/N, (r+1)*B/N) of every global minibatch; loss means over the global minibatch; "
-                                 "arithmetic of the single-GPU update up to fp32 summation order"}
+        try:
+            el_s, n_s, keep_s = run_mode("strict")
+            out["strict"] = {"value": FRAME_SKIP * n_s * args.steps / el_s, "unit": "env-frames/s", "scaling": "strong",
+                             "ms_per_step": 1e3 * el_s / args.steps, "global_batch": bsz,
+                             "rows_per_gpu": bsz // world, "env_steps_per_update": n_s, "sgd_steps_per_update": sgd_steps,
+                             "note": "same rollout + same permutations on every rank, rank r takes rows "
+                                     "[r*B/N, (r+1)*B/N) of every global minibatch; loss means over the global minibatch; "
+                                     "arithmetic of the single-GPU update up to fp32 summation order"}
+            del keep_s
+        except Exception as exc:      # noqa: BLE001 -- the weak-mode headline above must still be reported
+            out["strict"] = {"error": repr(exc)}
+        torch.cuda.empty_cache()
+        try:
+            out["secondary"] = [bench_impala_dp(k, rank, world, dev, dist) for k in ("pong_impala_speedup", "breakout_impala")]
+        except Exception as exc:      # noqa: BLE001
+            out["secondary"] = [{"error": repr(exc)}]
         if rank == 0:
             _emit(out)
         dist.destroy_process_group()

@@ -112,3 +112,29 @@ def test_impala_sum_loss_two_ranks_whole_trajectory_shards(tmp_path):
     torch.cuda.synchronize()
     ref = net.params.cpu().numpy()
     assert _delta_err(got, ref, start) < 5e-3, _delta_err(got, ref, start)
+
+
+def test_bench_self_spawns_two_ranks_and_reports_weak_strict_and_impala():
+    """``python bench.py --gpus 2`` outside a launcher must start the two ranks itself and print ONE JSON line with
+    ``n_gpus: 2``, the weak-scaling headline, the strict-sharding result and the IMPALA data-parallel secondaries
+    (here with the diagnostic gloo transport, the two ranks sharing the one GPU)."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--test-backend", "gloo", "--steps", "2", "--warmup", "1"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+    assert proc.returncode == 0, proc.stderr.decode()[-3000:]
+    lines = [l for l in proc.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["ranks_in_group"] == 2
+    assert d["config"]["global_batch"] == 640 and d["config"]["env_steps_per_update"] == 8192
+    assert d["strict"]["rows_per_gpu"] == 160 and d["strict"]["global_batch"] == 320 and d["strict"]["value"] > 0
+    sec = {s["workload"].split()[0]: s for s in d["secondary"]}
+    assert sec["examples/pong_impala_speedup.yaml"]["strict"]["trajectories_per_rank"] == "10..10"
+    assert sec["examples/breakout_impala.yaml"]["weak"]["frames_per_train_global"] == 256
+    # a launcher environment with another world size is refused, never silently reduced
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--quick"],
+                         env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         timeout=120)
+    assert bad.returncode != 0 and b"WORLD_SIZE=2" in bad.stderr
