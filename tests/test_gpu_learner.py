@@ -990,3 +990,17 @@ def test_rollouts_through_the_transport_ring_feed_the_ingest_bit_identically():
     assert results[0][0] == results[1][0] == results[2][0]
     for k in results[0][1]:
         assert np.array_equal(results[0][1][k], results[1][1][k]) and np.array_equal(results[0][1][k], results[2][1][k]), k
+
+
+def test_cartpole_reward_curve_through_plugins_with_cpu_replica_explorers():
+    """BASELINE configs[0] (examples/cartpole_ppo.yaml) closed loop: explorers = the inference-only numpy replica,
+    learner = HIP PPO with GAE on the GPU, weights published by name after every update (tools/cartpole_e2e.py).
+    The policy must actually LEARN: mean episode return of the last updates several times the random policy's."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import cartpole_e2e
+    curve = cartpole_e2e.run(updates=30, seed=0, verbose=False)
+    first, last = float(np.nanmean(curve[:3])), float(np.nanmean(curve[-5:]))
+    assert first < 60.0, curve                     # a fresh policy balances for ~20-30 steps
+    assert last > 100.0 and last > 3.0 * first, curve
