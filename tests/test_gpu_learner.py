@@ -1004,3 +1004,43 @@ def test_cartpole_reward_curve_through_plugins_with_cpu_replica_explorers():
     first, last = float(np.nanmean(curve[:3])), float(np.nanmean(curve[-5:]))
     assert first < 60.0, curve                     # a fresh policy balances for ~20-30 steps
     assert last > 100.0 and last > 3.0 * first, curve
+
+
+def test_rollout_ingest_grows_and_alternates_buffer_sets_without_losing_rows():
+    """RolloutIngest: capacity growth in the middle of a rollout (already staged rows are carried over), the two
+    alternating buffer sets, float -> uint8 / float64 -> float32 casts of arriving arrays, and the pinned-source path:
+    the device buffers always hold exactly the concatenation of what was put."""
+    from xingtian_amd.ingest import PPO_FIELDS, RolloutIngest, impala_fields
+    rng = np.random.default_rng(17)
+    ing = RolloutIngest("cuda:0", n_epochs=2, initial_capacity=100, obs_u8=True)
+    for rollout in range(3):                       # rollout 0 grows 100 -> 200 -> 400; 1 uses the other set; 2 reuses set 0
+        parts = []
+        for t in (64, 70, 90, 33):
+            obs = rng.integers(0, 256, (t, 12, 12, 4)).astype(np.uint8 if rollout != 1 else np.float32)
+            lab = [rng.integers(0, 4, t).astype(np.int32), rng.standard_normal((t, 1)).astype(np.float32),
+                   rng.standard_normal((t, 1)), rng.standard_normal((t, 1)).astype(np.float32), rng.standard_normal((t, 1))]
+            ing.put(obs, *lab)
+            parts.append((obs, lab))
+        n, dev = ing.finish()
+        torch.cuda.synchronize()
+        assert n == 257 and dev["perm"].shape[0] == 2
+        assert np.array_equal(dev["obs"][:n].cpu().numpy(), np.concatenate([p[0] for p in parts]).astype(np.uint8))
+        for i, (name, _, _) in enumerate(PPO_FIELDS):
+            want = np.concatenate([p[1][i].reshape(-1) for p in parts])
+            assert np.array_equal(dev[name][:n].cpu().numpy(), want), (rollout, name)
+        ing.mark_consumed()
+    imp = RolloutIngest("cuda:0", n_epochs=0, initial_capacity=16, obs_u8=True, fields=impala_fields(6))
+    msgs = []
+    for t in (20, 30):
+        m = (rng.integers(0, 256, (t, 8, 8, 4)).astype(np.uint8), rng.standard_normal((t, 6)).astype(np.float32),
+             rng.integers(0, 6, t).astype(np.int32), rng.random(t) < 0.3, rng.choice([-1.0, 0.0, 2.0], t))
+        imp.put(*m)
+        msgs.append(m)
+    n, dev = imp.finish()
+    torch.cuda.synchronize()
+    assert n == 50 and "perm" not in dev
+    assert np.array_equal(dev["done"][:n].cpu().numpy(), np.concatenate([m[3] for m in msgs]).astype(np.uint8))
+    assert np.array_equal(dev["reward"][:n].cpu().numpy(), np.concatenate([m[4] for m in msgs]).astype(np.float32))
+    assert np.array_equal(dev["logit"][:n].cpu().numpy(), np.concatenate([m[1] for m in msgs]))
+    with pytest.raises(ValueError):
+        imp.put(msgs[0][0], msgs[0][1])
