@@ -698,3 +698,29 @@ def test_shared_memory_ring_carries_rollouts_between_processes():
         if proc.is_alive():
             proc.terminate()
         ring.close()
+
+
+def test_yaml_to_alg_para_matches_the_reference_executed_patching():
+    """xingtian_amd.config (YAML -> alg_para -> alg_builder) against what the reference's OWN
+    patch_alg_within_config / patch_model_config_by_env_info / setup_learner produce for its example YAMLs
+    (tests/golden/learner_config.json, executed by oracle/gen_golden_cfg.py)."""
+    import json
+    from xingtian_amd import config as cfg
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "learner_config.json")))
+    assert len(golden) == 5
+    for rel, g in golden.items():
+        got = cfg.learner_alg_para(g["config"], g["env_info"])
+        assert got == g["alg_para"], rel
+        assert got["model_info"]["actor"]["type"] == "learner"
+        # the YAML without an explicit node_config means one local node
+        bare = {k: v for k, v in g["config"].items() if k != "node_config"}
+        assert cfg.learner_alg_para(bare, g["env_info"]) == g["alg_para"], rel
+    if not torch.cuda.is_available():
+        # explorer side of the same YAML: the CPU replica, with the reference's predict shapes
+        g = golden["examples/breakout_ppo.yaml"]
+        actor = cfg.build_explorer_model(g["config"], g["env_info"])
+        assert actor.net.inference_only
+        a, lp, v = actor.predict(np.zeros((2, 84, 84, 4), np.uint8))
+        assert a.shape == (2,) and lp.shape == (2, 1) and v.shape == (2, 1)
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            cfg.build_learner_algorithm(g["config"], g["env_info"])
