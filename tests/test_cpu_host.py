@@ -724,3 +724,31 @@ def test_yaml_to_alg_para_matches_the_reference_executed_patching():
         assert a.shape == (2,) and lp.shape == (2, 1) and v.shape == (2, 1)
         with pytest.raises(RuntimeError, match="no HIP device"):
             cfg.build_learner_algorithm(g["config"], g["env_info"])
+
+
+def test_transport_codec_property_random_payloads():
+    """hypothesis: arbitrary dicts of ndarrays (any of the wire dtypes, 0-d to 4-d, empty included) and python
+    scalars / lists / nested dicts survive encode -> decode exactly, with the field order preserved."""
+    from hypothesis import given, settings, strategies as st
+    from hypothesis.extra import numpy as hnp
+    from xingtian_amd import transport
+    dtypes = st.sampled_from([np.uint8, np.int32, np.int64, np.float32, np.float64, np.bool_])
+    arrays = dtypes.flatmap(lambda dt: hnp.arrays(dt, hnp.array_shapes(min_dims=0, max_dims=4, min_side=0, max_side=5)))
+    scalars = st.one_of(st.integers(-2 ** 40, 2 ** 40), st.floats(allow_nan=False, allow_infinity=False), st.booleans(),
+                        st.text(max_size=8), st.none())
+    objects = st.one_of(scalars, st.lists(scalars, max_size=6), st.dictionaries(st.text(max_size=4), scalars, max_size=3))
+    payloads = st.dictionaries(st.text(min_size=1, max_size=10), st.one_of(arrays, objects), max_size=6)
+
+    @settings(max_examples=60, deadline=None)
+    @given(payloads, st.dictionaries(st.text(min_size=1, max_size=6), scalars, max_size=4))
+    def check(data, ctr):
+        buf = transport.encode(ctr, data)
+        ctr2, out = transport.decode(buf)
+        assert ctr2 == ctr and list(out) == list(data)
+        for k, v in data.items():
+            if isinstance(v, np.ndarray):
+                assert out[k].dtype == v.dtype and out[k].shape == v.shape and np.array_equal(out[k], v)
+            else:
+                assert out[k] == v
+
+    check()

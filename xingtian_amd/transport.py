@@ -57,8 +57,8 @@ def encode(ctr_info, data):
     off = 0
     for key, val in data.items():
         if isinstance(val, np.ndarray) and val.dtype != object:
-            arr = np.ascontiguousarray(val)
-            metas.append([key, arr.dtype.str, list(arr.shape), off, arr.nbytes])
+            arr = np.ascontiguousarray(val)            # (promotes 0-d to 1-d: the shape on the wire is the original one)
+            metas.append([key, arr.dtype.str, list(val.shape), off, arr.nbytes])
             arrays.append(arr)
             off += _pad(arr.nbytes)
         else:
