@@ -752,3 +752,34 @@ def test_transport_codec_property_random_payloads():
                 assert out[k] == v
 
     check()
+
+
+def test_shard_partition_properties():
+    """hypothesis: for any (items, world) the rank shards of ``shard_range`` / ``split_minibatch`` are contiguous,
+    disjoint, cover everything exactly once and differ in size by at most one -- including short last minibatches
+    and more ranks than rows."""
+    from hypothesis import given, settings, strategies as st
+    from xingtian_amd import parallel
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(0, 5000), st.integers(1, 64))
+    def ranges(n, world):
+        spans = [parallel.shard_range(n, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[r][1] == spans[r + 1][0] for r in range(world - 1))
+        sizes = [e - b for b, e in spans]
+        assert min(sizes) >= 0 and max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+    @settings(max_examples=100, deadline=None)
+    @given(st.integers(1, 700), st.integers(1, 320), st.integers(1, 16), st.integers(0, 2 ** 31 - 1))
+    def minibatches(n, bsz, world, seed):
+        perm = np.random.default_rng(seed).permutation(n).astype(np.int32)
+        seen = []
+        for start in range(0, n, bsz):
+            parts = [parallel.split_minibatch(perm, start, bsz, r, world) for r in range(world)]
+            assert np.array_equal(np.concatenate(parts), perm[start:start + bsz])
+            seen.append(np.concatenate(parts))
+        assert np.array_equal(np.sort(np.concatenate(seen)), np.arange(n))
+
+    ranges()
+    minibatches()
