@@ -181,7 +181,11 @@ def test_ppo_train_matches_oracle_and_graph_replay_is_bitwise():
     (84, 4, 128, 1, 0.0, 255.0),      # BASELINE configs[2] breakout_impala.yaml: one 128-step trajectory per SGD step
     (84, 4, 128, 4, 0.0, 255.0),      # ... and BATCH_SIZE 512 = four trajectories in one step
     (42, 6, 50, 20, 128.0, 128.0),    # BASELINE configs[4] pong_impala_speedup.yaml: 1000 rows = 20 trajectories of 50
-    (42, 18, 8, 3, 128.0, 128.0)])    # A = 18 (full Atari action set): outside the fused head kernels -> unfused launches
+    (42, 18, 8, 3, 128.0, 128.0),     # A = 18 (full Atari action set): outside the fused head kernels -> unfused launches
+    (42, 6, 2, 3, 128.0, 128.0),      # T = 2: a single loss-carrying step per trajectory + the bootstrap row
+    (42, 4, 9, 2, 128.0, 128.0),      # T = 9: a row block of 8 + a block holding only the bootstrap row
+    (42, 6, 256, 1, 128.0, 128.0),    # T = 256: the largest trajectory of the fused v-trace kernel
+    (42, 6, 257, 1, 128.0, 128.0)])   # T = 257: falls back to the unfused launches
 def test_impala_step_vs_oracle(dim, a_dim, tlen, ntraj, mean, std):
     from xingtian_amd.model import netspec
     from xingtian_amd.model.hip_net import HipActorCritic
