@@ -19,14 +19,16 @@ Parity status
 * The TensorFlow-side FORMULAS the reference itself writes down -- the PPO actor/critic losses
   (``xt/model/ppo/__init__.py:4-25``), ``CategoricalDist`` / ``DiagGaussianDist`` (``xt/model/tf_dist.py:49-130``),
   v-trace (``xt/model/impala/vtrace.py:39-115``), ``split_batches`` + ``vtrace_loss`` and its parts
-  (``xt/model/impala/impala_cnn_opt.py:171-196, 299-351``): **pinned** -- ``oracle/gen_golden_tf.py`` EXECUTES those
+  (``xt/model/impala/impala_cnn_opt.py:171-196, 299-351``), the Keras-form ``impala_loss`` closures
+  (``xt/model/impala/impala_cnn.py:99-108``, ``impala_mlp.py:84-93``; ``K`` = a three-function torch-float64
+  backend stand-in, ``tests/golden/tf_keras_impala_*.npz``): **pinned** -- ``oracle/gen_golden_tf.py`` EXECUTES those
   sources unmodified under a torch-float64 ``tf`` stand-in (``oracle/tf_shim.py``: only primitive ops are restated,
   each citing the TF 1.15 op / gradient function it follows) and commits values + autograd gradients as
   ``tests/golden/tf_*.npz`` (ratio exactly at 1 +- eps, |v - old_v| = VF_CLIP, done at t = 0 / T-2 / everywhere,
   A in {2, 4, 6, 18}, the BASELINE shapes (T=128, B=1/4) and (T=50, B=20, A=6)); ``tests/test_oracle.py`` holds the
   numpy restatement to ~1e-12 of them, ``tests/test_gpu_kernels.py`` the HIP loss kernels to fp32 tolerance.
-* What TensorFlow's own LIBRARY computes (Conv2D / Dense forward and backward, the Keras ``impala_loss`` composition
-  inside ``model.compile``, ``clip_by_global_norm``, ``AdamOptimizer`` / ``RMSPropOptimizer`` / ``tf.keras`` Adam
+* What TensorFlow's own LIBRARY computes (Conv2D / Dense forward and backward, what Keras' ``model.compile`` does around the ``impala_loss``
+  closure (batch mean, 'mse', loss_weights), ``clip_by_global_norm``, ``AdamOptimizer`` / ``RMSPropOptimizer`` / ``tf.keras`` Adam
   update rules): **parity unpinned** -- TensorFlow (1.15 / 2.3.1, un-vendored, not installable here) holds that
   arithmetic and the reference's tests pin no numbers for it, so this package restates TF's published semantics
   (VALID / asymmetric-SAME padding, NHWC / HWIO layouts, TF1 Adam with eps outside the bias correction,

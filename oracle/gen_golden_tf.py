@@ -16,6 +16,12 @@ The composition ``loss = actor_loss + CRITIC_LOSS_COEF * critic_loss`` (xt/model
 DiagGaussian ``dist_param = concat([pi_latent, pi_latent * 0.0 + log_std])`` (:75-79) are three lines
 restated here (they live inside ``build_graph`` next to session/placeholder code).
 
+* ``xt/model/impala/impala_cnn.py`` :99-108 and ``xt/model/impala/impala_mlp.py`` :84-93: the Keras-form
+  ``impala_loss(advantage)`` closures, by exec-ing exactly those source lines with ``K`` = a three-function
+  Keras-backend stand-in over torch float64 (``KerasBackend`` below) and the reference's own ``ENTROPY_LOSS``.
+  What Keras does AROUND the closure -- the batch mean of the per-sample loss vector, ``'mse'`` for the value
+  head, ``loss_weights`` [1.0, 0.5] (impala_cnn.py:59-62) -- is library behaviour restated in three lines.
+
 Outputs (values and torch-autograd gradients, float64): ``tests/golden/tf_*.npz``.
 Usage:  python oracle/gen_golden_tf.py
 """
@@ -226,6 +232,57 @@ def impala_case(opt, vtrace, gamma, wiring, tf, rng, tlen, n_traj, a_dim, done_m
                 vs=f64(vs), pg_adv=f64(pg))
 
 
+class KerasBackend(object):
+    """The three ``K.`` functions the Keras-form loss closures use, over torch float64."""
+
+    @staticmethod
+    def log(x):
+        return torch.log(x)
+
+    @staticmethod
+    def mean(x, axis=None):
+        return torch.mean(x) if axis is None else torch.mean(x, dim=axis)
+
+    @staticmethod
+    def cast(x, dtype=None):
+        return x.to(torch.float64)
+
+
+def keras_loss_source(relpath, first, last):
+    """``def impala_loss(advantage): ... return loss`` of ``relpath`` verbatim; asserts the line span."""
+    with open(os.path.join(REF, relpath)) as f:
+        lines = f.read().split("\n")
+    start = next(i for i, s in enumerate(lines) if s.startswith("def impala_loss(advantage):"))
+    end = next(i for i in range(start, len(lines)) if lines[i].strip() == "return loss")
+    assert (start + 1, end + 1) == (first, last), (relpath, start + 1, end + 1)
+    return "\n".join(lines[start:end + 1])
+
+
+def keras_impala_case(source, ent_coef, rng, b, a_dim, peaked):
+    scope = {"K": KerasBackend, "ENTROPY_LOSS": ent_coef}
+    exec(source, scope)
+    logits = (rng.standard_normal((b, a_dim)) * (9.0 if peaked else 1.5)).astype(np.float32)
+    if peaked:
+        logits[:4, 0] += 40.0                    # p underflows next to 1e-10: the epsilon decides the value
+    value = rng.standard_normal((b, 1)).astype(np.float32)
+    adv = (rng.standard_normal((b, 1)) * 2).astype(np.float32)
+    action = rng.integers(0, a_dim, b)
+    onehot = np.eye(a_dim, dtype=np.float32)[action]
+    target_v = (value + rng.standard_normal((b, 1))).astype(np.float32)
+    lg = torch.tensor(logits, dtype=torch.float64, requires_grad=True)
+    v = torch.tensor(value, dtype=torch.float64, requires_grad=True)
+    policy = torch.softmax(lg, dim=-1)                       # the model's 'output_actions' activation
+    per_sample = scope["impala_loss"](torch.tensor(adv, dtype=torch.float64))(
+        torch.tensor(onehot, dtype=torch.float64), policy)   # <- the reference closure
+    l_pi = per_sample.mean()                                 # Keras: batch mean of whatever the closure returns
+    l_v = ((v - torch.tensor(target_v, dtype=torch.float64)) ** 2).mean()      # 'mse'
+    loss = 1.0 * l_pi + 0.5 * l_v                            # loss_weights
+    dl, dv = torch.autograd.grad(loss, [lg, v])
+    return dict(logits=logits, value=value, adv=adv, onehot=onehot, target_v=target_v, ent_coef=ent_coef,
+                per_sample=f64(per_sample).reshape(-1), loss=f64(loss), loss_pi=f64(l_pi), loss_v=f64(l_v),
+                dlogits=f64(dl), dvalue=f64(dv))
+
+
 def main():
     tf = tf_shim.make_tf()
     ppo_loss, tf_dist, vtrace, opt, gamma = load_reference(tf)
@@ -254,6 +311,18 @@ def main():
         case = impala_case(opt, vtrace, gamma, wiring, tf, rng, tlen, n_traj, a_dim, mode)
         np.savez(os.path.join(OUT, "tf_impala_T{}_B{}_A{}_{}.npz".format(tlen, n_traj, a_dim, mode)), **case)
         print("tf_impala", tlen, n_traj, a_dim, mode, float(case["loss"]))
+    # Keras-form IMPALA loss (ImpalaCnn / ImpalaMlp): both closures, plain and peaked policies
+    cfg = {}
+    with open(os.path.join(REF, "xt/model/impala/default_config.py")) as f:
+        exec(f.read(), cfg)
+    for tag, rel, span in [("cnn", "xt/model/impala/impala_cnn.py", (99, 108)),
+                           ("mlp", "xt/model/impala/impala_mlp.py", (84, 93))]:
+        src = keras_loss_source(rel, *span)
+        for a_dim, b, peaked in [(4, 128, False), (6, 50, True), (2, 33, False)]:
+            rng = np.random.default_rng(400 + k); k += 1
+            case = keras_impala_case(src, cfg["ENTROPY_LOSS"], rng, b, a_dim, peaked)
+            np.savez(os.path.join(OUT, "tf_keras_impala_{}_A{}_B{}.npz".format(tag, a_dim, b)), **case)
+            print("tf_keras_impala", tag, a_dim, b, float(case["loss"]))
 
 
 if __name__ == "__main__":

@@ -460,6 +460,34 @@ def test_keras_impala_loss_vs_oracle(L, b, a_dim):
     assert np.linalg.norm(d_dv.cpu().numpy() - dv.reshape(-1)) <= 1e-5 * np.linalg.norm(dv)
 
 
+def test_keras_impala_loss_kernel_vs_executed_reference(L, golden_dir):
+    """xt_keras_impala_loss against the reference's own Keras-form closures executed under the torch-float64
+    backend stand-in (tests/golden/tf_keras_impala_*.npz; impala_cnn.py:99-108, impala_mlp.py:84-93), including the
+    peaked-policy cases where the 1e-10 epsilon decides the value.  fp32 kernel vs float64 golden."""
+    files = sorted(glob.glob(os.path.join(golden_dir, "tf_keras_impala_*.npz")))
+    assert len(files) == 6
+    lib = L.load()
+    for f in files:
+        g = np.load(f)
+        b, a_dim = g["logits"].shape
+        d = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        dev = [d(g["logits"]), d(g["value"].reshape(-1)), d(np.arange(b, dtype=np.int32)), d(g["adv"].reshape(-1)),
+               d(g["onehot"]), d(g["target_v"].reshape(-1))]
+        d_dl = torch.empty((b, a_dim), dtype=torch.float32, device="cuda")
+        d_dv = torch.empty((b,), dtype=torch.float32, device="cuda")
+        out = torch.zeros((4 + 2 * b,), dtype=torch.float32, device="cuda")
+        acc = torch.zeros((2,), dtype=torch.float32, device="cuda")
+        L.check(lib.xt_keras_impala_loss(L.ptr(dev[0]), L.ptr(dev[1]), b, a_dim, L.ptr(dev[2]), L.ptr(dev[3]),
+                                         L.ptr(dev[4]), L.ptr(dev[5]), float(g["ent_coef"]), L.ptr(d_dl), L.ptr(d_dv),
+                                         L.ptr(out), L.ptr(acc), L.stream_ptr()), "xt_keras_impala_loss")
+        torch.cuda.synchronize()
+        o = out.cpu().numpy()
+        for got, ref in ((o[0], g["loss"]), (o[1], g["loss_pi"]), (o[2], g["loss_v"])):
+            assert abs(got - float(ref)) < 2e-5 * max(1.0, abs(float(ref))), (f, got, float(ref))
+        assert np.linalg.norm(d_dl.cpu().numpy() - g["dlogits"]) <= 2e-5 * np.linalg.norm(g["dlogits"]), f
+        assert np.linalg.norm(d_dv.cpu().numpy() - g["dvalue"].reshape(-1)) <= 1e-5 * np.linalg.norm(g["dvalue"]), f
+
+
 # ----------------------------------------------------------------------------------------------
 # the loss kernels against the reference's OWN formula sources executed under the torch-float64 tf stand-in
 # (oracle/gen_golden_tf.py -> tests/golden/tf_*.npz): no restatement between the kernel and the reference

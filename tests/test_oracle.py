@@ -228,6 +228,22 @@ def test_ppo_categorical_loss_matches_executed_reference(golden_dir):
         assert (np.abs(g["value"][4:8].astype(np.float64) - g["old_v"][4:8]) == float(g["vf_clip"])).all()
 
 
+def test_keras_impala_loss_matches_executed_reference(golden_dir):
+    """oracle.nets.keras_impala_loss_and_grads against the reference's two Keras-form ``impala_loss`` closures
+    (impala_cnn.py:99-108: K.mean(..., 1) per sample; impala_mlp.py:84-93: K.mean over everything) executed
+    verbatim under a torch-float64 Keras-backend stand-in: both reduce to the same mean over batch and actions."""
+    files = sorted(glob.glob(os.path.join(golden_dir, "tf_keras_impala_*.npz")))
+    assert len(files) == 6
+    for f in files:
+        g = np.load(f)
+        loss, dl, dv, (l_pi, l_v) = nets.keras_impala_loss_and_grads(
+            g["logits"].astype(np.float64), g["value"].astype(np.float64), g["adv"].astype(np.float64),
+            g["onehot"].astype(np.float64), g["target_v"].astype(np.float64), float(g["ent_coef"]))
+        _close(loss, g["loss"]); _close(l_pi, g["loss_pi"]); _close(l_v, g["loss_v"])
+        _close(dl, g["dlogits"]); _close(dv, g["dvalue"])
+        assert g["per_sample"].shape == ((g["logits"].shape[0],) if "_cnn_" in f else (1,))
+
+
 def test_ppo_gaussian_loss_matches_executed_reference(golden_dir):
     files = sorted(glob.glob(os.path.join(golden_dir, "tf_ppo_gauss_*.npz")))
     assert len(files) == 3
