@@ -285,24 +285,34 @@ __global__ __launch_bounds__(512, 2) void conv_u8c4k8_fwd_flat_kernel(const C1Fw
   const float bias = p.bias[il];
   __syncthreads();
   XT_TL(2);
-  uint4 wq[3];
-  uint2 aq[SLOTS];
-  auto lds_fetch = [&](int s) {
+  // The step count is a compile-time constant (KH = 8 -> 16 half kernel rows) and the loop is fully unrolled with
+  // two explicit operand register sets: as a rolled loop hipcc rotated the pipeline with 16 v_mov per step and
+  // waited lgkmcnt(0) for the NEXT step's operands right behind the first MFMA of the current one (ISA), i.e. the
+  // LDS latency was exposed once per step.
+  constexpr int NS = 16;
+  uint4 wq[2][3];
+  uint2 aq[2][SLOTS];
+  auto lds_fetch = [&](int s, uint4 (&w3)[3], uint2 (&a2)[SLOTS]) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) wq[pl] = wpl[(s * 3 + pl) * 64 + lane];
+    for (int pl = 0; pl < 3; ++pl) w3[pl] = wpl[(s * 3 + pl) * 64 + lane];
     const int koff = (s >> 1) * Wrow + (s & 1) * 16;
 #pragma unroll
-    for (int ti = 0; ti < SLOTS; ++ti) aq[ti] = *reinterpret_cast<const uint2*>(limg + poff[ti] + koff);
+    for (int ti = 0; ti < SLOTS; ++ti) a2[ti] = *reinterpret_cast<const uint2*>(limg + poff[ti] + koff);
   };
-  lds_fetch(0);
-  for (int s = 0; s < nsteps; ++s) {
+  lds_fetch(0, wq[0], aq[0]);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int cur = s & 1;
     BF8 bp[3];
     bf16x8 av[SLOTS];
+    // the NEXT step's five LDS reads go out first and stay there (sched_barrier: left alone, hipcc sinks each read
+    // to just in front of its use to save registers and then waits for it behind one MFMA)
+    if (s + 1 < NS) lds_fetch(s + 1, wq[cur ^ 1], aq[cur ^ 1]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) { bp[pl].u[0] = wq[pl].x; bp[pl].u[1] = wq[pl].y; bp[pl].u[2] = wq[pl].z; bp[pl].u[3] = wq[pl].w; }
+    for (int pl = 0; pl < 3; ++pl) { bp[pl].u[0] = wq[cur][pl].x; bp[pl].u[1] = wq[cur][pl].y; bp[pl].u[2] = wq[cur][pl].z; bp[pl].u[3] = wq[cur][pl].w; }
 #pragma unroll
-    for (int ti = 0; ti < SLOTS; ++ti) av[ti] = bytes_to_bf16x8(aq[ti].x, aq[ti].y);
-    if (s + 1 < nsteps) lds_fetch(s + 1);
+    for (int ti = 0; ti < SLOTS; ++ti) av[ti] = bytes_to_bf16x8(aq[cur][ti].x, aq[cur][ti].y);
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
@@ -398,6 +408,7 @@ struct C1WgArgs {
   float* out;          // [B][(K+1)*32] partial slabs
   int B, H, W, OH, OW, S, KH;
   float xs, xb;
+  int img_cap;         // flattened form: LDS bytes reserved for the packed input rows (multiple of 16)
 };
 
 // NKQ = kernel-row groups per pixel parity: 2 pixel parities x NKQ groups = 2*NKQ waves, 8/NKQ kernel rows (k
@@ -535,109 +546,179 @@ __global__ __launch_bounds__(128 * NKQ, NKQ) void conv_u8c4k8_wgrad_bf16x3_kerne
 
 // ---- position-flattened weight gradient: one workgroup = 512 consecutive positions of the flattened [B*OH*OW]
 // range (32 pixel steps of 16) -> ceil(B*OH*OW / 512) equal workgroups, one per CU, and as many partial slabs
-// (250 instead of 320 at B = 320).  Same wave roles as above (2 pixel parities x 4 kernel-row groups).  The dY rows
-// of a position range are one contiguous block; the frame-stack rows are staged as in the flattened forward.
+// (250 instead of 320 at B = 320).  Wave roles as above (2 pixel parities x 4 kernel-row groups).
+//
+// The loop of the first form was ISSUE-bound (ISA: ~200 instructions per 16-pixel step and wave for 6 MFMAs = 192
+// matrix cycles: 16 ds_read_u8 + 16 address adds + 24 convert/pack for the x operand, and the 3-way split of the
+// SAME eight dY values repeated by all four kernel-row waves).  This form feeds the matrix cores with ~40:
+//  * dY is split into its three bf16 planes ONCE, while it is staged (global -> registers -> LDS in B-operand
+//    order [step][plane][lane] x 16 B), so a step reads its B operands with three ds_read_b128;
+//  * the x operand (row = byte kx*4+c of kernel row ky, reduction = 8 consecutive positions) is ONE
+//    ds_read_b64_tr_b8 per kernel row: in every 16-lane group lanes 2j, 2j+1 supply the address of bytes
+//    [cb + 0..7], [cb + 8..15] of position j's kernel row and lane c receives column cb + c of the eight positions
+//    (semantics measured on the GPU, tools/tr_probe.hip) -- the transposition the byte gather did by hand;
+//  * only the input rows the position range needs are staged, packed back to back (<= 44 KB instead of 3 x 28 KB),
+//    which is what makes room for the 96 KB of dY planes.
+template <int NIMG, int NT, int U>
+__device__ __forceinline__ void stage_position_rows_packed(const uint8_t* __restrict__ in, const int32_t* __restrict__ idx,
+                                                           int B, int HWC, int Wrow, int OHOW, int OW, int S, int KH,
+                                                           int p0, int p1, uint8_t* limg, int t, int (&shift)[NIMG]) {
+  const int s0 = p0 / OHOW, slast = (p1 - 1) / OHOW;
+  int un[NIMG], dbase[NIMG], srow[NIMG];
+  long long goff[NIMG];
+  int ntot = 0;
+#pragma unroll
+  for (int i = 0; i < NIMG; ++i) {
+    const int sc = min(s0 + i, B - 1);
+    srow[i] = idx ? idx[sc] : sc;
+  }
+#pragma unroll
+  for (int i = 0; i < NIMG; ++i) {
+    const int sidx = s0 + i;
+    un[i] = 0; dbase[i] = 0; goff[i] = 0; shift[i] = 0;
+    if (sidx <= slast) {
+      const int lo = max(p0, sidx * OHOW) - sidx * OHOW, hi = min(p1, (sidx + 1) * OHOW) - 1 - sidx * OHOW;
+      const int blo = S * (lo / OW) * Wrow, bhi = (S * (hi / OW) + KH) * Wrow;
+      const int ul = blo >> 4;
+      un[i] = ((bhi + 15) >> 4) - ul;
+      goff[i] = (long long)srow[i] * (long long)HWC + (long long)ul * 16;
+      dbase[i] = ntot * 16;
+      shift[i] = (ntot - ul) * 16;          // LDS byte of the stack's byte o: shift + o
+    }
+    ntot += un[i];
+  }
+  for (int base = 0; base < ntot; base += NT * U) {
+    uint4 v[U];
+    int dsto[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      int u = base + t + NT * q;
+      const bool ok = u < ntot;
+      u = ok ? u : 0;
+      long long go = goff[0];
+      int db = dbase[0];
+#pragma unroll
+      for (int j = 0; j + 1 < NIMG; ++j) {
+        int cum = 0;
+#pragma unroll
+        for (int k = 0; k <= j; ++k) cum += un[k];
+        if (u >= cum) { go = goff[j + 1] - (long long)cum * 16; db = dbase[j + 1] - cum * 16; }
+      }
+      v[q] = *reinterpret_cast<const uint4*>(in + go + (long long)u * 16);
+      dsto[q] = db + u * 16;
+    }
+#pragma unroll
+    for (int q = 0; q < U; ++q) *reinterpret_cast<uint4*>(limg + dsto[q]) = v[q];
+  }
+}
+
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ i32x2 lds_read_tr8(const uint8_t* p) {
+  return __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(p));
+}
+
 __global__ __launch_bounds__(512, 2) void conv_u8c4k8_wgrad_flat_kernel(const C1WgArgs p) {
-  constexpr int NKQ = 4, NT = 512, RQ = 2, PB = 512, NIMG = 3, DQ = PB * 8 / NT;
+  constexpr int NKQ = 4, NT = 512, RQ = 2, PB = 512, NIMG = 3, NSTEP = PB / 16, NITEM = NSTEP * 64 / NT;
   extern __shared__ __attribute__((aligned(16))) uint8_t lsm[];
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int HWC = p.H * p.W * 4, Wrow = p.W * 4, OHOW = p.OH * p.OW;
   const int total = p.B * OHOW;
   const int p0 = blockIdx.x * PB, p1 = min(total, p0 + PB);
-  uint8_t* limg = lsm;
-  float* dys = reinterpret_cast<float*>(lsm + NIMG * HWC);                        // [PB][32]
-  int* pixoff = reinterpret_cast<int*>(lsm + NIMG * HWC + PB * 32 * 4);            // [PB]
+  uint8_t* limg = lsm;                                                             // packed input rows, <= img_cap
+  uint4* dpl = reinterpret_cast<uint4*>(lsm + p.img_cap);                           // [NSTEP][3 planes][64 lanes] x 16 B
+  int* pixoff = reinterpret_cast<int*>(lsm + p.img_cap + NSTEP * 3 * 64 * 16);      // [PB]
   float* bred = reinterpret_cast<float*>(pixoff);       // aliases pixoff after the main loop
   XT_TL(0);
   XT_TL_ROLE(50);
+  const int il = lane & 31, h = lane >> 5;
+  float bsum = 0.f;
   {
-    const float4* dsrc = reinterpret_cast<const float4*>(p.dy + (size_t)p0 * 32);
-    const int n4 = (p1 - p0) * 8;
-    float4 dv[DQ];
+    // dY of this thread's NITEM B-operand slots: slot = (step, k half, column) -> 8 pixels x one column (the 32
+    // lanes of a half wave read one 128-byte row per load).  All loads of the block are issued before the first use.
+    float dv[NITEM][8];
 #pragma unroll
-    for (int q = 0; q < DQ; ++q) {
-      const int i = t + NT * q;
-      dv[q] = dsrc[i < n4 ? i : 0];
+    for (int q = 0; q < NITEM; ++q) {
+      const int slot = t + NT * q, pos = p0 + (slot >> 6) * 16 + ((slot >> 5) & 1) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dv[q][e] = p.dy[(size_t)min(pos + e, p1 - 1) * 32 + il];
     }
-    stage_position_range<NIMG, NT, 6>(p.in, p.idx, p.B, HWC, Wrow, OHOW, p.OW, p.S, p.KH, p0, p1, limg, t);
+    int shift[NIMG];
+    stage_position_rows_packed<NIMG, NT, 6>(p.in, p.idx, p.B, HWC, Wrow, OHOW, p.OW, p.S, p.KH, p0, p1, limg, t, shift);
 #pragma unroll
-    for (int q = 0; q < DQ; ++q) {
-      const int i = t + NT * q;
-      reinterpret_cast<float4*>(dys)[i] = i < n4 ? dv[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < NITEM; ++q) {
+      const int slot = t + NT * q, pos = p0 + (slot >> 6) * 16 + ((slot >> 5) & 1) * 8;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[e] = pos + e < p1 ? dv[q][e] : 0.f; bsum += v[e]; }
+      bf16x8 pl3[3];
+      split3_regs(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), pl3);
+      const int st = slot >> 6, ln = slot & 63;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        BF8 u; u.v = pl3[pl];
+        dpl[(st * 3 + pl) * 64 + ln] = make_uint4(u.u[0], u.u[1], u.u[2], u.u[3]);
+      }
     }
     const int s0 = p0 / OHOW;
     {
       const int pp = min(p0 + t, p1 - 1);        // PB == NT: one position per thread; tail positions carry dY = 0
       const int sidx = pp / OHOW, rem = pp - sidx * OHOW;
       const int oy = rem / p.OW, ox = rem - oy * p.OW;
-      pixoff[t] = (sidx - s0) * HWC + (p.S * oy * p.W + p.S * ox) * 4;
+      const int di = sidx - s0;
+      pixoff[t] = (di == 0 ? shift[0] : di == 1 ? shift[1] : shift[2]) + (p.S * oy * p.W + p.S * ox) * 4;
     }
   }
-  const int il = lane & 31, h = lane >> 5;
   const int pg = wave / NKQ, kq = wave - pg * NKQ;
   f32x16 acc[RQ];
 #pragma unroll
   for (int q = 0; q < RQ; ++q)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-  float bsum = 0.f;
   XT_TL(1);
   __syncthreads();
   XT_TL(2);
-  float dyr[8];
-  uint32_t xr[RQ][8];
-  int po[8];
-  auto read_po = [&](int s) {
+  // A-operand role of this lane inside its 16-lane group (see the header): position row j, byte half m
+  const int c16 = lane & 15, grp = lane >> 4;
+  const int prow = 8 * (grp >> 1) + (c16 >> 1);
+  const uint8_t* abase = limg + (kq * RQ) * Wrow + (grp & 1) * 16 + (c16 & 1) * 8;
+  int po = pixoff[pg * 16 + prow];
+  i32x2 xr[RQ];
+  uint4 bq[3];
+  auto read_ops = [&](int s) {     // uses po of step s
 #pragma unroll
-    for (int e = 0; e < 8; ++e) po[e] = pixoff[s * 16 + 8 * h + e];
+    for (int pl = 0; pl < 3; ++pl) bq[pl] = dpl[(s * 3 + pl) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) xr[q] = lds_read_tr8(abase + po + q * Wrow);
   };
-  auto read_ops = [&](int s) {
+  read_ops(pg);
+  po = pixoff[(pg + 2) * 16 + prow];
+  // constant trip count (the tail positions of the last block carry dY = 0 and a clamped pixel offset), unrolled
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dyr[e] = dys[(s * 16 + 8 * h + e) * 32 + il];
+  for (int it = 0; it < NSTEP / 2; ++it) {
+    const int s = pg + 2 * it;
+    BF8 bp[3];
+    bf16x8 av[RQ];
 #pragma unroll
-    for (int q = 0; q < RQ; ++q) {
-      const int kb = (kq * RQ + q) * Wrow + il;
+    for (int pl = 0; pl < 3; ++pl) { bp[pl].u[0] = bq[pl].x; bp[pl].u[1] = bq[pl].y; bp[pl].u[2] = bq[pl].z; bp[pl].u[3] = bq[pl].w; }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) xr[q][e] = limg[po[e] + kb];
-    }
-  };
-  const int nsteps = (p1 - p0 + 15) >> 4;      // <= NSTEP
-  if (pg < nsteps) { read_po(pg); read_ops(pg); }
-  if (pg + 2 < nsteps) read_po(pg + 2);
-  for (int s = pg; s < nsteps; s += 2) {
-    BF8 bp[3], av[RQ];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float w0 = dyr[2 * q], w1 = dyr[2 * q + 1];
-      bsum += w0 + w1;
-      const float r0 = w0 - trunc_bf16(w0), r1 = w1 - trunc_bf16(w1);
-      const float q0 = r0 - trunc_bf16(r0), q1 = r1 - trunc_bf16(r1);
-      bp[0].u[q] = pack_hi16(w0, w1);
-      bp[1].u[q] = pack_hi16(r0, r1);
-      bp[2].u[q] = pack_hi16(q0, q1);
-    }
-#pragma unroll
-    for (int q = 0; q < RQ; ++q)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) av[q].u[e] = pack_hi16((float)xr[q][2 * e], (float)xr[q][2 * e + 1]);
-    if (s + 2 < nsteps) {
-      read_ops(s + 2);
-      if (s + 4 < nsteps) read_po(s + 4);
+    for (int q = 0; q < RQ; ++q) av[q] = bytes_to_bf16x8((uint32_t)xr[q].x, (uint32_t)xr[q].y);
+    if (it + 1 < NSTEP / 2) {
+      read_ops(s + 2);                       // po currently holds step s + 2
+      if (it + 2 < NSTEP / 2) po = pixoff[(s + 4) * 16 + prow];
     }
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
       for (int q = 0; q < RQ; ++q)
-        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q].v, bp[pl].v, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q], bp[pl].v, acc[q], 0, 0, 0);
   }
-  bsum += __shfl_xor(bsum, 32, 64);
   XT_TL(3);
   __syncthreads();                         // every staged operand is dead: the LDS is reused for the combine
   // both pixel-parity halves park their tiles as [parity][k row][36]; then all 512 threads add the two copies and
   // store 16 bytes each: the slab is written as 4 fully coalesced 8 KB passes (the dword form, stored by the four
   // parity-0 waves only, took 3.7 us of the block's 13.9)
   float* T = reinterpret_cast<float*>(lsm);
-  if (kq == 0 && h == 0) bred[pg * 32 + il] = bsum;
+  bred[(t >> 5) * 32 + il] = bsum;          // 16 row groups x 32 columns of bias-gradient partials (staging threads)
 #pragma unroll
   for (int q = 0; q < RQ; ++q)
 #pragma unroll
@@ -649,23 +730,46 @@ __global__ __launch_bounds__(512, 2) void conv_u8c4k8_wgrad_flat_kernel(const C1
   {
     float* slab = p.out + (size_t)blockIdx.x * ((size_t)(p.KH * 32 + 1) * 32);
     const int c4 = (t & 7) * 4;
-    float corr[4];
+    float db[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) corr[c] = p.xb * (bred[c4 + c] + bred[32 + c4 + c]);   // d/dW of (x*xs + xb): xb * sum_p dY
+    for (int c = 0; c < 4; ++c) {
+      float sum = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) sum += bred[g * 32 + c4 + c];
+      db[c] = sum;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int krow = (t >> 3) + 64 * j;
       const float4 u0 = *reinterpret_cast<const float4*>(&T[krow * 36 + c4]);
       const float4 u1 = *reinterpret_cast<const float4*>(&T[(256 + krow) * 36 + c4]);
-      float4 v;
-      v.x = fmaf(u0.x + u1.x, p.xs, corr[0]); v.y = fmaf(u0.y + u1.y, p.xs, corr[1]);
-      v.z = fmaf(u0.z + u1.z, p.xs, corr[2]); v.w = fmaf(u0.w + u1.w, p.xs, corr[3]);
+      float4 v;                                // d/dW of (x*xs + xb): xb * sum_p dY
+      v.x = fmaf(u0.x + u1.x, p.xs, p.xb * db[0]); v.y = fmaf(u0.y + u1.y, p.xs, p.xb * db[1]);
+      v.z = fmaf(u0.z + u1.z, p.xs, p.xb * db[2]); v.w = fmaf(u0.w + u1.w, p.xs, p.xb * db[3]);
       *reinterpret_cast<float4*>(slab + (size_t)krow * 32 + c4) = v;
     }
-    if (t < 32) slab[(size_t)p.KH * 32 * 32 + t] = bred[t] + bred[32 + t];
+    if (t < 8) *reinterpret_cast<float4*>(slab + (size_t)p.KH * 32 * 32 + c4) = make_float4(db[0], db[1], db[2], db[3]);
   }
   XT_TL(4);
   XT_TL_DRAIN(5);
+}
+
+// bytes of packed input rows the largest 512-position range of the launch stages (host side)
+static int c1_packed_cap(int B, int OH, int OW, int S, int KH, int Wrow, int PB) {
+  const int OHOW = OH * OW, total = B * OHOW;
+  int cap = 0;
+  for (int p0 = 0; p0 < total; p0 += PB) {
+    const int p1 = total < p0 + PB ? total : p0 + PB;
+    int units = 0;
+    for (int sidx = p0 / OHOW; sidx <= (p1 - 1) / OHOW; ++sidx) {
+      const int lo = (p0 > sidx * OHOW ? p0 : sidx * OHOW) - sidx * OHOW;
+      const int hi = (p1 < (sidx + 1) * OHOW ? p1 : (sidx + 1) * OHOW) - 1 - sidx * OHOW;
+      const int blo = S * (lo / OW) * Wrow, bhi = (S * (hi / OW) + KH) * Wrow;
+      units += ((bhi + 15) >> 4) - (blo >> 4);
+    }
+    if (units * 16 > cap) cap = units * 16;
+  }
+  return cap;
 }
 
 XT_TL_SETTER(conv1)
@@ -681,7 +785,7 @@ int launch_conv1_wgrad_bf16x3(const xt_conv_geom* g, const xt_input_xform* xf, i
   if (!slabs || B > max_slabs) return -1;
   C1WgArgs a;
   a.in = static_cast<const uint8_t*>(in); a.idx = idx; a.dy = dy; a.out = (B == 1) ? dwb : slabs;
-  a.B = B; a.H = g->H; a.W = g->W; a.OH = g->OH; a.OW = g->OW; a.S = g->S; a.KH = g->KH;
+  a.B = B; a.H = g->H; a.W = g->W; a.OH = g->OH; a.OW = g->OW; a.S = g->S; a.KH = g->KH; a.img_cap = 0;
   const float mean = fabsf(xf->mean) >= 1e-4f ? xf->mean : 0.f;
   a.xs = 1.f / xf->std; a.xb = -mean * a.xs;
   const int nsteps = (g->OH * g->OW + 15) / 16;
@@ -693,9 +797,11 @@ int launch_conv1_wgrad_bf16x3(const xt_conv_geom* g, const xt_input_xform* xf, i
   {
     const int flat = tuning().conv1_flat;
     const int total = B * g->OH * g->OW, nblk = (total + 511) / 512;
-    const size_t fl = (size_t)3 * HWC + (size_t)512 * 32 * 4 + (size_t)512 * 4;
+    a.img_cap = c1_packed_cap(B, g->OH, g->OW, g->S, g->KH, g->W * 4, 512);
+    size_t fl = (size_t)a.img_cap + (size_t)32 * 3 * 64 * 16 + (size_t)512 * 4;
+    if (fl < (size_t)2 * 256 * 36 * 4) fl = (size_t)2 * 256 * 36 * 4;            // the combine buffer aliases everything
     if (flat && c1_waves() == 8 && nblk >= 200 && nblk <= max_slabs && 511 / (g->OH * g->OW) + 2 <= 3 &&
-        fl <= 160 * 1024 && B > 1) {
+        fl <= 160 * 1024 && B > 1 && (g->W * 4) % 8 == 0 && (g->S * 4) % 16 == 0) {
       static bool attr_done = false;
       if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4k8_wgrad_flat_kernel),
