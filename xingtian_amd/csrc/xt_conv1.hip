@@ -25,6 +25,7 @@ struct C1FwdArgs {
   float* y;            // [B*OH*OW][32]
   int B, H, W, OH, OW, S, KH, act;
   float xs, xb;        // y = act(acc*xs + bias)   (xb must be 0 for this kernel)
+  int img_cap;         // flattened form: LDS bytes of the bf16 image of the packed input rows (multiple of 16)
 };
 
 constexpr int kC1TileSlots = 16;   // 32-pixel tile slots per workgroup -> OH*OW <= 512
@@ -217,6 +218,90 @@ __device__ __forceinline__ void stage_position_range(const uint8_t* __restrict__
   }
 }
 
+// Packed form of stage_position_range: only the input rows the position range needs, the (<= NIMG) per-stack row
+// groups back to back; shift[i] + o is the LDS byte of byte o of stack i.  BF16: every byte is converted to bf16 on the
+// way (exact), i.e. the image occupies 2 bytes per element and LDS byte = 2 * (shift + o).
+template <int NIMG, int NT, int U, bool BF16 = false>
+__device__ __forceinline__ void stage_position_rows_packed(const uint8_t* __restrict__ in, const int32_t* __restrict__ idx,
+                                                           int B, int HWC, int Wrow, int OHOW, int OW, int S, int KH,
+                                                           int p0, int p1, uint8_t* limg, int t, int (&shift)[NIMG]) {
+  const int s0 = p0 / OHOW, slast = (p1 - 1) / OHOW;
+  int un[NIMG], dbase[NIMG], srow[NIMG];
+  long long goff[NIMG];
+  int ntot = 0;
+#pragma unroll
+  for (int i = 0; i < NIMG; ++i) {
+    const int sc = min(s0 + i, B - 1);
+    srow[i] = idx ? idx[sc] : sc;
+  }
+#pragma unroll
+  for (int i = 0; i < NIMG; ++i) {
+    const int sidx = s0 + i;
+    un[i] = 0; dbase[i] = 0; goff[i] = 0; shift[i] = 0;
+    if (sidx <= slast) {
+      const int lo = max(p0, sidx * OHOW) - sidx * OHOW, hi = min(p1, (sidx + 1) * OHOW) - 1 - sidx * OHOW;
+      const int blo = S * (lo / OW) * Wrow, bhi = (S * (hi / OW) + KH) * Wrow;
+      const int ul = blo >> 4;
+      un[i] = ((bhi + 15) >> 4) - ul;
+      goff[i] = (long long)srow[i] * (long long)HWC + (long long)ul * 16;
+      dbase[i] = ntot * 16;
+      shift[i] = (ntot - ul) * 16;          // LDS byte of the stack's byte o: shift + o
+    }
+    ntot += un[i];
+  }
+  for (int base = 0; base < ntot; base += NT * U) {
+    uint4 v[U];
+    int dsto[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      int u = base + t + NT * q;
+      const bool ok = u < ntot;
+      u = ok ? u : 0;
+      long long go = goff[0];
+      int db = dbase[0];
+#pragma unroll
+      for (int j = 0; j + 1 < NIMG; ++j) {
+        int cum = 0;
+#pragma unroll
+        for (int k = 0; k <= j; ++k) cum += un[k];
+        if (u >= cum) { go = goff[j + 1] - (long long)cum * 16; db = dbase[j + 1] - cum * 16; }
+      }
+      v[q] = *reinterpret_cast<const uint4*>(in + go + (long long)u * 16);
+      dsto[q] = db + u * 16;
+    }
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      if constexpr (BF16) {
+        BF8 lo, hi;
+        lo.v = bytes_to_bf16x8(v[q].x, v[q].y);
+        hi.v = bytes_to_bf16x8(v[q].z, v[q].w);
+        *reinterpret_cast<uint4*>(limg + 2 * dsto[q]) = make_uint4(lo.u[0], lo.u[1], lo.u[2], lo.u[3]);
+        *reinterpret_cast<uint4*>(limg + 2 * dsto[q] + 16) = make_uint4(hi.u[0], hi.u[1], hi.u[2], hi.u[3]);
+      } else {
+        *reinterpret_cast<uint4*>(limg + dsto[q]) = v[q];
+      }
+    }
+  }
+}
+
+// bytes of packed input rows the largest 512-position range of the launch stages (host side)
+static int c1_packed_cap(int B, int OH, int OW, int S, int KH, int Wrow, int PB) {
+  const int OHOW = OH * OW, total = B * OHOW;
+  int cap = 0;
+  for (int p0 = 0; p0 < total; p0 += PB) {
+    const int p1 = total < p0 + PB ? total : p0 + PB;
+    int units = 0;
+    for (int sidx = p0 / OHOW; sidx <= (p1 - 1) / OHOW; ++sidx) {
+      const int lo = (p0 > sidx * OHOW ? p0 : sidx * OHOW) - sidx * OHOW;
+      const int hi = (p1 < (sidx + 1) * OHOW ? p1 : (sidx + 1) * OHOW) - 1 - sidx * OHOW;
+      const int blo = S * (lo / OW) * Wrow, bhi = (S * (hi / OW) + KH) * Wrow;
+      units += ((bhi + 15) >> 4) - (blo >> 4);
+    }
+    if (units * 16 > cap) cap = units * 16;
+  }
+  return cap;
+}
+
 // ---- position-flattened forward: one workgroup = PB consecutive output positions of the flattened [B*OH*OW]
 // range instead of one frame stack.  With one frame stack per workgroup, B = 320 on 256 CUs leaves 64 CUs with two
 // co-resident workgroups (13.9 us) while the other 192 finish their single one in 9.9 us (profiles/r01_timeline*);
@@ -232,7 +317,7 @@ __global__ __launch_bounds__(512, 2) void conv_u8c4k8_fwd_flat_kernel(const C1Fw
   const int total = p.B * OHOW;
   const int p0 = blockIdx.x * PB, p1 = min(total, p0 + PB);
   const int nsteps = 2 * p.KH;
-  uint4* wpl = reinterpret_cast<uint4*>(limg + NIMG * HWC);
+  uint4* wpl = reinterpret_cast<uint4*>(limg + p.img_cap);     // behind the bf16 image of the packed input rows
   XT_TL(0);
   XT_TL_ROLE(40);
   float wv[WQ][8];
@@ -245,7 +330,11 @@ __global__ __launch_bounds__(512, 2) void conv_u8c4k8_fwd_flat_kernel(const C1Fw
 #pragma unroll
     for (int j = 0; j < 8; ++j) wv[q][j] = wl[j * 32];
   }
-  stage_position_range<NIMG, NT, U>(p.in, p.idx, p.B, HWC, Wrow, OHOW, p.OW, p.S, p.KH, p0, p1, limg, t);
+  // The input rows are converted to bf16 ONCE while they are staged (2 bytes per element, packed rows: <= 88 KB):
+  // the loop's A operand is then one ds_read_b128 per tile.  Converting at operand-read time repeated every byte's
+  // conversion four times (8x8 windows at stride 4) and cost 24 VALU instructions per step next to 6 MFMAs.
+  int shift[NIMG];
+  stage_position_rows_packed<NIMG, NT, U, true>(p.in, p.idx, p.B, HWC, Wrow, OHOW, p.OW, p.S, p.KH, p0, p1, limg, t, shift);
   const int s0 = p0 / OHOW;
   XT_TL(1);
 #pragma unroll
@@ -269,13 +358,17 @@ __global__ __launch_bounds__(512, 2) void conv_u8c4k8_fwd_flat_kernel(const C1Fw
     }
   }
   const int il = lane & 31, h = lane >> 5;
-  int poff[SLOTS];
+  int poff[SLOTS];                           // LDS byte of this lane's 8 bf16 at step 0
 #pragma unroll
   for (int ti = 0; ti < SLOTS; ++ti) {
     const int pp = min(p0 + (wave + NW * ti) * 32 + il, p1 - 1);      // tail positions recompute the last valid one
     const int sidx = pp / OHOW, rem = pp - sidx * OHOW;
     const int oy = rem / p.OW, ox = rem - oy * p.OW;
-    poff[ti] = (sidx - s0) * HWC + (p.S * oy * p.W + p.S * ox) * 4 + 8 * h;
+    const int di = sidx - s0;
+    int sh = shift[0];
+#pragma unroll
+    for (int j = 1; j < NIMG; ++j) sh = di == j ? shift[j] : sh;
+    poff[ti] = 2 * (sh + (p.S * oy * p.W + p.S * ox) * 4 + 8 * h);
   }
   f32x16 acc[SLOTS];
 #pragma unroll
@@ -290,38 +383,36 @@ __global__ __launch_bounds__(512, 2) void conv_u8c4k8_fwd_flat_kernel(const C1Fw
   // waited lgkmcnt(0) for the NEXT step's operands right behind the first MFMA of the current one (ISA), i.e. the
   // LDS latency was exposed once per step.
   constexpr int NS = 16;
-  uint4 wq[2][3];
-  uint2 aq[2][SLOTS];
-  auto lds_fetch = [&](int s, uint4 (&w3)[3], uint2 (&a2)[SLOTS]) {
+  uint4 wq[2][3], aq[2][SLOTS];
+  auto lds_fetch = [&](int s, uint4 (&w3)[3], uint4 (&a2)[SLOTS]) {
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) w3[pl] = wpl[(s * 3 + pl) * 64 + lane];
-    const int koff = (s >> 1) * Wrow + (s & 1) * 16;
+    const int koff = 2 * ((s >> 1) * Wrow + (s & 1) * 16);
 #pragma unroll
-    for (int ti = 0; ti < SLOTS; ++ti) a2[ti] = *reinterpret_cast<const uint2*>(limg + poff[ti] + koff);
+    for (int ti = 0; ti < SLOTS; ++ti) a2[ti] = *reinterpret_cast<const uint4*>(limg + poff[ti] + koff);
   };
   lds_fetch(0, wq[0], aq[0]);
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int cur = s & 1;
-    BF8 bp[3];
-    bf16x8 av[SLOTS];
-    // the NEXT step's five LDS reads go out first and stay there (sched_barrier: left alone, hipcc sinks each read
-    // to just in front of its use to save registers and then waits for it behind one MFMA)
+    BF8 bp[3], av[SLOTS];
+    // the NEXT step's LDS reads go out first and stay there (sched_barrier: left alone, hipcc sinks each read to just
+    // in front of its use to save registers and then waits for it behind one MFMA)
     if (s + 1 < NS) lds_fetch(s + 1, wq[cur ^ 1], aq[cur ^ 1]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) { bp[pl].u[0] = wq[cur][pl].x; bp[pl].u[1] = wq[cur][pl].y; bp[pl].u[2] = wq[cur][pl].z; bp[pl].u[3] = wq[cur][pl].w; }
 #pragma unroll
-    for (int ti = 0; ti < SLOTS; ++ti) av[ti] = bytes_to_bf16x8(aq[cur][ti].x, aq[cur][ti].y);
+    for (int ti = 0; ti < SLOTS; ++ti) { av[ti].u[0] = aq[cur][ti].x; av[ti].u[1] = aq[cur][ti].y; av[ti].u[2] = aq[cur][ti].z; av[ti].u[3] = aq[cur][ti].w; }
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
       for (int ti = 0; ti < SLOTS; ++ti)
-        acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ti], bp[pl].v, acc[ti], 0, 0, 0);
+        acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ti].v, bp[pl].v, acc[ti], 0, 0, 0);
   }
   __syncthreads();
   XT_TL(3);
-  float* tbuf = reinterpret_cast<float*>(limg + NIMG * HWC) + wave * (32 * 36);
+  float* tbuf = reinterpret_cast<float*>(limg + p.img_cap) + wave * (32 * 36);
 #pragma unroll
   for (int ti = 0; ti < SLOTS; ++ti) {
     const int pix0 = p0 + (wave + NW * ti) * 32;
@@ -358,7 +449,7 @@ int launch_conv1_fwd_bf16x3(const xt_conv_geom* g, const xt_input_xform* xf, int
   a.in = static_cast<const uint8_t*>(in); a.idx = idx; a.w = w; a.bias = bias; a.y = y;
   a.B = B; a.H = g->H; a.W = g->W; a.OH = g->OH; a.OW = g->OW; a.S = g->S; a.KH = g->KH; a.act = g->act;
   const float mean = fabsf(xf->mean) >= 1e-4f ? xf->mean : 0.f;
-  a.xs = 1.f / xf->std; a.xb = -mean * a.xs;
+  a.xs = 1.f / xf->std; a.xb = -mean * a.xs; a.img_cap = 0;
   const int nw = c1_waves();
   size_t lds = (size_t)2 * g->KH * 3 * 64 * 16;                    // weight planes, reused by the output transpose
   if (lds < (size_t)nw * 32 * 36 * 4) lds = (size_t)nw * 32 * 36 * 4;
@@ -369,7 +460,8 @@ int launch_conv1_fwd_bf16x3(const xt_conv_geom* g, const xt_input_xform* xf, int
     const bool two = (total + 511) / 512 >= 200;
     const int pb = two ? 512 : 256, nimg = two ? 3 : 2;
     if ((pb - 1) / (g->OH * g->OW) + 2 <= nimg) {          // a range of pb positions touches at most nimg frame stacks
-      const size_t fl = (size_t)nimg * HWC + (size_t)2 * g->KH * 3 * 64 * 16;
+      a.img_cap = 2 * c1_packed_cap(B, g->OH, g->OW, g->S, g->KH, g->W * 4, pb);
+      const size_t fl = (size_t)a.img_cap + (size_t)2 * g->KH * 3 * 64 * 16;
       static bool attr_done = false;
       if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4k8_fwd_flat_kernel<2>),
@@ -559,59 +651,6 @@ __global__ __launch_bounds__(128 * NKQ, NKQ) void conv_u8c4k8_wgrad_bf16x3_kerne
 //    (semantics measured on the GPU, tools/tr_probe.hip) -- the transposition the byte gather did by hand;
 //  * only the input rows the position range needs are staged, packed back to back (<= 44 KB instead of 3 x 28 KB),
 //    which is what makes room for the 96 KB of dY planes.
-template <int NIMG, int NT, int U>
-__device__ __forceinline__ void stage_position_rows_packed(const uint8_t* __restrict__ in, const int32_t* __restrict__ idx,
-                                                           int B, int HWC, int Wrow, int OHOW, int OW, int S, int KH,
-                                                           int p0, int p1, uint8_t* limg, int t, int (&shift)[NIMG]) {
-  const int s0 = p0 / OHOW, slast = (p1 - 1) / OHOW;
-  int un[NIMG], dbase[NIMG], srow[NIMG];
-  long long goff[NIMG];
-  int ntot = 0;
-#pragma unroll
-  for (int i = 0; i < NIMG; ++i) {
-    const int sc = min(s0 + i, B - 1);
-    srow[i] = idx ? idx[sc] : sc;
-  }
-#pragma unroll
-  for (int i = 0; i < NIMG; ++i) {
-    const int sidx = s0 + i;
-    un[i] = 0; dbase[i] = 0; goff[i] = 0; shift[i] = 0;
-    if (sidx <= slast) {
-      const int lo = max(p0, sidx * OHOW) - sidx * OHOW, hi = min(p1, (sidx + 1) * OHOW) - 1 - sidx * OHOW;
-      const int blo = S * (lo / OW) * Wrow, bhi = (S * (hi / OW) + KH) * Wrow;
-      const int ul = blo >> 4;
-      un[i] = ((bhi + 15) >> 4) - ul;
-      goff[i] = (long long)srow[i] * (long long)HWC + (long long)ul * 16;
-      dbase[i] = ntot * 16;
-      shift[i] = (ntot - ul) * 16;          // LDS byte of the stack's byte o: shift + o
-    }
-    ntot += un[i];
-  }
-  for (int base = 0; base < ntot; base += NT * U) {
-    uint4 v[U];
-    int dsto[U];
-#pragma unroll
-    for (int q = 0; q < U; ++q) {
-      int u = base + t + NT * q;
-      const bool ok = u < ntot;
-      u = ok ? u : 0;
-      long long go = goff[0];
-      int db = dbase[0];
-#pragma unroll
-      for (int j = 0; j + 1 < NIMG; ++j) {
-        int cum = 0;
-#pragma unroll
-        for (int k = 0; k <= j; ++k) cum += un[k];
-        if (u >= cum) { go = goff[j + 1] - (long long)cum * 16; db = dbase[j + 1] - cum * 16; }
-      }
-      v[q] = *reinterpret_cast<const uint4*>(in + go + (long long)u * 16);
-      dsto[q] = db + u * 16;
-    }
-#pragma unroll
-    for (int q = 0; q < U; ++q) *reinterpret_cast<uint4*>(limg + dsto[q]) = v[q];
-  }
-}
-
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ i32x2 lds_read_tr8(const uint8_t* p) {
   return __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(p));
@@ -752,24 +791,6 @@ __global__ __launch_bounds__(512, 2) void conv_u8c4k8_wgrad_flat_kernel(const C1
   }
   XT_TL(4);
   XT_TL_DRAIN(5);
-}
-
-// bytes of packed input rows the largest 512-position range of the launch stages (host side)
-static int c1_packed_cap(int B, int OH, int OW, int S, int KH, int Wrow, int PB) {
-  const int OHOW = OH * OW, total = B * OHOW;
-  int cap = 0;
-  for (int p0 = 0; p0 < total; p0 += PB) {
-    const int p1 = total < p0 + PB ? total : p0 + PB;
-    int units = 0;
-    for (int sidx = p0 / OHOW; sidx <= (p1 - 1) / OHOW; ++sidx) {
-      const int lo = (p0 > sidx * OHOW ? p0 : sidx * OHOW) - sidx * OHOW;
-      const int hi = (p1 < (sidx + 1) * OHOW ? p1 : (sidx + 1) * OHOW) - 1 - sidx * OHOW;
-      const int blo = S * (lo / OW) * Wrow, bhi = (S * (hi / OW) + KH) * Wrow;
-      units += ((bhi + 15) >> 4) - (blo >> 4);
-    }
-    if (units * 16 > cap) cap = units * 16;
-  }
-  return cap;
 }
 
 XT_TL_SETTER(conv1)
