@@ -47,5 +47,8 @@ SWEEP = [{}, {"reduce_z_lanes": 16}, {"reduce_z_lanes": 32}, {"reduce_z_lanes": 
          {"wgrad_split_target": 640}, {"wgrad_split_target": 768}, {"bwd_fit_slots": 0}, {"bwd_fit_slots": 640},
          {"fwd_split_target": 192}, {"fwd_split_target": 320}, {"direct_waves": 1024}, {"direct_waves": 2048},
          {"direct_max_waves": 4}, {"dgrad_halo": 0}, {"fwd_two_groups": 0}, {"defer_splitk": 0}, {}]
+if len(sys.argv) > 1:          # python tools/ppo_sweep.py '[{}, {"direct_fwd": 0}]'
+    import json
+    SWEEP = json.loads(sys.argv[1])
 for knobs in SWEEP:
     print("%-32s %8.3f ms/update" % (knobs, run(knobs)), flush=True)

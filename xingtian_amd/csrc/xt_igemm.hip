@@ -141,7 +141,27 @@ struct FwdArgs {
 // KG = 2: the block has two 4-wave groups that split the reduction range in halves, each with its own LDS
 // stages (same barriers), combined through LDS at the end: halves the dependent step chain of kernels that have
 // too few blocks to fill the chip (<= 1 block per CU) without partial buffers or a finish launch.
-template <int BI, int BJ, int WI, int WJ, bool U8, bool PADDED, int KG>
+//
+// X6 ("bf16x6", fp32 layers only): both operands are split into three bf16 planes when they are written to LDS and
+// every 16-deep chunk is six v_mfma_f32_32x32x16_bf16 (see igemm_dgrad4_body for the arithmetic).  A (reduction axis
+// contiguous in memory) lands in operand order [plane][chunk][k half][row][8 bf16] -> one ds_read_b128 per operand.
+// B = W[k][n] (n contiguous) stays in its NATURAL orientation [plane][k][n] -- the split writes are 8 bytes, no
+// transposition through scalar writes -- and the operand (8 consecutive k of one column) is gathered by two
+// ds_read_b64_tr_b16: in every 16-lane group lanes 4j..4j+3 supply the address of 16 columns of row j and lane c
+// receives column c of the four rows (semantics measured with tools/tr_probe.hip).  Row stride 160 B: the four rows of
+// a read fall into disjoint bank ranges.
+constexpr int kX6SlotA = 64 * 16 + 32;                  // bytes per (plane, chunk, k half) slot of 64 rows
+constexpr int kX6RowB = 64 * 2 + 32, kX6PlaneB = 32 * kX6RowB;
+constexpr int kX6Stage = 12 * kX6SlotA + 3 * kX6PlaneB; // bytes per LDS stage
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 lds_read_tr16x2(const uint8_t* p, int second_off) {
+  union { i16x4 h[2]; bf16x8 v; } u;
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(p));
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(p + second_off));
+  return u.v;
+}
+
+template <int BI, int BJ, int WI, int WJ, bool U8, bool PADDED, int KG, bool X6 = false>
 __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
   constexpr int TI = BI / (32 * WI), TJ = BJ / (32 * WJ);
   constexpr int SA = BI + 1, SB = BJ;
@@ -149,7 +169,8 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
   constexpr int CPRB = BJ / 4;           // float4 groups per B row
   constexpr int RPB = 256 / CPRB;        // B rows per pass
   constexpr int NB = 32 / RPB;
-  constexpr int BUF = 32 * SA + 32 * SB; // one LDS stage (A then B); two stages, one barrier per step
+  static_assert(!X6 || (BI == 64 && BJ == 64 && !U8), "igemm_fwd: the bf16x6 form is built for 64x64 fp32 tiles");
+  constexpr int BUF = X6 ? kX6Stage / 4 : 32 * SA + 32 * SB; // one LDS stage (A then B); two stages, one barrier per step
   __shared__ __attribute__((aligned(16))) float smem_all[2 * BUF * KG];
   const Geom& g = p.g;
   const int grp = (KG == 1) ? 0 : (int)(threadIdx.x >> 8);
@@ -204,6 +225,18 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
     }
   };
   auto stash = [&](const Regs& R, float* As, float* Bs) {
+    if constexpr (X6) {
+      uint8_t* Ap = reinterpret_cast<uint8_t*>(As);             // k = 4*c4 + e -> slot (c4 >> 1) = chunk*2 + k half
+      uint8_t* Bp = Ap + 12 * kX6SlotA;
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        split3_store(Ap + (r0 + 32 * i) * 16 + (c4 >> 1) * kX6SlotA + (c4 & 1) * 8, 4 * kX6SlotA,
+                     cook4<U8>(R.a[i], (R.ok >> i) & 1u, g.xs, g.xb));
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        split3_store(Bp + (rb + RPB * i) * kX6RowB + cb * 8, kX6PlaneB, sel4((R.ok >> (8 + i)) & 1u, R.b[i]));
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int r = r0 + 32 * i;
@@ -228,6 +261,34 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
 
   const int wi = wave / WJ, wj = wave % WJ;
   const int nsteps = kend > kbeg ? (kend - kbeg + 31) / 32 : 0;      // this group's steps (<= nsteps_all)
+  auto mma = [&](const float* stage) {
+    if constexpr (X6) {
+      const uint8_t* Ap = reinterpret_cast<const uint8_t*>(stage);
+      const uint8_t* Bp = Ap + 12 * kX6SlotA;
+      const int kl = lane >> 5, il = lane & 31, c16 = lane & 15;
+      const uint8_t* bq = Bp + (8 * kl + (c16 >> 2)) * kX6RowB + (wj * TJ * 32 + ((lane >> 4) & 1) * 16 + 4 * (c16 & 3)) * 2;
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        bf16x8 a[TI][3], b[TJ][3];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            a[ti][pl] = *reinterpret_cast<const bf16x8*>(Ap + (pl * 4 + ch * 2 + kl) * kX6SlotA + ((wi * TI + ti) * 32 + il) * 16);
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            b[tj][pl] = lds_read_tr16x2(bq + pl * kX6PlaneB + ch * 16 * kX6RowB + tj * 64, 4 * kX6RowB);
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < TJ; ++tj) acc[ti][tj] = mfma_bf16x6(a[ti], b[tj], acc[ti][tj]);
+      }
+    } else {
+      mma_tile<TI, TJ, SA, SB>(stage, stage + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+    }
+  };
   Regs R0, R1;
   if (nsteps > 0) fetch(kbeg, R0);
   if (nsteps > 1) fetch(kbeg + 32, R1);
@@ -237,13 +298,12 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
     __syncthreads();
     if (s == 0) XT_TL(2);
     if (s + 2 < nsteps) fetch(kbeg + (s + 2) * 32, R0);
-    if (s < nsteps) mma_tile<TI, TJ, SA, SB>(smem, smem + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+    if (s < nsteps) mma(smem);
     if (s + 1 < nsteps_all) {
       if (s + 1 < nsteps) stash(R1, smem + BUF, smem + BUF + 32 * SA);
       __syncthreads();
       if (s + 3 < nsteps) fetch(kbeg + (s + 3) * 32, R1);
-      if (s + 1 < nsteps)
-        mma_tile<TI, TJ, SA, SB>(smem + BUF, smem + BUF + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+      if (s + 1 < nsteps) mma(smem + BUF);
     }
   }
   if constexpr (KG == 2) {
@@ -1058,7 +1118,15 @@ int launch_fwd(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const vo
     else hipLaunchKernelGGL((igemm_fwd_kernel<BI, BJ, WI, WJ, false, false, KGV>), grid, blk, 0, st, a);             \
   } while (0)
 #define XT_FWD(BI, BJ, WI, WJ) do { if (kg2) XT_FWD2(BI, BJ, WI, WJ, 2); else XT_FWD2(BI, BJ, WI, WJ, 1); } while (0)
-  if (N <= 32) XT_FWD(128, 32, 4, 1); else XT_FWD(64, 64, 2, 2);
+#define XT_FWD6(KGV)                                                                                        \
+  do {                                                                                                      \
+    dim3 grid((M + 63) / 64, (N + 63) / 64, ksplit);                                                        \
+    if (pad) hipLaunchKernelGGL((igemm_fwd_kernel<64, 64, 2, 2, false, true, KGV, true>), grid, dim3(256 * KGV), 0, st, a);  \
+    else hipLaunchKernelGGL((igemm_fwd_kernel<64, 64, 2, 2, false, false, KGV, true>), grid, dim3(256 * KGV), 0, st, a);     \
+  } while (0)
+  if (N > 32 && !u8 && tuning().bf16x6) { if (kg2) XT_FWD6(2); else XT_FWD6(1); }
+  else if (N <= 32) XT_FWD(128, 32, 4, 1); else XT_FWD(64, 64, 2, 2);
+#undef XT_FWD6
 #undef XT_FWD
 #undef XT_FWD2
   XT_LAUNCH_CHECK();
