@@ -26,6 +26,7 @@ struct C1FwdArgs {
   int B, H, W, OH, OW, S, KH, act;
   float xs, xb;        // y = act(acc*xs + bias)   (xb must be 0 for this kernel)
   int img_cap;         // flattened form: LDS bytes of the bf16 image of the packed input rows (multiple of 16)
+  uint32_t* mask;      // flattened form, optional: one word per output position, bit n = (output channel n > 0)
 };
 
 constexpr int kC1TileSlots = 16;   // 32-pixel tile slots per workgroup -> OH*OW <= 512
@@ -417,11 +418,33 @@ __global__ __launch_bounds__(512, 2) void conv_u8c4k8_fwd_flat_kernel(const C1Fw
   for (int ti = 0; ti < SLOTS; ++ti) {
     const int pix0 = p0 + (wave + NW * ti) * 32;
     if (pix0 < p1) {
+      // relu (un-switched by hand: with the activation selected per element the loop kept a branch tree and a tanh
+      // CALL per value) + the sign mask of the outputs for the consumer's input gradient, which needs relu'(y) only
+      // -- one word per position instead of a 128-byte row: a ballot over the wave is the 32 channel bits of two rows
+      uint32_t mw = 0u;
+      if (p.act == XT_ACT_RELU) {
+        // word of row L lands in lane L: v_writelane_b32 moves the (wave-uniform) ballot halves into lanes row0 and
+        // row0 + 4 -- two instructions per ballot; selecting with per-lane compares took six
+#define XT_C1_RELU_ROW(r)                                                                                        \
+        {                                                                                                        \
+          constexpr int row0 = ((r) & 3) + 8 * ((r) >> 2);                                                       \
+          const float z = fmaf(acc[ti][r], p.xs, bias);                                                          \
+          const unsigned long long bal = __ballot(z > 0.f);                                                      \
+          tbuf[(row0 + 4 * h) * 36 + il] = z > 0.f ? z : 0.f;                                                    \
+          asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mw) : "s"((uint32_t)bal), "n"(row0));                \
+          asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mw) : "s"((uint32_t)(bal >> 32)), "n"(row0 + 4));    \
+        }
+        XT_C1_RELU_ROW(0) XT_C1_RELU_ROW(1) XT_C1_RELU_ROW(2) XT_C1_RELU_ROW(3)
+        XT_C1_RELU_ROW(4) XT_C1_RELU_ROW(5) XT_C1_RELU_ROW(6) XT_C1_RELU_ROW(7)
+        XT_C1_RELU_ROW(8) XT_C1_RELU_ROW(9) XT_C1_RELU_ROW(10) XT_C1_RELU_ROW(11)
+        XT_C1_RELU_ROW(12) XT_C1_RELU_ROW(13) XT_C1_RELU_ROW(14) XT_C1_RELU_ROW(15)
+#undef XT_C1_RELU_ROW
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        tbuf[row * 36 + il] = act_apply(fmaf(acc[ti][r], p.xs, bias), p.act);
+        for (int r = 0; r < 16; ++r)
+          tbuf[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + il] = act_apply(fmaf(acc[ti][r], p.xs, bias), p.act);
       }
+      if (p.mask && lane < 32 && pix0 + lane < p1) p.mask[pix0 + lane] = mw;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row = q * 8 + (lane >> 3), c4 = (lane & 7) * 4;
@@ -438,7 +461,9 @@ static int c1_waves() { return tuning().conv1_waves == 4 ? 4 : 8; }      // 4: t
 
 // returns 0 launched, 1 error, -1 geometry not handled by this kernel
 int launch_conv1_fwd_bf16x3(const xt_conv_geom* g, const xt_input_xform* xf, int B, const void* in,
-                            const int32_t* idx, const float* w, const float* bias, float* y, hipStream_t st) {
+                            const int32_t* idx, const float* w, const float* bias, float* y, hipStream_t st,
+                            uint32_t* relu_mask, int* mask_written) {
+  if (mask_written) *mask_written = 0;
   if (!xf || !xf->is_u8 || g->C != 4 || g->KW != 8 || g->N != 32 || g->PT != 0 || g->PL != 0) return -1;
   if ((g->OH - 1) * g->S + g->KH > g->H || (g->OW - 1) * g->S + g->KW > g->W) return -1;
   const int HWC = g->H * g->W * 4;
@@ -450,6 +475,7 @@ int launch_conv1_fwd_bf16x3(const xt_conv_geom* g, const xt_input_xform* xf, int
   a.B = B; a.H = g->H; a.W = g->W; a.OH = g->OH; a.OW = g->OW; a.S = g->S; a.KH = g->KH; a.act = g->act;
   const float mean = fabsf(xf->mean) >= 1e-4f ? xf->mean : 0.f;
   a.xs = 1.f / xf->std; a.xb = -mean * a.xs; a.img_cap = 0;
+  a.mask = (g->act == XT_ACT_RELU) ? relu_mask : nullptr;
   const int nw = c1_waves();
   size_t lds = (size_t)2 * g->KH * 3 * 64 * 16;                    // weight planes, reused by the output transpose
   if (lds < (size_t)nw * 32 * 36 * 4) lds = (size_t)nw * 32 * 36 * 4;
@@ -475,6 +501,7 @@ int launch_conv1_fwd_bf16x3(const xt_conv_geom* g, const xt_input_xform* xf, int
         if (two) hipLaunchKernelGGL(conv_u8c4k8_fwd_flat_kernel<2>, dim3((total + pb - 1) / pb), dim3(512), fl, st, a);
         else hipLaunchKernelGGL(conv_u8c4k8_fwd_flat_kernel<1>, dim3((total + pb - 1) / pb), dim3(512), fl, st, a);
         XT_LAUNCH_CHECK();
+        if (mask_written && a.mask) *mask_written = 1;
         return 0;
       }
     }

@@ -31,9 +31,10 @@ xt_tuning& tuning() {
 }
 
 int launch_fwd(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*, const float*,
-               const float*, float*, float*, int, hipStream_t, int* deferred_ksplit = nullptr);
+               const float*, float*, float*, int, hipStream_t, int* deferred_ksplit = nullptr,
+               uint32_t* relu_mask = nullptr, int* mask_written = nullptr);
 int launch_bwd_layer(const xt_conv_geom*, int, const float*, const float*, const float*, int, float*, float*, float*,
-                     int, const HeadWgArgs*, int*, hipStream_t);
+                     int, const HeadWgArgs*, int*, hipStream_t, const uint32_t* xmask = nullptr);
 int launch_wgrad(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*, const float*,
                  float*, float*, int, hipStream_t, int reduce_now = 1, int* msplit_out = nullptr, int slab_cap = 0);
 int launch_dgrad(const xt_conv_geom*, int, const float*, const float*, const float*, int, float*, hipStream_t);
@@ -67,6 +68,8 @@ struct Layer {
   int64_t part_off;            // split-K partials of a trunk's last layer (deferred finish), else -1
   int last_msplit, last_ksplit;
   int slab_cap;                // number of slabs the region can hold
+  int64_t mask_off;            // relu sign mask of this layer's output (one word per position), else -1
+  int mask_valid;              // the last forward of this layer wrote the mask
 };
 
 static inline int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
@@ -142,10 +145,12 @@ static int net_forward(xt_net* n, const void* obs, const int32_t* idx, int B, bo
       const bool first = (l == n->t_begin[tr]);
       const bool defer = defer_last && (l == n->t_end[tr] - 1) && L.part_off >= 0;
       L.last_ksplit = 1;
+      L.mask_valid = 0;
       if (int rc = launch_fwd(&L.g, first ? &n->xf : nullptr, B, x, first ? idx : nullptr, n->params + L.poff,
                               n->params + L.poff + (int64_t)L.K * L.g.N, n->ws + L.act_off,
                               n->ws + (defer ? L.part_off : n->off_partial), fwd_split(L, B), st,
-                              defer ? &L.last_ksplit : nullptr))
+                              defer ? &L.last_ksplit : nullptr,
+                              L.mask_off >= 0 ? reinterpret_cast<uint32_t*>(n->ws + L.mask_off) : nullptr, &L.mask_valid))
         return rc;
       x = n->ws + L.act_off;
     }
@@ -207,7 +212,8 @@ static int trunk_backward(xt_net* n, const void* obs, const int32_t* idx, int B,
       }
       if (int rc = launch_bwd_layer(&L.g, B, n->ws + Lprev.act_off, n->ws + L.dact_off, n->params + L.poff,
                                     Lprev.g.act, n->ws + Lprev.dact_off, n->grads + L.poff, n->ws + L.slab_off,
-                                    wgrad_split(L, B), hwp, &L.last_msplit, st))
+                                    wgrad_split(L, B), hwp, &L.last_msplit, st,
+                                    Lprev.mask_valid ? reinterpret_cast<const uint32_t*>(n->ws + Lprev.mask_off) : nullptr))
         return rc;
     }
   return 0;
@@ -516,6 +522,11 @@ int xt_net_create(const xt_net_desc* d, int32_t max_batch, xt_net** out) {
     n->layers.back().last_msplit = 1;
     n->layers.back().last_ksplit = 1;
     n->layers.back().part_off = -1;
+    n->layers.back().mask_off = -1;
+    n->layers.back().mask_valid = 0;
+    if (i == n->t_begin[cur] && L.g.N == 32 && L.g.act == XT_ACT_RELU) {   // first-layer relu sign mask (see xt_conv1.hip)
+      n->layers.back().mask_off = off; off += xt::align4((int64_t)max_batch * L.OHOW);
+    }
   }
   for (int tr = 0; tr < d->n_trunks; ++tr) {   // deferred split-K partials of each trunk's last layer
     xt::Layer& L = n->layers[n->t_end[tr] - 1];
@@ -768,7 +779,8 @@ int xt_net_time_layer(xt_net* n, int32_t layer, int32_t which, const void* obs, 
     if (which == 0)
       return xt::launch_fwd(&L.g, first ? &n->xf : nullptr, B, x, first ? idx : nullptr, n->params + L.poff,
                             n->params + L.poff + (int64_t)L.K * L.g.N, n->ws + L.act_off, n->ws + n->off_partial,
-                            xt::fwd_split(L, B), st);
+                            xt::fwd_split(L, B), st, nullptr,
+                            L.mask_off >= 0 ? reinterpret_cast<uint32_t*>(n->ws + L.mask_off) : nullptr, &L.mask_valid);
     if (which == 1)
       return xt::launch_wgrad(&L.g, first ? &n->xf : nullptr, B, x, first ? idx : nullptr, n->ws + L.dact_off,
                               n->grads + L.poff, n->ws + L.slab_off, xt::wgrad_split(L, B), st, 0, &L.last_msplit,
@@ -777,7 +789,8 @@ int xt_net_time_layer(xt_net* n, int32_t layer, int32_t which, const void* obs, 
     if (which == 3)   // the fused per-layer backward launch (dgrad + wgrad) used by the update loop
       return xt::launch_bwd_layer(&L.g, B, n->ws + Lp.act_off, n->ws + L.dact_off, n->params + L.poff, Lp.g.act,
                                   n->ws + Lp.dact_off, n->grads + L.poff, n->ws + L.slab_off, xt::wgrad_split(L, B),
-                                  nullptr, &L.last_msplit, st);
+                                  nullptr, &L.last_msplit, st,
+                                  Lp.mask_valid ? reinterpret_cast<const uint32_t*>(n->ws + Lp.mask_off) : nullptr);
     return xt::launch_dgrad(&L.g, B, n->ws + L.dact_off, n->params + L.poff, n->ws + Lp.act_off, Lp.g.act,
                             n->ws + Lp.dact_off, st);
   };
