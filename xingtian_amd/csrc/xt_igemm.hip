@@ -110,8 +110,8 @@ __device__ __forceinline__ void mma_tile(const float* As, const float* Bs, int a
                                          f32x16 (&acc)[TI][TJ], int lane) {
   const int kl = lane >> 5, il = lane & 31;
 #pragma unroll
-  for (int kk = 0; kk < 16; ++kk) {
-    float a[TI], b[TJ];
+  for (int kk = 0; kk < 16; ++kk) {        // (reads of the whole step hoisted in front of the MFMAs: slower with three
+    float a[TI], b[TJ];                    //  co-resident waves per SIMD -- conv2/conv3/Dense bwd +1.1/+1.1/+1.3 us)
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti) a[ti] = As[(kk * 2 + kl) * SA + a_off + ti * 32 + il];
 #pragma unroll
@@ -1019,7 +1019,7 @@ struct BwdLayerArgs {
 // a kernel is the maximum over all of its paths: the generic form needs 144 VGPR (LDS-tiled dgrad) + 32 AGPR
 // (register-direct dgrad) = two workgroups per CU, this one three.
 template <int WBI, int WBJ, int WWI, int WWJ, bool WPAD, int DBI, int DBJ, int DWI, int DWJ, int D4 = 0, int HALO = 0>
-__global__ __launch_bounds__(256, (D4 || HALO) ? 3 : 1) void igemm_bwd_layer_kernel(const BwdLayerArgs p) {
+__global__ __launch_bounds__(256, 3) void igemm_bwd_layer_kernel(const BwdLayerArgs p) {
   constexpr int SMD = HALO == 2 ? 11 * 1024 : HALO == 1 ? 9 * 1024 : dgrad_smem_floats<DBI, DBJ>();
   constexpr int SM0 = wgrad_smem_floats<WBI, WBJ, WPAD>() > SMD ? wgrad_smem_floats<WBI, WBJ, WPAD>() : SMD;
   constexpr int SM = (D4 && dgrad4_smem_floats<D4 == 2>() > SM0) ? dgrad4_smem_floats<D4 == 2>() : SM0;
