@@ -590,16 +590,22 @@ struct DgradArgs {
   FastDiv d_hw[kMaxClasses], d_w[kMaxClasses];   // per class: divide by HC*WC and by WC (row decode without idiv)
 };
 
-template <int BI, int BJ>
-constexpr int dgrad_smem_floats() { return 2 * (32 * (BI + 1) + 32 * (BJ + 1)) + BI; }
+// X6 ("bf16x6"): both operands have the reduction axis contiguous in memory (dY rows along n, W rows along n), so both
+// go to LDS in MFMA operand order [plane][chunk][k half][row][8 bf16] with 8-byte split writes and are read back with
+// one ds_read_b128 per operand; six v_mfma_f32_32x32x16_bf16 per 16-deep chunk (see igemm_dgrad4_body).
+template <int BI, int BJ, bool X6 = false>
+constexpr int dgrad_smem_floats() {
+  return X6 ? 2 * (12 * (BI * 16 + 32) + 12 * (BJ * 16 + 32)) / 4 + BI : 2 * (32 * (BI + 1) + 32 * (BJ + 1)) + BI;
+}
 
-template <int BI, int BJ, int WI, int WJ>
+template <int BI, int BJ, int WI, int WJ, bool X6 = false>
 __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int bx, const int by, const int bz,
                                                  float* smem) {
   constexpr int TI = BI / (32 * WI), TJ = BJ / (32 * WJ);
   constexpr int SA = BI + 1, SB = BJ + 1;
   constexpr int NA = BI / 32, NB = BJ / 32;
-  constexpr int BUF = 32 * SA + 32 * SB;
+  constexpr int SLA = BI * 16 + 32, SLB = BJ * 16 + 32;      // X6: bytes per (plane, chunk, k half) slot
+  constexpr int BUF = X6 ? (12 * SLA + 12 * SLB) / 4 : 32 * SA + 32 * SB;
   int* rowOut = reinterpret_cast<int*>(smem + 2 * BUF);
   const Geom& g = p.g;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -674,6 +680,17 @@ __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int b
     }
   };
   auto stash = [&](const Regs& R, float* As, float* Bs) {
+    if constexpr (X6) {
+      uint8_t* Ap = reinterpret_cast<uint8_t*>(As);             // k = 4*c4 + e -> slot (c4 >> 1) = chunk*2 + k half
+      uint8_t* Bp = Ap + 12 * SLA;
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        split3_store(Ap + (r0 + 32 * i) * 16 + (c4 >> 1) * SLA + (c4 & 1) * 8, 4 * SLA, sel4((R.ok >> i) & 1u, R.a[i]));
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        split3_store(Bp + (r0 + 32 * i) * 16 + (c4 >> 1) * SLB + (c4 & 1) * 8, 4 * SLB, sel4((R.ok >> (8 + i)) & 1u, R.b[i]));
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int r = r0 + 32 * i;
@@ -723,17 +740,44 @@ __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int b
       }
     }
   XT_TL(1);
+  auto mma = [&](const float* stage) {
+    if constexpr (X6) {
+      const uint8_t* Ap = reinterpret_cast<const uint8_t*>(stage);
+      const uint8_t* Bp = Ap + 12 * SLA;
+      const int kl = lane >> 5, il = lane & 31;
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        bf16x8 a[TI][3], b[TJ][3];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            a[ti][pl] = *reinterpret_cast<const bf16x8*>(Ap + (pl * 4 + ch * 2 + kl) * SLA + ((wi * TI + ti) * 32 + il) * 16);
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            b[tj][pl] = *reinterpret_cast<const bf16x8*>(Bp + (pl * 4 + ch * 2 + kl) * SLB + ((wj * TJ + tj) * 32 + il) * 16);
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < TJ; ++tj) acc[ti][tj] = mfma_bf16x6(a[ti], b[tj], acc[ti][tj]);
+      }
+    } else {
+      mma_tile<TI, TJ, SA, SB>(stage, stage + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+    }
+  };
   for (int s = 0; s < nsteps; s += 2) {
     stash(R0, smem, smem + 32 * SA);
     __syncthreads();
     if (s == 0) XT_TL(2);
     if (s + 2 < nsteps) fetch((s + 2) * 32, R0);
-    mma_tile<TI, TJ, SA, SB>(smem, smem + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+    mma(smem);
     if (s + 1 < nsteps) {
       stash(R1, smem + BUF, smem + BUF + 32 * SA);
       __syncthreads();
       if (s + 3 < nsteps) fetch((s + 3) * 32, R1);
-      mma_tile<TI, TJ, SA, SB>(smem + BUF, smem + BUF + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+      mma(smem + BUF);
     }
   }
   XT_TL(3);
@@ -994,10 +1038,10 @@ __device__ __forceinline__ void igemm_dgrad4_body(const DgradArgs& p, const int 
   XT_TL_DRAIN(5);
 }
 
-template <int BI, int BJ, int WI, int WJ>
+template <int BI, int BJ, int WI, int WJ, bool X6 = false>
 __global__ __launch_bounds__(256) void igemm_dgrad_kernel(const DgradArgs p) {
-  __shared__ __attribute__((aligned(16))) float smem[dgrad_smem_floats<BI, BJ>()];
-  igemm_dgrad_body<BI, BJ, WI, WJ>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+  __shared__ __attribute__((aligned(16))) float smem[dgrad_smem_floats<BI, BJ, X6>()];
+  igemm_dgrad_body<BI, BJ, WI, WJ, X6>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 // ------------------------------------------------------------------ fused backward of one layer
@@ -1018,9 +1062,10 @@ struct BwdLayerArgs {
 // HALO = true: the input-gradient blocks are halo_dgrad_body, selected at COMPILE time.  The register allocation of
 // a kernel is the maximum over all of its paths: the generic form needs 144 VGPR (LDS-tiled dgrad) + 32 AGPR
 // (register-direct dgrad) = two workgroups per CU, this one three.
-template <int WBI, int WBJ, int WWI, int WWJ, bool WPAD, int DBI, int DBJ, int DWI, int DWJ, int D4 = 0, int HALO = 0>
+template <int WBI, int WBJ, int WWI, int WWJ, bool WPAD, int DBI, int DBJ, int DWI, int DWJ, int D4 = 0, int HALO = 0,
+          bool DX6 = false>
 __global__ __launch_bounds__(256, 3) void igemm_bwd_layer_kernel(const BwdLayerArgs p) {
-  constexpr int SMD = HALO == 2 ? 11 * 1024 : HALO == 1 ? 9 * 1024 : dgrad_smem_floats<DBI, DBJ>();
+  constexpr int SMD = HALO == 2 ? 11 * 1024 : HALO == 1 ? 9 * 1024 : dgrad_smem_floats<DBI, DBJ, DX6>();
   constexpr int SM0 = wgrad_smem_floats<WBI, WBJ, WPAD>() > SMD ? wgrad_smem_floats<WBI, WBJ, WPAD>() : SMD;
   constexpr int SM = (D4 && dgrad4_smem_floats<D4 == 2>() > SM0) ? dgrad4_smem_floats<D4 == 2>() : SM0;
   __shared__ __attribute__((aligned(16))) float smem[SM];
@@ -1047,7 +1092,7 @@ __global__ __launch_bounds__(256, 3) void igemm_bwd_layer_kernel(const BwdLayerA
       return;
     }
     const int bx = b % p.dg_gx, r = b / p.dg_gx;
-    igemm_dgrad_body<DBI, DBJ, DWI, DWJ>(p.dg, bx, r % p.dg_gy, r / p.dg_gy, smem);
+    igemm_dgrad_body<DBI, DBJ, DWI, DWJ, DX6>(p.dg, bx, r % p.dg_gy, r / p.dg_gy, smem);
     return;
   }
   b -= p.n_dg;
@@ -1223,12 +1268,15 @@ int launch_dgrad(const xt_conv_geom* cg, int B, const float* dy, const float* w,
   if (int rc = fill_class_divs(g, &a)) return rc;
   const int hc = (g.H + g.S - 1) / g.S, wc = (g.W + g.S - 1) / g.S;   // upper bound on class extent
   const int mc = B * hc * wc;
+  const bool x6 = tuning().bf16x6 != 0;
   if (g.C <= 32) {
     dim3 grid((mc + 127) / 128, (g.C + 31) / 32, g.S * g.S);
-    hipLaunchKernelGGL((igemm_dgrad_kernel<128, 32, 4, 1>), grid, dim3(256), 0, st, a);
+    if (x6) hipLaunchKernelGGL((igemm_dgrad_kernel<128, 32, 4, 1, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((igemm_dgrad_kernel<128, 32, 4, 1>), grid, dim3(256), 0, st, a);
   } else {
     dim3 grid((mc + 63) / 64, (g.C + 63) / 64, g.S * g.S);
-    hipLaunchKernelGGL((igemm_dgrad_kernel<64, 64, 2, 2>), grid, dim3(256), 0, st, a);
+    if (x6) hipLaunchKernelGGL((igemm_dgrad_kernel<64, 64, 2, 2, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((igemm_dgrad_kernel<64, 64, 2, 2>), grid, dim3(256), 0, st, a);
   }
   XT_LAUNCH_CHECK();
   return 0;
@@ -1320,12 +1368,18 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
   }
   const int total = a.n_wg + a.n_dg + a.n_hw;
   const bool pad = is_padded(g);
+  const bool dx6 = tuning().bf16x6 != 0 && a.dg_direct == 0;     // LDS-tiled input gradient on the bf16 matrix cores
+#define XT_BWD2(WBI, WBJ, WWI, WWJ, DBI, DBJ, DWI, DWJ, X6V)                                                    \
+  do {                                                                                                          \
+    if (pad) hipLaunchKernelGGL((igemm_bwd_layer_kernel<WBI, WBJ, WWI, WWJ, true, DBI, DBJ, DWI, DWJ, 0, 0, X6V>), \
+                                dim3(total), dim3(256), 0, st, a);                                              \
+    else hipLaunchKernelGGL((igemm_bwd_layer_kernel<WBI, WBJ, WWI, WWJ, false, DBI, DBJ, DWI, DWJ, 0, 0, X6V>),  \
+                            dim3(total), dim3(256), 0, st, a);                                                  \
+  } while (0)
 #define XT_BWD(WBI, WBJ, WWI, WWJ, DBI, DBJ, DWI, DWJ)                                                          \
   do {                                                                                                          \
-    if (pad) hipLaunchKernelGGL((igemm_bwd_layer_kernel<WBI, WBJ, WWI, WWJ, true, DBI, DBJ, DWI, DWJ>),         \
-                                dim3(total), dim3(256), 0, st, a);                                              \
-    else hipLaunchKernelGGL((igemm_bwd_layer_kernel<WBI, WBJ, WWI, WWJ, false, DBI, DBJ, DWI, DWJ>),            \
-                            dim3(total), dim3(256), 0, st, a);                                                  \
+    if (dx6) XT_BWD2(WBI, WBJ, WWI, WWJ, DBI, DBJ, DWI, DWJ, true);                                             \
+    else XT_BWD2(WBI, WBJ, WWI, WWJ, DBI, DBJ, DWI, DWJ, false);                                                \
   } while (0)
   if (halo_inst) {
     const int hx6 = tuning().bf16x6;     // 0: fp32 MFMA (A/B)
@@ -1344,6 +1398,7 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
   else if (dsmall) XT_BWD(64, 64, 2, 2, 128, 32, 4, 1);
   else XT_BWD(64, 64, 2, 2, 64, 64, 2, 2);
 #undef XT_BWD
+#undef XT_BWD2
   XT_LAUNCH_CHECK();
   return 0;
 }
