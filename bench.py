@@ -230,31 +230,29 @@ def cpu_baseline_impala(w, data, max_seconds=5.0):
 # ------------------------------------------------------------------------------------------------ GPU measurements
 def layer_rooflines(net, spec, rows, obs, idx, x6=True):
     """Every layer kernel of one SGD step timed live with HIP events on the launch stream (xt_net_time_layer);
-    algorithmic FLOPs = 2*M*N*K per GEMM.  Returns {label: (ms, flops, arithmetic kind)}."""
+    algorithmic FLOPs = 2*M*N*K per GEMM.  The arithmetic kind a launch is priced against is
+    what the library reports for it (xt_last_launch_arith: fp32 MFMA, bf16x3 first-layer kernels, bf16x6, or a fused
+    backward launch with an fp32 weight-gradient half and a bf16x6 input-gradient half).
+    Returns {label: (ms, flops, arithmetic kind)}."""
+    from xingtian_amd import lib as L
+    handle = L.load()
+    names = {0: "fp32", 1: "bf16x3", 2: "bf16x6", 3: "fp32+bf16x6"}
     kern = {}
     for li, lay in enumerate(spec.layers):
         mnk2 = 2.0 * rows * lay.OH * lay.OW * lay.N * lay.K
-        first = li == 0
-        # the bf16x3 first-layer kernels (xt_conv1.hip: uint8 NHWC C=4, 8x8 VALID -> 32 channels, mean 0)
-        u8c4 = bool(first and spec.input_xform[0] and lay.C == 4 and lay.KH == 8 and lay.N == 32 and lay.PT == 0
-                    and spec.input_xform[1] == 0.0)
-        kern["L%d %s fwd" % (li, lay.name)] = (net.time_layer(li, 0, obs, idx, rows, 50), mnk2, "bf16x3" if u8c4 else "fp32")
-        if first:
-            kern["L0 %s wgrad" % lay.name] = (net.time_layer(0, 1, obs, idx, rows, 50), mnk2, "bf16x3" if u8c4 else "fp32")
+        ms = net.time_layer(li, 0, obs, idx, rows, 50)
+        kern["L%d %s fwd" % (li, lay.name)] = (ms, mnk2, names[int(handle.xt_last_launch_arith())])
+        if li == 0:
+            ms = net.time_layer(0, 1, obs, idx, rows, 50)
+            kern["L0 %s wgrad" % lay.name] = (ms, mnk2, names[int(handle.xt_last_launch_arith())])
         else:
-            # conv backward launches: the input-gradient half runs bf16x6 (six bf16 MFMAs per 16-deep chunk), the
-            # weight-gradient half fp32 MFMA -> peak of the launch = harmonic mean of the two halves' peaks
-            # (xt_igemm.hip launch_bwd_layer: the all-classes stride-2 form needs VALID, C = N = 32 and even extents;
-            # the halo-staged stride-1 form a small map)
-            valid = lay.PT == 0 and lay.PL == 0 and (lay.OH - 1) * lay.S + lay.KH <= lay.H
-            s2 = lay.S == 2 and lay.C == 32 and lay.N == 32 and lay.H % 2 == 0 and lay.KH % 2 == 0
-            s1 = lay.S == 1 and lay.KH > 1 and lay.H * lay.W <= 128 and rows * lay.H * lay.W > 512 * 64
-            kind = "fp32+bf16x6" if (x6 and valid and (s2 or s1)) else "fp32"
-            kern["L%d %s dgrad+wgrad" % (li, lay.name)] = (net.time_layer(li, 3, obs, idx, rows, 50), 2 * mnk2, kind)
+            ms = net.time_layer(li, 3, obs, idx, rows, 50)
+            kern["L%d %s dgrad+wgrad" % (li, lay.name)] = (ms, 2 * mnk2, names[int(handle.xt_last_launch_arith())])
     return kern
 
 
-PEAK = {"fp32": FP32_MFMA_PEAK_TFLOPS, "bf16x3": BF16_MFMA_PEAK_TFLOPS / 3.0,
+# peak of a fused backward launch = harmonic mean of its two halves' peaks (equal FLOPs in each half)
+PEAK = {"fp32": FP32_MFMA_PEAK_TFLOPS, "bf16x3": BF16_MFMA_PEAK_TFLOPS / 3.0, "bf16x6": BF16_MFMA_PEAK_TFLOPS / 6.0,
         "fp32+bf16x6": 2.0 / (1.0 / FP32_MFMA_PEAK_TFLOPS + 6.0 / BF16_MFMA_PEAK_TFLOPS)}
 
 
@@ -262,18 +260,18 @@ PEAK = {"fp32": FP32_MFMA_PEAK_TFLOPS, "bf16x3": BF16_MFMA_PEAK_TFLOPS / 3.0,
 # rocprofv3 --pmc summaries (profiles/r02_pmc_<workload>.json, tools/profile_round.sh)
 KERNEL_OF = {
     "ppo": {"L0 shared_conv_layer_0 fwd": "conv_u8c4k8_fwd_flat_kernel", "L0 shared_conv_layer_0 wgrad": "conv_u8c4k8_wgrad_flat_kernel",
-            "L1 shared_conv_layer_1 fwd": "direct_fwd_kernel<1, 1, false, 512>",
-            "L1 shared_conv_layer_1 dgrad+wgrad": "igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, 2, 0>",
-            "L2 shared_conv_layer_2 fwd": "igemm_fwd_kernel<64, 64, 2, 2, false, false, 2>",
-            "L2 shared_conv_layer_2 dgrad+wgrad": "igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1, 0, 2>",
-            "L3 shared_hidden_mlp_0 fwd": "igemm_fwd_kernel<64, 64, 2, 2, false, false, 2>",
-            "L3 shared_hidden_mlp_0 dgrad+wgrad": "igemm_bwd_layer_kernel<64, 64, 2, 2, false, 64, 64, 2, 2, 0, 0>"},
-    "impala": {"L0 explore_agent/conv2d fwd": "igemm_fwd_kernel<128, 32, 4, 1, true, true, 1>",
-               "L0 explore_agent/conv2d wgrad": "igemm_wgrad_kernel<128, 32, 4, 1, true, true>",
-               "L1 explore_agent/conv2d_1 fwd": "direct_fwd_kernel<1, 1, true, 512>",
-               "L1 explore_agent/conv2d_1 dgrad+wgrad": "igemm_bwd_layer_kernel<128, 32, 4, 1, true, 128, 32, 4, 1, 0, 0>",
+            "L1 shared_conv_layer_1 fwd": "direct_fwd_kernel<1, 1, false, 512",
+            "L1 shared_conv_layer_1 dgrad+wgrad": "igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, 2, 0",
+            "L2 shared_conv_layer_2 fwd": "igemm_fwd_kernel<64, 64, 2, 2, false, false, 2",
+            "L2 shared_conv_layer_2 dgrad+wgrad": "igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1, 0, 2",
+            "L3 shared_hidden_mlp_0 fwd": "igemm_fwd_kernel<64, 64, 2, 2, false, false, 2",
+            "L3 shared_hidden_mlp_0 dgrad+wgrad": "igemm_bwd_layer_kernel<64, 64, 2, 2, false, 64, 64, 2, 2, 0, 0"},
+    "impala": {"L0 explore_agent/conv2d fwd": "igemm_fwd_kernel<128, 32, 4, 1, true, true, 1",
+               "L0 explore_agent/conv2d wgrad": "igemm_wgrad_kernel<128, 32, 4, 1, true, true",
+               "L1 explore_agent/conv2d_1 fwd": "direct_fwd_kernel<1, 1, true, 512",
+               "L1 explore_agent/conv2d_1 dgrad+wgrad": "igemm_bwd_layer_kernel<128, 32, 4, 1, true, 128, 32, 4, 1, 0, 0",
                "L2 explore_agent/conv2d_2 fwd": "igemm_fwd_kernel<64, 64, 2, 2, false, false",
-               "L2 explore_agent/conv2d_2 dgrad+wgrad": "igemm_bwd_layer_kernel<64, 64, 2, 2, false, 64, 64, 2, 2, 0, 0>"},
+               "L2 explore_agent/conv2d_2 dgrad+wgrad": "igemm_bwd_layer_kernel<64, 64, 2, 2, false, 64, 64, 2, 2, 0, 0"},
 }
 
 

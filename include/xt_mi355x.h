@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define XT_ABI_VERSION 6
+#define XT_ABI_VERSION 7
 
 #define XT_ACT_NONE 0
 #define XT_ACT_RELU 1
@@ -369,6 +369,14 @@ int xt_net_apply(xt_net* net, float lr, float beta1, float beta2, float eps, flo
  * output [B,OH,OW,N] (out4[0]), its d(pre-activation) buffer (out4[1]), its weight-gradient slabs (out4[2]) and
  * their capacity in slabs (out4[3]) */
 int xt_net_layer_offsets(const xt_net* net, int32_t layer, int64_t* out4);
+
+/* arithmetic of the most recent layer launch made through this library by the calling process (diagnostic, for
+ * bench.py's roofline: which matrix-core peak a timed kernel is priced against).  ABI >= 7. */
+#define XT_ARITH_FP32 0          /* v_mfma_f32_32x32x2_f32                                                     */
+#define XT_ARITH_BF16X3 1        /* uint8 x fp32 as 3 x v_mfma_f32_32x32x16_bf16 (first-layer kernels)          */
+#define XT_ARITH_BF16X6 2        /* fp32 x fp32 as 6 x v_mfma_f32_32x32x16_bf16                                 */
+#define XT_ARITH_FP32_BF16X6 3   /* fused backward launch: weight gradient fp32 MFMA, input gradient bf16x6     */
+int32_t xt_last_launch_arith(void);
 
 /* kernel-time probe: average duration (ms) of `reps` back-to-back launches of ONE layer kernel of the bound
  * network on `stream`, measured with HIP events on that stream (bench.py's roofline, tools/layer_bench.py). */

@@ -27,7 +27,7 @@ def test_cabi_library_loads_and_exports_every_header_symbol():
     for name in sorted(declared):
         assert hasattr(handle, name), "missing C-ABI symbol " + name
         assert name in lib.SIGNATURES, "no ctypes prototype for " + name
-    assert handle.xt_abi_version() == lib.ABI_VERSION == 6
+    assert handle.xt_abi_version() == lib.ABI_VERSION == 7
     assert handle.xt_build_arch() == b"gfx950"
 
 

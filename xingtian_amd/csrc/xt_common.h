@@ -10,7 +10,8 @@
 namespace xt {
 
 void set_error(const char* fmt, ...);
-xt_tuning& tuning();      // process-wide kernel-selection knobs (xt_tuning_get / xt_tuning_set); defined in xt_net.hip
+xt_tuning& tuning();
+int& last_arith();             // XT_ARITH_* of the most recent layer launch (diagnostic)      // process-wide kernel-selection knobs (xt_tuning_get / xt_tuning_set); defined in xt_net.hip
 
 #define XT_CHECK_HIP(expr)                                                                  \
   do {                                                                                      \

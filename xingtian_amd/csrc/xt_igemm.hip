@@ -1151,7 +1151,7 @@ int launch_fwd(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const vo
   if (mask_written) *mask_written = 0;
   if (use_bf16x3()) {     // uint8 first layer: exact 3-way bf16 split on the bf16 matrix cores
     const int rc = launch_conv1_fwd_bf16x3(cg, xf, B, in, idx, w, bias, y, st, relu_mask, mask_written);
-    if (rc >= 0) { if (deferred_ksplit) *deferred_ksplit = 1; return rc; }
+    if (rc >= 0) { last_arith() = XT_ARITH_BF16X3; if (deferred_ksplit) *deferred_ksplit = 1; return rc; }
   }
   FwdArgs a;
   if (int rc = make_geom(cg, xf, B, &a.g)) return rc;
@@ -1160,6 +1160,7 @@ int launch_fwd(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const vo
     const int rc = launch_fwd_direct(cg, xf, B, in, idx, w, bias, y, partial, ksplit, st, &ks);
     if (rc > 0) return rc;
     if (rc == 0) {
+      last_arith() = XT_ARITH_FP32;
       if (deferred_ksplit) *deferred_ksplit = ks;
       if (ks > 1 && !deferred_ksplit) {
         const int MN = a.g.M * a.g.N;
@@ -1199,6 +1200,7 @@ int launch_fwd(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const vo
     if (pad) hipLaunchKernelGGL((igemm_fwd_kernel<64, 64, 2, 2, false, true, KGV, true>), grid, dim3(256 * KGV), 0, st, a);  \
     else hipLaunchKernelGGL((igemm_fwd_kernel<64, 64, 2, 2, false, false, KGV, true>), grid, dim3(256 * KGV), 0, st, a);     \
   } while (0)
+  last_arith() = (N > 32 && !u8 && tuning().bf16x6) ? XT_ARITH_BF16X6 : XT_ARITH_FP32;
   if (N > 32 && !u8 && tuning().bf16x6) { if (kg2) XT_FWD6(2); else XT_FWD6(1); }
   else if (N <= 32) XT_FWD(128, 32, 4, 1); else XT_FWD(64, 64, 2, 2);
 #undef XT_FWD6
@@ -1221,10 +1223,11 @@ int launch_wgrad(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const 
   if (use_bf16x3() && slabs && !reduce_now && slab_cap >= B) {   // uint8 first layer: one slab per frame stack
     int ms = 0;
     const int rc = launch_conv1_wgrad_bf16x3(cg, xf, B, in, idx, dy, dwb, slabs, slab_cap, &ms, st);
-    if (rc >= 0) { if (msplit_out) *msplit_out = ms; return rc; }
+    if (rc >= 0) { last_arith() = XT_ARITH_BF16X3; if (msplit_out) *msplit_out = ms; return rc; }
   }
   WgradArgs a;
   if (int rc = make_geom(cg, xf, B, &a.g)) return rc;
+  last_arith() = XT_ARITH_FP32;
   const bool u8 = xf && xf->is_u8;
   a.in = in; a.idx = idx; a.dy = dy;
   if (msplit < 1) msplit = 1;
@@ -1269,6 +1272,7 @@ int launch_dgrad(const xt_conv_geom* cg, int B, const float* dy, const float* w,
   const int hc = (g.H + g.S - 1) / g.S, wc = (g.W + g.S - 1) / g.S;   // upper bound on class extent
   const int mc = B * hc * wc;
   const bool x6 = tuning().bf16x6 != 0;
+  last_arith() = x6 ? XT_ARITH_BF16X6 : XT_ARITH_FP32;
   if (g.C <= 32) {
     dim3 grid((mc + 127) / 128, (g.C + 31) / 32, g.S * g.S);
     if (x6) hipLaunchKernelGGL((igemm_dgrad_kernel<128, 32, 4, 1, true>), grid, dim3(256), 0, st, a);
@@ -1381,9 +1385,12 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
     if (dx6) XT_BWD2(WBI, WBJ, WWI, WWJ, DBI, DBJ, DWI, DWJ, true);                                             \
     else XT_BWD2(WBI, WBJ, WWI, WWJ, DBI, DBJ, DWI, DWJ, false);                                                \
   } while (0)
+  last_arith() = XT_ARITH_FP32;          // (register-direct input gradients and the x6 = 0 forms)
+  if (dx6 || (tuning().bf16x6 && a.dg_direct == 2)) last_arith() = XT_ARITH_FP32_BF16X6;
   if (halo_inst) {
     const int hx6 = tuning().bf16x6;     // 0: fp32 MFMA (A/B)
     const int nsamp = 63 / (g.H * g.W) + 2;
+    if (hx6 && (size_t)3 * (nsamp * g.OHOW + 1) * (g.N * 2 + 16) <= 44 * 1024) last_arith() = XT_ARITH_FP32_BF16X6;
     if (hx6 && (size_t)3 * (nsamp * g.OHOW + 1) * (g.N * 2 + 16) <= 44 * 1024)
       hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1, 0, 2>), dim3(total), dim3(256), 0, st, a);
     else

@@ -20,6 +20,7 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+int& last_arith() { static int a = 0; return a; }
 xt_tuning& tuning() {
   static xt_tuning t = {/*bf16x6*/ 1, /*dgrad_all_classes*/ 1, /*dgrad_tile64*/ 1, /*dgrad_halo*/ 1, /*bwd_own_instance*/ 1,
                         /*bwd_fit_slots*/ 768, /*conv1_bf16x3*/ 1, /*conv1_flat*/ 1, /*conv1_waves*/ 8,
@@ -461,6 +462,7 @@ static int impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int n
 extern "C" {
 
 int xt_abi_version(void) { return XT_ABI_VERSION; }
+int32_t xt_last_launch_arith(void) { return xt::last_arith(); }
 int xt_tuning_get(xt_tuning* out) {
   XT_REQUIRE(out, "xt_tuning_get: null argument");
   *out = xt::tuning();

@@ -29,7 +29,7 @@ class LayerDesc(Structure):
     _fields_ = [("g", ConvGeom), ("param_off", c_int64), ("trunk", c_int32)]
 
 
-ABI_VERSION = 6          # XT_ABI_VERSION of include/xt_mi355x.h
+ABI_VERSION = 7          # XT_ABI_VERSION of include/xt_mi355x.h
 ACTION_TYPE = {"Categorical": 0, "DiagGaussian": 1}
 
 
@@ -67,6 +67,7 @@ _P = c_void_p
 # name -> (restype, argtypes); every symbol include/xt_mi355x.h declares
 SIGNATURES = {
     "xt_abi_version": (c_int32, []),
+    "xt_last_launch_arith": (c_int32, []),
     "xt_last_error": (c_char_p, []),
     "xt_build_arch": (c_char_p, []),
     "xt_tuning_get": (c_int32, [POINTER(Tuning)]),
