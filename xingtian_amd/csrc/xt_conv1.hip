@@ -163,64 +163,11 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void conv_u8c4k8_fwd_bf16x3_kernel
   XT_TL_DRAIN(5);
 }
 
-// Stage the input rows that the output positions [p0, p1) of the flattened [B*OH*OW] range need: the range touches
-// at most NIMG frame stacks (first one = p0 / OHOW); stack i goes to LDS slot i at its own byte offsets.  All loads
-// of a pass are issued back to back (offsets relative to `in`, not per-stack pointers: a select between pointers
-// degrades to flat loads; unconditional LDS writes: a guarded one makes hipcc sink each load into its branch).
-template <int NIMG, int NT, int U>
-__device__ __forceinline__ void stage_position_range(const uint8_t* __restrict__ in, const int32_t* __restrict__ idx,
-                                                     int B, int HWC, int Wrow, int OHOW, int OW, int S, int KH, int p0,
-                                                     int p1, uint8_t* limg, int t) {
-  const int s0 = p0 / OHOW, slast = (p1 - 1) / OHOW;
-  int un[NIMG], dbase[NIMG], srow[NIMG];
-  long long goff[NIMG];
-  int ntot = 0;
-#pragma unroll
-  for (int i = 0; i < NIMG; ++i) {       // the (dependent) row-gather loads first, all in flight together
-    const int sc = min(s0 + i, B - 1);
-    srow[i] = idx ? idx[sc] : sc;
-  }
-#pragma unroll
-  for (int i = 0; i < NIMG; ++i) {
-    const int sidx = s0 + i;
-    un[i] = 0; dbase[i] = 0; goff[i] = 0;
-    if (sidx <= slast) {
-      const int lo = max(p0, sidx * OHOW) - sidx * OHOW, hi = min(p1, (sidx + 1) * OHOW) - 1 - sidx * OHOW;
-      const int blo = S * (lo / OW) * Wrow, bhi = (S * (hi / OW) + KH) * Wrow;
-      const int ul = blo >> 4;
-      un[i] = ((bhi + 15) >> 4) - ul;
-      goff[i] = (long long)srow[i] * (long long)HWC + (long long)ul * 16;
-      dbase[i] = i * HWC + ul * 16;
-    }
-    ntot += un[i];
-  }
-  for (int base = 0; base < ntot; base += NT * U) {
-    uint4 v[U];
-    int dsto[U];
-#pragma unroll
-    for (int q = 0; q < U; ++q) {
-      int u = base + t + NT * q;
-      const bool ok = u < ntot;
-      u = ok ? u : 0;
-      long long go = goff[0];
-      int db = dbase[0];
-#pragma unroll
-      for (int j = 0; j + 1 < NIMG; ++j) {
-        int cum = 0;
-#pragma unroll
-        for (int k = 0; k <= j; ++k) cum += un[k];
-        if (u >= cum) { go = goff[j + 1] - (long long)cum * 16; db = dbase[j + 1] - cum * 16; }
-      }
-      v[q] = *reinterpret_cast<const uint4*>(in + go + (long long)u * 16);
-      dsto[q] = db + u * 16;       // units past the end re-copy unit 0 (same bytes to the same place)
-    }
-#pragma unroll
-    for (int q = 0; q < U; ++q) *reinterpret_cast<uint4*>(limg + dsto[q]) = v[q];
-  }
-}
-
-// Packed form of stage_position_range: only the input rows the position range needs, the (<= NIMG) per-stack row
-// groups back to back; shift[i] + o is the LDS byte of byte o of stack i.  BF16: every byte is converted to bf16 on the
+// Stage the input rows that the output positions [p0, p1) of the flattened [B*OH*OW] range need (the range touches at
+// most NIMG frame stacks, first one = p0 / OHOW; minibatch row gather fused), the per-stack row groups packed back to
+// back.  All loads of a pass are issued back to back (offsets relative to `in`, not per-stack pointers: a select
+// between pointers degrades to flat loads; unconditional LDS writes: a guarded one makes hipcc sink each load into its
+// branch); shift[i] + o is the LDS byte of byte o of stack i.  BF16: every byte is converted to bf16 on the
 // way (exact), i.e. the image occupies 2 bytes per element and LDS byte = 2 * (shift + o).
 template <int NIMG, int NT, int U, bool BF16 = false>
 __device__ __forceinline__ void stage_position_rows_packed(const uint8_t* __restrict__ in, const int32_t* __restrict__ idx,
@@ -818,6 +765,502 @@ __global__ __launch_bounds__(512, 2) void conv_u8c4k8_wgrad_flat_kernel(const C1
   }
   XT_TL(4);
   XT_TL_DRAIN(5);
+}
+
+// ================================================================================================================
+// The same two kernels for the first layers of ImpalaCnnOpt (xt/model/impala/impala_cnn_opt.py:118-121,
+// atari_model.py:4-23): uint8 NHWC C = 4 -> NOUT = 16 channels, square KW x KW kernels at stride KW / 2 (8x8/4 on
+// 84x84 frames, 4x4/2 on 42x42), TF SAME padding.  They ran on the generic fp32 implicit-GEMM kernels before -- half
+// of every 32-column tile empty, 28-30 % of both IMPALA workloads.  Differences to the PpoCnn forms above:
+//  * SAME padding is made PHYSICAL in LDS: the staged image is the zero-padded one (row stride Wp = W + PL + PR pixels,
+//    zero rows above / below), so the loops are those of a VALID convolution on it -- no per-operand masks.  The region
+//    is zero-filled, then the real pixels are copied in as 8-byte pixel pairs (source rows are 8-byte aligned for even
+//    W; the destination is only pixel-aligned because of the left pad: two dword / two 8-byte LDS writes per pair);
+//  * NOUT = 16: the B operand (weights / dY) carries zeros in columns 16..31 of the 32x32x16 MFMA -- the bf16 matrix
+//    time is irrelevant here -- and the epilogues write NOUT-wide rows;
+//  * KW = 4: one 16-byte kernel row = one 16-deep step (the forward) and a 32-row k tile = TWO kernel rows (the weight
+//    gradient: the two 16-lane halves of a tr_b8 read address consecutive kernel rows instead of byte halves).
+struct C1sArgs {
+  const uint8_t* in;
+  const int32_t* idx;
+  const float* w;      // [KW*KW*4][NOUT]
+  const float* bias;   // [NOUT]
+  float* y;            // forward: [B*OH*OW][NOUT]
+  const float* dy;     // weight gradient: [B*OH*OW][NOUT] d(pre-activation)
+  float* out;          // weight gradient: [blocks][(K+1)*NOUT] partial slabs
+  int B, H, W, OH, OW, S, PT, PL, Wp, act;
+  float xs, mean;      // input transform (x - mean) * xs; mean is an integer in [0, 255]: (x - mean) is then exact in
+                       // bf16 (forward: the staged image holds x - mean, pads 0) and a pad pixel of value `mean` is a zero
+                       // of the normalised input (weight gradient: uint8 image with pads = mean, the constant term
+                       // -mean * xs * sum_p dY[p, n] is added to every row of the slab)
+  int img_cap;         // LDS bytes of the staged (padded) image: u8 form; the forward's bf16 image takes twice that
+};
+
+// Stage the zero-padded input rows of the position range [p0, p1): stack i's padded rows [ra, rb) go to LDS back to
+// back; shift[i] + (rp * Wp + cp) * 4 (+ channel) is the (u8-equivalent) LDS byte of padded pixel (rp, cp) of stack i;
+// BF16: LDS byte = 2 * that.  All global loads are issued before the zero fill and its barrier.
+template <int NIMG, int NT, int U, bool BF16>
+__device__ __forceinline__ void stage_rows_padded(const C1sArgs& p, int KH, int p0, int p1, uint8_t* limg, int t,
+                                                  int (&shift)[NIMG]) {
+  const int OHOW = p.OH * p.OW, HWC = p.H * p.W * 4, Wp4 = p.Wp * 4, W2 = p.W >> 1;
+  const int s0 = p0 / OHOW, slast = (p1 - 1) / OHOW;
+  int npair[NIMG], dst0[NIMG], srow[NIMG];
+  long long gbase[NIMG];
+  int seg = 0, ntot = 0;
+#pragma unroll
+  for (int i = 0; i < NIMG; ++i) {
+    const int sc = min(s0 + i, p.B - 1);
+    srow[i] = p.idx ? p.idx[sc] : sc;
+  }
+#pragma unroll
+  for (int i = 0; i < NIMG; ++i) {
+    const int sidx = s0 + i;
+    npair[i] = 0; dst0[i] = 0; gbase[i] = 0; shift[i] = 0;
+    if (sidx <= slast) {
+      const int lo = max(p0, sidx * OHOW) - sidx * OHOW, hi = min(p1, (sidx + 1) * OHOW) - 1 - sidx * OHOW;
+      const int ra = p.S * (lo / p.OW), rb = p.S * (hi / p.OW) + KH;          // padded rows [ra, rb)
+      shift[i] = seg - ra * Wp4;
+      const int rlo = max(ra - p.PT, 0), rhi = min(rb - p.PT, p.H);           // image rows inside
+      npair[i] = max(rhi - rlo, 0) * W2;
+      gbase[i] = (long long)srow[i] * (long long)HWC + (long long)rlo * p.W * 4;
+      dst0[i] = shift[i] + ((rlo + p.PT) * p.Wp + p.PL) * 4;
+      seg += (rb - ra) * Wp4;
+    }
+    ntot += npair[i];
+  }
+  uint2 v[U];
+  int dsto[U];
+#pragma unroll
+  for (int q = 0; q < U; ++q) {
+    int u = t + NT * q;
+    const bool ok = u < ntot;
+    u = ok ? u : 0;
+    long long gb = gbase[0];
+    int db = dst0[0], ul = u;
+#pragma unroll
+    for (int j = 0; j + 1 < NIMG; ++j) {
+      int cum = 0;
+#pragma unroll
+      for (int k = 0; k <= j; ++k) cum += npair[k];
+      if (u >= cum) { gb = gbase[j + 1]; db = dst0[j + 1]; ul = u - cum; }
+    }
+    v[q] = *reinterpret_cast<const uint2*>(p.in + gb + (long long)ul * 8);
+    const int row = ul / W2, cp = ul - row * W2;
+    dsto[q] = ok ? db + (row * p.Wp + 2 * cp) * 4 : -1;
+  }
+  // pad fill (and everything else), then the pixels
+  const int fill16 = ((BF16 ? 2 : 1) * seg + 15) >> 4;
+  const uint32_t fw = BF16 ? 0u : (uint32_t)p.mean * 0x01010101u;
+  for (int e = t; e < fill16; e += NT) reinterpret_cast<uint4*>(limg)[e] = make_uint4(fw, fw, fw, fw);
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < U; ++q) {
+    if (dsto[q] >= 0) {
+      if constexpr (BF16) {
+        BF8 b;
+        const uint32_t d0 = v[q].x, d1 = v[q].y;
+        const float m = p.mean;
+        b.u[0] = pack_hi16((float)(d0 & 0xffu) - m, (float)((d0 >> 8) & 0xffu) - m);
+        b.u[1] = pack_hi16((float)((d0 >> 16) & 0xffu) - m, (float)(d0 >> 24) - m);
+        b.u[2] = pack_hi16((float)(d1 & 0xffu) - m, (float)((d1 >> 8) & 0xffu) - m);
+        b.u[3] = pack_hi16((float)((d1 >> 16) & 0xffu) - m, (float)(d1 >> 24) - m);
+        *reinterpret_cast<uint2*>(limg + 2 * dsto[q]) = make_uint2(b.u[0], b.u[1]);
+        *reinterpret_cast<uint2*>(limg + 2 * dsto[q] + 8) = make_uint2(b.u[2], b.u[3]);
+      } else {
+        *reinterpret_cast<uint32_t*>(limg + dsto[q]) = v[q].x;
+        *reinterpret_cast<uint32_t*>(limg + dsto[q] + 4) = v[q].y;
+      }
+    }
+  }
+}
+
+// padded-image bytes (u8 form) of the largest PB-position range of the launch (host side)
+static int c1_padded_cap(int B, int OH, int OW, int S, int KH, int Wp, int PB) {
+  const int OHOW = OH * OW, total = B * OHOW;
+  int cap = 0;
+  for (int p0 = 0; p0 < total; p0 += PB) {
+    const int p1 = total < p0 + PB ? total : p0 + PB;
+    int bytes = 0;
+    for (int sidx = p0 / OHOW; sidx <= (p1 - 1) / OHOW; ++sidx) {
+      const int lo = (p0 > sidx * OHOW ? p0 : sidx * OHOW) - sidx * OHOW;
+      const int hi = (p1 < (sidx + 1) * OHOW ? p1 : (sidx + 1) * OHOW) - 1 - sidx * OHOW;
+      bytes += (S * (hi / OW) + KH - S * (lo / OW)) * Wp * 4;
+    }
+    if (bytes > cap) cap = bytes;
+  }
+  return (cap + 15) & ~15;
+}
+
+template <int SLOTS, int KW, int NOUT>
+__global__ __launch_bounds__(512, 2) void conv_u8c4_same_fwd_kernel(const C1sArgs p) {
+  constexpr int NW = 8, NT = 512, PB = 32 * NW * SLOTS, NIMG = SLOTS == 2 ? 3 : 2, NS = KW * KW / 4, U = SLOTS == 2 ? 14 : 8;
+  extern __shared__ __attribute__((aligned(16))) uint8_t limg[];
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int OHOW = p.OH * p.OW, WrowP = p.Wp * 4;
+  const int total = p.B * OHOW;
+  const int p0 = blockIdx.x * PB, p1 = min(total, p0 + PB);
+  uint4* wpl = reinterpret_cast<uint4*>(limg + 2 * p.img_cap);     // [NS][3 planes][64 lanes] x 16 B
+  XT_TL(0);
+  XT_TL_ROLE(40);
+  // weights: slot = (step, lane (n = il, k half h)): k = 16 * step + 8 h + j, columns >= NOUT are zero
+  constexpr int WQ = (NS * 64 + NT - 1) / NT;
+  float wv[WQ][8];
+#pragma unroll
+  for (int q = 0; q < WQ; ++q) {
+    const int slot = t + NT * q;
+    const int sc = slot < NS * 64 ? slot : 0;
+    const int n = sc & 31, k0 = (sc >> 6) * 16 + 8 * ((sc & 63) >> 5);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[q][j] = p.w[(size_t)(k0 + j) * NOUT + (n < NOUT ? n : 0)];
+  }
+  int shift[NIMG];
+  stage_rows_padded<NIMG, NT, U, true>(p, KW, p0, p1, limg, t, shift);
+  const int s0 = p0 / OHOW;
+  XT_TL(1);
+#pragma unroll
+  for (int q = 0; q < WQ; ++q) {
+    const int slot = t + NT * q;
+    if (slot < NS * 64) {
+      const bool live = (slot & 31) < NOUT;
+      BF8 b1, b2, b3;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float w0 = live ? wv[q][2 * e] : 0.f, w1 = live ? wv[q][2 * e + 1] : 0.f;
+        const float r0 = w0 - trunc_bf16(w0), r1 = w1 - trunc_bf16(w1);
+        const float q0 = r0 - trunc_bf16(r0), q1 = r1 - trunc_bf16(r1);
+        b1.u[e] = pack_hi16(w0, w1);
+        b2.u[e] = pack_hi16(r0, r1);
+        b3.u[e] = pack_hi16(q0, q1);
+      }
+      const int sidx = slot >> 6, ln = slot & 63;
+      wpl[(sidx * 3 + 0) * 64 + ln] = make_uint4(b1.u[0], b1.u[1], b1.u[2], b1.u[3]);
+      wpl[(sidx * 3 + 1) * 64 + ln] = make_uint4(b2.u[0], b2.u[1], b2.u[2], b2.u[3]);
+      wpl[(sidx * 3 + 2) * 64 + ln] = make_uint4(b3.u[0], b3.u[1], b3.u[2], b3.u[3]);
+    }
+  }
+  const int il = lane & 31, h = lane >> 5;
+  int poff[SLOTS];                           // LDS byte of this lane's 8 bf16 at step 0 (padded coordinates)
+#pragma unroll
+  for (int ti = 0; ti < SLOTS; ++ti) {
+    const int pp = min(p0 + (wave + NW * ti) * 32 + il, p1 - 1);
+    const int sidx = pp / OHOW, rem = pp - sidx * OHOW;
+    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+    const int di = sidx - s0;
+    int sh = shift[0];
+#pragma unroll
+    for (int j = 1; j < NIMG; ++j) sh = di == j ? shift[j] : sh;
+    poff[ti] = 2 * (sh + (p.S * oy * p.Wp + p.S * ox) * 4 + 8 * h);
+  }
+  f32x16 acc[SLOTS];
+#pragma unroll
+  for (int ti = 0; ti < SLOTS; ++ti)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
+  const float bias = il < NOUT ? p.bias[il] : 0.f;
+  __syncthreads();
+  XT_TL(2);
+  uint4 wq[2][3], aq[2][SLOTS];
+  auto lds_fetch = [&](int s, uint4 (&w3)[3], uint4 (&a2)[SLOTS]) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) w3[pl] = wpl[(s * 3 + pl) * 64 + lane];
+    const int koff = KW == 8 ? 2 * ((s >> 1) * WrowP + (s & 1) * 16) : 2 * s * WrowP;   // KW = 4: a step = a kernel row
+#pragma unroll
+    for (int ti = 0; ti < SLOTS; ++ti) a2[ti] = *reinterpret_cast<const uint4*>(limg + poff[ti] + koff);
+  };
+  lds_fetch(0, wq[0], aq[0]);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int cur = s & 1;
+    BF8 bp[3], av[SLOTS];
+    if (s + 1 < NS) lds_fetch(s + 1, wq[cur ^ 1], aq[cur ^ 1]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) { bp[pl].u[0] = wq[cur][pl].x; bp[pl].u[1] = wq[cur][pl].y; bp[pl].u[2] = wq[cur][pl].z; bp[pl].u[3] = wq[cur][pl].w; }
+#pragma unroll
+    for (int ti = 0; ti < SLOTS; ++ti) { av[ti].u[0] = aq[cur][ti].x; av[ti].u[1] = aq[cur][ti].y; av[ti].u[2] = aq[cur][ti].z; av[ti].u[3] = aq[cur][ti].w; }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int ti = 0; ti < SLOTS; ++ti)
+        acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ti].v, bp[pl].v, acc[ti], 0, 0, 0);
+  }
+  __syncthreads();
+  XT_TL(3);
+  // epilogue: the tile through LDS (the weight planes are dead) so that every lane stores 16 bytes of a NOUT-wide row
+  float* tbuf = reinterpret_cast<float*>(limg) + wave * (32 * 36);
+#pragma unroll
+  for (int ti = 0; ti < SLOTS; ++ti) {
+    const int pix0 = p0 + (wave + NW * ti) * 32;
+    if (pix0 < p1) {
+      if (p.act == XT_ACT_RELU) {              // un-switched by hand (see the PpoCnn form)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float z = fmaf(acc[ti][r], p.xs, bias);
+          tbuf[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + il] = z > 0.f ? z : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          tbuf[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + il] = act_apply(fmaf(acc[ti][r], p.xs, bias), p.act);
+      }
+      constexpr int LPR = NOUT / 4;            // lanes per output row
+#pragma unroll
+      for (int q = 0; q < 32 * LPR / 64; ++q) {
+        const int row = q * (64 / LPR) + lane / LPR, c4 = (lane % LPR) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(&tbuf[row * 36 + c4]);
+        if (pix0 + row < p1) *reinterpret_cast<float4*>(&p.y[(size_t)(pix0 + row) * NOUT + c4]) = v;
+      }
+    }
+  }
+  XT_TL(4);
+  XT_TL_DRAIN(5);
+}
+
+// weight gradient: PB positions per workgroup (NSTEP = PB / 16 pixel steps), 8 waves = NPG pixel-step groups x NKQ
+// k-tile groups of RQ 32-row k tiles each (K = KW*KW*4: 8 tiles for KW = 8, 2 for KW = 4).
+template <int PB, int KW, int NOUT>
+__global__ __launch_bounds__(512, 2) void conv_u8c4_same_wgrad_kernel(const C1sArgs p) {
+  constexpr int NT = 512, K = KW * KW * 4, NKT = K / 32, NKQ = NKT >= 4 ? 4 : NKT, RQ = NKT / NKQ, NPG = 8 / NKQ;
+  constexpr int NIMG = PB == 512 ? 3 : 2, NSTEP = PB / 16, NITEM = NSTEP * 64 / NT, NIT = NSTEP / NPG, U = PB == 512 ? 14 : 8;
+  static_assert(NITEM >= 1 && NIT >= 1, "conv1 same wgrad: bad block shape");
+  extern __shared__ __attribute__((aligned(16))) uint8_t lsm[];
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int OHOW = p.OH * p.OW, WrowP = p.Wp * 4;
+  const int total = p.B * OHOW;
+  const int p0 = blockIdx.x * PB, p1 = min(total, p0 + PB);
+  uint8_t* limg = lsm;
+  uint4* dpl = reinterpret_cast<uint4*>(lsm + p.img_cap);                           // [NSTEP][3 planes][64 lanes] x 16 B
+  int* pixoff = reinterpret_cast<int*>(lsm + p.img_cap + NSTEP * 3 * 64 * 16);      // [PB]
+  XT_TL(0);
+  XT_TL_ROLE(50);
+  const int il = lane & 31, h = lane >> 5;
+  float bsum = 0.f;
+  {
+    float dv[NITEM][8];
+#pragma unroll
+    for (int q = 0; q < NITEM; ++q) {
+      const int slot = t + NT * q, pos = p0 + (slot >> 6) * 16 + ((slot >> 5) & 1) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dv[q][e] = p.dy[(size_t)min(pos + e, p1 - 1) * NOUT + (il < NOUT ? il : 0)];
+    }
+    int shift[NIMG];
+    stage_rows_padded<NIMG, NT, U, false>(p, KW, p0, p1, limg, t, shift);
+#pragma unroll
+    for (int q = 0; q < NITEM; ++q) {
+      const int slot = t + NT * q, pos = p0 + (slot >> 6) * 16 + ((slot >> 5) & 1) * 8;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[e] = (pos + e < p1 && il < NOUT) ? dv[q][e] : 0.f; bsum += v[e]; }
+      bf16x8 pl3[3];
+      split3_regs(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), pl3);
+      const int st = slot >> 6, ln = slot & 63;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        BF8 u; u.v = pl3[pl];
+        dpl[(st * 3 + pl) * 64 + ln] = make_uint4(u.u[0], u.u[1], u.u[2], u.u[3]);
+      }
+    }
+    const int s0 = p0 / OHOW;
+    if (t < PB) {
+      const int pp = min(p0 + t, p1 - 1);
+      const int sidx = pp / OHOW, rem = pp - sidx * OHOW;
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      const int di = sidx - s0;
+      int sh = shift[0];
+#pragma unroll
+      for (int j = 1; j < NIMG; ++j) sh = di == j ? shift[j] : sh;
+      pixoff[t] = sh + (p.S * oy * p.Wp + p.S * ox) * 4;
+    }
+  }
+  const int pg = wave / NKQ, kq = wave - pg * NKQ;
+  f32x16 acc[RQ];
+#pragma unroll
+  for (int q = 0; q < RQ; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  XT_TL(1);
+  __syncthreads();
+  XT_TL(2);
+  // A-operand role of this lane in its 16-lane group: position row j = c16 >> 1 of the 8 positions 8*(grp >> 1) + j,
+  // 8-byte half (c16 & 1); the group's 16 columns are bytes (grp & 1)*16.. of a kernel row (KW = 8) or the whole kernel
+  // row 2*tile + (grp & 1) (KW = 4)
+  const int c16 = lane & 15, grp = lane >> 4;
+  const int prow = 8 * (grp >> 1) + (c16 >> 1);
+  const uint8_t* abase = limg + (c16 & 1) * 8 +
+                         (KW == 8 ? (kq * RQ) * WrowP + (grp & 1) * 16 : (2 * kq * RQ + (grp & 1)) * WrowP);
+  constexpr int TSTRIDE_ROWS = KW == 8 ? 1 : 2;      // kernel rows per k tile
+  int po = pixoff[pg * 16 + prow];
+  i32x2 xr[RQ];
+  uint4 bq[3];
+  auto read_ops = [&](int s) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) bq[pl] = dpl[(s * 3 + pl) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) xr[q] = lds_read_tr8(abase + po + q * TSTRIDE_ROWS * WrowP);
+  };
+  read_ops(pg);
+  if (NIT > 1) po = pixoff[(pg + NPG) * 16 + prow];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int s = pg + NPG * it;
+    BF8 bp[3];
+    bf16x8 av[RQ];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) { bp[pl].u[0] = bq[pl].x; bp[pl].u[1] = bq[pl].y; bp[pl].u[2] = bq[pl].z; bp[pl].u[3] = bq[pl].w; }
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) av[q] = bytes_to_bf16x8((uint32_t)xr[q].x, (uint32_t)xr[q].y);
+    if (it + 1 < NIT) {
+      read_ops(s + NPG);
+      if (it + 2 < NIT) po = pixoff[(s + 2 * NPG) * 16 + prow];
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int q = 0; q < RQ; ++q)
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q], bp[pl].v, acc[q], 0, 0, 0);
+  }
+  XT_TL(3);
+  __syncthreads();                         // every staged operand is dead: the LDS is reused for the combine
+  float* bred = reinterpret_cast<float*>(lsm);         // [16 row groups][32 columns] bias-gradient partials
+  float* T = reinterpret_cast<float*>(lsm) + 512;      // [NPG][K rows][36]
+  bred[(t >> 5) * 32 + il] = bsum;
+#pragma unroll
+  for (int q = 0; q < RQ; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int krow = (kq * RQ + q) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      T[(pg * K + krow) * 36 + il] = acc[q][r];
+    }
+  __syncthreads();
+  {
+    float* slab = p.out + (size_t)blockIdx.x * ((size_t)(K + 1) * NOUT);
+    constexpr int LPR = NOUT / 4;
+    for (int e = t; e < K * LPR; e += NT) {
+      const int krow = e / LPR, c4 = (e - krow * LPR) * 4;
+      float4 v = *reinterpret_cast<const float4*>(&T[krow * 36 + c4]);
+#pragma unroll
+      for (int g = 1; g < NPG; ++g) {
+        const float4 u = *reinterpret_cast<const float4*>(&T[(g * K + krow) * 36 + c4]);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+      float db[4];                             // d/dW of ((x - mean) * xs): xs * sum x dY - mean * xs * sum_p dY
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float sum = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) sum += bred[g * 32 + c4 + c];
+        db[c] = sum;
+      }
+      const float xb = -p.mean * p.xs;
+      v.x = fmaf(v.x, p.xs, xb * db[0]); v.y = fmaf(v.y, p.xs, xb * db[1]);
+      v.z = fmaf(v.z, p.xs, xb * db[2]); v.w = fmaf(v.w, p.xs, xb * db[3]);
+      *reinterpret_cast<float4*>(slab + (size_t)krow * NOUT + c4) = v;
+    }
+    if (t < NOUT) {
+      float sum = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) sum += bred[g * 32 + t];
+      slab[(size_t)K * NOUT + t] = sum;
+    }
+  }
+  XT_TL(4);
+  XT_TL_DRAIN(5);
+}
+
+// geometry test shared by the two launchers below
+static bool c1s_geometry(const xt_conv_geom* g, const xt_input_xform* xf) {
+  if (!xf || !xf->is_u8 || g->C != 4 || g->N != 16 || g->KH != g->KW || (g->KW != 8 && g->KW != 4)) return false;
+  if (g->S * 2 != g->KW || (g->W & 1)) return false;
+  const float m = fabsf(xf->mean) >= 1e-4f ? xf->mean : 0.f;      // state_transform: |mean| < 1e-4 -> x / std
+  if (m < 0.f || m > 255.f || m != floorf(m)) return false;
+  if (g->PT < 0 || g->PL < 0 || g->PT >= g->KH || g->PL >= g->KW) return false;
+  return true;
+}
+static void c1s_fill(C1sArgs* a, const xt_conv_geom* g, const xt_input_xform* xf, int B) {
+  a->B = B; a->H = g->H; a->W = g->W; a->OH = g->OH; a->OW = g->OW; a->S = g->S; a->PT = g->PT; a->PL = g->PL;
+  const int pr = (g->OW - 1) * g->S + g->KW - g->W - g->PL;        // right pad (SAME: the remainder goes right / below)
+  a->Wp = g->W + g->PL + (pr > 0 ? pr : 0);
+  a->act = g->act; a->xs = 1.f / xf->std;
+  a->mean = fabsf(xf->mean) >= 1e-4f ? xf->mean : 0.f;
+}
+
+// returns 0 launched, 1 error, -1 geometry not handled
+int launch_conv1_same_fwd(const xt_conv_geom* g, const xt_input_xform* xf, int B, const void* in, const int32_t* idx,
+                          const float* w, const float* bias, float* y, hipStream_t st) {
+  if (!c1s_geometry(g, xf)) return -1;
+  C1sArgs a;
+  c1s_fill(&a, g, xf, B);
+  a.in = static_cast<const uint8_t*>(in); a.idx = idx; a.w = w; a.bias = bias; a.y = y; a.dy = nullptr; a.out = nullptr;
+  const int OHOW = g->OH * g->OW, total = B * OHOW;
+  const bool two = (total + 511) / 512 >= 200;
+  const int pb = two ? 512 : 256, nimg = two ? 3 : 2;
+  if ((pb - 1) / OHOW + 2 > nimg) return -1;
+  a.img_cap = c1_padded_cap(B, g->OH, g->OW, g->S, g->KH, a.Wp, pb);
+  const int ns = g->KW * g->KW / 4;
+  size_t fl = (size_t)2 * a.img_cap + (size_t)ns * 3 * 64 * 16;
+  if (fl < (size_t)8 * 32 * 36 * 4) fl = (size_t)8 * 32 * 36 * 4;            // the output transpose aliases the image
+  if (fl > 160 * 1024) return -1;
+  const int maxpairs = a.img_cap / 8, u = two ? 14 : 8;
+  if (maxpairs > 512 * u) return -1;                                          // staging: U pixel pairs per thread
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4_same_fwd_kernel<2, 8, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4_same_fwd_kernel<1, 8, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4_same_fwd_kernel<2, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4_same_fwd_kernel<1, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr_done = true;
+  }
+  const dim3 grid((total + pb - 1) / pb), blk(512);
+  if (g->KW == 8) {
+    if (two) hipLaunchKernelGGL((conv_u8c4_same_fwd_kernel<2, 8, 16>), grid, blk, fl, st, a);
+    else hipLaunchKernelGGL((conv_u8c4_same_fwd_kernel<1, 8, 16>), grid, blk, fl, st, a);
+  } else {
+    if (two) hipLaunchKernelGGL((conv_u8c4_same_fwd_kernel<2, 4, 16>), grid, blk, fl, st, a);
+    else hipLaunchKernelGGL((conv_u8c4_same_fwd_kernel<1, 4, 16>), grid, blk, fl, st, a);
+  }
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_conv1_same_wgrad(const xt_conv_geom* g, const xt_input_xform* xf, int B, const void* in, const int32_t* idx,
+                            const float* dy, float* dwb, float* slabs, int max_slabs, int* msplit_out, hipStream_t st) {
+  if (!c1s_geometry(g, xf) || !slabs) return -1;
+  C1sArgs a;
+  c1s_fill(&a, g, xf, B);
+  a.in = static_cast<const uint8_t*>(in); a.idx = idx; a.w = nullptr; a.bias = nullptr; a.y = nullptr; a.dy = dy;
+  const int OHOW = g->OH * g->OW, total = B * OHOW;
+  const bool two = (total + 511) / 512 >= 200;
+  const int pb = two ? 512 : 256, nimg = two ? 3 : 2, nblk = (total + pb - 1) / pb;
+  if ((pb - 1) / OHOW + 2 > nimg || nblk > max_slabs) return -1;
+  a.out = nblk == 1 ? dwb : slabs;
+  a.img_cap = c1_padded_cap(B, g->OH, g->OW, g->S, g->KH, a.Wp, pb);
+  const int K = g->KW * g->KW * 4, npg = g->KW == 8 ? 2 : 4;
+  size_t fl = (size_t)a.img_cap + (size_t)(pb / 16) * 3 * 64 * 16 + (size_t)pb * 4;
+  if (fl < (size_t)2048 + (size_t)npg * K * 36 * 4) fl = (size_t)2048 + (size_t)npg * K * 36 * 4;   // combine buffers alias everything
+  if (fl > 160 * 1024) return -1;
+  const int maxpairs = a.img_cap / 8, u = two ? 14 : 8;
+  if (maxpairs > 512 * u) return -1;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4_same_wgrad_kernel<512, 8, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4_same_wgrad_kernel<256, 8, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4_same_wgrad_kernel<512, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4_same_wgrad_kernel<256, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr_done = true;
+  }
+  const dim3 grid(nblk), blk(512);
+  if (g->KW == 8) {
+    if (two) hipLaunchKernelGGL((conv_u8c4_same_wgrad_kernel<512, 8, 16>), grid, blk, fl, st, a);
+    else hipLaunchKernelGGL((conv_u8c4_same_wgrad_kernel<256, 8, 16>), grid, blk, fl, st, a);
+  } else {
+    if (two) hipLaunchKernelGGL((conv_u8c4_same_wgrad_kernel<512, 4, 16>), grid, blk, fl, st, a);
+    else hipLaunchKernelGGL((conv_u8c4_same_wgrad_kernel<256, 4, 16>), grid, blk, fl, st, a);
+  }
+  XT_LAUNCH_CHECK();
+  if (msplit_out) *msplit_out = nblk;
+  return 0;
 }
 
 XT_TL_SETTER(conv1)

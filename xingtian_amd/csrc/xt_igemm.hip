@@ -1123,6 +1123,10 @@ int launch_conv1_fwd_bf16x3(const xt_conv_geom*, const xt_input_xform*, int, con
                             const float*, float*, hipStream_t, uint32_t*, int*);
 int launch_conv1_wgrad_bf16x3(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*,
                               const float*, float*, float*, int, int*, hipStream_t);
+int launch_conv1_same_fwd(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*, const float*,
+                          const float*, float*, hipStream_t);
+int launch_conv1_same_wgrad(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*, const float*,
+                            float*, float*, int, int*, hipStream_t);
 bool plan_dgrad_direct_fused(const Geom&, DDgradArgs*, int*);
 int launch_dgrad_direct(const xt_conv_geom*, int, const float*, const float*, const float*, int, float*, hipStream_t);
 int launch_fwd_direct(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*, const float*,
@@ -1152,6 +1156,8 @@ int launch_fwd(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const vo
   if (use_bf16x3()) {     // uint8 first layer: exact 3-way bf16 split on the bf16 matrix cores
     const int rc = launch_conv1_fwd_bf16x3(cg, xf, B, in, idx, w, bias, y, st, relu_mask, mask_written);
     if (rc >= 0) { last_arith() = XT_ARITH_BF16X3; if (deferred_ksplit) *deferred_ksplit = 1; return rc; }
+    const int rs = launch_conv1_same_fwd(cg, xf, B, in, idx, w, bias, y, st);      // ImpalaCnnOpt's first layers
+    if (rs >= 0) { last_arith() = XT_ARITH_BF16X3; if (deferred_ksplit) *deferred_ksplit = 1; return rs; }
   }
   FwdArgs a;
   if (int rc = make_geom(cg, xf, B, &a.g)) return rc;
@@ -1223,6 +1229,11 @@ int launch_wgrad(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const 
   if (use_bf16x3() && slabs && !reduce_now && slab_cap >= B) {   // uint8 first layer: one slab per frame stack
     int ms = 0;
     const int rc = launch_conv1_wgrad_bf16x3(cg, xf, B, in, idx, dy, dwb, slabs, slab_cap, &ms, st);
+    if (rc >= 0) { last_arith() = XT_ARITH_BF16X3; if (msplit_out) *msplit_out = ms; return rc; }
+  }
+  if (use_bf16x3() && slabs && !reduce_now) {
+    int ms = 0;
+    const int rc = launch_conv1_same_wgrad(cg, xf, B, in, idx, dy, dwb, slabs, slab_cap, &ms, st);
     if (rc >= 0) { last_arith() = XT_ARITH_BF16X3; if (msplit_out) *msplit_out = ms; return rc; }
   }
   WgradArgs a;

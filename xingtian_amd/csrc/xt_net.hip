@@ -518,6 +518,10 @@ int xt_net_create(const xt_net_desc* d, int32_t max_batch, xt_net** out) {
     const int tiles = (L.g.N <= 32) ? ((L.K + 127) / 128) : ((L.K + 63) / 64) * ((L.g.N + 63) / 64);
     int nsl = (512 / tiles) < 1 ? 1 : (512 / tiles);
     if (i == n->t_begin[cur] && nsl < max_batch) nsl = max_batch;   // first layer: one slab per sample (bf16x3 wgrad)
+    if (i == n->t_begin[cur]) {                                     // ... or one per 256-position range (flattened forms)
+      const int64_t nr = ((int64_t)max_batch * L.OHOW + 255) / 256;
+      if (nr < 4096 && nsl < (int)nr) nsl = (int)nr;
+    }
     const int64_t sl = (int64_t)nsl * (int64_t)(L.K + 1) * L.g.N;
     n->layers.back().slab_cap = nsl;
     n->layers.back().slab_off = off; off += xt::align4(sl);
