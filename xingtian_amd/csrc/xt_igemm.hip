@@ -150,9 +150,12 @@ struct FwdArgs {
 // ds_read_b64_tr_b16: in every 16-lane group lanes 4j..4j+3 supply the address of 16 columns of row j and lane c
 // receives column c of the four rows (semantics measured with tools/tr_probe.hip).  Row stride 160 B: the four rows of
 // a read fall into disjoint bank ranges.
-constexpr int kX6SlotA = 64 * 16 + 32;                  // bytes per (plane, chunk, k half) slot of 64 rows
-constexpr int kX6RowB = 64 * 2 + 32, kX6PlaneB = 32 * kX6RowB;
-constexpr int kX6Stage = 12 * kX6SlotA + 3 * kX6PlaneB; // bytes per LDS stage
+template <int BI, int BJ>
+struct X6Lay {
+  static constexpr int SlotA = BI * 16 + 32;            // bytes per (plane, chunk, k half) slot of BI rows
+  static constexpr int RowB = BJ * 2 + 32, PlaneB = 32 * RowB;
+  static constexpr int Stage = 12 * SlotA + 3 * PlaneB; // bytes per LDS stage
+};
 typedef short i16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 lds_read_tr16x2(const uint8_t* p, int second_off) {
   union { i16x4 h[2]; bf16x8 v; } u;
@@ -169,8 +172,9 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
   constexpr int CPRB = BJ / 4;           // float4 groups per B row
   constexpr int RPB = 256 / CPRB;        // B rows per pass
   constexpr int NB = 32 / RPB;
-  static_assert(!X6 || (BI == 64 && BJ == 64 && !U8), "igemm_fwd: the bf16x6 form is built for 64x64 fp32 tiles");
-  constexpr int BUF = X6 ? kX6Stage / 4 : 32 * SA + 32 * SB; // one LDS stage (A then B); two stages, one barrier per step
+  static_assert(!X6 || !U8, "igemm_fwd: the bf16x6 form is for fp32 inputs");
+  constexpr int kX6SlotA = X6Lay<BI, BJ>::SlotA, kX6RowB = X6Lay<BI, BJ>::RowB, kX6PlaneB = X6Lay<BI, BJ>::PlaneB;
+  constexpr int BUF = X6 ? X6Lay<BI, BJ>::Stage / 4 : 32 * SA + 32 * SB; // one LDS stage (A then B); two stages, one barrier per step
   __shared__ __attribute__((aligned(16))) float smem_all[2 * BUF * KG];
   const Geom& g = p.g;
   const int grp = (KG == 1) ? 0 : (int)(threadIdx.x >> 8);
@@ -1161,7 +1165,12 @@ int launch_fwd(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const vo
   }
   FwdArgs a;
   if (int rc = make_geom(cg, xf, B, &a.g)) return rc;
-  {                       // register-direct kernel (xt_direct.hip) when the shape is inside its envelope
+  // register-direct kernel (xt_direct.hip) when the shape is inside its envelope -- except un-padded N <= 32 layers when
+  // the LDS-tiled bf16x6 forward is on (PpoCnn conv2: 7.53 / 7.59 -> 7.40 / 7.49 ms per update; with SAME padding the
+  // direct kernel stays ahead: ImpalaCnnOpt conv2 7.1 vs 11.3 us at 128 frames, 28.6 vs 31.1 at 1000)
+  const bool tiled_first = tuning().fwd_tiled_valid && tuning().bf16x6 && !(xf && xf->is_u8) && a.g.N <= 32 &&
+                           a.g.K >= 256 && !is_padded(a.g);
+  if (!tiled_first) {
     int ks = 1;
     const int rc = launch_fwd_direct(cg, xf, B, in, idx, w, bias, y, partial, ksplit, st, &ks);
     if (rc > 0) return rc;
@@ -1200,14 +1209,16 @@ int launch_fwd(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const vo
     else hipLaunchKernelGGL((igemm_fwd_kernel<BI, BJ, WI, WJ, false, false, KGV>), grid, blk, 0, st, a);             \
   } while (0)
 #define XT_FWD(BI, BJ, WI, WJ) do { if (kg2) XT_FWD2(BI, BJ, WI, WJ, 2); else XT_FWD2(BI, BJ, WI, WJ, 1); } while (0)
-#define XT_FWD6(KGV)                                                                                        \
+#define XT_FWD6(BI, BJ, WI, WJ, KGV)                                                                        \
   do {                                                                                                      \
-    dim3 grid((M + 63) / 64, (N + 63) / 64, ksplit);                                                        \
-    if (pad) hipLaunchKernelGGL((igemm_fwd_kernel<64, 64, 2, 2, false, true, KGV, true>), grid, dim3(256 * KGV), 0, st, a);  \
-    else hipLaunchKernelGGL((igemm_fwd_kernel<64, 64, 2, 2, false, false, KGV, true>), grid, dim3(256 * KGV), 0, st, a);     \
+    dim3 grid((M + BI - 1) / BI, (N + BJ - 1) / BJ, ksplit);                                                \
+    if (pad) hipLaunchKernelGGL((igemm_fwd_kernel<BI, BJ, WI, WJ, false, true, KGV, true>), grid, dim3(256 * KGV), 0, st, a);  \
+    else hipLaunchKernelGGL((igemm_fwd_kernel<BI, BJ, WI, WJ, false, false, KGV, true>), grid, dim3(256 * KGV), 0, st, a);     \
   } while (0)
-  last_arith() = (N > 32 && !u8 && tuning().bf16x6) ? XT_ARITH_BF16X6 : XT_ARITH_FP32;
-  if (N > 32 && !u8 && tuning().bf16x6) { if (kg2) XT_FWD6(2); else XT_FWD6(1); }
+  const bool x6 = !u8 && tuning().bf16x6 != 0;
+  last_arith() = x6 ? XT_ARITH_BF16X6 : XT_ARITH_FP32;
+  if (x6 && N > 32) { if (kg2) XT_FWD6(64, 64, 2, 2, 2); else XT_FWD6(64, 64, 2, 2, 1); }
+  else if (x6) { if (kg2) XT_FWD6(128, 32, 4, 1, 2); else XT_FWD6(128, 32, 4, 1, 1); }
   else if (N <= 32) XT_FWD(128, 32, 4, 1); else XT_FWD(64, 64, 2, 2);
 #undef XT_FWD6
 #undef XT_FWD
