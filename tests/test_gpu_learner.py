@@ -97,13 +97,15 @@ def _mk(which, batch):
     return net, ospec, sd, u8
 
 
-@pytest.mark.parametrize("which,b", [("cnn84", 48), ("cnn84", 320), ("cnn84", 261), ("cnn42_unshared", 33), ("cnn42_a18", 40),
-                                     ("cnn30_inferred", 50), ("mlp", 200)])
+@pytest.mark.parametrize("which,b", [("cnn84", 48), ("cnn84", 320), ("cnn84", 261), ("cnn84", 255), ("cnn84", 256),
+                                     ("cnn42_unshared", 33), ("cnn42_a18", 40), ("cnn30_inferred", 50), ("mlp", 200)])
 def test_ppo_step_loss_and_grads_vs_oracle(which, b):
     """b = 320 is BASELINE.json's minibatch (breakout_ppo.yaml BATCH_SIZE): the launch configurations of the
     benchmark (flattened first-layer kernels, two-wave-group forwards, register-direct conv2, bf16x6 input
     gradients, halo-staged conv3 input gradient) against the oracle; b = 261 is the same set of kernels with ragged
-    last tiles (position ranges, 64-row input-gradient tiles and 128-position class tiles that end mid-tile)."""
+    last tiles (position ranges, 64-row input-gradient tiles and 128-position class tiles that end mid-tile); b = 255 /
+    256 sit on either side of the switch between the per-frame-stack and the flattened first-layer weight gradient
+    (200 position ranges of 512) and between 256- and 512-position forward ranges."""
     net, ospec, sd, u8 = _mk(which, b)
     params = oracle_params_for(net, ospec, seed=7)
     rng = np.random.default_rng(0)
@@ -192,7 +194,10 @@ def test_ppo_train_matches_oracle_and_graph_replay_is_bitwise():
     (42, 6, 2, 3, 128.0, 128.0),      # T = 2: a single loss-carrying step per trajectory + the bootstrap row
     (42, 4, 9, 2, 128.0, 128.0),      # T = 9: a row block of 8 + a block holding only the bootstrap row
     (42, 6, 256, 1, 128.0, 128.0),    # T = 256: the largest trajectory of the fused v-trace kernel
-    (42, 6, 257, 1, 128.0, 128.0)])   # T = 257: falls back to the unfused launches
+    (42, 6, 257, 1, 128.0, 128.0),    # T = 257: falls back to the unfused launches
+    (84, 4, 116, 2, 0.0, 255.0),      # 232 frames: the first-layer kernels still use 256-position ranges (199.8 < 200 ...
+    (84, 4, 233, 1, 0.0, 255.0),      # ... and 233 frames: 512-position ranges touching three frame stacks
+    (84, 4, 16, 3, 127.5, 127.5)])    # non-integer mean: outside the bf16x3 first-layer kernels -> generic fp32 kernels
 def test_impala_step_vs_oracle(dim, a_dim, tlen, ntraj, mean, std):
     from xingtian_amd.model import netspec
     from xingtian_amd.model.hip_net import HipActorCritic
