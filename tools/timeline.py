@@ -88,14 +88,23 @@ def main():
     from xingtian_amd.model import netspec
     from xingtian_amd.model.hip_net import HipActorCritic
 
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 320
-    spec = netspec.ppo_cnn((84, 84, 4), 4, (256,), "relu", True)
+    impala = len(sys.argv) > 1 and sys.argv[1] in ("impala42", "impala84")     # ImpalaCnnOpt layers instead of PpoCnn
+    if impala:
+        dim = 42 if sys.argv[1] == "impala42" else 84
+        B = int(sys.argv[2]) if len(sys.argv) > 2 else (1000 if dim == 42 else 128)
+        spec = netspec.impala_cnn_opt((dim, dim, 4), 6 if dim == 42 else 4, 128.0 if dim == 42 else 0.0,
+                                      128.0 if dim == 42 else 255.0)
+        N = B
+    else:
+        dim = 84
+        B = int(sys.argv[1]) if len(sys.argv) > 1 else 320
+        spec = netspec.ppo_cnn((84, 84, 4), 4, (256,), "relu", True)
+        N = 4096
     net = HipActorCritic(spec, max_batch=B, seed=0)
     lib = net.lib
     rng = np.random.default_rng(0)
-    N = 4096
-    obs = torch.from_numpy(rng.integers(0, 256, (N, 84, 84, 4), dtype=np.uint8)).cuda()
-    idx = torch.from_numpy(rng.permutation(N)[:B].astype(np.int32)).cuda()
+    obs = torch.from_numpy(rng.integers(0, 256, (N, dim, dim, 4), dtype=np.uint8)).cuda()
+    idx = None if impala else torch.from_numpy(rng.permutation(N)[:B].astype(np.int32)).cuda()
     net.forward(obs[:B])
     cap = 8192
     buf = torch.zeros((cap, 8), dtype=torch.int64, device="cuda")
@@ -160,6 +169,11 @@ def main():
         arm(False)
         out[name] = buf.cpu().numpy().copy()
         out[name + "_ms"] = np.float64(ms)
+    if impala:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        path = os.path.join(ROOT, "gpurun_out", "timeline_%s.npz" % sys.argv[1])
+        np.savez_compressed(path, **out)
+        return report(path)
     # one whole SGD step: later kernels overwrite earlier ones' rows; the grads_finish rows (role 60) survive
     act = torch.from_numpy(rng.integers(0, 4, N).astype(np.int32)).cuda()
     f = lambda: torch.from_numpy(rng.standard_normal(N).astype(np.float32)).cuda()
