@@ -1021,43 +1021,49 @@ __global__ __launch_bounds__(512, 2) void conv_u8c4_same_fwd_kernel(const C1sArg
 template <int PB, int KW, int NOUT>
 __global__ __launch_bounds__(512, 2) void conv_u8c4_same_wgrad_kernel(const C1sArgs p) {
   constexpr int NT = 512, K = KW * KW * 4, NKT = K / 32, NKQ = NKT >= 4 ? 4 : NKT, RQ = NKT / NKQ, NPG = 8 / NKQ;
-  constexpr int NIMG = PB == 512 ? 3 : 2, NSTEP = PB / 16, NITEM = NSTEP * 64 / NT, NIT = NSTEP / NPG, U = PB == 512 ? 14 : 8;
-  static_assert(NITEM >= 1 && NIT >= 1, "conv1 same wgrad: bad block shape");
+  constexpr int NIMG = PB == 512 ? 3 : 2, NSTEP = PB / 16, NIT = NSTEP / NPG, U = PB == 512 ? 14 : 8;
+  // dY planes hold the NOUT real columns only: [step][plane][k half][NOUT] x 16 B (+ one zero cell that the lanes of the
+  // empty columns NOUT..31 read) -- 48 KB instead of 96 KB per 512 positions, i.e. two workgroups per CU
+  constexpr int SPP = 2 * NOUT, NITEM = NSTEP * SPP / NT, ZCELL = NSTEP * 3 * SPP;
+  static_assert(NITEM >= 1 && NIT >= 1 && NT % NOUT == 0 && NOUT <= 32, "conv1 same wgrad: bad block shape");
   extern __shared__ __attribute__((aligned(16))) uint8_t lsm[];
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int OHOW = p.OH * p.OW, WrowP = p.Wp * 4;
   const int total = p.B * OHOW;
   const int p0 = blockIdx.x * PB, p1 = min(total, p0 + PB);
   uint8_t* limg = lsm;
-  uint4* dpl = reinterpret_cast<uint4*>(lsm + p.img_cap);                           // [NSTEP][3 planes][64 lanes] x 16 B
-  int* pixoff = reinterpret_cast<int*>(lsm + p.img_cap + NSTEP * 3 * 64 * 16);      // [PB]
+  uint4* dpl = reinterpret_cast<uint4*>(lsm + p.img_cap);                           // [NSTEP][3 planes][2][NOUT] x 16 B + zero cell
+  int* pixoff = reinterpret_cast<int*>(lsm + p.img_cap + (ZCELL + 1) * 16);          // [PB]
   XT_TL(0);
   XT_TL_ROLE(50);
   const int il = lane & 31, h = lane >> 5;
   float bsum = 0.f;
   {
+    // slot = (step, k half, column): 8 pixels x one real column; this thread's column is t % NOUT in all its slots
     float dv[NITEM][8];
+    const int col = t % NOUT;
 #pragma unroll
     for (int q = 0; q < NITEM; ++q) {
-      const int slot = t + NT * q, pos = p0 + (slot >> 6) * 16 + ((slot >> 5) & 1) * 8;
+      const int slot = t + NT * q, pos = p0 + (slot / SPP) * 16 + ((slot / NOUT) & 1) * 8;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dv[q][e] = p.dy[(size_t)min(pos + e, p1 - 1) * NOUT + (il < NOUT ? il : 0)];
+      for (int e = 0; e < 8; ++e) dv[q][e] = p.dy[(size_t)min(pos + e, p1 - 1) * NOUT + col];
     }
     int shift[NIMG];
     stage_rows_padded<NIMG, NT, U, false>(p, KW, p0, p1, limg, t, shift);
+    if (t == 0) dpl[ZCELL] = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
     for (int q = 0; q < NITEM; ++q) {
-      const int slot = t + NT * q, pos = p0 + (slot >> 6) * 16 + ((slot >> 5) & 1) * 8;
+      const int slot = t + NT * q, pos = p0 + (slot / SPP) * 16 + ((slot / NOUT) & 1) * 8;
       float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { v[e] = (pos + e < p1 && il < NOUT) ? dv[q][e] : 0.f; bsum += v[e]; }
+      for (int e = 0; e < 8; ++e) { v[e] = pos + e < p1 ? dv[q][e] : 0.f; bsum += v[e]; }
       bf16x8 pl3[3];
       split3_regs(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), pl3);
-      const int st = slot >> 6, ln = slot & 63;
+      const int st = slot / SPP, ln = slot % SPP;          // ln = k half * NOUT + column
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) {
         BF8 u; u.v = pl3[pl];
-        dpl[(st * 3 + pl) * 64 + ln] = make_uint4(u.u[0], u.u[1], u.u[2], u.u[3]);
+        dpl[(st * 3 + pl) * SPP + ln] = make_uint4(u.u[0], u.u[1], u.u[2], u.u[3]);
       }
     }
     const int s0 = p0 / OHOW;
@@ -1092,9 +1098,12 @@ __global__ __launch_bounds__(512, 2) void conv_u8c4_same_wgrad_kernel(const C1sA
   int po = pixoff[pg * 16 + prow];
   i32x2 xr[RQ];
   uint4 bq[3];
+  // B operand of lane (column il, k half h): the real columns from the planes, the empty ones from the zero cell (strides 0)
+  const uint4* bsrc = dpl + (il < NOUT ? h * NOUT + il : ZCELL);
+  const int bstep = il < NOUT ? 3 * SPP : 0, bplane = il < NOUT ? SPP : 0;
   auto read_ops = [&](int s) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) bq[pl] = dpl[(s * 3 + pl) * 64 + lane];
+    for (int pl = 0; pl < 3; ++pl) bq[pl] = bsrc[s * bstep + pl * bplane];
 #pragma unroll
     for (int q = 0; q < RQ; ++q) xr[q] = lds_read_tr8(abase + po + q * TSTRIDE_ROWS * WrowP);
   };
@@ -1123,7 +1132,7 @@ __global__ __launch_bounds__(512, 2) void conv_u8c4_same_wgrad_kernel(const C1sA
   __syncthreads();                         // every staged operand is dead: the LDS is reused for the combine
   float* bred = reinterpret_cast<float*>(lsm);         // [16 row groups][32 columns] bias-gradient partials
   float* T = reinterpret_cast<float*>(lsm) + 512;      // [NPG][K rows][36]
-  bred[(t >> 5) * 32 + il] = bsum;
+  bred[(t / NOUT) * NOUT + t % NOUT] = bsum;          // [NT / NOUT groups][NOUT columns] (= bred[t])
 #pragma unroll
   for (int q = 0; q < RQ; ++q)
 #pragma unroll
@@ -1148,7 +1157,7 @@ __global__ __launch_bounds__(512, 2) void conv_u8c4_same_wgrad_kernel(const C1sA
       for (int c = 0; c < 4; ++c) {
         float sum = 0.f;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) sum += bred[g * 32 + c4 + c];
+        for (int g = 0; g < NT / NOUT; ++g) sum += bred[g * NOUT + c4 + c];
         db[c] = sum;
       }
       const float xb = -p.mean * p.xs;
@@ -1159,7 +1168,7 @@ __global__ __launch_bounds__(512, 2) void conv_u8c4_same_wgrad_kernel(const C1sA
     if (t < NOUT) {
       float sum = 0.f;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) sum += bred[g * 32 + t];
+      for (int g = 0; g < NT / NOUT; ++g) sum += bred[g * NOUT + t];
       slab[(size_t)K * NOUT + t] = sum;
     }
   }
@@ -1236,7 +1245,7 @@ int launch_conv1_same_wgrad(const xt_conv_geom* g, const xt_input_xform* xf, int
   a.out = nblk == 1 ? dwb : slabs;
   a.img_cap = c1_padded_cap(B, g->OH, g->OW, g->S, g->KH, a.Wp, pb);
   const int K = g->KW * g->KW * 4, npg = g->KW == 8 ? 2 : 4;
-  size_t fl = (size_t)a.img_cap + (size_t)(pb / 16) * 3 * 64 * 16 + (size_t)pb * 4;
+  size_t fl = (size_t)a.img_cap + ((size_t)(pb / 16) * 3 * 2 * 16 + 1) * 16 + (size_t)pb * 4;
   if (fl < (size_t)2048 + (size_t)npg * K * 36 * 4) fl = (size_t)2048 + (size_t)npg * K * 36 * 4;   // combine buffers alias everything
   if (fl > 160 * 1024) return -1;
   const int maxpairs = a.img_cap / 8, u = two ? 14 : 8;
