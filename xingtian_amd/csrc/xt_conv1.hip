@@ -892,7 +892,7 @@ static int c1_padded_cap(int B, int OH, int OW, int S, int KH, int Wp, int PB) {
 }
 
 template <int SLOTS, int KW, int NOUT>
-__global__ __launch_bounds__(512, 2) void conv_u8c4_same_fwd_kernel(const C1sArgs p) {
+__global__ __launch_bounds__(512, (KW == 4 && SLOTS == 1) ? 8 : 2) void conv_u8c4_same_fwd_kernel(const C1sArgs p) {
   constexpr int NW = 8, NT = 512, PB = 32 * NW * SLOTS, NIMG = SLOTS == 2 ? 3 : 2, NS = KW * KW / 4, U = SLOTS == 2 ? 14 : 8;
   extern __shared__ __attribute__((aligned(16))) uint8_t limg[];
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1201,7 +1201,8 @@ int launch_conv1_same_fwd(const xt_conv_geom* g, const xt_input_xform* xf, int B
   c1s_fill(&a, g, xf, B);
   a.in = static_cast<const uint8_t*>(in); a.idx = idx; a.w = w; a.bias = bias; a.y = y; a.dy = nullptr; a.out = nullptr;
   const int OHOW = g->OH * g->OW, total = B * OHOW;
-  const bool two = (total + 511) / 512 >= 200;
+  // 4x4 kernels: 256-position ranges always -- 63 VGPRs, four workgroups per CU hide each other's staging latency
+  const bool two = g->KW == 8 && (total + 511) / 512 >= 200;
   const int pb = two ? 512 : 256, nimg = two ? 3 : 2;
   if ((pb - 1) / OHOW + 2 > nimg) return -1;
   a.img_cap = c1_padded_cap(B, g->OH, g->OW, g->S, g->KH, a.Wp, pb);
@@ -1239,7 +1240,8 @@ int launch_conv1_same_wgrad(const xt_conv_geom* g, const xt_input_xform* xf, int
   c1s_fill(&a, g, xf, B);
   a.in = static_cast<const uint8_t*>(in); a.idx = idx; a.w = nullptr; a.bias = nullptr; a.y = nullptr; a.dy = dy;
   const int OHOW = g->OH * g->OW, total = B * OHOW;
-  const bool two = (total + 511) / 512 >= 200;
+  const bool two = (total + 511) / 512 >= 200;      // (256-position ranges for 4x4 kernels as in the forward: kernel
+                                                    //  19.3 -> 17.8 us but twice the slabs: pong 270 -> 280 us per train)
   const int pb = two ? 512 : 256, nimg = two ? 3 : 2, nblk = (total + pb - 1) / pb;
   if ((pb - 1) / OHOW + 2 > nimg || nblk > max_slabs) return -1;
   a.out = nblk == 1 ? dwb : slabs;
