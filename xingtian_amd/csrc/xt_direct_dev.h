@@ -406,4 +406,103 @@ __device__ __forceinline__ void halo_dgrad_body(const DDgradArgs& p, uint32_t bi
   XT_TL_DRAIN(5);
 }
 
+// ------------------------------------------------------------------ stride-2 4x4 input gradient, 16 input channels
+// ImpalaCnnOpt's second conv (21x21x16 -> 11x11x32, 4x4 / 2, SAME; xt/model/atari_model.py:8-17): the generic
+// per-class kernel gives its 16 input channels a 32-column MFMA tile (half empty), decodes 128 class positions per
+// workgroup for four 32-deep steps and re-gathers dY per class from global memory -- 61 of pong_impala_speedup's 270 us.
+// Here ONE workgroup owns one SAMPLE: its dY ([OH*OW][32], 15.5 KB) is staged once into LDS as bf16 planes (+ a zero
+// row that padding taps point to), and wave w computes parity class (w >> 1, w & 1) of the sample's input pixels with
+// v_mfma_f32_16x16x32_bf16 -- 16 positions x 16 channels per accumulator, one 32-deep MFMA slab = one tap (N = 32) --
+// in the bf16x6 form; the class's four weight taps live in registers (split once).  Requires S = 2, KH = KW = 4,
+// C = 16, N = 32; smem >= 3 * (OH*OW + 1) * 80 bytes.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16_bf16x6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+  return acc;
+}
+
+__device__ __forceinline__ void s2c16_dgrad_body(const DDgradArgs& p, uint32_t bid, float* smem) {
+  const Geom& g = p.g;
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int c = lane & 15, g4 = lane >> 4;               // operand role: column (channel) / row c, k group g4
+  XT_TL(0);
+  XT_TL_ROLE(80);
+  const int b = (int)bid;
+  constexpr int RB = 32 * 2 + 16;                         // bytes per plane row (N = 32 bf16 + pad)
+  const int nrows = g.OHOW;
+  const int PS = (nrows + 1) * RB;
+  uint8_t* sb = reinterpret_cast<uint8_t*>(smem);
+  {                                                       // stage + split this sample's dY
+    const float4* src = reinterpret_cast<const float4*>(p.dy + (size_t)b * g.OHOW * 32);
+    const int total4 = nrows * 8;
+    for (int base = 0; base < total4; base += 256 * 4) {
+      float4 v[4];
+      int dst[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int e = base + t + 256 * q;
+        e = e < total4 ? e : 0;
+        v[q] = src[e];
+        dst[q] = (e >> 3) * RB + (e & 7) * 8;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) split3_store(sb + dst[q], PS, v[q]);
+    }
+    for (int e = t; e < 3 * (RB >> 2); e += 256) {
+      const int pl = e / (RB >> 2);
+      reinterpret_cast<uint32_t*>(sb + pl * PS + nrows * RB)[e - pl * (RB >> 2)] = 0u;
+    }
+  }
+  // this wave's parity class
+  const int ry = w >> 1, rx = w & 1;
+  const int cy0 = ((ry - g.PT) % 2 + 2) % 2, cx0 = ((rx - g.PL) % 2 + 2) % 2;
+  const int HC = cy0 < g.H ? (g.H - cy0 + 1) / 2 : 0, WC = cx0 < g.W ? (g.W - cx0 + 1) / 2 : 0;
+  const int Mc = HC * WC;
+  const int qy0 = (cy0 + g.PT) / 2, qx0 = (cx0 + g.PL) / 2;
+  // the class's four taps (ky, kx) = (ry + 2 jy, rx + 2 jx): B operand of lane (channel c, k group g4) = 8 consecutive n
+  bf16x8 wreg[4][3];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ky = ry + 2 * (j >> 1), kx = rx + 2 * (j & 1);
+    const float* wp = p.w + (size_t)((ky * 4 + kx) * 16 + c) * 32 + 8 * g4;
+    split3_regs(*reinterpret_cast<const float4*>(wp), *reinterpret_cast<const float4*>(wp + 4), wreg[j]);
+  }
+  __syncthreads();
+  XT_TL(1);
+  const size_t xbase = (size_t)b * g.H * g.W * 16;
+  for (int sub = 0; sub < Mc; sub += 16) {
+    const int pos = min(sub + c, Mc - 1);                 // A-operand row of this lane: class position sub + c
+    const int ty = pos / WC, tx = pos - ty * WC;
+    const int pix = (cy0 + 2 * ty) * g.W + cx0 + 2 * tx;  // input pixel of that row
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int oy = ty - (j >> 1) + qy0, ox = tx - (j & 1) + qx0;
+      const bool ok = ((unsigned)oy < (unsigned)g.OH) && ((unsigned)ox < (unsigned)g.OW);
+      const uint8_t* ap = sb + (ok ? oy * g.OW + ox : nrows) * RB + 16 * g4;
+      bf16x8 a[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(ap + pl * PS);
+      acc = mfma16_bf16x6(a, wreg[j], acc);
+    }
+    // accumulator element i of lane (c, g4) = (row 4 g4 + i, channel c): that row's pixel comes from lane 4 g4 + i
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 4 * g4 + i;
+      const int rpix = __shfl(pix, row, 64);
+      if (sub + row < Mc) {
+        const size_t off = xbase + (size_t)rpix * 16 + c;
+        p.dx[off] = acc[i] * act_grad(p.x[off], p.act_prev);
+      }
+    }
+  }
+  XT_TL(4);
+  XT_TL_DRAIN(5);
+}
+
 }  // namespace xt
