@@ -71,6 +71,7 @@ struct DDgradArgs {
   float* dx;
   int act_prev;
   int mt, ct;         // pixel tiles per stride-parity class (upper bound), channel tiles
+  const uint32_t* xmask;   // optional (s2c16 form, act_prev = relu, C = 32): sign mask of x, one word per pixel
 };
 
 // bid / nblocks: this block's index among the launch's input-gradient blocks (the fused per-layer backward
@@ -414,7 +415,7 @@ __device__ __forceinline__ void halo_dgrad_body(const DDgradArgs& p, uint32_t bi
 // row that padding taps point to), and wave w computes parity class (w >> 1, w & 1) of the sample's input pixels with
 // v_mfma_f32_16x16x32_bf16 -- 16 positions x 16 channels per accumulator, one 32-deep MFMA slab = one tap (N = 32) --
 // in the bf16x6 form; the class's four weight taps live in registers (split once).  Requires S = 2, KH = KW = 4,
-// C = 16, N = 32; smem >= 3 * (OH*OW + 1) * 80 bytes.
+// C = 16 or 32 (NC channel tiles), N = 32; smem >= 3 * (OH*OW + 1) * 80 bytes.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma16_bf16x6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
@@ -426,7 +427,9 @@ __device__ __forceinline__ f32x4 mfma16_bf16x6(const bf16x8 (&a)[3], const bf16x
   return acc;
 }
 
+template <int NC>      // NC = C / 16 channel tiles (1: ImpalaCnnOpt conv2, 2: PpoCnn conv2)
 __device__ __forceinline__ void s2c16_dgrad_body(const DDgradArgs& p, uint32_t bid, float* smem) {
+  constexpr int C = 16 * NC;
   const Geom& g = p.g;
   const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int c = lane & 15, g4 = lane >> 4;               // operand role: column (channel) / row c, k group g4
@@ -464,22 +467,29 @@ __device__ __forceinline__ void s2c16_dgrad_body(const DDgradArgs& p, uint32_t b
   const int HC = cy0 < g.H ? (g.H - cy0 + 1) / 2 : 0, WC = cx0 < g.W ? (g.W - cx0 + 1) / 2 : 0;
   const int Mc = HC * WC;
   const int qy0 = (cy0 + g.PT) / 2, qx0 = (cx0 + g.PL) / 2;
-  // the class's four taps (ky, kx) = (ry + 2 jy, rx + 2 jx): B operand of lane (channel c, k group g4) = 8 consecutive n
-  bf16x8 wreg[4][3];
+  // the class's four taps (ky, kx) = (ry + 2 jy, rx + 2 jx): B operand of lane (channel c [+ 16 per tile], k group g4)
+  // = 8 consecutive n
+  bf16x8 wreg[4][NC][3];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int ky = ry + 2 * (j >> 1), kx = rx + 2 * (j & 1);
-    const float* wp = p.w + (size_t)((ky * 4 + kx) * 16 + c) * 32 + 8 * g4;
-    split3_regs(*reinterpret_cast<const float4*>(wp), *reinterpret_cast<const float4*>(wp + 4), wreg[j]);
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+      const float* wp = p.w + (size_t)((ky * 4 + kx) * C + 16 * ct + c) * 32 + 8 * g4;
+      split3_regs(*reinterpret_cast<const float4*>(wp), *reinterpret_cast<const float4*>(wp + 4), wreg[j][ct]);
+    }
   }
   __syncthreads();
   XT_TL(1);
-  const size_t xbase = (size_t)b * g.H * g.W * 16;
+  const size_t xbase = (size_t)b * g.H * g.W * C;
+  const uint32_t* mrow = p.xmask ? p.xmask + (size_t)b * g.H * g.W : nullptr;
   for (int sub = 0; sub < Mc; sub += 16) {
     const int pos = min(sub + c, Mc - 1);                 // A-operand row of this lane: class position sub + c
     const int ty = pos / WC, tx = pos - ty * WC;
     const int pix = (cy0 + 2 * ty) * g.W + cx0 + 2 * tx;  // input pixel of that row
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[NC];
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int oy = ty - (j >> 1) + qy0, ox = tx - (j & 1) + qx0;
@@ -488,16 +498,27 @@ __device__ __forceinline__ void s2c16_dgrad_body(const DDgradArgs& p, uint32_t b
       bf16x8 a[3];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(ap + pl * PS);
-      acc = mfma16_bf16x6(a, wreg[j], acc);
+#pragma unroll
+      for (int ct = 0; ct < NC; ++ct) acc[ct] = mfma16_bf16x6(a, wreg[j][ct], acc[ct]);
     }
-    // accumulator element i of lane (c, g4) = (row 4 g4 + i, channel c): that row's pixel comes from lane 4 g4 + i
+    // accumulator element i of lane (c, g4) = (row 4 g4 + i, channel 16 ct + c): that row's pixel comes from lane 4 g4 + i
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = 4 * g4 + i;
       const int rpix = __shfl(pix, row, 64);
       if (sub + row < Mc) {
-        const size_t off = xbase + (size_t)rpix * 16 + c;
-        p.dx[off] = acc[i] * act_grad(p.x[off], p.act_prev);
+        if (mrow) {                                       // relu'(x) from the producer's sign mask
+          const uint32_t mw = mrow[rpix];
+#pragma unroll
+          for (int ct = 0; ct < NC; ++ct)
+            p.dx[xbase + (size_t)rpix * C + 16 * ct + c] = ((mw >> (16 * ct + c)) & 1u) ? acc[ct][i] : 0.f;
+        } else {
+#pragma unroll
+          for (int ct = 0; ct < NC; ++ct) {
+            const size_t off = xbase + (size_t)rpix * C + 16 * ct + c;
+            p.dx[off] = acc[ct][i] * act_grad(p.x[off], p.act_prev);
+          }
+        }
       }
     }
   }
