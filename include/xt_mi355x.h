@@ -71,8 +71,6 @@ typedef struct xt_tuning {
   int32_t reduce_z_lanes;     /* gradient reduction: slab lanes per block (power of two <= 32)                  */
   int32_t defer_splitk;       /* 1: the fused head kernel finishes the last trunk layer's split-K partials      */
   int32_t finalize_ticket;    /* 1: last-block finalize of the norm instead of the clip factor inside Adam      */
-  int32_t dgrad_sample;       /* 1: 4x4 / 2 input gradients with 32 input channels in the sample-per-workgroup
-                                 16x16x32-MFMA form instead of the all-classes 128-position tiles (ABI >= 7)      */
   int32_t fwd_tiled_valid;    /* 1: un-padded fp32 layers with N <= 32 run the LDS-tiled bf16x6 forward instead
                                  of the register-direct fp32 one (ABI >= 7; PpoCnn conv2: -2 us per step)       */
 } xt_tuning;

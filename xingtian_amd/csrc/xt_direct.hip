@@ -284,7 +284,7 @@ int launch_dgrad_direct(const xt_conv_geom* cg, int B, const float* dy, const fl
   if (make_geom(cg, nullptr, B, &a.g)) return -1;
   const Geom& g = a.g;
   if (g.N % 32 != 0 || g.C % 32 != 0) return -1;
-  a.dy = dy; a.w = w; a.x = x; a.dx = dx; a.act_prev = act_prev; a.xmask = nullptr;
+  a.dy = dy; a.w = w; a.x = x; a.dx = dx; a.act_prev = act_prev;
   const int TJ = (g.C % 64 == 0) ? 2 : 1;
   const int hc = (g.H + g.S - 1) / g.S, wc = (g.W + g.S - 1) / g.S;   // upper bound on class extent
   const int mc = B * hc * wc;

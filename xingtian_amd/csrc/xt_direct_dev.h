@@ -71,7 +71,6 @@ struct DDgradArgs {
   float* dx;
   int act_prev;
   int mt, ct;         // pixel tiles per stride-parity class (upper bound), channel tiles
-  const uint32_t* xmask;   // optional (s2c16 form, act_prev = relu, C = 32): sign mask of x, one word per pixel
 };
 
 // bid / nblocks: this block's index among the launch's input-gradient blocks (the fused per-layer backward
@@ -427,7 +426,8 @@ __device__ __forceinline__ f32x4 mfma16_bf16x6(const bf16x8 (&a)[3], const bf16x
   return acc;
 }
 
-template <int NC>      // NC = C / 16 channel tiles (1: ImpalaCnnOpt conv2, 2: PpoCnn conv2)
+template <int NC>      // NC = C / 16 channel tiles (1: ImpalaCnnOpt conv2; 2 = PpoCnn conv2 measured slower than the
+                       // all-classes tiles of igemm_dgrad4_body and is not dispatched)
 __device__ __forceinline__ void s2c16_dgrad_body(const DDgradArgs& p, uint32_t bid, float* smem) {
   constexpr int C = 16 * NC;
   const Geom& g = p.g;
@@ -482,7 +482,6 @@ __device__ __forceinline__ void s2c16_dgrad_body(const DDgradArgs& p, uint32_t b
   __syncthreads();
   XT_TL(1);
   const size_t xbase = (size_t)b * g.H * g.W * C;
-  const uint32_t* mrow = p.xmask ? p.xmask + (size_t)b * g.H * g.W : nullptr;
   for (int sub = 0; sub < Mc; sub += 16) {
     const int pos = min(sub + c, Mc - 1);                 // A-operand row of this lane: class position sub + c
     const int ty = pos / WC, tx = pos - ty * WC;
@@ -507,17 +506,10 @@ __device__ __forceinline__ void s2c16_dgrad_body(const DDgradArgs& p, uint32_t b
       const int row = 4 * g4 + i;
       const int rpix = __shfl(pix, row, 64);
       if (sub + row < Mc) {
-        if (mrow) {                                       // relu'(x) from the producer's sign mask
-          const uint32_t mw = mrow[rpix];
 #pragma unroll
-          for (int ct = 0; ct < NC; ++ct)
-            p.dx[xbase + (size_t)rpix * C + 16 * ct + c] = ((mw >> (16 * ct + c)) & 1u) ? acc[ct][i] : 0.f;
-        } else {
-#pragma unroll
-          for (int ct = 0; ct < NC; ++ct) {
-            const size_t off = xbase + (size_t)rpix * C + 16 * ct + c;
-            p.dx[off] = acc[ct][i] * act_grad(p.x[off], p.act_prev);
-          }
+        for (int ct = 0; ct < NC; ++ct) {
+          const size_t off = xbase + (size_t)rpix * C + 16 * ct + c;
+          p.dx[off] = acc[ct][i] * act_grad(p.x[off], p.act_prev);
         }
       }
     }

@@ -1069,7 +1069,7 @@ struct BwdLayerArgs {
 template <int WBI, int WBJ, int WWI, int WWJ, bool WPAD, int DBI, int DBJ, int DWI, int DWJ, int D4 = 0, int HALO = 0,
           bool DX6 = false>
 __global__ __launch_bounds__(256, 3) void igemm_bwd_layer_kernel(const BwdLayerArgs p) {
-  constexpr int SMD = (HALO == 3 || HALO == 4) ? 8 * 1024 : HALO == 2 ? 11 * 1024 : HALO == 1 ? 9 * 1024 : dgrad_smem_floats<DBI, DBJ, DX6>();
+  constexpr int SMD = HALO == 3 ? 8 * 1024 : HALO == 2 ? 11 * 1024 : HALO == 1 ? 9 * 1024 : dgrad_smem_floats<DBI, DBJ, DX6>();
   constexpr int SM0 = wgrad_smem_floats<WBI, WBJ, WPAD>() > SMD ? wgrad_smem_floats<WBI, WBJ, WPAD>() : SMD;
   constexpr int SM = (D4 && dgrad4_smem_floats<D4 == 2>() > SM0) ? dgrad4_smem_floats<D4 == 2>() : SM0;
   __shared__ __attribute__((aligned(16))) float smem[SM];
@@ -1079,8 +1079,8 @@ __global__ __launch_bounds__(256, 3) void igemm_bwd_layer_kernel(const BwdLayerA
       igemm_dgrad4_body<D4 == 2>(p.dg, b, smem);
       return;
     }
-    if constexpr (HALO == 3 || HALO == 4) {   // stride-2 4x4, 16 / 32 input channels: one sample per workgroup, one class per wave
-      s2c16_dgrad_body<HALO - 2>(p.ddg, (uint32_t)b, smem);
+    if constexpr (HALO == 3) {            // stride-2 4x4, 16 input channels: one sample per workgroup, one class per wave
+      s2c16_dgrad_body<1>(p.ddg, (uint32_t)b, smem);
       return;
     }
     if constexpr (HALO == 1 || HALO == 2) {
@@ -1357,7 +1357,7 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
   if (a.dg_direct == 0) {
     int nblk = 0;
     if (plan_dgrad_direct_fused(g, &a.ddg, &nblk)) {
-      a.ddg.dy = dy; a.ddg.w = w; a.ddg.x = x_in; a.ddg.dx = dx; a.ddg.act_prev = act_prev; a.ddg.xmask = nullptr;
+      a.ddg.dy = dy; a.ddg.w = w; a.ddg.x = x_in; a.ddg.dx = dx; a.ddg.act_prev = act_prev;
       a.dg_direct = 1;
       a.n_dg = nblk;
       const int ti2 = tuning().dgrad_tile64;   // 0: 32-row tiles (A/B; measured 30.4 vs 27.7 us for conv3 at B=320)
@@ -1397,13 +1397,11 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
     }
   }
   // stride-2 4x4 with 16 input channels (ImpalaCnnOpt conv2): sample-per-workgroup bf16x6 input gradient
-  const bool s2c16 = tuning().bf16x6 && g.S == 2 && g.KH == 4 && g.KW == 4 && g.N == 32 && wsmall &&
-                     (size_t)3 * (g.OHOW + 1) * 80 <= 8 * 1024 * 4 &&
-                     ((g.C == 16 && a.dg_direct == 0) || (g.C == 32 && tuning().dgrad_sample != 0));
+  const bool s2c16 = tuning().bf16x6 && a.dg_direct == 0 && g.S == 2 && g.KH == 4 && g.KW == 4 && g.C == 16 && g.N == 32 &&
+                     wsmall && (size_t)3 * (g.OHOW + 1) * 80 <= 8 * 1024 * 4;
   if (s2c16) {
     a.ddg.g = g; a.ddg.dy = dy; a.ddg.w = w; a.ddg.x = x_in; a.ddg.dx = dx; a.ddg.act_prev = act_prev;
     a.ddg.mt = 0; a.ddg.ct = 0;
-    a.ddg.xmask = (act_prev == XT_ACT_RELU && g.C == 32) ? xmask : nullptr;
     a.dg_direct = 5;
     a.n_dg = B;
   }
@@ -1426,13 +1424,8 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
   if (dx6 || (tuning().bf16x6 && a.dg_direct == 2)) last_arith() = XT_ARITH_FP32_BF16X6;
   if (s2c16) {
     last_arith() = XT_ARITH_FP32_BF16X6;
-    if (g.C == 32) {
-      if (pad) hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, true, 128, 32, 4, 1, 0, 4>), dim3(total), dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, 0, 4>), dim3(total), dim3(256), 0, st, a);
-    } else {
-      if (pad) hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, true, 128, 32, 4, 1, 0, 3>), dim3(total), dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, 0, 3>), dim3(total), dim3(256), 0, st, a);
-    }
+    if (pad) hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, true, 128, 32, 4, 1, 0, 3>), dim3(total), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, 0, 3>), dim3(total), dim3(256), 0, st, a);
   } else if (halo_inst) {
     const int hx6 = tuning().bf16x6;     // 0: fp32 MFMA (A/B)
     const int nsamp = 63 / (g.H * g.W) + 2;
