@@ -518,4 +518,197 @@ __device__ __forceinline__ void s2c16_dgrad_body(const DDgradArgs& p, uint32_t b
   XT_TL_DRAIN(5);
 }
 
+// ------------------------------------------------------------------ whole backward of the same layer, per sample
+// ImpalaCnnOpt conv2 again (C = 16, N = 32, 4x4 / 2), for LARGE batches: input gradient AND weight gradient of a sample
+// from ONE staging of its dY and of its input activation map -- the separate weight-gradient blocks re-read both through
+// im2col gathers (31 us at 1000 frames on top of the input gradient).  A workgroup walks samples bid, bid + nblk, ...;
+// per sample:
+//   stage dY ([OH*OW][32]) and x ([H*W][16]) as bf16 planes (+ a zero row / zero pixel), barrier;
+//   input gradient exactly as s2c16_dgrad_body (class per wave);
+//   weight gradient dW[(tap, c)][n] += sum_pos x[pixel(pos, tap)][c] dY[pos][n] on 16x16x32 tiles -- a tap's 16 channels
+//   are one 16-row tile, 32 positions one MFMA slab.  Both operands keep their NATURAL LDS layout ([pixel][c], [pos][n])
+//   and are gathered by ds_read_b64_tr_b16: lanes 4j..4j+3 of a 16-lane group address position j's 16 channels /
+//   columns -- the pixel of a tap is a per-lane address, so the im2col gather costs nothing; wave w owns kernel row
+//   ky = w (4 taps) x both 16-column halves = 8 accumulators that live across the workgroup's samples.
+// One slab [(K+1)*32] per workgroup; TWO workgroups per CU (72 KB of LDS each) so that one's staging latency hides
+// behind the other's MFMAs: with one per CU (256 slabs) every CU walked its samples strictly in sequence and the launch
+// was slower than the split form (58.5 vs 56.1 us at 1000 frames).  smem >= 3*(OH*OW+1)*80 + 3*(H*W+1)*32 bytes.
+__device__ __forceinline__ bf16x8 lds_tr16x2(const uint8_t* p0, const uint8_t* p1) {
+  typedef short i16x4 __attribute__((ext_vector_type(4)));
+  union { i16x4 h[2]; bf16x8 v; } u;
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(p0));
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(p1));
+  return u.v;
+}
+
+__device__ __forceinline__ void s2c16_bwd_body(const DDgradArgs& p, float* slabs, int nblk, uint32_t bid, float* smem) {
+  const Geom& g = p.g;
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int c = lane & 15, g4 = lane >> 4;
+  XT_TL(0);
+  XT_TL_ROLE(80);
+  constexpr int RB = 32 * 2 + 16, PB = 32;                // bytes per dY plane row / per image plane pixel (16 bf16)
+  const int nrows = g.OHOW, HW = g.H * g.W;
+  const int PS = (nrows + 1) * RB, IPS = (HW + 1) * PB;
+  uint8_t* sb = reinterpret_cast<uint8_t*>(smem);         // dY planes
+  uint8_t* img = sb + 3 * PS;                             // x planes
+  // input-gradient role: parity class of this wave, its four taps in registers
+  const int ry = w >> 1, rx = w & 1;
+  const int cy0 = ((ry - g.PT) % 2 + 2) % 2, cx0 = ((rx - g.PL) % 2 + 2) % 2;
+  const int HC = cy0 < g.H ? (g.H - cy0 + 1) / 2 : 0, WC = cx0 < g.W ? (g.W - cx0 + 1) / 2 : 0;
+  const int Mc = HC * WC;
+  const int qy0 = (cy0 + g.PT) / 2, qx0 = (cx0 + g.PL) / 2;
+  bf16x8 wreg[4][3];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ky = ry + 2 * (j >> 1), kx = rx + 2 * (j & 1);
+    const float* wp = p.w + (size_t)((ky * 4 + kx) * 16 + c) * 32 + 8 * g4;
+    split3_regs(*reinterpret_cast<const float4*>(wp), *reinterpret_cast<const float4*>(wp + 4), wreg[j]);
+  }
+  // weight-gradient role: kernel row ky = w, taps kx = 0..3, both column halves
+  f32x4 dw[4][2];
+#pragma unroll
+  for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) dw[kx][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int jrow = c >> 2, mq = c & 3;                    // tr-read role: position row j of the 4-row read, 8-byte quarter
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};                   // bias gradient: columns 4 * (t & 7) .. + 3 of this thread's rows
+
+  for (int b = (int)bid; b < g.B; b += nblk) {
+    {   // ---- stage + split dY and x of this sample
+      const float4* src = reinterpret_cast<const float4*>(p.dy + (size_t)b * g.OHOW * 32);
+      const int total4 = nrows * 8;
+      for (int base = 0; base < total4; base += 256 * 4) {
+        float4 v[4];
+        int dst[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int e = base + t + 256 * q;
+          const bool ok = e < total4;
+          v[q] = src[ok ? e : 0];
+          if (!ok) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+          dst[q] = ok ? (e >> 3) * RB + (e & 7) * 8 : nrows * RB + (t & 7) * 8;     // past the end: zeros into the zero row
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          bsum[0] += v[q].x; bsum[1] += v[q].y; bsum[2] += v[q].z; bsum[3] += v[q].w;
+          split3_store(sb + dst[q], PS, v[q]);
+        }
+      }
+      const float4* xs = reinterpret_cast<const float4*>(p.x + (size_t)b * HW * 16);
+      const int xt4 = HW * 4;
+      for (int base = 0; base < xt4; base += 256 * 4) {
+        float4 v[4];
+        int dst[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int e = base + t + 256 * q;
+          const bool ok = e < xt4;
+          v[q] = xs[ok ? e : 0];
+          if (!ok) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+          dst[q] = ok ? (e >> 2) * PB + (e & 3) * 8 : HW * PB + (t & 3) * 8;         // ... zeros into the zero pixel
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) split3_store(img + dst[q], IPS, v[q]);
+      }
+      if (t < 3 * (RB >> 2)) {                             // zero row of dY, zero pixel of x (every sample: cheap)
+        const int pl = t / (RB >> 2);
+        reinterpret_cast<uint32_t*>(sb + pl * PS + nrows * RB)[t - pl * (RB >> 2)] = 0u;
+      }
+      if (t < 3 * (PB >> 2)) {
+        const int pl = t / (PB >> 2);
+        reinterpret_cast<uint32_t*>(img + pl * IPS + HW * PB)[t - pl * (PB >> 2)] = 0u;
+      }
+    }
+    __syncthreads();
+    // ---- input gradient of this wave's parity class (s2c16_dgrad_body)
+    const size_t xbase = (size_t)b * HW * 16;
+    for (int sub = 0; sub < Mc; sub += 16) {
+      const int pos = min(sub + c, Mc - 1);
+      const int ty = pos / WC, tx = pos - ty * WC;
+      const int pix = (cy0 + 2 * ty) * g.W + cx0 + 2 * tx;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int oy = ty - (j >> 1) + qy0, ox = tx - (j & 1) + qx0;
+        const bool ok = ((unsigned)oy < (unsigned)g.OH) && ((unsigned)ox < (unsigned)g.OW);
+        const uint8_t* ap = sb + (ok ? oy * g.OW + ox : nrows) * RB + 16 * g4;
+        bf16x8 a[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(ap + pl * PS);
+        acc = mfma16_bf16x6(a, wreg[j], acc);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = 4 * g4 + i;
+        const int rpix = __shfl(pix, row, 64);
+        if (sub + row < Mc) {
+          const size_t off = xbase + (size_t)rpix * 16 + c;
+          p.dx[off] = acc[i] * act_grad(p.x[off], p.act_prev);
+        }
+      }
+    }
+    // ---- weight gradient: kernel row ky = w
+    for (int s0 = 0; s0 < nrows; s0 += 32) {
+      int prow[2], piy[2], pix0[2];                       // the two 4-position rows this lane addresses in the slab
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int pp = s0 + 8 * g4 + 4 * r + jrow;
+        const bool live = pp < nrows;
+        const int pc = live ? pp : 0;
+        const int oy = pc / g.OW, ox = pc - oy * g.OW;
+        prow[r] = live ? pp : nrows;                        // dY row (zero row past the end)
+        piy[r] = live ? 2 * oy - g.PT + w : -(1 << 20);     // input row of tap row ky = w
+        pix0[r] = 2 * ox - g.PL;                            // input column of tap kx = 0
+      }
+      bf16x8 bop[2][3];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          bop[nt][pl] = lds_tr16x2(sb + pl * PS + prow[0] * RB + (nt * 16 + 4 * mq) * 2,
+                                   sb + pl * PS + prow[1] * RB + (nt * 16 + 4 * mq) * 2);
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        int pidx[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int x = pix0[r] + kx;
+          const bool ok = ((unsigned)piy[r] < (unsigned)g.H) && ((unsigned)x < (unsigned)g.W);
+          pidx[r] = ok ? piy[r] * g.W + x : HW;
+        }
+        bf16x8 aop[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          aop[pl] = lds_tr16x2(img + pl * IPS + pidx[0] * PB + mq * 8, img + pl * IPS + pidx[1] * PB + mq * 8);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) dw[kx][nt] = mfma16_bf16x6(aop, bop[nt], dw[kx][nt]);
+      }
+    }
+    __syncthreads();                                        // the next sample overwrites the planes
+  }
+  XT_TL(3);
+  // ---- this workgroup's slab: dW rows (ky = w, kx, c = 4 g4 + i), columns nt * 16 + c; then the bias gradient
+  float* slab = slabs + (size_t)bid * ((size_t)(g.K + 1) * 32);
+#pragma unroll
+  for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        slab[(size_t)((w * 4 + kx) * 16 + 4 * g4 + i) * 32 + nt * 16 + c] = dw[kx][nt][i];
+  float* red = smem;                                        // [32 thread groups][32 columns] (planes are dead: last barrier)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) red[(t >> 3) * 32 + (t & 7) * 4 + q] = bsum[q];
+  __syncthreads();
+  if (t < 32) {
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) sum += red[r * 32 + t];
+    slab[(size_t)g.K * 32 + t] = sum;
+  }
+  XT_TL(4);
+  XT_TL_DRAIN(5);
+}
+
 }  // namespace xt

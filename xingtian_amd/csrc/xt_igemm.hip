@@ -1069,7 +1069,7 @@ struct BwdLayerArgs {
 template <int WBI, int WBJ, int WWI, int WWJ, bool WPAD, int DBI, int DBJ, int DWI, int DWJ, int D4 = 0, int HALO = 0,
           bool DX6 = false>
 __global__ __launch_bounds__(256, 3) void igemm_bwd_layer_kernel(const BwdLayerArgs p) {
-  constexpr int SMD = HALO == 3 ? 8 * 1024 : HALO == 2 ? 11 * 1024 : HALO == 1 ? 9 * 1024 : dgrad_smem_floats<DBI, DBJ, DX6>();
+  constexpr int SMD = HALO == 5 ? 18 * 1024 : HALO == 3 ? 8 * 1024 : HALO == 2 ? 11 * 1024 : HALO == 1 ? 9 * 1024 : dgrad_smem_floats<DBI, DBJ, DX6>();
   constexpr int SM0 = wgrad_smem_floats<WBI, WBJ, WPAD>() > SMD ? wgrad_smem_floats<WBI, WBJ, WPAD>() : SMD;
   constexpr int SM = (D4 && dgrad4_smem_floats<D4 == 2>() > SM0) ? dgrad4_smem_floats<D4 == 2>() : SM0;
   __shared__ __attribute__((aligned(16))) float smem[SM];
@@ -1077,6 +1077,10 @@ __global__ __launch_bounds__(256, 3) void igemm_bwd_layer_kernel(const BwdLayerA
   if (b < p.n_dg) {                       // dgrad first: it is on the critical path of the next layer
     if constexpr (D4 != 0) {              // stride-2 conv: the four parity classes of a position tile in one block
       igemm_dgrad4_body<D4 == 2>(p.dg, b, smem);
+      return;
+    }
+    if constexpr (HALO == 5) {            // ... input AND weight gradient per sample (the launch has no weight-gradient blocks)
+      s2c16_bwd_body(p.ddg, p.wg.out, p.n_dg, (uint32_t)b, smem);
       return;
     }
     if constexpr (HALO == 3) {            // stride-2 4x4, 16 input channels: one sample per workgroup, one class per wave
@@ -1315,7 +1319,7 @@ int launch_dgrad(const xt_conv_geom* cg, int B, const float* dy, const float* w,
 // wgrad (fp32 input) + dgrad (+ head wgrad) of one non-first layer in ONE launch.
 int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const float* dy, const float* w,
                      int act_prev, float* dx, float* dwb, float* slabs, int msplit, const HeadWgArgs* hw,
-                     int* msplit_out, hipStream_t st, const uint32_t* xmask) {
+                     int* msplit_out, hipStream_t st, const uint32_t* xmask, int slab_cap) {
   BwdLayerArgs a;
   if (int rc = make_geom(cg, nullptr, B, &a.wg.g)) return rc;
   a.dg.g = a.wg.g;
@@ -1405,6 +1409,16 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
     a.dg_direct = 5;
     a.n_dg = B;
   }
+  // ... and, for large batches, the weight gradient in the same workgroups: 512 of them (two per CU), one slab each
+  const bool s2fused = s2c16 && B >= 512 && slabs != nullptr && slab_cap >= 512 &&
+                       (size_t)3 * (g.OHOW + 1) * 80 + (size_t)3 * (g.H * g.W + 1) * 32 <= 18 * 1024 * 4;
+  if (s2fused) {
+    a.n_dg = 512;                                    // each walks samples bid, bid + 512, ...
+    a.n_wg = 0;
+    a.wg.out = slabs;
+    a.wg.msplit = a.n_dg;
+    if (msplit_out) *msplit_out = a.n_dg;
+  }
   const int total = a.n_wg + a.n_dg + a.n_hw;
   const bool pad = is_padded(g);
   const bool dx6 = tuning().bf16x6 != 0 && a.dg_direct == 0;     // LDS-tiled input gradient on the bf16 matrix cores
@@ -1422,7 +1436,11 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
   } while (0)
   last_arith() = XT_ARITH_FP32;          // (register-direct input gradients and the x6 = 0 forms)
   if (dx6 || (tuning().bf16x6 && a.dg_direct == 2)) last_arith() = XT_ARITH_FP32_BF16X6;
-  if (s2c16) {
+  if (s2fused) {
+    last_arith() = XT_ARITH_BF16X6;
+    if (pad) hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, true, 128, 32, 4, 1, 0, 5>), dim3(total), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, 0, 5>), dim3(total), dim3(256), 0, st, a);
+  } else if (s2c16) {
     last_arith() = XT_ARITH_FP32_BF16X6;
     if (pad) hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, true, 128, 32, 4, 1, 0, 3>), dim3(total), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, 0, 3>), dim3(total), dim3(256), 0, st, a);

@@ -35,7 +35,7 @@ int launch_fwd(const xt_conv_geom*, const xt_input_xform*, int, const void*, con
                const float*, float*, float*, int, hipStream_t, int* deferred_ksplit = nullptr,
                uint32_t* relu_mask = nullptr, int* mask_written = nullptr);
 int launch_bwd_layer(const xt_conv_geom*, int, const float*, const float*, const float*, int, float*, float*, float*,
-                     int, const HeadWgArgs*, int*, hipStream_t, const uint32_t* xmask = nullptr);
+                     int, const HeadWgArgs*, int*, hipStream_t, const uint32_t* xmask = nullptr, int slab_cap = 0);
 int launch_wgrad(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*, const float*,
                  float*, float*, int, hipStream_t, int reduce_now = 1, int* msplit_out = nullptr, int slab_cap = 0);
 int launch_dgrad(const xt_conv_geom*, int, const float*, const float*, const float*, int, float*, hipStream_t);
@@ -214,7 +214,8 @@ static int trunk_backward(xt_net* n, const void* obs, const int32_t* idx, int B,
       if (int rc = launch_bwd_layer(&L.g, B, n->ws + Lprev.act_off, n->ws + L.dact_off, n->params + L.poff,
                                     Lprev.g.act, n->ws + Lprev.dact_off, n->grads + L.poff, n->ws + L.slab_off,
                                     wgrad_split(L, B), hwp, &L.last_msplit, st,
-                                    Lprev.mask_valid ? reinterpret_cast<const uint32_t*>(n->ws + Lprev.mask_off) : nullptr))
+                                    Lprev.mask_valid ? reinterpret_cast<const uint32_t*>(n->ws + Lprev.mask_off) : nullptr,
+                                    L.slab_cap))
         return rc;
     }
   return 0;
@@ -518,6 +519,8 @@ int xt_net_create(const xt_net_desc* d, int32_t max_batch, xt_net** out) {
     const int tiles = (L.g.N <= 32) ? ((L.K + 127) / 128) : ((L.K + 63) / 64) * ((L.g.N + 63) / 64);
     int nsl = (512 / tiles) < 1 ? 1 : (512 / tiles);
     if (i == n->t_begin[cur] && nsl < max_batch) nsl = max_batch;   // first layer: one slab per sample (bf16x3 wgrad)
+    if (L.g.S == 2 && L.g.KH == 4 && L.g.KW == 4 && L.g.C == 16 && L.g.N == 32 && max_batch >= 512 && nsl < 512)
+      nsl = 512;                                                    // fused per-sample backward: one slab per workgroup
     if (i == n->t_begin[cur]) {                                     // ... or one per 256-position range (flattened forms)
       const int64_t nr = ((int64_t)max_batch * L.OHOW + 255) / 256;
       if (nr < 4096 && nsl < (int)nr) nsl = (int)nr;
@@ -796,7 +799,7 @@ int xt_net_time_layer(xt_net* n, int32_t layer, int32_t which, const void* obs, 
       return xt::launch_bwd_layer(&L.g, B, n->ws + Lp.act_off, n->ws + L.dact_off, n->params + L.poff, Lp.g.act,
                                   n->ws + Lp.dact_off, n->grads + L.poff, n->ws + L.slab_off, xt::wgrad_split(L, B),
                                   nullptr, &L.last_msplit, st,
-                                  Lp.mask_valid ? reinterpret_cast<const uint32_t*>(n->ws + Lp.mask_off) : nullptr);
+                                  Lp.mask_valid ? reinterpret_cast<const uint32_t*>(n->ws + Lp.mask_off) : nullptr, L.slab_cap);
     return xt::launch_dgrad(&L.g, B, n->ws + L.dact_off, n->params + L.poff, n->ws + Lp.act_off, Lp.g.act,
                             n->ws + Lp.dact_off, st);
   };
