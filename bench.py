@@ -266,10 +266,10 @@ KERNEL_OF = {
             "L2 shared_conv_layer_2 dgrad+wgrad": "igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1, 0, 2",
             "L3 shared_hidden_mlp_0 fwd": "igemm_fwd_kernel<64, 64, 2, 2, false, false, 2",
             "L3 shared_hidden_mlp_0 dgrad+wgrad": "igemm_bwd_layer_kernel<64, 64, 2, 2, false, 64, 64, 2, 2, 0, 0"},
-    "impala": {"L0 explore_agent/conv2d fwd": "igemm_fwd_kernel<128, 32, 4, 1, true, true, 1",
-               "L0 explore_agent/conv2d wgrad": "igemm_wgrad_kernel<128, 32, 4, 1, true, true",
+    "impala": {"L0 explore_agent/conv2d fwd": "conv_u8c4_same_fwd_kernel",
+               "L0 explore_agent/conv2d wgrad": "conv_u8c4_same_wgrad_kernel",
                "L1 explore_agent/conv2d_1 fwd": "direct_fwd_kernel<1, 1, true, 512",
-               "L1 explore_agent/conv2d_1 dgrad+wgrad": "igemm_bwd_layer_kernel<128, 32, 4, 1, true, 128, 32, 4, 1, 0, 0",
+               "L1 explore_agent/conv2d_1 dgrad+wgrad": "igemm_bwd_layer_kernel<128, 32, 4, 1, true, 128, 32, 4, 1, 0, ",
                "L2 explore_agent/conv2d_2 fwd": "igemm_fwd_kernel<64, 64, 2, 2, false, false",
                "L2 explore_agent/conv2d_2 dgrad+wgrad": "igemm_bwd_layer_kernel<64, 64, 2, 2, false, 64, 64, 2, 2, 0, 0"},
 }
