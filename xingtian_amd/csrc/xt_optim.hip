@@ -227,7 +227,19 @@ __device__ void loss_reduce_body(const LossArgs& la, double* sh) {
 // sum of the per-block squared-norm partials (double, fixed order: identical in every block that calls it)
 __device__ double sqnorm_total(const float* partial, int nblocks, double* sh) {
   double s = 0.0;
-  for (int i = threadIdx.x; i < nblocks; i += 256) s += (double)partial[i];
+  // eight partials per thread in flight at once (clamped unconditional loads, same summation order as the plain loop:
+  // as a rolled loop the ~8 dependent-latency round trips of a 2000-partial norm sat at the head of every Adam block)
+  for (int base = threadIdx.x; base < nblocks; base += 256 * 8) {
+    float q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + 256 * u;
+      q[u] = partial[i < nblocks ? i : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (base + 256 * u < nblocks) s += (double)q[u];
+  }
   sh[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
