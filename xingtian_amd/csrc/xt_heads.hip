@@ -713,33 +713,57 @@ __global__ __launch_bounds__(256) void impala_vtrace_bwd_kernel(const ImpalaLoss
   }
   float rho = 0.f, disc = 0.f, rew = 0.f, val = 0.f, ce = 0.f, ent = 0.f, logz = 0.f, mx = 0.f, z = 1.f;
   int act = 0;
+  // every global operand of this thread's time step is requested before the first use: as rolled loops over the A
+  // actions (runtime trip count) the logits were fetched one per iteration, each followed by s_waitcnt vmcnt(0) -- three
+  // such loops = ~3 A dependent round trips at the head of a latency-bound kernel (ISA)
+  float lgv[AM], blv[AM];
+#pragma unroll
+  for (int a = 0; a < AM; ++a) { lgv[a] = 0.f; blv[a] = 0.f; }
   if (t < T) s_val[t] = p.baseline[base + t];
   if (t < Tm) {
     const float* lg = p.logits + (base + t) * A;
     const float* bl = p.bp_logits + (base + t) * A;
+#pragma unroll
+    for (int a = 0; a < AM; ++a) {
+      const int ac = a < A ? a : 0;
+      lgv[a] = lg[ac];
+      blv[a] = bl[ac];
+    }
     act = p.action[base + t];
-    mx = lg[0];
-    float bmx = bl[0];
-    for (int a = 1; a < A; ++a) { mx = fmaxf(mx, lg[a]); bmx = fmaxf(bmx, bl[a]); }
-    z = 0.f;
-    float bz = 0.f;
-    for (int a = 0; a < A; ++a) { z += expf(lg[a] - mx); bz += expf(bl[a] - bmx); }
-    logz = logf(z);
-    const float tlp = (lg[act] - mx) - logz;
-    const float blp = (bl[act] - bmx) - logf(bz);
-    ce = -tlp;
-    rho = expf(tlp - blp);
-    disc = p.done[base + t] ? 0.f : p.gamma;
-    rew = fminf(fmaxf(p.reward[base + t], -1.f), 1.f);
+    const bool dn = p.done[base + t] != 0;
+    const float rraw = p.reward[base + t];
     val = p.baseline[base + t];
     const float nval = p.baseline[base + t + 1];
+    mx = lgv[0];
+    float bmx = blv[0];
+#pragma unroll
+    for (int a = 1; a < AM; ++a)
+      if (a < A) { mx = fmaxf(mx, lgv[a]); bmx = fmaxf(bmx, blv[a]); }
+    z = 0.f;
+    float bz = 0.f;
+#pragma unroll
+    for (int a = 0; a < AM; ++a)
+      if (a < A) { z += expf(lgv[a] - mx); bz += expf(blv[a] - bmx); }
+    logz = logf(z);
+    float lga = lgv[0], bla = blv[0];
+#pragma unroll
+    for (int a = 1; a < AM; ++a)
+      if (a == act) { lga = lgv[a]; bla = blv[a]; }
+    const float tlp = (lga - mx) - logz;
+    const float blp = (bla - bmx) - logf(bz);
+    ce = -tlp;
+    rho = expf(tlp - blp);
+    disc = dn ? 0.f : p.gamma;
+    rew = fminf(fmaxf(rraw, -1.f), 1.f);
     const float crho = fminf(1.f, rho);
     s_delta[t] = crho * (rew + disc * nval - val);
     s_dc[t] = disc * fminf(1.f, rho);
-    for (int a = 0; a < A; ++a) {
-      const float rl = lg[a] - mx;
-      ent += (expf(rl) / z) * (logz - rl);
-    }
+#pragma unroll
+    for (int a = 0; a < AM; ++a)
+      if (a < A) {
+        const float rl = lgv[a] - mx;
+        ent += (expf(rl) / z) * (logz - rl);
+      }
   }
   __syncthreads();
   if (t == 0) {
@@ -768,16 +792,17 @@ __global__ __launch_bounds__(256) void impala_vtrace_bwd_kernel(const ImpalaLoss
   if (t < Tm) {
     const float vs = s_vs[t], vsn = s_vs[t + 1];
     const float pg = fminf(1.f, rho) * (rew + disc * vsn - val);
-    const float* lg = p.logits + (base + t) * A;
-    for (int a = 0; a < A; ++a) {
-      const float rl = lg[a] - mx;
-      const float pa = expf(rl) / z;
-      const float lpa = rl - logz;
-      const float onehot = (a == act) ? 1.f : 0.f;
-      const float dl = pg * (pa - onehot) + 0.01f * (pa * (lpa + ent));
-      if (lead) p.dlogits[(base + t) * A + a] = dl;
-      s_dl[t * AM + a] = dl;
-    }
+#pragma unroll
+    for (int a = 0; a < AM; ++a)
+      if (a < A) {
+        const float rl = lgv[a] - mx;
+        const float pa = expf(rl) / z;
+        const float lpa = rl - logz;
+        const float onehot = (a == act) ? 1.f : 0.f;
+        const float dl = pg * (pa - onehot) + 0.01f * (pa * (lpa + ent));
+        if (lead) p.dlogits[(base + t) * A + a] = dl;
+        s_dl[t * AM + a] = dl;
+      }
     const float dvl = 0.5f * (val - vs);
     if (lead) p.dbaseline[base + t] = dvl;
     s_dv[t] = dvl;
