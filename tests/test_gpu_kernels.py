@@ -87,10 +87,12 @@ def test_gae_goldens_bit_exact(L, golden_dir):
         assert np.array_equal(ov.reshape(-1, 1), g["old_value"]), f
 
 
-def test_gae_many_trajectories_bit_exact(L):
+@pytest.mark.parametrize("n,t", [(300, 128), (5, 1024), (3, 1025), (4, 700)])
+def test_gae_many_trajectories_bit_exact(L, n, t):
+    """T <= 1024: one workgroup per trajectory (parallel loads, serial recurrence from LDS); longer trajectories: the
+    one-thread-per-trajectory kernel; T = 700 walks the 16-step register chunks with a ragged tail."""
     from xingtian_amd import ops
     rng = np.random.default_rng(11)
-    n, t = 300, 128
     value = rng.standard_normal((n, t + 1)).astype(np.float32)
     reward = rng.choice([-1.0, 0.0, 1.0], size=(n, t), p=[0.05, 0.9, 0.05])
     reward[::7] = rng.standard_normal((len(reward[::7]), t))   # unclipped rewards too
