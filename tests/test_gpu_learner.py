@@ -130,7 +130,7 @@ def test_ppo_step_loss_and_grads_vs_oracle(which, b):
     for k, ref in out["grads"].items():
         e = rel_err(g[k].reshape(ref.shape), ref)
         worst = max(worst, e)
-        assert e < 1e-5, (k, e)      # north_star bar 1e-4; measured worst case 2.6e-6 (bf16x6 input gradients) -> guard the margin
+        assert e < 1e-5, (k, e)      # north_star bar 1e-4; measured worst case 6.8e-6 (b = 261; 3.6e-6 at b = 320) with the bf16x6 forwards / input gradients
     st = net.adam_state.cpu().numpy()
     assert abs(st[4] - out["gnorm"]) < 1e-4 * out["gnorm"]
     assert_update_close(net.get_weights(), orc.net.params, params, cfg["LR"], which)
