@@ -197,7 +197,9 @@ def test_ppo_train_matches_oracle_and_graph_replay_is_bitwise():
     (42, 6, 257, 1, 128.0, 128.0),    # T = 257: falls back to the unfused launches
     (84, 4, 116, 2, 0.0, 255.0),      # 232 frames: the first-layer kernels still use 256-position ranges (199.8 < 200 ...
     (84, 4, 233, 1, 0.0, 255.0),      # ... and 233 frames: 512-position ranges touching three frame stacks
-    (84, 4, 16, 3, 127.5, 127.5)])    # non-integer mean: outside the bf16x3 first-layer kernels -> generic fp32 kernels
+    (84, 4, 16, 3, 127.5, 127.5),     # non-integer mean: outside the bf16x3 first-layer kernels -> generic fp32 kernels
+    (42, 6, 64, 9, 128.0, 128.0),     # 576 frames: the per-sample conv2 backward (>= 512 frames) with 64 workgroups walking two samples
+    (42, 6, 73, 7, 128.0, 128.0)])    # 511 frames: the last size on the split form (sample-per-workgroup input gradient + tiled weight gradient)
 def test_impala_step_vs_oracle(dim, a_dim, tlen, ntraj, mean, std):
     from xingtian_amd.model import netspec
     from xingtian_amd.model.hip_net import HipActorCritic
