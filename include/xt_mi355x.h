@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define XT_ABI_VERSION 7
+#define XT_ABI_VERSION 8
 
 #define XT_ACT_NONE 0
 #define XT_ACT_RELU 1
@@ -106,6 +106,25 @@ typedef struct xt_input_xform {
 int xt_gae_f64(const float* value, const double* reward, const uint8_t* done,
                double* adv, double* target_value, float* old_value,
                int32_t n_traj, int32_t T, double gamma, double lam, void* stream);
+
+/* ------------------------------------------------ rollout staging (host) */
+/* Copy `bytes` of an arriving rollout array from (pageable) host memory `src` into the page-locked staging buffer
+ * `dst_pinned` with a pool of native worker threads (non-temporal stores), in chunks of `chunk_bytes` (<= 0: 1 MiB);
+ * if dev_dst != NULL the hipMemcpyAsync of every chunk to dev_dst + offset is enqueued on `stream` as soon as the
+ * chunk is staged, so the H2D of chunk k runs under the staging of chunk k+1.  n_threads < 0: the tuned count
+ * (xt_stage_tune); 0: the calling thread copies inline (still chunked and pipelined with the H2D).  Returns when everything is staged and enqueued; the caller releases the GIL (ctypes does).
+ * Host pointers.  ABI >= 8.  Replaces the host half of the reference's rollout hand-over: np.concatenate of the
+ * trajectories + the feed_dict upload of every minibatch (xt/algorithm/ppo/ppo.py:66-71, xt/model/ppo/ppo.py:123-129;
+ * called from the learner thread's prepare_data loop, xt/framework/learner.py:306-313). */
+int xt_stage_rows(void* dst_pinned, const void* src, int64_t bytes, void* dev_dst, int64_t chunk_bytes,
+                  int32_t n_threads, void* stream);
+/* Measure the staging copy on this host inline and with 1/2/4/8 worker threads x {memcpy, non-temporal stores} on a
+ * private sample of `sample_bytes` (staged in trajectory-sized pieces, as an ingest burst does) and keep the fastest
+ * as the default of xt_stage_rows.  gbps10 (may be NULL): the ten measured rates in GB/s,
+ * [memcpy: inline,1,2,4,8 threads | non-temporal: inline,1,2,4,8 threads]. */
+int xt_stage_tune(int64_t sample_bytes, float* gbps10);
+int xt_stage_get(int32_t* threads, int32_t* non_temporal);
+int xt_stage_set(int32_t threads, int32_t non_temporal);
 
 /* ----------------------------------------------- implicit-GEMM layer ops */
 /* Forward of one layer.  in: [B,H,W,C] (u8 or f32); idx (may be NULL): [B] int32 row

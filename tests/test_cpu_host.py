@@ -27,7 +27,7 @@ def test_cabi_library_loads_and_exports_every_header_symbol():
     for name in sorted(declared):
         assert hasattr(handle, name), "missing C-ABI symbol " + name
         assert name in lib.SIGNATURES, "no ctypes prototype for " + name
-    assert handle.xt_abi_version() == lib.ABI_VERSION == 7
+    assert handle.xt_abi_version() == lib.ABI_VERSION == 8
     assert handle.xt_build_arch() == b"gfx950"
 
 
@@ -783,3 +783,76 @@ def test_shard_partition_properties():
 
     ranges()
     minibatches()
+
+
+def test_native_staging_pool_copies_bit_for_bit_and_tunes_itself():
+    """xt_stage_rows (the native worker pool that replaces the Python np.copyto into pinned staging): every thread
+    count / store kind / chunk size / misalignment copies bit for bit and never writes outside its range; xt_stage_tune
+    measures the ten variants on this host and keeps one of them (no GPU involved: dev_dst = NULL)."""
+    import ctypes
+    from xingtian_amd import ingest, lib
+    h = lib.load()
+    rep = ingest.staging_report()
+    assert rep["threads"] in (0, 1, 2, 4, 8) and len(rep["gbps"]) == 10 and all(v > 0 for v in rep["gbps"].values())
+    picked = (ctypes.c_int32(), ctypes.c_int32())
+    h.xt_stage_get(ctypes.byref(picked[0]), ctypes.byref(picked[1]))
+    rng = np.random.default_rng(3)
+    try:
+        for threads, nt in ((0, 0), (0, 1), (1, 1), (3, 0), (8, 1)):
+            lib.check(h.xt_stage_set(threads, nt), "xt_stage_set")
+            for n, chunk in ((1, 0), (63, 0), (64 * 1024 + 5, 4096), (3612672, 0), (3612672 + 17, 1 << 18)):
+                src = rng.integers(0, 256, n, dtype=np.uint8)
+                dst = np.full(n + 128, 7, np.uint8)
+                for off in (0, 3, 64):
+                    dst[:] = 7
+                    lib.check(h.xt_stage_rows(dst[off:].ctypes.data, src.ctypes.data, n, None, chunk, -1, None), "xt_stage_rows")
+                    assert np.array_equal(dst[off:off + n], src), (threads, nt, n, off)
+                    assert (dst[:off] == 7).all() and (dst[off + n:] == 7).all(), (threads, nt, n, off)
+        assert h.xt_stage_set(99, 0) != 0 and b"threads" in h.xt_last_error()
+        assert h.xt_stage_rows(None, None, 4, None, 0, -1, None) != 0
+    finally:
+        h.xt_stage_set(picked[0].value, picked[1].value)
+
+
+def test_rollout_fields_copy_transport_views_but_keep_owned_arrays():
+    """with STREAM_INGEST off, prepare_data keeps the arriving arrays until train(); a zero-copy transport
+    hands it views into a slot that is recycled right after the call, so views are copied and owned arrays are not."""
+    from xingtian_amd import transport
+    from xingtian_amd.algorithm.algorithm import RolloutFields
+    msg = bytearray(transport.encode({"cmd": "train"}, {"cur_state": np.arange(24, dtype=np.uint8).reshape(2, 12),
+                                                         "action": np.array([1, 2], np.int32)}))
+    _, data = transport.decode(msg)
+    owned = np.array([5, 6], np.int32)
+    rf = RolloutFields("cur_state", "action")
+    rf.add(cur_state=data["cur_state"], action=owned)
+    for i in range(len(msg)):          # the producer overwrites the slot
+        msg[i] = 0xff
+    assert np.array_equal(rf.parts["cur_state"][0], np.arange(24, dtype=np.uint8).reshape(2, 12))
+    assert rf.parts["action"][0] is owned
+
+
+def test_data_parallel_guards_fail_identically_on_every_rank():
+    """strict sharding of a minibatch with fewer rows than ranks must fail on EVERY rank before the first
+    collective (only the empty ranks raised: the others hung in the all-reduce), and the data-parallel IMPALA step
+    refuses optimisers its clip+Adam tail would silently replace."""
+    from xingtian_amd import lib, parallel
+    cfg = dict(BATCH_SIZE=8, NUM_SGD_ITER=1, LR=1e-3, MAX_GRAD_NORM=1.0)
+    perm = torch.arange(8 + 3, dtype=torch.int32).reshape(1, -1)       # last minibatch: 3 rows
+    for rank in range(4):
+        class _Net(object):
+            def make_ppo_cfg(self, *a, **k):
+                return None
+
+            def ppo_step(self, *a, **k):
+                pass
+
+            def apply(self, *a, **k):
+                pass
+            grads = torch.zeros(4)
+            loss_out = None
+        with pytest.raises(ValueError, match="3 rows cannot be split over 4 ranks"):
+            parallel.dp_ppo_update(_Net(), cfg, None, perm, None, None, None, None, None, rank, 4, mode="strict")
+    c = lib.ImpalaCfg()
+    c.opt_type = lib.OPT_TYPE["rmsprop"]
+    with pytest.raises(NotImplementedError, match="adam"):
+        parallel.dp_impala_step(None, c, 1e-3, 40.0, None, None, None, None, None, 4, 8, 0, 2)

@@ -1106,3 +1106,75 @@ def test_every_example_yaml_builds_a_learner_and_trains(rel):
     assert isinstance(loss, (float, np.floating)) and np.isfinite(loss)
     w = alg.get_weights()
     assert all(isinstance(v, np.ndarray) for v in w.values()) and len(w) >= 8
+
+
+def test_rollout_ingest_growth_keeps_frames_that_were_dma_copied_from_a_pinned_source():
+    """frames that arrive as views into page-locked memory (a pinned transport ring) are DMA-copied straight
+    to HBM and never exist in the host staging buffer; growing the buffer set in the middle of such a rollout must
+    carry them over device-to-device.  The source is overwritten after every put, as a recycled slot is."""
+    from xingtian_amd.ingest import RolloutIngest, impala_fields
+    rng = np.random.default_rng(23)
+    ing = RolloutIngest("cuda:0", n_epochs=0, initial_capacity=64, obs_u8=True, fields=impala_fields(4))
+    slot = torch.empty((128, 8, 8, 4), dtype=torch.uint8, pin_memory=True)
+    parts = []
+    for t in (50, 40, 100, 7):                 # 64 -> 128 -> 256 rows
+        obs = rng.integers(0, 256, (t, 8, 8, 4)).astype(np.uint8)
+        m = (rng.standard_normal((t, 4)).astype(np.float32), rng.integers(0, 4, t).astype(np.int32), rng.random(t) < 0.3,
+             rng.choice([-1.0, 0.0, 1.0], t))
+        slot.numpy()[:t] = obs
+        ing.put(slot.numpy()[:t], *m, pinned=True)
+        slot.zero_()
+        parts.append((obs, m))
+    n, dev = ing.finish()
+    torch.cuda.synchronize()
+    assert n == 197
+    assert np.array_equal(dev["obs"][:n].cpu().numpy(), np.concatenate([p[0] for p in parts]))
+    assert np.array_equal(dev["logit"][:n].cpu().numpy(), np.concatenate([p[1][0] for p in parts]))
+    assert np.array_equal(dev["action"][:n].cpu().numpy(), np.concatenate([p[1][1] for p in parts]))
+    assert np.array_equal(dev["done"][:n].cpu().numpy(), np.concatenate([p[1][2] for p in parts]).astype(np.uint8))
+    assert np.array_equal(dev["reward"][:n].cpu().numpy(), np.concatenate([p[1][3] for p in parts]).astype(np.float32))
+
+
+def test_weight_publish_snapshot_is_current_and_views_outlive_the_next_updates():
+    """the D2H of the new weights is enqueued by the update itself (side stream, pinned block) and
+    get_weights() hands out per-variable views.  The published weights are always the ones the update produced, a
+    parameter change without a new snapshot is noticed, and a returned dict stays intact while SNAP_SLOTS - 1 further
+    snapshots are taken."""
+    from xingtian_amd.model import netspec
+    from xingtian_amd.model.hip_net import HipActorCritic
+    spec = netspec.ppo_mlp((4,), 2, (16, 16), "tanh", True)
+    net = HipActorCritic(spec, max_batch=8, seed=0)
+    flat = lambda w: np.concatenate([w[k].reshape(-1) for k in spec.names])
+    gather = lambda: np.concatenate([net.params.cpu().numpy()[off:off + int(np.prod(shape))]
+                                     for off, shape in spec.names.values()])
+    w0 = net.get_weights()
+    assert np.array_equal(flat(w0), gather())
+    keep0 = flat(w0).copy()
+    for i in range(net.SNAP_SLOTS - 1):
+        net.params.add_(1.0)
+        net.touch()
+        net.snapshot_weights_async()
+        wi = net.get_weights()
+        assert np.array_equal(flat(wi), gather())
+        assert np.array_equal(flat(w0), keep0), "an earlier publish was overwritten too early"
+    net.set_weights({k: v + 1 for k, v in w0.items()})          # no pre-enqueued snapshot: copied on demand
+    assert np.array_equal(flat(net.get_weights()), gather())
+    owned = net.get_weights(copy=True)
+    assert all(v.flags.owndata for v in owned.values())
+    # through the plugin classes: train() -> get_weights() is what the update produced
+    from xingtian_amd.algorithm import alg_builder
+    mi = {"actor": {"model_name": "PpoMlp", "state_dim": [4], "action_dim": 2, "type": "learner",
+                    "model_config": {"BATCH_SIZE": 16, "NUM_SGD_ITER": 2, "SEED": 1}}}
+    alg = alg_builder("PPO", mi, {"instance_num": 2, "agent_num": 1})
+    rng = np.random.default_rng(0)
+    for upd in range(3):
+        for _ in range(2):
+            alg.prepare_data({"cur_state": rng.standard_normal((16, 4)).astype(np.float32),
+                              "action": rng.integers(0, 2, 16).astype(np.int32), "logp": -np.ones((16, 1), np.float32),
+                              "adv": rng.standard_normal((16, 1)), "old_value": rng.standard_normal((16, 1)).astype(np.float32),
+                              "target_value": rng.standard_normal((16, 1))})
+        alg.train()
+        w = alg.get_weights()
+        dev = alg.actor.net.params.cpu().numpy()
+        for k, (off, shape) in alg.actor.net.spec.names.items():
+            assert np.array_equal(w[k].reshape(-1), dev[off:off + w[k].size]), (upd, k)

@@ -25,8 +25,14 @@ class RolloutFields(object):
         self.parts = {n: [] for n in names}
 
     def add(self, **arrays):
+        """Arrays that do not own their memory are COPIED: a zero-copy transport hands ``prepare_data`` views into a
+        slot that the producer overwrites as soon as the call returns (``transport.ShmRing.recv_into``); the reference's
+        channel delivers private objects (zeus/common/ipc/share_by_plasma.py:74-95)."""
         for n in self.names:
-            self.parts[n].append(arrays[n])
+            v = arrays[n]
+            if isinstance(v, np.ndarray) and not v.flags.owndata:
+                v = np.array(v, copy=True)
+            self.parts[n].append(v)
 
     def stacked(self):
         return [np.concatenate(self.parts[n]) for n in self.names]

@@ -5,10 +5,35 @@ reference's ``np.concatenate`` of the whole rollout (xt/algorithm/ppo/ppo.py:66-
 host->device upload are gone from the critical path.  Two buffer sets alternate so that the next rollout can
 stream in while the previous update still reads the other set.
 
+The frames of a trajectory (the only large field: 3.6 MB per 128-step Atari trajectory) are staged by the library's
+native worker pool (``xt_stage_rows``: chunked, the H2D of chunk k enqueued while chunk k+1 is being staged, GIL
+released); the label fields (a few hundred bytes each) are written into their pinned arrays and shipped with ONE copy
+per field when the rollout is complete (``finish``) instead of one per field and trajectory.
+
 Plumbing only (PyTorch-ROCm tensors / streams); no arithmetic happens here.
 """
+import ctypes
+
 import numpy as np
 import torch
+
+from xingtian_amd import lib as L
+
+_TUNED = {}
+
+
+def staging_report():
+    """What ``xt_stage_tune`` measured on this host (GB/s per variant) and picked; tuned once per process."""
+    if not _TUNED:
+        h = L.load()
+        g = (ctypes.c_float * 10)()
+        L.check(h.xt_stage_tune(32 << 20, g), "xt_stage_tune")
+        t, nt = ctypes.c_int32(), ctypes.c_int32()
+        h.xt_stage_get(ctypes.byref(t), ctypes.byref(nt))
+        names = ["inline", "1", "2", "4", "8"]
+        _TUNED.update(threads=t.value, non_temporal=bool(nt.value),
+                      gbps={("nt_" if i >= 5 else "memcpy_") + names[i % 5]: round(float(g[i]), 2) for i in range(10)})
+    return dict(_TUNED)
 
 # label fields of a PPO trajectory (xt/algorithm/ppo/ppo.py:79-85): name, device dtype, per-row width (0 = scalar)
 PPO_FIELDS = (("action", torch.int32, 0), ("old_logp", torch.float32, 0), ("adv", torch.float64, 0),
@@ -57,6 +82,8 @@ class RolloutIngest(object):
         self.sets = [None, None]
         self.cur = 0
         self.n = 0
+        self._lib = L.load()
+        staging_report()                # pick the staging-copy variant for this host once
 
     # ------------------------------------------------------------------
     def _ensure(self, need, obs):
@@ -71,20 +98,23 @@ class RolloutIngest(object):
             cap = max(cap, 2 * s.cap)
         new = _BufferSet(cap, tuple(obs.shape[1:]), u8, self.n_epochs, self.device, sig, self.fields)
         if same and self.n > 0:                        # grow: keep what was already ingested
-            self.copy_stream.synchronize()
-            for k in new.host:
-                new.host[k][:self.n].copy_(s.host[k][:self.n])
+            # frames travel device-to-device in copy-stream order (a frame that was DMA-copied straight out of a pinned
+            # transport slot never existed in the host staging buffer); labels are still host-side only
             with torch.cuda.stream(self.copy_stream):
-                for k in new.host:
-                    new.dev[k][:self.n].copy_(new.host[k][:self.n], non_blocking=True)
+                new.dev["obs"][:self.n].copy_(s.dev["obs"][:self.n], non_blocking=True)
+            for k in new.host:
+                if k != "obs":
+                    new.host[k][:self.n].copy_(s.host[k][:self.n])
+            self.copy_stream.synchronize()             # the old set is released when this function returns
         self.sets[self.cur] = new
         return new
 
     def put(self, obs, *labels, pinned=False):
         """Append one trajectory / rollout message ([T,...] arrays as the explorer ships them, labels in the order
-        of ``fields``) and start its H2D copy.  ``pinned``: the arrays are views into page-locked memory (a pinned
-        transport ring): fields whose dtype already is the device dtype are DMA-copied straight from the source, and
-        the call returns only when those copies have landed (the caller recycles the slot right after)."""
+        of ``fields``) and start the H2D copy of its frames.  ``pinned``: the arrays are views into page-locked memory
+        (a pinned transport ring): frames whose dtype already is the device dtype are DMA-copied straight from the
+        source, and the call returns only when that copy has landed (the caller recycles the slot right after).  The
+        arriving arrays are never referenced after the call returns."""
         obs = np.asarray(obs)
         t = obs.shape[0]
         s = self._ensure(self.n + t, obs)
@@ -94,22 +124,28 @@ class RolloutIngest(object):
         if len(labels) != len(self.fields):
             raise ValueError("RolloutIngest.put: {} label arrays for fields {}".format(
                 len(labels), [f[0] for f in self.fields]))
-        direct = {}
-        named = [("obs", obs)] + [(f[0], np.asarray(a)) for f, a in zip(self.fields, labels)]
-        for name, arr in named:
-            dst = s.host_np[name][lo:hi]
-            if pinned and isinstance(arr, np.ndarray) and arr.dtype == dst.dtype and arr.flags.c_contiguous \
-                    and arr.flags.writeable and arr.size == dst.size:
-                direct[name] = torch.from_numpy(arr.reshape(dst.shape))     # DMA source = the pinned transport slot
-            else:
-                # bool -> uint8 and float64 -> float32 are the casts the reference's placeholders apply
-                np.copyto(dst, arr.reshape(dst.shape), casting="unsafe" if (name == "obs" or arr.dtype == np.bool_)
-                          else "same_kind")
-        with torch.cuda.stream(self.copy_stream):
-            for k in s.host:
-                s.dev[k][lo:hi].copy_(direct[k] if k in direct else s.host[k][lo:hi], non_blocking=True)
-        if direct:
+        obs_dst = s.host_np["obs"][lo:hi]
+        row_bytes = obs_dst.dtype.itemsize * int(np.prod(obs_dst.shape[1:], dtype=np.int64))
+        dev_ptr = s.dev["obs"].data_ptr() + lo * row_bytes
+        plain = obs.dtype == obs_dst.dtype and obs.flags.c_contiguous and obs.size == obs_dst.size
+        if pinned and plain and obs.flags.writeable:
+            # DMA source = the pinned transport slot: no host copy at all; the caller recycles the slot right after
+            with torch.cuda.stream(self.copy_stream):
+                s.dev["obs"][lo:hi].copy_(torch.from_numpy(obs.reshape(obs_dst.shape)), non_blocking=True)
             self.copy_stream.synchronize()
+        elif plain:
+            L.check(self._lib.xt_stage_rows(ctypes.c_void_p(s.host["obs"].data_ptr() + lo * row_bytes),
+                                            ctypes.c_void_p(obs.ctypes.data), obs.nbytes, ctypes.c_void_p(dev_ptr), 0, -1,
+                                            ctypes.c_void_p(self.copy_stream.cuda_stream)), "xt_stage_rows")
+        else:       # a cast on the way in (float frames for a uint8 network, ...): as the upload path casts them
+            np.copyto(obs_dst, obs.reshape(obs_dst.shape), casting="unsafe")
+            with torch.cuda.stream(self.copy_stream):
+                s.dev["obs"][lo:hi].copy_(s.host["obs"][lo:hi], non_blocking=True)
+        for f, a in zip(self.fields, labels):
+            arr = np.asarray(a)
+            dst = s.host_np[f[0]][lo:hi]
+            # bool -> uint8 and float64 -> float32 are the casts the reference's placeholders apply
+            np.copyto(dst, arr.reshape(dst.shape), casting="unsafe" if arr.dtype == np.bool_ else "same_kind")
         self.n = hi
 
     def finish(self):
@@ -119,6 +155,9 @@ class RolloutIngest(object):
         n = self.n
         if s is None or n == 0:
             raise RuntimeError("RolloutIngest.finish(): nothing was ingested")
+        with torch.cuda.stream(self.copy_stream):          # the labels of the whole rollout: one copy per field
+            for f in self.fields:
+                s.dev[f[0]][:n].copy_(s.host[f[0]][:n], non_blocking=True)
         s.done.record(self.copy_stream)
         torch.cuda.current_stream(self.device).wait_event(s.done)
         self.cur ^= 1

@@ -29,7 +29,7 @@ class LayerDesc(Structure):
     _fields_ = [("g", ConvGeom), ("param_off", c_int64), ("trunk", c_int32)]
 
 
-ABI_VERSION = 7          # XT_ABI_VERSION of include/xt_mi355x.h
+ABI_VERSION = 8          # XT_ABI_VERSION of include/xt_mi355x.h
 ACTION_TYPE = {"Categorical": 0, "DiagGaussian": 1}
 
 
@@ -72,6 +72,10 @@ SIGNATURES = {
     "xt_build_arch": (c_char_p, []),
     "xt_tuning_get": (c_int32, [POINTER(Tuning)]),
     "xt_tuning_set": (c_int32, [POINTER(Tuning)]),
+    "xt_stage_rows": (c_int32, [_P, _P, c_int64, _P, c_int64, c_int32, _P]),
+    "xt_stage_tune": (c_int32, [c_int64, POINTER(c_float)]),
+    "xt_stage_get": (c_int32, [POINTER(c_int32), POINTER(c_int32)]),
+    "xt_stage_set": (c_int32, [c_int32, c_int32]),
     "xt_gae_f64": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_double, c_double, _P]),
     "xt_layer_fwd": (c_int32, [POINTER(ConvGeom), POINTER(InputXform), c_int32, _P, _P, _P, _P, _P, _P, c_int32, _P]),
     "xt_layer_wgrad": (c_int32, [POINTER(ConvGeom), POINTER(InputXform), c_int32, _P, _P, _P, _P, _P, c_int32, _P]),

@@ -83,14 +83,51 @@ class HipActorCritic(object):
         torch.cuda.current_stream(self.device).synchronize()
         return pin[tag].numpy()
 
-    def get_weights(self):
+    # ---- weight publish: the D2H of the new parameters is enqueued by the update itself
+    SNAP_SLOTS = 4
+
+    def touch(self):
+        """The parameters are about to change (or have been assigned): a snapshot taken earlier is stale."""
+        self._version = getattr(self, "_version", 0) + 1
+
+    def snapshot_weights_async(self):
+        """Enqueue the D2H of the flat parameter buffer into the next of ``SNAP_SLOTS`` pinned host blocks on a side
+        stream, ordered after everything already enqueued on the compute stream (the update whose result it
+        publishes).  Returns immediately: the copy runs under whatever the host does next (the loss read-back, the next
+        rollout's ingest).  ``get_weights`` picks the block up once its event has fired."""
+        snap = getattr(self, "_snap", None)
+        if snap is None:
+            snap = self._snap = dict(stream=torch.cuda.Stream(device=self.device), slot=-1, version=-1, events=[],
+                                     host=[torch.empty(self.params.shape, dtype=torch.float32, pin_memory=True)
+                                           for _ in range(self.SNAP_SLOTS)])
+            snap["events"] = [torch.cuda.Event() for _ in range(self.SNAP_SLOTS)]
+        i = (snap["slot"] + 1) % self.SNAP_SLOTS
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(snap["stream"]):
+            snap["stream"].wait_event(ready)
+            snap["host"][i].copy_(self.params.detach(), non_blocking=True)
+            snap["events"][i].record(snap["stream"])
+        snap["slot"], snap["version"] = i, getattr(self, "_version", 0)
+
+    def get_weights(self, copy=False):
         """dict TF-variable-name -> ndarray (TFVariables.get_weights, xt/model/tf_utils.py:99-102).  The flat
-        parameter buffer IS the packed form: one pinned D2H, then per-variable copies (the caller owns them)."""
-        flat = self._flat_to_host(self.params, "params")
+        parameter buffer IS the packed form: ONE pinned D2H -- already in flight when the last update enqueued it
+        (``snapshot_weights_async``), else issued now -- and per-variable VIEWS into the pinned block.  The views stay
+        valid until ``SNAP_SLOTS - 1`` further snapshots have been taken (the learner serialises them right away,
+        xt/framework/learner.py:361-363); ``copy=True`` returns arrays the caller owns."""
+        snap = getattr(self, "_snap", None)
+        if snap is None or snap["version"] != getattr(self, "_version", 0):
+            self.snapshot_weights_async()
+            snap = self._snap
+        snap["version"] = -1            # a pre-enqueued snapshot serves ONE publish; later calls copy again
+        snap["events"][snap["slot"]].synchronize()
+        flat = snap["host"][snap["slot"]].numpy()
         out = OrderedDict()
         for name, (off, shape) in self.spec.names.items():
             size = int(np.prod(shape))
-            out[name] = flat[off:off + size].reshape(shape).copy()
+            v = flat[off:off + size].reshape(shape)
+            out[name] = v.copy() if copy else v
         return out
 
     def set_weights(self, weights):
@@ -108,6 +145,7 @@ class HipActorCritic(object):
                 raise KeyError("update {} encounter error: shape {} vs {}".format(name, val.shape, shape))
             flat[off:off + val.size] = val.reshape(-1)
         self.params.copy_(torch.from_numpy(flat))
+        self.touch()
 
     # ------------------------------------------------------------------ optimizer state
     # The reference never checkpoints its AdamOptimizer slots (TFVariables only walks the trainable variables,
@@ -198,6 +236,7 @@ class HipActorCritic(object):
     def ppo_step(self, c, obs, idx, action, old_logp, adv, old_v, target_v, apply=True):
         """One SGD step on rows idx (int32 device tensor or None) of device-resident data."""
         b = int(idx.numel()) if idx is not None else int(obs.shape[0])
+        self.touch()
         L.check(self.lib.xt_net_ppo_step(self.handle, ctypes.byref(c), L.ptr(obs), L.ptr(idx), b, L.ptr(action),
                                          L.ptr(old_logp), L.ptr(adv), L.ptr(old_v), L.ptr(target_v),
                                          1 if apply else 0, L.ptr(self.loss_out), None, L.stream_ptr()),
@@ -206,6 +245,7 @@ class HipActorCritic(object):
 
     def ppo_train(self, c, obs, perm, action, old_logp, adv, old_v, target_v, use_graph=False):
         n = int(obs.shape[0])
+        self.touch()
         L.check(self.lib.xt_net_ppo_train(self.handle, ctypes.byref(c), L.ptr(obs), n, L.ptr(perm), L.ptr(action),
                                           L.ptr(old_logp), L.ptr(adv), L.ptr(old_v), L.ptr(target_v),
                                           L.ptr(self.loss_acc), 1 if use_graph else 0, L.stream_ptr()),
@@ -232,6 +272,7 @@ class HipActorCritic(object):
 
     def impala_step(self, c, obs, bp_logits, action, done, reward, apply=True, loss_acc=None):
         n = int(obs.shape[0])
+        self.touch()
         L.check(self.lib.xt_net_impala_step(self.handle, ctypes.byref(c), L.ptr(obs), n, L.ptr(bp_logits),
                                             L.ptr(action), L.ptr(done), L.ptr(reward), 1 if apply else 0,
                                             L.ptr(self.loss_out), L.ptr(loss_acc), L.stream_ptr()),
@@ -243,6 +284,7 @@ class HipActorCritic(object):
         rollout; ``lr_steps`` (float32 device tensor, one step size per chunk) or None.  Returns the device tensor
         [sum of chunk losses, number of chunks]."""
         n = int(obs.shape[0])
+        self.touch()
         L.check(self.lib.xt_net_impala_train(self.handle, ctypes.byref(c), L.ptr(obs), n, int(batch_size),
                                              L.ptr(bp_logits), L.ptr(action), L.ptr(done), L.ptr(reward),
                                              L.ptr(lr_steps), L.ptr(self.loss_acc), 1 if use_graph else 0,
@@ -275,11 +317,13 @@ class HipActorCritic(object):
         t = iterations + 1
         lr_t = np.float32(lr) / (np.float32(1.0) + np.float32(decay) * np.float32(iterations))
         lr_t = lr_t * np.sqrt(np.float32(1.0) - np.float32(beta2) ** t) / (np.float32(1.0) - np.float32(beta1) ** t)
+        self.touch()
         L.check(self.lib.xt_adam_keras(L.ptr(self.params), L.ptr(self.grads), L.ptr(self.adam_m), L.ptr(self.adam_v), n,
                                        offs.data_ptr(), sizes.data_ptr(), float(clipnorm), float(lr_t), beta1, beta2,
                                        eps, L.ptr(self._keras_scratch), L.stream_ptr()), "xt_adam_keras")
 
     def apply(self, lr, clip_norm, grad_scale=1.0):
+        self.touch()
         L.check(self.lib.xt_net_apply(self.handle, lr, 0.9, 0.999, 1e-8, clip_norm, grad_scale, L.stream_ptr()),
                 "xt_net_apply")
 

@@ -102,10 +102,10 @@ def dp_ppo_update(net, cfg, obs, perm, action, old_logp, adv, old_v, target_v, r
         for start in range(0, n, bsz):
             rows = min(bsz, n - start)
             if mode == "strict":
+                if rows < world:        # the same test on EVERY rank, before any collective: nobody is left waiting
+                    raise ValueError("strict sharding: a minibatch of {} rows cannot be split over {} ranks".format(
+                        rows, world))
                 idx = split_minibatch(perm[ep], start, bsz, rank, world)
-                if idx.numel() == 0:
-                    raise ValueError("strict sharding: minibatch of {} rows over {} ranks leaves rank {} empty".format(
-                        rows, world, rank))
                 key, scale = rows, grad_scale("global_mean", world)
                 if key not in structs:
                     structs[key] = net.make_ppo_cfg(cfg, grad_scale=scale, global_batch=rows)
@@ -126,6 +126,11 @@ def dp_impala_step(net, cfg_struct, lr, grad_norm_clip, obs, bp_logits, action, 
                    world):
     """One data-parallel ImpalaCnnOpt step: the chunk's ``n_traj`` trajectories (flat env-major rows b*T+t) are
     split into whole-trajectory shards, gradients of the sum-form loss are SUMMED, no scaling."""
+    from xingtian_amd import lib as L
+    if int(cfg_struct.opt_type) != L.OPT_TYPE["adam"]:
+        # net.apply is clip + Adam; the single-process path (xt_net_impala_train) also serves opt_type: rmsprop and
+        # lr_schedule -- refusing is better than silently training with another optimiser
+        raise NotImplementedError("dp_impala_step: data-parallel IMPALA supports opt_type 'adam' with a fixed step size")
     b, e = shard_range(n_traj, rank, world)
     if e > b:
         sl = slice(b * t_len, e * t_len)
