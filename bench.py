@@ -737,6 +737,10 @@ def main():
                                     "train() (incl. H2D of the uint8 rollout) + get_weights() (D2H), plugin classes",
                       "env_num_32": bench_e2e_ppo(32), "env_num_10_yaml": bench_e2e_ppo(10),
                       "env_num_32_pinned_ring": bench_e2e_ppo(32, via_ring=True)}
+        from xingtian_amd import ingest
+        out["e2e"]["staging_copy"] = dict(ingest.staging_report(), note="xt_stage_tune on this host: GB/s of the pageable -> "
+                                          "pinned copy per variant (memcpy / non-temporal stores x inline,1,2,4,8 worker "
+                                          "threads, 4 MiB pieces); the fastest is what prepare_data uses")
         out["value_e2e"] = out["e2e"]["env_num_32"]["value"]
         out["secondary"] = [bench_impala(k, 10, 3, not args.no_cpu_baseline)
                             for k in ("breakout_impala", "pong_impala_speedup")]

@@ -109,15 +109,16 @@ int xt_gae_f64(const float* value, const double* reward, const uint8_t* done,
 
 /* ------------------------------------------------ rollout staging (host) */
 /* Copy `bytes` of an arriving rollout array from (pageable) host memory `src` into the page-locked staging buffer
- * `dst_pinned` with a pool of native worker threads (non-temporal stores), in chunks of `chunk_bytes` (<= 0: 1 MiB);
- * if dev_dst != NULL the hipMemcpyAsync of every chunk to dev_dst + offset is enqueued on `stream` as soon as the
- * chunk is staged, so the H2D of chunk k runs under the staging of chunk k+1.  n_threads < 0: the tuned count
+ * `dst_pinned` with a pool of native worker threads (non-temporal stores), in work units of `chunk_bytes` (<= 0:
+ * 256 KiB); if dev_dst != NULL, a hipMemcpyAsync to dev_dst + offset is enqueued on `stream` for every `ship_bytes`
+ * (<= 0: 4 MiB) of contiguous staged data and for the remainder, so the H2D of one piece runs under the staging of
+ * the next (and the H2D of one trajectory under the staging of the following one).  n_threads < 0: the tuned count
  * (xt_stage_tune); 0: the calling thread copies inline (still chunked and pipelined with the H2D).  Returns when everything is staged and enqueued; the caller releases the GIL (ctypes does).
  * Host pointers.  ABI >= 8.  Replaces the host half of the reference's rollout hand-over: np.concatenate of the
  * trajectories + the feed_dict upload of every minibatch (xt/algorithm/ppo/ppo.py:66-71, xt/model/ppo/ppo.py:123-129;
  * called from the learner thread's prepare_data loop, xt/framework/learner.py:306-313). */
 int xt_stage_rows(void* dst_pinned, const void* src, int64_t bytes, void* dev_dst, int64_t chunk_bytes,
-                  int32_t n_threads, void* stream);
+                  int64_t ship_bytes, int32_t n_threads, void* stream);
 /* Measure the staging copy on this host inline and with 1/2/4/8 worker threads x {memcpy, non-temporal stores} on a
  * private sample of `sample_bytes` (staged in trajectory-sized pieces, as an ingest burst does) and keep the fastest
  * as the default of xt_stage_rows.  gbps10 (may be NULL): the ten measured rates in GB/s,

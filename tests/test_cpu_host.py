@@ -805,11 +805,11 @@ def test_native_staging_pool_copies_bit_for_bit_and_tunes_itself():
                 dst = np.full(n + 128, 7, np.uint8)
                 for off in (0, 3, 64):
                     dst[:] = 7
-                    lib.check(h.xt_stage_rows(dst[off:].ctypes.data, src.ctypes.data, n, None, chunk, -1, None), "xt_stage_rows")
+                    lib.check(h.xt_stage_rows(dst[off:].ctypes.data, src.ctypes.data, n, None, chunk, 0, -1, None), "xt_stage_rows")
                     assert np.array_equal(dst[off:off + n], src), (threads, nt, n, off)
                     assert (dst[:off] == 7).all() and (dst[off + n:] == 7).all(), (threads, nt, n, off)
         assert h.xt_stage_set(99, 0) != 0 and b"threads" in h.xt_last_error()
-        assert h.xt_stage_rows(None, None, 4, None, 0, -1, None) != 0
+        assert h.xt_stage_rows(None, None, 4, None, 0, 0, -1, None) != 0
     finally:
         h.xt_stage_set(picked[0].value, picked[1].value)
 

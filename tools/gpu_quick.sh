@@ -1,0 +1,25 @@
+#!/bin/bash
+# One GPU-box call: the -m gpu suite + the default bench line (no profiling).  usage: tools/gpu_quick.sh <tag> [pytest -k expr]
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${1:-r03}
+mkdir -p $R/gpurun_out
+cd $R
+if [ -n "$2" ]; then K=(-k "$2"); else K=(); fi
+timeout 900 python -m pytest tests -m gpu -x -q "${K[@]}" > gpurun_out/${TAG}_pytest.log 2>&1; tail -15 gpurun_out/${TAG}_pytest.log
+timeout 600 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -3 gpurun_out/${TAG}_bench.err
+python - <<P
+import json
+try:
+    d = json.loads(open("gpurun_out/${TAG}_bench.json").read().strip().splitlines()[-1])
+    print("PPO value", d["value"], "ms", d["ms_per_step"], "frac", d["roofline"]["frac"], d["roofline"]["kernel"])
+    print("kernels", d["roofline"]["kernels_us"])
+    print("sustained", d.get("sustained"))
+    for k, v in d.get("e2e", {}).items():
+        if isinstance(v, dict): print("e2e", k, {q: (round(x, 3) if isinstance(x, float) else x) for q, x in v.items() if q not in ("path", "note")})
+    for s in d.get("secondary", []):
+        print("SEC", s["workload"][:40], "value", round(s["value"]), "us/train", round(s["us_per_train"], 1), "frac", round(s["update_frac_of_fp32_mfma_peak"], 3), "e2e", {q: (round(x, 3) if isinstance(x, float) else x) for q, x in s["e2e"].items() if q != "path"})
+        print("   kernels", s["roofline"]["kernels_us"], "cpu", s.get("cpu_baseline", {}).get("value"))
+    print("cpu", d.get("cpu_baseline"))
+except Exception as e:
+    print("bench parse failed", e)
+P

@@ -24,7 +24,8 @@ namespace xt {
 namespace {
 
 constexpr int kMaxWorkers = 16;
-constexpr int64_t kDefaultChunk = 1 << 20;
+constexpr int64_t kDefaultChunk = 256 << 10;     // work unit of the pool (balance over the workers)
+constexpr int64_t kDefaultShip = 4 << 20;        // H2D granularity: every hipMemcpyAsync costs ~5-10 us of DMA set-up
 
 // 64 bytes per iteration with streaming stores; head/tail through memcpy.  The final sfence makes the data globally
 // visible before the caller hands the range to the DMA engine.
@@ -157,10 +158,11 @@ std::atomic<int> g_threads{4}, g_nt{1};
 extern "C" {
 
 int xt_stage_rows(void* dst_pinned, const void* src, int64_t bytes, void* dev_dst, int64_t chunk_bytes,
-                  int32_t n_threads, void* stream) {
+                  int64_t ship_bytes, int32_t n_threads, void* stream) {
   XT_REQUIRE(dst_pinned && src && bytes >= 0, "xt_stage_rows: null buffer / negative size");
   if (bytes == 0) return 0;
   if (chunk_bytes <= 0) chunk_bytes = xt::kDefaultChunk;
+  if (ship_bytes <= 0) ship_bytes = xt::kDefaultShip;
   if (n_threads < 0) n_threads = xt::g_threads.load();
   if (n_threads > xt::kMaxWorkers) n_threads = xt::kMaxWorkers;
   XT_REQUIRE((bytes + chunk_bytes - 1) / chunk_bytes < (1 << 20), "xt_stage_rows: chunk size too small for %lld bytes",
@@ -173,11 +175,14 @@ int xt_stage_rows(void* dst_pinned, const void* src, int64_t bytes, void* dev_ds
   j.nt = xt::g_nt.load();
   hipError_t err = hipSuccess;
   hipStream_t st = xt::as_stream(stream);
-  auto ship = [&](int k) {
+  int64_t shipped = 0;            // [0, shipped) has been handed to the DMA engine
+  auto ship = [&](int k) {        // chunks 0..k are staged: ship once ship_bytes have accumulated (or at the end)
     if (!dev_dst || err != hipSuccess) return;
-    const int64_t off = (int64_t)k * chunk_bytes;
-    const int64_t len = (bytes - off) < chunk_bytes ? (bytes - off) : chunk_bytes;
-    err = hipMemcpyAsync(static_cast<uint8_t*>(dev_dst) + off, j.dst + off, (size_t)len, hipMemcpyHostToDevice, st);
+    const int64_t staged = (k + 1 == j.nchunks) ? bytes : (int64_t)(k + 1) * chunk_bytes;
+    if (staged - shipped < ship_bytes && staged < bytes) return;
+    err = hipMemcpyAsync(static_cast<uint8_t*>(dev_dst) + shipped, j.dst + shipped, (size_t)(staged - shipped),
+                         hipMemcpyHostToDevice, st);
+    shipped = staged;
   };
   if (n_threads == 0) {       // inline: the calling thread copies chunk by chunk (hosts where a hand-over does not pay)
     for (int k = 0; k < j.nchunks; ++k) {

@@ -50,16 +50,25 @@ def impala_fields(action_dim):
 
 
 class _BufferSet(object):
+    """Pinned host staging + device buffers of one rollout.  The label fields share ONE pinned block and ONE device
+    block (256-byte aligned sub-arrays), so the labels of a whole rollout travel with a single H2D copy."""
+
     def __init__(self, cap, obs_tail, obs_u8, n_epochs, device, sig, fields=PPO_FIELDS):
         self.cap = cap
         self.sig = sig
         tdt = torch.uint8 if obs_u8 else torch.float32
         self.host = {"obs": torch.empty((cap,) + obs_tail, dtype=tdt, pin_memory=True)}
         self.dev = {"obs": torch.empty((cap,) + obs_tail, dtype=tdt, device=device)}
+        off, lay = 0, []
         for name, tdt2, width in fields:
-            shape = (cap, width) if width else (cap,)
-            self.host[name] = torch.empty(shape, dtype=tdt2, pin_memory=True)
-            self.dev[name] = torch.empty(shape, dtype=tdt2, device=device)
+            nbytes = cap * max(width, 1) * torch.empty((), dtype=tdt2).element_size()
+            lay.append((name, tdt2, (cap, width) if width else (cap,), off, nbytes))
+            off += (nbytes + 255) // 256 * 256
+        self.lab_host = torch.empty((max(off, 256),), dtype=torch.uint8, pin_memory=True)
+        self.lab_dev = torch.empty((max(off, 256),), dtype=torch.uint8, device=device)
+        for name, tdt2, shape, o, nbytes in lay:
+            self.host[name] = self.lab_host[o:o + nbytes].view(tdt2).view(shape)
+            self.dev[name] = self.lab_dev[o:o + nbytes].view(tdt2).view(shape)
         if n_epochs > 0:
             self.dev["perm"] = torch.empty((n_epochs, cap), dtype=torch.int32, device=device)
         self.host_np = {k: v.numpy() for k, v in self.host.items()}
@@ -135,7 +144,7 @@ class RolloutIngest(object):
             self.copy_stream.synchronize()
         elif plain:
             L.check(self._lib.xt_stage_rows(ctypes.c_void_p(s.host["obs"].data_ptr() + lo * row_bytes),
-                                            ctypes.c_void_p(obs.ctypes.data), obs.nbytes, ctypes.c_void_p(dev_ptr), 0, -1,
+                                            ctypes.c_void_p(obs.ctypes.data), obs.nbytes, ctypes.c_void_p(dev_ptr), 0, 0, -1,
                                             ctypes.c_void_p(self.copy_stream.cuda_stream)), "xt_stage_rows")
         else:       # a cast on the way in (float frames for a uint8 network, ...): as the upload path casts them
             np.copyto(obs_dst, obs.reshape(obs_dst.shape), casting="unsafe")
@@ -155,9 +164,8 @@ class RolloutIngest(object):
         n = self.n
         if s is None or n == 0:
             raise RuntimeError("RolloutIngest.finish(): nothing was ingested")
-        with torch.cuda.stream(self.copy_stream):          # the labels of the whole rollout: one copy per field
-            for f in self.fields:
-                s.dev[f[0]][:n].copy_(s.host[f[0]][:n], non_blocking=True)
+        with torch.cuda.stream(self.copy_stream):          # the labels of the whole rollout: ONE copy (a few 10 KB)
+            s.lab_dev.copy_(s.lab_host, non_blocking=True)
         s.done.record(self.copy_stream)
         torch.cuda.current_stream(self.device).wait_event(s.done)
         self.cur ^= 1

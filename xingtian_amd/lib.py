@@ -72,7 +72,7 @@ SIGNATURES = {
     "xt_build_arch": (c_char_p, []),
     "xt_tuning_get": (c_int32, [POINTER(Tuning)]),
     "xt_tuning_set": (c_int32, [POINTER(Tuning)]),
-    "xt_stage_rows": (c_int32, [_P, _P, c_int64, _P, c_int64, c_int32, _P]),
+    "xt_stage_rows": (c_int32, [_P, _P, c_int64, _P, c_int64, c_int64, c_int32, _P]),
     "xt_stage_tune": (c_int32, [c_int64, POINTER(c_float)]),
     "xt_stage_get": (c_int32, [POINTER(c_int32), POINTER(c_int32)]),
     "xt_stage_set": (c_int32, [c_int32, c_int32]),
