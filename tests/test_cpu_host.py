@@ -856,3 +856,120 @@ def test_data_parallel_guards_fail_identically_on_every_rank():
     c.opt_type = lib.OPT_TYPE["rmsprop"]
     with pytest.raises(NotImplementedError, match="adam"):
         parallel.dp_impala_step(None, c, 1e-3, 40.0, None, None, None, None, None, 4, 8, 0, 2)
+
+
+def _fanin_producer(name, explorer_id, n_msgs, slots, slot_bytes):
+    from xingtian_amd import transport
+    ring = transport.RingSet.attach(name, slots=slots, slot_bytes=slot_bytes)
+    rng = np.random.default_rng(1000 + explorer_id)
+    for seq in range(n_msgs):
+        obs = rng.integers(0, 256, (4, 84, 84, 4), dtype=np.uint8)
+        ok = ring.send({"cmd": "train", "from": explorer_id, "seq": seq},
+                       {"cur_state": obs, "action": np.full(4, explorer_id, np.int32), "sum": int(obs.sum())}, timeout=120.0)
+        assert ok
+    ring.close()
+
+
+def test_ring_set_fans_32_explorer_processes_into_one_learner_with_back_pressure():
+    """SURVEY 8 f1 fan-in: 32 producer PROCESSES, one 2-slot ring each (every producer has more messages than slots:
+    it blocks until the learner drains), one consumer polling round robin.  Every message arrives exactly once, intact,
+    in per-explorer order, tagged with the explorer it came from; a sweep serves at most one message per ring."""
+    from xingtian_amd import transport
+    n_exp, n_msgs, slots, slot_bytes = 32, 5, 2, 1 << 18
+    rs = transport.RingSet(n_exp, slots=slots, slot_bytes=slot_bytes)
+    ctx = mp.get_context("fork")
+    procs = [ctx.Process(target=_fanin_producer, args=(rs.names[i], i, n_msgs, slots, slot_bytes)) for i in range(n_exp)]
+    for p in procs:
+        p.start()
+    seen = {i: [] for i in range(n_exp)}
+    sweeps = []
+
+    def sink(data, ctr_info=None):
+        i = ctr_info["explorer_id"]
+        assert ctr_info["from"] == i and ctr_info["cmd"] == "train"
+        assert not data["cur_state"].flags.owndata                      # zero-copy view into the slot
+        assert int(data["cur_state"].sum()) == data["sum"] and (data["action"] == i).all()
+        seen[i].append(ctr_info["seq"])
+
+    try:
+        import time as _time
+        t0 = _time.monotonic()
+        total = 0
+        while total < n_exp * n_msgs and _time.monotonic() - t0 < 120.0:
+            k = rs.poll_into(sink)
+            assert k <= n_exp
+            if k:
+                sweeps.append(k)
+            else:
+                _time.sleep(0.001)
+            total += k
+        assert total == n_exp * n_msgs
+        for i in range(n_exp):
+            assert seen[i] == list(range(n_msgs)), (i, seen[i])
+        assert rs.served == [n_msgs] * n_exp and rs.pending() == 0
+        assert rs.recv_many_into(sink, 1, timeout=0.05) == 0
+        for p in procs:
+            p.join(30)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        rs.close()
+
+
+def _weights_reader(name, slot_bytes, last_seq, out_q):
+    from xingtian_amd import transport
+    import time as _time
+    ring = transport.WeightsRing(name=name, slot_bytes=slot_bytes, create=False)
+    seqs, t0 = [], _time.monotonic()
+    while (not seqs or seqs[-1] < last_seq) and _time.monotonic() - t0 < 120.0:
+        got = ring.fetch()
+        if got is None:
+            _time.sleep(0.0005)
+            continue
+        seq, ctr, w = got
+        ok = ctr["seq"] == seq and ctr["cmd"] == "weights" and all(v.flags.owndata and (v == float(seq)).all() for v in w.values()) \
+            and list(w) == ["conv/kernel:0", "conv/bias:0", "dense/kernel:0"]
+        if not ok:
+            out_q.put(("torn", seq))
+            return
+        seqs.append(seq)
+    out_q.put(("ok", seqs))
+    ring.close()
+
+
+def test_weights_ring_publishes_to_many_readers_without_torn_reads():
+    """SURVEY 8 f1 fan-out: one writer publishes 60 versions of a 1.2 MB weights dict (every element = the version
+    number, so a torn or half-written read is visible), four reader PROCESSES fetch concurrently: every fetch is one
+    internally consistent publish, sequence numbers only grow, everybody ends on the last version."""
+    from xingtian_amd import transport
+    slot_bytes = 2 << 20
+    ring = transport.WeightsRing(slot_bytes=slot_bytes, slots=3)
+    assert ring.fetch() is None
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    last = 60
+    readers = [ctx.Process(target=_weights_reader, args=(ring.name, slot_bytes, last, q)) for _ in range(4)]
+    for p in readers:
+        p.start()
+    try:
+        shapes = {"conv/kernel:0": (8, 8, 4, 32), "conv/bias:0": (32,), "dense/kernel:0": (1152, 256)}
+        import time as _time
+        for v in range(1, last + 1):
+            assert ring.publish({k: np.full(s, float(v), np.float32) for k, s in shapes.items()}, {"train_count": v}) == v
+            _time.sleep(0.002 if v % 7 else 0.0)
+        results = [q.get(timeout=120) for _ in readers]
+        for status, seqs in results:
+            assert status == "ok", (status, seqs)
+            assert seqs[-1] == last and all(b > a for a, b in zip(seqs, seqs[1:]))
+        with pytest.raises(ValueError):
+            ring.publish({"big": np.zeros(slot_bytes, np.uint8)})
+        for p in readers:
+            p.join(30)
+            assert p.exitcode == 0
+    finally:
+        for p in readers:
+            if p.is_alive():
+                p.terminate()
+        ring.close()

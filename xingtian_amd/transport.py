@@ -14,6 +14,8 @@ rollout batches to the learner (``cmd: train``) and weight dicts back to the exp
 * ``decode(buf)`` -> ``(ctr_info, data)`` with the arrays as ZERO-COPY views into ``buf``.
 * ``decode_into(buf, sink)`` -> hands the views straight to an ingest callback (``Algorithm.prepare_data``), so that a
   trajectory goes wire -> pinned staging -> HBM with exactly one host copy (``RolloutIngest.put``).
+* ``RingSet`` -- fan-in: one ``ShmRing`` per explorer, drained round robin by the learner (the broker's receive loop);
+  ``WeightsRing`` -- fan-out: the learner's weights to N explorers through a sequence-locked slot ring (``ShareBuf``).
 * ``ShmRing`` -- a single-producer / single-consumer ring of fixed-size slots in ``multiprocessing.shared_memory``
   carrying encoded messages between an explorer-side process and the learner process: the role of plasma's
   ``put_raw_buffer`` / ``get_buffers`` pair plus its control queue, without a server process.  ``send`` / ``recv``
@@ -50,9 +52,8 @@ def _plain(obj):
     return obj
 
 
-def encode(ctr_info, data):
-    """``data``: dict field -> ndarray | python object (the reference's train_data / weights dict).  Returns a
-    ``bytearray``: MAGIC | u32 header length | msgpack header | padding | array bytes (64-byte aligned each)."""
+def _layout(ctr_info, data):
+    """-> (msgpack header bytes, byte offset of the array section, [(offset, nbytes, contiguous array)], total bytes)"""
     arrays, objects, metas = [], {}, []
     off = 0
     for key, val in data.items():
@@ -66,15 +67,35 @@ def encode(ctr_info, data):
     header = msgpack.packb({"ctr": _plain(ctr_info), "obj": objects, "arr": metas, "order": list(data.keys())},
                            use_bin_type=True)
     base = _pad(8 + len(header))
-    buf = bytearray(base + off)
-    buf[0:4] = MAGIC
-    struct.pack_into("<I", buf, 4, len(header))
-    buf[8:8 + len(header)] = header
-    view = memoryview(buf)
-    for (_, _, _, aoff, nbytes), arr in zip(metas, arrays):
+    return header, base, [(m[3], m[4], a) for m, a in zip(metas, arrays)], base + off
+
+
+def _write(view, header, base, arrays):
+    view[0:4] = MAGIC
+    struct.pack_into("<I", view, 4, len(header))
+    view[8:8 + len(header)] = header
+    for aoff, nbytes, arr in arrays:
         if nbytes:
             view[base + aoff:base + aoff + nbytes] = arr.reshape(-1).view(np.uint8)
+
+
+def encode(ctr_info, data):
+    """``data``: dict field -> ndarray | python object (the reference's train_data / weights dict).  Returns a
+    ``bytearray``: MAGIC | u32 header length | msgpack header | padding | array bytes (64-byte aligned each)."""
+    header, base, arrays, total = _layout(ctr_info, data)
+    buf = bytearray(total)
+    _write(memoryview(buf), header, base, arrays)
     return buf
+
+
+def encode_into(view, ctr_info, data):
+    """Encode straight into a writable buffer (a shared-memory slot): one copy per array, no intermediate message.
+    Returns the encoded length; ValueError if the buffer is too small."""
+    header, base, arrays, total = _layout(ctr_info, data)
+    if total > len(view):
+        raise ValueError("message of {} bytes exceeds the {}-byte buffer".format(total, len(view)))
+    _write(view, header, base, arrays)
+    return total
 
 
 def _header(buf):
@@ -220,6 +241,168 @@ class ShmRing(object):
             self._hip.hipHostUnregister.argtypes = [__import__("ctypes").c_void_p]
             self._hip.hipHostUnregister(__import__("ctypes").c_void_p(self._pin_addr))
             self.pinned = False
+        try:
+            self.shm.close()
+            if self.owner:
+                self.shm.unlink()
+        except (BufferError, FileNotFoundError):
+            pass
+
+
+class RingSet(object):
+    """Fan-in of many explorers into one learner: ONE single-producer ring per explorer (so producers never contend and
+    ``ShmRing``'s lock-free single-writer protocol holds) and a learner-side poller that drains them round robin -- the
+    role of the broker's receive loop, which forwards every explorer's ``cmd: train`` message into the one queue the
+    learner's ``prepare_data`` loop reads (xt/framework/broker.py:97-119, xt/framework/learner.py:306-313).
+
+    * at most one message per ring per sweep and the sweep resumes behind the ring served last: a fast explorer cannot
+      starve the others;
+    * back pressure is per explorer: a full ring blocks (or times out) only its own producer;
+    * the sink sees ``ctr_info["explorer_id"]`` = ring index, the tag the broker derives from the socket identity
+      and ``FIFODistPolicy`` uses to route the new weights back (xt/algorithm/alg_utils.py:FIFODistPolicy).
+
+    Learner side: ``RingSet(n)`` creates the rings; explorer i attaches with ``RingSet.attach(names[i], ...)``."""
+
+    def __init__(self, n_rings, slots=4, slot_bytes=8 << 20):
+        self.rings = [ShmRing(slots=slots, slot_bytes=slot_bytes) for _ in range(int(n_rings))]
+        self.names = [r.name for r in self.rings]
+        self.slots, self.slot_bytes = int(slots), self.rings[0].slot_bytes if self.rings else int(slot_bytes)
+        self._next = 0
+        self.served = [0] * len(self.rings)
+
+    @staticmethod
+    def attach(name, slots=4, slot_bytes=8 << 20):
+        """Explorer side: open the ring the learner created for this explorer."""
+        return ShmRing(name=name, create=False, slots=slots, slot_bytes=slot_bytes)
+
+    def pin(self):
+        """Page-lock every ring (``ShmRing.pin``): frames are then DMA-copied to HBM straight out of the slots."""
+        return all([r.pin() for r in self.rings])
+
+    def pending(self):
+        return sum(r.pending() for r in self.rings)
+
+    def poll_into(self, sink, max_msgs=None):
+        """One non-blocking round-robin sweep: deliver at most one waiting message per ring to
+        ``sink(data, ctr_info=...)`` (zero-copy views, released after the sink returns).  Returns the number
+        delivered (0: nothing was waiting)."""
+        n = len(self.rings)
+        got = 0
+        for k in range(n):
+            if max_msgs is not None and got >= max_msgs:
+                break
+            i = (self._next + k) % n
+            ring = self.rings[i]
+            if ring.pending() == 0:
+                continue
+            tag = lambda data, ctr_info=None, _i=i: sink(data, ctr_info=dict(ctr_info or {}, explorer_id=_i))
+            if ring.recv_into(tag, block=False) is not None:
+                got += 1
+                self.served[i] += 1
+                last = i
+        if got:
+            self._next = (last + 1) % n
+        return got
+
+    def recv_many_into(self, sink, count, timeout=None):
+        """Block until ``count`` messages have been delivered (the learner's ``prepare_data_times`` loop,
+        learner.py:306-313) or ``timeout`` seconds passed; returns the number delivered."""
+        t0 = time.monotonic()
+        got = 0
+        while got < count:
+            k = self.poll_into(sink, max_msgs=count - got)
+            got += k
+            if k == 0:
+                if timeout is not None and time.monotonic() - t0 > timeout:
+                    break
+                time.sleep(0.0002)
+        return got
+
+    def close(self):
+        for r in self.rings:
+            r.close()
+
+
+class WeightsRing(object):
+    """Fan-out of the learner's weights to any number of explorers: one writer, N readers, no server process, no
+    per-reader queue -- the role of the reference's ``ShareBuf`` (one plasma object per publish that every explorer
+    fetches by id and the learner reference-counts, zeus/common/ipc/share_buffer.py:131-168) for the
+    ``get_weights()`` hand-over (xt/framework/learner.py:361-363).
+
+    Layout: 64-byte control block {latest u64 = sequence number of the newest COMPLETE publish} + ``slots`` x
+    (64-byte slot header {seq u64, nbytes u64} + payload).  Publish k goes to slot k % slots: the writer first sets
+    the slot's seq to 0 (invalid), writes the payload (``encode_into``: the packed parameter arrays + their name
+    table), then seq = k, then latest = k.  A reader copies the payload of slot latest % slots and accepts it only if
+    the slot's seq was k before AND after the copy (a sequence lock: a writer that laps the reader is detected, the
+    reader retries on the newer publish).  x86-64 total store order + one C call per store keep the order."""
+
+    def __init__(self, name=None, slot_bytes=8 << 20, slots=3, create=True):
+        self.slots, self.slot_bytes = int(slots), int(_pad(slot_bytes))
+        size = _ALIGN + self.slots * (_ALIGN + self.slot_bytes)
+        if create:
+            self.shm = shared_memory.SharedMemory(name=name, create=True, size=size)
+            self.shm.buf[:_ALIGN] = bytes(_ALIGN)
+            for i in range(self.slots):
+                o = _ALIGN + i * (_ALIGN + self.slot_bytes)
+                self.shm.buf[o:o + _ALIGN] = bytes(_ALIGN)
+        else:
+            self.shm = shared_memory.SharedMemory(name=name)
+        self.owner = bool(create)
+        self.name = self.shm.name
+        self._latest = np.ndarray((1,), dtype=np.uint64, buffer=self.shm.buf, offset=0)
+        self._hdr = [np.ndarray((2,), dtype=np.uint64, buffer=self.shm.buf, offset=_ALIGN + i * (_ALIGN + self.slot_bytes))
+                     for i in range(self.slots)]
+        self._seen = 0
+
+    def _payload(self, i):
+        o = _ALIGN + i * (_ALIGN + self.slot_bytes) + _ALIGN
+        return self.shm.buf[o:o + self.slot_bytes]
+
+    # ---- writer (the learner)
+    def publish(self, weights, ctr_info=None):
+        """Write the name -> ndarray dict (``get_weights()``: views into the pinned D2H block are fine, every array
+        is copied exactly once, into the slot).  Returns the sequence number of this publish."""
+        k = int(self._latest[0]) + 1
+        i = k % self.slots
+        self._hdr[i][0] = 0
+        view = self._payload(i)
+        n = encode_into(view, dict(ctr_info or {}, cmd="weights", seq=k), weights)
+        del view
+        self._hdr[i][1] = n
+        self._hdr[i][0] = k
+        self._latest[0] = k
+        return k
+
+    # ---- readers (explorers)
+    def latest(self):
+        return int(self._latest[0])
+
+    def fetch(self, newer_than=None, retries=64):
+        """-> (seq, ctr_info, weights) of the newest complete publish with private copies of the arrays, or None when
+        nothing newer than ``newer_than`` (default: the last one this reader fetched) has been published."""
+        floor = self._seen if newer_than is None else int(newer_than)
+        for _ in range(retries):
+            k = int(self._latest[0])
+            if k == 0 or k <= floor:
+                return None
+            i = k % self.slots
+            if int(self._hdr[i][0]) != k:
+                continue                              # the writer already recycles this slot: a newer publish is coming
+            n = int(self._hdr[i][1])
+            view = self._payload(i)
+            blob = bytes(view[:n])                    # the one copy out of shared memory
+            del view
+            if int(self._hdr[i][0]) != k:
+                continue                              # torn: the writer lapped us during the copy
+            ctr, data = decode(blob)
+            data = {name: (v.copy() if isinstance(v, np.ndarray) else v) for name, v in data.items()}
+            self._seen = k
+            return k, ctr, data
+        raise RuntimeError("WeightsRing.fetch: no stable publish after {} attempts".format(retries))
+
+    def close(self):
+        self._latest = None
+        self._hdr = None
         try:
             self.shm.close()
             if self.owner:
