@@ -35,6 +35,13 @@ extern "C" {
 #define XT_ACT_NONE 0
 #define XT_ACT_RELU 1
 #define XT_ACT_TANH 2
+/* ABI >= 8: the other monotonic entries of ACTIVATION_MAP (xt/model/model_utils.py:8-20); swish / gelu are refused */
+#define XT_ACT_SIGMOID 3
+#define XT_ACT_SOFTSIGN 4
+#define XT_ACT_SOFTPLUS 5
+#define XT_ACT_LEAKY_RELU 6      /* tf.nn.leaky_relu, alpha = 0.2 */
+#define XT_ACT_ELU 7
+#define XT_ACT_SELU 8
 
 /* ------------------------------------------------------------------ misc */
 int xt_abi_version(void);
@@ -106,6 +113,13 @@ typedef struct xt_input_xform {
 int xt_gae_f64(const float* value, const double* reward, const uint8_t* done,
                double* adv, double* target_value, float* old_value,
                int32_t n_traj, int32_t T, double gamma, double lam, void* stream);
+
+/* Advantage normalisation over the whole rollout, in place, float64 (ABI >= 8):
+ *     adv <- (adv - mean(adv)) / (std(adv) + eps)        (numpy's population std)
+ * the line the reference carries commented out, xt/algorithm/ppo/ppo.py:73 -- so it is an option of the plugin
+ * (model_config ADV_NORM, default False), applied to the concatenated rollout before Model.train.  One workgroup,
+ * wave-level (DPP shuffle) reductions in a fixed order.  stats (may be NULL): 2 doubles, mean and std. */
+int xt_adv_normalize_f64(double* adv, int64_t n, double eps, double* stats, void* stream);
 
 /* ------------------------------------------------ rollout staging (host) */
 /* Copy `bytes` of an arriving rollout array from (pageable) host memory `src` into the page-locked staging buffer

@@ -258,23 +258,60 @@ def col2im(dcols, lay, b):
     return dxp[:, lay.pt:lay.pt + lay.in_h, lay.pl:lay.pl + lay.in_w, :]
 
 
+SELU_SCALE, SELU_ALPHA, LEAKY_ALPHA = 1.0507009873554805, 1.6732632423543772, 0.2     # tf.nn.selu / tf.nn.leaky_relu
+
+
 def act_fwd(z, act):
+    """ACTIVATION_MAP of xt/model/model_utils.py:8-20 (TF 1.15 op definitions); swish / gelu are not supported by the
+    product (their derivative needs the pre-activation, which is not stored) and are absent here too."""
     if act == "relu":
         return np.maximum(z, 0)
     if act == "tanh":
         return np.tanh(z)
+    if act == "sigmoid":
+        return 1.0 / (1.0 + np.exp(-z))
+    if act == "softsign":
+        return z / (1.0 + np.abs(z))
+    if act == "softplus":
+        return np.logaddexp(0.0, z)
+    if act == "leaky_relu":
+        return np.where(z > 0, z, LEAKY_ALPHA * z)
+    if act == "elu":
+        return np.where(z > 0, z, np.expm1(np.minimum(z, 0)))
+    if act == "selu":
+        return SELU_SCALE * np.where(z > 0, z, SELU_ALPHA * np.expm1(np.minimum(z, 0)))
     if act is None or act == "none":
         return z
     raise KeyError(act)
 
 
 def act_bwd(dy, y, act):
-    """d(pre-activation) from d(post) and the saved OUTPUT y."""
+    """d(pre-activation) from d(post) and the saved OUTPUT y.  The pre-activation z is recovered from y in closed
+    form (every supported activation is strictly monotonic) and the textbook derivative is evaluated at z -- not the
+    from-the-output shortcuts the kernels use (cross-checked against torch autograd in tests/test_oracle.py)."""
     if act == "relu":
         return dy * (y > 0)
     if act == "tanh":
         return dy * (1.0 - y * y)
-    return dy
+    if act == "sigmoid":
+        return dy * y * (1.0 - y)
+    if act == "softsign":
+        z = y / (1.0 - np.abs(y))
+        return dy / np.square(1.0 + np.abs(z))
+    if act == "softplus":
+        z = y + np.log(-np.expm1(-y))                # y = log(1 + e^z)  ->  z = log(e^y - 1)
+        return dy / (1.0 + np.exp(-z))
+    if act == "leaky_relu":
+        return dy * np.where(y > 0, 1.0, LEAKY_ALPHA)
+    if act == "elu":
+        z = np.where(y > 0, y, np.log1p(np.minimum(y, 0)))
+        return dy * np.where(z > 0, 1.0, np.exp(np.minimum(z, 0)))
+    if act == "selu":
+        z = np.where(y > 0, y / SELU_SCALE, np.log1p(np.minimum(y, 0) / (SELU_SCALE * SELU_ALPHA)))
+        return dy * SELU_SCALE * np.where(z > 0, 1.0, SELU_ALPHA * np.exp(np.minimum(z, 0)))
+    if act is None or act == "none":
+        return dy
+    raise KeyError(act)
 
 
 class ActorCritic(object):

@@ -50,17 +50,18 @@ class TorchActorCritic(object):
                     y = y.permute(0, 2, 3, 1)  # back to NHWC (Flatten order H,W,C)
                 else:
                     y = x.reshape(b, -1) @ w + bias
-                if lay.act == "relu":
-                    y = torch.relu(y)
-                elif lay.act == "tanh":
-                    y = torch.tanh(y)
-                x = y
+                x = _ACT[lay.act](y)
             feats.append(x.reshape(b, -1))
         f_pi, f_v = feats[0], feats[-1]
         wpi = self.params[self.spec["pi_name"] + "/kernel"].reshape(f_pi.shape[1], -1)
         logits = f_pi @ wpi + self.params[self.spec["pi_name"] + "/bias"]
         value = f_v @ self.params[self.spec["v_name"] + "/kernel"] + self.params[self.spec["v_name"] + "/bias"]
         return logits, value
+
+
+_ACT = {"relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid, "softsign": F.softsign, "softplus": lambda y: torch.logaddexp(y, torch.zeros_like(y)),   # (F.softplus switches to the identity above 20)
+        
+        "leaky_relu": lambda y: F.leaky_relu(y, 0.2), "elu": F.elu, "selu": F.selu, None: lambda y: y, "none": lambda y: y}
 
 
 def ppo_loss_torch(logits, value, action, old_logp, adv, old_v, target_v,

@@ -120,6 +120,13 @@ LAYER_CASES = [
     ("mlp_64_tanh", "dense", (1, 1), 64, 64, 1, 1, "valid", "tanh", 130, False),
     ("conv5_s1", "conv", (15, 15), 4, 32, 5, 1, "valid", "none", 3, False),
     ("conv3_s3_same", "conv", (10, 10), 8, 12, 3, 3, "same", "tanh", 3, False),
+    # the other monotonic entries of ACTIVATION_MAP (xt/model/model_utils.py:8-20), one per kernel family
+    ("fc_sigmoid", "dense", (1, 1), 64, 64, 1, 1, "valid", "sigmoid", 130, False),
+    ("fc_softsign", "dense", (1, 1), 3136, 256, 1, 1, "valid", "softsign", 37, False),
+    ("conv2_softplus", "conv", (20, 20), 32, 32, 4, 2, "valid", "softplus", 7, False),
+    ("conv3_leaky", "conv", (9, 9), 32, 64, 3, 1, "valid", "leaky_relu", 9, False),
+    ("conv1_u8_elu", "conv", (84, 84), 4, 32, 8, 4, "valid", "elu", 5, True),
+    ("imp_conv2_same_selu", "conv", (21, 21), 16, 32, 4, 2, "same", "selu", 6, False),
 ]
 
 
@@ -212,8 +219,9 @@ def test_layer_dgrad(L, case):
     dy = rng.standard_normal((m, lay.cout)).astype(np.float32)
     dcols = dy.astype(np.float64) @ w.astype(np.float64).T
     dx = nets.col2im(dcols, lay, b) if lay.kind == "conv" else dcols.reshape(x_raw.shape)
-    for act_prev in ("relu", "tanh"):
-        xp = x_raw if act_prev == "relu" else np.tanh(x_raw).astype(np.float32)
+    extra = (lay.act,) if lay.act not in (None, "relu", "tanh") else ()     # the producer's activation derivative
+    for act_prev in ("relu", "tanh") + extra:
+        xp = x_raw if act_prev == "relu" else nets.act_fwd(x_raw.astype(np.float64), act_prev).astype(np.float32)
         ref = nets.act_bwd(dx.reshape(xp.shape), xp.astype(np.float64), act_prev)
         g = geom_of(L, lay)
         out = torch.full(xp.shape, float("nan"), device="cuda")
@@ -221,7 +229,8 @@ def test_layer_dgrad(L, case):
                                         L.ACT[act_prev], L.ptr(out), None), "dgrad")
         got = out.cpu().numpy()
         assert np.isfinite(got).all(), case[0]
-        assert rel_err(got, ref) < 3e-6, (case[0], act_prev)
+        # (softplus / softsign: the fp32 output carries the pre-activation only to ~1e-7 relative near saturation)
+        assert rel_err(got, ref) < (3e-6 if not extra or act_prev in ("relu", "tanh") else 2e-5), (case[0], act_prev)
 
 
 # ------------------------------------------------------------------ heads / losses
@@ -574,3 +583,22 @@ def test_impala_loss_kernel_vs_executed_reference(L, golden_dir):
         # index/mask behaviour bit-exact: zero gradient exactly where the executed reference has zero gradient
         assert np.array_equal(dlogits.cpu().numpy() == 0, g["dlogits"] == 0), f
         assert (dbase.cpu().numpy().reshape(n_traj, tlen)[:, -1] == 0).all(), f
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 1000, 4096, 4097, 40000])
+def test_adv_normalize_f64_matches_numpy(L, n):
+    """ADV_NORM (the reference's commented-out line, xt/algorithm/ppo/ppo.py:73): (adv - adv.mean()) / (adv.std() + 1e-8)
+    in float64 on the device with wave-level reductions; numpy sums pairwise, the kernel in a fixed strided order, so the
+    bar is 1e-12 relative to the normalised scale (float64 eps x a small multiple), not bit equality."""
+    rng = np.random.default_rng(n)
+    adv = rng.standard_normal(n) * 3.0 + 0.7
+    want = (adv - adv.mean()) / (adv.std() + 1e-8)
+    d = torch.from_numpy(adv.copy()).cuda()
+    stats = torch.zeros(2, dtype=torch.float64, device="cuda")
+    L.check(L.load().xt_adv_normalize_f64(L.ptr(d), n, 1e-8, L.ptr(stats), None), "xt_adv_normalize_f64")
+    got, st = d.cpu().numpy(), stats.cpu().numpy()
+    assert abs(st[0] - adv.mean()) < 1e-13 * max(1.0, abs(adv.mean())) and abs(st[1] - adv.std()) < 1e-13 * max(1.0, adv.std())
+    assert np.max(np.abs(got - want)) <= 1e-12 * max(1.0, np.max(np.abs(want)))
+    d2 = torch.from_numpy(adv.copy()).cuda()              # reproducible: same bits run to run
+    L.check(L.load().xt_adv_normalize_f64(L.ptr(d2), n, 1e-8, None, None), "xt_adv_normalize_f64")
+    assert torch.equal(d, d2)

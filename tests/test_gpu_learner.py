@@ -89,6 +89,16 @@ def _mk(which, batch):
         spec = netspec.ppo_cnn((42, 42, 4), 6, (64,), "tanh", False)
         ospec = nets.ppo_cnn_spec((42, 42, 4), 6, (64,), "tanh", False)
         sd, u8 = (42, 42, 4), True
+    elif which.startswith("cnn42_act_"):      # the other monotonic entries of ACTIVATION_MAP (model_utils.py:8-20)
+        act = which[len("cnn42_act_"):]
+        spec = netspec.ppo_cnn((42, 42, 4), 6, (64,), act, False)
+        ospec = nets.ppo_cnn_spec((42, 42, 4), 6, (64,), act, False)
+        sd, u8 = (42, 42, 4), True
+    elif which.startswith("mlp_act_"):
+        act = which[len("mlp_act_"):]
+        spec = netspec.ppo_mlp((4,), 2, (64, 64), act, False)
+        ospec = nets.ppo_mlp_spec((4,), 2, (64, 64), act, False)
+        sd, u8 = (4,), False
     else:
         spec = netspec.ppo_mlp((4,), 2, (64, 64), "tanh", False)
         ospec = nets.ppo_mlp_spec((4,), 2, (64, 64), "tanh", False)
@@ -98,7 +108,9 @@ def _mk(which, batch):
 
 
 @pytest.mark.parametrize("which,b", [("cnn84", 48), ("cnn84", 320), ("cnn84", 261), ("cnn84", 255), ("cnn84", 256),
-                                     ("cnn42_unshared", 33), ("cnn42_a18", 40), ("cnn30_inferred", 50), ("mlp", 200)])
+                                     ("cnn42_unshared", 33), ("cnn42_a18", 40), ("cnn30_inferred", 50), ("mlp", 200),
+                                     ("cnn42_act_softplus", 33), ("cnn42_act_selu", 33), ("cnn42_act_leaky_relu", 33),
+                                     ("mlp_act_elu", 200), ("mlp_act_sigmoid", 64), ("mlp_act_softsign", 64)])
 def test_ppo_step_loss_and_grads_vs_oracle(which, b):
     """b = 320 is BASELINE.json's minibatch (breakout_ppo.yaml BATCH_SIZE): the launch configurations of the
     benchmark (flattened first-layer kernels, two-wave-group forwards, register-direct conv2, bf16x6 input
@@ -1178,3 +1190,36 @@ def test_weight_publish_snapshot_is_current_and_views_outlive_the_next_updates()
         dev = alg.actor.net.params.cpu().numpy()
         for k, (off, shape) in alg.actor.net.spec.names.items():
             assert np.array_equal(w[k].reshape(-1), dev[off:off + w[k].size]), (upd, k)
+
+
+def test_adv_norm_option_normalises_the_rollout_before_training_and_defaults_off():
+    """model_config ADV_NORM: the update equals the plain update on host-normalised advantages (same shuffles), for
+    the upload path and the streamed path; without the key nothing is normalised (the reference's behaviour)."""
+    from xingtian_amd.algorithm import alg_builder
+    rng = np.random.default_rng(11)
+    trajs = []
+    for _ in range(3):
+        t = 40
+        trajs.append({"cur_state": rng.standard_normal((t, 4)).astype(np.float32), "action": rng.integers(0, 2, t).astype(np.int32),
+                      "logp": (-np.abs(rng.standard_normal((t, 1))) - 0.3).astype(np.float32), "adv": rng.standard_normal((t, 1)) * 2 + 1,
+                      "old_value": rng.standard_normal((t, 1)).astype(np.float32), "target_value": rng.standard_normal((t, 1))})
+    alladv = np.concatenate([tr["adv"] for tr in trajs])
+    mean, std = alladv.mean(), alladv.std()
+    normed = [dict(tr, adv=(tr["adv"] - mean) / (std + 1e-8)) for tr in trajs]
+    perms = np.stack([rng.permutation(120) for _ in range(2)]).astype(np.int32)
+
+    def run(cfg_extra, data, stream):
+        mi = {"actor": {"model_name": "PpoMlp", "state_dim": [4], "action_dim": 2, "type": "learner",
+                        "model_config": dict({"BATCH_SIZE": 32, "NUM_SGD_ITER": 2, "SEED": 1, "STREAM_INGEST": stream}, **cfg_extra)}}
+        alg = alg_builder("PPO", mi, {"instance_num": 3, "agent_num": 1})
+        for tr in data:
+            alg.prepare_data(tr)
+        loss = alg.train(perms=perms)
+        return float(loss), alg.actor.net.params.cpu().numpy().copy()
+
+    for stream in (True, False):
+        l_opt, w_opt = run({"ADV_NORM": True}, trajs, stream)
+        l_ref, w_ref = run({}, normed, stream)
+        l_off, w_off = run({}, trajs, stream)
+        assert abs(l_opt - l_ref) < 1e-6 * max(1.0, abs(l_ref)) and np.allclose(w_opt, w_ref, rtol=0, atol=1e-7)
+        assert not np.allclose(w_off, w_ref, rtol=0, atol=1e-5), "ADV_NORM must default to off"

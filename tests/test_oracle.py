@@ -73,6 +73,34 @@ def test_ppo_grads_match_torch_autograd_fp64(which):
             np.testing.assert_allclose(o.net.params[k], t.net.params[k].detach().numpy(), rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("act", ["sigmoid", "softsign", "softplus", "leaky_relu", "elu", "selu"])
+def test_monotonic_activations_match_torch_autograd_fp64(act):
+    """The other monotonic entries of the reference's ACTIVATION_MAP (xt/model/model_utils.py:8-20): the oracle's
+    forward and its hand-derived backward (pre-activation recovered from the saved output, textbook derivative) against
+    torch autograd through torch's own definitions of the same functions, on a conv + dense PPO network."""
+    rng = np.random.default_rng(5)
+    b = 5
+    spec = nets.ppo_cnn_spec((15, 15, 4), 3, hidden_sizes=(12,), act=act, vf_share=False)
+    obs = rng.integers(0, 256, (b, 15, 15, 4)).astype(np.uint8)
+    params = nets.init_params(spec, seed=2, bias_scale=0.2)
+    cfg = dict(LR=3e-4, LOSS_CLIPPING=0.2, ENTROPY_LOSS=0.01, VF_CLIP=0.7, CRITIC_LOSS_COEF=0.8,
+               MAX_GRAD_NORM=0.5, BATCH_SIZE=b, NUM_SGD_ITER=1)
+    lab = _labels(rng, b, spec["action_dim"])
+    out = nets.PpoLearnerOracle(spec, params, cfg, np.float64).step(obs, *lab)
+    tl, tg, gn = torch_ref.TorchPpoLearner(spec, params, cfg, torch.float64).step(obs, *lab)
+    assert abs(out["loss"] - tl) < 1e-10 * max(1, abs(tl))
+    for k in tg:
+        np.testing.assert_allclose(out["grads"][k], tg[k].numpy(), rtol=1e-8, atol=1e-12, err_msg=k)
+    z = np.linspace(-30.0, 30.0, 241)
+    y = nets.act_fwd(z, act)
+    zt = torch.tensor(z, requires_grad=True)
+    yt = torch_ref._ACT[act](zt)
+    yt.sum().backward()
+    np.testing.assert_allclose(y, yt.detach().numpy(), rtol=1e-12, atol=1e-300)
+    keep = np.abs(y) < 1 - 1e-9 if act == "softsign" else (y > 1e-12 if act == "softplus" else np.ones_like(y, bool))
+    np.testing.assert_allclose(nets.act_bwd(np.ones_like(z), y, act)[keep], zt.grad.numpy()[keep], rtol=1e-6, atol=1e-12)
+
+
 def test_gauss_ppo_grads_match_torch_autograd_fp64():
     """DiagGaussian PPO (pendulum_ppo.yaml shape: state 3, action 1, tanh 64-64 unshared) + a 3-dim action case."""
     for sd, ad in (((3,), 1), ((5,), 3)):

@@ -83,20 +83,49 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) {
   return f.d <= 1 ? n : __umulhi(n, f.magic);
 }
 
-// tanhf is ~60 instructions of libdevice code; kept OUT of line so that epilogues that apply the activation to
-// 16..64 accumulator registers do not inline it 64 times (code size = cold instruction-fetch time per launch)
-__device__ __noinline__ static float xt_tanhf(float z) { return tanhf(z); }
+// The transcendental activations are kept OUT of line (one shared body) so that epilogues that apply the activation to
+// 16..64 accumulator registers do not inline ~60 instructions of libdevice code 64 times (code size = cold
+// instruction-fetch time per launch).  ACTIVATION_MAP of xt/model/model_utils.py:8-20; swish and gelu are not
+// monotonic, so their derivative cannot be taken from the saved OUTPUT (this design stores post-activations only)
+// and the plugin refuses them.
+constexpr float kSeluScale = 1.0507009873554805f, kSeluAlpha = 1.6732632423543772f;   // tf.nn.selu
+constexpr float kLeakyAlpha = 0.2f;                                                  // tf.nn.leaky_relu default
+__device__ __noinline__ static float xt_act_slow(float z, int act) {
+  switch (act) {
+    case XT_ACT_TANH: return tanhf(z);
+    case XT_ACT_SIGMOID: return 1.f / (1.f + expf(-z));
+    case XT_ACT_SOFTSIGN: return z / (1.f + fabsf(z));
+    case XT_ACT_SOFTPLUS: return fmaxf(z, 0.f) + log1pf(expf(-fabsf(z)));       // log(1 + e^z), overflow-free
+    case XT_ACT_ELU: return z > 0.f ? z : expm1f(z);
+    case XT_ACT_SELU: return kSeluScale * (z > 0.f ? z : kSeluAlpha * expm1f(z));
+    default: return z;
+  }
+}
+__device__ __noinline__ static float xt_act_grad_slow(float y, int act) {
+  switch (act) {
+    case XT_ACT_TANH: return 1.f - y * y;
+    case XT_ACT_SIGMOID: return y * (1.f - y);
+    case XT_ACT_SOFTSIGN: { const float u = 1.f - fabsf(y); return u * u; }     // 1 - |y| = 1 / (1 + |z|)
+    case XT_ACT_SOFTPLUS: return -expm1f(-y);                                   // sigmoid(z) = 1 - e^{-y}
+    case XT_ACT_ELU: return y > 0.f ? 1.f : y + 1.f;                            // TF EluGrad (from the outputs)
+    case XT_ACT_SELU: return y > 0.f ? kSeluScale : y + kSeluScale * kSeluAlpha; // TF SeluGrad (from the outputs)
+    default: return 1.f;
+  }
+}
 
 __device__ __forceinline__ float act_apply(float z, int act) {
   if (act == XT_ACT_RELU) return z > 0.f ? z : 0.f;
-  if (act == XT_ACT_TANH) return xt_tanhf(z);
-  return z;
+  if (act == XT_ACT_NONE) return z;
+  if (act == XT_ACT_LEAKY_RELU) return z > 0.f ? z : kLeakyAlpha * z;
+  return xt_act_slow(z, act);
 }
-// d(pre-activation)/d(post) from the saved OUTPUT y
+// d(post)/d(pre-activation) from the saved OUTPUT y (every supported activation is monotonic)
 __device__ __forceinline__ float act_grad(float y, int act) {
   if (act == XT_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  if (act == XT_ACT_NONE) return 1.f;
   if (act == XT_ACT_TANH) return 1.f - y * y;
-  return 1.f;
+  if (act == XT_ACT_LEAKY_RELU) return y > 0.f ? 1.f : kLeakyAlpha;
+  return xt_act_grad_slow(y, act);
 }
 
 // ---- argument blocks shared between translation units -------------------------------------

@@ -1068,6 +1068,39 @@ __global__ __launch_bounds__(256) void keras_impala_loss_reduce_kernel(const flo
     if (acc) { acc[0] += l * (float)B; acc[1] += (float)B; }
   }
 }
+// Advantage normalisation over a whole rollout, float64, in place:  adv <- (adv - mean(adv)) / (std(adv) + eps) with
+// numpy's population std (two passes: mean, then mean((x - mean)^2)), the line the reference carries as a comment
+// (xt/algorithm/ppo/ppo.py:73) -- an OPTION here (model_config ADV_NORM, default off).  One workgroup: every thread
+// sums a strided slice, the 64 lanes of a wave combine with xor shuffles (DPP, no LDS), the 16 wave sums go through
+// LDS in wave order: a fixed summation order, so the result is reproducible run to run (it differs from numpy's
+// pairwise order in the last bits; the parity test states 1e-12).
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double block_sum_f64(double v, double* red) {
+  v = wave_sum_f64(v);
+  __syncthreads();                       // red may still be read from the previous reduction
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+  return s;
+}
+__global__ __launch_bounds__(1024) void adv_normalize_f64_kernel(double* __restrict__ adv, long long n, double eps,
+                                                                 double* __restrict__ stats) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) s += adv[i];
+  const double mean = block_sum_f64(s, red) / (double)n;
+  double q = 0.0;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) { const double d = adv[i] - mean; q += d * d; }
+  const double sd = sqrt(block_sum_f64(q, red) / (double)n);
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) adv[i] = (adv[i] - mean) / (sd + eps);
+  if (stats && threadIdx.x == 0) { stats[0] = mean; stats[1] = sd; }
+}
+
 }  // namespace xt
 
 int xt_keras_impala_loss(const float* logits, const float* value, int32_t B, int32_t A, const int32_t* idx,
@@ -1132,6 +1165,14 @@ int xt_heads_bwd(const float* f_pi, const float* f_v, int32_t B, int32_t F, int3
   XT_LAUNCH_CHECK();
   hipLaunchKernelGGL(xt::heads_wgrad_kernel, dim3((F + 63) / 64), dim3(256), 0, st, f_pi, f_v, B, F, A, dlogits, dvalue,
                      dwpi, dbpi, dwv, dbv);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
+int xt_adv_normalize_f64(double* adv, int64_t n, double eps, double* stats, void* stream) {
+  XT_REQUIRE(adv && n >= 0, "xt_adv_normalize_f64: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(xt::adv_normalize_f64_kernel, dim3(1), dim3(1024), 0, xt::as_stream(stream), adv, (long long)n, eps, stats);
   XT_LAUNCH_CHECK();
   return 0;
 }

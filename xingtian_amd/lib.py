@@ -14,7 +14,8 @@ import torch  # noqa: F401  (must precede loading the HIP library, see module do
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxt_mi355x.so")
 
-ACT = {"none": 0, None: 0, "relu": 1, "tanh": 2}
+ACT = {"none": 0, None: 0, "relu": 1, "tanh": 2, "sigmoid": 3, "softsign": 4, "softplus": 5, "leaky_relu": 6, "elu": 7,
+       "selu": 8}
 
 
 class ConvGeom(Structure):
@@ -76,6 +77,7 @@ SIGNATURES = {
     "xt_stage_tune": (c_int32, [c_int64, POINTER(c_float)]),
     "xt_stage_get": (c_int32, [POINTER(c_int32), POINTER(c_int32)]),
     "xt_stage_set": (c_int32, [c_int32, c_int32]),
+    "xt_adv_normalize_f64": (c_int32, [_P, c_int64, c_double, _P, _P]),
     "xt_gae_f64": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_double, c_double, _P]),
     "xt_layer_fwd": (c_int32, [POINTER(ConvGeom), POINTER(InputXform), c_int32, _P, _P, _P, _P, _P, _P, c_int32, _P]),
     "xt_layer_wgrad": (c_int32, [POINTER(ConvGeom), POINTER(InputXform), c_int32, _P, _P, _P, _P, _P, c_int32, _P]),

@@ -42,11 +42,26 @@ def initial_weights(spec, seed=None, baseline_norm_std=None):
 
 
 def _act(z, act):
+    """ACTIVATION_MAP of xt/model/model_utils.py:8-20 (the monotonic entries the HIP learner trains with)."""
     if act == "relu":
         return np.maximum(z, 0.0, out=z)
     if act == "tanh":
         return np.tanh(z, out=z)
-    return z
+    if act == "sigmoid":
+        return (1.0 / (1.0 + np.exp(-z))).astype(z.dtype)
+    if act == "softsign":
+        return z / (1.0 + np.abs(z))
+    if act == "softplus":
+        return np.logaddexp(0.0, z).astype(z.dtype)
+    if act == "leaky_relu":
+        return np.where(z > 0, z, np.float32(0.2) * z)
+    if act == "elu":
+        return np.where(z > 0, z, np.expm1(np.minimum(z, 0)))
+    if act == "selu":
+        return (1.0507009873554805 * np.where(z > 0, z, 1.6732632423543772 * np.expm1(np.minimum(z, 0)))).astype(z.dtype)
+    if act in (None, "none"):
+        return z
+    raise KeyError("activation {} not implemented.".format(act))
 
 
 class CpuActorCritic(object):

@@ -39,6 +39,9 @@ class PPO(XTModel):
         self.verbose = model_config.get("SUMMARY", SUMMARY)
         self.vf_clip = model_config.get("VF_CLIP", VF_CLIP)
         self.use_graph = bool(model_config.get("USE_HIP_GRAPH", True))
+        # (adv - adv.mean()) / (adv.std() + 1e-8) over the whole rollout: a COMMENT in the reference
+        # (xt/algorithm/ppo/ppo.py:73), hence off unless the configuration asks for it
+        self.adv_norm = bool(model_config.get("ADV_NORM", False))
         self.seed = model_config.get("SEED")
         self._rng = np.random.default_rng(self.seed)
 
@@ -59,7 +62,10 @@ class PPO(XTModel):
         super().__init__(model_info)
 
     # ---- trunk options shared by the CNN / MLP variants -------------------------------------------------------
-    TRUNK_ACTIVATIONS = ("relu", "tanh")        # what the HIP epilogues implement (the reference's map has more)
+    # what the HIP epilogues implement: every MONOTONIC entry of the reference's ACTIVATION_MAP
+    # (xt/model/model_utils.py:8-20).  swish / gelu are refused: their derivative cannot be taken from the stored
+    # post-activation, and no bundled configuration uses them.
+    TRUNK_ACTIVATIONS = ("relu", "tanh", "sigmoid", "softsign", "softplus", "leaky_relu", "elu", "selu")
 
     def _read_trunk_options(self, model_config, share_default, hidden_default, act_default):
         """VF_SHARE_LAYERS / hidden_sizes / activation with the reference's per-variant defaults
@@ -173,11 +179,19 @@ class PPO(XTModel):
                 self._perm_dense = torch.empty((self.num_sgd_iter, n), dtype=torch.int32, device=self.net.device)
             perm = self._perm_dense
         perm.copy_(self._take_perms(n, perms), non_blocking=True)
+        self._normalize_adv(d["adv"][:n])
         # the library keeps a small cache of hipGraphs: the two alternating buffer sets replay their own graph
         acc = self.net.ppo_train(self._cfg, d["obs"][:n], perm, d["action"][:n], d["old_logp"][:n], d["adv"][:n],
                                  d["old_v"][:n], d["target_v"][:n], use_graph=self.use_graph)
         self._ingest.mark_consumed()
         return self._finish_update(acc, n)
+
+    def _normalize_adv(self, adv_dev):
+        """ADV_NORM: the rollout's float64 advantages normalised in place on the device (C ABI xt_adv_normalize_f64)."""
+        if self.adv_norm:
+            from xingtian_amd import lib as L
+            L.check(self.net.lib.xt_adv_normalize_f64(L.ptr(adv_dev), int(adv_dev.numel()), 1e-8, None, L.stream_ptr()),
+                    "xt_adv_normalize_f64")
 
     def _finish_update(self, acc, n):
         """Everything the host has to do for the NEXT publish / update is done while the GPU runs this one: the D2H of
@@ -230,6 +244,7 @@ class PPO(XTModel):
         r = self._upload(state, label)
         nbatch = r["obs"].shape[0]
         r["perm"].copy_(self._take_perms(nbatch, perms), non_blocking=True)
+        self._normalize_adv(r["adv"])
         acc = self.net.ppo_train(self._cfg, r["obs"], r["perm"], r["action"], r["old_logp"], r["adv"], r["old_v"],
                                  r["target_v"], use_graph=self.use_graph)
         return self._finish_update(acc, nbatch)
