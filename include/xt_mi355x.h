@@ -80,6 +80,12 @@ typedef struct xt_tuning {
   int32_t finalize_ticket;    /* 1: last-block finalize of the norm instead of the clip factor inside Adam      */
   int32_t fwd_tiled_valid;    /* 1: un-padded fp32 layers with N <= 32 run the LDS-tiled bf16x6 forward instead
                                  of the register-direct fp32 one (ABI >= 7; PpoCnn conv2: -2 us per step)       */
+  int32_t wgrad_rows;         /* 0 (default): the LDS-tiled im2col weight gradient.  1: 4x4/2 32->32 conv weight
+                                 gradient from input ROWS staged in LDS (no im2col gather) next to an input gradient
+                                 with all four taps in flight; 2: the same without the deep input-gradient prefetch
+                                 (ABI >= 8; measured 7.54 vs 7.47 ms per update: kept for A/B)         */
+  int32_t fwd_prefetch_all;   /* 0 (default): two reduction steps in flight.  1: bf16x6 forwards with <= 8 steps
+                                 per wave group issue all operand loads up front (ABI >= 8; measured +0.1 ms)     */
 } xt_tuning;
 int xt_tuning_get(xt_tuning* out);
 int xt_tuning_set(const xt_tuning* in);

@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 PHASES = {
     10: ("fwd", ["decode+fetch0/1 issued", "first stash+barrier", "k loop", "epilogue issue", "store drain"]),
     20: ("wgrad", ["rowtab+fetch issued", "first stash+barrier", "m loop", "epilogue issue", "store drain"]),
+    21: ("wgrad (staged rows)", ["offset table + first fetch issued", "first stash+barrier", "sample loop (MFMA)", "slab store issue", "store drain"]),
     31: ("dgrad (all classes)", ["decode+fetch issued", "first stash+barrier", "k loop", "epilogue (x load + store issue)", "store drain"]),
     30: ("dgrad", ["decode+fetch issued", "first stash+barrier", "k loop", "epilogue (x load + store issue)", "store drain"]),
     40: ("conv1 fwd", ["loads issued", "split+LDS+barrier", "mfma loop", "transpose+store issue", "store drain"]),
@@ -85,6 +86,9 @@ def main():
     import torch
     from xingtian_amd import lib as L
     L.LIB_PATH = os.environ.get("XT_TL_LIB") or os.path.join(ROOT, "xingtian_amd", "libxt_mi355x_tl.so")
+    if os.environ.get("XT_TL_KNOBS"):          # e.g. XT_TL_KNOBS='{"wgrad_rows": 3}' (experiment builds)
+        import json
+        L.set_tuning(**json.loads(os.environ["XT_TL_KNOBS"]))
     from xingtian_amd.model import netspec
     from xingtian_amd.model.hip_net import HipActorCritic
 

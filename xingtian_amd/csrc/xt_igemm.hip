@@ -164,7 +164,12 @@ __device__ __forceinline__ bf16x8 lds_read_tr16x2(const uint8_t* p, int second_o
   return u.v;
 }
 
-template <int BI, int BJ, int WI, int WJ, bool U8, bool PADDED, int KG, bool X6 = false>
+// NST > 0 (round 3): the block's reduction has at most NST steps per wave group and ALL of their operand loads are
+// issued before the first one is consumed (NST register stages, straight-line code, exact s_waitcnt counts).  A step
+// of the bf16x6 form is ~0.25 us of LDS + MFMA work, a global round trip under load 2-3 us: with two steps in flight
+// the loop ran at the memory latency (timeline: 4.7 us for the 8 steps of PpoCnn's conv2, 14.8 us launch).  Steps
+// past a group's range load clamped addresses and contribute zeros.
+template <int BI, int BJ, int WI, int WJ, bool U8, bool PADDED, int KG, bool X6 = false, int NST = 0>
 __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
   constexpr int TI = BI / (32 * WI), TJ = BJ / (32 * WJ);
   constexpr int SA = BI + 1, SB = BJ;
@@ -293,6 +298,20 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
       mma_tile<TI, TJ, SA, SB>(stage, stage + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
     }
   };
+  if constexpr (NST > 0) {
+    Regs R[NST];
+#pragma unroll
+    for (int d = 0; d < NST; ++d) fetch(kbeg + 32 * d, R[d]);
+    XT_TL(1);
+#pragma unroll
+    for (int d = 0; d < NST; ++d) {
+      float* stage = smem + (d & 1) * BUF;
+      stash(R[d], stage, stage + 32 * SA);
+      __syncthreads();
+      if (d == 0) XT_TL(2);
+      mma(stage);
+    }
+  } else {
   Regs R0, R1;
   if (nsteps > 0) fetch(kbeg, R0);
   if (nsteps > 1) fetch(kbeg + 32, R1);
@@ -309,6 +328,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
       if (s + 3 < nsteps) fetch(kbeg + (s + 3) * 32, R1);
       if (s + 1 < nsteps) mma(smem + BUF);
     }
+  }
   }
   if constexpr (KG == 2) {
     // combine the two groups' accumulators AND transpose: both groups park their tiles in LDS (every stage buffer
@@ -403,6 +423,7 @@ struct WgradArgs {
   const float* dy;
   float* out;      // [msplit][(K+1)*N]
   int msplit, mchunk;
+  FastDiv d_rowq;  // wgrad_rows_body: divide by the float4 count of an input row
 };
 
 constexpr int kRowTab = 1024;                       // rows decoded at once into the LDS row table
@@ -830,7 +851,7 @@ constexpr int dgrad4_smem_floats() {
   return SPLIT ? (12 * kD4SlotA + kD4Classes * 12 * kD4SlotB) / 4 + 128 : 32 * 129 + kD4Classes * 32 * 33 + 128;
 }
 
-template <bool SPLIT>
+template <bool SPLIT, bool PF4 = false>
 __device__ __forceinline__ void igemm_dgrad4_body(const DgradArgs& p, const int bx, float* smem) {
   constexpr int BI = 128, SA = BI + 1, SB = 33, NA = 4;
   float* As = smem;
@@ -928,9 +949,13 @@ __device__ __forceinline__ void igemm_dgrad4_body(const DgradArgs& p, const int 
   for (int cls = 0; cls < kD4Classes; ++cls)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[cls][r] = 0.f;
-  // one register stage: a step carries 64 MFMAs per wave (4096 cycles), which covers the fetch of the next one
-  Regs R0;
+  // one register stage: a step carries 64 MFMAs per wave (4096 cycles), which covers the fetch of the next one --
+  // with fp32 MFMAs.  On the bf16 pipes (SPLIT) a step is 1536 cycles = 0.64 us, a fraction of a global round trip
+  // under load: the loop then runs at the memory latency (timeline: 3 us per step).  PF4 (nsteps == 4, two workgroups
+  // per CU = 256 VGPRs): the operands of ALL four taps are requested up front, the loop only splits, syncs and multiplies.
+  Regs R0, R1, R2, R3;
   fetch(0, R0);
+  if constexpr (PF4) { fetch(1, R1); fetch(2, R2); fetch(3, R3); }
   XT_TL(1);
   const int kl = lane >> 5, il = lane & 31;
   auto mma = [&]() {
@@ -960,13 +985,20 @@ __device__ __forceinline__ void igemm_dgrad4_body(const DgradArgs& p, const int 
         acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bs[cls * 32 * SB + (kk * 2 + kl) * SB + il], acc[cls], 0, 0, 0);
     }
   };
-  for (int s = 0; s < nsteps; ++s) {
-    stash(R0);
-    __syncthreads();
-    if (s == 0) XT_TL(2);
-    if (s + 1 < nsteps) fetch(s + 1, R0);
-    mma();
-    __syncthreads();
+  if constexpr (PF4) {
+    stash(R0); __syncthreads(); XT_TL(2); mma(); __syncthreads();
+    stash(R1); __syncthreads(); mma(); __syncthreads();
+    stash(R2); __syncthreads(); mma(); __syncthreads();
+    stash(R3); __syncthreads(); mma(); __syncthreads();
+  } else {
+    for (int s = 0; s < nsteps; ++s) {
+      stash(R0);
+      __syncthreads();
+      if (s == 0) XT_TL(2);
+      if (s + 1 < nsteps) fetch(s + 1, R0);
+      mma();
+      __syncthreads();
+    }
   }
   XT_TL(3);
   // epilogue: class (ry, rx) of position row i writes pixel rowOut[i] + (ry*W + rx)*C.  A pixel is one contiguous
@@ -1048,6 +1080,213 @@ __global__ __launch_bounds__(256) void igemm_dgrad_kernel(const DgradArgs p) {
   igemm_dgrad_body<BI, BJ, WI, WJ, X6>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
+// ------------------------------------------------------------------ weight gradient from staged input ROWS
+// (round 3) Weight gradient of a VALID stride-S conv with C = N = 32 and KW = 4 (PpoCnn conv2: 4x4/2, 20x20x32 ->
+// 9x9x32) WITHOUT the im2col gather: the LDS-tiled form above streams the KH*KW/S^2-times expanded im2col view of the
+// layer input through the L1 (53 MB for a 16.4 MB activation at B = 320, plus dY once per k tile) and that vector-memory
+// traffic -- not the matrix pipe -- paced the whole fused backward launch (in-kernel phase probe).
+//   workgroup = (sample group g, kernel row ky); wave = kernel column kx  -> one 32 (c) x 32 (n) accumulator tile
+//   per wave, kept in registers across the group's samples; reduction = the OH*OW output positions of a sample.
+// Per sample the OH input rows ky, ky+S, ... (each W*C contiguous floats: plain 16-byte row copies, no gather) and
+// the sample's dY [OH*OW, 32] are staged in LDS once; BOTH MFMA operands are then plain ds_read_b32 of the natural
+// layouts: A[c][m] = x[row oy][(S*ox + kx)*32 + c] (32 consecutive floats), B[m][n] = dY[m][n] -- the im2col view is
+// a per-lane address (a small per-position offset table in LDS), not data movement.  The two reduction slots of
+// v_mfma_f32_32x32x2_f32 take the even / odd positions; positions past the map multiply a zero dY row.
+// The next sample's rows are requested into registers before the current one is multiplied.
+// Input traffic: every input row is read by the KH/S kernel rows that use it (2x for 4x4/2) instead of KH*KW/S^2 (4x)
+// and dY KH times, all as full-line row copies.  Slab layout as igemm_wgrad_body: slab g, rows [ky*KW*32, +KW*32).
+constexpr int kWrC = 32, kWrN = 32, kWrKW = 4;
+__host__ __device__ constexpr int wrows_smem_floats(int OH, int OW, int W) {
+  return OH * (W * kWrC + 4) + 2 * (((OH * OW + 7) >> 3) << 2) * kWrN + 256 + 2 * (((OH * OW + 7) >> 3) << 2);
+}
+constexpr int kWrMaxSmemFloats = 12 * 1024;     // what the fused kernel instance reserves (>= wrows_smem_floats of the shape)
+
+#ifndef XT_WR_CHAINS
+#define XT_WR_CHAINS 4
+#endif
+constexpr int kWrChains = XT_WR_CHAINS;      // independent accumulator chains per wave (A/B: 1, 2, 4)
+constexpr int kWrXQ = 6, kWrDQ = 3;          // per-thread float4 slots of a sample's staging (<= 1536 / 768 float4)
+typedef float f4v __attribute__((ext_vector_type(4)));   // (HIP float4 members kept this struct in scratch memory)
+struct WrRegs { f4v x[kWrXQ]; f4v d[kWrDQ]; };
+
+__device__ __forceinline__ void wr_fetch(WrRegs& R, const float* __restrict__ xb, const float* __restrict__ db, int t,
+                                         int ky, int S, int WC, int rowq, FastDiv d_rowq, int nxq, int ndq) {
+#pragma unroll
+  for (int i = 0; i < kWrXQ; ++i) {
+    const int q = t + 256 * i;
+    const int oy = (int)fdiv((uint32_t)q, d_rowq), c4 = q - oy * rowq;
+    R.x[i] = *reinterpret_cast<const f4v*>(xb + (q < nxq ? (oy * S + ky) * WC + c4 * 4 : 0));
+  }
+#pragma unroll
+  for (int i = 0; i < kWrDQ; ++i) {
+    const int q = t + 256 * i;
+    R.d[i] = *reinterpret_cast<const f4v*>(db + (q < ndq ? q * 4 : 0));
+  }
+}
+__device__ __forceinline__ void wr_stash(const WrRegs& R, float* xs, float* ds, int t, int RS, int rowq, FastDiv d_rowq,
+                                         int nxq, int ndq) {
+#pragma unroll
+  for (int i = 0; i < kWrXQ; ++i) {
+    const int q = t + 256 * i;
+    const int oy = (int)fdiv((uint32_t)q, d_rowq), c4 = q - oy * rowq;
+    if (q < nxq) *reinterpret_cast<f4v*>(xs + oy * RS + c4 * 4) = R.x[i];
+  }
+#pragma unroll
+  for (int i = 0; i < kWrDQ; ++i) {
+    const int q = t + 256 * i;
+    if (q < ndq) *reinterpret_cast<f4v*>(ds + q * 4) = R.d[i];
+  }
+}
+
+__device__ __forceinline__ void wgrad_rows_body(const WgradArgs& p, const int group, const int ky, const int per_group,
+                                                float* smem) {
+  const Geom& g = p.g;
+  const int t = threadIdx.x, lane = t & 63, kx = t >> 6;
+  const int il = lane & 31, kl = lane >> 5;
+  const int WC = g.W * kWrC;
+  const int RS = WC + 4;                               // LDS row stride (floats), 16-byte aligned rows
+  const int half = ((g.OHOW + 7) >> 3) << 2;           // positions per reduction slot, a multiple of 4 (zero rows pad)
+  float* xs = smem;                                    // [OH][RS]
+  float* ds = smem + g.OH * RS;                        // [2*half][32]; rows >= OHOW are zero
+  float* red = ds + 2 * half * kWrN;                   // [8][32] bias partials
+  int* tab = reinterpret_cast<int*>(red + 256);        // [2][half] A-operand byte offsets per position
+  const float* x = static_cast<const float*>(p.in);
+  const int s_beg = group * per_group, s_end = min(g.B, s_beg + per_group);
+  XT_TL(0);
+  XT_TL_ROLE(21);
+  if (s_beg >= s_end) return;                          // (block-uniform)
+
+  const int rowq = WC / 4;                             // float4 per input row
+  const int nxq = g.OH * rowq, ndq = g.OHOW * (kWrN / 4);
+  const FastDiv d_rowq = p.d_rowq;
+  // zero rows of the dY tile (positions OHOW .. 2*half-1), written once
+  for (int e = t; e < (2 * half - g.OHOW) * kWrN; e += 256) ds[g.OHOW * kWrN + e] = 0.f;
+
+  // FOUR independent accumulator chains (position pair u of every step): a dependent v_mfma_f32_32x32x2_f32 issues
+  // only ~160 cycles after its predecessor from a lone wave (timeline: 164 cycles per MFMA with one chain, 64 is the
+  // pipe rate); summed in fixed order at the end
+  f32x16 acc4[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc4[u][r] = 0.f;
+  const bool do_bias = (ky == 0);
+  const int bn = t & 31, bg = t >> 5;
+  float bsum = 0.f;
+
+  // A-operand byte offset of every position (same for every sample): [slot kl][half] ints; the two reduction slots
+  // take the even / odd positions (lane groups {0-31} / {32-63} of a ds_read_b32 never conflict with each other);
+  // positions past the map read pixel 0 against a zero dY row
+  for (int e = t; e < 2 * half; e += 256) {
+    const int slot = e >= half ? 1 : 0, pos = 2 * (e - slot * half) + slot;
+    const int oy = (int)fdiv((uint32_t)pos, g.d_ow), ox = pos - oy * g.OW;
+    tab[e] = pos < g.OHOW ? (oy * RS + ox * g.S * kWrC) * 4 : 0;
+  }
+
+  // two register sets: sample s+2 is requested while sample s is multiplied (one sample's MFMAs, ~1.2 us, are
+  // shorter than a global round trip under load: with a single set the loop ran at the memory latency, 3 us per sample)
+  WrRegs RA, RB;
+  auto fetch_s = [&](WrRegs& R, int sidx) __attribute__((always_inline)) {
+    const int sn = sidx < s_end ? sidx : s_end - 1;          // (unconditional, clamped)
+    wr_fetch(R, x + (size_t)sn * g.HWC, p.dy + (size_t)sn * g.OHOW * kWrN, t, ky, g.S, WC, rowq, d_rowq, nxq, ndq);
+  };
+  fetch_s(RA, s_beg);
+  fetch_s(RB, s_beg + 1);
+  XT_TL(1);
+  const char* ap = reinterpret_cast<const char*>(xs + kx * kWrC + il);
+  const float* bp = ds + kl * kWrN + il;                 // position 2*j + kl -> row stride 2*32 floats per j
+  const int4* tp = reinterpret_cast<const int4*>(tab + kl * half);
+  const int nst = half >> 2;
+  for (int s = s_beg; s < s_end; ++s) {
+    const bool even = ((s - s_beg) & 1) == 0;            // block-uniform
+    __syncthreads();                       // everybody is done reading the previous sample's tiles
+    if (even) wr_stash(RA, xs, ds, t, RS, rowq, d_rowq, nxq, ndq); else wr_stash(RB, xs, ds, t, RS, rowq, d_rowq, nxq, ndq);
+    __syncthreads();
+    if (s == s_beg) XT_TL(2);
+    if (s + 2 < s_end) { if (even) fetch_s(RA, s + 2); else fetch_s(RB, s + 2); }
+#ifdef XT_TL_EXPERIMENT
+    if (s == s_beg) XT_TL(3);
+#endif
+    // four position pairs per step, two register sets (no copies): the eight operand reads of step i+1 are ISSUED
+    // before the four MFMAs of step i and the offset quad of step i+2 before that (clamped, unconditional).  The
+    // sched_barriers pin that order: left alone, the scheduler sinks every read next to its MFMA and the wave -- the
+    // only one this workgroup has on its SIMD -- exposes a full LDS round trip per MFMA (measured: 26.5 us launch).
+    auto load4 = [&](float (&av)[4], float (&bv)[4], const int4 o, int st) __attribute__((always_inline)) {
+      av[0] = *reinterpret_cast<const float*>(ap + o.x); av[1] = *reinterpret_cast<const float*>(ap + o.y);
+      av[2] = *reinterpret_cast<const float*>(ap + o.z); av[3] = *reinterpret_cast<const float*>(ap + o.w);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bv[u] = bp[(st * 4 + u) * 2 * kWrN];
+    };
+    auto mma4 = [&](const float (&av)[4], const float (&bv)[4]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        acc4[u % kWrChains] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc4[u % kWrChains], 0, 0, 0);
+    };
+    const int last = nst - 1;
+    float a0[4], b0[4], a1[4], b1[4];
+    int4 oa = tp[last < 1 ? last : 1], ob = tp[last < 2 ? last : 2];
+    load4(a0, b0, tp[0], 0);
+    // Issue order inside a half step (sched_group_barrier): MFMA, then two VALU (next A addresses) and two LDS reads,
+    // four times.  A lone wave issues in order and stalls at an MFMA until the pipe is free, so only what sits BETWEEN
+    // two MFMAs runs in the shadow of the first; with the 17 address / LDS instructions of a half step behind its four
+    // MFMAs the loop measured 115 cycles per MFMA (64 is the pipe rate).
+#define XT_WR_INTERLEAVE()                                  \
+  do {                                                      \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {      \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    \
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);    \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);    \
+    }                                                       \
+  } while (0)
+    for (int i = 0; i + 1 < nst; i += 2) {      // steps i (set 0) and i + 1 (set 1); an odd last step follows the loop
+      const int i2 = i + 2 < last ? i + 2 : last, i3 = i + 3 < last ? i + 3 : last, i4 = i + 4 < last ? i + 4 : last;
+      load4(a1, b1, oa, i + 1);
+      oa = tp[i3];
+      mma4(a0, b0);
+      XT_WR_INTERLEAVE();
+      __builtin_amdgcn_sched_barrier(0);
+      load4(a0, b0, ob, i2);
+      ob = tp[i4];
+      mma4(a1, b1);
+      XT_WR_INTERLEAVE();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (nst & 1) mma4(a0, b0);
+#undef XT_WR_INTERLEAVE
+#ifdef XT_TL_EXPERIMENT
+    if (s == s_beg) XT_TL(4);
+#endif
+    if (do_bias) {
+      for (int m = bg; m < g.OHOW; m += 8) bsum += ds[m * kWrN + bn];
+    }
+  }
+#ifndef XT_TL_EXPERIMENT
+  XT_TL(3);
+#endif
+  float* out = p.out + (size_t)group * ((size_t)(g.K + 1) * kWrN);
+  const int k0 = (ky * kWrKW + kx) * kWrC;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int c = (r & 3) + 8 * (r >> 2) + 4 * kl;
+    out[(size_t)(k0 + c) * kWrN + il] = (acc4[0][r] + acc4[1][r]) + (acc4[2][r] + acc4[3][r]);
+  }
+  if (do_bias) {
+    __syncthreads();
+    red[bg * kWrN + bn] = bsum;
+    __syncthreads();
+    if (t < kWrN) {
+      float sum = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sum += red[q * kWrN + t];
+      out[(size_t)g.K * kWrN + t] = sum;
+    }
+  }
+#ifndef XT_TL_EXPERIMENT
+  XT_TL(4);
+#endif
+  XT_TL_DRAIN(5);
+}
+
 // ------------------------------------------------------------------ fused backward of one layer
 // One launch = weight-gradient blocks + input-gradient blocks (+ the head weight-gradient blocks for the
 // last trunk layer).  All three only consume d(pre-activation) of this layer, so running them side by side
@@ -1067,16 +1306,20 @@ struct BwdLayerArgs {
 // a kernel is the maximum over all of its paths: the generic form needs 144 VGPR (LDS-tiled dgrad) + 32 AGPR
 // (register-direct dgrad) = two workgroups per CU, this one three.
 template <int WBI, int WBJ, int WWI, int WWJ, bool WPAD, int DBI, int DBJ, int DWI, int DWJ, int D4 = 0, int HALO = 0,
-          bool DX6 = false>
-__global__ __launch_bounds__(256, 3) void igemm_bwd_layer_kernel(const BwdLayerArgs p) {
+          bool DX6 = false, int WROWS = 0>
+__global__ __launch_bounds__(256, WROWS ? 2 : 3) void igemm_bwd_layer_kernel(const BwdLayerArgs p) {
   constexpr int SMD = HALO == 5 ? 18 * 1024 : HALO == 3 ? 8 * 1024 : HALO == 2 ? 11 * 1024 : HALO == 1 ? 9 * 1024 : dgrad_smem_floats<DBI, DBJ, DX6>();
-  constexpr int SM0 = wgrad_smem_floats<WBI, WBJ, WPAD>() > SMD ? wgrad_smem_floats<WBI, WBJ, WPAD>() : SMD;
+  constexpr int SMW = WROWS ? kWrMaxSmemFloats : wgrad_smem_floats<WBI, WBJ, WPAD>();
+  constexpr int SM0 = SMW > SMD ? SMW : SMD;
   constexpr int SM = (D4 && dgrad4_smem_floats<D4 == 2>() > SM0) ? dgrad4_smem_floats<D4 == 2>() : SM0;
   __shared__ __attribute__((aligned(16))) float smem[SM];
   int b = blockIdx.x;
+#ifdef XT_TL_EXPERIMENT
+  if (b < p.n_dg && p.dg_direct == 99) return;      // experiment: weight-gradient blocks alone
+#endif
   if (b < p.n_dg) {                       // dgrad first: it is on the critical path of the next layer
     if constexpr (D4 != 0) {              // stride-2 conv: the four parity classes of a position tile in one block
-      igemm_dgrad4_body<D4 == 2>(p.dg, b, smem);
+      igemm_dgrad4_body<D4 == 2, (WROWS == 2)>(p.dg, b, smem);
       return;
     }
     if constexpr (HALO == 5) {            // ... input AND weight gradient per sample (the launch has no weight-gradient blocks)
@@ -1113,6 +1356,10 @@ __global__ __launch_bounds__(256, 3) void igemm_bwd_layer_kernel(const BwdLayerA
     // rows; consecutive block ids land on different XCDs (round-robin dispatch, private L2s), which made every
     // XCD fetch the layer input once per k tile (PMC: FETCH 2x35 MB for a 16 MB input)
     b = (int)xcd_chunk((uint32_t)b, (uint32_t)p.n_wg);
+    if constexpr (WROWS != 0) {           // staged-rows weight gradient: (sample group, kernel row) per workgroup
+      wgrad_rows_body(p.wg, b / p.wg_gx, b % p.wg_gx, p.wg.mchunk, smem);
+      return;
+    }
     const int bx = b % p.wg_gx, r = b / p.wg_gx;
     igemm_wgrad_body<WBI, WBJ, WWI, WWJ, false, WPAD>(p.wg, bx, r % p.wg_gy, r / p.wg_gy, smem);
     return;
@@ -1225,6 +1472,19 @@ int launch_fwd(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const vo
   } while (0)
   const bool x6 = !u8 && tuning().bf16x6 != 0;
   last_arith() = x6 ? XT_ARITH_BF16X6 : XT_ARITH_FP32;
+  // steps per wave group of the two-group form: all of them in flight when there are at most 8 (fwd_prefetch_all)
+  const int nst2 = ((chunk + 31) / 32 + 1) / 2;
+#define XT_FWD6N(BI, BJ, WI, WJ, NSTV)                                                                      \
+  hipLaunchKernelGGL((igemm_fwd_kernel<BI, BJ, WI, WJ, false, false, 2, true, NSTV>),                       \
+                     dim3((M + BI - 1) / BI, (N + BJ - 1) / BJ, ksplit), dim3(512), 0, st, a)
+  const bool all = x6 && kg2 && !pad && tuning().fwd_prefetch_all != 0;
+  if (all && N > 32 && nst2 <= 4) XT_FWD6N(64, 64, 2, 2, 4);
+  else if (all && N > 32 && nst2 == 5) XT_FWD6N(64, 64, 2, 2, 5);
+  else if (all && N > 32 && nst2 <= 8) XT_FWD6N(64, 64, 2, 2, 8);
+  else if (all && N <= 32 && nst2 <= 4) XT_FWD6N(128, 32, 4, 1, 4);
+  else if (all && N <= 32 && nst2 <= 8) XT_FWD6N(128, 32, 4, 1, 8);
+  else
+#undef XT_FWD6N
   if (x6 && N > 32) { if (kg2) XT_FWD6(64, 64, 2, 2, 2); else XT_FWD6(64, 64, 2, 2, 1); }
   else if (x6) { if (kg2) XT_FWD6(128, 32, 4, 1, 2); else XT_FWD6(128, 32, 4, 1, 1); }
   else if (N <= 32) XT_FWD(128, 32, 4, 1); else XT_FWD(64, 64, 2, 2);
@@ -1419,8 +1679,29 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
     a.wg.msplit = a.n_dg;
     if (msplit_out) *msplit_out = a.n_dg;
   }
-  const int total = a.n_wg + a.n_dg + a.n_hw;
   const bool pad = is_padded(g);
+  // staged-rows weight gradient (wgrad_rows_body) next to the all-classes input gradient: workgroup = (sample group,
+  // kernel row), ceil(B / 64) samples per group so that KH * groups ~ one workgroup per CU, one slab per group
+  bool wrows = false;
+  if (tuning().wgrad_rows && tuning().bf16x6 && a.dg_direct == 2 && !pad && g.C == kWrC && g.N == kWrN && g.KW == kWrKW &&
+      slabs != nullptr && wrows_smem_floats(g.OH, g.OW, g.W) <= kWrMaxSmemFloats &&
+      g.OH * (g.W * kWrC / 4) <= kWrXQ * 256 && g.OHOW * (kWrN / 4) <= kWrDQ * 256) {
+    const int per = (B + 63) / 64, groups = (B + per - 1) / per;
+    if (groups <= slab_cap) {
+      wrows = true;
+      a.wg.mchunk = per;                  // samples per group
+      a.wg.d_rowq = make_fastdiv((uint32_t)(g.W * kWrC / 4));
+      a.wg.msplit = groups;
+      a.wg.out = slabs;
+      a.wg_gx = g.KH; a.wg_gy = 1; a.wg_gz = groups;
+      a.n_wg = g.KH * groups;
+      if (msplit_out) *msplit_out = groups;
+    }
+  }
+  const int total = a.n_wg + a.n_dg + a.n_hw;
+#ifdef XT_TL_EXPERIMENT
+  const bool exp_alone = wrows && tuning().wgrad_rows == 3;
+#endif
   const bool dx6 = tuning().bf16x6 != 0 && a.dg_direct == 0;     // LDS-tiled input gradient on the bf16 matrix cores
 #define XT_BWD2(WBI, WBJ, WWI, WWJ, DBI, DBJ, DWI, DWJ, X6V)                                                    \
   do {                                                                                                          \
@@ -1452,6 +1733,15 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
       hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1, 0, 2>), dim3(total), dim3(256), 0, st, a);
     else
       hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1, 0, 1>), dim3(total), dim3(256), 0, st, a);
+  } else if (a.dg_direct == 2 && wrows) {
+    // (KH/S) * (KW/S) * (N/32) == 4 reduction steps: the input-gradient blocks keep all four taps' operands in flight
+#ifdef XT_TL_EXPERIMENT
+    if (exp_alone) a.dg_direct = 99;
+#endif
+    if ((g.KH / g.S) * (g.KW / g.S) * (g.N >> 5) == 4 && tuning().wgrad_rows != 2)
+      hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, 2, 0, false, 2>), dim3(total), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, 2, 0, false, 1>), dim3(total), dim3(256), 0, st, a);
   } else if (a.dg_direct == 2) {
     XT_REQUIRE(wsmall && dsmall && !pad, "bwd_layer: the all-classes input gradient needs the small-tile configuration");
     const int x6 = tuning().bf16x6;      // 0: fp32 MFMA in the all-classes input gradient (A/B)
