@@ -86,6 +86,9 @@ typedef struct xt_tuning {
                                  (ABI >= 8; measured 7.54 vs 7.47 ms per update: kept for A/B)         */
   int32_t fwd_prefetch_all;   /* 0 (default): two reduction steps in flight.  1: bf16x6 forwards with <= 8 steps
                                  per wave group issue all operand loads up front (ABI >= 8; measured +0.1 ms)     */
+  int32_t fwd_xcd_chunk;      /* 1: LDS-tiled forwards with several N tiles / k splits give every XCD a contiguous
+                                 run of the (m tile, n tile, k slice) order: tiles that share operand slices share
+                                 an L2 (ABI >= 8)                                                                  */
 } xt_tuning;
 int xt_tuning_get(xt_tuning* out);
 int xt_tuning_set(const xt_tuning* in);

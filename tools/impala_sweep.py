@@ -44,6 +44,9 @@ def run(key, knobs):
 SWEEP = [{}, {"wgrad_split_target": 256}, {"wgrad_split_target": 1024}, {"wgrad_split_target": 2048},
          {"fwd_split_target": 128}, {"fwd_split_target": 512}, {"direct": 0}, {"direct_all": 1}, {"fwd_two_groups": 0},
          {"direct_waves": 768}, {"direct_waves": 3072}, {"reduce_z_lanes": 4}, {"reduce_z_lanes": 16}, {"defer_splitk": 0}]
+if len(sys.argv) > 1:          # python tools/impala_sweep.py '[{}, {"fwd_xcd_chunk": 0}]'
+    import json
+    SWEEP = json.loads(sys.argv[1])
 for key in ("breakout_impala", "pong_impala_speedup"):
     for knobs in SWEEP:
         print("%-22s %-32s %8.1f us/train" % (key, knobs, run(key, knobs)), flush=True)

@@ -682,8 +682,8 @@ int launch_impala_heads_fwd(const ImpalaHeadArgs& a, hipStream_t st) {
 // by the gradient w.r.t. the trunk features (the arithmetic of heads_dfeat_kernel).  Grid (trajectory, row block):
 // every workgroup of a trajectory repeats the (cheap, LDS-resident) v-trace of the whole trajectory and then
 // produces d(features) of its own kVtRows rows -- one workgroup per trajectory walking all T rows was a chain of
-// T/4 dependent global-load round trips (47 us at T = 128 for breakout_impala's single trajectory).  The reverse scan stays SERIAL in time (tf.scan, vtrace.py:94-106) but runs
-// from registers: thread 0 pulls delta / discount*c / V in chunks of 16 from LDS, then a pure FMA chain.
+// T/4 dependent global-load round trips (47 us at T = 128 for breakout_impala's single trajectory).  The reverse scan (tf.scan,
+// vtrace.py:94-106) is a wave-parallel suffix scan over affine maps (round 3, see below).
 constexpr int kVtRows = 8;
 template <int AM>
 __global__ __launch_bounds__(256) void impala_vtrace_bwd_kernel(const ImpalaLossArgs p) {
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256) void impala_vtrace_bwd_kernel(const ImpalaLoss
       xpre[u] = p.feat[(base + r) * F + f];
     }
   }
-  float rho = 0.f, disc = 0.f, rew = 0.f, val = 0.f, ce = 0.f, ent = 0.f, logz = 0.f, mx = 0.f, z = 1.f;
+  float rho = 0.f, disc = 0.f, rew = 0.f, val = 0.f, ce = 0.f, ent = 0.f, logz = 0.f, mx = 0.f, z = 1.f, p_nval = 0.f;
   int act = 0;
   // every global operand of this thread's time step is requested before the first use: as rolled loops over the A
   // actions (runtime trip count) the logits were fetched one per iteration, each followed by s_waitcnt vmcnt(0) -- three
@@ -755,9 +755,7 @@ __global__ __launch_bounds__(256) void impala_vtrace_bwd_kernel(const ImpalaLoss
     rho = expf(tlp - blp);
     disc = dn ? 0.f : p.gamma;
     rew = fminf(fmaxf(rraw, -1.f), 1.f);
-    const float crho = fminf(1.f, rho);
-    s_delta[t] = crho * (rew + disc * nval - val);
-    s_dc[t] = disc * fminf(1.f, rho);
+    p_nval = nval;
 #pragma unroll
     for (int a = 0; a < AM; ++a)
       if (a < A) {
@@ -765,27 +763,27 @@ __global__ __launch_bounds__(256) void impala_vtrace_bwd_kernel(const ImpalaLoss
         ent += (expf(rl) / z) * (logz - rl);
       }
   }
-  __syncthreads();
-  if (t == 0) {
-    float acc = 0.f;
-    for (int q0 = Tm; q0 > 0; q0 -= 16) {         // rows q0-1 .. q0-16, newest first
-      float d[16], c[16], v[16];
+  // The v-trace recurrence acc_t = delta_t + (discount_t c_t) acc_{t+1}, acc_Tm = 0 (tf.scan in reverse, vtrace.py:94-106)
+  // is a composition of affine maps x -> B + A x, which is associative: a suffix scan over the pairs (A, B) with
+  // (A1,B1) o (A2,B2) = (A1 A2, B1 + A1 B2) gives every acc_t in log2(64) shuffle steps inside a wave plus one
+  // combination of the (at most four) wave totals, instead of a one-lane chain of T dependent LDS reads and FMAs
+  // (round 2: 13.1 us for this kernel at T = 128).  Same real arithmetic, different rounding order than the serial
+  // loop: values agree to ~1e-7 relative (the parity bar for vs / pg_adv is 1e-5); masks and indices are untouched.
+  {
+    float sa = (t < Tm) ? disc * fminf(1.f, rho) : 1.f;     // identity (1, 0) beyond the last transition
+    float sb = (t < Tm) ? fminf(1.f, rho) * (rew + disc * p_nval - val) : 0.f;
+    const int lane = t & 63, wv = t >> 6;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int q = q0 - 1 - u;
-        const int qc = q >= 0 ? q : 0;
-        d[u] = s_delta[qc]; c[u] = s_dc[qc]; v[u] = s_val[qc];
-      }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int q = q0 - 1 - u;
-        if (q >= 0) {
-          acc = d[u] + c[u] * acc;
-          s_vs[q] = acc + v[u];
-        }
-      }
+    for (int d = 1; d < 64; d <<= 1) {
+      const float oa = __shfl_down(sa, d, 64), ob = __shfl_down(sb, d, 64);
+      if (lane + d < 64) { sb = fmaf(sa, ob, sb); sa *= oa; }
     }
-    s_vs[Tm] = s_val[Tm];
+    if (lane == 0) { s_delta[wv] = sa; s_dc[wv] = sb; }     // the wave's total map (s_delta / s_dc are scratch here)
+    __syncthreads();
+    float ta = sa, tb = sb;                                  // maps of the following waves, nearest first, applied to 0
+    for (int w2 = wv + 1; w2 < 4; ++w2) { tb = fmaf(ta, s_dc[w2], tb); ta *= s_delta[w2]; }
+    if (t < Tm) s_vs[t] = tb + val;
+    if (t == Tm) s_vs[Tm] = s_val[Tm];
   }
   __syncthreads();
   float lterm = 0.f;
@@ -815,13 +813,12 @@ __global__ __launch_bounds__(256) void impala_vtrace_bwd_kernel(const ImpalaLoss
     if (lead) p.dbaseline[base + t] = 0.f;
     s_dv[t] = 0.f;
   }
-  if (t < MAXT) s_red[t] = lterm;
-  __syncthreads();
-  if (t == 64 && blockIdx.y == 0) {               // lane 0 of the second wave: the others go on with d(features)
-    float s = 0.f;
-    for (int q = 0; q < T; ++q) s += s_red[q];
-    p.traj_loss[traj] = s;
+  {                                               // trajectory loss: wave sums, then the four of them in wave order
+    const float ws = wave_sum(lterm);
+    if ((t & 63) == 0) s_red[t >> 6] = ws;
   }
+  __syncthreads();
+  if (t == 0 && blockIdx.y == 0) p.traj_loss[traj] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
   // d(features)[r, f] = (sum_a dlogits[r,a] Wpi[f,a] + dbaseline[r] Wv[f]) * act'(feature)   (heads_dfeat_kernel)
   // for this block's kVtRows rows: every row's feature load is issued before the first use
   for (int f = t; f < F; f += 256) {

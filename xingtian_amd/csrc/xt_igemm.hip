@@ -133,6 +133,7 @@ struct FwdArgs {
   const float* bias;
   float* y;        // ksplit==1: final output; else partial [ksplit][M][N]
   int ksplit, kchunk;
+  int xcd_chunked; // block ids remapped so that every XCD owns a contiguous run of the (m tile, n tile, k slice) order
 };
 
 // PADDED: the receptive field can leave the image (TF SAME) -> per-element bounds checks; VALID convs and
@@ -185,8 +186,20 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
   const int grp = (KG == 1) ? 0 : (int)(threadIdx.x >> 8);
   float* smem = smem_all + grp * 2 * BUF;
   const int t = threadIdx.x & 255, lane = t & 63, wave = t >> 6;
-  const int i0 = blockIdx.x * BI, j0 = blockIdx.y * BJ;
-  const int kbeg0 = blockIdx.z * p.kchunk;
+  // Blocks are dispatched round robin over the 8 XCDs in linear order (x fastest).  With more than one N tile or k
+  // split, neighbours in that order share operand slices (the M tiles of one (n tile, k slice) stream the same weight
+  // columns, the N tiles of one (m tile, k slice) the same input rows) and land on DIFFERENT L2s: ImpalaCnnOpt's
+  // 11x11 layer at 128 frames fetched 21 MB for 6 MB of operands (round 2 PMC).  xcd_chunk gives every XCD a
+  // contiguous run of the linear order instead.
+  int bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
+  if (p.xcd_chunked) {
+    const uint32_t nb = gridDim.x * gridDim.y * gridDim.z;
+    uint32_t lin = xcd_chunk(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nb);
+    bxi = (int)(lin % gridDim.x); lin /= gridDim.x;
+    byi = (int)(lin % gridDim.y); bzi = (int)(lin / gridDim.y);
+  }
+  const int i0 = bxi * BI, j0 = byi * BJ;
+  const int kbeg0 = bzi * p.kchunk;
   const int kend0 = min(g.K, kbeg0 + p.kchunk);
   const int nsteps_all = ((kend0 - kbeg0 + 31) / 32 + KG - 1) / KG;     // block-uniform loop length
   const int kbeg = kbeg0 + grp * nsteps_all * 32;
@@ -351,7 +364,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
         }
     __syncthreads();
     const bool fin = (p.ksplit == 1);
-    float* outp = fin ? p.y : p.y + (size_t)blockIdx.z * (size_t)g.M * g.N;
+    float* outp = fin ? p.y : p.y + (size_t)bzi * (size_t)g.M * g.N;
     for (int e = (int)threadIdx.x; e < BI * BJ / 4; e += 256 * KG) {
       const int row = e / (BJ / 4), c4 = (e - row * (BJ / 4)) * 4;
       const float4 a = *reinterpret_cast<const float4*>(&red[row * RS + c4]);
@@ -377,7 +390,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
 
   XT_TL(3);
   const bool final_out = (p.ksplit == 1);
-  float* out = final_out ? p.y : p.y + (size_t)blockIdx.z * (size_t)g.M * g.N;
+  float* out = final_out ? p.y : p.y + (size_t)bzi * (size_t)g.M * g.N;
 #pragma unroll
   for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
@@ -1450,6 +1463,7 @@ int launch_fwd(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const vo
   a.ksplit = ksplit; a.kchunk = chunk;
   a.y = ksplit == 1 ? y : partial;
   const int M = a.g.M, N = a.g.N;
+  a.xcd_chunked = (tuning().fwd_xcd_chunk != 0 && (N > (N <= 32 ? 32 : 64) || ksplit > 1)) ? 1 : 0;
   const bool pad = is_padded(a.g);
   // two wave groups per block when the launch cannot fill the chip and the step chain is long
   const int nblk = (N <= 32 ? ((M + 127) / 128) * ((N + 31) / 32) : ((M + 63) / 64) * ((N + 63) / 64)) * ksplit;
