@@ -1309,6 +1309,7 @@ struct BwdLayerArgs {
   DgradArgs dg;
   DDgradArgs ddg;            // register-direct input gradient (xt_direct_dev.h), used when dg_direct != 0
   int dg_direct;
+  int dg_xcd;                // LDS-tiled input-gradient blocks in XCD-contiguous order
   HeadWgArgs hw;
   int wg_gx, wg_gy, wg_gz;   // wgrad grid
   int dg_gx, dg_gy, dg_gz;   // dgrad grid
@@ -1359,6 +1360,8 @@ __global__ __launch_bounds__(256, WROWS ? 2 : 3) void igemm_bwd_layer_kernel(con
       direct_dgrad_body<1, 1, 4>(p.ddg, (uint32_t)b, (uint32_t)p.n_dg, smem);
       return;
     }
+    // (the M tiles of one channel tile stream the same W^T slice: XCD-contiguous order, as the forward)
+    if (p.dg_xcd) b = (int)xcd_chunk((uint32_t)b, (uint32_t)p.n_dg);
     const int bx = b % p.dg_gx, r = b / p.dg_gx;
     igemm_dgrad_body<DBI, DBJ, DWI, DWJ, DX6>(p.dg, bx, r % p.dg_gy, r / p.dg_gy, smem);
     return;
@@ -1623,6 +1626,7 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
   a.dg_gz = g.S * g.S;
   a.n_dg = a.dg_gx * a.dg_gy * a.dg_gz;
   a.dg_direct = 0;
+  a.dg_xcd = tuning().fwd_xcd_chunk != 0 ? 1 : 0;
   {
     const int no_d4 = tuning().dgrad_all_classes ? 0 : 1;
     if (!no_d4 && g.S == 2 && g.KH % 2 == 0 && g.KW % 2 == 0 && g.H % 2 == 0 && g.W % 2 == 0 && g.PT == 0 &&
