@@ -363,6 +363,15 @@ int xt_net_ppo_train(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, int32_
  * the step-wise path.  fn == NULL removes the hook. */
 typedef int (*xt_grad_exchange_fn)(float* grads, int64_t count, void* user, void* stream);
 int xt_net_set_grad_exchange(xt_net* net, xt_grad_exchange_fn fn, void* user);
+/* The same with flags (ABI >= 8).  XT_XCHG_OVERLAP (shared-trunk networks): every SGD step of xt_net_ppo_train
+ * exchanges the gradient in TWO buckets -- [offset of the last trunk layer, n_params) = that layer + the heads (the
+ * first gradients the backward pass produces; 95 % of PpoCnn's parameters), reduced and handed to fn on a side stream
+ * of the library right after the first backward launch, so that its all-reduce runs under the conv backward; then
+ * [0, that offset) on the compute stream, which finally waits for the side stream before the norm + clip + Adam.
+ * fn is called twice per step, each time with its own sub-range and stream; the calls are issued in the same order on
+ * every rank (RCCL's ordering requirement for one communicator). */
+#define XT_XCHG_OVERLAP 1
+int xt_net_set_grad_exchange_ex(xt_net* net, xt_grad_exchange_fn fn, void* user, int32_t flags);
 
 /* One minibatch of Keras `model.fit` for the non-opt IMPALA models (ABI >= 5): forward, xt_keras_impala_loss,
  * backward; the flat gradient is left in the net's gradient buffer for xt_adam_keras.  obs rows are gathered with

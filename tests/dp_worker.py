@@ -63,6 +63,25 @@ def main():
                                        d(lab[2].reshape(-1)), d(lab[3].reshape(-1)), d(lab[4].reshape(-1)), rank, world,
                                        mode=mode)
         assert steps == 6
+    elif mode in ("hook", "hook_overlap"):
+        # weak-mode update through the library's gradient-exchange hook (one C call, eager enqueue): one bucket, or two
+        # with the first exchanged on the side stream right after the first backward launch
+        spec, cfg, n = ppo_case()
+        net = HipActorCritic(spec, max_batch=cfg["BATCH_SIZE"], seed=5)
+        parallel.broadcast_weights_(net.params)
+        obs, lab, _ = ppo_rollout(200 + rank, n)
+        _, _, perms = ppo_rollout(100, n)
+        ex = parallel.TorchDistExchange(net)
+        ex.attach(overlap=(mode == "hook_overlap"))
+        c = net.make_ppo_cfg(cfg, grad_scale=1.0 / world, global_batch=0)
+        net.ppo_train(c, net.to_device_obs(obs), d(perms), d(lab[0]), d(lab[1].reshape(-1)), d(lab[2].reshape(-1)),
+                      d(lab[3].reshape(-1)), d(lab[4].reshape(-1)), use_graph=False)
+        torch.cuda.synchronize()
+        ex.detach()
+        nflat = net.params.numel()
+        off_a = spec.layers[-1].param_off
+        want = [(0, nflat)] * 6 if mode == "hook" else [(off_a, nflat - off_a), (0, off_a)] * 6
+        assert ex.calls == want, (ex.calls[:4], want[:4])
     elif mode == "impala":
         spec, data, tlen, ntraj = impala_case()
         net = HipActorCritic(spec, max_batch=tlen * ntraj, seed=5)

@@ -138,3 +138,15 @@ def test_bench_self_spawns_two_ranks_and_reports_weak_strict_and_impala():
                          env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          timeout=120)
     assert bad.returncode != 0 and b"WORLD_SIZE=2" in bad.stderr
+
+
+def test_exchange_hook_with_two_ranks_matches_the_stepwise_path_bitwise(tmp_path):
+    """The library's gradient-exchange hook (``xt_net_ppo_train`` enqueues fwd/bwd -> hook -> norm/clip/Adam itself) met
+    by two real ranks, with one bucket and with XT_XCHG_OVERLAP's two buckets (last trunk layer + heads exchanged from
+    the side stream right after the first backward launch, the conv layers afterwards): both reproduce the step-wise
+    weak-mode update bit for bit -- a 2-rank sum is the same in any bucket split -- and the hook is called with exactly
+    the documented sub-ranges, in the same order on both ranks."""
+    ref = _run_two_ranks(tmp_path, "weak")
+    for mode in ("hook", "hook_overlap"):
+        got = _run_two_ranks(tmp_path, mode)
+        assert np.array_equal(got, ref), mode

@@ -108,6 +108,7 @@ def _mk(which, batch):
 
 
 @pytest.mark.parametrize("which,b", [("cnn84", 48), ("cnn84", 320), ("cnn84", 261), ("cnn84", 255), ("cnn84", 256),
+                                     ("cnn84", 40), ("cnn84", 80), ("cnn84", 160),
                                      ("cnn42_unshared", 33), ("cnn42_a18", 40), ("cnn30_inferred", 50), ("mlp", 200),
                                      ("cnn42_act_softplus", 33), ("cnn42_act_selu", 33), ("cnn42_act_leaky_relu", 33),
                                      ("mlp_act_elu", 200), ("mlp_act_sigmoid", 64), ("mlp_act_softsign", 64)])
@@ -117,7 +118,9 @@ def test_ppo_step_loss_and_grads_vs_oracle(which, b):
     gradients, halo-staged conv3 input gradient) against the oracle; b = 261 is the same set of kernels with ragged
     last tiles (position ranges, 64-row input-gradient tiles and 128-position class tiles that end mid-tile); b = 255 /
     256 sit on either side of the switch between the per-frame-stack and the flattened first-layer weight gradient
-    (200 position ranges of 512) and between 256- and 512-position forward ranges."""
+    (200 position ranges of 512) and between 256- and 512-position forward ranges; b = 40 / 80 / 160 are the per-rank
+    shards of the 320-row global minibatch at 8 / 4 / 2 GPUs (strict data parallelism): the kernel selection
+    of those launches (per-frame-stack first layer, fewer split slabs) is exercised here because no 8-GPU box is."""
     net, ospec, sd, u8 = _mk(which, b)
     params = oracle_params_for(net, ospec, seed=7)
     rng = np.random.default_rng(0)

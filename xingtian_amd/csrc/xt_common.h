@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 
 #include "xt_mi355x.h"
 
@@ -206,5 +207,21 @@ struct FinalizeArgs {
 };
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// One-time set-up PER DEVICE (function attributes such as the dynamic-LDS limit belong to the device's copy of the
+// code object): a process may drive several GPUs, one learner thread each (PBT-style multi-learner set-ups).  The body
+// must be idempotent: two threads on the same device may both run it.
+struct PerDeviceOnce {
+  std::atomic<uint64_t> done{0};
+  template <typename F>
+  void run(F body) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    body();
+    done.fetch_or(bit, std::memory_order_release);
+  }
+};
 
 }  // namespace xt

@@ -435,15 +435,14 @@ int launch_conv1_fwd_bf16x3(const xt_conv_geom* g, const xt_input_xform* xf, int
     if ((pb - 1) / (g->OH * g->OW) + 2 <= nimg) {          // a range of pb positions touches at most nimg frame stacks
       a.img_cap = 2 * c1_packed_cap(B, g->OH, g->OW, g->S, g->KH, g->W * 4, pb);
       const size_t fl = (size_t)a.img_cap + (size_t)2 * g->KH * 3 * 64 * 16;
-      static bool attr_done = false;
-      if (!attr_done) {
+      static PerDeviceOnce attr_once;
+      attr_once.run([] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4k8_fwd_flat_kernel<2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4k8_fwd_flat_kernel<1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
-        attr_done = true;
-      }
+      });
       if (fl <= 160 * 1024) {
         if (two) hipLaunchKernelGGL(conv_u8c4k8_fwd_flat_kernel<2>, dim3((total + pb - 1) / pb), dim3(512), fl, st, a);
         else hipLaunchKernelGGL(conv_u8c4k8_fwd_flat_kernel<1>, dim3((total + pb - 1) / pb), dim3(512), fl, st, a);
@@ -1212,15 +1211,14 @@ int launch_conv1_same_fwd(const xt_conv_geom* g, const xt_input_xform* xf, int B
   if (fl > 160 * 1024) return -1;
   const int maxpairs = a.img_cap / 8, u = two ? 14 : 8;
   if (maxpairs > 512 * u) return -1;                                          // staging: U pixel pairs per thread
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr_once;
+  attr_once.run([] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4_same_fwd_kernel<2, 8, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4_same_fwd_kernel<1, 8, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4_same_fwd_kernel<2, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4_same_fwd_kernel<1, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
-    attr_done = true;
-  }
+  });
   const dim3 grid((total + pb - 1) / pb), blk(512);
   if (g->KW == 8) {
     if (two) hipLaunchKernelGGL((conv_u8c4_same_fwd_kernel<2, 8, 16>), grid, blk, fl, st, a);
@@ -1252,15 +1250,14 @@ int launch_conv1_same_wgrad(const xt_conv_geom* g, const xt_input_xform* xf, int
   if (fl > 160 * 1024) return -1;
   const int maxpairs = a.img_cap / 8, u = two ? 14 : 8;
   if (maxpairs > 512 * u) return -1;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr_once;
+  attr_once.run([] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4_same_wgrad_kernel<512, 8, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4_same_wgrad_kernel<256, 8, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4_same_wgrad_kernel<512, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4_same_wgrad_kernel<256, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
-    attr_done = true;
-  }
+  });
   const dim3 grid(nblk), blk(512);
   if (g->KW == 8) {
     if (two) hipLaunchKernelGGL((conv_u8c4_same_wgrad_kernel<512, 8, 16>), grid, blk, fl, st, a);
@@ -1304,13 +1301,12 @@ int launch_conv1_wgrad_bf16x3(const xt_conv_geom* g, const xt_input_xform* xf, i
     if (fl < (size_t)2 * 256 * 36 * 4) fl = (size_t)2 * 256 * 36 * 4;            // the combine buffer aliases everything
     if (flat && c1_waves() == 8 && nblk >= 200 && nblk <= max_slabs && 511 / (g->OH * g->OW) + 2 <= 3 &&
         fl <= 160 * 1024 && B > 1 && (g->W * 4) % 8 == 0 && (g->S * 4) % 16 == 0) {
-      static bool attr_done = false;
-      if (!attr_done) {
+      static PerDeviceOnce attr_once;
+      attr_once.run([] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4k8_wgrad_flat_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
-        attr_done = true;
-      }
+      });
       hipLaunchKernelGGL(conv_u8c4k8_wgrad_flat_kernel, dim3(nblk), dim3(512), fl, st, a);
       XT_LAUNCH_CHECK();
       if (msplit_out) *msplit_out = nblk;

@@ -2,6 +2,7 @@
 // minibatches of xt/model/ppo/ppo.py:111-132, or one ImpalaCnnOpt.train chunk) on a HIP
 // stream, optionally captured once into a hipGraph and replayed (a B=320 step is ~20
 // short kernels; the reference pays a feed_dict H2D + session dispatch per minibatch).
+#include <mutex>
 #include <vector>
 #include <string>
 #include <string.h>
@@ -20,7 +21,7 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-int& last_arith() { static int a = 0; return a; }
+int& last_arith() { static thread_local int a = 0; return a; }      // per calling thread (one learner thread per GPU)
 xt_tuning& tuning() {
   static xt_tuning t = {/*bf16x6*/ 1, /*dgrad_all_classes*/ 1, /*dgrad_tile64*/ 1, /*dgrad_halo*/ 1, /*bwd_own_instance*/ 1,
                         /*bwd_fit_slots*/ 768, /*conv1_bf16x3*/ 1, /*conv1_flat*/ 1, /*conv1_waves*/ 8,
@@ -102,6 +103,9 @@ struct xt_net {
   // graph cache for ppo_train
   xt_grad_exchange_fn xchg = nullptr;  // xt_net_set_grad_exchange
   void* xchg_user = nullptr;
+  int xchg_flags = 0;                  // XT_XCHG_OVERLAP: two buckets, the first exchanged under the rest of the backward
+  hipStream_t xchg_stream = nullptr;   // side stream of the first bucket's exchange
+  hipEvent_t xchg_fork = nullptr, xchg_join = nullptr;
   // hipGraph cache of the whole-update entry points: a few slots, because the streaming ingest alternates between
   // two rollout buffer sets (two pointer sets -> two graphs), least recently used replaced
   struct GraphSlot { std::string key; hipGraphExec_t exec = nullptr; unsigned long long used = 0; };
@@ -185,8 +189,12 @@ static int heads_wgrad(xt_net* n, int B, hipStream_t st) {
 // (input gradient + weight gradient [+ the head weight gradients with the very first one]), then the first layer's
 // weight gradient.  (Forking the weight-gradient kernels onto side streams inside the hipGraph measured SLOWER
 // than this chain -- 14.7 vs 13.9 ms per update -- and was removed.)
-static int trunk_backward(xt_net* n, const void* obs, const int32_t* idx, int B, hipStream_t st) {
+struct AfterFirstBwd { int (*fn)(void*); void* arg; };      // called once, right after the first backward launch
+
+static int trunk_backward(xt_net* n, const void* obs, const int32_t* idx, int B, hipStream_t st,
+                          const AfterFirstBwd* after_first = nullptr) {
   bool heads_done = false;
+  bool first_done = false;
   for (int tr = 0; tr < n->n_trunks; ++tr)
     for (int l = n->t_end[tr] - 1; l >= n->t_begin[tr]; --l) {
       const bool first = (l == n->t_begin[tr]);
@@ -217,17 +225,23 @@ static int trunk_backward(xt_net* n, const void* obs, const int32_t* idx, int B,
                                     Lprev.mask_valid ? reinterpret_cast<const uint32_t*>(n->ws + Lprev.mask_off) : nullptr,
                                     L.slab_cap))
         return rc;
+      if (!first_done && after_first) { if (int rc = after_first->fn(after_first->arg)) return rc; }
+      first_done = true;
     }
   return 0;
 }
 
 // ONE kernel: every slab reduction (trunk layers + heads) + the squared-norm partials
-static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t st) {
+// part 0: everything; part 1: the last trunk layer + the heads (the first gradients the backward produces, 95 % of
+// PpoCnn's parameters); part 2: the remaining layers.  Parts 1 / 2 serve the overlapped data-parallel exchange.
+static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t st, int part = 0) {
   const int F = n->feat, A = n->A;
   GradTable tab;
   tab.n = 0;
   XT_REQUIRE(n->layers.size() + 3 <= 12, "xt_net: too many layers for the gradient table");
+  const size_t l_last = n->layers.size() - 1;
   for (size_t li = 0; li < n->layers.size(); ++li) {
+    if ((part == 1 && li != l_last) || (part == 2 && li == l_last)) continue;
     Layer& L = n->layers[li];
     GradEntry& E = tab.e[tab.n++];
     E.count = (L.K + 1) * L.g.N;
@@ -236,17 +250,17 @@ static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t s
     E.src = (L.last_msplit > 1) ? n->ws + L.slab_off : E.dst;
     E.stride = E.count;
   }
-  {
+  if (part != 2) {
     GradEntry& E = tab.e[tab.n++];
     E.count = F * A + A; E.dst = n->grads + n->pi_off; E.src = n->ws + n->off_hslab_pi;
     E.nslab = n->head_chunks; E.stride = n->hstride_pi;
   }
-  {
+  if (part != 2) {
     GradEntry& E = tab.e[tab.n++];
     E.count = F + 1; E.dst = n->grads + n->v_off; E.src = n->ws + n->off_hslab_v;
     E.nslab = n->head_chunks; E.stride = n->hstride_v;
   }
-  if (n->action_type == XT_ACTION_DIAG_GAUSSIAN) {   // pi_logstd: the per-sample rows are the partial slabs
+  if (part != 2 && n->action_type == XT_ACTION_DIAG_GAUSSIAN) {   // pi_logstd: the per-sample rows are the partial slabs
     GradEntry& E = tab.e[tab.n++];
     E.count = A; E.dst = n->grads + n->logstd_off; E.src = n->ws + n->off_dls;
     E.nslab = n->dls_rows; E.stride = align4(A);
@@ -334,11 +348,31 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
                                     n->ws + Lp.dact_off, n->ws + Lv.dact_off, st))
       return rc;
   }
-  if (int rc = trunk_backward(n, obs, idx, B, st)) return rc;
+  // data-parallel overlap (apply == 2): reduce + exchange the last trunk layer's and the heads' gradient right after
+  // the first backward launch, on the side stream, while the conv backward runs
+  struct Ovl { xt_net* n; int B; hipStream_t st; } ovl{n, B, st};
+  AfterFirstBwd af{[](void* arg) -> int {
+                     Ovl* o = static_cast<Ovl*>(arg);
+                     xt_net* n = o->n;
+                     if (int rc = grads_finish(n, o->B, nullptr, o->st, 1)) return rc;
+                     const int64_t off = n->layers.back().poff;
+                     XT_CHECK_HIP(hipEventRecord(n->xchg_fork, o->st));
+                     XT_CHECK_HIP(hipStreamWaitEvent(n->xchg_stream, n->xchg_fork, 0));
+                     XT_REQUIRE(n->xchg(n->grads + off, n->P - off, n->xchg_user, n->xchg_stream) == 0,
+                                "xt_net: gradient exchange hook failed (first bucket)");
+                     XT_CHECK_HIP(hipEventRecord(n->xchg_join, n->xchg_stream));
+                     return 0;
+                   },
+                   &ovl};
+  if (int rc = trunk_backward(n, obs, idx, B, st, apply == 2 ? &af : nullptr)) return rc;
+  if (apply == 2) {
+    if (int rc = grads_finish(n, B, nullptr, st, 2)) return rc;
+    return xt_ppo_loss_reduce(n->ws + n->off_terms, B, c->ent_coef, c->critic_coef, inv_b, lo, loss_acc, st);
+  }
   LossArgs la{};
   la.terms = n->ws + n->off_terms; la.B = B; la.ent_coef = c->ent_coef; la.critic_coef = c->critic_coef;
   la.inv_b = inv_b; la.out = lo; la.acc = loss_acc;
-  if (apply) {
+  if (apply == 1) {
     const int tail_mode = tuning().finalize_ticket ? 1 : 2;     // 1: the old "last block finalises" form (A/B)
     FinalizeArgs fin{};
     fin.enable = tail_mode; fin.counter = reinterpret_cast<unsigned int*>(n->ws + n->off_counter);
@@ -469,6 +503,10 @@ int xt_tuning_get(xt_tuning* out) {
   *out = xt::tuning();
   return 0;
 }
+// The knobs are independent 32-bit words: a launch running on another thread while they are changed sees, per knob, the
+// old or the new value (aligned word stores), never a torn one; writers are serialised.  They are meant to be set once,
+// before networks are created (split counts and captured hipGraphs are not revisited).
+static std::mutex g_tuning_mu;
 int xt_tuning_set(const xt_tuning* in) {
   XT_REQUIRE(in, "xt_tuning_set: null argument");
   XT_REQUIRE(in->conv1_waves == 4 || in->conv1_waves == 8, "xt_tuning_set: conv1_waves must be 4 or 8");
@@ -477,6 +515,7 @@ int xt_tuning_set(const xt_tuning* in) {
              "xt_tuning_set: reduce_z_lanes must be a power of two <= 32");
   XT_REQUIRE(in->fwd_split_target >= 1 && in->wgrad_split_target >= 1 && in->direct_waves >= 1 && in->bwd_fit_slots >= 0,
              "xt_tuning_set: block-count targets must be positive");
+  std::lock_guard<std::mutex> lk(g_tuning_mu);
   xt::tuning() = *in;
   return 0;
 }
@@ -574,6 +613,7 @@ void xt_net_destroy(xt_net* net) {
   if (!net) return;
   for (auto& g : net->gslots) if (g.exec) hipGraphExecDestroy(g.exec);
   if (net->cap_stream) hipStreamDestroy(net->cap_stream);
+  if (net->xchg_stream) { hipStreamDestroy(net->xchg_stream); hipEventDestroy(net->xchg_fork); hipEventDestroy(net->xchg_join); }
   delete net;
 }
 
@@ -630,10 +670,18 @@ static int ppo_train_enqueue(xt_net* net, const xt_ppo_cfg* c, const void* obs, 
       }
       // data parallel: local gradient -> exchange (SUM over the replicas, on this stream) -> norm of the exchanged
       // gradient, clip, Adam
+      const int64_t off_a = net->layers.back().poff;      // first bucket = [off_a, P): last trunk layer + heads
+      const bool overlap = (net->xchg_flags & XT_XCHG_OVERLAP) && net->n_trunks == 1 && net->layers.size() > 1 &&
+                           off_a > 0 && net->pi_off > off_a && net->v_off > off_a && net->xchg_stream != nullptr;
       if (int rc = xt::ppo_step(net, &cc, obs, perm + (size_t)ep * n + start, B, action, old_logp, adv, old_v,
-                                target_v, 0, nullptr, loss_acc, st))
+                                target_v, overlap ? 2 : 0, nullptr, loss_acc, st))
         return rc;
-      XT_REQUIRE(net->xchg(net->grads, net->P, net->xchg_user, st) == 0, "xt_net_ppo_train: gradient exchange hook failed");
+      if (overlap) {
+        XT_REQUIRE(net->xchg(net->grads, off_a, net->xchg_user, st) == 0, "xt_net_ppo_train: gradient exchange hook failed");
+        XT_CHECK_HIP(hipStreamWaitEvent(st, net->xchg_join, 0));      // first bucket's exchange has finished
+      } else {
+        XT_REQUIRE(net->xchg(net->grads, net->P, net->xchg_user, st) == 0, "xt_net_ppo_train: gradient exchange hook failed");
+      }
       if (int rc = xt::net_apply(net, cc.lr, cc.beta1, cc.beta2, cc.eps, cc.max_grad_norm, cc.grad_scale, 0, nullptr, st))
         return rc;
     }
@@ -651,8 +699,8 @@ int xt_net_ppo_train(xt_net* net, const xt_ppo_cfg* c, const void* obs, int32_t 
   if (!use_graph)
     return ppo_train_enqueue(net, c, obs, n, perm, action, old_logp, adv, old_v, target_v, loss_acc, st);
   char key[512];
-  snprintf(key, sizeof(key), "P|%p|%p|%p|%d|%p|%p|%p|%p|%p|%p|%p|%g|%g|%g|%g|%g|%g|%g|%g|%g|%d|%d|%g|%d",
-           (void*)net->xchg, net->xchg_user, obs, n,
+  snprintf(key, sizeof(key), "P%d|%p|%p|%p|%d|%p|%p|%p|%p|%p|%p|%p|%g|%g|%g|%g|%g|%g|%g|%g|%g|%d|%d|%g|%d",
+           net->xchg_flags, (void*)net->xchg, net->xchg_user, obs, n,
            (const void*)perm, (const void*)action, (const void*)old_logp, (const void*)adv, (const void*)old_v,
            (const void*)target_v, (void*)loss_acc, c->lr, c->beta1, c->beta2, c->eps, c->clip_ratio, c->ent_coef,
            c->vf_clip, c->critic_coef, c->max_grad_norm, c->batch_size, c->num_sgd_iter, c->grad_scale,
@@ -749,11 +797,22 @@ int xt_net_keras_impala_step(xt_net* n, const void* obs, const int32_t* idx, int
   return xt::grads_finish(n, B, nullptr, st);
 }
 
-int xt_net_set_grad_exchange(xt_net* net, xt_grad_exchange_fn fn, void* user) {
+int xt_net_set_grad_exchange_ex(xt_net* net, xt_grad_exchange_fn fn, void* user, int32_t flags) {
   XT_REQUIRE(net, "xt_net_set_grad_exchange: null net");
+  XT_REQUIRE((flags & ~XT_XCHG_OVERLAP) == 0, "xt_net_set_grad_exchange_ex: unknown flags 0x%x", flags);
   net->xchg = fn;
   net->xchg_user = fn ? user : nullptr;
+  net->xchg_flags = fn ? flags : 0;
+  if (fn && (flags & XT_XCHG_OVERLAP) && !net->xchg_stream) {
+    XT_CHECK_HIP(hipStreamCreateWithFlags(&net->xchg_stream, hipStreamNonBlocking));
+    XT_CHECK_HIP(hipEventCreateWithFlags(&net->xchg_fork, hipEventDisableTiming));
+    XT_CHECK_HIP(hipEventCreateWithFlags(&net->xchg_join, hipEventDisableTiming));
+  }
   return 0;
+}
+
+int xt_net_set_grad_exchange(xt_net* net, xt_grad_exchange_fn fn, void* user) {
+  return xt_net_set_grad_exchange_ex(net, fn, user, 0);
 }
 
 int xt_net_apply(xt_net* n, float lr, float beta1, float beta2, float eps, float clip_norm, float grad_scale,

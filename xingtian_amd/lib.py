@@ -64,6 +64,7 @@ class Tuning(Structure):
 
 
 OPT_TYPE = {"adam": 0, "rmsprop": 1}
+XCHG_OVERLAP = 1         # XT_XCHG_OVERLAP
 _P = c_void_p
 # name -> (restype, argtypes); every symbol include/xt_mi355x.h declares
 SIGNATURES = {
@@ -101,6 +102,7 @@ SIGNATURES = {
     "xt_net_ppo_step": (c_int32, [_P, POINTER(PpoCfg), _P, _P, c_int32, _P, _P, _P, _P, _P, c_int32, _P, _P, _P]),
     "xt_net_ppo_train": (c_int32, [_P, POINTER(PpoCfg), _P, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, _P]),
     "xt_net_set_grad_exchange": (c_int32, [_P, _P, _P]),
+    "xt_net_set_grad_exchange_ex": (c_int32, [_P, _P, _P, c_int32]),
     "xt_keras_impala_loss": (c_int32, [_P, _P, c_int32, c_int32, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P]),
     "xt_adam_keras": (c_int32, [_P, _P, _P, _P, c_int32, _P, _P, c_float, c_float, c_float, c_float, c_float, _P, _P]),
     "xt_net_keras_impala_step": (c_int32, [_P, _P, _P, c_int32, _P, _P, _P, c_float, _P, _P, _P]),

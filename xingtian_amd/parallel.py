@@ -201,10 +201,19 @@ class RcclComm(object):
         self._check(self.lib.ncclAllReduce(flat.data_ptr(), flat.data_ptr(), flat.numel(), self.NCCL_FLOAT32,
                                            self.NCCL_SUM, self.comm, stream_ptr), "ncclAllReduce")
 
-    def attach(self, net):
+    def attach(self, net, overlap=False):
+        """``overlap``: two buckets per step, the last trunk layer + heads exchanged on the library's side stream while
+        the conv backward runs (C ABI ``xt_net_set_grad_exchange_ex`` with ``XT_XCHG_OVERLAP``)."""
         from xingtian_amd import lib as L
-        L.check(net.lib.xt_net_set_grad_exchange(net.handle, self._ct.cast(self._cb, self._ct.c_void_p), None),
-                "xt_net_set_grad_exchange")
+        L.check(net.lib.xt_net_set_grad_exchange_ex(net.handle, self._ct.cast(self._cb, self._ct.c_void_p), None,
+                                                    L.XCHG_OVERLAP if overlap else 0), "xt_net_set_grad_exchange_ex")
+
+    def count(self):
+        """ranks RCCL itself reports for this communicator (ncclCommCount)"""
+        n = self._ct.c_int(0)
+        self.lib.ncclCommCount.argtypes = [self._ct.c_void_p, self._ct.POINTER(self._ct.c_int)]
+        self._check(self.lib.ncclCommCount(self.comm, self._ct.byref(n)), "ncclCommCount")
+        return int(n.value)
 
     def detach(self, net):
         from xingtian_amd import lib as L
@@ -215,3 +224,42 @@ class RcclComm(object):
             self.lib.ncclCommDestroy.argtypes = [self._ct.c_void_p]
             self.lib.ncclCommDestroy(self.comm)
             self.comm = self._ct.c_void_p()
+
+
+class TorchDistExchange(object):
+    """The gradient-exchange hook served by ``torch.distributed`` from a host callback: the hook synchronises the
+    stream it is given, all-reduces the sub-range of ``net.grads`` it was called for, and returns -- host-synchronous,
+    so it cannot be captured into a hipGraph.  This is the TEST vehicle of the hook plumbing (bucket boundaries, the
+    side-stream fork / join of ``XT_XCHG_OVERLAP``) on boxes where RCCL cannot form a group (two ranks on one GPU go
+    through gloo); measurements use ``RcclComm``."""
+
+    def __init__(self, net):
+        import ctypes
+        self._ct = ctypes
+        self.net = net
+        self.calls = []                      # (offset, count) of every call, for the tests
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+
+        def _exchange(grads, count, user, stream):
+            try:
+                hip.hipStreamSynchronize(stream)
+                off = (int(grads) - net.grads.data_ptr()) // 4
+                self.calls.append((off, int(count)))
+                view = net.grads[off:off + int(count)]
+                allreduce_sum_(view)
+                torch.cuda.synchronize()
+                return 0
+            except Exception:        # noqa: BLE001 -- an exception must not unwind through the C frame
+                return 1
+
+        self._cb = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p)(_exchange)
+
+    def attach(self, overlap=False):
+        from xingtian_amd import lib as L
+        L.check(self.net.lib.xt_net_set_grad_exchange_ex(self.net.handle, self._ct.cast(self._cb, self._ct.c_void_p), None,
+                                                         L.XCHG_OVERLAP if overlap else 0), "xt_net_set_grad_exchange_ex")
+
+    def detach(self):
+        from xingtian_amd import lib as L
+        L.check(self.net.lib.xt_net_set_grad_exchange(self.net.handle, None, None), "xt_net_set_grad_exchange")
