@@ -12,13 +12,13 @@ import json
 try:
     d = json.loads(open("gpurun_out/${TAG}_bench.json").read().strip().splitlines()[-1])
     print("PPO value", d["value"], "ms", d["ms_per_step"], "frac", d["roofline"]["frac"], d["roofline"]["kernel"])
-    print("kernels", d["roofline"]["kernels_us"])
+    print("kernels", d["roofline"]["kernels_us_isolated"])
     print("sustained", d.get("sustained"))
     for k, v in d.get("e2e", {}).items():
         if isinstance(v, dict): print("e2e", k, {q: (round(x, 3) if isinstance(x, float) else x) for q, x in v.items() if q not in ("path", "note")})
     for s in d.get("secondary", []):
         print("SEC", s["workload"][:40], "value", round(s["value"]), "us/train", round(s["us_per_train"], 1), "frac", round(s["update_frac_of_fp32_mfma_peak"], 3), "e2e", {q: (round(x, 3) if isinstance(x, float) else x) for q, x in s["e2e"].items() if q != "path"})
-        print("   kernels", s["roofline"]["kernels_us"], "cpu", s.get("cpu_baseline", {}).get("value"))
+        print("   kernels", s["roofline"]["kernels_us_isolated"], "cpu", s.get("cpu_baseline", {}).get("value"))
     print("cpu", d.get("cpu_baseline"))
 except Exception as e:
     print("bench parse failed", e)

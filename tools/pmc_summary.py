@@ -69,7 +69,10 @@ def main():
             r["wait_inst_frac"] = s.get("SQ_WAIT_INST_ANY", 0.0) / s["SQ_WAVE_CYCLES"]
             r["active_frac"] = s.get("SQ_ACTIVE_INST_ANY", 0.0) / s["SQ_WAVE_CYCLES"]
         rows.append(r)
-    doc = {"note": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_* in separate runs) over tools/step_probe.py (eager updates of the three workloads); "
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from xingtian_amd.lib import kernel_sources_sha
+    doc = {"kernel_sources_sha": kernel_sources_sha(),
+           "note": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_* in separate runs) over tools/step_probe.py (eager updates of the three workloads); "
                    "mean per launch; hbm_side_MB = (2 x FETCH_SIZE_KB + WRITE_SIZE_KB) / 1024 (gfx950 correction for 16-byte "
                    "coalesced reads; L2 memory-side requests incl. Infinity-Cache hits).  SQ_VALU_MFMA_BUSY_CYCLES counts "
                    "cycles, SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md constants "

@@ -177,6 +177,19 @@ def stream_ptr():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def kernel_sources_sha():
+    """sha256 (16 hex digits) over the kernel sources the library is built from: profile artefacts carry it so that
+    counters measured on an older build of the kernels are recognised as stale (bench.py, tools/pmc_summary.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(_HERE, "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(src, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def require_gpu():
     if not torch.cuda.is_available():
         raise RuntimeError("xingtian_amd: no HIP device visible -- the learner update path runs only on the GPU "
