@@ -80,10 +80,13 @@ typedef struct xt_tuning {
   int32_t finalize_ticket;    /* 1: last-block finalize of the norm instead of the clip factor inside Adam      */
   int32_t fwd_tiled_valid;    /* 1: un-padded fp32 layers with N <= 32 run the LDS-tiled bf16x6 forward instead
                                  of the register-direct fp32 one (ABI >= 7; PpoCnn conv2: -2 us per step)       */
-  int32_t wgrad_rows;         /* 0 (default): the LDS-tiled im2col weight gradient.  1: 4x4/2 32->32 conv weight
-                                 gradient from input ROWS staged in LDS (no im2col gather) next to an input gradient
-                                 with all four taps in flight; 2: the same without the deep input-gradient prefetch
-                                 (ABI >= 8; measured 7.54 vs 7.47 ms per update: kept for A/B)         */
+  int32_t wgrad_rows;         /* fused backward of a 4x4/2 32->32 VALID conv (PpoCnn conv2), ABI >= 8:
+                                 4 (default): two workgroups per CU (250 VGPRs) -- input gradient with all four taps'
+                                   operands in flight, LDS-tiled im2col weight gradient with four register stages,
+                                   the launch cut to 512 co-resident workgroups (20.5 vs 22.4 us per launch);
+                                 0: the round-2 form (three workgroups per CU, one / two stages in flight);
+                                 1 / 2: weight gradient from input ROWS staged in LDS (no im2col gather) with / without
+                                   the deep input-gradient prefetch (measured slower: 24 us; kept for A/B)        */
   int32_t fwd_prefetch_all;   /* 0 (default): two reduction steps in flight.  1: bf16x6 forwards with <= 8 steps
                                  per wave group issue all operand loads up front (ABI >= 8; measured +0.1 ms)     */
   int32_t fwd_xcd_chunk;      /* 1: LDS-tiled forwards with several N tiles / k splits give every XCD a contiguous

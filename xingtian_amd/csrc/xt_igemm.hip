@@ -448,7 +448,10 @@ constexpr long long kRowInvalid = -(1ll << 62);
 template <int BI, int BJ, bool PADDED>
 constexpr int wgrad_smem_floats() { return 2 * (32 * BI + 32 * BJ) + 2 * kRowTab + (PADDED ? kRowTab : 0); }
 
-template <int BI, int BJ, int WI, int WJ, bool U8, bool PADDED>
+// PF4 (round 3): four register stages instead of two -- a step is 16 MFMAs (0.43 us), a global round trip under load
+// 2-3 us: with two steps in flight the m loop ran at ~1 us per step (timeline).  Needs the 256-VGPR budget of a kernel
+// instance limited to two workgroups per CU.
+template <int BI, int BJ, int WI, int WJ, bool U8, bool PADDED, bool PF4 = false>
 __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int bx, const int by, const int bz,
                                                  float* smem) {
   constexpr int TI = BI / (32 * WI), TJ = BJ / (32 * WJ);
@@ -546,6 +549,28 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
       }
     };
 
+    if constexpr (PF4) {
+      Regs R[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) fetch(u < nsteps ? u : nsteps - 1, R[u]);      // (clamped: steps past the range repeat the last)
+      if (sub == mbeg) XT_TL(1);
+      for (int s = 0; s < nsteps; s += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (s + u < nsteps) {                                                   // block-uniform
+            float* stage = smem + (u & 1) * BUF;
+            stash(R[u], stage, stage + 32 * SA);
+            __syncthreads();
+            if (s == 0 && u == 0 && sub == mbeg) XT_TL(2);
+            if (s + u + 4 < nsteps) fetch(s + u + 4, R[u]);
+            colsum(stage + 32 * SA);
+            mma_tile<TI, TJ, SA, SB>(stage, stage + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+          }
+        }
+      }
+      __syncthreads();
+      continue;
+    }
     Regs R0, R1;
     if (nsteps > 0) fetch(0, R0);
     if (nsteps > 1) fetch(1, R1);
@@ -1323,7 +1348,7 @@ template <int WBI, int WBJ, int WWI, int WWJ, bool WPAD, int DBI, int DBJ, int D
           bool DX6 = false, int WROWS = 0>
 __global__ __launch_bounds__(256, WROWS ? 2 : 3) void igemm_bwd_layer_kernel(const BwdLayerArgs p) {
   constexpr int SMD = HALO == 5 ? 18 * 1024 : HALO == 3 ? 8 * 1024 : HALO == 2 ? 11 * 1024 : HALO == 1 ? 9 * 1024 : dgrad_smem_floats<DBI, DBJ, DX6>();
-  constexpr int SMW = WROWS ? kWrMaxSmemFloats : wgrad_smem_floats<WBI, WBJ, WPAD>();
+  constexpr int SMW = (WROWS == 1 || WROWS == 2) ? kWrMaxSmemFloats : wgrad_smem_floats<WBI, WBJ, WPAD>();
   constexpr int SM0 = SMW > SMD ? SMW : SMD;
   constexpr int SM = (D4 && dgrad4_smem_floats<D4 == 2>() > SM0) ? dgrad4_smem_floats<D4 == 2>() : SM0;
   __shared__ __attribute__((aligned(16))) float smem[SM];
@@ -1333,7 +1358,7 @@ __global__ __launch_bounds__(256, WROWS ? 2 : 3) void igemm_bwd_layer_kernel(con
 #endif
   if (b < p.n_dg) {                       // dgrad first: it is on the critical path of the next layer
     if constexpr (D4 != 0) {              // stride-2 conv: the four parity classes of a position tile in one block
-      igemm_dgrad4_body<D4 == 2, (WROWS == 2)>(p.dg, b, smem);
+      igemm_dgrad4_body<D4 == 2, (WROWS >= 2)>(p.dg, b, smem);
       return;
     }
     if constexpr (HALO == 5) {            // ... input AND weight gradient per sample (the launch has no weight-gradient blocks)
@@ -1372,12 +1397,12 @@ __global__ __launch_bounds__(256, WROWS ? 2 : 3) void igemm_bwd_layer_kernel(con
     // rows; consecutive block ids land on different XCDs (round-robin dispatch, private L2s), which made every
     // XCD fetch the layer input once per k tile (PMC: FETCH 2x35 MB for a 16 MB input)
     b = (int)xcd_chunk((uint32_t)b, (uint32_t)p.n_wg);
-    if constexpr (WROWS != 0) {           // staged-rows weight gradient: (sample group, kernel row) per workgroup
+    if constexpr (WROWS == 1 || WROWS == 2) {   // staged-rows weight gradient: (sample group, kernel row) per workgroup
       wgrad_rows_body(p.wg, b / p.wg_gx, b % p.wg_gx, p.wg.mchunk, smem);
       return;
     }
     const int bx = b % p.wg_gx, r = b / p.wg_gx;
-    igemm_wgrad_body<WBI, WBJ, WWI, WWJ, false, WPAD>(p.wg, bx, r % p.wg_gy, r / p.wg_gy, smem);
+    igemm_wgrad_body<WBI, WBJ, WWI, WWJ, false, WPAD, (WROWS == 3)>(p.wg, bx, r % p.wg_gy, r / p.wg_gy, smem);
     return;
   }
   b -= p.n_wg;
@@ -1701,7 +1726,8 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
   // staged-rows weight gradient (wgrad_rows_body) next to the all-classes input gradient: workgroup = (sample group,
   // kernel row), ceil(B / 64) samples per group so that KH * groups ~ one workgroup per CU, one slab per group
   bool wrows = false;
-  if (tuning().wgrad_rows && tuning().bf16x6 && a.dg_direct == 2 && !pad && g.C == kWrC && g.N == kWrN && g.KW == kWrKW &&
+  if ((tuning().wgrad_rows == 1 || tuning().wgrad_rows == 2 || tuning().wgrad_rows == 3) && tuning().bf16x6 &&
+      a.dg_direct == 2 && !pad && g.C == kWrC && g.N == kWrN && g.KW == kWrKW &&
       slabs != nullptr && wrows_smem_floats(g.OH, g.OW, g.W) <= kWrMaxSmemFloats &&
       g.OH * (g.W * kWrC / 4) <= kWrXQ * 256 && g.OHOW * (kWrN / 4) <= kWrDQ * 256) {
     const int per = (B + 63) / 64, groups = (B + per - 1) / per;
@@ -1714,6 +1740,22 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
       a.wg_gx = g.KH; a.wg_gy = 1; a.wg_gz = groups;
       a.n_wg = g.KH * groups;
       if (msplit_out) *msplit_out = groups;
+    }
+  }
+  bool pf4_only = false;
+  if (!wrows && tuning().wgrad_rows == 4 && tuning().bf16x6 && a.dg_direct == 2 && !pad &&
+      (g.KH / g.S) * (g.KW / g.S) * (g.N >> 5) == 4) {
+    const int tiles = a.wg_gx * a.wg_gy, room = 512 - a.n_dg - a.n_hw;
+    if (room >= tiles * 8) {
+      pf4_only = true;
+      if (a.n_wg > room) {
+        msplit = pick_ksplit_chunk(g.M, room / tiles, &chunk);
+        a.wg.msplit = msplit; a.wg.mchunk = chunk;
+        a.wg.out = msplit == 1 ? dwb : slabs;
+        if (msplit_out) *msplit_out = msplit;
+        a.wg_gz = msplit;
+        a.n_wg = tiles * msplit;
+      }
     }
   }
   const int total = a.n_wg + a.n_dg + a.n_hw;
@@ -1751,6 +1793,10 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
       hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1, 0, 2>), dim3(total), dim3(256), 0, st, a);
     else
       hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1, 0, 1>), dim3(total), dim3(256), 0, st, a);
+  } else if (a.dg_direct == 2 && pf4_only) {
+    // WROWS = 3: the LDS-tiled im2col weight gradient next to the all-taps-in-flight input gradient (250 VGPRs: two
+    // workgroups per CU, the launch cut to 512 co-resident workgroups)
+    hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, 2, 0, false, 3>), dim3(total), dim3(256), 0, st, a);
   } else if (a.dg_direct == 2 && wrows) {
     // (KH/S) * (KW/S) * (N/32) == 4 reduction steps: the input-gradient blocks keep all four taps' operands in flight
 #ifdef XT_TL_EXPERIMENT
