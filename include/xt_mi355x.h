@@ -89,6 +89,9 @@ typedef struct xt_tuning {
                                    the deep input-gradient prefetch (measured slower: 24 us; kept for A/B)        */
   int32_t fwd_prefetch_all;   /* 0 (default): two reduction steps in flight.  1: bf16x6 forwards with <= 8 steps
                                  per wave group issue all operand loads up front (ABI >= 8; measured +0.1 ms)     */
+  int32_t bwd_deep_prefetch;  /* 1: fused backward of Dense (1x1, stride 1) layers as a two-workgroups-per-CU instance:
+                                 all (<= 8) reduction steps of the input gradient in flight, four register stages in
+                                 the weight gradient, split cut to 512 co-resident workgroups (ABI >= 8)           */
   int32_t fwd_xcd_chunk;      /* 1: LDS-tiled forwards with several N tiles / k splits give every XCD a contiguous
                                  run of the (m tile, n tile, k slice) order: tiles that share operand slices share
                                  an L2 (ABI >= 8)                                                                  */

@@ -32,6 +32,11 @@ __device__ __forceinline__ bf16x8 bytes_to_bf16x8(uint32_t d0, uint32_t d1) {
 // 8 bytes each, at p0 + plane * plane_stride.  Every bf16 x bf16 product is exact in fp32, so
 // x*w = x1*w1 + (x1*w2 + x2*w1) + (x1*w3 + x2*w2 + x3*w1) + terms below 2^-24 relative ("bf16x6").
 __device__ __forceinline__ void split3_store(uint8_t* p0, int plane_stride, const float4 v) {
+#if defined(XT_ABL) && XT_ABL == 1     // ablation: no split arithmetic (timing probe, wrong numerics)
+  const uint2 w = make_uint2(pack_hi16(v.x, v.y), pack_hi16(v.z, v.w));
+  *reinterpret_cast<uint2*>(p0) = w; *reinterpret_cast<uint2*>(p0 + plane_stride) = w; *reinterpret_cast<uint2*>(p0 + 2 * plane_stride) = w;
+  return;
+#endif
   const float rx = v.x - trunc_bf16(v.x), ry = v.y - trunc_bf16(v.y), rz = v.z - trunc_bf16(v.z), rw = v.w - trunc_bf16(v.w);
   const float qx = rx - trunc_bf16(rx), qy = ry - trunc_bf16(ry), qz = rz - trunc_bf16(rz), qw = rw - trunc_bf16(rw);
   *reinterpret_cast<uint2*>(p0) = make_uint2(pack_hi16(v.x, v.y), pack_hi16(v.z, v.w));

@@ -284,6 +284,9 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
   const int wi = wave / WJ, wj = wave % WJ;
   const int nsteps = kend > kbeg ? (kend - kbeg + 31) / 32 : 0;      // this group's steps (<= nsteps_all)
   auto mma = [&](const float* stage) {
+#if defined(XT_ABL) && XT_ABL == 2     // ablation: no operand reads, no MFMAs (timing probe)
+    return;
+#endif
     if constexpr (X6) {
       const uint8_t* Ap = reinterpret_cast<const uint8_t*>(stage);
       const uint8_t* Bp = Ap + 12 * kX6SlotA;
@@ -661,7 +664,10 @@ constexpr int dgrad_smem_floats() {
   return X6 ? 2 * (12 * (BI * 16 + 32) + 12 * (BJ * 16 + 32)) / 4 + BI : 2 * (32 * (BI + 1) + 32 * (BJ + 1)) + BI;
 }
 
-template <int BI, int BJ, int WI, int WJ, bool X6 = false>
+// NST > 0 (round 3): the class reduction has at most NST 32-deep steps and ALL of their operand loads are issued before
+// the first is consumed (NST register stages; needs the 256-VGPR budget of a two-workgroups-per-CU instance).  With
+// two steps in flight the 8-step loop of the Dense layer's input gradient ran at the memory latency, 1.2 us per step.
+template <int BI, int BJ, int WI, int WJ, bool X6 = false, int NST = 0>
 __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int bx, const int by, const int bz,
                                                  float* smem) {
   constexpr int TI = BI / (32 * WI), TJ = BJ / (32 * WJ);
@@ -785,8 +791,14 @@ __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int b
   const int wi = wave / WJ, wj = wave % WJ;
   const int nsteps = (Kc + 31) / 32;
   Regs R0, R1;
-  if (nsteps > 0) fetch(0, R0);
-  if (nsteps > 1) fetch(32, R1);
+  Regs RN[NST > 0 ? NST : 1];
+  if constexpr (NST > 0) {
+#pragma unroll
+    for (int d = 0; d < NST; ++d) fetch(32 * d, RN[d]);      // (steps past Kc load a clamped address and contribute zeros)
+  } else {
+    if (nsteps > 0) fetch(0, R0);
+    if (nsteps > 1) fetch(32, R1);
+  }
   // prefetch the producer activations of this thread's output elements (clamped, unconditional): their latency
   // hides behind the reduction loop instead of being exposed in the epilogue (4.5 of 13.9 us per block before)
   __syncthreads();                 // rowOut
@@ -830,6 +842,18 @@ __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int b
       mma_tile<TI, TJ, SA, SB>(stage, stage + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
     }
   };
+  if constexpr (NST > 0) {
+#pragma unroll
+    for (int d = 0; d < NST; ++d) {
+      if (d < nsteps) {                          // block-uniform
+        float* stage = smem + (d & 1) * BUF;
+        stash(RN[d], stage, stage + 32 * SA);
+        __syncthreads();
+        if (d == 0) XT_TL(2);
+        mma(stage);
+      }
+    }
+  } else {
   for (int s = 0; s < nsteps; s += 2) {
     stash(R0, smem, smem + 32 * SA);
     __syncthreads();
@@ -842,6 +866,7 @@ __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int b
       if (s + 3 < nsteps) fetch((s + 3) * 32, R1);
       mma(smem + BUF);
     }
+  }
   }
   XT_TL(3);
 
@@ -1388,7 +1413,7 @@ __global__ __launch_bounds__(256, WROWS ? 2 : 3) void igemm_bwd_layer_kernel(con
     // (the M tiles of one channel tile stream the same W^T slice: XCD-contiguous order, as the forward)
     if (p.dg_xcd) b = (int)xcd_chunk((uint32_t)b, (uint32_t)p.n_dg);
     const int bx = b % p.dg_gx, r = b / p.dg_gx;
-    igemm_dgrad_body<DBI, DBJ, DWI, DWJ, DX6>(p.dg, bx, r % p.dg_gy, r / p.dg_gy, smem);
+    igemm_dgrad_body<DBI, DBJ, DWI, DWJ, DX6, (WROWS == 3 ? 8 : 0)>(p.dg, bx, r % p.dg_gy, r / p.dg_gy, smem);
     return;
   }
   b -= p.n_dg;
@@ -1763,6 +1788,27 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
   const bool exp_alone = wrows && tuning().wgrad_rows == 3;
 #endif
   const bool dx6 = tuning().bf16x6 != 0 && a.dg_direct == 0;     // LDS-tiled input gradient on the bf16 matrix cores
+  // Deep-prefetch instance of the generic LDS-tiled pair (Dense layers: S = 1, 1x1): every class reduction has at most 8
+  // steps -> all input-gradient operands in flight, four register stages in the weight gradient, two workgroups per CU;
+  // the weight-gradient split is cut so that the launch stays within 512 co-resident workgroups
+  bool pf_generic = false;
+  if (tuning().bwd_deep_prefetch && dx6 && !pad && !wsmall && !dsmall && g.S == 1 && g.KH == 1 && g.KW == 1 && g.N <= 256 &&
+      a.dg_direct == 0) {
+    // (the head weight-gradient blocks come last in block order and are short: they may spill into a second round)
+    const int tiles = a.wg_gx * a.wg_gy, room = 512 - a.n_dg - a.n_hw;
+    if (512 - a.n_dg >= tiles) {
+      pf_generic = true;
+      if (a.n_wg > room) {
+        msplit = pick_ksplit_chunk(g.M, room / tiles > 1 ? room / tiles : 1, &chunk);
+        a.wg.msplit = msplit; a.wg.mchunk = chunk;
+        a.wg.out = msplit == 1 ? dwb : slabs;
+        if (msplit_out) *msplit_out = msplit;
+        a.wg_gz = msplit;
+        a.n_wg = tiles * msplit;
+      }
+    }
+  }
+  const int total2 = a.n_wg + a.n_dg + a.n_hw;
 #define XT_BWD2(WBI, WBJ, WWI, WWJ, DBI, DBJ, DWI, DWJ, X6V)                                                    \
   do {                                                                                                          \
     if (pad) hipLaunchKernelGGL((igemm_bwd_layer_kernel<WBI, WBJ, WWI, WWJ, true, DBI, DBJ, DWI, DWJ, 0, 0, X6V>), \
@@ -1811,6 +1857,8 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
     const int x6 = tuning().bf16x6;      // 0: fp32 MFMA in the all-classes input gradient (A/B)
     if (x6) hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, 2>), dim3(total), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, 1>), dim3(total), dim3(256), 0, st, a);
+  } else if (pf_generic) {
+    hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 64, 64, 2, 2, 0, 0, true, 3>), dim3(total2), dim3(256), 0, st, a);
   } else if (wsmall && dsmall) XT_BWD(128, 32, 4, 1, 128, 32, 4, 1);
   else if (wsmall) XT_BWD(128, 32, 4, 1, 64, 64, 2, 2);
   else if (dsmall) XT_BWD(64, 64, 2, 2, 128, 32, 4, 1);
