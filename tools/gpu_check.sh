@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box call: the -m gpu suite, the default bench line, and in-graph kernel averages of the three workloads.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r02}
+TAG=${1:-r03}
 mkdir -p $R/gpurun_out
 cd $R
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_pytest.log 2>&1; tail -4 gpurun_out/${TAG}_pytest.log
