@@ -408,13 +408,14 @@ def bench_e2e_ppo(env_num, min_seconds=1.0, max_updates=40, via_ring=False):
                 alg.prepare_data(tr)
             return time.perf_counter() - t0
         spent = 0.0
-        for lo in range(0, len(wire), ring.slots):
-            chunk = wire[lo:lo + ring.slots]
-            for m in chunk:
-                ring.send_bytes(m)                      # explorer side
+        for m in wire:
+            if not ring.send_bytes(m, block=False):     # explorer side; a full ring = copies still reading the slots
+                t0 = time.perf_counter()
+                ring.drain()                            # (learner time: it waits for its own DMAs)
+                spent += time.perf_counter() - t0
+                assert ring.send_bytes(m, block=False)
             t0 = time.perf_counter()
-            for _ in chunk:
-                ring.recv_into(alg.prepare_data)        # learner side: decode -> DMA out of the pinned slot
+            ring.recv_into(alg.prepare_data)            # learner side: decode -> DMA out of the pinned slot, no wait
             spent += time.perf_counter() - t0
         return spent
 

@@ -1226,3 +1226,48 @@ def test_adv_norm_option_normalises_the_rollout_before_training_and_defaults_off
         l_off, w_off = run({}, trajs, stream)
         assert abs(l_opt - l_ref) < 1e-6 * max(1.0, abs(l_ref)) and np.allclose(w_opt, w_ref, rtol=0, atol=1e-7)
         assert not np.allclose(w_off, w_ref, rtol=0, atol=1e-5), "ADV_NORM must default to off"
+
+
+def test_pinned_ring_defers_slot_release_until_the_dma_has_landed():
+    """A pinned ring hands prepare_data a SlotGuard: the ingest starts the DMA out of the slot, gives the ring the copy's
+    event and returns at once; the ring recycles the slot only after the event has fired.  Six trajectories through a
+    TWO-slot ring (every slot is overwritten twice while earlier copies may still be in flight): the rollout that
+    reaches HBM is bit for bit what was sent, and the update equals the one fed from plain host arrays."""
+    from xingtian_amd import transport
+    from xingtian_amd.algorithm import alg_builder
+    model_info = {"actor": {"model_name": "PpoCnn", "state_dim": [84, 84, 4], "action_dim": 4, "input_dtype": "uint8",
+                            "model_config": {"BATCH_SIZE": 64, "NUM_SGD_ITER": 1, "SEED": 3, "hidden_sizes": [64]}}}
+    rng = np.random.default_rng(41)
+    trajs = []
+    for _ in range(6):
+        obs, lab = synth_ppo_rollout(rng, 32, (84, 84, 4), 4)
+        trajs.append({"cur_state": obs, "action": lab[0], "logp": lab[1], "adv": lab[2], "old_value": lab[3], "target_value": lab[4]})
+    perms = rng.permutation(192).astype(np.int32).reshape(1, -1)
+    ref = alg_builder("PPO", model_info, {"instance_num": 6, "agent_num": 1})
+    for tr in trajs:
+        ref.prepare_data(tr)
+    loss_ref = ref.train(perms=perms)
+    alg = alg_builder("PPO", model_info, {"instance_num": 6, "agent_num": 1})
+    ring = transport.ShmRing(slots=2, slot_bytes=2 << 20)
+    assert ring.pin()
+    held_max = 0
+    try:
+        for i, tr in enumerate(trajs):
+            msg = transport.encode({"cmd": "train", "explorer_id": i}, tr)
+            while not ring.send_bytes(msg, block=False):
+                ring.drain()
+            assert ring.recv_into(alg.prepare_data)["explorer_id"] == i
+            held_max = max(held_max, len(ring._held))
+        n_ing = alg.actor.ingested()
+        assert n_ing == 192
+        dev_obs = alg.actor._ingest.sets[alg.actor._ingest.cur].dev["obs"]
+        alg.actor._ingest.copy_stream.synchronize()
+        assert np.array_equal(dev_obs[:192].cpu().numpy(), np.concatenate([t["cur_state"] for t in trajs]))
+        loss = alg.train(perms=perms)
+    finally:
+        ring.close()
+    assert held_max >= 1, "the pinned path never deferred a release"
+    assert loss == loss_ref
+    wa, wb = alg.get_weights(), ref.get_weights()
+    for k in wa:
+        assert np.array_equal(wa[k], wb[k]), k

@@ -42,8 +42,9 @@ class IMPALAOpt(Algorithm):
     def prepare_data(self, train_data, **kwargs):
         fields = self._data_proc(train_data)
         if getattr(self.actor, "stream_ingest", False) and hasattr(self.actor, "ingest_message"):
-            pinned = bool((kwargs.get("ctr_info") or {}).get("_pinned_views"))
-            self.actor.ingest_message(*fields, pinned=pinned)     # pinned staging + async H2D start now
+            ctr = kwargs.get("ctr_info") or {}
+            pinned = bool(ctr.get("_pinned_views"))
+            self.actor.ingest_message(*fields, pinned=pinned, slot_guard=ctr.get("_slot_guard"))   # async H2D starts now
             self._streamed += 1
             self._rollout.add(**{k: None for k in self.FIELDS})   # no reference kept: the arrays may be transport views
             return

@@ -50,8 +50,9 @@ class PPO(Algorithm):
             train_data = dict(train_data, adv=adv.reshape(-1, 1), old_value=old_v.reshape(-1, 1),
                               target_value=tgt.reshape(-1, 1))
         if getattr(self.actor, "stream_ingest", False) and hasattr(self.actor, "ingest_trajectory"):
-            pinned = bool((kwargs.get("ctr_info") or {}).get("_pinned_views"))     # views into a pinned transport ring
-            self.actor.ingest_trajectory(train_data, pinned=pinned)          # H2D copy starts now
+            ctr = kwargs.get("ctr_info") or {}
+            pinned = bool(ctr.get("_pinned_views"))                          # views into a pinned transport ring
+            self.actor.ingest_trajectory(train_data, pinned=pinned, slot_guard=ctr.get("_slot_guard"))   # H2D starts now
             self._streamed += 1
             # the staging buffers hold the copy: keep no reference to the arriving arrays (they may be zero-copy views
             # into a transport slot that is recycled as soon as this call returns, xingtian_amd/transport.py)

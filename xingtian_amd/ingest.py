@@ -118,12 +118,13 @@ class RolloutIngest(object):
         self.sets[self.cur] = new
         return new
 
-    def put(self, obs, *labels, pinned=False):
+    def put(self, obs, *labels, pinned=False, slot_guard=None):
         """Append one trajectory / rollout message ([T,...] arrays as the explorer ships them, labels in the order
         of ``fields``) and start the H2D copy of its frames.  ``pinned``: the arrays are views into page-locked memory
         (a pinned transport ring): frames whose dtype already is the device dtype are DMA-copied straight from the
-        source, and the call returns only when that copy has landed (the caller recycles the slot right after).  The
-        arriving arrays are never referenced after the call returns."""
+        source; the call returns when that copy has landed (the caller recycles the slot right after) -- or at once, if
+        the transport handed over a ``slot_guard`` (``transport.SlotGuard``): it then gets the copy's event and keeps
+        the slot until the event has fired.  Otherwise the arriving arrays are never referenced after the call returns."""
         obs = np.asarray(obs)
         t = obs.shape[0]
         s = self._ensure(self.n + t, obs)
@@ -141,7 +142,12 @@ class RolloutIngest(object):
             # DMA source = the pinned transport slot: no host copy at all; the caller recycles the slot right after
             with torch.cuda.stream(self.copy_stream):
                 s.dev["obs"][lo:hi].copy_(torch.from_numpy(obs.reshape(obs_dst.shape)), non_blocking=True)
-            self.copy_stream.synchronize()
+            if slot_guard is not None:      # the ring keeps the slot until this event has fired: no wait here
+                ev = torch.cuda.Event()
+                ev.record(self.copy_stream)
+                slot_guard.hold(ev)
+            else:
+                self.copy_stream.synchronize()
         elif plain:
             L.check(self._lib.xt_stage_rows(ctypes.c_void_p(s.host["obs"].data_ptr() + lo * row_bytes),
                                             ctypes.c_void_p(obs.ctypes.data), obs.nbytes, ctypes.c_void_p(dev_ptr), 0, 0, -1,

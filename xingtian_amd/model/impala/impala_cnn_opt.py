@@ -80,10 +80,10 @@ class ImpalaCnnOpt(XTModel):
                                          fields=impala_fields(self.action_dim))
         return self._ingest
 
-    def ingest_message(self, states, bp_logic_outs, actions, dones, rewards, pinned=False):
+    def ingest_message(self, states, bp_logic_outs, actions, dones, rewards, pinned=False, slot_guard=None):
         """Called by ``IMPALAOpt.prepare_data`` for every rollout message: its pinned-staging + asynchronous H2D
         copy starts now, so ``train`` finds the rollout resident."""
-        self._ingest_obj().put(states, bp_logic_outs, actions, dones, rewards, pinned=pinned)
+        self._ingest_obj().put(states, bp_logic_outs, actions, dones, rewards, pinned=pinned, slot_guard=slot_guard)
 
     def ingested(self):
         return 0 if self._ingest is None else self._ingest.n

@@ -154,7 +154,7 @@ class PPO(XTModel):
         return r
 
     # ---- streaming ingest: trajectories go to HBM as they arrive -------------------
-    def ingest_trajectory(self, train_data, pinned=False):
+    def ingest_trajectory(self, train_data, pinned=False, slot_guard=None):
         """Called by ``PPO.prepare_data`` for every trajectory; starts its pinned-staging + async H2D copy
         (``pinned``: the arrays already live in page-locked memory -- a pinned transport ring -- and are copied to HBM
         straight from there)."""
@@ -163,7 +163,7 @@ class PPO(XTModel):
             self._ingest = RolloutIngest(self.net.device, self.num_sgd_iter,
                                          obs_u8=bool(self.net.spec.input_xform[0]))
         self._ingest.put(train_data["cur_state"], train_data["action"], train_data["logp"], train_data["adv"],
-                         train_data["old_value"], train_data["target_value"], pinned=pinned)
+                         train_data["old_value"], train_data["target_value"], pinned=pinned, slot_guard=slot_guard)
 
     def ingested(self):
         return 0 if self._ingest is None else self._ingest.n

@@ -125,6 +125,18 @@ def decode_into(buf, sink):
     return ctr
 
 
+class SlotGuard(object):
+    """Handed to the sink of a PINNED ring in ``ctr_info["_slot_guard"]``: a sink that starts an asynchronous copy out of
+    the slot calls ``hold(event)`` with an object offering ``query()`` / ``synchronize()`` (a ``torch.cuda.Event``)
+    instead of waiting for the copy; the ring releases the slot once the event has completed."""
+
+    def __init__(self):
+        self.event = None
+
+    def hold(self, event):
+        self.event = event
+
+
 class ShmRing(object):
     """Single-producer / single-consumer ring of ``slots`` x ``slot_bytes`` in POSIX shared memory.
 
@@ -146,6 +158,8 @@ class ShmRing(object):
         self._len = np.ndarray((self.slots,), dtype=np.uint64, buffer=self.shm.buf, offset=_ALIGN)
         self._base = _ALIGN + 8 * self.slots
         self.pinned = False
+        self._held = []            # consumer side: guards of delivered messages whose slot is not released yet
+        self._taken = 0            # ... and their number (tail has not advanced past them)
 
     def pin(self):
         """Learner side, optional: page-lock the ring with the HIP runtime (``hipHostRegister``) so that the arrays
@@ -194,11 +208,14 @@ class ShmRing(object):
     def recv_view(self, block=True, timeout=None):
         """-> memoryview of the oldest unread message (valid until ``release``) or None."""
         t0 = time.monotonic()
-        while int(self._ctl[0]) == int(self._ctl[1]):
+        while int(self._ctl[0]) == int(self._ctl[1]) + self._taken:
+            self._reap()                  # slots held for a deferred copy may be what the producer is waiting for
+            if int(self._ctl[0]) != int(self._ctl[1]) + self._taken:
+                break
             if not block or (timeout is not None and time.monotonic() - t0 > timeout):
                 return None
             time.sleep(0.0002)
-        slot = int(self._ctl[1]) % self.slots
+        slot = (int(self._ctl[1]) + self._taken) % self.slots
         off = self._base + slot * self.slot_bytes
         return self.shm.buf[off:off + int(self._len[slot])]
 
@@ -218,24 +235,60 @@ class ShmRing(object):
 
     def recv_into(self, sink, block=True, timeout=None):
         """Zero-copy receive: ``sink(data, ctr_info=...)`` sees views into the slot; the slot is released after it
-        returns (``decode_into``)."""
+        returns (``decode_into``).  On a pinned ring the sink may start a DMA straight out of the slot and hand the
+        ring an event instead of waiting for it (``ctr_info["_slot_guard"].hold(event)``, see ``SlotGuard``): the slot
+        is then released, in order, once that copy has landed -- up to ``slots - 1`` messages' copies stay in flight
+        while the learner already decodes the next message."""
+        self._reap()
         view = self.recv_view(block, timeout)
         if view is None:
             return None
         if self.pinned:
             ctr, data = decode(view)
-            sink(data, ctr_info=dict(ctr, _pinned_views=True))      # the sink may DMA straight out of the slot
+            guard = SlotGuard()
+            sink(data, ctr_info=dict(ctr, _pinned_views=True, _slot_guard=guard))   # the sink may DMA straight out of the slot
             del data
-        else:
-            ctr = decode_into(view, sink)
+            del view
+            if guard.event is None and not self._held:
+                self.release()
+            else:
+                self._held.append(guard)          # released in order by _reap()
+                self._taken += 1
+            return ctr
+        ctr = decode_into(view, sink)
         del view
         self.release()
         return ctr
 
+    def _reap(self, wait=False):
+        """release the slots whose deferred copies have completed (oldest first)"""
+        while self._held:
+            g = self._held[0]
+            if g.event is not None:
+                if wait:
+                    g.event.synchronize()
+                elif not g.event.query():
+                    break
+            self._held.pop(0)
+            self._taken -= 1
+            self.release()
+
     def pending(self):
-        return int(self._ctl[0]) - int(self._ctl[1])
+        """messages sent and not yet delivered to the consumer"""
+        return int(self._ctl[0]) - int(self._ctl[1]) - self._taken
+
+    def reap(self):
+        """release the slots whose deferred copies have completed; returns the number still held"""
+        self._reap()
+        return len(self._held)
+
+    def drain(self):
+        """wait for every deferred copy and release its slot"""
+        self._reap(wait=True)
 
     def close(self):
+        if self._held:
+            self._reap(wait=True)
         self._ctl = self._len = None
         if self.pinned:
             self._hip.hipHostUnregister.argtypes = [__import__("ctypes").c_void_p]
