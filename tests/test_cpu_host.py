@@ -974,3 +974,47 @@ def test_weights_ring_publishes_to_many_readers_without_torn_reads():
             if p.is_alive():
                 p.terminate()
         ring.close()
+
+
+def test_ring_releases_slots_in_order_behind_a_deferred_copy():
+    """SlotGuard protocol of a pinned ring, without a GPU (fake events): a sink that holds its slot for an asynchronous
+    copy keeps the ring from recycling it, later messages -- even ones taken with the copying ``recv`` -- queue behind it
+    (slots are released in arrival order), the producer sees back pressure meanwhile, and everything is released once
+    the copy's event reports completion."""
+    from xingtian_amd import transport
+
+    class FakeEvent(object):
+        def __init__(self):
+            self.done = False
+
+        def query(self):
+            return self.done
+
+        def synchronize(self):
+            self.done = True
+
+    ring = transport.ShmRing(slots=2, slot_bytes=1 << 16)
+    ring.pinned = True                 # (no hipHostRegister here: only the guard protocol is under test)
+    ev = FakeEvent()
+    try:
+        msg = lambda i: transport.encode({"seq": i}, {"x": np.full(8, i, np.int32)})
+        assert ring.send_bytes(msg(0)) and ring.send_bytes(msg(1))
+        assert not ring.send_bytes(msg(2), block=False)                     # full
+        seen = []
+        ring.recv_into(lambda d, ctr_info=None: (seen.append(int(d["x"][0])), ctr_info["_slot_guard"].hold(ev)))
+        assert seen == [0] and ring.pending() == 1 and len(ring._held) == 1
+        assert not ring.send_bytes(msg(2), block=False)                     # slot 0 still belongs to the pending copy
+        ctr, data = ring.recv(block=False)                                  # message 1, copied out: queues behind message 0
+        assert ctr == {"seq": 1} and ring.pending() == 0 and len(ring._held) == 2
+        assert not ring.send_bytes(msg(2), block=False)
+        assert ring.recv(block=False) is None                               # nothing new; reaping finds the copy pending
+        ev.done = True
+        assert ring.reap() == 0                                             # both slots released, in order
+        assert ring.send_bytes(msg(2), block=False) and ring.send_bytes(msg(3), block=False)
+        got = []
+        for _ in range(2):
+            ring.recv_into(lambda d, ctr_info=None: got.append(int(d["x"][0])))
+        assert got == [2, 3] and not ring._held
+    finally:
+        ring.pinned = False
+        ring.close()

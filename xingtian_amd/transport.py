@@ -222,6 +222,15 @@ class ShmRing(object):
     def release(self):
         self._ctl[1] = int(self._ctl[1]) + 1
 
+    def _done_with_slot(self, guard=None):
+        """the message just delivered needs its slot no longer (or only until ``guard.event``): slots are released in
+        arrival order, so it queues behind earlier messages whose deferred copies are still pending"""
+        if (guard is None or guard.event is None) and not self._held:
+            self.release()
+        else:
+            self._held.append(guard if guard is not None else SlotGuard())
+            self._taken += 1
+
     def recv(self, block=True, timeout=None):
         """-> (ctr_info, data) with the arrays COPIED out of the slot (the reference channel's contract)."""
         view = self.recv_view(block, timeout)
@@ -230,7 +239,7 @@ class ShmRing(object):
         ctr, data = decode(view)
         data = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in data.items()}
         del view
-        self.release()
+        self._done_with_slot()
         return ctr, data
 
     def recv_into(self, sink, block=True, timeout=None):
@@ -249,15 +258,11 @@ class ShmRing(object):
             sink(data, ctr_info=dict(ctr, _pinned_views=True, _slot_guard=guard))   # the sink may DMA straight out of the slot
             del data
             del view
-            if guard.event is None and not self._held:
-                self.release()
-            else:
-                self._held.append(guard)          # released in order by _reap()
-                self._taken += 1
+            self._done_with_slot(guard)           # (released in order by _reap() when a copy is still pending)
             return ctr
         ctr = decode_into(view, sink)
         del view
-        self.release()
+        self._done_with_slot()
         return ctr
 
     def _reap(self, wait=False):
