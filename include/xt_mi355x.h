@@ -35,13 +35,17 @@ extern "C" {
 #define XT_ACT_NONE 0
 #define XT_ACT_RELU 1
 #define XT_ACT_TANH 2
-/* ABI >= 8: the other monotonic entries of ACTIVATION_MAP (xt/model/model_utils.py:8-20); swish / gelu are refused */
+/* ABI >= 8: the other entries of ACTIVATION_MAP (xt/model/model_utils.py:8-20) */
 #define XT_ACT_SIGMOID 3
 #define XT_ACT_SOFTSIGN 4
 #define XT_ACT_SOFTPLUS 5
 #define XT_ACT_LEAKY_RELU 6      /* tf.nn.leaky_relu, alpha = 0.2 */
 #define XT_ACT_ELU 7
 #define XT_ACT_SELU 8
+/* not monotonic: a network layer with one of these also keeps its PRE-activation (xt_net does; the stand-alone layer
+ * entry points then take the pre-activation as `x` of xt_layer_dgrad) */
+#define XT_ACT_SWISH 9           /* tf.nn.swish: x * sigmoid(x)                                   */
+#define XT_ACT_GELU 10           /* xt/model/tf_utils.py:157-166 (tanh form)                      */
 
 /* ------------------------------------------------------------------ misc */
 int xt_abi_version(void);

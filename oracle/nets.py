@@ -280,12 +280,19 @@ def act_fwd(z, act):
         return np.where(z > 0, z, np.expm1(np.minimum(z, 0)))
     if act == "selu":
         return SELU_SCALE * np.where(z > 0, z, SELU_ALPHA * np.expm1(np.minimum(z, 0)))
+    if act == "swish":                  # tf.nn.swish: x * sigmoid(x)
+        return z / (1.0 + np.exp(-z))
+    if act == "gelu":                   # xt/model/tf_utils.py:157-166 (the tanh form)
+        return 0.5 * z * (1.0 + np.tanh(np.sqrt(2.0 / np.pi) * (z + 0.044715 * z ** 3)))
     if act is None or act == "none":
         return z
     raise KeyError(act)
 
 
-def act_bwd(dy, y, act):
+NEEDS_PREACT = ("swish", "gelu")        # not monotonic: the derivative needs the pre-activation
+
+
+def act_bwd(dy, y, act, z=None):
     """d(pre-activation) from d(post) and the saved OUTPUT y.  The pre-activation z is recovered from y in closed
     form (every supported activation is strictly monotonic) and the textbook derivative is evaluated at z -- not the
     from-the-output shortcuts the kernels use (cross-checked against torch autograd in tests/test_oracle.py)."""
@@ -309,6 +316,13 @@ def act_bwd(dy, y, act):
     if act == "selu":
         z = np.where(y > 0, y / SELU_SCALE, np.log1p(np.minimum(y, 0) / (SELU_SCALE * SELU_ALPHA)))
         return dy * SELU_SCALE * np.where(z > 0, 1.0, SELU_ALPHA * np.exp(np.minimum(z, 0)))
+    if act == "swish":
+        sg = 1.0 / (1.0 + np.exp(-z))
+        return dy * (sg + z * sg * (1.0 - sg))
+    if act == "gelu":
+        c = np.sqrt(2.0 / np.pi)
+        th = np.tanh(c * (z + 0.044715 * z ** 3))
+        return dy * (0.5 * (1.0 + th) + 0.5 * z * (1.0 - th * th) * c * (1.0 + 3 * 0.044715 * z * z))
     if act is None or act == "none":
         return dy
     raise KeyError(act)
@@ -347,12 +361,14 @@ class ActorCritic(object):
                 bias = self.params[lay.name + "/bias"]
                 if lay.kind == "conv":
                     cols = im2col(x.reshape(b, lay.in_h, lay.in_w, lay.cin), lay)
-                    y = act_fwd(cols @ w.reshape(-1, lay.cout) + bias, lay.act)
-                    y = y.reshape(b, lay.out_h, lay.out_w, lay.cout)
+                    z = cols @ w.reshape(-1, lay.cout) + bias
+                    y = act_fwd(z, lay.act).reshape(b, lay.out_h, lay.out_w, lay.cout)
+                    z = z.reshape(y.shape)
                 else:
                     cols = x.reshape(b, -1)
-                    y = act_fwd(cols @ w + bias, lay.act)
-                tc.append((cols, y))
+                    z = cols @ w + bias
+                    y = act_fwd(z, lay.act)
+                tc.append((cols, y, z))
                 x = y
             self.cache.append(tc)
             feats.append(x.reshape(b, -1))
@@ -385,8 +401,8 @@ class ActorCritic(object):
         for trunk, tc, dy in zip(self.spec["trunks"], self.cache, dfeat):
             for li in range(len(trunk) - 1, -1, -1):
                 lay = trunk[li]
-                cols, y = tc[li]
-                dz = act_bwd(dy.reshape(y.shape), y, lay.act)
+                cols, y, z = tc[li]
+                dz = act_bwd(dy.reshape(y.shape), y, lay.act, z)
                 dz2 = dz.reshape(-1, lay.cout)
                 w = self.params[lay.name + "/kernel"]
                 grads[lay.name + "/kernel"] = (cols.T @ dz2).reshape(w.shape)

@@ -61,7 +61,8 @@ class TorchActorCritic(object):
 
 _ACT = {"relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid, "softsign": F.softsign, "softplus": lambda y: torch.logaddexp(y, torch.zeros_like(y)),   # (F.softplus switches to the identity above 20)
         
-        "leaky_relu": lambda y: F.leaky_relu(y, 0.2), "elu": F.elu, "selu": F.selu, None: lambda y: y, "none": lambda y: y}
+        "leaky_relu": lambda y: F.leaky_relu(y, 0.2), "elu": F.elu, "selu": F.selu, "swish": F.silu,
+        "gelu": lambda y: F.gelu(y, approximate="tanh"), None: lambda y: y, "none": lambda y: y}
 
 
 def ppo_loss_torch(logits, value, action, old_logp, adv, old_v, target_v,

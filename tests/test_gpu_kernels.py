@@ -127,6 +127,9 @@ LAYER_CASES = [
     ("conv3_leaky", "conv", (9, 9), 32, 64, 3, 1, "valid", "leaky_relu", 9, False),
     ("conv1_u8_elu", "conv", (84, 84), 4, 32, 8, 4, "valid", "elu", 5, True),
     ("imp_conv2_same_selu", "conv", (21, 21), 16, 32, 4, 2, "same", "selu", 6, False),
+    # not monotonic: the input-gradient epilogue is given the producer's PRE-activation
+    ("conv3_swish", "conv", (9, 9), 32, 64, 3, 1, "valid", "swish", 9, False),
+    ("fc_gelu", "dense", (1, 1), 64, 64, 1, 1, "valid", "gelu", 130, False),
 ]
 
 
@@ -222,7 +225,11 @@ def test_layer_dgrad(L, case):
     extra = (lay.act,) if lay.act not in (None, "relu", "tanh") else ()     # the producer's activation derivative
     for act_prev in ("relu", "tanh") + extra:
         xp = x_raw if act_prev == "relu" else nets.act_fwd(x_raw.astype(np.float64), act_prev).astype(np.float32)
-        ref = nets.act_bwd(dx.reshape(xp.shape), xp.astype(np.float64), act_prev)
+        if act_prev in nets.NEEDS_PREACT:       # the kernel is handed the producer's pre-activation for these
+            xp = x_raw
+            ref = nets.act_bwd(dx.reshape(xp.shape), None, act_prev, xp.astype(np.float64))
+        else:
+            ref = nets.act_bwd(dx.reshape(xp.shape), xp.astype(np.float64), act_prev)
         g = geom_of(L, lay)
         out = torch.full(xp.shape, float("nan"), device="cuda")
         L.check(L.load().xt_layer_dgrad(ctypes.byref(g), b, L.ptr(dev(dy)), L.ptr(dev(w)), L.ptr(dev(xp)),

@@ -111,7 +111,8 @@ def _mk(which, batch):
                                      ("cnn84", 40), ("cnn84", 80), ("cnn84", 160),
                                      ("cnn42_unshared", 33), ("cnn42_a18", 40), ("cnn30_inferred", 50), ("mlp", 200),
                                      ("cnn42_act_softplus", 33), ("cnn42_act_selu", 33), ("cnn42_act_leaky_relu", 33),
-                                     ("mlp_act_elu", 200), ("mlp_act_sigmoid", 64), ("mlp_act_softsign", 64)])
+                                     ("mlp_act_elu", 200), ("mlp_act_sigmoid", 64), ("mlp_act_softsign", 64),
+                                     ("cnn42_act_swish", 33), ("mlp_act_gelu", 64)])
 def test_ppo_step_loss_and_grads_vs_oracle(which, b):
     """b = 320 is BASELINE.json's minibatch (breakout_ppo.yaml BATCH_SIZE): the launch configurations of the
     benchmark (flattened first-layer kernels, two-wave-group forwards, register-direct conv2, bf16x6 input

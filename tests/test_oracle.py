@@ -73,9 +73,10 @@ def test_ppo_grads_match_torch_autograd_fp64(which):
             np.testing.assert_allclose(o.net.params[k], t.net.params[k].detach().numpy(), rtol=1e-9, atol=1e-12)
 
 
-@pytest.mark.parametrize("act", ["sigmoid", "softsign", "softplus", "leaky_relu", "elu", "selu"])
+@pytest.mark.parametrize("act", ["sigmoid", "softsign", "softplus", "leaky_relu", "elu", "selu", "swish", "gelu"])
 def test_monotonic_activations_match_torch_autograd_fp64(act):
-    """The other monotonic entries of the reference's ACTIVATION_MAP (xt/model/model_utils.py:8-20): the oracle's
+    """The other entries of the reference's ACTIVATION_MAP (xt/model/model_utils.py:8-20; swish and gelu -- the tanh form
+    of xt/model/tf_utils.py:157-166 -- take their derivative at the stored pre-activation): the oracle's
     forward and its hand-derived backward (pre-activation recovered from the saved output, textbook derivative) against
     torch autograd through torch's own definitions of the same functions, on a conv + dense PPO network."""
     rng = np.random.default_rng(5)
@@ -96,9 +97,10 @@ def test_monotonic_activations_match_torch_autograd_fp64(act):
     zt = torch.tensor(z, requires_grad=True)
     yt = torch_ref._ACT[act](zt)
     yt.sum().backward()
-    np.testing.assert_allclose(y, yt.detach().numpy(), rtol=1e-12, atol=1e-300)
+    # (gelu: 1 + tanh(.) cancels for very negative arguments -- both sides lose the same digits, in different orders)
+    np.testing.assert_allclose(y, yt.detach().numpy(), rtol=1e-12, atol=1e-300 if act != "gelu" else 1e-14)
     keep = np.abs(y) < 1 - 1e-9 if act == "softsign" else (y > 1e-12 if act == "softplus" else np.ones_like(y, bool))
-    np.testing.assert_allclose(nets.act_bwd(np.ones_like(z), y, act)[keep], zt.grad.numpy()[keep], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(nets.act_bwd(np.ones_like(z), y, act, z)[keep], zt.grad.numpy()[keep], rtol=1e-6, atol=1e-12)
 
 
 def test_gauss_ppo_grads_match_torch_autograd_fp64():

@@ -87,8 +87,7 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) {
 // The transcendental activations are kept OUT of line (one shared body) so that epilogues that apply the activation to
 // 16..64 accumulator registers do not inline ~60 instructions of libdevice code 64 times (code size = cold
 // instruction-fetch time per launch).  ACTIVATION_MAP of xt/model/model_utils.py:8-20; swish and gelu are not
-// monotonic, so their derivative cannot be taken from the saved OUTPUT (this design stores post-activations only)
-// and the plugin refuses them.
+// monotonic: for them act_grad is given the PRE-activation (see act_needs_preact).
 constexpr float kSeluScale = 1.0507009873554805f, kSeluAlpha = 1.6732632423543772f;   // tf.nn.selu
 constexpr float kLeakyAlpha = 0.2f;                                                  // tf.nn.leaky_relu default
 __device__ __noinline__ static float xt_act_slow(float z, int act) {
@@ -99,6 +98,8 @@ __device__ __noinline__ static float xt_act_slow(float z, int act) {
     case XT_ACT_SOFTPLUS: return fmaxf(z, 0.f) + log1pf(expf(-fabsf(z)));       // log(1 + e^z), overflow-free
     case XT_ACT_ELU: return z > 0.f ? z : expm1f(z);
     case XT_ACT_SELU: return kSeluScale * (z > 0.f ? z : kSeluAlpha * expm1f(z));
+    case XT_ACT_SWISH: return z / (1.f + expf(-z));
+    case XT_ACT_GELU: return 0.5f * z * (1.f + tanhf(0.7978845608028654f * (z + 0.044715f * z * z * z)));
     default: return z;
   }
 }
@@ -110,9 +111,19 @@ __device__ __noinline__ static float xt_act_grad_slow(float y, int act) {
     case XT_ACT_SOFTPLUS: return -expm1f(-y);                                   // sigmoid(z) = 1 - e^{-y}
     case XT_ACT_ELU: return y > 0.f ? 1.f : y + 1.f;                            // TF EluGrad (from the outputs)
     case XT_ACT_SELU: return y > 0.f ? kSeluScale : y + kSeluScale * kSeluAlpha; // TF SeluGrad (from the outputs)
+    // not monotonic: `y` IS the pre-activation z for these two (act_needs_preact)
+    case XT_ACT_SWISH: { const float sg = 1.f / (1.f + expf(-y)); return sg + y * sg * (1.f - sg); }
+    case XT_ACT_GELU: {
+      const float c = 0.7978845608028654f, th = tanhf(c * (y + 0.044715f * y * y * y));
+      return 0.5f * (1.f + th) + 0.5f * y * (1.f - th * th) * c * (1.f + 3.f * 0.044715f * y * y);
+    }
     default: return 1.f;
   }
 }
+
+// activations whose derivative cannot be taken from the output: the producer's PRE-activation is kept and handed to
+// act_grad instead (xt_net: Layer::z_off)
+static inline bool act_needs_preact(int act) { return act == XT_ACT_SWISH || act == XT_ACT_GELU; }
 
 __device__ __forceinline__ float act_apply(float z, int act) {
   if (act == XT_ACT_RELU) return z > 0.f ? z : 0.f;

@@ -974,6 +974,26 @@ int launch_ppo_loss_gauss(const float* mean, const float* log_std, const float* 
 
 }  // namespace xt
 
+namespace xt {
+// y = act(z), elementwise: the output of a layer whose pre-activation is kept (swish / gelu, see Layer::z_off)
+__global__ __launch_bounds__(256) void act_apply_kernel(const float* __restrict__ z, float* __restrict__ y, long long count, int act) {
+  const long long e4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e4 + 3 < count) {
+    float4 v = *reinterpret_cast<const float4*>(z + e4);
+    v.x = act_apply(v.x, act); v.y = act_apply(v.y, act); v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
+    *reinterpret_cast<float4*>(y + e4) = v;
+  } else {
+    for (long long e = e4; e < count; ++e) y[e] = act_apply(z[e], act);
+  }
+}
+int launch_act_apply(const float* z, float* y, long long count, int act, hipStream_t st) {
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(act_apply_kernel, dim3((unsigned)((count + 1023) / 1024)), dim3(256), 0, st, z, y, count, act);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace xt
+
 extern "C" {
 
 int xt_heads_fwd(const float* f_pi, const float* f_v, int32_t B, int32_t F, int32_t A, const float* wpi,

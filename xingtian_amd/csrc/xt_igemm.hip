@@ -1644,9 +1644,12 @@ int launch_dgrad(const xt_conv_geom* cg, int B, const float* dy, const float* w,
 }
 
 // wgrad (fp32 input) + dgrad (+ head wgrad) of one non-first layer in ONE launch.
+// x_grad (may be null = x_in): what the input gradient's activation-derivative epilogue reads -- the producer's
+// PRE-activation when its activation is not monotonic (act_needs_preact), else its output x_in
 int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const float* dy, const float* w,
                      int act_prev, float* dx, float* dwb, float* slabs, int msplit, const HeadWgArgs* hw,
-                     int* msplit_out, hipStream_t st, const uint32_t* xmask, int slab_cap) {
+                     int* msplit_out, hipStream_t st, const uint32_t* xmask, int slab_cap, const float* x_grad) {
+  if (!x_grad) x_grad = x_in;
   BwdLayerArgs a;
   if (int rc = make_geom(cg, nullptr, B, &a.wg.g)) return rc;
   a.dg.g = a.wg.g;
@@ -1666,7 +1669,7 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
   a.wg_gz = msplit;
   a.n_wg = a.wg_gx * a.wg_gy * a.wg_gz;
   // ---- dgrad part
-  a.dg.dy = dy; a.dg.w = w; a.dg.x = x_in; a.dg.dx = dx; a.dg.act_prev = act_prev; a.dg.xmask = nullptr;
+  a.dg.dy = dy; a.dg.w = w; a.dg.x = x_grad; a.dg.dx = dx; a.dg.act_prev = act_prev; a.dg.xmask = nullptr;
   if (int rc = fill_class_divs(g, &a.dg)) return rc;
   const int hc = (g.H + g.S - 1) / g.S, wc = (g.W + g.S - 1) / g.S;
   const int mc = B * hc * wc;
@@ -1689,7 +1692,7 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
   if (a.dg_direct == 0) {
     int nblk = 0;
     if (plan_dgrad_direct_fused(g, &a.ddg, &nblk)) {
-      a.ddg.dy = dy; a.ddg.w = w; a.ddg.x = x_in; a.ddg.dx = dx; a.ddg.act_prev = act_prev;
+      a.ddg.dy = dy; a.ddg.w = w; a.ddg.x = x_grad; a.ddg.dx = dx; a.ddg.act_prev = act_prev;
       a.dg_direct = 1;
       a.n_dg = nblk;
       const int ti2 = tuning().dgrad_tile64;   // 0: 32-row tiles (A/B; measured 30.4 vs 27.7 us for conv3 at B=320)
@@ -1732,7 +1735,7 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
   const bool s2c16 = tuning().bf16x6 && a.dg_direct == 0 && g.S == 2 && g.KH == 4 && g.KW == 4 && g.C == 16 && g.N == 32 &&
                      wsmall && (size_t)3 * (g.OHOW + 1) * 80 <= 8 * 1024 * 4;
   if (s2c16) {
-    a.ddg.g = g; a.ddg.dy = dy; a.ddg.w = w; a.ddg.x = x_in; a.ddg.dx = dx; a.ddg.act_prev = act_prev;
+    a.ddg.g = g; a.ddg.dy = dy; a.ddg.w = w; a.ddg.x = x_grad; a.ddg.dx = dx; a.ddg.act_prev = act_prev;
     a.ddg.mt = 0; a.ddg.ct = 0;
     a.dg_direct = 5;
     a.n_dg = B;

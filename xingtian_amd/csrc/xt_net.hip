@@ -36,7 +36,9 @@ int launch_fwd(const xt_conv_geom*, const xt_input_xform*, int, const void*, con
                const float*, float*, float*, int, hipStream_t, int* deferred_ksplit = nullptr,
                uint32_t* relu_mask = nullptr, int* mask_written = nullptr);
 int launch_bwd_layer(const xt_conv_geom*, int, const float*, const float*, const float*, int, float*, float*, float*,
-                     int, const HeadWgArgs*, int*, hipStream_t, const uint32_t* xmask = nullptr, int slab_cap = 0);
+                     int, const HeadWgArgs*, int*, hipStream_t, const uint32_t* xmask = nullptr, int slab_cap = 0,
+                     const float* x_grad = nullptr);
+int launch_act_apply(const float* z, float* y, long long count, int act, hipStream_t st);
 int launch_wgrad(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*, const float*,
                  float*, float*, int, hipStream_t, int reduce_now = 1, int* msplit_out = nullptr, int slab_cap = 0);
 int launch_dgrad(const xt_conv_geom*, int, const float*, const float*, const float*, int, float*, hipStream_t);
@@ -72,6 +74,7 @@ struct Layer {
   int slab_cap;                // number of slabs the region can hold
   int64_t mask_off;            // relu sign mask of this layer's output (one word per position), else -1
   int mask_valid;              // the last forward of this layer wrote the mask
+  int64_t z_off;               // pre-activation of this layer (swish / gelu: act_needs_preact), else -1
 };
 
 static inline int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
@@ -148,9 +151,22 @@ static int net_forward(xt_net* n, const void* obs, const int32_t* idx, int B, bo
     for (int l = l0; l < n->t_end[tr]; ++l) {
       Layer& L = n->layers[l];
       const bool first = (l == n->t_begin[tr]);
-      const bool defer = defer_last && (l == n->t_end[tr] - 1) && L.part_off >= 0;
+      const bool defer = defer_last && (l == n->t_end[tr] - 1) && L.part_off >= 0 && L.z_off < 0;
       L.last_ksplit = 1;
       L.mask_valid = 0;
+      if (L.z_off >= 0) {
+        // swish / gelu: the layer writes its PRE-activation (the backward pass needs it), then one elementwise launch
+        // produces the output the next layer reads -- a slow path, taken by no bundled configuration
+        xt_conv_geom gz = L.g;
+        gz.act = XT_ACT_NONE;
+        if (int rc = launch_fwd(&gz, first ? &n->xf : nullptr, B, x, first ? idx : nullptr, n->params + L.poff,
+                                n->params + L.poff + (int64_t)L.K * L.g.N, n->ws + L.z_off, n->ws + n->off_partial,
+                                fwd_split(L, B), st, nullptr, nullptr, nullptr))
+          return rc;
+        if (int rc = launch_act_apply(n->ws + L.z_off, n->ws + L.act_off, (long long)B * L.OHOW * L.g.N, L.g.act, st)) return rc;
+        x = n->ws + L.act_off;
+        continue;
+      }
       if (int rc = launch_fwd(&L.g, first ? &n->xf : nullptr, B, x, first ? idx : nullptr, n->params + L.poff,
                               n->params + L.poff + (int64_t)L.K * L.g.N, n->ws + L.act_off,
                               n->ws + (defer ? L.part_off : n->off_partial), fwd_split(L, B), st,
@@ -223,7 +239,7 @@ static int trunk_backward(xt_net* n, const void* obs, const int32_t* idx, int B,
                                     Lprev.g.act, n->ws + Lprev.dact_off, n->grads + L.poff, n->ws + L.slab_off,
                                     wgrad_split(L, B), hwp, &L.last_msplit, st,
                                     Lprev.mask_valid ? reinterpret_cast<const uint32_t*>(n->ws + Lprev.mask_off) : nullptr,
-                                    L.slab_cap))
+                                    L.slab_cap, Lprev.z_off >= 0 ? n->ws + Lprev.z_off : nullptr))
         return rc;
       if (!first_done && after_first) { if (int rc = after_first->fn(after_first->arg)) return rc; }
       first_done = true;
@@ -293,7 +309,9 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
   XT_REQUIRE(B > 0 && B <= n->maxB, "xt_net_ppo_step: batch %d outside (0,%d]", B, n->maxB);
   const bool gauss = (n->action_type == XT_ACTION_DIAG_GAUSSIAN);
   const int32_t* action = static_cast<const int32_t*>(action_v);
-  bool fused_head = (!gauss && n->A <= 8 && n->feat <= 512);
+  Layer& Lp0 = n->layers[n->t_end[0] - 1];
+  Layer& Lv0 = n->layers[n->t_end[n->n_trunks - 1] - 1];
+  bool fused_head = (!gauss && n->A <= 8 && n->feat <= 512 && Lp0.z_off < 0 && Lv0.z_off < 0);
   const int no_defer = tuning().defer_splitk ? 0 : 1;
   if (int rc = net_forward(n, obs, idx, B, false, st, fused_head && !no_defer)) return rc;
   const float inv_b = 1.f / (float)(c->global_batch > 0 ? c->global_batch : B);
@@ -343,7 +361,9 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
                                     old_v, target_v, c->clip_ratio, c->ent_coef, c->vf_clip, c->critic_coef, inv_b,
                                     n->ws + n->off_dlogits, n->ws + n->off_dvalue, n->ws + n->off_terms, st))
       return rc;
-    if (int rc = launch_heads_dfeat(n->ws + Lp.act_off, n->ws + Lv.act_off, B, F, A, n->params + n->pi_off,
+    // (launch_heads_dfeat reads the features only for the activation derivative: the pre-activation where one is kept)
+    if (int rc = launch_heads_dfeat(n->ws + (Lp.z_off >= 0 ? Lp.z_off : Lp.act_off), n->ws + (Lv.z_off >= 0 ? Lv.z_off : Lv.act_off),
+                                    B, F, A, n->params + n->pi_off,
                                     n->params + n->v_off, n->ws + n->off_dlogits, n->ws + n->off_dvalue, Lp.g.act,
                                     n->ws + Lp.dact_off, n->ws + Lv.dact_off, st))
       return rc;
@@ -432,7 +452,7 @@ static int impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int n
   float* lo = n->ws + n->off_loss;   // [0] = loss, [4 .. 4 + n_traj) per-trajectory sums
   // fused form (ImpalaCnnOpt: one trunk, A <= 8, T <= 256): split-K finish + heads in one launch, v-trace + loss +
   // d(heads) + d(features) in the next, loss scalar in the gradient-reduction launch
-  const bool fused = (n->n_trunks == 1 && A <= 8 && F <= 512 && T <= 256);
+  const bool fused = (n->n_trunks == 1 && A <= 8 && F <= 512 && T <= 256 && Lp.z_off < 0);
   bool loss_pending = false;
   if (fused) {
     if (int rc = net_forward(n, obs, nullptr, nfr, false, st, true)) return rc;
@@ -465,7 +485,7 @@ static int impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int n
                                 nullptr, st))
       return rc;
     if (loss_out) XT_CHECK_HIP(hipMemcpyAsync(loss_out, lo, sizeof(float), hipMemcpyDeviceToDevice, st));
-    if (int rc = launch_heads_dfeat(n->ws + Lp.act_off, n->ws + Lv.act_off, nfr, F, A, n->params + n->pi_off,
+    if (int rc = launch_heads_dfeat(n->ws + (Lp.z_off >= 0 ? Lp.z_off : Lp.act_off), n->ws + (Lv.z_off >= 0 ? Lv.z_off : Lv.act_off), nfr, F, A, n->params + n->pi_off,
                                     n->params + n->v_off, n->ws + n->off_dlogits, n->ws + n->off_dvalue, Lp.g.act,
                                     n->ws + Lp.dact_off, n->ws + Lv.dact_off, st))
       return rc;
@@ -553,6 +573,8 @@ int xt_net_create(const xt_net_desc* d, int32_t max_batch, xt_net** out) {
     const int64_t asz = xt::align4((int64_t)max_batch * L.OHOW * L.g.N);
     L.act_off = off; off += asz;
     L.dact_off = off; off += asz;
+    L.z_off = -1;
+    if (xt::act_needs_preact(L.g.act)) { L.z_off = off; off += asz; }
     n->layers.push_back(L);
     // wgrad slab bound: msplit <= max(1, 512/tiles) slabs of (K+1)*N floats
     const int tiles = (L.g.N <= 32) ? ((L.K + 127) / 128) : ((L.K + 63) / 64) * ((L.g.N + 63) / 64);
@@ -789,7 +811,7 @@ int xt_net_keras_impala_step(xt_net* n, const void* obs, const int32_t* idx, int
   if (loss_out) XT_CHECK_HIP(hipMemcpyAsync(loss_out, lo, 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
   xt::Layer& Lp = n->layers[n->t_end[0] - 1];
   xt::Layer& Lv = n->layers[n->t_end[n->n_trunks - 1] - 1];
-  if (int rc = xt::launch_heads_dfeat(n->ws + Lp.act_off, n->ws + Lv.act_off, B, n->feat, n->A, n->params + n->pi_off,
+  if (int rc = xt::launch_heads_dfeat(n->ws + (Lp.z_off >= 0 ? Lp.z_off : Lp.act_off), n->ws + (Lv.z_off >= 0 ? Lv.z_off : Lv.act_off), B, n->feat, n->A, n->params + n->pi_off,
                                       n->params + n->v_off, n->ws + n->off_dlogits, n->ws + n->off_dvalue, Lp.g.act,
                                       n->ws + Lp.dact_off, n->ws + Lv.dact_off, st))
     return rc;

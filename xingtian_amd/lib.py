@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxt_mi355x.so")
 
 ACT = {"none": 0, None: 0, "relu": 1, "tanh": 2, "sigmoid": 3, "softsign": 4, "softplus": 5, "leaky_relu": 6, "elu": 7,
-       "selu": 8}
+       "selu": 8, "swish": 9, "gelu": 10}
 
 
 class ConvGeom(Structure):

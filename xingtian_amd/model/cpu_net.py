@@ -59,6 +59,10 @@ def _act(z, act):
         return np.where(z > 0, z, np.expm1(np.minimum(z, 0)))
     if act == "selu":
         return (1.0507009873554805 * np.where(z > 0, z, 1.6732632423543772 * np.expm1(np.minimum(z, 0)))).astype(z.dtype)
+    if act == "swish":
+        return (z / (1.0 + np.exp(-z))).astype(z.dtype)
+    if act == "gelu":                    # xt/model/tf_utils.py:157-166
+        return (0.5 * z * (1.0 + np.tanh(np.sqrt(2.0 / np.pi) * (z + 0.044715 * z ** 3)))).astype(z.dtype)
     if act in (None, "none"):
         return z
     raise KeyError("activation {} not implemented.".format(act))

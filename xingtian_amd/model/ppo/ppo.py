@@ -62,10 +62,10 @@ class PPO(XTModel):
         super().__init__(model_info)
 
     # ---- trunk options shared by the CNN / MLP variants -------------------------------------------------------
-    # what the HIP epilogues implement: every MONOTONIC entry of the reference's ACTIVATION_MAP
-    # (xt/model/model_utils.py:8-20).  swish / gelu are refused: their derivative cannot be taken from the stored
-    # post-activation, and no bundled configuration uses them.
-    TRUNK_ACTIVATIONS = ("relu", "tanh", "sigmoid", "softsign", "softplus", "leaky_relu", "elu", "selu")
+    # the reference's ACTIVATION_MAP (xt/model/model_utils.py:8-20), all ten entries.  The eight monotonic ones are
+    # fused into the layer kernels (derivative from the stored output); swish and gelu keep the pre-activation of their
+    # layers as well (one extra buffer + one elementwise launch per layer: a slow path no bundled configuration takes)
+    TRUNK_ACTIVATIONS = ("relu", "tanh", "sigmoid", "softsign", "softplus", "leaky_relu", "elu", "selu", "swish", "gelu")
 
     def _read_trunk_options(self, model_config, share_default, hidden_default, act_default):
         """VF_SHARE_LAYERS / hidden_sizes / activation with the reference's per-variant defaults
