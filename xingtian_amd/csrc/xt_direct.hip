@@ -281,6 +281,7 @@ int launch_dgrad_direct(const xt_conv_geom* cg, int B, const float* dy, const fl
                         float* dx, hipStream_t st) {
   if (!use_direct()) return -1;
   DDgradArgs a;
+  a.deep = 0;
   if (make_geom(cg, nullptr, B, &a.g)) return -1;
   const Geom& g = a.g;
   if (g.N % 32 != 0 || g.C % 32 != 0) return -1;

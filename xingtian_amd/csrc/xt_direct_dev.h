@@ -71,6 +71,7 @@ struct DDgradArgs {
   float* dx;
   int act_prev;
   int mt, ct;         // pixel tiles per stride-parity class (upper bound), channel tiles
+  int deep;           // halo form: every weight stage of a wave's slice in flight (tuning.bwd_deep_prefetch)
 };
 
 // bid / nblocks: this block's index among the launch's input-gradient blocks (the fused per-layer backward
@@ -368,6 +369,17 @@ __device__ __forceinline__ void halo_dgrad_body(const DDgradArgs& p, uint32_t bi
     // is at most ceil(KH*KW*N/32 / 4) steps, so most of its weight loads are issued before the first MFMA
     StageB B2;
     loadB(B2, s0 + 2, s0 + 2 < s1);
+    if (per <= 5 && p.deep) {
+      // (round 3) a wave's slice is at most five steps: ALL of its weight loads in flight before the first MFMA, straight-line
+      StageB B3, B4;
+      loadB(B3, s0 + 3, s0 + 3 < s1);
+      loadB(B4, s0 + 4, s0 + 4 < s1);
+      step_split(B0, s0, s0 < s1);
+      step_split(B1, s0 + 1, s0 + 1 < s1);
+      step_split(B2, s0 + 2, s0 + 2 < s1);
+      step_split(B3, s0 + 3, s0 + 3 < s1);
+      step_split(B4, s0 + 4, s0 + 4 < s1);
+    } else
     for (int s = s0; s < s1; s += 3) {
       step_split(B0, s, true);
       loadB(B0, s + 3, s + 3 < s1);

@@ -1691,7 +1691,9 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
   }
   if (a.dg_direct == 0) {
     int nblk = 0;
+    a.ddg.deep = 0;
     if (plan_dgrad_direct_fused(g, &a.ddg, &nblk)) {
+      a.ddg.deep = tuning().bwd_deep_prefetch != 0 ? 1 : 0;
       a.ddg.dy = dy; a.ddg.w = w; a.ddg.x = x_grad; a.ddg.dx = dx; a.ddg.act_prev = act_prev;
       a.dg_direct = 1;
       a.n_dg = nblk;
@@ -1736,7 +1738,7 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
                      wsmall && (size_t)3 * (g.OHOW + 1) * 80 <= 8 * 1024 * 4;
   if (s2c16) {
     a.ddg.g = g; a.ddg.dy = dy; a.ddg.w = w; a.ddg.x = x_grad; a.ddg.dx = dx; a.ddg.act_prev = act_prev;
-    a.ddg.mt = 0; a.ddg.ct = 0;
+    a.ddg.mt = 0; a.ddg.ct = 0; a.ddg.deep = 0;
     a.dg_direct = 5;
     a.n_dg = B;
   }
