@@ -96,6 +96,8 @@ typedef struct xt_tuning {
   int32_t bwd_deep_prefetch;  /* 1: fused backward of Dense (1x1, stride 1) layers as a two-workgroups-per-CU instance:
                                  all (<= 8) reduction steps of the input gradient in flight, four register stages in
                                  the weight gradient, split cut to 512 co-resident workgroups (ABI >= 8)           */
+  int32_t fwd_four_groups;    /* 1: bf16x6 forwards with <= one block per CU and >= 4 steps per group run FOUR 4-wave groups
+                                 (a quarter of the reduction range each, one LDS stage) instead of two (ABI >= 8)  */
   int32_t fwd_xcd_chunk;      /* 1: LDS-tiled forwards with several N tiles / k splits give every XCD a contiguous
                                  run of the (m tile, n tile, k slice) order: tiles that share operand slices share
                                  an L2 (ABI >= 8)                                                                  */

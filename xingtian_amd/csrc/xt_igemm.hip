@@ -181,10 +181,14 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
   static_assert(!X6 || !U8, "igemm_fwd: the bf16x6 form is for fp32 inputs");
   constexpr int kX6SlotA = X6Lay<BI, BJ>::SlotA, kX6RowB = X6Lay<BI, BJ>::RowB, kX6PlaneB = X6Lay<BI, BJ>::PlaneB;
   constexpr int BUF = X6 ? X6Lay<BI, BJ>::Stage / 4 : 32 * SA + 32 * SB; // one LDS stage (A then B); two stages, one barrier per step
-  __shared__ __attribute__((aligned(16))) float smem_all[2 * BUF * KG];
+  // KG = 4 (round 3): four 4-wave groups, each a quarter of the reduction range with ONE LDS stage (two barriers per
+  // step): a step costs ~1 us whatever it contains (ablations), so the lever is the number of steps a block
+  // walks in sequence -- 16 waves per CU also give the phases of different groups something to overlap with.
+  constexpr int NSTG = (KG == 4) ? 1 : 2;
+  __shared__ __attribute__((aligned(16))) float smem_all[NSTG * BUF * KG];
   const Geom& g = p.g;
   const int grp = (KG == 1) ? 0 : (int)(threadIdx.x >> 8);
-  float* smem = smem_all + grp * 2 * BUF;
+  float* smem = smem_all + grp * NSTG * BUF;
   const int t = threadIdx.x & 255, lane = t & 63, wave = t >> 6;
   // Blocks are dispatched round robin over the 8 XCDs in linear order (x fastest).  With more than one N tile or k
   // split, neighbours in that order share operand slices (the M tiles of one (n tile, k slice) stream the same weight
@@ -327,6 +331,26 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
       if (d == 0) XT_TL(2);
       mma(stage);
     }
+  } else if constexpr (KG == 4) {
+    Regs R0, R1;
+    if (nsteps > 0) fetch(kbeg, R0);
+    if (nsteps > 1) fetch(kbeg + 32, R1);
+    XT_TL(1);
+    for (int s = 0; s < nsteps_all; s += 2) {
+      if (s < nsteps) stash(R0, smem, smem + 32 * SA);
+      __syncthreads();
+      if (s == 0) XT_TL(2);
+      if (s + 2 < nsteps) fetch(kbeg + (s + 2) * 32, R0);
+      if (s < nsteps) mma(smem);
+      __syncthreads();
+      if (s + 1 < nsteps_all) {
+        if (s + 1 < nsteps) stash(R1, smem, smem + 32 * SA);
+        __syncthreads();
+        if (s + 3 < nsteps) fetch(kbeg + (s + 3) * 32, R1);
+        if (s + 1 < nsteps) mma(smem);
+        __syncthreads();
+      }
+    }
   } else {
   Regs R0, R1;
   if (nsteps > 0) fetch(kbeg, R0);
@@ -346,15 +370,15 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
     }
   }
   }
-  if constexpr (KG == 2) {
-    // combine the two groups' accumulators AND transpose: both groups park their tiles in LDS (every stage buffer
+  if constexpr (KG >= 2) {
+    // combine the groups' accumulators AND transpose: both groups park their tiles in LDS (every stage buffer
     // is idle after the barrier) as [group][row][BJ + 4]; then all 512 threads sum the two copies and store 16
     // bytes each (a row of the tile is contiguous in y).  The dword form (lanes = columns, two 128-byte rows per
     // instruction, group 1 idle) spent 2.5 us of a 10.6 us block in the store issue.
     __syncthreads();
     XT_TL(3);
     constexpr int RS = BJ + 4;
-    static_assert(2 * BI * RS <= 2 * BUF * KG, "igemm_fwd: combine buffer does not fit the stage buffers");
+    static_assert(KG * BI * RS <= NSTG * BUF * KG, "igemm_fwd: combine buffer does not fit the stage buffers");
     float* red = smem_all;
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti)
@@ -370,9 +394,13 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
     float* outp = fin ? p.y : p.y + (size_t)bzi * (size_t)g.M * g.N;
     for (int e = (int)threadIdx.x; e < BI * BJ / 4; e += 256 * KG) {
       const int row = e / (BJ / 4), c4 = (e - row * (BJ / 4)) * 4;
-      const float4 a = *reinterpret_cast<const float4*>(&red[row * RS + c4]);
-      const float4 b = *reinterpret_cast<const float4*>(&red[(BI + row) * RS + c4]);
-      float v[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+      float4 a = *reinterpret_cast<const float4*>(&red[row * RS + c4]);
+#pragma unroll
+      for (int q = 1; q < KG; ++q) {            // groups in order: a fixed summation order
+        const float4 b = *reinterpret_cast<const float4*>(&red[(q * BI + row) * RS + c4]);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      float v[4] = {a.x, a.y, a.z, a.w};
       const int m = i0 + row, n = j0 + c4;
       if (m >= g.M) continue;
       if (fin) {
@@ -1552,6 +1580,9 @@ int launch_fwd(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const vo
   else if (all && N <= 32 && nst2 <= 8) XT_FWD6N(128, 32, 4, 1, 8);
   else
 #undef XT_FWD6N
+  if (x6 && kg2 && tuning().fwd_four_groups && nblk <= 256 && chunk >= 16 * 32) {      // <= one block per CU, >= 4 steps per group (shorter chains: no gain)
+    if (N > 32) XT_FWD6(64, 64, 2, 2, 4); else XT_FWD6(128, 32, 4, 1, 4);
+  } else
   if (x6 && N > 32) { if (kg2) XT_FWD6(64, 64, 2, 2, 2); else XT_FWD6(64, 64, 2, 2, 1); }
   else if (x6) { if (kg2) XT_FWD6(128, 32, 4, 1, 2); else XT_FWD6(128, 32, 4, 1, 1); }
   else if (N <= 32) XT_FWD(128, 32, 4, 1); else XT_FWD(64, 64, 2, 2);
