@@ -676,8 +676,14 @@ def main():
     def get_rccl():
         """one raw RCCL communicator for all hook variants (created on first use; its lazy set-up runs outside any
         stream capture)"""
+        if comm.get("error"):
+            raise RuntimeError(comm["error"])          # the communicator could not be formed: do not retry per variant
         if comm["rccl"] is None:
-            r = RcclComm(rank, world)
+            try:
+                r = RcclComm(rank, world)
+            except Exception as exc:                   # noqa: BLE001
+                comm["error"] = "raw RCCL communicator unavailable: {!r}".format(exc)
+                raise
             warm = torch.zeros(1024, dtype=torch.float32, device=dev)
             r.all_reduce_(warm, L.stream_ptr())
             torch.cuda.synchronize()
