@@ -270,7 +270,7 @@ PEAK = {"fp32": FP32_MFMA_PEAK_TFLOPS, "bf16x3": BF16_MFMA_PEAK_TFLOPS / 3.0, "b
 # rocprofv3 --pmc summaries (profiles/r02_pmc_<workload>.json, tools/profile_round.sh)
 KERNEL_OF = {
     "ppo": {"L0 shared_conv_layer_0 fwd": "conv_u8c4k8_fwd_flat_kernel", "L0 shared_conv_layer_0 wgrad": "conv_u8c4k8_wgrad_flat_kernel",
-            "L1 shared_conv_layer_1 fwd": "igemm_fwd_kernel<128, 32, 4, 1, false, false, 2",
+            "L1 shared_conv_layer_1 fwd": "igemm_fwd_kernel<128, 32, 4, 1, false, false, ",
             "L1 shared_conv_layer_1 dgrad+wgrad": "igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, 2, 0",
             "L2 shared_conv_layer_2 fwd": "igemm_fwd_kernel<64, 64, 2, 2, false, false, 2",
             "L2 shared_conv_layer_2 dgrad+wgrad": "igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1, 0, 2",
