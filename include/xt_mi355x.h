@@ -98,6 +98,8 @@ typedef struct xt_tuning {
                                  the weight gradient, split cut to 512 co-resident workgroups (ABI >= 8)           */
   int32_t fwd_four_groups;    /* 1: bf16x6 forwards with <= one block per CU and >= 4 steps per group run FOUR 4-wave groups
                                  (a quarter of the reduction range each, one LDS stage) instead of two (ABI >= 8)  */
+  int32_t reduce_deep_lanes;  /* gradient reduction: entries with at least this many slabs get up to 32 slab lanes per block
+                                 (0 = off; default 128: the first layer's one-slab-per-workgroup gradients)         */
   int32_t fwd_xcd_chunk;      /* 1: LDS-tiled forwards with several N tiles / k splits give every XCD a contiguous
                                  run of the (m tile, n tile, k slice) order: tiles that share operand slices share
                                  an L2 (ABI >= 8)                                                                  */

@@ -28,7 +28,7 @@ xt_tuning& tuning() {
                         /*fwd_two_groups*/ 1, /*direct*/ 1, /*direct_fwd*/ 1, /*direct_dgrad*/ 1, /*direct_all*/ 0,
                         /*direct_waves*/ 1536, /*direct_max_waves*/ 8, /*direct_tile64_tiles*/ 3072,
                         /*fwd_split_target*/ 256, /*wgrad_split_target*/ 512, /*reduce_z_lanes*/ 8,
-                        /*defer_splitk*/ 1, /*finalize_ticket*/ 0, /*fwd_tiled_valid*/ 1, /*wgrad_rows*/ 4, /*fwd_prefetch_all*/ 0, /*bwd_deep_prefetch*/ 1, /*fwd_four_groups*/ 1, /*fwd_xcd_chunk*/ 1};
+                        /*defer_splitk*/ 1, /*finalize_ticket*/ 0, /*fwd_tiled_valid*/ 1, /*wgrad_rows*/ 4, /*fwd_prefetch_all*/ 0, /*bwd_deep_prefetch*/ 1, /*fwd_four_groups*/ 1, /*reduce_deep_lanes*/ 128, /*fwd_xcd_chunk*/ 1};
   return t;
 }
 

@@ -411,7 +411,9 @@ int launch_grads_finish(GradTable* tab, float* partial, int max_partials, int* n
   for (int i = 0; i < tab->n; ++i) {
     GradEntry& E = tab->e[i];
     int zl = 1;
-    const int zcap = tuning().reduce_z_lanes;
+    // deep entries (the first layer's one-slab-per-workgroup gradients: 250 slabs) get up to 32 z lanes: their blocks
+    // were the stragglers of the launch (31 dependent slab loads per lane, 64 blocks) while ~800 shallow blocks had finished
+    const int zcap = (tuning().reduce_deep_lanes > 0 && E.nslab >= tuning().reduce_deep_lanes) ? 32 : tuning().reduce_z_lanes;
     while (zl < E.nslab && zl < zcap) zl <<= 1;   // fewer z lanes = longer contiguous runs per wave (512 B at 8)
     E.zl = zl;
     const int cols = 256 / zl;
