@@ -447,7 +447,10 @@ __device__ __forceinline__ void s2c16_dgrad_body(const DDgradArgs& p, uint32_t b
   const int c = lane & 15, g4 = lane >> 4;               // operand role: column (channel) / row c, k group g4
   XT_TL(0);
   XT_TL_ROLE(80);
-  const int b = (int)bid;
+  // p.ct (> 1): that many workgroups share a sample, each taking every p.ct-th 16-position tile of every class -- small
+  // batches (128 frames = 128 workgroups) left half of the CUs without an input-gradient block
+  const int nsplit = p.ct > 1 ? p.ct : 1;
+  const int b = (int)bid / nsplit, part = (int)bid - b * nsplit;
   constexpr int RB = 32 * 2 + 16;                         // bytes per plane row (N = 32 bf16 + pad)
   const int nrows = g.OHOW;
   const int PS = (nrows + 1) * RB;
@@ -494,7 +497,27 @@ __device__ __forceinline__ void s2c16_dgrad_body(const DDgradArgs& p, uint32_t b
   __syncthreads();
   XT_TL(1);
   const size_t xbase = (size_t)b * g.H * g.W * C;
-  for (int sub = 0; sub < Mc; sub += 16) {
+  // The producer activations of a tile's outputs (for act') are requested ONE TILE AHEAD (clamped, unconditional): read
+  // inside the epilogue they exposed a global round trip per 16-position tile -- 10 of the 12 us a sample's workgroup
+  // lived at 128 frames (timeline) -- with only ~24 MFMAs to hide behind.
+  auto tile_pix = [&](int sub) {
+    const int pos = min(sub + c, Mc - 1);
+    const int ty = pos / WC, tx = pos - ty * WC;
+    return (cy0 + 2 * ty) * g.W + cx0 + 2 * tx;
+  };
+  auto load_x = [&](int sub, float (&xv)[NC][4]) {
+    const int pixn = tile_pix(sub < Mc ? sub : 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rpix = __shfl(pixn, 4 * g4 + i, 64);
+#pragma unroll
+      for (int ct = 0; ct < NC; ++ct) xv[ct][i] = p.x[xbase + (size_t)rpix * C + 16 * ct + c];
+    }
+  };
+  float xcur[NC][4], xnext[NC][4];
+  load_x(16 * part, xcur);
+  for (int sub = 16 * part; sub < Mc; sub += 16 * nsplit) {
+    load_x(sub + 16 * nsplit, xnext);
     const int pos = min(sub + c, Mc - 1);                 // A-operand row of this lane: class position sub + c
     const int ty = pos / WC, tx = pos - ty * WC;
     const int pix = (cy0 + 2 * ty) * g.W + cx0 + 2 * tx;  // input pixel of that row
@@ -521,10 +544,14 @@ __device__ __forceinline__ void s2c16_dgrad_body(const DDgradArgs& p, uint32_t b
 #pragma unroll
         for (int ct = 0; ct < NC; ++ct) {
           const size_t off = xbase + (size_t)rpix * C + 16 * ct + c;
-          p.dx[off] = acc[ct][i] * act_grad(p.x[off], p.act_prev);
+          p.dx[off] = acc[ct][i] * act_grad(xcur[ct][i], p.act_prev);
         }
       }
     }
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xcur[ct][i] = xnext[ct][i];
   }
   XT_TL(4);
   XT_TL_DRAIN(5);
@@ -635,7 +662,17 @@ __device__ __forceinline__ void s2c16_bwd_body(const DDgradArgs& p, float* slabs
     __syncthreads();
     // ---- input gradient of this wave's parity class (s2c16_dgrad_body)
     const size_t xbase = (size_t)b * HW * 16;
+    auto load_x = [&](int sub, float (&xv)[4]) {          // producer activations of tile `sub`, requested a tile ahead
+      const int posn = min((sub < Mc ? sub : 0) + c, Mc - 1);
+      const int tyn = posn / WC, txn = posn - tyn * WC;
+      const int pixn = (cy0 + 2 * tyn) * g.W + cx0 + 2 * txn;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xv[i] = p.x[xbase + (size_t)__shfl(pixn, 4 * g4 + i, 64) * 16 + c];
+    };
+    float xcur[4], xnext[4];
+    load_x(0, xcur);
     for (int sub = 0; sub < Mc; sub += 16) {
+      load_x(sub + 16, xnext);
       const int pos = min(sub + c, Mc - 1);
       const int ty = pos / WC, tx = pos - ty * WC;
       const int pix = (cy0 + 2 * ty) * g.W + cx0 + 2 * tx;
@@ -656,9 +693,11 @@ __device__ __forceinline__ void s2c16_bwd_body(const DDgradArgs& p, float* slabs
         const int rpix = __shfl(pix, row, 64);
         if (sub + row < Mc) {
           const size_t off = xbase + (size_t)rpix * 16 + c;
-          p.dx[off] = acc[i] * act_grad(p.x[off], p.act_prev);
+          p.dx[off] = acc[i] * act_grad(xcur[i], p.act_prev);
         }
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xcur[i] = xnext[i];
     }
     // ---- weight gradient: kernel row ky = w
     for (int s0 = 0; s0 < nrows; s0 += 32) {

@@ -1772,6 +1772,7 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
     a.ddg.mt = 0; a.ddg.ct = 0; a.ddg.deep = 0;
     a.dg_direct = 5;
     a.n_dg = B;
+    if (tuning().bwd_deep_prefetch && 2 * B <= 256) { a.ddg.ct = 2; a.n_dg = 2 * B; }     // two workgroups per sample (four: no further gain)
   }
   // ... and, for large batches, the weight gradient in the same workgroups: 512 of them (two per CU), one slab each
   const bool s2fused = s2c16 && B >= 512 && slabs != nullptr && slab_cap >= 512 &&
