@@ -103,6 +103,11 @@ typedef struct xt_tuning {
   int32_t fwd_xcd_chunk;      /* 1: LDS-tiled forwards with several N tiles / k splits give every XCD a contiguous
                                  run of the (m tile, n tile, k slice) order: tiles that share operand slices share
                                  an L2 (ABI >= 8)                                                                  */
+  int32_t tail_overlap;       /* single-GPU update tail as graph branches (one-trunk nets with >= 2 layers; bit mask, ABI >= 8):
+                                 1: the slab reduction of the last trunk layer + heads (95 % of PpoCnn's gradient bytes) runs on a
+                                    side stream right after the first backward launch, under the conv backward;
+                                 2: Adam is split into [first layer] on the compute stream and [everything else] on the side
+                                    stream, which the NEXT step's first-layer forward overlaps (joined before layer 2)       */
 } xt_tuning;
 int xt_tuning_get(xt_tuning* out);
 int xt_tuning_set(const xt_tuning* in);

@@ -1272,3 +1272,72 @@ def test_pinned_ring_defers_slot_release_until_the_dma_has_landed():
     wa, wb = alg.get_weights(), ref.get_weights()
     for k in wa:
         assert np.array_equal(wa[k], wb[k]), k
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_update_tail_on_graph_branches_is_bitwise_the_single_stream_tail(mode):
+    """xt_tuning.tail_overlap: the first gradient bucket's slab reduction on a side stream under the conv backward (1),
+    Adam split into [first layer] + [rest on the side stream, joined before the next step's second layer] (2): same
+    partial slots, same clip factor, element-wise update -> bit-identical parameters, optimiser state and losses, in
+    the eager enqueue and in the captured graph, for PPO (incl. a short last minibatch) and the IMPALA entry."""
+    from xingtian_amd import lib as L
+    from xingtian_amd.model import netspec
+    from xingtian_amd.model.hip_net import HipActorCritic
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    rng = np.random.default_rng(5)
+    spec = netspec.ppo_cnn((42, 42, 4), 4, (64,), "relu", True)
+    cfg = dict(PPO_CFG, BATCH_SIZE=40, NUM_SGD_ITER=2)
+    n = 100
+    obs, lab = synth_ppo_rollout(rng, n, (42, 42, 4), 4)
+    perms = np.stack([rng.permutation(n) for _ in range(2)]).astype(np.int32)
+
+    def ppo(knob, use_graph):
+        old = L.set_tuning(tail_overlap=knob)
+        try:
+            net = HipActorCritic(spec, max_batch=40, seed=0)
+            bufs = [net.to_device_obs(obs), d(perms), d(lab[0]), d(lab[1].reshape(-1)), d(lab[2].reshape(-1)),
+                    d(lab[3].reshape(-1)), d(lab[4].reshape(-1))]
+            out = []
+            for _ in range(2):          # second call: replay of the cached graph, from the updated state
+                acc = net.ppo_train(net.make_ppo_cfg(cfg), *bufs, use_graph=use_graph)
+                torch.cuda.synchronize()
+                out.append(acc.cpu().numpy().copy())
+            logits, value = net.forward(bufs[0][:8])      # a reader of ALL parameters right behind the update
+            return (out, net.params.cpu().numpy().copy(), net.adam_state.cpu().numpy().copy(),
+                    logits.cpu().numpy().copy(), value.cpu().numpy().copy())
+        finally:
+            L.set_tuning(**old)
+
+    ref = ppo(0, True)
+    for use_graph in (False, True):
+        got = ppo(mode, use_graph)
+        assert all(np.array_equal(a, b) for a, b in zip(ref[0], got[0]))
+        for a, b in zip(ref[1:], got[1:]):
+            assert np.array_equal(a, b)
+
+    tlen, ntraj, a_dim, bs = 10, 5, 6, 20
+    m = tlen * ntraj
+    ispec = netspec.impala_cnn_opt((42, 42, 4), a_dim, 128.0, 128.0)
+    bufs = [d(rng.integers(0, 256, (m, 42, 42, 4)).astype(np.uint8)), d(rng.standard_normal((m, a_dim)).astype(np.float32)),
+            d(rng.integers(0, a_dim, m).astype(np.int32)), d((rng.random(m) < 0.1).astype(np.uint8)),
+            d(rng.choice([-2.0, 0.0, 1.0], m).astype(np.float32))]
+
+    def impala(knob, use_graph):
+        old = L.set_tuning(tail_overlap=knob)
+        try:
+            net = HipActorCritic(ispec, max_batch=bs, seed=0)
+            c = net.make_impala_cfg(7e-4, 40.0, tlen)
+            out = []
+            for _ in range(2):
+                acc = net.impala_train(c, bufs[0], bs, *bufs[1:], use_graph=use_graph)
+                torch.cuda.synchronize()
+                out.append(acc.cpu().numpy().copy())
+            return out, net.params.cpu().numpy().copy(), net.adam_state.cpu().numpy().copy()
+        finally:
+            L.set_tuning(**old)
+
+    ref = impala(0, True)
+    for use_graph in (False, True):
+        got = impala(mode, use_graph)
+        assert all(np.array_equal(a, b) for a, b in zip(ref[0], got[0]))
+        assert np.array_equal(ref[1], got[1]) and np.array_equal(ref[2], got[2])

@@ -161,7 +161,9 @@ struct GradEntry {
   int count, nslab;
   long long stride;
   int zl;               // z lanes per block (power of two <= 32)
-  int blk0, nblk;
+  int blk0, nblk;       // first block of the entry in THIS launch, number of blocks
+  int pblk0;            // slot of the entry's first squared-norm partial (position in the full table's block order: the same
+                        // whether the table is reduced by one launch or by two partial ones)
 };
 struct GradTable {
   int n;

@@ -28,7 +28,8 @@ xt_tuning& tuning() {
                         /*fwd_two_groups*/ 1, /*direct*/ 1, /*direct_fwd*/ 1, /*direct_dgrad*/ 1, /*direct_all*/ 0,
                         /*direct_waves*/ 1536, /*direct_max_waves*/ 8, /*direct_tile64_tiles*/ 3072,
                         /*fwd_split_target*/ 256, /*wgrad_split_target*/ 512, /*reduce_z_lanes*/ 8,
-                        /*defer_splitk*/ 1, /*finalize_ticket*/ 0, /*fwd_tiled_valid*/ 1, /*wgrad_rows*/ 4, /*fwd_prefetch_all*/ 0, /*bwd_deep_prefetch*/ 1, /*fwd_four_groups*/ 1, /*reduce_deep_lanes*/ 128, /*fwd_xcd_chunk*/ 1};
+                        /*defer_splitk*/ 1, /*finalize_ticket*/ 0, /*fwd_tiled_valid*/ 1, /*wgrad_rows*/ 4, /*fwd_prefetch_all*/ 0, /*bwd_deep_prefetch*/ 1, /*fwd_four_groups*/ 1, /*reduce_deep_lanes*/ 128, /*fwd_xcd_chunk*/ 1,
+                        /*tail_overlap*/ 0};
   return t;
 }
 
@@ -43,7 +44,8 @@ int launch_wgrad(const xt_conv_geom*, const xt_input_xform*, int, const void*, c
                  float*, float*, int, hipStream_t, int reduce_now = 1, int* msplit_out = nullptr, int slab_cap = 0);
 int launch_dgrad(const xt_conv_geom*, int, const float*, const float*, const float*, int, float*, hipStream_t);
 int launch_global_norm(const float*, long long, float, float, float, float, float, int, float*, float*, hipStream_t);
-int launch_grads_finish(GradTable*, float*, int, int*, const FinalizeArgs*, hipStream_t);
+int launch_grads_finish(GradTable*, float*, int, int*, const FinalizeArgs*, hipStream_t, unsigned select = 0,
+                        unsigned early = 0);
 int launch_norm_finalize(const float*, int, float, float, float, float, float, int, float*, const LossArgs*, hipStream_t);
 int launch_ppo_heads_fused(const PpoHeadArgs&, hipStream_t);
 int launch_adam_clip(float*, const float*, float*, float*, long long, float, float, float, float*, const float*, int,
@@ -109,6 +111,11 @@ struct xt_net {
   int xchg_flags = 0;                  // XT_XCHG_OVERLAP: two buckets, the first exchanged under the rest of the backward
   hipStream_t xchg_stream = nullptr;   // side stream of the first bucket's exchange
   hipEvent_t xchg_fork = nullptr, xchg_join = nullptr;
+  // single-GPU tail overlap (xt_tuning.tail_overlap): a side stream for the first gradient bucket's slab reduction and
+  // for the bulk of the optimiser update; adam_pending = the side stream's update has not been joined yet
+  hipStream_t tail_stream = nullptr;
+  hipEvent_t tail_fork = nullptr, tail_join = nullptr, adam_fork = nullptr, adam_join = nullptr;
+  bool adam_pending = false;
   // hipGraph cache of the whole-update entry points: a few slots, because the streaming ingest alternates between
   // two rollout buffer sets (two pointer sets -> two graphs), least recently used replaced
   struct GraphSlot { std::string key; hipGraphExec_t exec = nullptr; unsigned long long used = 0; };
@@ -141,6 +148,30 @@ static int wgrad_split(const Layer& L, int B) {
   return s < 1 ? 1 : s;
 }
 
+// xt_tuning.tail_overlap applies to one-trunk nets with >= 2 layers whose first layer opens the flat parameter buffer
+static int tail_overlap_mode(xt_net* n) {
+  const int t = tuning().tail_overlap;
+  if (!t || n->n_trunks != 1 || n->layers.size() < 2 || n->layers[0].poff != 0 || tuning().finalize_ticket) return 0;
+  const int64_t off_a = n->layers.back().poff;
+  if (!(off_a > 0 && n->pi_off > off_a && n->v_off > off_a)) return 0;
+  if (!n->tail_stream) {
+    if (hipStreamCreateWithFlags(&n->tail_stream, hipStreamNonBlocking) != hipSuccess) { n->tail_stream = nullptr; return 0; }
+    hipEvent_t* ev[4] = {&n->tail_fork, &n->tail_join, &n->adam_fork, &n->adam_join};
+    for (hipEvent_t* e : ev)
+      if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return 0;
+  }
+  return t & 3;
+}
+
+// the side stream's share of the previous optimiser update must have landed before anything but the first layer
+// reads the parameters
+static int join_pending_update(xt_net* n, hipStream_t st) {
+  if (!n->adam_pending) return 0;
+  XT_CHECK_HIP(hipStreamWaitEvent(st, n->adam_join, 0));
+  n->adam_pending = false;
+  return 0;
+}
+
 // defer_last: leave the split-K partials of every trunk's LAST layer un-finished (the fused PPO head kernel
 // sums them); each such layer has its own partial region.
 static int net_forward(xt_net* n, const void* obs, const int32_t* idx, int B, bool with_heads, hipStream_t st,
@@ -154,6 +185,7 @@ static int net_forward(xt_net* n, const void* obs, const int32_t* idx, int B, bo
       const bool defer = defer_last && (l == n->t_end[tr] - 1) && L.part_off >= 0 && L.z_off < 0;
       L.last_ksplit = 1;
       L.mask_valid = 0;
+      if (!first) { if (int rc = join_pending_update(n, st)) return rc; }
       if (L.z_off >= 0) {
         // swish / gelu: the layer writes its PRE-activation (the backward pass needs it), then one elementwise launch
         // produces the output the next layer reads -- a slow path, taken by no bundled configuration
@@ -176,6 +208,7 @@ static int net_forward(xt_net* n, const void* obs, const int32_t* idx, int B, bo
       x = n->ws + L.act_off;
     }
   }
+  if (int rc = join_pending_update(n, st)) return rc;     // (one-layer trunks: before the heads read their weights)
   if (!with_heads) return 0;
   const float* f_pi = n->ws + n->layers[n->t_end[0] - 1].act_off;
   const float* f_v = n->ws + n->layers[n->t_end[n->n_trunks - 1] - 1].act_off;
@@ -254,11 +287,12 @@ static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t s
   const int F = n->feat, A = n->A;
   GradTable tab;
   tab.n = 0;
+  unsigned first_bucket = 0;      // entries of part 1
   XT_REQUIRE(n->layers.size() + 3 <= 12, "xt_net: too many layers for the gradient table");
   const size_t l_last = n->layers.size() - 1;
   for (size_t li = 0; li < n->layers.size(); ++li) {
-    if ((part == 1 && li != l_last) || (part == 2 && li == l_last)) continue;
     Layer& L = n->layers[li];
+    if (li == l_last) first_bucket |= 1u << tab.n;
     GradEntry& E = tab.e[tab.n++];
     E.count = (L.K + 1) * L.g.N;
     E.dst = n->grads + L.poff;
@@ -266,22 +300,29 @@ static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t s
     E.src = (L.last_msplit > 1) ? n->ws + L.slab_off : E.dst;
     E.stride = E.count;
   }
-  if (part != 2) {
+  {
+    first_bucket |= 1u << tab.n;
     GradEntry& E = tab.e[tab.n++];
     E.count = F * A + A; E.dst = n->grads + n->pi_off; E.src = n->ws + n->off_hslab_pi;
     E.nslab = n->head_chunks; E.stride = n->hstride_pi;
   }
-  if (part != 2) {
+  {
+    first_bucket |= 1u << tab.n;
     GradEntry& E = tab.e[tab.n++];
     E.count = F + 1; E.dst = n->grads + n->v_off; E.src = n->ws + n->off_hslab_v;
     E.nslab = n->head_chunks; E.stride = n->hstride_v;
   }
-  if (part != 2 && n->action_type == XT_ACTION_DIAG_GAUSSIAN) {   // pi_logstd: the per-sample rows are the partial slabs
+  if (n->action_type == XT_ACTION_DIAG_GAUSSIAN) {   // pi_logstd: the per-sample rows are the partial slabs
+    first_bucket |= 1u << tab.n;
     GradEntry& E = tab.e[tab.n++];
     E.count = A; E.dst = n->grads + n->logstd_off; E.src = n->ws + n->off_dls;
     E.nslab = n->dls_rows; E.stride = align4(A);
   }
-  return launch_grads_finish(&tab, n->ws + n->off_norm, kMaxNormPartials, &n->norm_blocks, fin, st);
+  const unsigned all = (1u << tab.n) - 1u;
+  // (part 1 runs before the other layers' backward launches have set their slab counts: its entries own the FIRST
+  // partial slots, which depend on nothing else)
+  const unsigned select = part == 1 ? first_bucket : part == 2 ? (all & ~first_bucket) : 0u;
+  return launch_grads_finish(&tab, n->ws + n->off_norm, kMaxNormPartials, &n->norm_blocks, fin, st, select, first_bucket);
 }
 
 // mode 0: gradient was changed after grads_finish (all-reduce) -> recompute the norm;
@@ -302,9 +343,44 @@ static int net_apply(xt_net* n, float lr, float b1, float b2, float eps, float c
   return launch_adam(n->params, n->grads, n->m, n->v, n->P, b1, b2, eps, n->state, st);
 }
 
+// tail_overlap bit 2: Adam (mode 3: every block derives the clip factor from the partials) as two launches -- the first
+// layer's parameters on the compute stream, everything else on the side stream, where the next step's first-layer
+// forward overlaps it.  Element-wise, same clip factor in both: bitwise the single launch's result.
+static int net_apply_split(xt_net* n, float b1, float b2, float eps, float clip, float gscale, hipStream_t st) {
+  const Layer& L0 = n->layers[0];
+  const int64_t c0 = (int64_t)(L0.K + 1) * L0.g.N;
+  if (c0 % 4 != 0 || c0 >= n->P)
+    return launch_adam_clip(n->params, n->grads, n->m, n->v, n->P, b1, b2, eps, n->state, n->ws + n->off_norm,
+                            n->norm_blocks, clip, gscale, st);
+  XT_CHECK_HIP(hipEventRecord(n->adam_fork, st));
+  XT_CHECK_HIP(hipStreamWaitEvent(n->tail_stream, n->adam_fork, 0));
+  if (int rc = launch_adam_clip(n->params + c0, n->grads + c0, n->m + c0, n->v + c0, n->P - c0, b1, b2, eps, n->state,
+                                n->ws + n->off_norm, n->norm_blocks, clip, gscale, n->tail_stream))
+    return rc;
+  XT_CHECK_HIP(hipEventRecord(n->adam_join, n->tail_stream));
+  n->adam_pending = true;
+  return launch_adam_clip(n->params, n->grads, n->m, n->v, c0, b1, b2, eps, n->state, n->ws + n->off_norm,
+                          n->norm_blocks, clip, gscale, st);
+}
+
+// tail_overlap bit 1: called right after the first backward launch (last trunk layer + head weight gradients): their
+// slab reduction -- most of the gradient bytes -- goes to the side stream, under the remaining backward launches
+struct TailFork { xt_net* n; int B; hipStream_t st; bool done; };
+static int tail_fork_first_bucket(void* arg) {
+  TailFork* o = static_cast<TailFork*>(arg);
+  xt_net* n = o->n;
+  XT_CHECK_HIP(hipEventRecord(n->tail_fork, o->st));
+  XT_CHECK_HIP(hipStreamWaitEvent(n->tail_stream, n->tail_fork, 0));
+  if (int rc = grads_finish(n, o->B, nullptr, n->tail_stream, 1)) return rc;
+  XT_CHECK_HIP(hipEventRecord(n->tail_join, n->tail_stream));
+  o->done = true;
+  return 0;
+}
+
 static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32_t* idx, int B,
                     const void* action_v, const float* old_logp, const double* adv, const float* old_v,
-                    const double* target_v, int apply, float* loss_out, float* loss_acc, hipStream_t st) {
+                    const double* target_v, int apply, float* loss_out, float* loss_acc, hipStream_t st,
+                    bool defer_join = false) {
   XT_REQUIRE(n->params && n->ws, "xt_net: buffers not bound (call xt_net_bind)");
   XT_REQUIRE(B > 0 && B <= n->maxB, "xt_net_ppo_step: batch %d outside (0,%d]", B, n->maxB);
   const bool gauss = (n->action_type == XT_ACTION_DIAG_GAUSSIAN);
@@ -384,7 +460,10 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
                      return 0;
                    },
                    &ovl};
-  if (int rc = trunk_backward(n, obs, idx, B, st, apply == 2 ? &af : nullptr)) return rc;
+  const int tov = (apply == 1) ? tail_overlap_mode(n) : 0;
+  TailFork tfk{n, B, st, false};
+  AfterFirstBwd tf{tail_fork_first_bucket, &tfk};
+  if (int rc = trunk_backward(n, obs, idx, B, st, apply == 2 ? &af : (tov & 1) ? &tf : nullptr)) return rc;
   if (apply == 2) {
     if (int rc = grads_finish(n, B, nullptr, st, 2)) return rc;
     return xt_ppo_loss_reduce(n->ws + n->off_terms, B, c->ent_coef, c->critic_coef, inv_b, lo, loss_acc, st);
@@ -398,7 +477,14 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
     fin.enable = tail_mode; fin.counter = reinterpret_cast<unsigned int*>(n->ws + n->off_counter);
     fin.clip_norm = c->max_grad_norm; fin.grad_scale = c->grad_scale; fin.lr = c->lr; fin.beta1 = c->beta1;
     fin.beta2 = c->beta2; fin.state = n->state; fin.loss = la;
-    if (int rc = grads_finish(n, B, &fin, st)) return rc;
+    if (tfk.done) {
+      XT_CHECK_HIP(hipStreamWaitEvent(st, n->tail_join, 0));
+      if (int rc = grads_finish(n, B, &fin, st, 2)) return rc;
+    } else if (int rc = grads_finish(n, B, &fin, st)) return rc;
+    if (tov & 2) {
+      if (int rc = net_apply_split(n, c->beta1, c->beta2, c->eps, c->max_grad_norm, c->grad_scale, st)) return rc;
+      return defer_join ? 0 : join_pending_update(n, st);
+    }
     return net_apply(n, c->lr, c->beta1, c->beta2, c->eps, c->max_grad_norm, c->grad_scale, tail_mode == 1 ? 2 : 3,
                      nullptr, st);
   }
@@ -441,7 +527,7 @@ static int graph_run(xt_net* net, const char* key, hipStream_t st, F enqueue) {
 // step size in device memory (lr_schedule evaluated by the caller; lets a replayed hipGraph see a new value).
 static int impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int nfr, const float* bp_logits,
                        const int32_t* action, const uint8_t* done, const float* reward, int apply, const float* lr_dev,
-                       float* loss_out, float* loss_acc, hipStream_t st) {
+                       float* loss_out, float* loss_acc, hipStream_t st, bool defer_join = false) {
   const int T = c->sample_batch_step;
   XT_REQUIRE(T >= 2 && nfr > 0 && nfr % T == 0, "xt_net_impala_step: n=%d must be a multiple of sample_batch_step=%d",
              nfr, T);
@@ -490,7 +576,10 @@ static int impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int n
                                     n->ws + Lp.dact_off, n->ws + Lv.dact_off, st))
       return rc;
   }
-  if (int rc = trunk_backward(n, obs, nullptr, nfr, st)) return rc;
+  const int tov = (apply && c->opt_type == XT_OPT_ADAM) ? tail_overlap_mode(n) : 0;
+  TailFork tfk{n, nfr, st, false};
+  AfterFirstBwd tf{tail_fork_first_bucket, &tfk};
+  if (int rc = trunk_backward(n, obs, nullptr, nfr, st, (tov & 1) ? &tf : nullptr)) return rc;
   if (!apply) {
     if (int rc = grads_finish(n, nfr, nullptr, st)) return rc;
     if (loss_pending) return launch_impala_loss_reduce(lo + 4, ntraj, loss_out ? loss_out : lo, loss_acc, st);
@@ -504,7 +593,14 @@ static int impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int n
   if (loss_pending) {
     fin.loss.traj_loss = lo + 4; fin.loss.n_traj = ntraj; fin.loss.out = loss_out ? loss_out : lo; fin.loss.acc = loss_acc;
   }
-  if (int rc = grads_finish(n, nfr, &fin, st)) return rc;
+  if (tfk.done) {
+    XT_CHECK_HIP(hipStreamWaitEvent(st, n->tail_join, 0));
+    if (int rc = grads_finish(n, nfr, &fin, st, 2)) return rc;
+  } else if (int rc = grads_finish(n, nfr, &fin, st)) return rc;
+  if (tov & 2) {
+    if (int rc = net_apply_split(n, c->beta1, c->beta2, c->eps, c->grad_norm_clip, c->grad_scale, st)) return rc;
+    return defer_join ? 0 : join_pending_update(n, st);
+  }
   if (c->opt_type == XT_OPT_RMSPROP_CENTERED)
     return launch_rmsprop_clip(n->params, n->grads, n->m, n->v, n->P, c->lr, c->rms_decay, c->rms_eps, n->state,
                                n->ws + n->off_norm, n->norm_blocks, c->grad_norm_clip, c->grad_scale, st, lr_dev);
@@ -635,6 +731,10 @@ void xt_net_destroy(xt_net* net) {
   if (!net) return;
   for (auto& g : net->gslots) if (g.exec) hipGraphExecDestroy(g.exec);
   if (net->cap_stream) hipStreamDestroy(net->cap_stream);
+  if (net->tail_stream) {
+    hipStreamDestroy(net->tail_stream);
+    for (hipEvent_t e : {net->tail_fork, net->tail_join, net->adam_fork, net->adam_join}) if (e) hipEventDestroy(e);
+  }
   if (net->xchg_stream) { hipStreamDestroy(net->xchg_stream); hipEventDestroy(net->xchg_fork); hipEventDestroy(net->xchg_join); }
   delete net;
 }
@@ -686,7 +786,7 @@ static int ppo_train_enqueue(xt_net* net, const xt_ppo_cfg* c, const void* obs, 
         cc.global_batch = (int)((long long)cc.global_batch * B / c->batch_size);
       if (!net->xchg) {
         if (int rc = xt::ppo_step(net, &cc, obs, perm + (size_t)ep * n + start, B, action, old_logp, adv, old_v,
-                                  target_v, 1, nullptr, loss_acc, st))
+                                  target_v, 1, nullptr, loss_acc, st, /*defer_join*/ true))
           return rc;
         continue;
       }
@@ -708,7 +808,7 @@ static int ppo_train_enqueue(xt_net* net, const xt_ppo_cfg* c, const void* obs, 
         return rc;
     }
   }
-  return 0;
+  return xt::join_pending_update(net, st);
 }
 
 int xt_net_ppo_train(xt_net* net, const xt_ppo_cfg* c, const void* obs, int32_t n, const int32_t* perm,
@@ -718,6 +818,7 @@ int xt_net_ppo_train(xt_net* net, const xt_ppo_cfg* c, const void* obs, int32_t 
   XT_REQUIRE(n > 0 && c->batch_size > 0 && c->batch_size <= net->maxB && c->num_sgd_iter > 0,
              "xt_net_ppo_train: bad sizes (n=%d batch=%d max=%d)", n, c->batch_size, net->maxB);
   hipStream_t st = xt::as_stream(stream);
+  (void)xt::tail_overlap_mode(net);      // (creates the side stream outside of any capture)
   if (!use_graph)
     return ppo_train_enqueue(net, c, obs, n, perm, action, old_logp, adv, old_v, target_v, loss_acc, st);
   char key[512];
@@ -752,7 +853,7 @@ static int impala_train_enqueue(xt_net* net, const xt_impala_cfg* c, const void*
     const void* o = static_cast<const char*>(obs) + frame * lo;
     if (!net->xchg) {
       if (int rc = xt::impala_step(net, c, o, nfr, bp_logits + (size_t)lo * net->A, action + lo, done + lo, reward + lo, 1,
-                                   lr_dev, nullptr, loss_acc, st))
+                                   lr_dev, nullptr, loss_acc, st, /*defer_join*/ true))
         return rc;
       continue;
     }
@@ -767,7 +868,7 @@ static int impala_train_enqueue(xt_net* net, const xt_impala_cfg* c, const void*
     if (int rc = xt::net_apply(net, c->lr, c->beta1, c->beta2, c->eps, c->grad_norm_clip, c->grad_scale, 0, nullptr, st))
       return rc;
   }
-  return 0;
+  return xt::join_pending_update(net, st);
 }
 
 int xt_net_impala_train(xt_net* net, const xt_impala_cfg* c, const void* obs, int32_t n, int32_t batch_size,
@@ -784,6 +885,7 @@ int xt_net_impala_train(xt_net* net, const xt_impala_cfg* c, const void* obs, in
   XT_REQUIRE(batch_size <= net->maxB || n <= net->maxB, "xt_net_impala_train: chunk of %d frames > max batch %d",
              batch_size < n ? batch_size : n, net->maxB);
   hipStream_t st = xt::as_stream(stream);
+  (void)xt::tail_overlap_mode(net);
   if (!use_graph)
     return impala_train_enqueue(net, c, obs, n, batch_size, bp_logits, action, done, reward, lr_steps, loss_acc, st);
   char key[512];

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void grads_finish_kernel(const GradTable tab, 
   }
   XT_TL(2);
   if (fin.enable != 1) {
-    if (t == 0) partial[blockIdx.x] = shs[0];
+    if (t == 0) partial[E.pblk0 + ((int)blockIdx.x - E.blk0)] = shs[0];
     return;
   }
   // ---- last block to arrive finalises (norm, clip scale, Adam step size, loss scalars): saves a launch.
@@ -405,10 +405,16 @@ __global__ void adam_state_init_kernel(float* state) {
 }
 
 // entries: blk0/nblk/zl are filled here.  partial needs room for the returned block count.
+// `select` (bit i = entry i of the table is reduced by THIS launch; 0 = all).  The slot of every squared-norm partial
+// is that of the FULL table, so a table reduced by two partial launches leaves the same partial array (bitwise the
+// same norm) as one launch.  `early` = the entries whose slots come first: a partial launch of exactly these entries
+// may run before the slab counts of the others are known (their slots do not depend on them).
 int launch_grads_finish(GradTable* tab, float* partial, int max_partials, int* nblocks_out, const FinalizeArgs* fin,
-                        hipStream_t st) {
+                        hipStream_t st, unsigned select, unsigned early) {
   int blk = 0;
+  for (int pass = 0; pass < 2; ++pass)
   for (int i = 0; i < tab->n; ++i) {
+    if ((((early >> i) & 1u) != 0) != (pass == 0)) continue;
     GradEntry& E = tab->e[i];
     int zl = 1;
     // deep entries (the first layer's one-slab-per-workgroup gradients: 250 slabs) get up to 32 z lanes: their blocks
@@ -417,7 +423,7 @@ int launch_grads_finish(GradTable* tab, float* partial, int max_partials, int* n
     while (zl < E.nslab && zl < zcap) zl <<= 1;   // fewer z lanes = longer contiguous runs per wave (512 B at 8)
     E.zl = zl;
     const int cols = 256 / zl;
-    E.blk0 = blk;
+    E.pblk0 = blk;
     E.nblk = ((E.count + 3) / 4 + cols - 1) / cols;
     blk += E.nblk;
     XT_REQUIRE((((uintptr_t)E.src | (uintptr_t)E.dst) & 15) == 0 && (E.stride % 4) == 0,
@@ -426,7 +432,19 @@ int launch_grads_finish(GradTable* tab, float* partial, int max_partials, int* n
   XT_REQUIRE(blk > 0 && blk <= max_partials, "grads_finish: %d partial blocks > scratch %d", blk, max_partials);
   FinalizeArgs f;
   if (fin) f = *fin; else { memset(&f, 0, sizeof(f)); }
-  hipLaunchKernelGGL(grads_finish_kernel, dim3(blk + (f.enable == 2 ? 1 : 0)), dim3(256), 0, st, *tab, partial, f);
+  GradTable sub;
+  sub.n = 0;
+  int grid = 0;
+  for (int i = 0; i < tab->n; ++i) {
+    if (select && !((select >> i) & 1u)) continue;
+    GradEntry& E = sub.e[sub.n++];
+    E = tab->e[i];
+    E.blk0 = grid;
+    grid += E.nblk;
+  }
+  XT_REQUIRE(grid > 0, "grads_finish: empty selection");
+  XT_REQUIRE(f.enable != 1 || grid == blk, "grads_finish: the last-block finalize form needs the whole table in one launch");
+  hipLaunchKernelGGL(grads_finish_kernel, dim3(grid + (f.enable == 2 ? 1 : 0)), dim3(256), 0, st, sub, partial, f);
   XT_LAUNCH_CHECK();
   *nblocks_out = blk;
   return 0;
