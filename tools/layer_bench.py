@@ -13,6 +13,9 @@ from xingtian_amd import lib as L  # noqa: E402
 
 if len(sys.argv) > 1 and sys.argv[1].endswith(".so"):
     L.LIB_PATH = os.path.abspath(sys.argv[1])
+if os.environ.get("XT_KNOBS"):          # e.g. XT_KNOBS='{"wgrad_rows": 0}'
+    import json
+    L.set_tuning(**json.loads(os.environ["XT_KNOBS"]))
 BS = [int(a) for a in sys.argv[1:] if a.isdigit()] or [320]
 FUSED = "fused" in sys.argv[1:]      # time the fused dgrad+wgrad launch instead of the two separate kernels
 from xingtian_amd.model import netspec  # noqa: E402
