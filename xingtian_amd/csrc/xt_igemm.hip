@@ -529,12 +529,22 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
   for (int sub = mbeg; sub < mend; sub += kRowTab) {
     const int sub_end = min(mend, sub + kRowTab);
     const int nsteps = (sub_end - sub + 31) / 32;
+    // "lean" loads of the four-stage loop (fp32 input, no padding, no row gather): see the PF4 branch below
+    constexpr bool LEAN_T = PF4 && !PADDED && !U8;
+    const bool lean = LEAN_T && p.idx == nullptr && (long long)g.B * g.HWC * 4 < (1ll << 30) &&
+                      (long long)g.M * g.N * 4 < (1ll << 30);
+    uint32_t* tab32 = reinterpret_cast<uint32_t*>(rowtab);
     // ---- decode the rows of this sub-range once
     for (int r = t; r < nsteps * 32; r += 256) {
       int mr[1] = {sub + r < sub_end ? sub + r : g.M};
       long long base[1];
       int iy0[1], ix0[1];
       decode_rows<1>(g, mr, p.idx, base, iy0, ix0);
+      if (lean) {      // 32-bit byte offsets, the NA rows a thread loads in one step side by side: one LDS read per step
+        const int w = r & 31;
+        tab32[(r & ~31) + (w % RPA) * NA + w / RPA] = (sub + r < sub_end) ? (uint32_t)base[0] * 4u : kOob;
+        continue;
+      }
       rowtab[r] = (sub + r < sub_end) ? base[0] : kRowInvalid;
       if (PADDED) rowxy[r] = (iy0[0] << 16) | (ix0[0] & 0xffff);
     }
@@ -580,6 +590,63 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
       }
     };
 
+    // A wave does not issue its other instructions in the shadow of its own MFMA chain (tools/mfma_probe.hip: 64 cycles per
+    // dependent v_mfma_f32_32x32x2_f32 bare, 113 with ten independent VALU operations behind each), so with one such wave
+    // per SIMD every instruction of the step that is not an MFMA costs ~5 cycles of the step.  The lean form of the
+    // four-stage loop removes the ones that only exist for addressing and masking:
+    //  * buffer loads with 32-bit byte offsets; a row outside the range carries an offset beyond the buffer and reads as
+    //    zeros (hardware range check): no validity bits, no 64-bit address arithmetic, one add per load;
+    //  * the LDS writes store the load registers as they are (no zero-selects);
+    //  * one LDS read per step fetches all NA row offsets of the thread.
+    if constexpr (LEAN_T) if (lean) {
+      const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(p.in, (uint32_t)g.B * (uint32_t)g.HWC * 4u);
+      const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.dy, (uint32_t)g.M * (uint32_t)g.N * 4u);
+      const uint32_t koff4 = kok ? (uint32_t)koff * 4u : 0x40000000u;      // (any row offset + 2^30 is out of range)
+      struct LRegs { float4 a[NA]; float4 b[NB]; };
+      auto lfetch = [&](int sf, LRegs& Rf) {
+        uint32_t ro[NA];
+        if constexpr (NA == 4) {
+          const uint4 q = *reinterpret_cast<const uint4*>(&tab32[sf * 32 + rowa * 4]);
+          ro[0] = q.x; ro[1] = q.y; ro[2] = q.z; ro[3] = q.w;
+        } else {
+#pragma unroll
+          for (int i = 0; i < NA; ++i) ro[i] = tab32[sf * 32 + rowa * NA + i];
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) Rf.a[i] = buf_load4(rs_a, ro[i] + koff4, 0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const int m = sub + sf * 32 + rowb + RPB * i;
+          Rf.b[i] = buf_load4(rs_b, (nok && m < sub_end) ? (uint32_t)(m * g.N + nb) * 4u : kOob, 0);
+        }
+      };
+      auto lstash = [&](const LRegs& Rs, float* As, float* Bs) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<float4*>(&As[(rowa + RPA * i) * SA + ca * 4]) = Rs.a[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(&Bs[(rowb + RPB * i) * SB + cb * 4]) = Rs.b[i];
+      };
+      LRegs R[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) lfetch(u < nsteps ? u : nsteps - 1, R[u]);
+      if (sub == mbeg) XT_TL(1);
+      for (int s = 0; s < nsteps; s += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (s + u < nsteps) {                                                   // block-uniform
+            float* stage = smem + (u & 1) * BUF;
+            lstash(R[u], stage, stage + 32 * SA);
+            __syncthreads();
+            if (s == 0 && u == 0 && sub == mbeg) XT_TL(2);
+            if (s + u + 4 < nsteps) lfetch(s + u + 4, R[u]);
+            colsum(stage + 32 * SA);
+            mma_tile<TI, TJ, SA, SB>(stage, stage + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+          }
+        }
+      }
+      __syncthreads();
+      continue;
+    }
     if constexpr (PF4) {
       Regs R[4];
 #pragma unroll
