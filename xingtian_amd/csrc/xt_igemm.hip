@@ -1055,22 +1055,25 @@ __device__ __forceinline__ void igemm_dgrad4_body(const DgradArgs& p, const int 
   const int cN = r0 * g.N;                          // this thread's weight row (input channel r0 < 32 = C)
 
   struct Regs { float4 a[NA]; float4 b[kD4Classes]; uint32_t ok; };
+  // (buffer loads: 32-bit offsets, taps outside the gradient map read as zeros through the range check -- every
+  // instruction of the step that is not an MFMA costs the wave ~5 cycles, see igemm_wgrad_body)
+  const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(p.dy, (uint32_t)g.M * (uint32_t)g.N * 4u);
+  const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (uint32_t)g.K * (uint32_t)g.N * 4u);
   auto fetch = [&](int s, Regs& R) {
     const int tap = s / nps, n0 = (s - tap * nps) * 32 + c4 * 4;
     const int jy = tap / JX, jx = tap - jy * JX;
     const int tapoff = (jy * g.OW + jx) * g.N - n0;
-    R.ok = 0;
+    R.ok = 0xfu;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const bool ok = ((unsigned)(qy[i] - jy) < (unsigned)g.OH) && ((unsigned)(qx[i] - jx) < (unsigned)g.OW);
-      R.a[i] = load_f4_ok(p.dy, (long long)(rowbase[i] - tapoff), ok);
-      R.ok |= (ok ? 1u : 0u) << i;
+      R.a[i] = buf_load4(rs_dy, ok ? (uint32_t)(rowbase[i] - tapoff) * 4u : kOob, 0);
     }
 #pragma unroll
     for (int cls = 0; cls < kD4Classes; ++cls) {
       const int ry = cls / g.S, rx = cls - ry * g.S;
       const int wbase = ((ry + g.S * jy) * g.KW + rx + g.S * jx) * g.C * g.N + n0;
-      R.b[cls] = *reinterpret_cast<const float4*>(p.w + wbase + cN);
+      R.b[cls] = buf_load4(rs_w, (uint32_t)(wbase + cN) * 4u, 0);
     }
   };
   auto stash = [&](const Regs& R) {
@@ -1078,7 +1081,7 @@ __device__ __forceinline__ void igemm_dgrad4_body(const DgradArgs& p, const int 
       const int sub = c4 >> 1, byte = (c4 & 1) * 8;     // k = 4*c4 + e -> chunk = c4 >> 2, k half = (c4 & 3) >> 1
 #pragma unroll
       for (int i = 0; i < NA; ++i)
-        split3_store(Ap + (r0 + 32 * i) * 16 + sub * kD4SlotA + byte, 4 * kD4SlotA, sel4((R.ok >> i) & 1u, R.a[i]));
+        split3_store(Ap + (r0 + 32 * i) * 16 + sub * kD4SlotA + byte, 4 * kD4SlotA, R.a[i]);
 #pragma unroll
       for (int cls = 0; cls < kD4Classes; ++cls)
         split3_store(Bp + cls * 12 * kD4SlotB + r0 * 16 + sub * kD4SlotB + byte, 4 * kD4SlotB, R.b[cls]);
@@ -1087,7 +1090,7 @@ __device__ __forceinline__ void igemm_dgrad4_body(const DgradArgs& p, const int 
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int r = r0 + 32 * i;
-      const float4 v = sel4((R.ok >> i) & 1u, R.a[i]);
+      const float4 v = R.a[i];
       As[(c4 * 4 + 0) * SA + r] = v.x;
       As[(c4 * 4 + 1) * SA + r] = v.y;
       As[(c4 * 4 + 2) * SA + r] = v.z;
@@ -1752,6 +1755,9 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
   if (int rc = make_geom(cg, nullptr, B, &a.wg.g)) return rc;
   a.dg.g = a.wg.g;
   const Geom& g = a.wg.g;
+  // (the buffer loads of the backward kernels address their tensors with 32-bit byte offsets, 2^31 = "out of range")
+  XT_REQUIRE((long long)g.M * g.N * 4 < (1ll << 31) && (long long)g.B * g.HWC * 4 < (1ll << 31),
+             "bwd_layer: activation / gradient tensors of 2 GiB or more are not supported (batch %d)", B);
   // ---- wgrad part
   a.wg.in = x_in; a.wg.idx = nullptr; a.wg.dy = dy;
   if (msplit < 1) msplit = 1;
