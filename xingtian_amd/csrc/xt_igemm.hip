@@ -529,8 +529,8 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
   for (int sub = mbeg; sub < mend; sub += kRowTab) {
     const int sub_end = min(mend, sub + kRowTab);
     const int nsteps = (sub_end - sub + 31) / 32;
-    // "lean" loads of the four-stage loop (fp32 input, no padding, no row gather): see the PF4 branch below
-    constexpr bool LEAN_T = PF4 && !PADDED && !U8;
+    // "lean" loads (fp32 input, no row gather): see below
+    constexpr bool LEAN_T = !U8;
     const bool lean = LEAN_T && p.idx == nullptr && (long long)g.B * g.HWC * 4 < (1ll << 30) &&
                       (long long)g.M * g.N * 4 < (1ll << 30);
     uint32_t* tab32 = reinterpret_cast<uint32_t*>(rowtab);
@@ -541,8 +541,12 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
       int iy0[1], ix0[1];
       decode_rows<1>(g, mr, p.idx, base, iy0, ix0);
       if (lean) {      // 32-bit byte offsets, the NA rows a thread loads in one step side by side: one LDS read per step
-        const int w = r & 31;
-        tab32[(r & ~31) + (w % RPA) * NA + w / RPA] = (sub + r < sub_end) ? (uint32_t)base[0] * 4u : kOob;
+        const int w = r & 31, slot = (r & ~31) + (w % RPA) * NA + w / RPA;
+        const bool rv = sub + r < sub_end;
+        // (padded: the offset of an out-of-image top-left corner wraps, every tap is range-checked by its coordinates;
+        // an invalid row gets coordinates that fail every check)
+        tab32[slot] = (rv || PADDED) ? (uint32_t)((long long)base[0] * 4) : kOob;
+        if (PADDED) rowxy[slot] = rv ? ((iy0[0] << 16) | (ix0[0] & 0xffff)) : (int)0xC000C000;
         continue;
       }
       rowtab[r] = (sub + r < sub_end) ? base[0] : kRowInvalid;
@@ -601,19 +605,35 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
     if constexpr (LEAN_T) if (lean) {
       const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(p.in, (uint32_t)g.B * (uint32_t)g.HWC * 4u);
       const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.dy, (uint32_t)g.M * (uint32_t)g.N * 4u);
-      const uint32_t koff4 = kok ? (uint32_t)koff * 4u : 0x40000000u;      // (any row offset + 2^30 is out of range)
+      const uint32_t koff4 = (kok || PADDED) ? (uint32_t)koff * 4u : 0x40000000u;   // (any row offset + 2^30 is out of range)
       struct LRegs { float4 a[NA]; float4 b[NB]; };
       auto lfetch = [&](int sf, LRegs& Rf) {
         uint32_t ro[NA];
+        int rxy[NA];
         if constexpr (NA == 4) {
           const uint4 q = *reinterpret_cast<const uint4*>(&tab32[sf * 32 + rowa * 4]);
           ro[0] = q.x; ro[1] = q.y; ro[2] = q.z; ro[3] = q.w;
+          if constexpr (PADDED) {
+            const int4 c = *reinterpret_cast<const int4*>(&rowxy[sf * 32 + rowa * 4]);
+            rxy[0] = c.x; rxy[1] = c.y; rxy[2] = c.z; rxy[3] = c.w;
+          }
         } else {
 #pragma unroll
-          for (int i = 0; i < NA; ++i) ro[i] = tab32[sf * 32 + rowa * NA + i];
+          for (int i = 0; i < NA; ++i) {
+            ro[i] = tab32[sf * 32 + rowa * NA + i];
+            if constexpr (PADDED) rxy[i] = rowxy[sf * 32 + rowa * NA + i];
+          }
         }
 #pragma unroll
-        for (int i = 0; i < NA; ++i) Rf.a[i] = buf_load4(rs_a, ro[i] + koff4, 0);
+        for (int i = 0; i < NA; ++i) {
+          uint32_t vo = ro[i] + koff4;
+          if constexpr (PADDED) {
+            const bool ok = kok && ((unsigned)((rxy[i] >> 16) + (int)ky) < (unsigned)g.H) &&
+                            ((unsigned)((int)(short)(rxy[i] & 0xffff) + (int)kx) < (unsigned)g.W);
+            vo = ok ? vo : kOob;
+          }
+          Rf.a[i] = buf_load4(rs_a, vo, 0);
+        }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
           const int m = sub + sf * 32 + rowb + RPB * i;
@@ -626,21 +646,43 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
 #pragma unroll
         for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(&Bs[(rowb + RPB * i) * SB + cb * 4]) = Rs.b[i];
       };
-      LRegs R[4];
+      if constexpr (PF4) {
+        LRegs R[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) lfetch(u < nsteps ? u : nsteps - 1, R[u]);
-      if (sub == mbeg) XT_TL(1);
-      for (int s = 0; s < nsteps; s += 4) {
+        for (int u = 0; u < 4; ++u) lfetch(u < nsteps ? u : nsteps - 1, R[u]);
+        if (sub == mbeg) XT_TL(1);
+        for (int s = 0; s < nsteps; s += 4) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (s + u < nsteps) {                                                   // block-uniform
-            float* stage = smem + (u & 1) * BUF;
-            lstash(R[u], stage, stage + 32 * SA);
+          for (int u = 0; u < 4; ++u) {
+            if (s + u < nsteps) {                                                   // block-uniform
+              float* stage = smem + (u & 1) * BUF;
+              lstash(R[u], stage, stage + 32 * SA);
+              __syncthreads();
+              if (s == 0 && u == 0 && sub == mbeg) XT_TL(2);
+              if (s + u + 4 < nsteps) lfetch(s + u + 4, R[u]);
+              colsum(stage + 32 * SA);
+              mma_tile<TI, TJ, SA, SB>(stage, stage + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+            }
+          }
+        }
+      } else {
+        LRegs R0, R1;
+        if (nsteps > 0) lfetch(0, R0);
+        if (nsteps > 1) lfetch(1, R1);
+        if (sub == mbeg) XT_TL(1);
+        for (int s = 0; s < nsteps; s += 2) {
+          lstash(R0, smem, smem + 32 * SA);
+          __syncthreads();
+          if (s == 0 && sub == mbeg) XT_TL(2);
+          if (s + 2 < nsteps) lfetch(s + 2, R0);
+          colsum(smem + 32 * SA);
+          mma_tile<TI, TJ, SA, SB>(smem, smem + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+          if (s + 1 < nsteps) {
+            lstash(R1, smem + BUF, smem + BUF + 32 * SA);
             __syncthreads();
-            if (s == 0 && u == 0 && sub == mbeg) XT_TL(2);
-            if (s + u + 4 < nsteps) lfetch(s + u + 4, R[u]);
-            colsum(stage + 32 * SA);
-            mma_tile<TI, TJ, SA, SB>(stage, stage + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+            if (s + 3 < nsteps) lfetch(s + 3, R1);
+            colsum(smem + BUF + 32 * SA);
+            mma_tile<TI, TJ, SA, SB>(smem + BUF, smem + BUF + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
           }
         }
       }
