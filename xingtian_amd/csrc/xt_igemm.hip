@@ -863,10 +863,15 @@ __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int b
   for (int i = 0; i < NB; ++i) { const int c = j0 + r0 + 32 * i; cN[i] = c * g.N; cok |= (c < g.C ? 1u : 0u) << i; }
 
   struct Regs { float4 a[NA]; float4 b[NB]; uint32_t ok; };
+  // (buffer loads: 32-bit offsets, taps / rows / channels outside the problem read as zeros through the range check, the
+  // LDS writes take the registers as they are -- every instruction of the step that is not an MFMA costs the wave ~5
+  // cycles, see igemm_wgrad_body)
+  const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(p.dy, (uint32_t)g.M * (uint32_t)g.N * 4u);
+  const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (uint32_t)g.K * (uint32_t)g.N * 4u);
   auto fetch = [&](int k0, Regs& R) {
     const int kk = k0 + c4 * 4;
     const bool kok = kk < Kc;
-    R.ok = 0;
+    R.ok = 0xffffffffu;
     const uint32_t tap = fdiv((uint32_t)kk, g.d_n);
     const int n = kk - (int)tap * g.N;
     const int jy = JX > 0 ? (int)tap / JX : 0, jx = (int)tap - jy * JX;
@@ -874,15 +879,13 @@ __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int b
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const bool ok = kok && ((unsigned)(qy[i] - jy) < (unsigned)g.OH) && ((unsigned)(qx[i] - jx) < (unsigned)g.OW);
-      R.a[i] = load_f4_ok(p.dy, (long long)(rowbase[i] - tapoff), ok);
-      R.ok |= (ok ? 1u : 0u) << i;
+      R.a[i] = buf_load4(rs_dy, ok ? (uint32_t)(rowbase[i] - tapoff) * 4u : kOob, 0);
     }
     const int wbase = ((ry + g.S * jy) * g.KW + rx + g.S * jx) * g.C * g.N + n;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const bool okb = kok && ((cok >> i) & 1u);
-      R.b[i] = load_f4_ok(p.w, (long long)(wbase + cN[i]), okb);
-      R.ok |= (okb ? 1u : 0u) << (8 + i);
+      R.b[i] = buf_load4(rs_w, okb ? (uint32_t)(wbase + cN[i]) * 4u : kOob, 0);
     }
   };
   auto stash = [&](const Regs& R, float* As, float* Bs) {
@@ -891,16 +894,16 @@ __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int b
       uint8_t* Bp = Ap + 12 * SLA;
 #pragma unroll
       for (int i = 0; i < NA; ++i)
-        split3_store(Ap + (r0 + 32 * i) * 16 + (c4 >> 1) * SLA + (c4 & 1) * 8, 4 * SLA, sel4((R.ok >> i) & 1u, R.a[i]));
+        split3_store(Ap + (r0 + 32 * i) * 16 + (c4 >> 1) * SLA + (c4 & 1) * 8, 4 * SLA, R.a[i]);
 #pragma unroll
       for (int i = 0; i < NB; ++i)
-        split3_store(Bp + (r0 + 32 * i) * 16 + (c4 >> 1) * SLB + (c4 & 1) * 8, 4 * SLB, sel4((R.ok >> (8 + i)) & 1u, R.b[i]));
+        split3_store(Bp + (r0 + 32 * i) * 16 + (c4 >> 1) * SLB + (c4 & 1) * 8, 4 * SLB, R.b[i]);
       return;
     }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int r = r0 + 32 * i;
-      const float4 v = sel4((R.ok >> i) & 1u, R.a[i]);
+      const float4 v = R.a[i];
       As[(c4 * 4 + 0) * SA + r] = v.x;
       As[(c4 * 4 + 1) * SA + r] = v.y;
       As[(c4 * 4 + 2) * SA + r] = v.z;
@@ -909,7 +912,7 @@ __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int b
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int r = r0 + 32 * i;
-      const float4 v = sel4((R.ok >> (8 + i)) & 1u, R.b[i]);
+      const float4 v = R.b[i];
       Bs[(c4 * 4 + 0) * SB + r] = v.x;
       Bs[(c4 * 4 + 1) * SB + r] = v.y;
       Bs[(c4 * 4 + 2) * SB + r] = v.z;
@@ -1768,6 +1771,7 @@ int launch_dgrad(const xt_conv_geom* cg, int B, const float* dy, const float* w,
   if (int rc = make_geom(cg, nullptr, B, &a.g)) return rc;
   a.dy = dy; a.w = w; a.x = x; a.dx = dx; a.act_prev = act_prev; a.xmask = nullptr;
   const Geom& g = a.g;
+  XT_REQUIRE((long long)g.M * g.N * 4 < (1ll << 31), "dgrad: gradient tensors of 2 GiB or more are not supported (batch %d)", B);
   if (int rc = fill_class_divs(g, &a)) return rc;
   const int hc = (g.H + g.S - 1) / g.S, wc = (g.W + g.S - 1) / g.S;   // upper bound on class extent
   const int mc = B * hc * wc;
