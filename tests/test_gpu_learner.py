@@ -1341,3 +1341,85 @@ def test_update_tail_on_graph_branches_is_bitwise_the_single_stream_tail(mode):
         got = impala(mode, use_graph)
         assert all(np.array_equal(a, b) for a, b in zip(ref[0], got[0]))
         assert np.array_equal(ref[1], got[1]) and np.array_equal(ref[2], got[2])
+
+
+@pytest.mark.parametrize("which", ["cnn84", "impala84"])
+def test_multi_step_update_parity_with_the_oracle_put_into_the_learners_state(which):
+    """Multi-step parity without drift amplification: before EVERY step the float64 oracle is put into the HIP learner's
+    state -- parameters, Adam first / second moments and step count -- and both take the step on the same minibatch.
+    From the second step on the moments carry history, Adam's update is a smooth function of the gradient, and the
+    step's parameter change must agree per tensor to 2e-4 (the first step, m = v = 0, is the sign-like one that
+    assert_update_close bounds).  Eight consecutive steps of BASELINE configs[1]'s PpoCnn at B = 64 and of
+    ImpalaCnnOpt's 84x84 net on 2 x 16-step trajectories."""
+    from xingtian_amd.model import netspec
+    from xingtian_amd.model.hip_net import HipActorCritic
+    rng = np.random.default_rng(77)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    steps = 8
+    if which == "cnn84":
+        spec = netspec.ppo_cnn((84, 84, 4), 4, (256,), "relu", True)
+        ospec = nets.ppo_cnn_spec((84, 84, 4), 4, (256,), "relu", True)
+        cfg = dict(PPO_CFG, BATCH_SIZE=64)
+        n = 64 * steps
+        obs, lab = synth_ppo_rollout(rng, n, (84, 84, 4), 4)
+        net = HipActorCritic(spec, max_batch=64, seed=0)
+        params0 = oracle_params_for(net, ospec, seed=5)
+        orc = nets.PpoLearnerOracle(ospec, params0, cfg, np.float64)
+        c = net.make_ppo_cfg(cfg)
+        dobs = net.to_device_obs(obs)
+        dl = [d(lab[0]), d(lab[1].reshape(-1)), d(lab[2].reshape(-1)), d(lab[3].reshape(-1)), d(lab[4].reshape(-1))]
+        lr = cfg["LR"]
+    else:
+        tlen, ntraj, a_dim = 16, 2, 4
+        spec = netspec.impala_cnn_opt((84, 84, 4), a_dim, 0.0, 255.0)
+        ospec = nets.impala_cnn_opt_spec((84, 84, 4), a_dim, 0.0, 255.0)
+        bs = tlen * ntraj
+        n = bs * steps
+        obs = rng.integers(0, 256, (n, 84, 84, 4)).astype(np.uint8)
+        bp = rng.standard_normal((n, a_dim)).astype(np.float32)
+        act = rng.integers(0, a_dim, n).astype(np.int32)
+        done = rng.random(n) < 0.1
+        rew = rng.choice([-1.0, 0.0, 1.0], n).astype(np.float32)
+        net = HipActorCritic(spec, max_batch=bs, seed=0)
+        params0 = oracle_params_for(net, ospec, seed=5)
+        lr = 7e-4
+        orc = nets.ImpalaLearnerOracle(ospec, params0, dict(LR=lr, grad_norm_clip=40.0, sample_batch_step=tlen,
+                                                            BATCH_SIZE=bs), np.float64)
+        c = net.make_impala_cfg(lr, 40.0, tlen)
+        dbuf = [d(obs), d(bp), d(act), d(done.astype(np.uint8)), d(rew)]
+    net.reset_optimizer()
+    worst = 0.0
+    for s in range(steps):
+        # ---- the oracle takes over the learner's state
+        w = net.get_weights(copy=True)
+        opt = net.get_optimizer_state()
+        before = {}
+        for k in orc.net.params:
+            shape = orc.net.params[k].shape
+            orc.net.params[k][...] = np.asarray(w[k], np.float64).reshape(shape)
+            orc.opt.m[k][...] = np.asarray(opt[k + "/Adam"], np.float64).reshape(shape)
+            orc.opt.v[k][...] = np.asarray(opt[k + "/Adam_1"], np.float64).reshape(shape)
+            before[k] = orc.net.params[k].copy()
+        orc.opt.t = s
+        assert int(opt["adam_step"]) == s
+        # ---- one step on both
+        if which == "cnn84":
+            sl = slice(64 * s, 64 * (s + 1))
+            idx = d(np.arange(64 * s, 64 * (s + 1), dtype=np.int32))
+            net.ppo_step(c, dobs, idx, *dl)
+            orc.step(obs[sl], lab[0][sl], lab[1][sl].astype(np.float32), lab[2][sl].astype(np.float32),
+                     lab[3][sl].astype(np.float32), lab[4][sl].astype(np.float32))
+        else:
+            sl = slice(bs * s, bs * (s + 1))
+            net.impala_step(c, dbuf[0][sl], dbuf[1][sl], dbuf[2][sl], dbuf[3][sl], dbuf[4][sl])
+            orc.step(obs[sl], bp[sl], act[sl], done[sl], rew[sl])
+        torch.cuda.synchronize()
+        got = net.get_weights(copy=True)
+        if s == 0:
+            assert_update_close(got, orc.net.params, before, lr, which)
+            continue
+        for k, ref in orc.net.params.items():
+            e = rel_err(np.asarray(got[k], np.float64).reshape(ref.shape) - before[k], ref - before[k])
+            worst = max(worst, e)
+            assert e < 2e-4, (which, s, k, e)
+    print("worst per-tensor update error over steps 2..%d (%s): %.2e" % (steps, which, worst))
