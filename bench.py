@@ -18,6 +18,8 @@ The same JSON line also carries (rank 0, one GPU):
   cpu_baseline  the torch-CPU fp32 restatement of the same update on the host cores (all cores and 1 thread) and the
                 numpy GAE per trajectory (bit-for-bit the reference's PPO.data_proc)
   sustained     the headline loop repeated for >= 2 s
+  device        diagnostic: host CPU model and the GPU's clocks / power (rocm-smi) sampled WHILE the headline loop runs,
+                after the timed region (boxes of one pool have measured 7.0 and 11 ms for the same update)
 
 N > 1: ``python bench.py --gpus N`` spawns N ranks itself (torch.distributed.run, one process per GPU, RCCL) when it
 is not already running under a launcher, and FAILS if it cannot.  Two data-parallel modes are measured in the same
@@ -238,6 +240,40 @@ def cpu_baseline_impala(w, data, max_seconds=5.0):
 
 
 # ------------------------------------------------------------------------------------------------ GPU measurements
+def device_report(busy):
+    """Diagnostic only (never fails the line): what the box is -- host CPU, and the GPU's clocks / power as rocm-smi sees them
+    WHILE `busy()` keeps the GPU running the headline loop (an idle MI355X reports its 107 MHz sleep clock).  Boxes of the
+    same pool have measured 7.0 and 11 ms for the same update; this is what tells them apart in the record."""
+    import subprocess
+    rep = {}
+    try:
+        cpu = subprocess.run("lscpu", shell=True, capture_output=True, text=True, timeout=5).stdout
+        for line in cpu.splitlines():
+            if line.startswith("Model name:"):
+                rep["host_cpu"] = line.split(":", 1)[1].strip()
+        pr = subprocess.Popen(["rocm-smi", "--showclocks", "--showpower", "--showmaxpower", "--showperflevel", "--json"],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        t0 = time.perf_counter()
+        while pr.poll() is None and time.perf_counter() - t0 < 6.0:
+            busy()
+        txt = pr.communicate(timeout=5)[0]
+        js = json.loads(txt[txt.index("{"):])
+        card = js[sorted(js)[0]]
+        for k, v in card.items():
+            kk = k.strip(" :").lower()
+            if "clock speed" in kk:
+                rep[kk.split()[0] + "_mhz_busy"] = float("".join(ch for ch in v if ch.isdigit() or ch == "."))
+            elif kk.startswith("max graphics package power"):
+                rep["power_cap_w"] = float(v)
+            elif kk.startswith("current socket graphics package power"):
+                rep["power_w_busy"] = float(v)
+            elif kk == "performance level":
+                rep["perf_level"] = v
+    except Exception as e:  # noqa: BLE001
+        rep["note"] = "rocm-smi not usable here: %r" % (e,)
+    return rep
+
+
 def layer_rooflines(net, spec, rows, obs, idx, x6=True):
     """Every layer kernel of one SGD step timed live with HIP events on the launch stream (xt_net_time_layer);
     algorithmic FLOPs = 2*M*N*K per GEMM.  The arithmetic kind a launch is priced against is
@@ -918,6 +954,12 @@ def main():
         el = time.perf_counter() - t0
         out["sustained"] = {"seconds": el, "updates": reps, "value": FRAME_SKIP * n * reps / el,
                             "ms_per_step": 1e3 * el / reps}
+
+        def busy():
+            for _ in range(10):
+                one_update()
+            torch.cuda.synchronize()
+        out["device"] = device_report(busy)
     obs, action, logp, value, reward, done = (keep[k] for k in ("obs", "action", "logp", "value", "reward", "done"))
     del keep, net
     torch.cuda.empty_cache()
