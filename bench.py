@@ -244,8 +244,8 @@ def device_report(busy):
     """Diagnostic only (never fails the line): what the box is -- host CPU, and the GPU's clocks / power as rocm-smi sees them
     WHILE `busy()` keeps the GPU running the headline loop (an idle MI355X reports its 107 MHz sleep clock).  Boxes of the
     same pool have measured 7.0 and 11 ms for the same update; this is what tells them apart in the record."""
-    import subprocess
     rep = {}
+    pr = None
     try:
         cpu = subprocess.run("lscpu", shell=True, capture_output=True, text=True, timeout=5).stdout
         for line in cpu.splitlines():
@@ -271,6 +271,8 @@ def device_report(busy):
                 rep["perf_level"] = v
     except Exception as e:  # noqa: BLE001
         rep["note"] = "rocm-smi not usable here: %r" % (e,)
+        if pr is not None and pr.poll() is None:
+            pr.kill()
     return rep
 
 
