@@ -193,7 +193,10 @@ int xt_layer_wgrad(const xt_conv_geom* g, const xt_input_xform* xf, int32_t B,
 /* Input gradient of one layer, fused with the activation gradient of the producer:
  * dx[b,iy,ix,c] = act'(x)*sum dY.W^T, where x (fp32 [B,H,W,C]) is the producer's
  * post-activation output and act_prev its activation.  Strided convs are decomposed
- * into S*S parity classes so that no MAC is spent on structural zeros. */
+ * into S*S parity classes so that no MAC is spent on structural zeros.
+ * Limit: the gradient tensor dy (B*OH*OW*N floats) must be smaller than 2 GiB -- the kernels
+ * address it with 32-bit byte offsets of buffer loads (error otherwise; the same holds for the
+ * activation and gradient tensors of a layer inside xt_net_*). */
 int xt_layer_dgrad(const xt_conv_geom* g, int32_t B, const float* dy, const float* w,
                    const float* x, int32_t act_prev, float* dx, void* stream);
 
