@@ -251,7 +251,8 @@ def device_report(busy):
         for line in cpu.splitlines():
             if line.startswith("Model name:"):
                 rep["host_cpu"] = line.split(":", 1)[1].strip()
-        pr = subprocess.Popen(["rocm-smi", "--showclocks", "--showpower", "--showmaxpower", "--showperflevel", "--json"],
+        pr = subprocess.Popen(["rocm-smi", "--showclocks", "--showpower", "--showmaxpower", "--showperflevel",
+                               "--showcomputepartition", "--showmemorypartition", "--json"],
                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
         t0 = time.perf_counter()
         while pr.poll() is None and time.perf_counter() - t0 < 6.0:
@@ -269,6 +270,8 @@ def device_report(busy):
                 rep["power_w_busy"] = float(v)
             elif kk == "performance level":
                 rep["perf_level"] = v
+            elif "partition" in kk:
+                rep[kk.replace(" ", "_")] = v
     except Exception as e:  # noqa: BLE001
         rep["note"] = "rocm-smi not usable here: %r" % (e,)
         if pr is not None and pr.poll() is None:
