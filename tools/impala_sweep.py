@@ -14,6 +14,11 @@ from xingtian_amd import lib as L  # noqa: E402
 from xingtian_amd.model import netspec  # noqa: E402
 from xingtian_amd.model.hip_net import HipActorCritic  # noqa: E402
 
+for a in sys.argv[1:]:          # python tools/impala_sweep.py path/to/lib.so [json sweep]: A/B of two builds
+    if a.endswith(".so"):
+        L.LIB_PATH = os.path.abspath(a)
+        sys.argv.remove(a)
+        break
 dev = torch.device("cuda", 0)
 d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 

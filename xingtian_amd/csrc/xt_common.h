@@ -162,6 +162,8 @@ struct GradEntry {
   long long stride;
   int zl;               // z lanes per block (power of two <= 32)
   int blk0, nblk;       // first block of the entry in THIS launch, number of blocks
+  int pre;              // > 0: the producing kernel has written the entry's `pre` squared-norm partials already (and dst is
+                        // final): the entry only reserves its slots
   int pblk0;            // slot of the entry's first squared-norm partial (position in the full table's block order: the same
                         // whether the table is reduced by one launch or by two partial ones)
 };

@@ -104,6 +104,12 @@ __device__ __forceinline__ void decode_rows(const Geom& g, const int (&m)[N], co
     rowbase[i] = (long long)sidx[i] * g.HWC + (long long)((iy0[i] * g.W + ix0[i]) * g.C);
 }
 
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
 // 32 reduction steps of the tile product on the matrix cores
 template <int TI, int TJ, int SA, int SB>
 __device__ __forceinline__ void mma_tile(const float* As, const float* Bs, int a_off, int b_off,
@@ -468,6 +474,9 @@ struct WgradArgs {
   float* out;      // [msplit][(K+1)*N]
   int msplit, mchunk;
   FastDiv d_rowq;  // wgrad_rows_body: divide by the float4 count of an input row
+  int sq_gx;       // k tiles per n tile (row length of sq_out)
+  float* sq_out;   // (msplit == 1 only, may be null) [tiles] sum of squares of each block's share of the gradient: the
+                   // partials of the global norm, so that the reduction launch does not read the tensor again
 };
 
 constexpr int kRowTab = 1024;                       // rows decoded at once into the LDS row table
@@ -735,6 +744,7 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
 
   XT_TL(3);
   float* out = p.out + (size_t)bz * ((size_t)(g.K + 1) * g.N);
+  float sq = 0.f;
 #pragma unroll
   for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
@@ -743,7 +753,7 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int kr = i0 + (wi * TI + ti) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (kr < g.K && n < g.N) out[(size_t)kr * g.N + n] = acc[ti][tj][r];
+        if (kr < g.K && n < g.N) { out[(size_t)kr * g.N + n] = acc[ti][tj][r]; sq += acc[ti][tj][r] * acc[ti][tj][r]; }
       }
     }
   if (do_bias) {
@@ -754,8 +764,15 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
 #pragma unroll
       for (int q = 0; q < RG; ++q) sum += smem[q * BJ + t];
       const int n = j0 + t;
-      if (n < g.N) out[(size_t)g.K * g.N + n] = sum;
+      if (n < g.N) { out[(size_t)g.K * g.N + n] = sum; sq += sum * sum; }
     }
+  }
+  if (p.sq_out) {      // (single slab: `out` IS the gradient) this block's share of the squared global norm, fixed order
+    sq = wave_sum(sq);
+    __syncthreads();
+    if (lane == 0) smem[wave] = sq;
+    __syncthreads();
+    if (t == 0) p.sq_out[by * p.sq_gx + bx] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
   }
   XT_TL(4);
   XT_TL_DRAIN(5);
@@ -1739,6 +1756,7 @@ int launch_wgrad(const xt_conv_geom* cg, const xt_input_xform* xf, int B, const 
   XT_REQUIRE(msplit == 1 || slabs != nullptr, "xt_layer_wgrad: msplit>1 needs a slab buffer");
   a.msplit = msplit; a.mchunk = chunk;
   a.out = msplit == 1 ? dwb : slabs;
+  a.sq_out = nullptr; a.sq_gx = 0;
   const int K = a.g.K, N = a.g.N;
   const bool pad = is_padded(a.g);
 #define XT_WG(BI, BJ, WI, WJ)                                                                               \
@@ -1795,8 +1813,10 @@ int launch_dgrad(const xt_conv_geom* cg, int B, const float* dy, const float* w,
 // PRE-activation when its activation is not monotonic (act_needs_preact), else its output x_in
 int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const float* dy, const float* w,
                      int act_prev, float* dx, float* dwb, float* slabs, int msplit, const HeadWgArgs* hw,
-                     int* msplit_out, hipStream_t st, const uint32_t* xmask, int slab_cap, const float* x_grad) {
+                     int* msplit_out, hipStream_t st, const uint32_t* xmask, int slab_cap, const float* x_grad,
+                     float* sq_partials, int* npre_out) {
   if (!x_grad) x_grad = x_in;
+  if (npre_out) *npre_out = 0;
   BwdLayerArgs a;
   if (int rc = make_geom(cg, nullptr, B, &a.wg.g)) return rc;
   a.dg.g = a.wg.g;
@@ -1806,6 +1826,7 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
              "bwd_layer: activation / gradient tensors of 2 GiB or more are not supported (batch %d)", B);
   // ---- wgrad part
   a.wg.in = x_in; a.wg.idx = nullptr; a.wg.dy = dy;
+  a.wg.sq_out = nullptr; a.wg.sq_gx = 0;
   if (msplit < 1) msplit = 1;
   int chunk;
   msplit = pick_ksplit_chunk(g.M, msplit, &chunk);
@@ -1965,6 +1986,13 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
     }
   }
   const int total2 = a.n_wg + a.n_dg + a.n_hw;
+  // a weight gradient written by ONE slab per tile is final: its blocks also leave their share of the squared global
+  // norm, which saves the reduction launch a read of the whole tensor (PpoCnn's Dense layer: 6.4 of its 29 MB)
+  const bool generic_wg = !wrows && !s2fused && !s2c16 && !halo_inst && a.dg_direct != 2;
+  if (sq_partials && npre_out && generic_wg && a.wg.msplit == 1 && a.wg_gz == 1) {
+    a.wg.sq_out = sq_partials; a.wg.sq_gx = a.wg_gx;
+    *npre_out = a.wg_gx * a.wg_gy;
+  }
 #define XT_BWD2(WBI, WBJ, WWI, WWJ, DBI, DBJ, DWI, DWJ, X6V)                                                    \
   do {                                                                                                          \
     if (pad) hipLaunchKernelGGL((igemm_bwd_layer_kernel<WBI, WBJ, WWI, WWJ, true, DBI, DBJ, DWI, DWJ, 0, 0, X6V>), \

@@ -38,7 +38,7 @@ int launch_fwd(const xt_conv_geom*, const xt_input_xform*, int, const void*, con
                uint32_t* relu_mask = nullptr, int* mask_written = nullptr);
 int launch_bwd_layer(const xt_conv_geom*, int, const float*, const float*, const float*, int, float*, float*, float*,
                      int, const HeadWgArgs*, int*, hipStream_t, const uint32_t* xmask = nullptr, int slab_cap = 0,
-                     const float* x_grad = nullptr);
+                     const float* x_grad = nullptr, float* sq_partials = nullptr, int* npre_out = nullptr);
 int launch_act_apply(const float* z, float* y, long long count, int act, hipStream_t st);
 int launch_wgrad(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*, const float*,
                  float*, float*, int, hipStream_t, int reduce_now = 1, int* msplit_out = nullptr, int slab_cap = 0);
@@ -73,6 +73,7 @@ struct Layer {
   int64_t slab_off;            // this layer's wgrad slabs
   int64_t part_off;            // split-K partials of a trunk's last layer (deferred finish), else -1
   int last_msplit, last_ksplit;
+  int last_npre = 0;      // squared-norm partials the last backward launch of this layer left in the norm scratch (0: none)
   int slab_cap;                // number of slabs the region can hold
   int64_t mask_off;            // relu sign mask of this layer's output (one word per position), else -1
   int mask_valid;              // the last forward of this layer wrote the mask
@@ -244,6 +245,8 @@ static int trunk_backward(xt_net* n, const void* obs, const int32_t* idx, int B,
                           const AfterFirstBwd* after_first = nullptr) {
   bool heads_done = false;
   bool first_done = false;
+  const bool pre_ok = tuning().finalize_ticket == 0;      // (the last-block finalize form reads one partial per block)
+  for (auto& L : n->layers) L.last_npre = 0;
   for (int tr = 0; tr < n->n_trunks; ++tr)
     for (int l = n->t_end[tr] - 1; l >= n->t_begin[tr]; --l) {
       const bool first = (l == n->t_begin[tr]);
@@ -272,7 +275,9 @@ static int trunk_backward(xt_net* n, const void* obs, const int32_t* idx, int B,
                                     Lprev.g.act, n->ws + Lprev.dact_off, n->grads + L.poff, n->ws + L.slab_off,
                                     wgrad_split(L, B), hwp, &L.last_msplit, st,
                                     Lprev.mask_valid ? reinterpret_cast<const uint32_t*>(n->ws + Lprev.mask_off) : nullptr,
-                                    L.slab_cap, Lprev.z_off >= 0 ? n->ws + Lprev.z_off : nullptr))
+                                    L.slab_cap, Lprev.z_off >= 0 ? n->ws + Lprev.z_off : nullptr,
+                                    // (the last layer's entry owns the FIRST partial slots: see grads_finish)
+                                    pre_ok && l == (int)n->layers.size() - 1 ? n->ws + n->off_norm : nullptr, &L.last_npre))
         return rc;
       if (!first_done && after_first) { if (int rc = after_first->fn(after_first->arg)) return rc; }
       first_done = true;
@@ -296,6 +301,7 @@ static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t s
     GradEntry& E = tab.e[tab.n++];
     E.count = (L.K + 1) * L.g.N;
     E.dst = n->grads + L.poff;
+    E.pre = (li == l_last && L.last_msplit == 1) ? L.last_npre : 0;
     E.nslab = L.last_msplit;
     E.src = (L.last_msplit > 1) ? n->ws + L.slab_off : E.dst;
     E.stride = E.count;
@@ -303,19 +309,19 @@ static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t s
   {
     first_bucket |= 1u << tab.n;
     GradEntry& E = tab.e[tab.n++];
-    E.count = F * A + A; E.dst = n->grads + n->pi_off; E.src = n->ws + n->off_hslab_pi;
+    E.pre = 0; E.count = F * A + A; E.dst = n->grads + n->pi_off; E.src = n->ws + n->off_hslab_pi;
     E.nslab = n->head_chunks; E.stride = n->hstride_pi;
   }
   {
     first_bucket |= 1u << tab.n;
     GradEntry& E = tab.e[tab.n++];
-    E.count = F + 1; E.dst = n->grads + n->v_off; E.src = n->ws + n->off_hslab_v;
+    E.pre = 0; E.count = F + 1; E.dst = n->grads + n->v_off; E.src = n->ws + n->off_hslab_v;
     E.nslab = n->head_chunks; E.stride = n->hstride_v;
   }
   if (n->action_type == XT_ACTION_DIAG_GAUSSIAN) {   // pi_logstd: the per-sample rows are the partial slabs
     first_bucket |= 1u << tab.n;
     GradEntry& E = tab.e[tab.n++];
-    E.count = A; E.dst = n->grads + n->logstd_off; E.src = n->ws + n->off_dls;
+    E.pre = 0; E.count = A; E.dst = n->grads + n->logstd_off; E.src = n->ws + n->off_dls;
     E.nslab = n->dls_rows; E.stride = align4(A);
   }
   const unsigned all = (1u << tab.n) - 1u;

@@ -424,7 +424,7 @@ int launch_grads_finish(GradTable* tab, float* partial, int max_partials, int* n
     E.zl = zl;
     const int cols = 256 / zl;
     E.pblk0 = blk;
-    E.nblk = ((E.count + 3) / 4 + cols - 1) / cols;
+    E.nblk = E.pre > 0 ? E.pre : ((E.count + 3) / 4 + cols - 1) / cols;
     blk += E.nblk;
     XT_REQUIRE((((uintptr_t)E.src | (uintptr_t)E.dst) & 15) == 0 && (E.stride % 4) == 0,
                "grads_finish: entry %d not 16-byte aligned", i);
@@ -437,13 +437,15 @@ int launch_grads_finish(GradTable* tab, float* partial, int max_partials, int* n
   int grid = 0;
   for (int i = 0; i < tab->n; ++i) {
     if (select && !((select >> i) & 1u)) continue;
+    if (tab->e[i].pre > 0) continue;      // reduced and squared by its producer
     GradEntry& E = sub.e[sub.n++];
     E = tab->e[i];
     E.blk0 = grid;
     grid += E.nblk;
   }
   XT_REQUIRE(grid > 0, "grads_finish: empty selection");
-  XT_REQUIRE(f.enable != 1 || grid == blk, "grads_finish: the last-block finalize form needs the whole table in one launch");
+  XT_REQUIRE(f.enable != 1 || grid == blk, "grads_finish: the last-block finalize form needs the whole table in one launch "
+                                           "(no partial launches, no pre-reduced entries)");
   hipLaunchKernelGGL(grads_finish_kernel, dim3(grid + (f.enable == 2 ? 1 : 0)), dim3(256), 0, st, sub, partial, f);
   XT_LAUNCH_CHECK();
   *nblocks_out = blk;
