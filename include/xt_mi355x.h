@@ -108,6 +108,9 @@ typedef struct xt_tuning {
                                     side stream right after the first backward launch, under the conv backward;
                                  2: Adam is split into [first layer] on the compute stream and [everything else] on the side
                                     stream, which the NEXT step's first-layer forward overlaps (joined before layer 2)       */
+  int32_t tail_fused;         /* 1: slab reduction + global norm + clip + Adam in ONE launch: the thread that reduced a group of
+                                 elements also updates it, only the squared-norm partials and the step size cross a grid
+                                 barrier (all workgroups resident, checked; Adam only; ABI >= 8)                          */
 } xt_tuning;
 int xt_tuning_get(xt_tuning* out);
 int xt_tuning_set(const xt_tuning* in);

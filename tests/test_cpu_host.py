@@ -38,7 +38,7 @@ def test_tuning_struct_replaces_the_environment_switches():
     t = lib.get_tuning()
     assert t["bf16x6"] == 1 and t["conv1_bf16x3"] == 1 and t["conv1_waves"] == 8 and t["bwd_fit_slots"] == 768
     assert t["fwd_split_target"] == 256 and t["wgrad_split_target"] == 512 and t["finalize_ticket"] == 0 and t["fwd_tiled_valid"] == 1 \
-        and t["wgrad_rows"] == 4 and t["fwd_prefetch_all"] == 0 and t["fwd_xcd_chunk"] == 1 and t["bwd_deep_prefetch"] == 1 and t["fwd_four_groups"] == 1 and t["reduce_deep_lanes"] == 128 and t["tail_overlap"] == 0
+        and t["wgrad_rows"] == 4 and t["fwd_prefetch_all"] == 0 and t["fwd_xcd_chunk"] == 1 and t["bwd_deep_prefetch"] == 1 and t["fwd_four_groups"] == 1 and t["reduce_deep_lanes"] == 128 and t["tail_overlap"] == 0 and t["tail_fused"] == 0
     old = lib.set_tuning(bf16x6=0, direct_waves=1024)
     try:
         assert old == {"bf16x6": 1, "direct_waves": 1536}

@@ -1423,3 +1423,70 @@ def test_multi_step_update_parity_with_the_oracle_put_into_the_learners_state(wh
             worst = max(worst, e)
             assert e < 2e-4, (which, s, k, e)
     print("worst per-tensor update error over steps 2..%d (%s): %.2e" % (steps, which, worst))
+
+
+def test_fused_update_tail_is_bitwise_the_two_launch_tail():
+    """xt_tuning.tail_fused: slab reduction + global norm + clip + Adam in one launch behind a grid barrier.  Same partial
+    slots, same fixed-order norm, the same update formula per element -> bit-identical parameters, moments, state and
+    losses as the reduction launch + Adam launch, eager and replayed, PPO (incl. a short last minibatch) and IMPALA."""
+    from xingtian_amd import lib as L
+    from xingtian_amd.model import netspec
+    from xingtian_amd.model.hip_net import HipActorCritic
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    rng = np.random.default_rng(6)
+    spec = netspec.ppo_cnn((84, 84, 4), 4, (256,), "relu", True)
+    cfg = dict(PPO_CFG, BATCH_SIZE=64, NUM_SGD_ITER=2)
+    n = 160
+    obs, lab = synth_ppo_rollout(rng, n, (84, 84, 4), 4)
+    perms = np.stack([rng.permutation(n) for _ in range(2)]).astype(np.int32)
+
+    def ppo(knob, use_graph):
+        old = L.set_tuning(tail_fused=knob)
+        try:
+            net = HipActorCritic(spec, max_batch=64, seed=0)
+            bufs = [net.to_device_obs(obs), d(perms), d(lab[0]), d(lab[1].reshape(-1)), d(lab[2].reshape(-1)),
+                    d(lab[3].reshape(-1)), d(lab[4].reshape(-1))]
+            out = []
+            for _ in range(3):
+                acc = net.ppo_train(net.make_ppo_cfg(cfg), *bufs, use_graph=use_graph)
+                torch.cuda.synchronize()
+                out.append(acc.cpu().numpy().copy())
+            return (out, net.params.cpu().numpy().copy(), net.adam_m.cpu().numpy().copy(), net.adam_v.cpu().numpy().copy(),
+                    net.adam_state.cpu().numpy().copy())
+        finally:
+            L.set_tuning(**old)
+
+    ref = ppo(0, True)
+    for use_graph in (False, True):
+        got = ppo(1, use_graph)
+        assert all(np.array_equal(a, b) for a, b in zip(ref[0], got[0]))
+        for a, b in zip(ref[1:], got[1:]):
+            assert np.array_equal(a, b)
+
+    tlen, ntraj, a_dim, bs = 10, 5, 6, 20
+    m = tlen * ntraj
+    ispec = netspec.impala_cnn_opt((42, 42, 4), a_dim, 128.0, 128.0)
+    bufs = [d(rng.integers(0, 256, (m, 42, 42, 4)).astype(np.uint8)), d(rng.standard_normal((m, a_dim)).astype(np.float32)),
+            d(rng.integers(0, a_dim, m).astype(np.int32)), d((rng.random(m) < 0.1).astype(np.uint8)),
+            d(rng.choice([-2.0, 0.0, 1.0], m).astype(np.float32))]
+
+    def impala(knob, use_graph):
+        old = L.set_tuning(tail_fused=knob)
+        try:
+            net = HipActorCritic(ispec, max_batch=bs, seed=0)
+            c = net.make_impala_cfg(7e-4, 40.0, tlen)
+            out = []
+            for _ in range(3):
+                acc = net.impala_train(c, bufs[0], bs, *bufs[1:], use_graph=use_graph)
+                torch.cuda.synchronize()
+                out.append(acc.cpu().numpy().copy())
+            return out, net.params.cpu().numpy().copy(), net.adam_m.cpu().numpy().copy(), net.adam_state.cpu().numpy().copy()
+        finally:
+            L.set_tuning(**old)
+
+    ref = impala(0, True)
+    for use_graph in (False, True):
+        got = impala(1, use_graph)
+        assert all(np.array_equal(a, b) for a, b in zip(ref[0], got[0]))
+        for a, b in zip(ref[1:], got[1:]):
+            assert np.array_equal(a, b)

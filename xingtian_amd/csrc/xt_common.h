@@ -163,7 +163,7 @@ struct GradEntry {
   int zl;               // z lanes per block (power of two <= 32)
   int blk0, nblk;       // first block of the entry in THIS launch, number of blocks
   int pre;              // > 0: the producing kernel has written the entry's `pre` squared-norm partials already (and dst is
-                        // final): the entry only reserves its slots
+                        // final): the entry only reserves its slots (and, in the fused tail, its blocks only apply the update)
   int pblk0;            // slot of the entry's first squared-norm partial (position in the full table's block order: the same
                         // whether the table is reduced by one launch or by two partial ones)
 };
@@ -213,12 +213,19 @@ struct ImpalaLossArgs {
 
 // norm finalisation executed by the last block of grads_finish_kernel (ticket counter)
 struct FinalizeArgs {
-  int enable;
+  int enable;                // 1: last block finalises (ticket); 2: an extra block does the norm-independent scalars;
+                             // 3: as 2, and the launch ALSO applies Adam behind a grid barrier (fused tail, `ap`)
   unsigned int* counter;     // zero before the first launch; the last block resets it
   float clip_norm, grad_scale, lr, beta1, beta2;
   float* state;
   LossArgs loss;
   const float* lr_dev;       // != nullptr: the step size is read from device memory (lr_schedule inside a replayed hipGraph)
+  struct {                   // enable == 3
+    float *params, *m, *v;
+    const float* grads;      // base of the flat gradient buffer (entry dst - grads = offset into params / m / v)
+    float eps;
+    int npartials;           // squared-norm partial slots of the whole table
+  } ap;
 };
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

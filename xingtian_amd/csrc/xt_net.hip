@@ -29,7 +29,7 @@ xt_tuning& tuning() {
                         /*direct_waves*/ 1536, /*direct_max_waves*/ 8, /*direct_tile64_tiles*/ 3072,
                         /*fwd_split_target*/ 256, /*wgrad_split_target*/ 512, /*reduce_z_lanes*/ 8,
                         /*defer_splitk*/ 1, /*finalize_ticket*/ 0, /*fwd_tiled_valid*/ 1, /*wgrad_rows*/ 4, /*fwd_prefetch_all*/ 0, /*bwd_deep_prefetch*/ 1, /*fwd_four_groups*/ 1, /*reduce_deep_lanes*/ 128, /*fwd_xcd_chunk*/ 1,
-                        /*tail_overlap*/ 0};
+                        /*tail_overlap*/ 0, /*tail_fused*/ 0};
   return t;
 }
 
@@ -46,6 +46,8 @@ int launch_dgrad(const xt_conv_geom*, int, const float*, const float*, const flo
 int launch_global_norm(const float*, long long, float, float, float, float, float, int, float*, float*, hipStream_t);
 int launch_grads_finish(GradTable*, float*, int, int*, const FinalizeArgs*, hipStream_t, unsigned select = 0,
                         unsigned early = 0);
+int grads_finish_resident_blocks();
+int grads_finish_fused_grid(const GradTable*);
 int launch_norm_finalize(const float*, int, float, float, float, float, float, int, float*, const LossArgs*, hipStream_t);
 int launch_ppo_heads_fused(const PpoHeadArgs&, hipStream_t);
 int launch_adam_clip(float*, const float*, float*, float*, long long, float, float, float, float*, const float*, int,
@@ -288,7 +290,9 @@ static int trunk_backward(xt_net* n, const void* obs, const int32_t* idx, int B,
 // ONE kernel: every slab reduction (trunk layers + heads) + the squared-norm partials
 // part 0: everything; part 1: the last trunk layer + the heads (the first gradients the backward produces, 95 % of
 // PpoCnn's parameters); part 2: the remaining layers.  Parts 1 / 2 serve the overlapped data-parallel exchange.
-static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t st, int part = 0) {
+// fin->enable == 3 asks for the fused tail (reduction + norm + clip + Adam in one launch); *fused_out tells whether it ran
+// that way (it is downgraded to enable == 2 when its grid could not be resident at once)
+static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t st, int part = 0, bool* fused_out = nullptr) {
   const int F = n->feat, A = n->A;
   GradTable tab;
   tab.n = 0;
@@ -328,6 +332,18 @@ static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t s
   // (part 1 runs before the other layers' backward launches have set their slab counts: its entries own the FIRST
   // partial slots, which depend on nothing else)
   const unsigned select = part == 1 ? first_bucket : part == 2 ? (all & ~first_bucket) : 0u;
+  FinalizeArgs f2;
+  if (fused_out) *fused_out = false;
+  if (fin && fin->enable == 3) {
+    f2 = *fin;
+    const int cap = grads_finish_resident_blocks();
+    if (part == 0 && cap > 0 && grads_finish_fused_grid(&tab) <= cap) {
+      if (fused_out) *fused_out = true;
+    } else {
+      f2.enable = 2;
+    }
+    fin = &f2;
+  }
   return launch_grads_finish(&tab, n->ws + n->off_norm, kMaxNormPartials, &n->norm_blocks, fin, st, select, first_bucket);
 }
 
@@ -483,10 +499,18 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
     fin.enable = tail_mode; fin.counter = reinterpret_cast<unsigned int*>(n->ws + n->off_counter);
     fin.clip_norm = c->max_grad_norm; fin.grad_scale = c->grad_scale; fin.lr = c->lr; fin.beta1 = c->beta1;
     fin.beta2 = c->beta2; fin.state = n->state; fin.loss = la;
+    bool fused = false;
     if (tfk.done) {
       XT_CHECK_HIP(hipStreamWaitEvent(st, n->tail_join, 0));
       if (int rc = grads_finish(n, B, &fin, st, 2)) return rc;
-    } else if (int rc = grads_finish(n, B, &fin, st)) return rc;
+    } else {
+      if (tail_mode == 2 && !tov && tuning().tail_fused) {
+        fin.enable = 3;
+        fin.ap.params = n->params; fin.ap.m = n->m; fin.ap.v = n->v; fin.ap.grads = n->grads; fin.ap.eps = c->eps;
+      }
+      if (int rc = grads_finish(n, B, &fin, st, 0, &fused)) return rc;
+    }
+    if (fused) return 0;
     if (tov & 2) {
       if (int rc = net_apply_split(n, c->beta1, c->beta2, c->eps, c->max_grad_norm, c->grad_scale, st)) return rc;
       return defer_join ? 0 : join_pending_update(n, st);
@@ -599,10 +623,18 @@ static int impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int n
   if (loss_pending) {
     fin.loss.traj_loss = lo + 4; fin.loss.n_traj = ntraj; fin.loss.out = loss_out ? loss_out : lo; fin.loss.acc = loss_acc;
   }
+  bool fused_tail = false;
   if (tfk.done) {
     XT_CHECK_HIP(hipStreamWaitEvent(st, n->tail_join, 0));
     if (int rc = grads_finish(n, nfr, &fin, st, 2)) return rc;
-  } else if (int rc = grads_finish(n, nfr, &fin, st)) return rc;
+  } else {
+    if (!tov && tuning().tail_fused && c->opt_type == XT_OPT_ADAM) {
+      fin.enable = 3; fin.counter = reinterpret_cast<unsigned int*>(n->ws + n->off_counter);
+      fin.ap.params = n->params; fin.ap.m = n->m; fin.ap.v = n->v; fin.ap.grads = n->grads; fin.ap.eps = c->eps;
+    }
+    if (int rc = grads_finish(n, nfr, &fin, st, 0, &fused_tail)) return rc;
+  }
+  if (fused_tail) return 0;
   if (tov & 2) {
     if (int rc = net_apply_split(n, c->beta1, c->beta2, c->eps, c->grad_norm_clip, c->grad_scale, st)) return rc;
     return defer_join ? 0 : join_pending_update(n, st);

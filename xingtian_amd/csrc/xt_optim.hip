@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "xt_common.h"
+#include <atomic>
 
 namespace xt {
 
@@ -14,6 +15,32 @@ __device__ void finalize_body(const float* partial, int nblocks, float clip_norm
                               float beta1, float beta2, int advance, float* state, const LossArgs& la, double* sh);
 
 __device__ void loss_reduce_body(const LossArgs& la, double* sh);
+__device__ double sqnorm_total_coherent(const float* partial, int nblocks, double* sh);
+__device__ __forceinline__ void clip_scale(double sq, float clip_norm, float grad_scale, float* gnorm, float* scale);
+
+// Grid barrier of the fused tail (all blocks of the launch are resident: the host checks).  Arrivals go through 64
+// sub-counters (one 128-byte line each) and a top counter -- ~1500 same-address atomics would serialise at ~12 ns each --,
+// the last arrival resets them and flips the sense word the others spin on (bounded: a launch that could not be
+// co-resident would otherwise hang the GPU).
+__device__ __forceinline__ void grid_arrive(unsigned int* counter, unsigned int* flag, unsigned int sense) {
+  const unsigned nsub = gridDim.x < 64u ? gridDim.x : 64u;
+  const unsigned sub = blockIdx.x % nsub;
+  const unsigned cnt = (gridDim.x - sub + nsub - 1u) / nsub;
+  if (__hip_atomic_fetch_add(counter + 32u * (1u + sub), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cnt - 1u) {
+    __hip_atomic_store(counter + 32u * (1u + sub), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsub - 1u) {
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(flag, sense ^ 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+__device__ __forceinline__ void grid_wait(unsigned int* flag, unsigned int sense) {
+  for (unsigned it = 0; it < (1u << 24); ++it) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sense) return;
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
 __device__ __forceinline__ void adam_advance(float* state, float lr, float beta1, float beta2);
 __device__ void finalize_body(const float* partial, int nblocks, float clip_norm, float grad_scale, float lr,
                               float beta1, float beta2, int advance, float* state, const LossArgs& la, double* sh);
@@ -23,13 +50,25 @@ __global__ __launch_bounds__(256) void grads_finish_kernel(const GradTable tab, 
   __shared__ float4 sh4[256];
   __shared__ float shs[256];
   __shared__ int s_last;
+  __shared__ unsigned int s_sense;
   XT_TL(0);
   XT_TL_ROLE(60);
-  if (fin.enable == 2 && blockIdx.x == gridDim.x - 1) {
+  // fused tail: the barrier flips a sense word; every block reads the old sense BEFORE it arrives (the flip needs all arrivals)
+  unsigned int* const bar_flag = fin.counter ? fin.counter + 32u * 65u : nullptr;
+  if (fin.enable == 3 && threadIdx.x == 0)
+    s_sense = __hip_atomic_load(bar_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (fin.enable >= 2 && blockIdx.x == gridDim.x - 1) {
     // extra block of the "Adam computes the clip scale itself" form: everything of the old last-block finalize
     // that does not depend on the gradient norm (loss scalars, beta powers, step size) -- off the critical path
     loss_reduce_body(fin.loss, reinterpret_cast<double*>(sh4));
-    if (threadIdx.x == 0) adam_advance(fin.state, fin.lr_dev ? fin.lr_dev[0] : fin.lr, fin.beta1, fin.beta2);
+    if (threadIdx.x == 0) {
+      adam_advance(fin.state, fin.lr_dev ? fin.lr_dev[0] : fin.lr, fin.beta1, fin.beta2);
+      if (fin.enable == 3) {      // the step size crosses the barrier: write-through, drained, then arrive (and leave)
+        __hip_atomic_store(fin.state + 3, fin.state[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        grid_arrive(fin.counter, bar_flag, s_sense);
+      }
+    }
     return;
   }
   int ei = 0;
@@ -96,6 +135,75 @@ __global__ __launch_bounds__(256) void grads_finish_kernel(const GradTable tab, 
     __syncthreads();
   }
   XT_TL(2);
+  if (fin.enable == 3) {
+    // ---- fused tail.  The thread that holds a reduced group of four elements also applies Adam to it, so only the
+    // squared-norm partials (4 bytes per block, write-through) and the step size cross the grid barrier -- no gradient
+    // is read from another block.  The parameter / moment loads are issued BEFORE the wait.
+    const bool holder = (z0 == 0 && active);
+    const long long off = (long long)(E.dst - fin.ap.grads) + e0;
+    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), mv = pv, vv = pv;
+    if (holder) {
+      if (full) {
+        pv = *reinterpret_cast<const float4*>(fin.ap.params + off);
+        mv = *reinterpret_cast<const float4*>(fin.ap.m + off);
+        vv = *reinterpret_cast<const float4*>(fin.ap.v + off);
+      } else {
+        pv.x = fin.ap.params[off]; mv.x = fin.ap.m[off]; vv.x = fin.ap.v[off];
+        if (e0 + 1 < E.count) { pv.y = fin.ap.params[off + 1]; mv.y = fin.ap.m[off + 1]; vv.y = fin.ap.v[off + 1]; }
+        if (e0 + 2 < E.count) { pv.z = fin.ap.params[off + 2]; mv.z = fin.ap.m[off + 2]; vv.z = fin.ap.v[off + 2]; }
+      }
+    }
+    float4 gr = sh4[col];      // (holders: the reduced gradient, recomputed from the LDS copies in the same order)
+    if (holder) {
+      for (int z = 1; z < zl; ++z) {
+        const float4 q = sh4[z * cols + col];
+        gr.x += q.x; gr.y += q.y; gr.z += q.z; gr.w += q.w;
+      }
+    }
+    if (t == 0) {
+      if (E.pre == 0) {
+        __hip_atomic_store(partial + E.pblk0 + ((int)blockIdx.x - E.blk0), shs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      grid_arrive(fin.counter, bar_flag, s_sense);
+      grid_wait(bar_flag, s_sense);
+    }
+    __syncthreads();
+    double* shd = reinterpret_cast<double*>(sh4);
+    const double sqt = sqnorm_total_coherent(partial, fin.ap.npartials, shd);
+    if (t == 0) {
+      float gnorm, sc;
+      clip_scale(sqt, fin.clip_norm, fin.grad_scale, &gnorm, &sc);
+      shs[0] = sc;
+      shs[1] = __hip_atomic_load(fin.state + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (blockIdx.x == 0) { fin.state[2] = sc; fin.state[4] = gnorm; }
+    }
+    __syncthreads();
+    const float scale = shs[0], alpha = shs[1];
+    const float omb1 = 1.f - fin.beta1, omb2 = 1.f - fin.beta2, eps = fin.ap.eps;
+    if (holder) {
+#define XT_ADAMF(c)                                   \
+      {                                               \
+        const float gg = gr.c * scale;                \
+        mv.c += (gg - mv.c) * omb1;                   \
+        vv.c += (gg * gg - vv.c) * omb2;              \
+        pv.c -= (mv.c * alpha) / (sqrtf(vv.c) + eps); \
+      }
+      XT_ADAMF(x) XT_ADAMF(y) XT_ADAMF(z) XT_ADAMF(w)
+#undef XT_ADAMF
+      if (full) {
+        *reinterpret_cast<float4*>(fin.ap.params + off) = pv;
+        *reinterpret_cast<float4*>(fin.ap.m + off) = mv;
+        *reinterpret_cast<float4*>(fin.ap.v + off) = vv;
+      } else {
+        fin.ap.params[off] = pv.x; fin.ap.m[off] = mv.x; fin.ap.v[off] = vv.x;
+        if (e0 + 1 < E.count) { fin.ap.params[off + 1] = pv.y; fin.ap.m[off + 1] = mv.y; fin.ap.v[off + 1] = vv.y; }
+        if (e0 + 2 < E.count) { fin.ap.params[off + 2] = pv.z; fin.ap.m[off + 2] = mv.z; fin.ap.v[off + 2] = vv.z; }
+      }
+    }
+    XT_TL(4);
+    return;
+  }
   if (fin.enable != 1) {
     if (t == 0) partial[E.pblk0 + ((int)blockIdx.x - E.blk0)] = shs[0];
     return;
@@ -235,6 +343,30 @@ __device__ double sqnorm_total(const float* partial, int nblocks, double* sh) {
     for (int u = 0; u < 8; ++u) {
       const int i = base + 256 * u;
       q[u] = partial[i < nblocks ? i : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (base + 256 * u < nblocks) s += (double)q[u];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  const double tot = sh[0];
+  __syncthreads();
+  return tot;
+}
+// the same sum with agent-scope loads: the partials were written (write-through) by other blocks of the SAME launch
+__device__ double sqnorm_total_coherent(const float* partial, int nblocks, double* sh) {
+  double s = 0.0;
+  for (int base = threadIdx.x; base < nblocks; base += 256 * 8) {
+    float q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + 256 * u;
+      q[u] = __hip_atomic_load(partial + (i < nblocks ? i : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -424,32 +556,67 @@ int launch_grads_finish(GradTable* tab, float* partial, int max_partials, int* n
     E.zl = zl;
     const int cols = 256 / zl;
     E.pblk0 = blk;
-    E.nblk = E.pre > 0 ? E.pre : ((E.count + 3) / 4 + cols - 1) / cols;
-    blk += E.nblk;
+    E.nblk = ((E.count + 3) / 4 + cols - 1) / cols;
+    blk += E.pre > 0 ? E.pre : E.nblk;        // (a pre-reduced entry owns as many slots as its producer had blocks)
     XT_REQUIRE((((uintptr_t)E.src | (uintptr_t)E.dst) & 15) == 0 && (E.stride % 4) == 0,
                "grads_finish: entry %d not 16-byte aligned", i);
   }
   XT_REQUIRE(blk > 0 && blk <= max_partials, "grads_finish: %d partial blocks > scratch %d", blk, max_partials);
   FinalizeArgs f;
   if (fin) f = *fin; else { memset(&f, 0, sizeof(f)); }
+  const bool fused = (f.enable == 3);
   GradTable sub;
   sub.n = 0;
   int grid = 0;
+  bool any_pre = false;
   for (int i = 0; i < tab->n; ++i) {
     if (select && !((select >> i) & 1u)) continue;
-    if (tab->e[i].pre > 0) continue;      // reduced and squared by its producer
+    if (tab->e[i].pre > 0) {
+      any_pre = true;
+      if (!fused) continue;               // reduced and squared by its producer; the fused tail still has to update it
+    }
     GradEntry& E = sub.e[sub.n++];
     E = tab->e[i];
     E.blk0 = grid;
     grid += E.nblk;
   }
   XT_REQUIRE(grid > 0, "grads_finish: empty selection");
-  XT_REQUIRE(f.enable != 1 || grid == blk, "grads_finish: the last-block finalize form needs the whole table in one launch "
-                                           "(no partial launches, no pre-reduced entries)");
-  hipLaunchKernelGGL(grads_finish_kernel, dim3(grid + (f.enable == 2 ? 1 : 0)), dim3(256), 0, st, sub, partial, f);
+  XT_REQUIRE(f.enable != 1 || (!any_pre && !select),
+             "grads_finish: the last-block finalize form needs the whole table in one launch (no partial launches, no "
+             "pre-reduced entries)");
+  XT_REQUIRE(!fused || (!select && f.counter), "grads_finish: the fused tail takes the whole table and a barrier scratch");
+  if (fused) f.ap.npartials = blk;
+  hipLaunchKernelGGL(grads_finish_kernel, dim3(grid + (f.enable >= 2 ? 1 : 0)), dim3(256), 0, st, sub, partial, f);
   XT_LAUNCH_CHECK();
   *nblocks_out = blk;
   return 0;
+}
+
+// how many workgroups of the fused tail can be resident at once on this device (its grid barrier needs all of them)
+int grads_finish_resident_blocks() {
+  static std::atomic<int> cached{0};
+  int v = cached.load();
+  if (v > 0) return v;
+  int per_cu = 0, cus = 0, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, grads_finish_kernel, 256, 0) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  v = per_cu * cus;
+  cached.store(v);
+  return v;
+}
+// blocks the fused tail would launch for this table (pre-reduced entries included, + the scalar block)
+int grads_finish_fused_grid(const GradTable* tab) {
+  int grid = 1;
+  for (int i = 0; i < tab->n; ++i) {
+    const GradEntry& E = tab->e[i];
+    int zl = 1;
+    const int zcap = (tuning().reduce_deep_lanes > 0 && E.nslab >= tuning().reduce_deep_lanes) ? 32 : tuning().reduce_z_lanes;
+    while (zl < E.nslab && zl < zcap) zl <<= 1;
+    const int cols = 256 / zl;
+    grid += ((E.count + 3) / 4 + cols - 1) / cols;
+  }
+  return grid;
 }
 
 int launch_rmsprop_clip(float* param, const float* grad, float* mg, float* ms, long long count, float lr, float decay,
