@@ -101,8 +101,9 @@ class HipActorCritic(object):
                                      host=[torch.empty(self.params.shape, dtype=torch.float32, pin_memory=True)
                                            for _ in range(self.SNAP_SLOTS)])
             snap["events"] = [torch.cuda.Event() for _ in range(self.SNAP_SLOTS)]
+            snap["ready"] = [torch.cuda.Event() for _ in range(self.SNAP_SLOTS)]
         i = (snap["slot"] + 1) % self.SNAP_SLOTS
-        ready = torch.cuda.Event()
+        ready = snap["ready"][i]
         ready.record(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(snap["stream"]):
             snap["stream"].wait_event(ready)
@@ -123,10 +124,13 @@ class HipActorCritic(object):
         snap["version"] = -1            # a pre-enqueued snapshot serves ONE publish; later calls copy again
         snap["events"][snap["slot"]].synchronize()
         flat = snap["host"][snap["slot"]].numpy()
+        lay = getattr(self, "_name_layout", None)
+        if lay is None:
+            lay = self._name_layout = [(name, off, off + int(np.prod(shape)), tuple(shape))
+                                       for name, (off, shape) in self.spec.names.items()]
         out = OrderedDict()
-        for name, (off, shape) in self.spec.names.items():
-            size = int(np.prod(shape))
-            v = flat[off:off + size].reshape(shape)
+        for name, lo, hi, shape in lay:
+            v = flat[lo:hi].reshape(shape)
             out[name] = v.copy() if copy else v
         return out
 
