@@ -70,6 +70,31 @@ static __device__ unsigned long long* xt_tl_ptr;
 #define XT_TL_SETTER(name)
 #endif
 
+// 16-byte WRITE-THROUGH store (sc1): a large output that the next kernel reads goes to memory while the rest of the
+// launch still runs, instead of sitting dirty in the L2 until the end-of-kernel release writes it back -- the dependent
+// kernel boundary costs + (dirty bytes / ~6 TB/s) otherwise (MI355X_MICROARCH.md, rows "boundary" / "publish-large").
+// (sc1 is not reachable from a compiler-visible 16-byte store: __builtin_nontemporal_store sets nt instead, which measured
+// WORSE than plain stores here, 6.92 vs 6.89 ms per update against 6.77 for sc1.  The asm statements carry their own
+// hazard handling: on gfx940+ a VMEM store of more than 64 bits must be followed by two wait states before a VALU
+// instruction may overwrite its data registers, and the hazard recognizer cannot see a store inside an asm statement.)
+__device__ __forceinline__ void store1_wt(float* p, const float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#else
+  *p = v;
+#endif
+}
+typedef float xt_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store4_wt(float* p, const float4 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  xt_f4v q;
+  q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(q) : "memory");
+#else
+  *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+
 // n / d for n*d < 2^32 via one v_mul_hi_u32 (magic = floor(2^32/d)+1).
 struct FastDiv {
   uint32_t d, magic;
