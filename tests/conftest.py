@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # property tests must not replay (or depend on) an example database that is not part of the tree
+    try:
+        from hypothesis import settings
+        settings.register_profile("xt", database=None, deadline=None)
+        settings.load_profile("xt")
+    except ImportError:
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -740,7 +740,7 @@ def test_transport_codec_property_random_payloads():
     objects = st.one_of(scalars, st.lists(scalars, max_size=6), st.dictionaries(st.text(max_size=4), scalars, max_size=3))
     payloads = st.dictionaries(st.text(min_size=1, max_size=10), st.one_of(arrays, objects), max_size=6)
 
-    @settings(max_examples=60, deadline=None)
+    @settings(max_examples=60, deadline=None, database=None)
     @given(payloads, st.dictionaries(st.text(min_size=1, max_size=6), scalars, max_size=4))
     def check(data, ctr):
         buf = transport.encode(ctr, data)
@@ -748,7 +748,9 @@ def test_transport_codec_property_random_payloads():
         assert ctr2 == ctr and list(out) == list(data)
         for k, v in data.items():
             if isinstance(v, np.ndarray):
-                assert out[k].dtype == v.dtype and out[k].shape == v.shape and np.array_equal(out[k], v)
+                # bytes, not values: NaN payloads (and their bit patterns) must survive too
+                assert out[k].dtype == v.dtype and out[k].shape == v.shape
+                assert np.ascontiguousarray(out[k]).tobytes() == np.ascontiguousarray(v).tobytes()
             else:
                 assert out[k] == v
 
