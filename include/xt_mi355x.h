@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define XT_ABI_VERSION 8
+#define XT_ABI_VERSION 9
 
 #define XT_ACT_NONE 0
 #define XT_ACT_RELU 1
@@ -52,6 +52,10 @@ int xt_abi_version(void);
 const char* xt_last_error(void);
 /* name of the gfx target the device code was compiled for ("gfx950") */
 const char* xt_build_arch(void);
+/* sha256 (16 hex digits) over the kernel sources this binary was compiled from, embedded at build time (ABI >= 9;
+ * csrc/Makefile, -DXT_SRC_SHA): profile artefacts are tagged with it, so counters measured on another build of the
+ * kernels -- or a stale prebuilt library next to newer sources -- are recognised (bench.py, tools/pmc_summary.py). */
+const char* xt_build_sources_sha(void);
 
 /* --------------------------------------------------------------- tuning */
 /* Process-wide kernel-selection knobs (ABI >= 6).  The defaults (xt_tuning_get on a fresh process) are the forms
@@ -144,6 +148,25 @@ typedef struct xt_input_xform {
 int xt_gae_f64(const float* value, const double* reward, const uint8_t* done,
                double* adv, double* target_value, float* old_value,
                int32_t n_traj, int32_t T, double gamma, double lam, void* stream);
+
+/* The same GAE for a whole rollout of RAGGED trajectories laid out back to back as rows, the form the learner-side
+ * ingest holds them in (ABI >= 9): trajectory i = rows [offsets[i], offsets[i+1]) of reward / done / adv /
+ * target_value; value_rows[r] = V(s_r) (float32: the column the reference ships as `old_value`); boot[i] = V of the
+ * state after trajectory i's last step (value[T], xt/agent/ppo/ppo.py:90).  One workgroup per trajectory, bit-exact
+ * with the reference's numpy loop (xt/agent/ppo/ppo.py:87-104; CartPole twin cartpole_ppo.py:98-115).  offsets:
+ * int32 [n_traj + 1] on the device. */
+int xt_gae_f64_ragged(const float* value_rows, const float* boot, const double* reward, const uint8_t* done,
+                      const int32_t* offsets, double* adv, double* target_value, int32_t n_traj, double gamma,
+                      double lam, void* stream);
+
+/* Zero-pad the innermost axis: src [rows, c_src] -> dst [rows, c_dst], elements of elem_bytes = 1 (uint8) or 4
+ * (float32) bytes (ABI >= 9).  The reference's get_cnn_backbone (xt/model/model_utils.py:49-80) takes any channel
+ * count (examples/ant_ppo.yaml:20: [84, 84, 3]); the layer kernels read 4-channel groups, so such observations enter
+ * the first layer with a zero plane and its kernel carries a zero input-channel row that stays zero (zero operand ->
+ * zero gradient -> zero Adam step): bit-for-bit the arithmetic of the unpadded layer.  fill_u8: the byte written into
+ * the extra uint8 planes -- the value the input transform maps to 0 (state_mean; 0 for x / 255); float32 planes get 0. */
+int xt_pad_channels(const void* src, void* dst, int64_t rows, int32_t c_src, int32_t c_dst, int32_t elem_bytes,
+                    int32_t fill_u8, void* stream);
 
 /* Advantage normalisation over the whole rollout, in place, float64 (ABI >= 8):
  *     adv <- (adv - mean(adv)) / (std(adv) + eps)        (numpy's population std)
@@ -353,10 +376,15 @@ typedef struct xt_ppo_cfg {
   int32_t batch_size, num_sgd_iter;
   float grad_scale;             /* 1/world_size for data parallel, else 1             */
   int32_t global_batch;         /* rows of the GLOBAL minibatch (for the mean); 0 -> local */
+  /* ABI >= 9, xt_net_ppo_train only: shard_world > 1 = STRICT data parallelism inside the call -- every rank passes
+   * the same rollout and permutations, and takes rows [b0, b1) of every global minibatch (balanced contiguous shards,
+   * rank r of shard_world); the means run over the global rows (global_batch is set per minibatch), grad_scale = 1.
+   * Needs a gradient exchange (xt_net_set_rccl / xt_net_set_grad_exchange).  0 / 1 = off. */
+  int32_t shard_rank, shard_world;
 } xt_ppo_cfg;
 
 /* one SGD step on rows idx[0..B) of the rollout: forward, loss, backward -> net grads.
- * `apply` != 0 also runs clip+Adam (single GPU).  loss_out: 4 floats (see
+ * `apply` is a boolean: != 0 also runs clip+Adam (single GPU).  loss_out: 4 floats (see
  * xt_ppo_loss_reduce); loss_acc optional running sum. */
 int xt_net_ppo_step(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, const int32_t* idx,
                     int32_t B, const void* action /* int32 [N] | float32 [N,A], see XT_ACTION_* */,
@@ -398,6 +426,16 @@ int xt_net_set_grad_exchange(xt_net* net, xt_grad_exchange_fn fn, void* user);
 #define XT_XCHG_OVERLAP 1
 int xt_net_set_grad_exchange_ex(xt_net* net, xt_grad_exchange_fn fn, void* user, int32_t flags);
 
+/* The exchange served by the library itself (ABI >= 9): every hook call becomes
+ *     allreduce(grads, grads, count, ncclFloat32 (7), ncclSum (0), comm, stream)
+ * through the ncclAllReduce entry point the caller resolved from the RCCL instance its process already uses (dlsym /
+ * ctypes on torch's librccl.so) -- no host-language trampoline on the enqueue path.  comm == NULL removes it.
+ * xt_net_rccl_status: number of calls made and the last non-zero ncclResult (0 = none). */
+typedef int (*xt_nccl_allreduce_fn)(const void* sendbuff, void* recvbuff, size_t count, int datatype, int op,
+                                    void* comm, void* stream);
+int xt_net_set_rccl(xt_net* net, void* comm, xt_nccl_allreduce_fn allreduce, int32_t flags);
+int xt_net_rccl_status(const xt_net* net, int32_t* calls, int32_t* last_error);
+
 /* One minibatch of Keras `model.fit` for the non-opt IMPALA models (ABI >= 5): forward, xt_keras_impala_loss,
  * backward; the flat gradient is left in the net's gradient buffer for xt_adam_keras.  obs rows are gathered with
  * idx like the label rows (idx may be NULL: rows 0..B-1). */
@@ -435,7 +473,8 @@ int xt_net_impala_step(xt_net* net, const xt_impala_cfg* cfg, const void* obs, i
  * the number of chunks (the algorithm returns their mean, impala_opt.py:106).  use_graph != 0 captures the call into
  * a hipGraph on first use and replays it while pointers and sizes repeat (a small cache of graphs is kept, so that
  * alternating ingest buffer sets do not re-capture).  A gradient-exchange hook (xt_net_set_grad_exchange) makes every
- * chunk data parallel: local gradient -> exchange (SUM; the loss is a sum, grad_scale = 1) -> clip + Adam. */
+ * chunk data parallel: local gradient -> exchange (SUM; the loss is a sum, grad_scale = 1) -> norm of the exchanged
+ * gradient -> clip + the configured optimiser (Adam or centred RMSProp, lr_steps honoured; ABI >= 9). */
 int xt_net_impala_train(xt_net* net, const xt_impala_cfg* cfg, const void* obs, int32_t n, int32_t batch_size,
                         const float* bp_logits, const int32_t* action, const uint8_t* done, const float* reward,
                         const float* lr_steps, float* loss_acc, int32_t use_graph, void* stream);

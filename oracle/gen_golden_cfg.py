@@ -17,8 +17,12 @@ import yaml
 
 REF = "/root/reference"
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "learner_config.json")
+# every PPO / IMPALA example of the reference's examples/ directory (the YAML surface north_star asks to keep)
 YAMLS = ["examples/cartpole_ppo.yaml", "examples/breakout_ppo.yaml", "examples/breakout_impala.yaml",
-         "examples/pong_impala_speedup.yaml", "examples/pendulum_ppo.yaml"]
+         "examples/pong_impala_speedup.yaml", "examples/pendulum_ppo.yaml", "examples/ant_ppo.yaml", "examples/dog_ppo.yaml",
+         "examples/beamrider_ppo.yaml", "examples/pong_ppo.yaml", "examples/qbert_ppo.yaml", "examples/spaceinvader_ppo.yaml",
+         "examples/beamrider_impala.yaml", "examples/qbert_impala.yaml", "examples/spaceinvader_impala.yaml",
+         "examples/cartpole_impala.yaml"]
 
 
 def main():

@@ -49,6 +49,9 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
+    if os.environ.get("XT_TEST_LIB"):      # tests/test_gpu_wt_stress.py: the plain-store twin of the library
+        from xingtian_amd import lib as _lib
+        _lib.LIB_PATH = os.path.join(ROOT, "xingtian_amd", os.environ["XT_TEST_LIB"])
     from xingtian_amd import parallel
     from xingtian_amd.model.hip_net import HipActorCritic
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
@@ -82,6 +85,34 @@ def main():
         off_a = spec.layers[-1].param_off
         want = [(0, nflat)] * 6 if mode == "hook" else [(off_a, nflat - off_a), (0, off_a)] * 6
         assert ex.calls == want, (ex.calls[:4], want[:4])
+    elif mode == "strict_hook":
+        # strict sharding INSIDE xt_net_ppo_train (xt_ppo_cfg.shard_rank / shard_world, ABI 9): every rank passes the same
+        # rollout and permutations, the library takes this rank's rows of every global minibatch and exchanges through the hook
+        spec, cfg, n = ppo_case()
+        net = HipActorCritic(spec, max_batch=cfg["BATCH_SIZE"], seed=5)
+        parallel.broadcast_weights_(net.params)
+        obs, lab, perms = ppo_rollout(100, n)
+        ex = parallel.TorchDistExchange(net)
+        ex.attach()
+        c = net.make_ppo_cfg(cfg, grad_scale=1.0, global_batch=0, shard_rank=rank, shard_world=world)
+        net.ppo_train(c, net.to_device_obs(obs), d(perms), d(lab[0]), d(lab[1].reshape(-1)), d(lab[2].reshape(-1)),
+                      d(lab[3].reshape(-1)), d(lab[4].reshape(-1)), use_graph=False)
+        torch.cuda.synchronize()
+        ex.detach()
+        assert len(ex.calls) == 6
+    elif mode in ("impala_rms", "impala_sched"):
+        # data-parallel IMPALA with opt_type rmsprop / an lr_schedule step size: through the exchange hook of
+        # xt_net_impala_train, which applies the configured optimiser to the exchanged gradient itself
+        spec, data, tlen, ntraj = impala_case()
+        net = HipActorCritic(spec, max_batch=tlen * ntraj, seed=5)
+        parallel.broadcast_weights_(net.params)
+        if mode == "impala_rms":
+            net.set_optimizer("rmsprop")
+        c = net.make_impala_cfg(1e-3, 40.0, tlen, opt_type="rmsprop" if mode == "impala_rms" else "adam")
+        for step in range(2):
+            lr_steps = d(np.asarray([7e-4 / (step + 1)], np.float32)) if mode == "impala_sched" else None
+            parallel.dp_impala_step(net, c, 1e-3, 40.0, d(data["obs"]), d(data["bp"]), d(data["act"]), d(data["done"]),
+                                    d(data["rew"]), ntraj, tlen, rank, world, lr_steps=lr_steps)
     elif mode == "impala":
         spec, data, tlen, ntraj = impala_case()
         net = HipActorCritic(spec, max_batch=tlen * ntraj, seed=5)

@@ -5,6 +5,7 @@ import os
 import re
 import socket
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -27,8 +28,11 @@ def test_cabi_library_loads_and_exports_every_header_symbol():
     for name in sorted(declared):
         assert hasattr(handle, name), "missing C-ABI symbol " + name
         assert name in lib.SIGNATURES, "no ctypes prototype for " + name
-    assert handle.xt_abi_version() == lib.ABI_VERSION == 8
+    assert handle.xt_abi_version() == lib.ABI_VERSION == 9
     assert handle.xt_build_arch() == b"gfx950"
+    # the binary carries the digest of the sources it was compiled from: a stale prebuilt .so next to newer kernel
+    # sources is caught here (and profile artefacts are tagged with THIS digest, not with the tree's)
+    assert lib.built_sources_sha() == lib.kernel_sources_sha(), "libxt_mi355x.so is stale: rebuild (make -C xingtian_amd/csrc)"
 
 
 def test_tuning_struct_replaces_the_environment_switches():
@@ -708,7 +712,7 @@ def test_yaml_to_alg_para_matches_the_reference_executed_patching():
     import json
     from xingtian_amd import config as cfg
     golden = json.load(open(os.path.join(ROOT, "tests", "golden", "learner_config.json")))
-    assert len(golden) == 5
+    assert len(golden) == 15      # every PPO / IMPALA example of the reference (oracle/gen_golden_cfg.py)
     for rel, g in golden.items():
         got = cfg.learner_alg_para(g["config"], g["env_info"])
         assert got == g["alg_para"], rel
@@ -836,8 +840,8 @@ def test_rollout_fields_copy_transport_views_but_keep_owned_arrays():
 
 def test_data_parallel_guards_fail_identically_on_every_rank():
     """strict sharding of a minibatch with fewer rows than ranks must fail on EVERY rank before the first
-    collective (only the empty ranks raised: the others hung in the all-reduce), and the data-parallel IMPALA step
-    refuses optimisers its clip+Adam tail would silently replace."""
+    collective (only the empty ranks raised: the others hung in the all-reduce); the same holds for the hook-routed
+    data-parallel IMPALA step."""
     from xingtian_amd import lib, parallel
     cfg = dict(BATCH_SIZE=8, NUM_SGD_ITER=1, LR=1e-3, MAX_GRAD_NORM=1.0)
     perm = torch.arange(8 + 3, dtype=torch.int32).reshape(1, -1)       # last minibatch: 3 rows
@@ -855,10 +859,14 @@ def test_data_parallel_guards_fail_identically_on_every_rank():
             loss_out = None
         with pytest.raises(ValueError, match="3 rows cannot be split over 4 ranks"):
             parallel.dp_ppo_update(_Net(), cfg, None, perm, None, None, None, None, None, rank, 4, mode="strict")
+    # data-parallel IMPALA with opt_type rmsprop / an lr_schedule goes through the library's exchange hook (round 4: the
+    # optimiser is applied to the exchanged gradient by xt_net_impala_train itself); fewer trajectories than ranks is
+    # refused on every rank alike, before any collective
     c = lib.ImpalaCfg()
     c.opt_type = lib.OPT_TYPE["rmsprop"]
-    with pytest.raises(NotImplementedError, match="adam"):
-        parallel.dp_impala_step(None, c, 1e-3, 40.0, None, None, None, None, None, 4, 8, 0, 2)
+    for rank in range(4):
+        with pytest.raises(ValueError, match="3 trajectories cannot be split over 4 ranks"):
+            parallel.dp_impala_step(None, c, 1e-3, 40.0, None, None, None, None, None, 3, 8, rank, 4)
 
 
 def _fanin_producer(name, explorer_id, n_msgs, slots, slot_bytes):
@@ -1020,3 +1028,90 @@ def test_ring_releases_slots_in_order_behind_a_deferred_copy():
     finally:
         ring.pinned = False
         ring.close()
+
+
+def test_ring_set_reaps_pinned_rings_whose_slots_are_all_held():
+    """RingSet + a pinned ring (fake events, no GPU): every delivered message holds its slot behind a deferred copy that
+    completes 20 ms later.  ``pending()`` does not count held slots, so the poller must reap them itself -- otherwise
+    the ring is skipped forever, the producer blocks on 'ring full' and ``recv_many_into`` spins (the round-3 advisor's
+    reproduction: 2 of 6 delivered).  All six messages must arrive, in order, and every slot must come back."""
+    import threading
+    from xingtian_amd import transport
+
+    class TimedEvent(object):
+        def __init__(self, delay):
+            self.t = time.monotonic() + delay
+
+        def query(self):
+            return time.monotonic() >= self.t
+
+        def synchronize(self):
+            while not self.query():
+                time.sleep(0.001)
+
+    rs = transport.RingSet(1, slots=2, slot_bytes=1 << 16)
+    rs.rings[0].pinned = True
+    sent = []
+
+    def producer():
+        prod = transport.RingSet.attach(rs.names[0], slots=2, slot_bytes=1 << 16)
+        for i in range(6):
+            sent.append(prod.send_bytes(transport.encode({"seq": i}, {"x": np.full(4, i, np.int32)}), block=True, timeout=5.0))
+        prod.close()
+
+    th = threading.Thread(target=producer)
+    th.start()
+    seen = []
+
+    def sink(data, ctr_info=None):
+        seen.append(int(data["x"][0]))
+        ctr_info["_slot_guard"].hold(TimedEvent(0.02))
+
+    try:
+        got = rs.recv_many_into(sink, 6, timeout=10.0)
+        th.join(10.0)
+        assert got == 6 and seen == list(range(6)) and all(sent), (got, seen, sent)
+        time.sleep(0.05)
+        assert rs.rings[0].reap() == 0 and rs.pending() == 0
+    finally:
+        rs.rings[0].pinned = False
+        rs.close()
+
+
+def test_image_observations_with_three_channels_pad_to_four_exactly():
+    """examples/ant_ppo.yaml / dog_ppo.yaml: PpoCnn on [84, 84, 3] uint8 (the reference's get_cnn_backbone takes any
+    channel count, xt/model/model_utils.py:49-80).  The first layer is stored as a [8, 8, 4, 32] block whose fourth
+    input-channel rows are zero; the TF-shaped [8, 8, 3, 32] kernel is a strided view of it (get / set by name), and the
+    CPU replica's forward on 3-channel frames equals the float64 oracle on the unpadded network."""
+    from xingtian_amd.model import netspec
+    from xingtian_amd.model.cpu_net import CpuActorCritic
+    spec = netspec.ppo_cnn((84, 84, 3), 4, (512,), "relu", True)
+    lay0 = spec.layers[0]
+    assert lay0.C == 4 and lay0.kernel_shape == (8, 8, 3, 32) and spec.obs_channels_padded == 4
+    assert spec.names["shared_conv_layer_0/kernel"][1] == (8, 8, 3, 32)
+    assert spec.store_shape["shared_conv_layer_0/kernel"] == (8, 8, 4, 32)
+    assert netspec.ppo_cnn((84, 84, 4), 4, (512,), "relu", True).obs_channels_padded is None
+    net = CpuActorCritic(spec, seed=3)
+    w = net.get_weights()
+    assert w["shared_conv_layer_0/kernel"].shape == (8, 8, 3, 32)
+    off, size = spec.var_extent("shared_conv_layer_0/kernel")
+    block = net.params[off:off + size].reshape(8, 8, 4, 32)
+    assert np.array_equal(block[:, :, :3], w["shared_conv_layer_0/kernel"]) and not block[:, :, 3].any()
+    rng = np.random.default_rng(0)
+    k = rng.standard_normal((8, 8, 3, 32)).astype(np.float32)
+    net.set_weights({"shared_conv_layer_0/kernel": k})
+    assert np.array_equal(net.get_weights()["shared_conv_layer_0/kernel"], k) and not block[:, :, 3].any()
+    with pytest.raises(KeyError, match="shape"):
+        net.set_weights({"shared_conv_layer_0/kernel": np.zeros((8, 8, 4, 32), np.float32)})
+    # forward parity with the unpadded float64 oracle
+    ospec = nets.ppo_cnn_spec((84, 84, 3), 4, (512,), "relu", True)
+    params = nets.init_params(ospec, seed=5, bias_scale=0.05)
+    net.set_weights({n: v.reshape(spec.names[n][1]) for n, v in params.items()})
+    obs = rng.integers(0, 256, (3, 84, 84, 3)).astype(np.uint8)
+    logits, value = net.forward(obs)
+    olog, oval = nets.ActorCritic(ospec, params, np.float64).forward(obs)
+    assert np.allclose(logits, olog, rtol=2e-4, atol=2e-5) and np.allclose(value, np.asarray(oval).reshape(-1), rtol=2e-4, atol=2e-5)
+    # a uint8 transform with a non-zero mean pads with the byte that maps to zero; a fractional mean is refused by the
+    # learner (HipActorCritic.obs_fill_byte), the CPU replica pads after the transform
+    spec_i = netspec.impala_cnn_opt((84, 84, 3), 4, 128.0, 128.0)
+    assert spec_i.layers[0].C == 4 and spec_i.obs_channels_padded == 4

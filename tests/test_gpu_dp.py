@@ -150,3 +150,38 @@ def test_exchange_hook_with_two_ranks_matches_the_stepwise_path_bitwise(tmp_path
     for mode in ("hook", "hook_overlap"):
         got = _run_two_ranks(tmp_path, mode)
         assert np.array_equal(got, ref), mode
+
+
+def test_strict_sharding_inside_the_library_call_matches_the_stepwise_strict_path_bitwise(tmp_path):
+    """xt_ppo_cfg.shard_rank / shard_world (ABI 9): ONE xt_net_ppo_train call per rank walks the shared permutations,
+    takes this rank's balanced shard of every global minibatch (16 + 16 rows, 8 + 8 in the short last one), exchanges
+    through the hook and applies clip + Adam to the exchanged gradient -- bit for bit the Python-stepped strict path
+    (and therefore the single-GPU update up to fp32 summation order, test_strict_sharding_two_ranks_...)."""
+    ref = _run_two_ranks(tmp_path, "strict")
+    got = _run_two_ranks(tmp_path, "strict_hook")
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("mode", ["impala_rms", "impala_sched"])
+def test_data_parallel_impala_with_rmsprop_and_scheduled_step_sizes(tmp_path, mode):
+    """impala_cnn_opt.py:198-217,234-249 data parallel: opt_type rmsprop (centred RMSProp on the EXCHANGED gradient)
+    and an lr_schedule step size read from device memory, 5 trajectories as shards of 3 + 2, against the single-process
+    xt_net_impala_train with the same optimiser settings."""
+    import dp_worker
+    from xingtian_amd.model.hip_net import HipActorCritic
+    got = _run_two_ranks(tmp_path, mode)
+    spec, data, tlen, ntraj = dp_worker.impala_case()
+    net = HipActorCritic(spec, max_batch=tlen * ntraj, seed=5)
+    start = net.params.cpu().numpy().copy()
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    if mode == "impala_rms":
+        net.set_optimizer("rmsprop")
+    c = net.make_impala_cfg(1e-3, 40.0, tlen, opt_type="rmsprop" if mode == "impala_rms" else "adam")
+    for step in range(2):
+        lr_steps = d(np.asarray([7e-4 / (step + 1)], np.float32)) if mode == "impala_sched" else None
+        net.impala_train(c, d(data["obs"]), tlen * ntraj, d(data["bp"]), d(data["act"]), d(data["done"]), d(data["rew"]),
+                         lr_steps=lr_steps, use_graph=False)
+    torch.cuda.synchronize()
+    ref = net.params.cpu().numpy()
+    assert not np.array_equal(ref, start)
+    assert _delta_err(got, ref, start) < 5e-3, _delta_err(got, ref, start)

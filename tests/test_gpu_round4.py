@@ -1,0 +1,274 @@
+"""GPU parity tests of the round-4 additions, all through the C ABI: ragged learner-side GAE, channel padding of
+3-channel image observations (examples/ant_ppo.yaml), raw-trajectory ingest (GAE batched on the device), the packed
+weight publish into a page-locked ring, the RCCL shim of the exchange hook, and the hook-routed data-parallel IMPALA
+optimisers."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets, returns
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _d(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_gae_ragged_is_bit_exact_with_the_reference_loop():
+    """xt_gae_f64_ragged on trajectories of different lengths laid out back to back (T = 1, 2, 37, 128, 200, 1024, 1025,
+    1500: both the LDS form and the one-lane walk) against oracle.returns.gae, which is pinned bit-for-bit to the
+    reference's PPO.data_proc (tests/golden/gae_*.npz)."""
+    from xingtian_amd import lib as L
+    lib = L.load()
+    rng = np.random.default_rng(11)
+    lens = [1, 2, 37, 128, 200, 1024, 1025, 1500, 128, 5]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    n = int(offs[-1])
+    value_rows = np.empty(n, np.float32)
+    boot = np.empty(len(lens), np.float32)
+    reward = np.empty(n, np.float64)
+    done = np.zeros(n, np.uint8)
+    want_adv, want_tgt = np.empty(n), np.empty(n)
+    for i, t in enumerate(lens):
+        v = rng.standard_normal(t + 1).astype(np.float32)
+        r = rng.choice([-1.0, 0.0, 1.0, 0.37], size=t)
+        dn = rng.random(t) < (0.0 if i == 0 else 0.05)
+        if i == 3:
+            dn[:] = True
+        if i == 4:
+            dn[0] = dn[-1] = True
+        a, ov, tg = returns.gae(v.reshape(-1, 1), r.copy(), dn)
+        lo, hi = offs[i], offs[i + 1]
+        value_rows[lo:hi], boot[i], reward[lo:hi], done[lo:hi] = v[:t], v[t], r, dn
+        want_adv[lo:hi], want_tgt[lo:hi] = a[:, 0], tg[:, 0]
+        assert np.array_equal(ov[:, 0], v[:t])
+    adv = torch.full((n,), np.nan, dtype=torch.float64, device="cuda")
+    tgt = torch.full((n,), np.nan, dtype=torch.float64, device="cuda")
+    L.check(lib.xt_gae_f64_ragged(L.ptr(_d(value_rows)), L.ptr(_d(boot)), L.ptr(_d(reward)), L.ptr(_d(done)), L.ptr(_d(offs)),
+                                  L.ptr(adv), L.ptr(tgt), len(lens), 0.99, 0.95, L.stream_ptr()), "xt_gae_f64_ragged")
+    torch.cuda.synchronize()
+    assert np.array_equal(adv.cpu().numpy(), want_adv) and np.array_equal(tgt.cpu().numpy(), want_tgt)
+
+
+def test_pad_channels_u8_and_f32():
+    from xingtian_amd import lib as L
+    lib = L.load()
+    rng = np.random.default_rng(2)
+    for dt, fill in ((np.uint8, 128), (np.uint8, 0), (np.float32, 0)):
+        src = (rng.integers(0, 256, (7, 5, 3)) if dt == np.uint8 else rng.standard_normal((7, 5, 3))).astype(dt)
+        dst = torch.empty((7, 5, 4), dtype=torch.uint8 if dt == np.uint8 else torch.float32, device="cuda")
+        L.check(lib.xt_pad_channels(L.ptr(_d(src)), L.ptr(dst), 35, 3, 4, src.itemsize, fill, L.stream_ptr()), "xt_pad_channels")
+        got = dst.cpu().numpy()
+        assert np.array_equal(got[..., :3], src) and np.all(got[..., 3] == (fill if dt == np.uint8 else 0))
+    with pytest.raises(RuntimeError, match="elem_bytes"):
+        L.check(lib.xt_pad_channels(L.ptr(dst), L.ptr(dst), 1, 3, 4, 2, 0, L.stream_ptr()), "xt_pad_channels")
+
+
+@pytest.mark.parametrize("b", [10, 64])
+def test_ppo_step_on_three_channel_frames_vs_oracle(b):
+    """ant_ppo.yaml's shape (PpoCnn on [84, 84, 3] uint8, hidden 512, BATCH_SIZE 10): the padded HIP network against the
+    float64 oracle of the UNPADDED network -- loss 1e-4, every gradient tensor 1e-5 (kernel gradient compared in the TF
+    shape [8, 8, 3, 32]); the padded input-channel rows of the flat buffers stay exactly zero through the update."""
+    from test_gpu_learner import PPO_CFG, assert_update_close, oracle_params_for, rel_err, synth_ppo_rollout
+    from xingtian_amd.model import netspec
+    from xingtian_amd.model.hip_net import HipActorCritic
+    spec = netspec.ppo_cnn((84, 84, 3), 4, (512,), "relu", True)
+    ospec = nets.ppo_cnn_spec((84, 84, 3), 4, (512,), "relu", True)
+    net = HipActorCritic(spec, max_batch=b, seed=0)
+    params = oracle_params_for(net, ospec, seed=7)
+    rng = np.random.default_rng(0)
+    n = b + 6
+    obs, lab = synth_ppo_rollout(rng, n, (84, 84, 3), 4, True)
+    idx = rng.permutation(n)[:b].astype(np.int32)
+    cfg = dict(PPO_CFG, BATCH_SIZE=b)
+    orc = nets.PpoLearnerOracle(ospec, params, cfg, np.float64)
+    out = orc.step(obs[idx], lab[0][idx], lab[1][idx].astype(np.float32), lab[2][idx].astype(np.float32),
+                   lab[3][idx].astype(np.float32), lab[4][idx].astype(np.float32), apply=True)
+    dobs = net.to_device_obs(obs)
+    assert tuple(dobs.shape) == (n, 84, 84, 4) and not dobs[..., 3].any()
+    lo = net.ppo_step(net.make_ppo_cfg(cfg), dobs, _d(idx), _d(lab[0]), _d(lab[1].reshape(-1)), _d(lab[2].reshape(-1)),
+                      _d(lab[3].reshape(-1)), _d(lab[4].reshape(-1)), apply=True)
+    torch.cuda.synchronize()
+    loss = lo.cpu().numpy()[0]
+    assert abs(loss - out["loss"]) <= 1e-4 * max(1.0, abs(out["loss"]))
+    g = net.grads_dict()
+    assert g["shared_conv_layer_0/kernel"].shape == (8, 8, 3, 32)
+    for k, ref in out["grads"].items():
+        assert rel_err(g[k].reshape(ref.shape), ref) < 1e-5, k
+    assert_update_close(net.get_weights(), orc.net.params, params, cfg["LR"], "cnn84_c3")
+    off, size = spec.var_extent("shared_conv_layer_0/kernel")
+    for buf in (net.params, net.grads, net.adam_m, net.adam_v):
+        block = buf[off:off + size].cpu().numpy().reshape(8, 8, 4, 32)
+        assert not block[:, :, 3].any()
+    assert net.get_weights()["shared_conv_layer_0/kernel"].shape == (8, 8, 3, 32)
+
+
+@pytest.mark.parametrize("rel", ["examples/ant_ppo.yaml", "examples/dog_ppo.yaml", "examples/beamrider_ppo.yaml",
+                                 "examples/pong_ppo.yaml", "examples/qbert_ppo.yaml", "examples/spaceinvader_ppo.yaml",
+                                 "examples/beamrider_impala.yaml", "examples/qbert_impala.yaml",
+                                 "examples/spaceinvader_impala.yaml"])
+def test_remaining_example_yamls_build_a_learner_and_train(rel):
+    """The other PPO / IMPALA examples of the reference (tests/golden/learner_config.json now holds all 15) through
+    xingtian_amd.config.build_learner_algorithm: one synthetic update through prepare_data (streaming ingest, incl. the
+    channel padding of ant / dog), a finite loss, weights by TF name in the reference's shapes."""
+    from xingtian_amd import config as cfg
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "learner_config.json")))[rel]
+    conf = json.loads(json.dumps(g["config"]))
+    conf["model_para"]["actor"].setdefault("model_config", {})
+    conf["model_para"]["actor"]["model_config"]["SEED"] = 0
+    alg = cfg.build_learner_algorithm(conf, g["env_info"])
+    actor_info = conf["model_para"]["actor"]
+    sd, ad = tuple(actor_info["state_dim"]), actor_info["action_dim"]
+    rng = np.random.default_rng(3)
+    if g["alg_para"]["alg_name"] == "PPO":
+        t = 40
+        for _ in range(alg.prepare_data_times):
+            alg.prepare_data({"cur_state": rng.integers(0, 256, (t,) + sd).astype(np.uint8),
+                              "action": rng.integers(0, ad, t).astype(np.int32), "logp": -np.ones((t, 1), np.float32),
+                              "adv": rng.standard_normal((t, 1)), "old_value": rng.standard_normal((t, 1)).astype(np.float32),
+                              "target_value": rng.standard_normal((t, 1))})
+    else:
+        tlen = actor_info["model_config"]["sample_batch_step"]
+        envs = conf["env_para"]["env_info"].get("vector_env_size", 1)
+        for _ in range(conf["alg_para"]["alg_config"]["prepare_times_per_train"]):
+            n = tlen * envs
+            alg.prepare_data({"cur_state": rng.integers(0, 256, (n,) + sd).astype(np.uint8),
+                              "logit": rng.standard_normal((n, ad)).astype(np.float32),
+                              "action": rng.integers(0, ad, n).astype(np.int32), "done": list(rng.random(n) < 0.05),
+                              "reward": list(rng.choice([-1.0, 0.0, 1.0], n))})
+    loss = alg.train(episode_num=0)
+    assert isinstance(loss, (float, np.floating)) and np.isfinite(loss)
+    w = alg.get_weights()
+    first = next(iter(w.values()))
+    assert first.shape[2] == sd[2] and all(isinstance(v, np.ndarray) and v.flags.owndata for v in w.values())
+
+
+def test_raw_trajectories_get_one_batched_gae_on_the_device_and_match_the_actor_side_path():
+    """SURVEY 8(a1) on the learner: trajectories that arrive WITHOUT advantages (value [T+1], reward, done as the explorer
+    holds them before data_proc) are streamed to HBM like any other, and ONE xt_gae_f64_ragged launch inside train()
+    produces adv / target_v on the device -- no per-message launch, no read-back.  The update is bit-identical to the
+    reference protocol (actor-side numpy GAE, shipped adv / old_value / target_value), lengths ragged."""
+    from test_gpu_learner import synth_ppo_rollout
+    from xingtian_amd.algorithm import alg_builder
+
+    def mk():
+        model_info = {"actor": {"model_name": "PpoCnn", "state_dim": [42, 42, 4], "action_dim": 3, "input_dtype": "uint8",
+                                "model_config": {"BATCH_SIZE": 64, "NUM_SGD_ITER": 2, "hidden_sizes": [64], "SEED": 5,
+                                                 "action_type": "Categorical", "USE_HIP_GRAPH": True}}}
+        return alg_builder("PPO", model_info, {"instance_num": 5, "agent_num": 1})
+
+    rng = np.random.default_rng(21)
+    lens = [50, 37, 64, 1, 50]
+    raw, cooked = [], []
+    for t in lens:
+        obs, lab = synth_ppo_rollout(rng, t, (42, 42, 4), 3)
+        value = rng.standard_normal((t + 1, 1)).astype(np.float32)
+        reward = rng.choice([-1.0, 0.0, 1.0], size=t)
+        done = rng.random(t) < 0.05
+        a, ov, tg = returns.gae(value, reward.copy(), done)
+        raw.append({"cur_state": obs, "action": lab[0], "logp": lab[1], "value": value, "reward": list(reward), "done": list(done)})
+        cooked.append({"cur_state": obs, "action": lab[0], "logp": lab[1], "adv": a, "old_value": ov, "target_value": tg})
+    n = sum(lens)
+    perms = np.stack([rng.permutation(n) for _ in range(2)]).astype(np.int32)
+    res = []
+    for msgs in (cooked, raw):
+        alg = mk()
+        for rep in range(2):            # the second update replays the captured graph on the other buffer set
+            for m in msgs:
+                alg.prepare_data(m)
+            loss = alg.train(perms=perms)
+        res.append((loss, alg.actor.net.params.cpu().numpy().copy()))
+        if msgs is raw:
+            d = alg.actor._ingest.last.dev
+            want = np.concatenate([c["adv"][:, 0] for c in cooked])
+            assert np.array_equal(d["adv"][:n].cpu().numpy(), want)
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
+    # a rollout must not mix the two kinds
+    alg = mk()
+    alg.prepare_data(raw[0])
+    alg.prepare_data(cooked[1])
+    with pytest.raises(RuntimeError, match="must not mix"):
+        alg.train()
+
+
+def test_weights_publish_into_a_page_locked_ring_is_one_dma_and_readers_get_the_dict():
+    """f2 fast path: ``Algorithm.publish_weights(ring)`` on a pinned WeightsRing copies the packed parameter block from
+    HBM straight into the shared-memory slot (no host copy on the learner); a reader's ``fetch`` rebuilds the name-keyed
+    dict -- equal to ``get_weights()``, also for a channel-padded first layer.  Unpinned rings take the per-variable copy."""
+    from xingtian_amd import transport
+    from xingtian_amd.model import netspec
+    from xingtian_amd.model.hip_net import HipActorCritic
+    for sd in ((84, 84, 4), (84, 84, 3)):
+        net = HipActorCritic(netspec.ppo_cnn(sd, 4, (256,), "relu", True), max_batch=8, seed=3)
+        want = net.get_weights()
+        for pinned in (True, False):
+            ring = transport.WeightsRing(slot_bytes=8 << 20, slots=3)
+            try:
+                if pinned:
+                    assert ring.pin()
+                k = net.publish_weights(ring, {"train_count": 7})
+                reader = transport.WeightsRing(name=ring.name, slot_bytes=8 << 20, slots=3, create=False)
+                seq, ctr, got = reader.fetch()
+                assert seq == k == 1 and ctr["train_count"] == 7 and list(got) == list(want)
+                for name in want:
+                    assert got[name].shape == want[name].shape and np.array_equal(got[name], want[name]), name
+                net.params.mul_(1.5)
+                net.touch()
+                assert net.publish_weights(ring) == 2
+                _, _, got2 = reader.fetch()
+                assert np.array_equal(got2["pi_latent/kernel"], net.get_weights()["pi_latent/kernel"])
+                reader.close()
+            finally:
+                ring.close()
+    w1 = net.get_weights()
+    w2 = net.get_weights()
+    assert all(w1[k].flags.owndata and w1[k] is not w2[k] for k in w1)        # public API: private arrays
+    v = net.get_weights(copy=False)
+    assert not any(a.flags.owndata for a in v.values())
+
+
+def test_rccl_shim_exchange_on_one_rank_matches_the_stepwise_path_bitwise():
+    """xt_net_set_rccl: the library calls ncclAllReduce itself through the function pointer (no Python trampoline).  A
+    1-rank communicator (all a 1-GPU box can form) must reproduce the step-wise data-parallel path bit for bit -- eager
+    enqueue, captured into the update's hipGraph, and with the two-bucket overlap -- and the status word counts the calls."""
+    from test_gpu_learner import synth_ppo_rollout
+    from xingtian_amd import parallel
+    from xingtian_amd.model import netspec
+    from xingtian_amd.model.hip_net import HipActorCritic
+    spec = netspec.ppo_cnn((42, 42, 4), 4, (64,), "relu", True)
+    cfg = dict(LR=2.5e-4, LOSS_CLIPPING=0.1, ENTROPY_LOSS=0.003, VF_CLIP=5.0, CRITIC_LOSS_COEF=1.0, MAX_GRAD_NORM=5.0,
+               BATCH_SIZE=32, NUM_SGD_ITER=2)
+    rng = np.random.default_rng(4)
+    n = 80
+    obs, lab = synth_ppo_rollout(rng, n, (42, 42, 4), 4)
+    perms = np.stack([rng.permutation(n) for _ in range(2)]).astype(np.int32)
+    args = lambda net: (net.to_device_obs(obs), _d(perms), _d(lab[0]), _d(lab[1].reshape(-1)), _d(lab[2].reshape(-1)),
+                        _d(lab[3].reshape(-1)), _d(lab[4].reshape(-1)))
+    ref = HipActorCritic(spec, max_batch=32, seed=5)
+    parallel.dp_ppo_update(ref, cfg, *args(ref), 0, 1, mode="weak")
+    torch.cuda.synchronize()
+    want = ref.params.cpu().numpy()
+    try:
+        comm = parallel.RcclComm(0, 1)
+    except Exception as exc:      # noqa: BLE001
+        pytest.skip("no RCCL communicator on this box: %r" % (exc,))
+    from xingtian_amd import lib as L
+    warm = torch.zeros(256, dtype=torch.float32, device="cuda")
+    comm.all_reduce_(warm, L.stream_ptr())
+    torch.cuda.synchronize()
+    for graph, overlap in ((False, False), (True, False), (False, True)):
+        net = HipActorCritic(spec, max_batch=32, seed=5)
+        comm.attach(net, overlap=overlap)
+        net.ppo_train(net.make_ppo_cfg(cfg, grad_scale=1.0), *args(net), use_graph=graph)
+        torch.cuda.synchronize()
+        calls, err = comm.status(net)
+        comm.detach(net)
+        assert err == 0 and calls == 6 * (2 if overlap else 1), (graph, overlap, calls, err)
+        assert np.array_equal(net.params.cpu().numpy(), want), (graph, overlap)
+    comm.destroy()

@@ -1,10 +1,11 @@
 #!/bin/bash
 # One GPU-box call: the -m gpu suite, the default bench line, and in-graph kernel averages of the three workloads.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r03}
+TAG=${1:-r04}
 mkdir -p $R/gpurun_out
 cd $R
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_pytest.log 2>&1; tail -4 gpurun_out/${TAG}_pytest.log
+timeout 600 python -m pytest tests -m "not gpu" -x -q > gpurun_out/${TAG}_pytest_cpu.log 2>&1; tail -2 gpurun_out/${TAG}_pytest_cpu.log
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_pytest.log 2>&1; tail -4 gpurun_out/${TAG}_pytest.log
 timeout 600 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -3 gpurun_out/${TAG}_bench.err
 python - <<P
 import json
@@ -16,9 +17,12 @@ try:
     for k, v in d.get("e2e", {}).items():
         if isinstance(v, dict): print("e2e", k, {q: (round(x, 3) if isinstance(x, float) else x) for q, x in v.items() if q != "path"})
     for s in d.get("secondary", []):
-        print("SEC", s["workload"][:40], "value", round(s["value"]), "us/train", round(s["us_per_train"], 1), "frac", round(s["update_frac_of_fp32_mfma_peak"], 3), "e2e", {q: (round(x, 3) if isinstance(x, float) else x) for q, x in s["e2e"].items() if q != "path"})
+        print("SEC", s["workload"][:40], "value", round(s["value"]), "us/train", round(s["us_per_train"], 1), "frac", round(s["update_frac_of_fp32_mfma_peak"], 3), "e2e", {q: (round(x, 3) if isinstance(x, float) else x) for q, x in s["e2e"].items() if q != "path"}, "publish", {q: (round(x, 3) if isinstance(x, float) else x) for q, x in s.get("e2e_publish", {}).items() if q != "path"})
         print("   kernels", s["roofline"]["kernels_us_isolated"], "cpu", s.get("cpu_baseline", {}).get("value"))
     print("cpu", d.get("cpu_baseline"))
+    print("library", d.get("library"), "box", d.get("box"))
+    ms = d.get("modelled_scaling", {})
+    print("modelled step us", ms.get("measured_sgd_step_us_by_rows"), "strict8", ms.get("strict", {}).get("8"), "weak8", ms.get("weak", {}).get("8"))
 except Exception as e:
     print("bench parse failed", e)
 P

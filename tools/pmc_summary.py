@@ -70,8 +70,9 @@ def main():
             r["active_frac"] = s.get("SQ_ACTIVE_INST_ANY", 0.0) / s["SQ_WAVE_CYCLES"]
         rows.append(r)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from xingtian_amd.lib import kernel_sources_sha
-    doc = {"kernel_sources_sha": kernel_sources_sha(),
+    from xingtian_amd.lib import built_sources_sha
+    # the digest embedded in the library that RAN (xt_build_sources_sha), not the digest of the tree next to it
+    doc = {"kernel_sources_sha": built_sources_sha(),
            "note": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_* in separate runs) over tools/step_probe.py (eager updates of the three workloads); "
                    "mean per launch; hbm_side_MB = (2 x FETCH_SIZE_KB + WRITE_SIZE_KB) / 1024 (gfx950 correction for 16-byte "
                    "coalesced reads; L2 memory-side requests incl. Infinity-Cache hits).  SQ_VALU_MFMA_BUSY_CYCLES counts "

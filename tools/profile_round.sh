@@ -6,7 +6,7 @@
 #   gpurun_out/<tag>_pmc_<workload>.json         tools/pmc_summary.py of three --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*) over
 #                                                tools/step_probe.py <workload> (eager updates: every kernel of a step)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r03}
+TAG=${1:-r04}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err

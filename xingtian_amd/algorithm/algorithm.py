@@ -125,6 +125,10 @@ class Algorithm(object):
     def set_weights(self, weights):
         return self.actor.set_weights(weights)
 
+    def publish_weights(self, ring, ctr_info=None):
+        """``get_weights`` + hand-over to the explorers in one step (``transport.WeightsRing``)."""
+        return self.actor.publish_weights(ring, ctr_info)
+
     @staticmethod
     def update_weights_map(agent_in_group="agent_0", agent_in_env="agent_0"):
         """{agent_id: {"prefix": ..., "name": ...}} for multi-model setups; every agent shares one model by default."""

@@ -26,6 +26,10 @@ class PPO(Algorithm):
         self.async_flag = False
         self._rollout = RolloutFields(*self.FIELDS)
         self._streamed = 0
+        # GAMMA / LAM belong to the algorithm's configuration (xt/algorithm/ppo/default_config.py): the model's
+        # learner-side GAE (trajectories arriving without advantages) uses them
+        if hasattr(self.actor, "gamma"):
+            self.actor.gamma, self.actor.lam = float(GAMMA), float(LAM)
         if model_info.get("finetune_weight"):
             self.actor.load_model(model_info["finetune_weight"], by_name=True)
 
@@ -42,14 +46,17 @@ class PPO(Algorithm):
         self._streamed = 0
 
     def prepare_data(self, train_data, **kwargs):
-        if "adv" not in train_data:      # raw value/reward/done: GAE on the learner GPU instead of on the actors
+        streaming = getattr(self.actor, "stream_ingest", False) and hasattr(self.actor, "ingest_trajectory")
+        if "adv" not in train_data and not streaming:
+            # raw value/reward/done without the streaming ingest (continuous actions, odd vector widths): GAE on the
+            # learner GPU per message; the streaming path below batches it into ONE launch per rollout instead
             from xingtian_amd import ops
             adv, old_v, tgt = ops.gae(np.asarray(train_data["value"], np.float32).reshape(1, -1),
                                       np.asarray(train_data["reward"], np.float64).reshape(1, -1),
                                       np.asarray(train_data["done"], bool).reshape(1, -1), GAMMA, LAM)
             train_data = dict(train_data, adv=adv.reshape(-1, 1), old_value=old_v.reshape(-1, 1),
                               target_value=tgt.reshape(-1, 1))
-        if getattr(self.actor, "stream_ingest", False) and hasattr(self.actor, "ingest_trajectory"):
+        if streaming:
             ctr = kwargs.get("ctr_info") or {}
             pinned = bool(ctr.get("_pinned_views"))                          # views into a pinned transport ring
             self.actor.ingest_trajectory(train_data, pinned=pinned, slot_guard=ctr.get("_slot_guard"))   # H2D starts now

@@ -70,28 +70,37 @@ static __device__ unsigned long long* xt_tl_ptr;
 #define XT_TL_SETTER(name)
 #endif
 
-// 16-byte WRITE-THROUGH store (sc1): a large output that the next kernel reads goes to memory while the rest of the
-// launch still runs, instead of sitting dirty in the L2 until the end-of-kernel release writes it back -- the dependent
-// kernel boundary costs + (dirty bytes / ~6 TB/s) otherwise (MI355X_MICROARCH.md, rows "boundary" / "publish-large").
-// (sc1 is not reachable from a compiler-visible 16-byte store: __builtin_nontemporal_store sets nt instead, which measured
-// WORSE than plain stores here, 6.92 vs 6.89 ms per update against 6.77 for sc1.  The asm statements carry their own
-// hazard handling: on gfx940+ a VMEM store of more than 64 bits must be followed by two wait states before a VALU
-// instruction may overwrite its data registers, and the hazard recognizer cannot see a store inside an asm statement.)
-__device__ __forceinline__ void store1_wt(float* p, const float v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+// WRITE-THROUGH stores (sc1): a large output that the next kernel reads goes to memory while the rest of the launch
+// still runs, instead of sitting dirty in the L2 until the end-of-kernel release writes it back -- the dependent kernel
+// boundary costs + (dirty bytes / ~6 TB/s) otherwise (MI355X_MICROARCH.md, rows "boundary" / "publish-large").
+// Round 4: both forms are COMPILER-VISIBLE, no inline asm.  The 16-byte store is a raw buffer store with aux = sc1
+// through a descriptor of the output tensor (cdna_hip_programming.md, the publish recipe); the 4-byte one a relaxed
+// agent-scope atomic store, which gfx950 lowers to `global_store_dword ... sc1`.  Round 3 used
+// `asm volatile("global_store_dwordx4 ... sc1\n\ts_nop 1")`: on gfx940+ a VMEM store of more than 64 bits must be followed
+// by two wait states before a VALU instruction overwrites its data registers (LLVM GCNHazardRecognizer::
+// checkVALUHazardsHelper, VALUWaitStates = 2 with GFX940 instructions), and the hazard recogniser does not look inside an
+// asm statement -- correctness hung on a hand-placed s_nop.  Now the recogniser sees the store.
+// (__builtin_nontemporal_store sets nt instead, which measured WORSE than plain stores: 6.92 vs 6.89 ms per update
+// against 6.77 for sc1.)  -DXT_NO_WT (the `nowt` twin library, tests/test_gpu_wt_stress.py) compiles both to plain stores.
+typedef uint32_t xt_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kAuxSc1 = 16;         // gfx940+ cache-policy bits of buffer instructions: 1 = sc0, 2 = nt, 16 = sc1
+__device__ __forceinline__ void store1_wt(float* base, size_t off, const float v) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(XT_NO_WT)
+  __hip_atomic_store(base + off, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
-  *p = v;
+  base[off] = v;
 #endif
 }
-typedef float xt_f4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store4_wt(float* p, const float4 v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  xt_f4v q;
-  q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(q) : "memory");
+// `base`: wave-uniform tensor base (it becomes the descriptor in SGPRs), `off`: element offset < 2^29 (the ABI bounds
+// every activation / gradient tensor by 2 GiB, include/xt_mi355x.h: xt_layer_dgrad)
+__device__ __forceinline__ void store4_wt(float* base, size_t off, const float4 v) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(XT_NO_WT)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+  xt_u32x4 q;
+  q.x = __float_as_uint(v.x); q.y = __float_as_uint(v.y); q.z = __float_as_uint(v.z); q.w = __float_as_uint(v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(q, rs, (int)(off * 4), 0, kAuxSc1);
 #else
-  *reinterpret_cast<float4*>(p) = v;
+  *reinterpret_cast<float4*>(base + off) = v;
 #endif
 }
 

@@ -396,7 +396,7 @@ __global__ __launch_bounds__(512, 2) void conv_u8c4k8_fwd_flat_kernel(const C1Fw
       for (int q = 0; q < 4; ++q) {
         const int row = q * 8 + (lane >> 3), c4 = (lane & 7) * 4;
         const float4 v = *reinterpret_cast<const float4*>(&tbuf[row * 36 + c4]);
-        if (pix0 + row < p1) store4_wt(&p.y[(size_t)(pix0 + row) * 32 + c4], v);
+        if (pix0 + row < p1) store4_wt(p.y, (size_t)(pix0 + row) * 32 + c4, v);
       }
     }
   }
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(128 * NKQ, NKQ) void conv_u8c4k8_wgrad_bf16x3_kerne
       for (int r = 0; r < 16; ++r) {
         const float v = acc[q][r] + red[((kq * RQ + q) * 16 + r) * 64 + lane];
         const int k = (kq * RQ + q) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        store1_wt(&slab[(size_t)k * 32 + il], fmaf(v, p.xs, corr));
+        store1_wt(slab, (size_t)k * 32 + il, fmaf(v, p.xs, corr));
       }
     if (kq == 0 && h == 0) slab[(size_t)p.KH * 32 * 32 + il] = db;
   }

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(MAXT) void direct_fwd_kernel(const DFwdArgs p) {
         v.x = act_apply(v.x + bv.x, g.act); v.y = act_apply(v.y + bv.y, g.act);
         v.z = act_apply(v.z + bv.z, g.act); v.w = act_apply(v.w + bv.w, g.act);
       }
-      store4_wt(out + (size_t)m * g.N + n, v);
+      store4_wt(out, (size_t)m * g.N + n, v);
     }
   });
   XT_TL(4);

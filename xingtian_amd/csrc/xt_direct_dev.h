@@ -200,7 +200,7 @@ __device__ __forceinline__ void direct_dgrad_body(const DDgradArgs& p, uint32_t 
     if (eoff[j] >= 0) {
       v.x *= act_grad(xv[j].x, p.act_prev); v.y *= act_grad(xv[j].y, p.act_prev);
       v.z *= act_grad(xv[j].z, p.act_prev); v.w *= act_grad(xv[j].w, p.act_prev);
-      store4_wt(p.dx + (size_t)eoff[j], v);
+      store4_wt(p.dx, (size_t)eoff[j], v);
     }
   });
   XT_TL(4);
@@ -411,7 +411,7 @@ __device__ __forceinline__ void halo_dgrad_body(const DDgradArgs& p, uint32_t bi
     if (eoff[j] >= 0) {
       v.x *= act_grad(xv[j].x, p.act_prev); v.y *= act_grad(xv[j].y, p.act_prev);
       v.z *= act_grad(xv[j].z, p.act_prev); v.w *= act_grad(xv[j].w, p.act_prev);
-      store4_wt(p.dx + (size_t)eoff[j], v);
+      store4_wt(p.dx, (size_t)eoff[j], v);
     }
   });
   XT_TL(4);

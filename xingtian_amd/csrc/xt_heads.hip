@@ -959,6 +959,86 @@ __global__ __launch_bounds__(256) void gae_f64_block_kernel(const float* __restr
   }
 }
 
+// Ragged form for the learner-side ingest (ABI >= 9): the rollout's trajectories lie back to back as ROWS (trajectory i
+// = rows [offsets[i], offsets[i+1])), value_rows[r] = V(s_r) -- which is also the reference's old_value column -- and
+// boot[i] = V of the state after trajectory i's last step (value[T] of xt/agent/ppo/ppo.py:90).  Same arithmetic, same
+// roundings, same serial recurrence as gae_f64_block_kernel; lengths differ per trajectory (CartPole: <= 200).
+__global__ __launch_bounds__(256) void gae_f64_ragged_kernel(const float* __restrict__ value_rows, const float* __restrict__ boot,
+                                                             const double* __restrict__ reward, const uint8_t* __restrict__ done,
+                                                             const int32_t* __restrict__ offsets, double* __restrict__ adv,
+                                                             double* __restrict__ target, double gamma, double lam) {
+  __shared__ double s_a[kGaeMaxT], s_dl[kGaeMaxT];
+  const int tr = blockIdx.x, t = threadIdx.x;
+  const int r0 = offsets[tr], T = offsets[tr + 1] - r0;
+  if (T <= 0) return;
+  const float* v = value_rows + r0;
+  const double* r = reward + r0;
+  const uint8_t* d = done + r0;
+  const float vb = boot[tr];
+  if (T <= kGaeMaxT) {
+    for (int j = t; j < T; j += 256) {
+      const double disc = d[j] ? 0.0 : gamma;
+      const double vj = (double)v[j], vn = (double)(j + 1 < T ? v[j + 1] : vb);
+      s_a[j] = __dsub_rn(__dadd_rn(r[j], __dmul_rn(disc, vn)), vj);
+      s_dl[j] = disc;
+    }
+    __syncthreads();
+    if (t == 0) {
+      double carry = 0.0;
+      for (int j0 = T; j0 > 0; j0 -= 16) {
+        double dl[16], dc[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int j = j0 - 1 - u;
+          const int jc = j >= 0 ? j : 0;
+          dl[u] = s_a[jc]; dc[u] = s_dl[jc];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int j = j0 - 1 - u;
+          if (j >= 0) {
+            double a = dl[u];
+            if (j < T - 1) a = __dadd_rn(dl[u], __dmul_rn(__dmul_rn(carry, dc[u]), lam));
+            s_a[j] = a;
+            carry = a;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int j = t; j < T; j += 256) {
+      const double a = s_a[j];
+      adv[r0 + j] = a;
+      target[r0 + j] = __dadd_rn(a, (double)v[j]);
+    }
+  } else if (t == 0) {        // longer than the LDS form holds: one lane walks the trajectory
+    double carry = 0.0;
+    for (int j = T - 1; j >= 0; --j) {
+      const double disc = d[j] ? 0.0 : gamma;
+      const double vj = (double)v[j], vn = (double)(j + 1 < T ? v[j + 1] : vb);
+      const double delta = __dsub_rn(__dadd_rn(r[j], __dmul_rn(disc, vn)), vj);
+      double a = delta;
+      if (j < T - 1) a = __dadd_rn(delta, __dmul_rn(__dmul_rn(carry, disc), lam));
+      adv[r0 + j] = a;
+      target[r0 + j] = __dadd_rn(a, vj);
+      carry = a;
+    }
+  }
+}
+
+// zero-pad the innermost axis of a [rows, c_src] array to [rows, c_dst] (elements of 1 or 4 bytes): image observations
+// whose channel count is not a multiple of 4 (examples/ant_ppo.yaml: [84, 84, 3]) enter the first layer as C = 4 with a
+// zero plane -- the weights' fourth input-channel rows see a zero operand, get a zero gradient and stay zero (exact).
+template <typename E>
+__global__ __launch_bounds__(256) void pad_channels_kernel(const E* __restrict__ src, E* __restrict__ dst, long long rows,
+                                                           int c_src, int c_dst, E fill) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= rows * c_dst) return;
+  const long long r = e / c_dst;
+  const int c = (int)(e - r * c_dst);
+  dst[e] = c < c_src ? src[r * c_src + c] : fill;
+}
+
 int launch_ppo_loss_gauss(const float* mean, const float* log_std, const float* value, int B, int A, const int32_t* idx,
                           const float* action, const float* old_logp, const double* adv, const float* old_v,
                           const double* target_v, float clip_ratio, float ent_coef, float vf_clip, float critic_coef,
@@ -1204,6 +1284,38 @@ int xt_gae_f64(const float* value, const double* reward, const uint8_t* done, do
   else
     hipLaunchKernelGGL(xt::gae_f64_kernel, dim3((n_traj + 63) / 64), dim3(64), 0, xt::as_stream(stream), value, reward,
                        done, adv, target_value, old_value, n_traj, T, gamma, lam);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
+int xt_gae_f64_ragged(const float* value_rows, const float* boot, const double* reward, const uint8_t* done,
+                      const int32_t* offsets, double* adv, double* target_value, int32_t n_traj, double gamma, double lam,
+                      void* stream) {
+  XT_REQUIRE(n_traj >= 0, "xt_gae_f64_ragged: bad sizes");
+  if (n_traj == 0) return 0;
+  XT_REQUIRE(value_rows && boot && reward && done && offsets && adv && target_value, "xt_gae_f64_ragged: null argument");
+  hipLaunchKernelGGL(xt::gae_f64_ragged_kernel, dim3(n_traj), dim3(256), 0, xt::as_stream(stream), value_rows, boot, reward,
+                     done, offsets, adv, target_value, gamma, lam);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
+int xt_pad_channels(const void* src, void* dst, int64_t rows, int32_t c_src, int32_t c_dst, int32_t elem_bytes,
+                    int32_t fill_u8, void* stream) {
+  XT_REQUIRE(src && dst && rows >= 0 && c_src > 0 && c_dst >= c_src && (elem_bytes == 1 || elem_bytes == 4),
+             "xt_pad_channels: bad arguments (c_src=%d c_dst=%d elem_bytes=%d)", c_src, c_dst, elem_bytes);
+  XT_REQUIRE(fill_u8 >= 0 && fill_u8 <= 255, "xt_pad_channels: fill byte %d outside [0,255]", fill_u8);
+  if (rows == 0) return 0;
+  const long long n = (long long)rows * c_dst;
+  XT_REQUIRE((n + 255) / 256 < (1ll << 31), "xt_pad_channels: array too large");
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (elem_bytes == 1)
+    hipLaunchKernelGGL((xt::pad_channels_kernel<uint8_t>), grid, dim3(256), 0, xt::as_stream(stream),
+                       static_cast<const uint8_t*>(src), static_cast<uint8_t*>(dst), (long long)rows, c_src, c_dst,
+                       (uint8_t)fill_u8);
+  else
+    hipLaunchKernelGGL((xt::pad_channels_kernel<float>), grid, dim3(256), 0, xt::as_stream(stream),
+                       static_cast<const float*>(src), static_cast<float*>(dst), (long long)rows, c_src, c_dst, 0.f);
   XT_LAUNCH_CHECK();
   return 0;
 }

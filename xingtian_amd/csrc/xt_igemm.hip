@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(const FwdArgs p) {
         for (int q = 0; q < 4; ++q) v[q] = act_apply(v[q] + (n + q < g.N ? p.bias[n + q] : 0.f), g.act);
       }
       float* dst = outp + (size_t)m * g.N + n;
-      if (n + 3 < g.N && (g.N & 3) == 0) store4_wt(dst, make_float4(v[0], v[1], v[2], v[3]));
+      if (n + 3 < g.N && (g.N & 3) == 0) store4_wt(outp, (size_t)m * g.N + n, make_float4(v[0], v[1], v[2], v[3]));
       else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) if (n + q < g.N) dst[q] = v[q];
@@ -753,7 +753,7 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int kr = i0 + (wi * TI + ti) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (kr < g.K && n < g.N) { store1_wt(&out[(size_t)kr * g.N + n], acc[ti][tj][r]); sq += acc[ti][tj][r] * acc[ti][tj][r]; }
+        if (kr < g.K && n < g.N) { store1_wt(out, (size_t)kr * g.N + n, acc[ti][tj][r]); sq += acc[ti][tj][r] * acc[ti][tj][r]; }
       }
     }
   if (do_bias) {
@@ -1038,7 +1038,7 @@ __device__ __forceinline__ void igemm_dgrad_body(const DgradArgs& p, const int b
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int off = rowOut[(wi * TI + ti) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
-        if (off >= 0 && cok) store1_wt(&p.dx[(size_t)off + c], acc[ti][tj][r] * act_grad(xv[ti][tj][r], p.act_prev));
+        if (off >= 0 && cok) store1_wt(p.dx, (size_t)off + c, acc[ti][tj][r] * act_grad(xv[ti][tj][r], p.act_prev));
       }
     }
   XT_TL(4);
@@ -1253,7 +1253,7 @@ __device__ __forceinline__ void igemm_dgrad4_body(const DgradArgs& p, const int 
       v.y *= act_grad(xv[q].y, p.act_prev);
       v.z *= act_grad(xv[q].z, p.act_prev);
       v.w *= act_grad(xv[q].w, p.act_prev);
-      if (roff[q] >= 0) store4_wt(p.dx + (size_t)(roff[q] + coff), v);
+      if (roff[q] >= 0) store4_wt(p.dx, (size_t)(roff[q] + coff), v);
     }
   };
   if (p.xmask) {
@@ -1277,7 +1277,7 @@ __device__ __forceinline__ void igemm_dgrad4_body(const DgradArgs& p, const int 
         const uint32_t bits = mw[cls][q] >> tc4;
         v.x = (bits & 1u) ? v.x : 0.f; v.y = (bits & 2u) ? v.y : 0.f;
         v.z = (bits & 4u) ? v.z : 0.f; v.w = (bits & 8u) ? v.w : 0.f;
-        if (roff[q] >= 0) store4_wt(p.dx + (size_t)(roff[q] + coff), v);
+        if (roff[q] >= 0) store4_wt(p.dx, (size_t)(roff[q] + coff), v);
       }
     }
     XT_TL(4);

@@ -43,12 +43,14 @@ int launch_act_apply(const float* z, float* y, long long count, int act, hipStre
 int launch_wgrad(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*, const float*,
                  float*, float*, int, hipStream_t, int reduce_now = 1, int* msplit_out = nullptr, int slab_cap = 0);
 int launch_dgrad(const xt_conv_geom*, int, const float*, const float*, const float*, int, float*, hipStream_t);
-int launch_global_norm(const float*, long long, float, float, float, float, float, int, float*, float*, hipStream_t);
+int launch_global_norm(const float*, long long, float, float, float, float, float, int, float*, float*, hipStream_t,
+                       const float* lr_dev = nullptr, int* nblocks_out = nullptr);
 int launch_grads_finish(GradTable*, float*, int, int*, const FinalizeArgs*, hipStream_t, unsigned select = 0,
                         unsigned early = 0);
 int grads_finish_resident_blocks();
 int grads_finish_fused_grid(const GradTable*);
-int launch_norm_finalize(const float*, int, float, float, float, float, float, int, float*, const LossArgs*, hipStream_t);
+int launch_norm_finalize(const float*, int, float, float, float, float, float, int, float*, const LossArgs*, hipStream_t,
+                         const float* lr_dev = nullptr);
 int launch_ppo_heads_fused(const PpoHeadArgs&, hipStream_t);
 int launch_adam_clip(float*, const float*, float*, float*, long long, float, float, float, float*, const float*, int,
                      float, float, hipStream_t);
@@ -112,6 +114,11 @@ struct xt_net {
   xt_grad_exchange_fn xchg = nullptr;  // xt_net_set_grad_exchange
   void* xchg_user = nullptr;
   int xchg_flags = 0;                  // XT_XCHG_OVERLAP: two buckets, the first exchanged under the rest of the backward
+  // xt_net_set_rccl: the exchange served by the library itself (a direct call of ncclAllReduce through the function
+  // pointer the caller resolved, no host-language trampoline on the enqueue path)
+  void* rccl_comm = nullptr;
+  xt_nccl_allreduce_fn rccl_fn = nullptr;
+  int rccl_calls = 0, rccl_last_error = 0;
   hipStream_t xchg_stream = nullptr;   // side stream of the first bucket's exchange
   hipEvent_t xchg_fork = nullptr, xchg_join = nullptr;
   // single-GPU tail overlap (xt_tuning.tail_overlap): a side stream for the first gradient bucket's slab reduction and
@@ -405,6 +412,9 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
                     bool defer_join = false) {
   XT_REQUIRE(n->params && n->ws, "xt_net: buffers not bound (call xt_net_bind)");
   XT_REQUIRE(B > 0 && B <= n->maxB, "xt_net_ppo_step: batch %d outside (0,%d]", B, n->maxB);
+  XT_REQUIRE(apply >= 0 && apply <= 2, "xt_net_ppo_step: bad apply mode %d", apply);
+  XT_REQUIRE(apply != 2 || (n->xchg && n->xchg_stream && n->xchg_fork && n->xchg_join),
+             "xt_net_ppo_step: the overlapped exchange mode needs a hook installed with XT_XCHG_OVERLAP");
   const bool gauss = (n->action_type == XT_ACTION_DIAG_GAUSSIAN);
   const int32_t* action = static_cast<const int32_t*>(action_v);
   Layer& Lp0 = n->layers[n->t_end[0] - 1];
@@ -675,6 +685,10 @@ int xt_tuning_set(const xt_tuning* in) {
 }
 const char* xt_last_error(void) { return xt::g_err; }
 const char* xt_build_arch(void) { return "gfx950"; }
+#ifndef XT_SRC_SHA
+#define XT_SRC_SHA "unknown"
+#endif
+const char* xt_build_sources_sha(void) { return XT_SRC_SHA; }
 
 int xt_net_create(const xt_net_desc* d, int32_t max_batch, xt_net** out) {
   XT_REQUIRE(d && out && max_batch > 0, "xt_net_create: bad arguments");
@@ -808,7 +822,9 @@ int xt_net_ppo_step(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, const i
                     const void* action, const float* old_logp, const double* adv, const float* old_v,
                     const double* target_v, int32_t apply, float* loss_out, float* loss_acc, void* stream) {
   XT_REQUIRE(net && cfg, "xt_net_ppo_step: null argument");
-  return xt::ppo_step(net, cfg, obs, idx, B, action, old_logp, adv, old_v, target_v, apply, loss_out, loss_acc,
+  // `apply` is a boolean on the ABI; the internal tri-state (2 = overlapped data-parallel exchange) is only reachable
+  // from xt_net_ppo_train with a hook installed
+  return xt::ppo_step(net, cfg, obs, idx, B, action, old_logp, adv, old_v, target_v, apply ? 1 : 0, loss_out, loss_acc,
                       xt::as_stream(stream));
 }
 
@@ -818,12 +834,28 @@ static int ppo_train_enqueue(xt_net* net, const xt_ppo_cfg* c, const void* obs, 
   XT_CHECK_HIP(hipMemsetAsync(loss_acc, 0, 2 * sizeof(float), st));
   for (int ep = 0; ep < c->num_sgd_iter; ++ep) {
     for (int start = 0; start < n; start += c->batch_size) {
-      const int B = (n - start) < c->batch_size ? (n - start) : c->batch_size;
+      int B = (n - start) < c->batch_size ? (n - start) : c->batch_size;
       xt_ppo_cfg cc = *c;
       if (cc.global_batch > 0 && B != c->batch_size)   // short last minibatch: keep the local/global ratio
         cc.global_batch = (int)((long long)cc.global_batch * B / c->batch_size);
+      const int32_t* rows = perm + (size_t)ep * n + start;
+      if (c->shard_world > 1) {
+        // strict data parallelism (ABI >= 9): this rank owns a balanced contiguous shard of every GLOBAL minibatch of the
+        // shared permutation (xingtian_amd/parallel.py::shard_range); the loss means run over the global rows
+        XT_REQUIRE(c->shard_rank >= 0 && c->shard_rank < c->shard_world, "xt_net_ppo_train: shard_rank %d outside [0,%d)",
+                   c->shard_rank, c->shard_world);
+        XT_REQUIRE(B >= c->shard_world, "xt_net_ppo_train: a minibatch of %d rows cannot be split over %d ranks", B,
+                   c->shard_world);
+        XT_REQUIRE(net->xchg, "xt_net_ppo_train: sharded minibatches need a gradient exchange (xt_net_set_rccl / "
+                              "xt_net_set_grad_exchange)");
+        const int base = B / c->shard_world, rem = B % c->shard_world;
+        const int b0 = c->shard_rank * base + (c->shard_rank < rem ? c->shard_rank : rem);
+        cc.global_batch = B;
+        rows += b0;
+        B = base + (c->shard_rank < rem ? 1 : 0);
+      }
       if (!net->xchg) {
-        if (int rc = xt::ppo_step(net, &cc, obs, perm + (size_t)ep * n + start, B, action, old_logp, adv, old_v,
+        if (int rc = xt::ppo_step(net, &cc, obs, rows, B, action, old_logp, adv, old_v,
                                   target_v, 1, nullptr, loss_acc, st, /*defer_join*/ true))
           return rc;
         continue;
@@ -833,7 +865,7 @@ static int ppo_train_enqueue(xt_net* net, const xt_ppo_cfg* c, const void* obs, 
       const int64_t off_a = net->layers.back().poff;      // first bucket = [off_a, P): last trunk layer + heads
       const bool overlap = (net->xchg_flags & XT_XCHG_OVERLAP) && net->n_trunks == 1 && net->layers.size() > 1 &&
                            off_a > 0 && net->pi_off > off_a && net->v_off > off_a && net->xchg_stream != nullptr;
-      if (int rc = xt::ppo_step(net, &cc, obs, perm + (size_t)ep * n + start, B, action, old_logp, adv, old_v,
+      if (int rc = xt::ppo_step(net, &cc, obs, rows, B, action, old_logp, adv, old_v,
                                 target_v, overlap ? 2 : 0, nullptr, loss_acc, st))
         return rc;
       if (overlap) {
@@ -860,8 +892,8 @@ int xt_net_ppo_train(xt_net* net, const xt_ppo_cfg* c, const void* obs, int32_t 
   if (!use_graph)
     return ppo_train_enqueue(net, c, obs, n, perm, action, old_logp, adv, old_v, target_v, loss_acc, st);
   char key[512];
-  snprintf(key, sizeof(key), "P%d|%p|%p|%p|%d|%p|%p|%p|%p|%p|%p|%p|%g|%g|%g|%g|%g|%g|%g|%g|%g|%d|%d|%g|%d",
-           net->xchg_flags, (void*)net->xchg, net->xchg_user, obs, n,
+  snprintf(key, sizeof(key), "P%d.%d.%d|%p|%p|%p|%d|%p|%p|%p|%p|%p|%p|%p|%g|%g|%g|%g|%g|%g|%g|%g|%g|%d|%d|%g|%d",
+           net->xchg_flags, c->shard_rank, c->shard_world, (void*)net->xchg, net->xchg_user, obs, n,
            (const void*)perm, (const void*)action, (const void*)old_logp, (const void*)adv, (const void*)old_v,
            (const void*)target_v, (void*)loss_acc, c->lr, c->beta1, c->beta2, c->eps, c->clip_ratio, c->ent_coef,
            c->vf_clip, c->critic_coef, c->max_grad_norm, c->batch_size, c->num_sgd_iter, c->grad_scale,
@@ -897,14 +929,26 @@ static int impala_train_enqueue(xt_net* net, const xt_impala_cfg* c, const void*
     }
     // data parallel: local gradient of this rank's trajectories -> SUM over the replicas (the loss is a sum:
     // grad_scale = 1) -> norm of the exchanged gradient, clip, optimiser
-    XT_REQUIRE(c->opt_type == XT_OPT_ADAM && !lr_dev,
-               "xt_net_impala_train: the gradient exchange path supports Adam with a fixed step size");
     if (int rc = xt::impala_step(net, c, o, nfr, bp_logits + (size_t)lo * net->A, action + lo, done + lo, reward + lo, 0,
                                  lr_dev, nullptr, loss_acc, st))
       return rc;
     XT_REQUIRE(net->xchg(net->grads, net->P, net->xchg_user, st) == 0, "xt_net_impala_train: gradient exchange hook failed");
-    if (int rc = xt::net_apply(net, c->lr, c->beta1, c->beta2, c->eps, c->grad_norm_clip, c->grad_scale, 0, nullptr, st))
+    // norm of the EXCHANGED gradient (+ the step-size bookkeeping; lr_schedule's value is read on the device), then the
+    // configured optimiser: Adam, or centred RMSProp which derives the clip factor from the same partials itself
+    int nb = 0;
+    if (int rc = xt::launch_global_norm(net->grads, net->P, c->grad_norm_clip, c->grad_scale, c->lr, c->beta1, c->beta2, 1,
+                                        net->state, net->ws + net->off_norm, st, lr_dev, &nb))
       return rc;
+    if (c->opt_type == XT_OPT_RMSPROP_CENTERED) {
+      if (int rc = xt::launch_rmsprop_clip(net->params, net->grads, net->m, net->v, net->P, c->lr, c->rms_decay, c->rms_eps,
+                                           net->state, net->ws + net->off_norm, nb, c->grad_norm_clip, c->grad_scale, st,
+                                           lr_dev))
+        return rc;
+    } else {
+      XT_REQUIRE(c->opt_type == XT_OPT_ADAM, "xt_net_impala_train: unknown opt_type %d", c->opt_type);
+      if (int rc = xt::launch_adam(net->params, net->grads, net->m, net->v, net->P, c->beta1, c->beta2, c->eps, net->state, st))
+        return rc;
+    }
   }
   return xt::join_pending_update(net, st);
 }
@@ -975,6 +1019,33 @@ int xt_net_set_grad_exchange_ex(xt_net* net, xt_grad_exchange_fn fn, void* user,
 
 int xt_net_set_grad_exchange(xt_net* net, xt_grad_exchange_fn fn, void* user) {
   return xt_net_set_grad_exchange_ex(net, fn, user, 0);
+}
+
+// the exchange served by the library: ncclAllReduce(grads, grads, count, ncclFloat32, ncclSum, comm, stream) through the
+// function pointer the caller resolved from the RCCL instance of its process (dlsym / ctypes)
+static int rccl_exchange(float* grads, int64_t count, void* user, void* stream) {
+  xt_net* net = static_cast<xt_net*>(user);
+  const int rc = net->rccl_fn(grads, grads, (size_t)count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, net->rccl_comm, stream);
+  net->rccl_calls++;
+  if (rc != 0) net->rccl_last_error = rc;
+  return rc;
+}
+
+int xt_net_set_rccl(xt_net* net, void* comm, xt_nccl_allreduce_fn allreduce, int32_t flags) {
+  XT_REQUIRE(net, "xt_net_set_rccl: null net");
+  if (!comm || !allreduce) {
+    net->rccl_comm = nullptr; net->rccl_fn = nullptr;
+    return xt_net_set_grad_exchange_ex(net, nullptr, nullptr, 0);
+  }
+  net->rccl_comm = comm; net->rccl_fn = allreduce; net->rccl_calls = 0; net->rccl_last_error = 0;
+  return xt_net_set_grad_exchange_ex(net, rccl_exchange, net, flags);
+}
+
+int xt_net_rccl_status(const xt_net* net, int32_t* calls, int32_t* last_error) {
+  XT_REQUIRE(net, "xt_net_rccl_status: null net");
+  if (calls) *calls = net->rccl_calls;
+  if (last_error) *last_error = net->rccl_last_error;
+  return 0;
 }
 
 int xt_net_apply(xt_net* n, float lr, float beta1, float beta2, float eps, float clip_norm, float grad_scale,

@@ -410,9 +410,10 @@ __device__ void finalize_body(const float* partial, int nblocks, float clip_norm
 
 __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restrict__ partial, int nblocks, float clip_norm,
                                                             float grad_scale, float lr, float beta1, float beta2,
-                                                            int advance, float* __restrict__ state, LossArgs la) {
+                                                            int advance, float* __restrict__ state, LossArgs la,
+                                                            const float* __restrict__ lr_dev) {
   __shared__ double sh[256];
-  finalize_body(partial, nblocks, clip_norm, grad_scale, lr, beta1, beta2, advance, state, la, sh);
+  finalize_body(partial, nblocks, clip_norm, grad_scale, lr_dev ? lr_dev[0] : lr, beta1, beta2, advance, state, la, sh);
 }
 
 __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -723,17 +724,19 @@ int launch_adam_keras(float* param, const float* grad, float* m, float* v, int n
 }
 
 int launch_norm_finalize(const float* partial, int nblocks, float clip_norm, float grad_scale, float lr, float beta1,
-                         float beta2, int advance, float* state, const LossArgs* la, hipStream_t st) {
+                         float beta2, int advance, float* state, const LossArgs* la, hipStream_t st,
+                         const float* lr_dev = nullptr) {
   LossArgs l{};
   if (la) l = *la;
   hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblocks, clip_norm, grad_scale, lr, beta1,
-                     beta2, advance, state, l);
+                     beta2, advance, state, l, lr_dev);
   XT_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_global_norm(const float* grad, long long count, float clip_norm, float grad_scale, float lr, float beta1,
-                       float beta2, int advance, float* state, float* scratch, hipStream_t st) {
+                       float beta2, int advance, float* state, float* scratch, hipStream_t st, const float* lr_dev,
+                       int* nblocks_out) {
   XT_REQUIRE(count > 0 && grad && state && scratch, "global_norm: bad arguments");
   XT_REQUIRE(((uintptr_t)grad & 15) == 0, "global_norm: grad must be 16-byte aligned");
   int nb = (int)((count / 4 + 255) / 256);
@@ -741,7 +744,8 @@ int launch_global_norm(const float* grad, long long count, float clip_norm, floa
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nb), dim3(256), 0, st, grad, count, scratch);
   XT_LAUNCH_CHECK();
-  return launch_norm_finalize(scratch, nb, clip_norm, grad_scale, lr, beta1, beta2, advance, state, nullptr, st);
+  if (nblocks_out) *nblocks_out = nb;
+  return launch_norm_finalize(scratch, nb, clip_norm, grad_scale, lr, beta1, beta2, advance, state, nullptr, st, lr_dev);
 }
 
 int launch_adam(float* param, const float* grad, float* m, float* v, long long count, float beta1, float beta2,
@@ -769,7 +773,7 @@ int xt_adam_state_init(float* state, void* stream) {
 int xt_grad_global_norm(const float* grad, int64_t count, float clip_norm, float grad_scale, float* state,
                         float* scratch, void* stream) {
   return xt::launch_global_norm(grad, count, clip_norm, grad_scale, 0.f, 0.f, 0.f, 0, state, scratch,
-                                xt::as_stream(stream));
+                                xt::as_stream(stream), nullptr, nullptr);
 }
 
 int xt_adam_keras(float* param, const float* grad, float* m, float* v, int32_t n_seg, const int64_t* seg_off,
@@ -783,7 +787,7 @@ int xt_adam_tf_clip(float* param, const float* grad, float* m, float* v, int64_t
                     float beta2, float eps, float clip_norm, float grad_scale, float* state, float* scratch,
                     void* stream) {
   if (int rc = xt::launch_global_norm(grad, count, clip_norm, grad_scale, lr, beta1, beta2, 1, state, scratch,
-                                      xt::as_stream(stream)))
+                                      xt::as_stream(stream), nullptr, nullptr))
     return rc;
   return xt::launch_adam(param, grad, m, v, count, beta1, beta2, eps, state, xt::as_stream(stream));
 }

@@ -71,19 +71,33 @@ class _BufferSet(object):
             self.dev[name] = self.lab_dev[o:o + nbytes].view(tdt2).view(shape)
         if n_epochs > 0:
             self.dev["perm"] = torch.empty((n_epochs, cap), dtype=torch.int32, device=device)
+        if any(f[0] == "boot" for f in fields):      # ragged-GAE row offsets: [n_traj + 1] <= cap + 1 entries
+            self.host["offsets"] = torch.empty((cap + 1,), dtype=torch.int32, pin_memory=True)
+            self.dev["offsets"] = torch.empty((cap + 1,), dtype=torch.int32, device=device)
+        self.dev_padded = None      # [cap, H, W, pad4(C)] copy of the frames (RolloutIngest.pad_channels)
         self.host_np = {k: v.numpy() for k, v in self.host.items()}
         self.done = torch.cuda.Event()
         self.free = None          # recorded on the compute stream after the update that read this set
 
 
+# extra label fields of a trajectory that arrives WITHOUT advantages (value / reward / done instead): the inputs of the
+# learner-side GAE (xt/agent/ppo/ppo.py:77-106 moved to the learner GPU, one xt_gae_f64_ragged per rollout)
+PPO_RAW_FIELDS = (("reward", torch.float64, 0), ("done", torch.uint8, 0), ("boot", torch.float32, 0))
+
+
 class RolloutIngest(object):
-    def __init__(self, device, n_epochs, initial_capacity=4096, obs_u8=None, fields=PPO_FIELDS):
+    def __init__(self, device, n_epochs, initial_capacity=4096, obs_u8=None, fields=PPO_FIELDS, pad_channels=None):
         """``obs_u8``: the observation type the NETWORK reads (``spec.input_xform[0]``: uint8 frames vs float32);
         arriving arrays of another dtype are cast into the staging buffer like the upload path casts them.  None
         = take the dtype of the first array (stand-alone use).  ``fields``: the label arrays that travel with the
         observations (``PPO_FIELDS`` / ``impala_fields(A)``); ``n_epochs`` = 0: no permutation buffer."""
         self.obs_u8 = obs_u8
         self.fields = tuple(fields)
+        # pad_channels = (c_dst, fill byte): image observations are staged with their own channel count and expanded on
+        # the device to the multiple of 4 the first layer reads (xt_pad_channels), see netspec._conv
+        self.pad_channels = pad_channels
+        self.raw_traj = 0               # trajectories of the current rollout that came without advantages
+        self.adv_traj = 0               # ... and with them
         self.device = torch.device(device)
         self.n_epochs = n_epochs
         self.initial_capacity = initial_capacity
@@ -113,12 +127,13 @@ class RolloutIngest(object):
                 new.dev["obs"][:self.n].copy_(s.dev["obs"][:self.n], non_blocking=True)
             for k in new.host:
                 if k != "obs":
-                    new.host[k][:self.n].copy_(s.host[k][:self.n])
+                    m = self.n + 1 if k == "offsets" else self.n
+                    new.host[k][:m].copy_(s.host[k][:m])
             self.copy_stream.synchronize()             # the old set is released when this function returns
         self.sets[self.cur] = new
         return new
 
-    def put(self, obs, *labels, pinned=False, slot_guard=None):
+    def put(self, obs, *labels, pinned=False, slot_guard=None, _raw=False):
         """Append one trajectory / rollout message ([T,...] arrays as the explorer ships them, labels in the order
         of ``fields``) and start the H2D copy of its frames.  ``pinned``: the arrays are views into page-locked memory
         (a pinned transport ring): frames whose dtype already is the device dtype are DMA-copied straight from the
@@ -131,9 +146,14 @@ class RolloutIngest(object):
         if self.n == 0 and s.free is not None:      # do not overwrite a set an enqueued update still reads
             self.copy_stream.wait_event(s.free)
         lo, hi = self.n, self.n + t
+        n_raw = sum(1 for f in self.fields if f in PPO_RAW_FIELDS)
+        if len(labels) == len(self.fields) - n_raw and n_raw:
+            labels = tuple(labels) + (None,) * n_raw        # a trajectory that brings its advantages: no GAE inputs
         if len(labels) != len(self.fields):
             raise ValueError("RolloutIngest.put: {} label arrays for fields {}".format(
                 len(labels), [f[0] for f in self.fields]))
+        if not _raw:
+            self.adv_traj += 1
         obs_dst = s.host_np["obs"][lo:hi]
         row_bytes = obs_dst.dtype.itemsize * int(np.prod(obs_dst.shape[1:], dtype=np.int64))
         dev_ptr = s.dev["obs"].data_ptr() + lo * row_bytes
@@ -157,11 +177,43 @@ class RolloutIngest(object):
             with torch.cuda.stream(self.copy_stream):
                 s.dev["obs"][lo:hi].copy_(s.host["obs"][lo:hi], non_blocking=True)
         for f, a in zip(self.fields, labels):
+            if a is None:                    # filled by the caller (put_raw) or on the device (GAE outputs)
+                continue
             arr = np.asarray(a)
             dst = s.host_np[f[0]][lo:hi]
             # bool -> uint8 and float64 -> float32 are the casts the reference's placeholders apply
             np.copyto(dst, arr.reshape(dst.shape), casting="unsafe" if arr.dtype == np.bool_ else "same_kind")
         self.n = hi
+        return s, lo, hi
+
+    def put_raw(self, obs, action, logp, value, reward, done, pinned=False, slot_guard=None):
+        """A PPO trajectory as the explorer holds it BEFORE ``data_proc`` (xt/agent/ppo/ppo.py:77-106): value [T+1],
+        reward [T], done [T] instead of adv / old_value / target_value.  The value column is staged as ``old_v`` (it is
+        that column), the bootstrap value and the row range are kept per trajectory; ``gae_on_device`` then fills adv /
+        target_v for the whole rollout with one kernel launch."""
+        names = [f[0] for f in self.fields]
+        if "boot" not in names:
+            raise RuntimeError("RolloutIngest.put_raw: built without PPO_RAW_FIELDS")
+        value = np.asarray(value, np.float32).reshape(-1)
+        t = int(np.asarray(obs).shape[0])
+        if value.shape[0] != t + 1:
+            raise ValueError("put_raw: value must have T+1 = {} entries, got {}".format(t + 1, value.shape[0]))
+        by_name = dict(action=action, old_logp=logp, adv=None, old_v=value[:t], target_v=None,
+                       reward=np.asarray(reward, np.float64), done=np.asarray(done, bool), boot=None)
+        s, lo, hi = self.put(obs, *[by_name[n] for n in names], pinned=pinned, slot_guard=slot_guard, _raw=True)
+        k = self.raw_traj
+        s.host_np["boot"][k] = value[t]
+        s.host_np["offsets"][k] = lo
+        s.host_np["offsets"][k + 1] = hi
+        self.raw_traj = k + 1
+
+    def gae_on_device(self, dev, n, gamma, lam, stream_ptr):
+        """adv / target_v of the rollout just finished, on the device (C ABI xt_gae_f64_ragged; float64, bit-exact with
+        the reference's numpy loop).  Call after ``finish`` on the compute stream."""
+        k = self.last_raw_traj
+        L.check(self._lib.xt_gae_f64_ragged(L.ptr(dev["old_v"]), L.ptr(dev["boot"]), L.ptr(dev["reward"]), L.ptr(dev["done"]),
+                                            L.ptr(dev["offsets"]), L.ptr(dev["adv"]), L.ptr(dev["target_v"]), k,
+                                            float(gamma), float(lam), stream_ptr), "xt_gae_f64_ragged")
 
     def finish(self):
         """All trajectories are in: make the compute stream wait for the copies, return (n, device buffers) and
@@ -170,14 +222,30 @@ class RolloutIngest(object):
         n = self.n
         if s is None or n == 0:
             raise RuntimeError("RolloutIngest.finish(): nothing was ingested")
+        if self.raw_traj and self.adv_traj:
+            raise RuntimeError("RolloutIngest.finish(): a rollout must not mix trajectories with and without advantages")
+        dev = s.dev
         with torch.cuda.stream(self.copy_stream):          # the labels of the whole rollout: ONE copy (a few 10 KB)
             s.lab_dev.copy_(s.lab_host, non_blocking=True)
+            if self.raw_traj:
+                s.dev["offsets"][:self.raw_traj + 1].copy_(s.host["offsets"][:self.raw_traj + 1], non_blocking=True)
+            if self.pad_channels is not None and s.dev["obs"].shape[-1] != self.pad_channels[0]:
+                c_dst, fill = self.pad_channels
+                src = s.dev["obs"]
+                if s.dev_padded is None:
+                    s.dev_padded = torch.empty(tuple(src.shape[:-1]) + (c_dst,), dtype=src.dtype, device=src.device)
+                rows = n * int(np.prod(src.shape[1:-1], dtype=np.int64))
+                L.check(self._lib.xt_pad_channels(L.ptr(src), L.ptr(s.dev_padded), rows, int(src.shape[-1]), c_dst,
+                                                  src.element_size(), int(fill),
+                                                  ctypes.c_void_p(self.copy_stream.cuda_stream)), "xt_pad_channels")
+                dev = dict(s.dev, obs=s.dev_padded)
         s.done.record(self.copy_stream)
         torch.cuda.current_stream(self.device).wait_event(s.done)
         self.cur ^= 1
         self.n = 0
         self.last = s
-        return n, s.dev
+        self.last_raw_traj, self.raw_traj, self.adv_traj = self.raw_traj, 0, 0
+        return n, dev
 
     def mark_consumed(self):
         """call after the update that reads the last finished set has been enqueued on the compute stream"""
@@ -187,3 +255,4 @@ class RolloutIngest(object):
 
     def reset(self):
         self.n = 0
+        self.raw_traj = self.adv_traj = 0

@@ -30,7 +30,7 @@ class LayerDesc(Structure):
     _fields_ = [("g", ConvGeom), ("param_off", c_int64), ("trunk", c_int32)]
 
 
-ABI_VERSION = 8          # XT_ABI_VERSION of include/xt_mi355x.h
+ABI_VERSION = 9          # XT_ABI_VERSION of include/xt_mi355x.h
 ACTION_TYPE = {"Categorical": 0, "DiagGaussian": 1}
 
 
@@ -45,7 +45,8 @@ class PpoCfg(Structure):
     _fields_ = [("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
                 ("clip_ratio", c_float), ("ent_coef", c_float), ("vf_clip", c_float),
                 ("critic_coef", c_float), ("max_grad_norm", c_float), ("batch_size", c_int32),
-                ("num_sgd_iter", c_int32), ("grad_scale", c_float), ("global_batch", c_int32)]
+                ("num_sgd_iter", c_int32), ("grad_scale", c_float), ("global_batch", c_int32),
+                ("shard_rank", c_int32), ("shard_world", c_int32)]
 
 
 class ImpalaCfg(Structure):
@@ -72,6 +73,11 @@ SIGNATURES = {
     "xt_last_launch_arith": (c_int32, []),
     "xt_last_error": (c_char_p, []),
     "xt_build_arch": (c_char_p, []),
+    "xt_build_sources_sha": (c_char_p, []),
+    "xt_gae_f64_ragged": (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_double, c_double, _P]),
+    "xt_pad_channels": (c_int32, [_P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P]),
+    "xt_net_set_rccl": (c_int32, [_P, _P, _P, c_int32]),
+    "xt_net_rccl_status": (c_int32, [_P, POINTER(c_int32), POINTER(c_int32)]),
     "xt_tuning_get": (c_int32, [POINTER(Tuning)]),
     "xt_tuning_set": (c_int32, [POINTER(Tuning)]),
     "xt_stage_rows": (c_int32, [_P, _P, c_int64, _P, c_int64, c_int64, c_int32, _P]),
@@ -188,6 +194,13 @@ def kernel_sources_sha():
             with open(os.path.join(src, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
+
+
+def built_sources_sha():
+    """The digest the LOADED library was compiled from (xt_build_sources_sha, embedded by csrc/Makefile).  Differs from
+    ``kernel_sources_sha()`` when a stale prebuilt ``.so`` sits next to newer sources."""
+    v = load().xt_build_sources_sha()
+    return v.decode() if v else "unknown"
 
 
 def require_gpu():

@@ -85,9 +85,8 @@ class CpuActorCritic(object):
     # ------------------------------------------------------------------ weights by TF variable name
     def get_weights(self):
         out = OrderedDict()
-        for name, (off, shape) in self.spec.names.items():
-            size = int(np.prod(shape))
-            out[name] = self.params[off:off + size].reshape(shape).copy()
+        for name in self.spec.names:
+            out[name] = self.spec.var_view(self.params, name).copy()
         return out
 
     def set_weights(self, weights):
@@ -101,7 +100,7 @@ class CpuActorCritic(object):
             val = np.asarray(weights[name], np.float32)
             if tuple(val.shape) != tuple(shape):
                 raise KeyError("update {} encounter error: shape {} vs {}".format(name, val.shape, shape))
-            self.params[off:off + val.size] = val.reshape(-1)
+            self.spec.var_view(self.params, name)[...] = val
 
     # ------------------------------------------------------------------ forward
     def _layer(self, lay, x):
@@ -139,6 +138,8 @@ class CpuActorCritic(object):
             if x0.shape[1] < lay0.C:
                 x0 = np.pad(x0, ((0, 0), (0, lay0.C - x0.shape[1])))
             x0 = x0.reshape(x0.shape[0], 1, 1, lay0.C)
+        elif x0.ndim == 4 and x0.shape[3] < lay0.C:          # image channels zero-padded to a multiple of 4 (netspec._conv)
+            x0 = np.pad(x0, ((0, 0), (0, 0), (0, 0), (0, lay0.C - x0.shape[3])))
         feats = []
         for tr in range(spec.n_trunks):
             x = x0

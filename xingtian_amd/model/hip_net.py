@@ -42,7 +42,7 @@ class HipActorCritic(object):
         d.n_layers, d.layers, d.n_trunks = len(spec.layers), lay_arr, spec.n_trunks
         d.feat, d.action_dim, d.pi_off, d.v_off, d.n_params = spec.feat, spec.action_dim, spec.pi_off, spec.v_off, n
         d.xf = L.InputXform(*spec.input_xform)
-        d.in_h, d.in_w, d.in_c = spec.layers[0].H, spec.layers[0].W, spec.layers[0].C
+        d.in_h, d.in_w, d.in_c = spec.layers[0].H, spec.layers[0].W, spec.layers[0].C      # (C: as the kernels read it, padded)
         d.action_type = L.ACTION_TYPE[getattr(spec, "action_type", "Categorical")]
         d.logstd_off = getattr(spec, "logstd_off", 0)
         self._desc = d
@@ -111,28 +111,38 @@ class HipActorCritic(object):
             snap["events"][i].record(snap["stream"])
         snap["slot"], snap["version"] = i, getattr(self, "_version", 0)
 
-    def get_weights(self, copy=False):
+    def get_weights(self, copy=True):
         """dict TF-variable-name -> ndarray (TFVariables.get_weights, xt/model/tf_utils.py:99-102).  The flat
         parameter buffer IS the packed form: ONE pinned D2H -- already in flight when the last update enqueued it
-        (``snapshot_weights_async``), else issued now -- and per-variable VIEWS into the pinned block.  The views stay
-        valid until ``SNAP_SLOTS - 1`` further snapshots have been taken (the learner serialises them right away,
-        xt/framework/learner.py:361-363); ``copy=True`` returns arrays the caller owns."""
+        (``snapshot_weights_async``), else issued now.  By default the arrays are private copies, as the reference hands
+        them out (a caller may keep them: best-checkpoint retention, PBT).  ``copy=False`` returns per-variable VIEWS into
+        the pinned block, valid until ``SNAP_SLOTS - 1`` further snapshots have been taken: for consumers that
+        serialise them at once (``transport.WeightsRing.publish``, ``save_model``)."""
+        flat = self._snapshot_flat()
+        out = OrderedDict()
+        for name in self.spec.names:
+            v = self.spec.var_view(flat, name)
+            out[name] = v.copy() if copy else v
+        return out
+
+    def _snapshot_flat(self):
+        """the flat float32 parameter buffer in pinned host memory, as of everything enqueued so far"""
         snap = getattr(self, "_snap", None)
         if snap is None or snap["version"] != getattr(self, "_version", 0):
             self.snapshot_weights_async()
             snap = self._snap
         snap["version"] = -1            # a pre-enqueued snapshot serves ONE publish; later calls copy again
         snap["events"][snap["slot"]].synchronize()
-        flat = snap["host"][snap["slot"]].numpy()
-        lay = getattr(self, "_name_layout", None)
-        if lay is None:
-            lay = self._name_layout = [(name, off, off + int(np.prod(shape)), tuple(shape))
-                                       for name, (off, shape) in self.spec.names.items()]
-        out = OrderedDict()
-        for name, lo, hi, shape in lay:
-            v = flat[lo:hi].reshape(shape)
-            out[name] = v.copy() if copy else v
-        return out
+        return snap["host"][snap["slot"]].numpy()
+
+    def publish_weights(self, ring, ctr_info=None):
+        """The learner's weight hand-over (xt/framework/learner.py:361-363) without an intermediate dict: the packed
+        parameter block goes pinned block -> ring slot with one copy per variable, or -- when the ring is page-locked
+        (``WeightsRing.pin``) -- by ONE D2H straight from HBM into the slot (no host copy at all).  Returns the
+        publish's sequence number."""
+        if getattr(ring, "pinned", False):
+            return ring.publish_flat_from_device(self, ctr_info)
+        return ring.publish(self.get_weights(copy=False), ctr_info)
 
     def set_weights(self, weights):
         """Assign by name; unknown names are ignored, KeyError if nothing matches
@@ -147,7 +157,7 @@ class HipActorCritic(object):
             val = np.asarray(weights[name], np.float32)
             if tuple(val.shape) != tuple(shape):
                 raise KeyError("update {} encounter error: shape {} vs {}".format(name, val.shape, shape))
-            flat[off:off + val.size] = val.reshape(-1)
+            self.spec.var_view(flat, name)[...] = val
         self.params.copy_(torch.from_numpy(flat))
         self.touch()
 
@@ -168,11 +178,10 @@ class HipActorCritic(object):
         v = self.adam_v.detach().cpu().numpy()
         st = self.adam_state.detach().cpu().numpy()
         out = OrderedDict()
-        for name, (off, shape) in self.spec.names.items():
-            size = int(np.prod(shape))
+        for name in self.spec.names:
             sm, sv = self._slot_suffixes()
-            out[name + sm] = m[off:off + size].reshape(shape).copy()
-            out[name + sv] = v[off:off + size].reshape(shape).copy()
+            out[name + sm] = self.spec.var_view(m, name).copy()
+            out[name + sv] = self.spec.var_view(v, name).copy()
         out[self.OPT_B1] = np.float32(st[0])
         out[self.OPT_B2] = np.float32(st[1])
         out[self.OPT_STEP] = np.int64(round(float(st[5])))
@@ -191,7 +200,7 @@ class HipActorCritic(object):
                 val = np.asarray(state[name + sfx], np.float32)
                 if tuple(val.shape) != tuple(shape):
                     raise KeyError("optimizer slot {} shape {} vs {}".format(name + sfx, val.shape, shape))
-                dst[off:off + val.size] = val.reshape(-1)
+                self.spec.var_view(dst, name)[...] = val
         st = self.adam_state.detach().cpu().numpy().copy()
         st[0], st[1] = np.float32(state[self.OPT_B1]), np.float32(state[self.OPT_B2])
         st[5] = np.float32(state[self.OPT_STEP]) if self.OPT_STEP in state else 0.0
@@ -213,7 +222,28 @@ class HipActorCritic(object):
         lay0 = self.spec.layers[0]
         if t.dim() == 2 and lay0.H == lay0.W == 1 and t.shape[1] < lay0.C:      # zero-pad odd feature counts (netspec._mlp)
             t = torch.nn.functional.pad(t, (0, lay0.C - t.shape[1]))
+        elif t.dim() == 4 and t.shape[3] < lay0.C:                                 # image channels -> multiple of 4
+            t = self.pad_obs_channels(t.contiguous())
         return t.contiguous()
+
+    def obs_fill_byte(self):
+        """the uint8 value the input transform maps to 0 (what padded channel planes are filled with)"""
+        is_u8, mean, _ = self.spec.input_xform
+        if not is_u8 or mean == 0.0:
+            return 0
+        if float(mean) != int(mean) or not 0 <= int(mean) <= 255:
+            raise ValueError("channel padding of uint8 observations needs an integral state_mean in [0, 255], got {}".format(mean))
+        return int(mean)
+
+    def pad_obs_channels(self, t, out=None):
+        """[n, H, W, c] device tensor -> [n, H, W, pad4(c)] with neutral extra planes (C ABI xt_pad_channels)."""
+        c_dst = self.spec.layers[0].C
+        n, h, w, c = t.shape
+        if out is None:
+            out = torch.empty((n, h, w, c_dst), dtype=t.dtype, device=t.device)
+        L.check(self.lib.xt_pad_channels(L.ptr(t), L.ptr(out), n * h * w, c, c_dst, t.element_size(), self.obs_fill_byte(),
+                                         L.stream_ptr()), "xt_pad_channels")
+        return out
 
     def forward(self, obs):
         """obs [B, ...] (host or device) -> (logits [B,A], value [B]) device tensors."""
@@ -228,13 +258,15 @@ class HipActorCritic(object):
                                             L.ptr(value[s:e]), L.stream_ptr()), "xt_net_forward")
         return logits, value
 
-    def make_ppo_cfg(self, cfg, grad_scale=1.0, global_batch=0):
+    def make_ppo_cfg(self, cfg, grad_scale=1.0, global_batch=0, shard_rank=0, shard_world=0):
         c = L.PpoCfg()
         c.lr, c.beta1, c.beta2, c.eps = cfg["LR"], 0.9, 0.999, 1e-8
         c.clip_ratio, c.ent_coef, c.vf_clip = cfg["LOSS_CLIPPING"], cfg["ENTROPY_LOSS"], cfg["VF_CLIP"]
         c.critic_coef, c.max_grad_norm = cfg["CRITIC_LOSS_COEF"], cfg["MAX_GRAD_NORM"]
         c.batch_size, c.num_sgd_iter = int(cfg["BATCH_SIZE"]), int(cfg["NUM_SGD_ITER"])
         c.grad_scale, c.global_batch = grad_scale, int(global_batch)
+        # strict data parallelism inside xt_net_ppo_train: this rank's shard of every global minibatch (ABI >= 9)
+        c.shard_rank, c.shard_world = int(shard_rank), int(shard_world)
         return c
 
     def ppo_step(self, c, obs, idx, action, old_logp, adv, old_v, target_v, apply=True):
@@ -311,9 +343,10 @@ class HipActorCritic(object):
         learning rate; ``iterations`` = number of updates applied so far."""
         if not hasattr(self, "_keras_segs"):
             offs, sizes = [], []
-            for _, (off, shape) in self.spec.names.items():
+            for name in self.spec.names:      # (a channel-padded kernel: its storage block; the padding is zero)
+                off, size = self.spec.var_extent(name)
                 offs.append(int(off))
-                sizes.append(int(np.prod(shape)))
+                sizes.append(int(size))
             dev = self.device
             self._keras_segs = (torch.tensor(offs, dtype=torch.int64), torch.tensor(sizes, dtype=torch.int64), len(offs))
             self._keras_scratch = torch.zeros((16 * len(offs),), dtype=torch.float32, device=dev)
@@ -348,7 +381,6 @@ class HipActorCritic(object):
     def grads_dict(self):
         flat = self.grads.detach().cpu().numpy()
         out = OrderedDict()
-        for name, (off, shape) in self.spec.names.items():
-            size = int(np.prod(shape))
-            out[name] = flat[off:off + size].reshape(shape).copy()
+        for name in self.spec.names:
+            out[name] = self.spec.var_view(flat, name).copy()
         return out

@@ -75,9 +75,11 @@ class ImpalaCnnOpt(XTModel):
     def _ingest_obj(self):
         if self._ingest is None:
             from xingtian_amd.ingest import RolloutIngest, impala_fields
+            cpad = self.net.spec.obs_channels_padded
             self._ingest = RolloutIngest(self.net.device, 0, initial_capacity=self.max_batch,
                                          obs_u8=bool(self.net.spec.input_xform[0]),
-                                         fields=impala_fields(self.action_dim))
+                                         fields=impala_fields(self.action_dim),
+                                         pad_channels=(cpad, self.net.obs_fill_byte()) if cpad else None)
         return self._ingest
 
     def ingest_message(self, states, bp_logic_outs, actions, dones, rewards, pinned=False, slot_guard=None):

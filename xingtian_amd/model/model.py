@@ -92,6 +92,12 @@ class XTModel(object):
     def set_weights(self, weights):
         self.net.set_weights(weights)
 
+    def publish_weights(self, ring, ctr_info=None):
+        """Hand the current weights to the explorers through a ``transport.WeightsRing`` (the learner's
+        ``get_weights`` + ``_dist_policy`` pair, xt/framework/learner.py:361-366) without building an intermediate
+        dict of private arrays; on a page-locked ring the parameters travel HBM -> slot with one DMA."""
+        return self.net.publish_weights(ring, ctr_info)
+
     # ---- checkpoints
     def save_model(self, file_name):
         """``<file_name>.npz`` = {tf_variable_name: ndarray} as ``TFVariables.save_weights`` writes it
@@ -99,7 +105,7 @@ class XTModel(object):
         slot names; the reference's loader skips names it does not know, so the file stays loadable there."""
         if self.max_to_keep > -1:
             check_keep_model(os.path.dirname(file_name), self.max_to_keep)
-        arrays = OrderedDict(self.get_weights())
+        arrays = OrderedDict(self.net.get_weights(copy=False) if hasattr(self.net, "publish_weights") else self.get_weights())
         if self.save_optimizer and hasattr(self.net, "get_optimizer_state"):
             arrays.update(self.net.get_optimizer_state())
             arrays.update(self.extra_optimizer_state())

@@ -72,7 +72,7 @@ def impala_filters(state_dim):
 
 class Layer(object):
     __slots__ = ("name", "H", "W", "C", "KH", "KW", "S", "PT", "PL", "OH", "OW", "N", "act", "trunk",
-                 "param_off", "kernel_shape")
+                 "param_off", "kernel_shape", "store_shape")
 
     @property
     def K(self):
@@ -81,11 +81,19 @@ class Layer(object):
 
 def _conv(name, h, w, c, cout, k, s, padding, act, trunk):
     lay = Layer()
-    lay.name, lay.H, lay.W, lay.C, lay.KH, lay.KW, lay.S = name, h, w, c, k, k, s
+    # an image whose channel count is not a multiple of 4 (examples/ant_ppo.yaml: [84, 84, 3]; the reference's
+    # get_cnn_backbone takes any C, xt/model/model_utils.py:49-80) enters the layer kernels with zero planes up to the
+    # next multiple of 4 (xt_pad_channels): the TF kernel [k, k, c, cout] lives inside a [k, k, pad4(c), cout] block
+    # whose extra input-channel rows start at 0 and stay 0 (zero operand -> zero gradient -> zero Adam step) -- exact.
+    cpad = (c + 3) & ~3
+    lay.name, lay.H, lay.W, lay.C, lay.KH, lay.KW, lay.S = name, h, w, cpad, k, k, s
     lay.OH, lay.PT = conv_out(h, k, s, padding)
     lay.OW, lay.PL = conv_out(w, k, s, padding)
     lay.N, lay.act, lay.trunk = cout, act, trunk
     lay.kernel_shape = (k, k, c, cout)
+    lay.store_shape = (k, k, cpad, cout) if cpad != c else None
+    if cpad != c and padding == "valid" and k == h == w:
+        raise ValueError("layer {}: a whole-image kernel on {} channels is not supported".format(name, c))
     if padding == "valid" and k == h == w:
         # a VALID conv whose kernel covers the whole image (ImpalaCnnOpt's 11x11 -> 1x1x256,
         # impala_cnn_opt.py:129-136) IS a dense layer on the NHWC-flattened input: HWIO kernel memory
@@ -103,6 +111,7 @@ def _dense(name, cin, cout, act, trunk):
     lay.PT = lay.PL = 0
     lay.N, lay.act, lay.trunk = cout, act, trunk
     lay.kernel_shape = (cin, cout)
+    lay.store_shape = None
     return lay
 
 
@@ -119,12 +128,15 @@ class NetSpec(object):
         self.pi_name, self.v_name, self.input_xform, self.state_dim = pi_name, v_name, input_xform, tuple(state_dim)
         off = 0
         self.names = OrderedDict()
+        self.store_shape = {}       # name -> shape of the block in the flat buffer, where it differs from the TF shape
         for lay in layers:
             if lay.C % 4 or lay.N % 4:
                 raise ValueError("layer {}: channel counts must be multiples of 4 for the HIP kernels "
                                  "(C={}, N={})".format(lay.name, lay.C, lay.N))
             lay.param_off = off
             self.names[lay.name + "/kernel"] = (off, lay.kernel_shape)
+            if getattr(lay, "store_shape", None):
+                self.store_shape[lay.name + "/kernel"] = tuple(lay.store_shape)
             self.names[lay.name + "/bias"] = (off + lay.K * lay.N, (lay.N,))
             off += (lay.K + 1) * lay.N
             off = (off + 3) & ~3
@@ -143,6 +155,29 @@ class NetSpec(object):
             off = (off + action_dim + 3) & ~3
         self.n_flat = off
         self.n_params = sum(int(_prod(s)) for _, s in self.names.values())
+
+    def var_view(self, flat, name):
+        """The variable ``name`` (TF shape) as a VIEW into the flat numpy buffer ``flat`` -- contiguous for every block
+        but a channel-padded first-layer kernel, whose TF tensor is a strided sub-block of its storage."""
+        off, shape = self.names[name]
+        st = self.store_shape.get(name)
+        if st is None:
+            return flat[off:off + int(_prod(shape))].reshape(shape)
+        return flat[off:off + int(_prod(st))].reshape(st)[tuple(slice(0, d) for d in shape)]
+
+    def var_extent(self, name):
+        """(offset, number of floats) the variable occupies in the flat buffer (its storage block, padding included)."""
+        off, shape = self.names[name]
+        return off, int(_prod(self.store_shape.get(name, shape)))
+
+    @property
+    def obs_channels_padded(self):
+        """channels of the observation as the first layer reads it (>= the reference's state_dim[-1]) for image
+        inputs, else None"""
+        lay0 = self.layers[0]
+        if len(self.state_dim) == 3 and not (lay0.H == lay0.W == 1):
+            return lay0.C if lay0.C != int(self.state_dim[2]) else None
+        return None
 
 
 def _prod(shape):

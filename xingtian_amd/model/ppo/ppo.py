@@ -56,9 +56,11 @@ class PPO(XTModel):
         self._perm_dense = None
         self._perm_pin = None           # two pinned [NUM_SGD_ITER, n] blocks: this update's shuffles / the next one's
         self._perm_last, self._perm_next = 0, None    # block of the last H2D; block holding shuffles drawn ahead
-        # the streaming ingest stages int32 actions and unpadded observations: discrete, 4-aligned inputs only
+        # the streaming ingest stages int32 actions: discrete actions; vector observations must be 4-aligned (image
+        # observations with another channel count are expanded on the device, RolloutIngest.pad_channels)
         self.stream_ingest = bool(model_config.get("STREAM_INGEST", True)) and not self.gauss and \
             (len(self.state_dim) != 1 or int(self.state_dim[0]) % 4 == 0)
+        self.gamma, self.lam = 0.99, 0.95       # GAE of raw trajectories; the PPO algorithm assigns its GAMMA / LAM
         super().__init__(model_info)
 
     # ---- trunk options shared by the CNN / MLP variants -------------------------------------------------------
@@ -125,12 +127,14 @@ class PPO(XTModel):
         key = (obs.shape, str(obs.dtype))
         lay0 = self.net.spec.layers[0]
         pad = lay0.C - obs.shape[1] if (obs.ndim == 2 and lay0.H == lay0.W == 1) else 0   # netspec._mlp zero padding
+        cpad = self.net.spec.obs_channels_padded if obs.ndim == 4 else None                # netspec._conv channel padding
         if self._resident is None or self._resident["key"] != key:
             odt = torch.uint8 if self.net.spec.input_xform[0] else torch.float32
-            oshape = (n, lay0.C) if pad > 0 else obs.shape
+            oshape = (n, lay0.C) if pad > 0 else (tuple(obs.shape[:3]) + (cpad,) if cpad else obs.shape)
             self._resident = dict(
                 key=key,
                 obs=torch.zeros(oshape, dtype=odt, device=dev),
+                obs_raw=torch.empty(obs.shape, dtype=odt, device=dev) if cpad else None,
                 action=(torch.empty((n, self.action_dim), dtype=torch.float32, device=dev) if self.gauss
                         else torch.empty((n,), dtype=torch.int32, device=dev)),
                 old_logp=torch.empty((n,), dtype=torch.float32, device=dev),
@@ -141,7 +145,11 @@ class PPO(XTModel):
         r = self._resident
         src = torch.from_numpy(obs).to(r["obs"].dtype) if obs.dtype != np.uint8 and r["obs"].dtype == torch.uint8 \
             else torch.from_numpy(obs)
-        (r["obs"][:, :obs.shape[1]] if pad > 0 else r["obs"]).copy_(src, non_blocking=True)
+        if cpad:
+            r["obs_raw"].copy_(src, non_blocking=True)
+            self.net.pad_obs_channels(r["obs_raw"], out=r["obs"])
+        else:
+            (r["obs"][:, :obs.shape[1]] if pad > 0 else r["obs"]).copy_(src, non_blocking=True)
         if self.gauss:
             r["action"].copy_(torch.from_numpy(
                 np.ascontiguousarray(label[0], dtype=np.float32).reshape(n, self.action_dim)))
@@ -159,9 +167,17 @@ class PPO(XTModel):
         (``pinned``: the arrays already live in page-locked memory -- a pinned transport ring -- and are copied to HBM
         straight from there)."""
         if self._ingest is None:
-            from xingtian_amd.ingest import RolloutIngest
+            from xingtian_amd.ingest import PPO_FIELDS, PPO_RAW_FIELDS, RolloutIngest
+            cpad = self.net.spec.obs_channels_padded
             self._ingest = RolloutIngest(self.net.device, self.num_sgd_iter,
-                                         obs_u8=bool(self.net.spec.input_xform[0]))
+                                         obs_u8=bool(self.net.spec.input_xform[0]), fields=PPO_FIELDS + PPO_RAW_FIELDS,
+                                         pad_channels=(cpad, self.net.obs_fill_byte()) if cpad else None)
+        if "adv" not in train_data:
+            # value / reward / done as the explorer holds them before data_proc: GAE runs on the learner GPU, once per
+            # rollout, inside train_ingested (no per-message launch, no read-back)
+            self._ingest.put_raw(train_data["cur_state"], train_data["action"], train_data["logp"], train_data["value"],
+                                 train_data["reward"], train_data["done"], pinned=pinned, slot_guard=slot_guard)
+            return
         self._ingest.put(train_data["cur_state"], train_data["action"], train_data["logp"], train_data["adv"],
                          train_data["old_value"], train_data["target_value"], pinned=pinned, slot_guard=slot_guard)
 
@@ -179,6 +195,9 @@ class PPO(XTModel):
                 self._perm_dense = torch.empty((self.num_sgd_iter, n), dtype=torch.int32, device=self.net.device)
             perm = self._perm_dense
         perm.copy_(self._take_perms(n, perms), non_blocking=True)
+        if self._ingest.last_raw_traj:
+            from xingtian_amd import lib as L
+            self._ingest.gae_on_device(d, n, self.gamma, self.lam, L.stream_ptr())
         self._normalize_adv(d["adv"][:n])
         # the library keeps a small cache of hipGraphs: the two alternating buffer sets replay their own graph
         acc = self.net.ppo_train(self._cfg, d["obs"][:n], perm, d["action"][:n], d["old_logp"][:n], d["adv"][:n],

@@ -123,15 +123,30 @@ def dp_ppo_update(net, cfg, obs, perm, action, old_logp, adv, old_v, target_v, r
 
 
 def dp_impala_step(net, cfg_struct, lr, grad_norm_clip, obs, bp_logits, action, done, reward, n_traj, t_len, rank,
-                   world):
+                   world, exchange=None, lr_steps=None):
     """One data-parallel ImpalaCnnOpt step: the chunk's ``n_traj`` trajectories (flat env-major rows b*T+t) are
-    split into whole-trajectory shards, gradients of the sum-form loss are SUMMED, no scaling."""
+    split into whole-trajectory shards, gradients of the sum-form loss are SUMMED, no scaling.
+
+    Adam with the fixed step size goes step-wise (local gradient -> ``torch.distributed`` all-reduce -> clip + Adam).
+    ``opt_type: rmsprop``, an ``lr_schedule`` step size (``lr_steps``: one-element float32 device tensor) or an explicit
+    ``exchange`` (``RcclComm`` / ``TorchDistExchange``) go through the gradient-exchange hook of ``xt_net_impala_train``:
+    the library applies the configured optimiser to the EXCHANGED gradient itself
+    (xt/model/impala/impala_cnn_opt.py:198-217,234-249)."""
     from xingtian_amd import lib as L
-    if int(cfg_struct.opt_type) != L.OPT_TYPE["adam"]:
-        # net.apply is clip + Adam; the single-process path (xt_net_impala_train) also serves opt_type: rmsprop and
-        # lr_schedule -- refusing is better than silently training with another optimiser
-        raise NotImplementedError("dp_impala_step: data-parallel IMPALA supports opt_type 'adam' with a fixed step size")
     b, e = shard_range(n_traj, rank, world)
+    hook = exchange is not None or lr_steps is not None or int(cfg_struct.opt_type) != L.OPT_TYPE["adam"]
+    if hook:
+        if n_traj < world:        # the same test on every rank, before any collective
+            raise ValueError("dp_impala_step: {} trajectories cannot be split over {} ranks".format(n_traj, world))
+        ex = exchange if exchange is not None else TorchDistExchange(net)
+        ex.attach(net) if isinstance(ex, RcclComm) else ex.attach()
+        try:
+            sl = slice(b * t_len, e * t_len)
+            net.impala_train(cfg_struct, obs[sl], (e - b) * t_len, bp_logits[sl], action[sl], done[sl], reward[sl],
+                             lr_steps=lr_steps, use_graph=False)
+        finally:
+            ex.detach(net) if isinstance(ex, RcclComm) else ex.detach()
+        return
     if e > b:
         sl = slice(b * t_len, e * t_len)
         net.impala_step(cfg_struct, obs[sl], bp_logits[sl], action[sl], done[sl], reward[sl], apply=False)
@@ -150,8 +165,9 @@ class RcclComm(object):
     without any host involvement.  The communicator is created with ctypes on the ``librccl.so`` that torch ships
     (already loaded in the process); the 128-byte unique id travels through the existing ``torch.distributed`` group.
 
-    Opt-in (``bench.py --dp-mode ingraph``): validated with a 1-rank communicator on one GPU (bit-identical to the
-    step-wise path); it has not met a second rank yet, so the default data-parallel path is the step-wise one.
+    Validated with a 1-rank communicator on one GPU (bit-identical to the step-wise path); it has not met a second rank
+    yet (no multi-GPU box was available to the builders), so ``bench.py`` validates every hook variant against the
+    step-wise path before it may carry a number.
     """
     NCCL_FLOAT32, NCCL_SUM = 7, 0
 
@@ -181,15 +197,6 @@ class RcclComm(object):
         self.lib.ncclAllReduce.restype = ctypes.c_int
         self.errors = []
 
-        def _exchange(grads, count, user, stream):
-            rc = self.lib.ncclAllReduce(grads, grads, count, self.NCCL_FLOAT32, self.NCCL_SUM, self.comm, stream)
-            if rc != 0:
-                self.errors.append(rc)
-            return rc
-
-        self._cb_type = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p)
-        self._cb = self._cb_type(_exchange)          # keep alive: the library stores the raw pointer
-
     @staticmethod
     def _check(rc, what):
         if rc != 0:
@@ -202,11 +209,22 @@ class RcclComm(object):
                                            self.NCCL_SUM, self.comm, stream_ptr), "ncclAllReduce")
 
     def attach(self, net, overlap=False):
-        """``overlap``: two buckets per step, the last trunk layer + heads exchanged on the library's side stream while
-        the conv backward runs (C ABI ``xt_net_set_grad_exchange_ex`` with ``XT_XCHG_OVERLAP``)."""
+        """Install this communicator as the network's gradient exchange (C ABI ``xt_net_set_rccl``): the library calls
+        ``ncclAllReduce`` itself through the function pointer resolved here -- no Python frame on the enqueue path.
+        ``overlap``: two buckets per step, the last trunk layer + heads exchanged on the library's side stream while the
+        conv backward runs (``XT_XCHG_OVERLAP``)."""
         from xingtian_amd import lib as L
-        L.check(net.lib.xt_net_set_grad_exchange_ex(net.handle, self._ct.cast(self._cb, self._ct.c_void_p), None,
-                                                    L.XCHG_OVERLAP if overlap else 0), "xt_net_set_grad_exchange_ex")
+        fn = self._ct.cast(self.lib.ncclAllReduce, self._ct.c_void_p)
+        L.check(net.lib.xt_net_set_rccl(net.handle, self.comm, fn, L.XCHG_OVERLAP if overlap else 0), "xt_net_set_rccl")
+
+    def status(self, net):
+        """(calls, last non-zero ncclResult) of the exchange installed on ``net`` (C ABI ``xt_net_rccl_status``)."""
+        from xingtian_amd import lib as L
+        calls, err = self._ct.c_int32(0), self._ct.c_int32(0)
+        L.check(net.lib.xt_net_rccl_status(net.handle, self._ct.byref(calls), self._ct.byref(err)), "xt_net_rccl_status")
+        if err.value:
+            self.errors.append(int(err.value))
+        return int(calls.value), int(err.value)
 
     def count(self):
         """ranks RCCL itself reports for this communicator (ncclCommCount)"""
@@ -217,7 +235,8 @@ class RcclComm(object):
 
     def detach(self, net):
         from xingtian_amd import lib as L
-        L.check(net.lib.xt_net_set_grad_exchange(net.handle, None, None), "xt_net_set_grad_exchange")
+        self.status(net)                     # (collects an error the library saw inside the hook)
+        L.check(net.lib.xt_net_set_rccl(net.handle, None, None, 0), "xt_net_set_rccl")
 
     def destroy(self):
         if self.comm:

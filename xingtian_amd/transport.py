@@ -253,6 +253,11 @@ class ShmRing(object):
         if view is None:
             return None
         if self.pinned:
+            if self._taken >= self.slots - 1:     # at most slots - 1 deferred copies in flight: wait for the oldest
+                g = self._held[0]
+                if g.event is not None:
+                    g.event.synchronize()
+                self._reap()
             ctr, data = decode(view)
             guard = SlotGuard()
             sink(data, ctr_info=dict(ctr, _pinned_views=True, _slot_guard=guard))   # the sink may DMA straight out of the slot
@@ -351,6 +356,10 @@ class RingSet(object):
                 break
             i = (self._next + k) % n
             ring = self.rings[i]
+            # slots held behind deferred copies (pinned rings) are released HERE as their events fire: pending() does not
+            # count them, so a ring whose slots are all held would otherwise never be visited again and its producer
+            # would wait on a full ring forever
+            ring.reap()
             if ring.pending() == 0:
                 continue
             tag = lambda data, ctr_info=None, _i=i: sink(data, ctr_info=dict(ctr_info or {}, explorer_id=_i))
@@ -373,6 +382,8 @@ class RingSet(object):
             if k == 0:
                 if timeout is not None and time.monotonic() - t0 > timeout:
                     break
+                for r in self.rings:          # idle: give back the slots whose copies have landed meanwhile
+                    r.reap()
                 time.sleep(0.0002)
         return got
 
@@ -411,6 +422,7 @@ class WeightsRing(object):
         self._hdr = [np.ndarray((2,), dtype=np.uint64, buffer=self.shm.buf, offset=_ALIGN + i * (_ALIGN + self.slot_bytes))
                      for i in range(self.slots)]
         self._seen = 0
+        self.pinned = False
 
     def _payload(self, i):
         o = _ALIGN + i * (_ALIGN + self.slot_bytes) + _ALIGN
@@ -427,6 +439,70 @@ class WeightsRing(object):
         n = encode_into(view, dict(ctr_info or {}, cmd="weights", seq=k), weights)
         del view
         self._hdr[i][1] = n
+        self._hdr[i][0] = k
+        self._latest[0] = k
+        return k
+
+    def pin(self):
+        """Learner side, optional: page-lock the ring (``hipHostRegister``) so that ``publish_flat_from_device`` can DMA
+        the parameter block from HBM straight into the slot.  Needs a GPU process; returns True on success."""
+        import ctypes
+        if getattr(self, "pinned", False):
+            return True
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            self._hip = hip
+            probe = np.frombuffer(self.shm.buf, dtype=np.uint8)
+            self._pin_addr = int(probe.ctypes.data)
+            del probe
+            hip.hipHostRegister.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint]
+            hip.hipHostRegister.restype = ctypes.c_int
+            rc = hip.hipHostRegister(ctypes.c_void_p(self._pin_addr), ctypes.c_size_t(self.shm.size), 0)
+        except OSError:
+            return False
+        self.pinned = (rc == 0)
+        return self.pinned
+
+    def publish_flat_from_device(self, net, ctr_info=None):
+        """Publish the learner network's packed parameter block with ONE device-to-host copy straight into the (pinned)
+        slot: the message carries the flat float32 buffer plus the name -> (offset, shape) table, ``fetch`` rebuilds
+        the name-keyed dict on the reader side.  ``net``: a ``HipActorCritic`` (``params``, ``spec``).  The copy is
+        ordered behind everything enqueued on the current stream (the update whose result it publishes)."""
+        import torch
+        spec = net.spec
+        lay = getattr(self, "_flat_layout", None)
+        if lay is None or lay[0] is not spec:
+            table = [[name, int(off), [int(d) for d in shape],
+                      [int(d) for d in spec.store_shape[name]] if name in spec.store_shape else None]
+                     for name, (off, shape) in spec.names.items()]
+            lay = self._flat_layout = (spec, table)
+        nbytes = int(net.params.numel()) * 4
+        k = int(self._latest[0]) + 1
+        i = k % self.slots
+        self._hdr[i][0] = 0
+        header = msgpack.packb({"ctr": _plain(dict(ctr_info or {}, cmd="weights", seq=k)), "obj": {"__layout__": lay[1]},
+                                "arr": [["__flat__", "<f4", [nbytes // 4], 0, nbytes]], "order": ["__layout__", "__flat__"]},
+                               use_bin_type=True)
+        base = _pad(8 + len(header))
+        if base + nbytes > self.slot_bytes:
+            raise ValueError("weights of {} bytes exceed the {}-byte slot".format(base + nbytes, self.slot_bytes))
+        view = self._payload(i)
+        view[0:4] = MAGIC
+        struct.pack_into("<I", view, 4, len(header))
+        view[8:8 + len(header)] = header
+        dst = torch.frombuffer(view, dtype=torch.float32, count=nbytes // 4, offset=base)
+        st = getattr(self, "_d2h", None)
+        if st is None:
+            st = self._d2h = (torch.cuda.Stream(device=net.device), torch.cuda.Event(), torch.cuda.Event())
+        side, ready, done = st
+        ready.record(torch.cuda.current_stream(net.device))
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            dst.copy_(net.params.detach(), non_blocking=True)
+            done.record(side)
+        done.synchronize()
+        del dst, view
+        self._hdr[i][1] = base + nbytes
         self._hdr[i][0] = k
         self._latest[0] = k
         return k
@@ -453,7 +529,17 @@ class WeightsRing(object):
             if int(self._hdr[i][0]) != k:
                 continue                              # torn: the writer lapped us during the copy
             ctr, data = decode(blob)
-            data = {name: (v.copy() if isinstance(v, np.ndarray) else v) for name, v in data.items()}
+            if "__flat__" in data:                    # packed form (publish_flat_from_device): rebuild the name-keyed dict
+                flat, out = data["__flat__"], {}
+                for name, off, shape, st in data["__layout__"]:
+                    if st:
+                        v = flat[off:off + int(np.prod(st))].reshape(st)[tuple(slice(0, d) for d in shape)]
+                    else:
+                        v = flat[off:off + int(np.prod(shape, dtype=np.int64))].reshape(shape)
+                    out[name] = v.copy()
+                data = out
+            else:
+                data = {name: (v.copy() if isinstance(v, np.ndarray) else v) for name, v in data.items()}
             self._seen = k
             return k, ctr, data
         raise RuntimeError("WeightsRing.fetch: no stable publish after {} attempts".format(retries))
@@ -461,6 +547,11 @@ class WeightsRing(object):
     def close(self):
         self._latest = None
         self._hdr = None
+        if getattr(self, "pinned", False):
+            import ctypes
+            self._hip.hipHostUnregister.argtypes = [ctypes.c_void_p]
+            self._hip.hipHostUnregister(ctypes.c_void_p(self._pin_addr))
+            self.pinned = False
         try:
             self.shm.close()
             if self.owner:
