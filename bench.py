@@ -643,7 +643,7 @@ def bench_impala(key, steps, warmup, with_cpu, in_graph=False, quick=False):
             t1 = time.perf_counter()
             loss = alg.train(episode_num=i)
             t2 = time.perf_counter()
-            if alg.checkpoint_ready(i + 1):
+            if alg.checkpoint_ready(i):         # train_count BEFORE its increment, as learner.py:361 passes it
                 if ring is not None:
                     assert alg.publish_weights(ring) > 0
                 else:

@@ -1262,7 +1262,7 @@ def test_pinned_ring_defers_slot_release_until_the_dma_has_landed():
         n_ing = alg.actor.ingested()
         assert n_ing == 192
         dev_obs = alg.actor._ingest.sets[alg.actor._ingest.cur].dev["obs"]
-        alg.actor._ingest.copy_stream.synchronize()
+        alg.actor._ingest._join_copy_streams()
         assert np.array_equal(dev_obs[:192].cpu().numpy(), np.concatenate([t["cur_state"] for t in trajs]))
         loss = alg.train(perms=perms)
     finally:

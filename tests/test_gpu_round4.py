@@ -50,7 +50,8 @@ def test_gae_ragged_is_bit_exact_with_the_reference_loop():
         assert np.array_equal(ov[:, 0], v[:t])
     adv = torch.full((n,), np.nan, dtype=torch.float64, device="cuda")
     tgt = torch.full((n,), np.nan, dtype=torch.float64, device="cuda")
-    L.check(lib.xt_gae_f64_ragged(L.ptr(_d(value_rows)), L.ptr(_d(boot)), L.ptr(_d(reward)), L.ptr(_d(done)), L.ptr(_d(offs)),
+    dv, db, dr, dd, do = _d(value_rows), _d(boot), _d(reward), _d(done), _d(offs)      # (kept alive across the launch)
+    L.check(lib.xt_gae_f64_ragged(L.ptr(dv), L.ptr(db), L.ptr(dr), L.ptr(dd), L.ptr(do),
                                   L.ptr(adv), L.ptr(tgt), len(lens), 0.99, 0.95, L.stream_ptr()), "xt_gae_f64_ragged")
     torch.cuda.synchronize()
     assert np.array_equal(adv.cpu().numpy(), want_adv) and np.array_equal(tgt.cpu().numpy(), want_tgt)
@@ -63,7 +64,8 @@ def test_pad_channels_u8_and_f32():
     for dt, fill in ((np.uint8, 128), (np.uint8, 0), (np.float32, 0)):
         src = (rng.integers(0, 256, (7, 5, 3)) if dt == np.uint8 else rng.standard_normal((7, 5, 3))).astype(dt)
         dst = torch.empty((7, 5, 4), dtype=torch.uint8 if dt == np.uint8 else torch.float32, device="cuda")
-        L.check(lib.xt_pad_channels(L.ptr(_d(src)), L.ptr(dst), 35, 3, 4, src.itemsize, fill, L.stream_ptr()), "xt_pad_channels")
+        dsrc = _d(src)
+        L.check(lib.xt_pad_channels(L.ptr(dsrc), L.ptr(dst), 35, 3, 4, src.itemsize, fill, L.stream_ptr()), "xt_pad_channels")
         got = dst.cpu().numpy()
         assert np.array_equal(got[..., :3], src) and np.all(got[..., 3] == (fill if dt == np.uint8 else 0))
     with pytest.raises(RuntimeError, match="elem_bytes"):

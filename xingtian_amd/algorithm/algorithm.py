@@ -66,6 +66,8 @@ class Algorithm(object):
         self.dist_model_policy = DefaultAlgDistPolicy(cfg["instance_num"], prepare_times=self._prepare_times_per_train)
         self.learning_starts = cfg.get("learning_starts", 0)
         self._train_per_checkpoint = cfg.get("train_per_checkpoint", 1)
+        if hasattr(self.actor, "eager_snapshot"):
+            self.actor.eager_snapshot = (self._train_per_checkpoint == 1)
         self.if_save_model, self.save_interval = cfg.get("save_model", False), cfg.get("save_interval", 500)
 
     # ---- data in
@@ -101,6 +103,8 @@ class Algorithm(object):
     @train_per_checkpoint.setter
     def train_per_checkpoint(self, interval):
         self._train_per_checkpoint = interval
+        if hasattr(self.actor, "eager_snapshot"):
+            self.actor.eager_snapshot = (interval == 1)
 
     def if_save(self, train_count):
         if self.if_save_model and train_count % self.save_interval == 0:

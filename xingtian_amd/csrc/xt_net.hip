@@ -1077,11 +1077,17 @@ int xt_net_time_layer(xt_net* n, int32_t layer, int32_t which, const void* obs, 
   XT_CHECK_HIP(hipEventCreate(&e1));
   int rc = 0;
   auto one = [&]() -> int {
-    if (which == 0)
+    if (which == 0) {
+      // a trunk's last layer runs as the update runs it: split-K partials left for the fused head kernel to finish
+      // (timing it with its stand-alone finish launch charged the layer for a kernel the update never launches: 13.7 vs
+      // 7.9 us in-graph for ImpalaCnnOpt's 11x11 layer, round 3)
+      const bool defer = L.part_off >= 0 && L.z_off < 0 && xt::tuning().defer_splitk != 0;
       return xt::launch_fwd(&L.g, first ? &n->xf : nullptr, B, x, first ? idx : nullptr, n->params + L.poff,
-                            n->params + L.poff + (int64_t)L.K * L.g.N, n->ws + L.act_off, n->ws + n->off_partial,
-                            xt::fwd_split(L, B), st, nullptr,
+                            n->params + L.poff + (int64_t)L.K * L.g.N, n->ws + L.act_off,
+                            n->ws + (defer ? L.part_off : n->off_partial), xt::fwd_split(L, B), st,
+                            defer ? &L.last_ksplit : nullptr,
                             L.mask_off >= 0 ? reinterpret_cast<uint32_t*>(n->ws + L.mask_off) : nullptr, &L.mask_valid);
+    }
     if (which == 1)
       return xt::launch_wgrad(&L.g, first ? &n->xf : nullptr, B, x, first ? idx : nullptr, n->ws + L.dact_off,
                               n->grads + L.poff, n->ws + L.slab_off, xt::wgrad_split(L, B), st, 0, &L.last_msplit,

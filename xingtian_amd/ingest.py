@@ -86,7 +86,8 @@ PPO_RAW_FIELDS = (("reward", torch.float64, 0), ("done", torch.uint8, 0), ("boot
 
 
 class RolloutIngest(object):
-    def __init__(self, device, n_epochs, initial_capacity=4096, obs_u8=None, fields=PPO_FIELDS, pad_channels=None):
+    def __init__(self, device, n_epochs, initial_capacity=4096, obs_u8=None, fields=PPO_FIELDS, pad_channels=None,
+                 copy_streams=2):
         """``obs_u8``: the observation type the NETWORK reads (``spec.input_xform[0]``: uint8 frames vs float32);
         arriving arrays of another dtype are cast into the staging buffer like the upload path casts them.  None
         = take the dtype of the first array (stand-alone use).  ``fields``: the label arrays that travel with the
@@ -96,12 +97,18 @@ class RolloutIngest(object):
         # pad_channels = (c_dst, fill byte): image observations are staged with their own channel count and expanded on
         # the device to the multiple of 4 the first layer reads (xt_pad_channels), see netspec._conv
         self.pad_channels = pad_channels
+        self._n_raw = len(PPO_RAW_FIELDS) if self.fields[-len(PPO_RAW_FIELDS):] == PPO_RAW_FIELDS else 0
         self.raw_traj = 0               # trajectories of the current rollout that came without advantages
         self.adv_traj = 0               # ... and with them
         self.device = torch.device(device)
         self.n_epochs = n_epochs
         self.initial_capacity = initial_capacity
-        self.copy_stream = torch.cuda.Stream(device=self.device)
+        # the frames of consecutive trajectories alternate between `copy_streams` HIP streams: one stream issues its
+        # copies back to back with a gap after every piece (a 3.6 MB trajectory reaches ~49 GB/s, one 115 MB copy 57);
+        # two streams keep a second DMA queued while the first one's completion is processed
+        self.copy_streams = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(copy_streams)))]
+        self.copy_stream = self.copy_streams[0]         # labels, padding, growth copies; joins the others in finish()
+        self._rr = 0
         self.sets = [None, None]
         self.cur = 0
         self.n = 0
@@ -123,6 +130,7 @@ class RolloutIngest(object):
         if same and self.n > 0:                        # grow: keep what was already ingested
             # frames travel device-to-device in copy-stream order (a frame that was DMA-copied straight out of a pinned
             # transport slot never existed in the host staging buffer); labels are still host-side only
+            self._join_copy_streams()
             with torch.cuda.stream(self.copy_stream):
                 new.dev["obs"][:self.n].copy_(s.dev["obs"][:self.n], non_blocking=True)
             for k in new.host:
@@ -144,10 +152,13 @@ class RolloutIngest(object):
         t = obs.shape[0]
         s = self._ensure(self.n + t, obs)
         if self.n == 0 and s.free is not None:      # do not overwrite a set an enqueued update still reads
-            self.copy_stream.wait_event(s.free)
+            for cs in self.copy_streams:
+                cs.wait_event(s.free)
+        cstream = self.copy_streams[self._rr % len(self.copy_streams)]
+        self._rr += 1
         lo, hi = self.n, self.n + t
-        n_raw = sum(1 for f in self.fields if f in PPO_RAW_FIELDS)
-        if len(labels) == len(self.fields) - n_raw and n_raw:
+        n_raw = self._n_raw
+        if n_raw and len(labels) == len(self.fields) - n_raw:
             labels = tuple(labels) + (None,) * n_raw        # a trajectory that brings its advantages: no GAE inputs
         if len(labels) != len(self.fields):
             raise ValueError("RolloutIngest.put: {} label arrays for fields {}".format(
@@ -160,21 +171,21 @@ class RolloutIngest(object):
         plain = obs.dtype == obs_dst.dtype and obs.flags.c_contiguous and obs.size == obs_dst.size
         if pinned and plain and obs.flags.writeable:
             # DMA source = the pinned transport slot: no host copy at all; the caller recycles the slot right after
-            with torch.cuda.stream(self.copy_stream):
+            with torch.cuda.stream(cstream):
                 s.dev["obs"][lo:hi].copy_(torch.from_numpy(obs.reshape(obs_dst.shape)), non_blocking=True)
             if slot_guard is not None:      # the ring keeps the slot until this event has fired: no wait here
                 ev = torch.cuda.Event()
-                ev.record(self.copy_stream)
+                ev.record(cstream)
                 slot_guard.hold(ev)
             else:
-                self.copy_stream.synchronize()
+                cstream.synchronize()
         elif plain:
             L.check(self._lib.xt_stage_rows(ctypes.c_void_p(s.host["obs"].data_ptr() + lo * row_bytes),
                                             ctypes.c_void_p(obs.ctypes.data), obs.nbytes, ctypes.c_void_p(dev_ptr), 0, 0, -1,
-                                            ctypes.c_void_p(self.copy_stream.cuda_stream)), "xt_stage_rows")
+                                            ctypes.c_void_p(cstream.cuda_stream)), "xt_stage_rows")
         else:       # a cast on the way in (float frames for a uint8 network, ...): as the upload path casts them
             np.copyto(obs_dst, obs.reshape(obs_dst.shape), casting="unsafe")
-            with torch.cuda.stream(self.copy_stream):
+            with torch.cuda.stream(cstream):
                 s.dev["obs"][lo:hi].copy_(s.host["obs"][lo:hi], non_blocking=True)
         for f, a in zip(self.fields, labels):
             if a is None:                    # filled by the caller (put_raw) or on the device (GAE outputs)
@@ -225,6 +236,7 @@ class RolloutIngest(object):
         if self.raw_traj and self.adv_traj:
             raise RuntimeError("RolloutIngest.finish(): a rollout must not mix trajectories with and without advantages")
         dev = s.dev
+        self._join_copy_streams(wait=False)
         with torch.cuda.stream(self.copy_stream):          # the labels of the whole rollout: ONE copy (a few 10 KB)
             s.lab_dev.copy_(s.lab_host, non_blocking=True)
             if self.raw_traj:
@@ -247,11 +259,21 @@ class RolloutIngest(object):
         self.last_raw_traj, self.raw_traj, self.adv_traj = self.raw_traj, 0, 0
         return n, dev
 
+    def _join_copy_streams(self, wait=True):
+        """stream 0 waits for the other copy streams (device-side); ``wait``: the host waits for all of them too"""
+        if len(self.copy_streams) > 1 and not hasattr(self, "_join_ev"):
+            self._join_ev = [torch.cuda.Event() for _ in self.copy_streams[1:]]
+        for i, cs in enumerate(self.copy_streams[1:]):
+            self._join_ev[i].record(cs)
+            self.copy_stream.wait_event(self._join_ev[i])
+        if wait:
+            self.copy_stream.synchronize()
+
     def mark_consumed(self):
         """call after the update that reads the last finished set has been enqueued on the compute stream"""
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
-        self.last.free = ev
+        if self.last.free is None:
+            self.last.free = torch.cuda.Event()
+        self.last.free.record(torch.cuda.current_stream(self.device))
 
     def reset(self):
         self.n = 0

@@ -95,6 +95,12 @@ class HipActorCritic(object):
         stream, ordered after everything already enqueued on the compute stream (the update whose result it
         publishes).  Returns immediately: the copy runs under whatever the host does next (the loss read-back, the next
         rollout's ingest).  ``get_weights`` picks the block up once its event has fired."""
+        ring = getattr(self, "_wring", None)
+        if ring is not None:
+            # a page-locked WeightsRing is attached: the copy goes straight into its next slot (no pinned bounce block)
+            ring.begin_flat_publish(self, getattr(self, "_wring_ctr", None))
+            self._wring_version = getattr(self, "_version", 0)
+            return
         snap = getattr(self, "_snap", None)
         if snap is None:
             snap = self._snap = dict(stream=torch.cuda.Stream(device=self.device), slot=-1, version=-1, events=[],
@@ -129,7 +135,11 @@ class HipActorCritic(object):
         """the flat float32 parameter buffer in pinned host memory, as of everything enqueued so far"""
         snap = getattr(self, "_snap", None)
         if snap is None or snap["version"] != getattr(self, "_version", 0):
-            self.snapshot_weights_async()
+            ring, self._wring = getattr(self, "_wring", None), None       # (a private snapshot, not a ring publish)
+            try:
+                self.snapshot_weights_async()
+            finally:
+                self._wring = ring
             snap = self._snap
         snap["version"] = -1            # a pre-enqueued snapshot serves ONE publish; later calls copy again
         snap["events"][snap["slot"]].synchronize()
@@ -141,8 +151,19 @@ class HipActorCritic(object):
         (``WeightsRing.pin``) -- by ONE D2H straight from HBM into the slot (no host copy at all).  Returns the
         publish's sequence number."""
         if getattr(ring, "pinned", False):
+            if getattr(self, "_wring", None) is ring and ring._pending is not None and \
+                    getattr(self, "_wring_version", -1) == getattr(self, "_version", 0) and not ctr_info:
+                return ring.commit_flat_publish()       # the update itself enqueued the copy (snapshot_weights_async)
             return ring.publish_flat_from_device(self, ctr_info)
         return ring.publish(self.get_weights(copy=False), ctr_info)
+
+    def attach_weights_ring(self, ring):
+        """From now on the weight snapshot that every update enqueues (``snapshot_weights_async``) lands directly in
+        ``ring``'s next slot (``ring`` must be page-locked, ``WeightsRing.pin``): ``publish_weights(ring)`` then only
+        waits for that copy and commits it.  ``None`` detaches."""
+        if ring is not None and not getattr(ring, "pinned", False):
+            raise ValueError("attach_weights_ring: the ring must be page-locked (WeightsRing.pin())")
+        self._wring = ring
 
     def set_weights(self, weights):
         """Assign by name; unknown names are ignored, KeyError if nothing matches

@@ -117,7 +117,8 @@ class ImpalaCnnOpt(XTModel):
                                     d["reward"][:n], lr_steps=lr_steps, use_graph=self.use_graph)
         self._ingest.mark_consumed()
         self._global_step += n_chunks
-        self.net.snapshot_weights_async()       # the D2H of the new weights runs under the loss read-back
+        if self.eager_snapshot:
+            self.net.snapshot_weights_async()   # the D2H of the new weights runs under the loss read-back
         a = acc.cpu().numpy()
         return np.float32(a[0] / max(a[1], 1.0))
 

@@ -52,6 +52,11 @@ def as_numpy(x):
 
 
 class XTModel(object):
+    # every update enqueues the D2H of its new weights behind itself (the learner hands them out after every train when
+    # train_per_checkpoint = 1, xt/framework/learner.py:361-363); the algorithm clears this when weights only go out every
+    # k-th train (pong_impala_speedup.yaml: 3) -- the copy is then issued when they are asked for
+    eager_snapshot = True
+
     def __init__(self, model_info):
         cfg = model_info.get("model_config") or {}
         self.actor_var = None
@@ -96,6 +101,8 @@ class XTModel(object):
         """Hand the current weights to the explorers through a ``transport.WeightsRing`` (the learner's
         ``get_weights`` + ``_dist_policy`` pair, xt/framework/learner.py:361-366) without building an intermediate
         dict of private arrays; on a page-locked ring the parameters travel HBM -> slot with one DMA."""
+        if getattr(ring, "pinned", False) and getattr(self.net, "_wring", None) is not ring:
+            self.net.attach_weights_ring(ring)      # later updates copy their weights straight into the ring
         return self.net.publish_weights(ring, ctr_info)
 
     # ---- checkpoints

@@ -39,6 +39,7 @@ class PPO(XTModel):
         self.verbose = model_config.get("SUMMARY", SUMMARY)
         self.vf_clip = model_config.get("VF_CLIP", VF_CLIP)
         self.use_graph = bool(model_config.get("USE_HIP_GRAPH", True))
+        self.copy_streams = int(model_config.get("COPY_STREAMS", 2))      # HIP streams the rollout's H2D copies alternate over
         # (adv - adv.mean()) / (adv.std() + 1e-8) over the whole rollout: a COMMENT in the reference
         # (xt/algorithm/ppo/ppo.py:73), hence off unless the configuration asks for it
         self.adv_norm = bool(model_config.get("ADV_NORM", False))
@@ -171,6 +172,7 @@ class PPO(XTModel):
             cpad = self.net.spec.obs_channels_padded
             self._ingest = RolloutIngest(self.net.device, self.num_sgd_iter,
                                          obs_u8=bool(self.net.spec.input_xform[0]), fields=PPO_FIELDS + PPO_RAW_FIELDS,
+                                         copy_streams=self.copy_streams,
                                          pad_channels=(cpad, self.net.obs_fill_byte()) if cpad else None)
         if "adv" not in train_data:
             # value / reward / done as the explorer holds them before data_proc: GAE runs on the learner GPU, once per
@@ -216,7 +218,8 @@ class PPO(XTModel):
         """Everything the host has to do for the NEXT publish / update is done while the GPU runs this one: the D2H of
         the new weights is enqueued behind the update, the next update's epoch shuffles are drawn (0.3 ms of host RNG
         per 4 x 4096), and only then does the host block on the loss."""
-        self.net.snapshot_weights_async()
+        if self.eager_snapshot:
+            self.net.snapshot_weights_async()
         self._draw_ahead(n)
         a = acc.cpu().numpy()
         return np.float32(a[0] / max(a[1], 1.0))

@@ -423,6 +423,7 @@ class WeightsRing(object):
                      for i in range(self.slots)]
         self._seen = 0
         self.pinned = False
+        self._pending = None
 
     def _payload(self, i):
         o = _ALIGN + i * (_ALIGN + self.slot_bytes) + _ALIGN
@@ -463,11 +464,12 @@ class WeightsRing(object):
         self.pinned = (rc == 0)
         return self.pinned
 
-    def publish_flat_from_device(self, net, ctr_info=None):
-        """Publish the learner network's packed parameter block with ONE device-to-host copy straight into the (pinned)
-        slot: the message carries the flat float32 buffer plus the name -> (offset, shape) table, ``fetch`` rebuilds
-        the name-keyed dict on the reader side.  ``net``: a ``HipActorCritic`` (``params``, ``spec``).  The copy is
-        ordered behind everything enqueued on the current stream (the update whose result it publishes)."""
+    def begin_flat_publish(self, net, ctr_info=None):
+        """First half of a packed publish: write the message header into the next slot and ENQUEUE the device-to-host
+        copy of the learner network's flat parameter block straight into the (pinned) slot, ordered behind everything
+        already enqueued on the current stream (the update whose result it publishes).  Returns at once; the slot stays
+        invalid (seq 0) until ``commit_flat_publish``.  Calling it again before a commit re-targets the same slot (an
+        update whose weights were never handed out)."""
         import torch
         spec = net.spec
         lay = getattr(self, "_flat_layout", None)
@@ -475,14 +477,20 @@ class WeightsRing(object):
             table = [[name, int(off), [int(d) for d in shape],
                       [int(d) for d in spec.store_shape[name]] if name in spec.store_shape else None]
                      for name, (off, shape) in spec.names.items()]
-            lay = self._flat_layout = (spec, table)
+            lay = self._flat_layout = (spec, table, {})
         nbytes = int(net.params.numel()) * 4
         k = int(self._latest[0]) + 1
         i = k % self.slots
         self._hdr[i][0] = 0
-        header = msgpack.packb({"ctr": _plain(dict(ctr_info or {}, cmd="weights", seq=k)), "obj": {"__layout__": lay[1]},
-                                "arr": [["__flat__", "<f4", [nbytes // 4], 0, nbytes]], "order": ["__layout__", "__flat__"]},
-                               use_bin_type=True)
+        ctr = _plain(dict(ctr_info or {}, cmd="weights", seq=k))
+        hkey = msgpack.packb(ctr, use_bin_type=True)
+        header = lay[2].get(hkey)
+        if header is None:
+            header = msgpack.packb({"ctr": ctr, "obj": {"__layout__": lay[1]},
+                                    "arr": [["__flat__", "<f4", [nbytes // 4], 0, nbytes]], "order": ["__layout__", "__flat__"]},
+                                   use_bin_type=True)
+            if len(lay[2]) < 8:
+                lay[2][hkey] = header
         base = _pad(8 + len(header))
         if base + nbytes > self.slot_bytes:
             raise ValueError("weights of {} bytes exceed the {}-byte slot".format(base + nbytes, self.slot_bytes))
@@ -500,12 +508,26 @@ class WeightsRing(object):
             side.wait_event(ready)
             dst.copy_(net.params.detach(), non_blocking=True)
             done.record(side)
-        done.synchronize()
         del dst, view
-        self._hdr[i][1] = base + nbytes
+        self._pending = (k, i, base + nbytes, done)
+        return k
+
+    def commit_flat_publish(self):
+        """Second half: wait for the copy and make the publish visible to the readers.  Returns its sequence number."""
+        k, i, total, done = self._pending
+        self._pending = None
+        done.synchronize()
+        self._hdr[i][1] = total
         self._hdr[i][0] = k
         self._latest[0] = k
         return k
+
+    def publish_flat_from_device(self, net, ctr_info=None):
+        """Publish the learner network's packed parameter block with ONE device-to-host copy straight into the (pinned)
+        slot: the message carries the flat float32 buffer plus the name -> (offset, shape) table, ``fetch`` rebuilds
+        the name-keyed dict on the reader side.  ``net``: a ``HipActorCritic`` (``params``, ``spec``)."""
+        self.begin_flat_publish(net, ctr_info)
+        return self.commit_flat_publish()
 
     # ---- readers (explorers)
     def latest(self):
