@@ -208,8 +208,8 @@ def test_weights_publish_into_a_page_locked_ring_is_one_dma_and_readers_get_the_
     from xingtian_amd.model.hip_net import HipActorCritic
     for sd in ((84, 84, 4), (84, 84, 3)):
         net = HipActorCritic(netspec.ppo_cnn(sd, 4, (256,), "relu", True), max_batch=8, seed=3)
-        want = net.get_weights()
         for pinned in (True, False):
+            want = net.get_weights()
             ring = transport.WeightsRing(slot_bytes=8 << 20, slots=3)
             try:
                 if pinned:
