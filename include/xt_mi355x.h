@@ -311,7 +311,8 @@ int xt_heads_bwd(const float* f_pi, const float* f_v, int32_t B, int32_t F, int3
 
 /* ----------------------------------------------------------- optimiser */
 /* state[8] floats on the device: [0]=beta1^t [1]=beta2^t [2]=scale [3]=alpha
- * [4]=global_norm [5]=step(as float) [6..7] reserved.  Initialise with
+ * [4]=global_norm [5]=step(as float) [6]=device-side error word (0 = none; 1 = the grid barrier of the fused update tail,
+ * xt_tuning.tail_fused, timed out: that update was SKIPPED, parameters untouched) [7] reserved.  Initialise with
  * xt_adam_state_init (beta powers = 1). */
 int xt_adam_state_init(float* state, void* stream);
 

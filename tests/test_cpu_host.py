@@ -1115,3 +1115,36 @@ def test_image_observations_with_three_channels_pad_to_four_exactly():
     # learner (HipActorCritic.obs_fill_byte), the CPU replica pads after the transform
     spec_i = netspec.impala_cnn_opt((84, 84, 3), 4, 128.0, 128.0)
     assert spec_i.layers[0].C == 4 and spec_i.obs_channels_padded == 4
+
+
+def _stage_in_child(q):
+    import ctypes as ct
+    from xingtian_amd import lib
+    h = lib.load()
+    src = np.arange(1 << 20, dtype=np.uint8)
+    dst = np.zeros_like(src)
+    rc = h.xt_stage_rows(ct.c_void_p(dst.ctypes.data), ct.c_void_p(src.ctypes.data), src.nbytes, None, 0, 0, 4, None)
+    q.put((rc, bool(np.array_equal(src, dst))))
+
+
+def test_staging_pool_survives_fork():
+    """the native staging pool's worker threads do not exist in a forked child and its mutexes may be copied
+    locked; the child must build its own pool instead of waiting for workers that are not there."""
+    import ctypes as ct
+    import multiprocessing as mp_
+    from xingtian_amd import lib
+    h = lib.load()
+    src = np.arange(1 << 20, dtype=np.uint8)[::-1].copy()
+    dst = np.zeros_like(src)
+    assert h.xt_stage_rows(ct.c_void_p(dst.ctypes.data), ct.c_void_p(src.ctypes.data), src.nbytes, None, 0, 0, 4, None) == 0
+    assert np.array_equal(src, dst)              # the parent's pool now has 4 live workers
+    ctx = mp_.get_context("fork")
+    q = ctx.Queue()
+    p = ctx.Process(target=_stage_in_child, args=(q,))
+    p.start()
+    p.join(30)
+    assert not p.is_alive(), "the forked child hung in xt_stage_rows"
+    assert q.get(timeout=5) == (0, True)
+    dst[:] = 0
+    assert h.xt_stage_rows(ct.c_void_p(dst.ctypes.data), ct.c_void_p(src.ctypes.data), src.nbytes, None, 0, 0, 4, None) == 0
+    assert np.array_equal(src, dst)

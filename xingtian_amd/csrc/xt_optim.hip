@@ -35,11 +35,13 @@ __device__ __forceinline__ void grid_arrive(unsigned int* counter, unsigned int*
     }
   }
 }
-__device__ __forceinline__ void grid_wait(unsigned int* flag, unsigned int sense) {
+// -> false when the (bounded) wait ran out: the caller must NOT go on with partials / a step size it cannot trust
+__device__ __forceinline__ bool grid_wait(unsigned int* flag, unsigned int sense) {
   for (unsigned it = 0; it < (1u << 24); ++it) {
-    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sense) return;
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sense) return true;
     __builtin_amdgcn_s_sleep(2);
   }
+  return false;
 }
 __device__ __forceinline__ void adam_advance(float* state, float lr, float beta1, float beta2);
 __device__ void finalize_body(const float* partial, int nblocks, float clip_norm, float grad_scale, float lr,
@@ -166,9 +168,15 @@ __global__ __launch_bounds__(256) void grads_finish_kernel(const GradTable tab, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       grid_arrive(fin.counter, bar_flag, s_sense);
-      grid_wait(bar_flag, s_sense);
+      s_last = grid_wait(bar_flag, s_sense) ? 1 : 0;
     }
     __syncthreads();
+    if (!s_last) {
+      // the barrier never completed (a grid that is not co-resident: the host-side check was wrong for this device):
+      // leave parameters and moments untouched and raise the device-side error word the host reads with the loss
+      if (t == 0) fin.state[6] = 1.f;
+      return;
+    }
     double* shd = reinterpret_cast<double*>(sh4);
     const double sqt = sqnorm_total_coherent(partial, fin.ap.npartials, shd);
     if (t == 0) {
@@ -595,11 +603,12 @@ int launch_grads_finish(GradTable* tab, float* partial, int max_partials, int* n
 
 // how many workgroups of the fused tail can be resident at once on this device (its grid barrier needs all of them)
 int grads_finish_resident_blocks() {
-  static std::atomic<int> cached{0};
-  int v = cached.load();
-  if (v > 0) return v;
+  static std::atomic<int> cached_dev[64];      // per device: a process may drive several (different) GPUs
   int per_cu = 0, cus = 0, dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;
+  std::atomic<int>& cached = cached_dev[dev & 63];
+  int v = cached.load();
+  if (v > 0) return v;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, grads_finish_kernel, 256, 0) != hipSuccess) return 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
   v = per_cu * cus;

@@ -14,6 +14,7 @@
 #include <condition_variable>
 #include <emmintrin.h>
 #include <mutex>
+#include <pthread.h>
 #include <string.h>
 #include <thread>
 #include <vector>
@@ -59,7 +60,20 @@ struct Job {
 
 class Pool {
  public:
-  static Pool& get() { static Pool* p = new Pool(); return *p; }   // leaked on purpose: workers may outlive static destructors
+  // Leaked on purpose: workers may outlive static destructors.  NOT inherited across fork(): the worker threads do not
+  // exist in the child and the mutexes may have been copied locked, so a child handler drops the pointer and the first
+  // call in the child builds a fresh pool (the parent's is simply abandoned there).
+  static Pool& get() {
+    static std::once_flag once;
+    std::call_once(once, [] { pthread_atfork(nullptr, nullptr, [] { instance().store(nullptr, std::memory_order_release); }); });
+    Pool* p = instance().load(std::memory_order_acquire);
+    if (!p) {
+      Pool* fresh = new Pool();
+      if (instance().compare_exchange_strong(p, fresh, std::memory_order_acq_rel)) p = fresh;
+      else delete fresh;
+    }
+    return *p;
+  }
 
   // copies with `threads` participants (the caller is NOT one of them: it pipelines the H2D copies); calls
   // on_chunk(k) on the calling thread for k = 0 .. nchunks-1 in order, each as soon as chunk k is staged.
@@ -90,6 +104,7 @@ class Pool {
   }
 
  private:
+  static std::atomic<Pool*>& instance() { static std::atomic<Pool*> p{nullptr}; return p; }
   void ensure_workers(int n) {
     while ((int)workers_.size() < n && (int)workers_.size() < kMaxWorkers) {
       const int id = (int)workers_.size();

@@ -112,8 +112,7 @@ class RolloutIngest(object):
         self.sets = [None, None]
         self.cur = 0
         self.n = 0
-        self._lib = L.load()
-        staging_report()                # pick the staging-copy variant for this host once
+        self._lib = L.load()            # (the staging-copy variant for this host is picked on the first host copy)
 
     # ------------------------------------------------------------------
     def _ensure(self, need, obs):
@@ -180,6 +179,8 @@ class RolloutIngest(object):
             else:
                 cstream.synchronize()
         elif plain:
+            if not _TUNED:
+                staging_report()        # measure the host's copy variants once per process, on first use
             L.check(self._lib.xt_stage_rows(ctypes.c_void_p(s.host["obs"].data_ptr() + lo * row_bytes),
                                             ctypes.c_void_p(obs.ctypes.data), obs.nbytes, ctypes.c_void_p(dev_ptr), 0, 0, -1,
                                             ctypes.c_void_p(cstream.cuda_stream)), "xt_stage_rows")
