@@ -238,20 +238,21 @@ class RolloutIngest(object):
             raise RuntimeError("RolloutIngest.finish(): a rollout must not mix trajectories with and without advantages")
         dev = s.dev
         self._join_copy_streams(wait=False)
-        with torch.cuda.stream(self.copy_stream):          # the labels of the whole rollout: ONE copy (a few 10 KB)
-            s.lab_dev.copy_(s.lab_host, non_blocking=True)
-            if self.raw_traj:
-                s.dev["offsets"][:self.raw_traj + 1].copy_(s.host["offsets"][:self.raw_traj + 1], non_blocking=True)
-            if self.pad_channels is not None and s.dev["obs"].shape[-1] != self.pad_channels[0]:
-                c_dst, fill = self.pad_channels
-                src = s.dev["obs"]
-                if s.dev_padded is None:
-                    s.dev_padded = torch.empty(tuple(src.shape[:-1]) + (c_dst,), dtype=src.dtype, device=src.device)
-                rows = n * int(np.prod(src.shape[1:-1], dtype=np.int64))
-                L.check(self._lib.xt_pad_channels(L.ptr(src), L.ptr(s.dev_padded), rows, int(src.shape[-1]), c_dst,
-                                                  src.element_size(), int(fill),
-                                                  ctypes.c_void_p(self.copy_stream.cuda_stream)), "xt_pad_channels")
-                dev = dict(s.dev, obs=s.dev_padded)
+        # the labels of the whole rollout: ONE copy (a few 10 KB)
+        L.memcpy_async(s.lab_dev.data_ptr(), s.lab_host.data_ptr(), s.lab_host.numel(), L.H2D, self.copy_stream)
+        if self.raw_traj:
+            L.memcpy_async(s.dev["offsets"].data_ptr(), s.host["offsets"].data_ptr(), 4 * (self.raw_traj + 1), L.H2D,
+                           self.copy_stream)
+        if self.pad_channels is not None and s.dev["obs"].shape[-1] != self.pad_channels[0]:
+            c_dst, fill = self.pad_channels
+            src = s.dev["obs"]
+            if s.dev_padded is None:
+                s.dev_padded = torch.empty(tuple(src.shape[:-1]) + (c_dst,), dtype=src.dtype, device=src.device)
+            rows = n * int(np.prod(src.shape[1:-1], dtype=np.int64))
+            L.check(self._lib.xt_pad_channels(L.ptr(src), L.ptr(s.dev_padded), rows, int(src.shape[-1]), c_dst,
+                                              src.element_size(), int(fill),
+                                              ctypes.c_void_p(self.copy_stream.cuda_stream)), "xt_pad_channels")
+            dev = dict(s.dev, obs=s.dev_padded)
         s.done.record(self.copy_stream)
         torch.cuda.current_stream(self.device).wait_event(s.done)
         self.cur ^= 1

@@ -111,10 +111,9 @@ class HipActorCritic(object):
         i = (snap["slot"] + 1) % self.SNAP_SLOTS
         ready = snap["ready"][i]
         ready.record(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(snap["stream"]):
-            snap["stream"].wait_event(ready)
-            snap["host"][i].copy_(self.params.detach(), non_blocking=True)
-            snap["events"][i].record(snap["stream"])
+        snap["stream"].wait_event(ready)
+        L.memcpy_async(snap["host"][i].data_ptr(), self.params.data_ptr(), self.params.numel() * 4, L.D2H, snap["stream"])
+        snap["events"][i].record(snap["stream"])
         snap["slot"], snap["version"] = i, getattr(self, "_version", 0)
 
     def get_weights(self, copy=True):

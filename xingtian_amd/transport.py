@@ -425,8 +425,11 @@ class WeightsRing(object):
         self.pinned = False
         self._pending = None
 
+    def _payload_offset(self, i):
+        return _ALIGN + i * (_ALIGN + self.slot_bytes) + _ALIGN
+
     def _payload(self, i):
-        o = _ALIGN + i * (_ALIGN + self.slot_bytes) + _ALIGN
+        o = self._payload_offset(i)
         return self.shm.buf[o:o + self.slot_bytes]
 
     # ---- writer (the learner)
@@ -498,17 +501,16 @@ class WeightsRing(object):
         view[0:4] = MAGIC
         struct.pack_into("<I", view, 4, len(header))
         view[8:8 + len(header)] = header
-        dst = torch.frombuffer(view, dtype=torch.float32, count=nbytes // 4, offset=base)
+        del view
         st = getattr(self, "_d2h", None)
         if st is None:
             st = self._d2h = (torch.cuda.Stream(device=net.device), torch.cuda.Event(), torch.cuda.Event())
         side, ready, done = st
         ready.record(torch.cuda.current_stream(net.device))
-        with torch.cuda.stream(side):
-            side.wait_event(ready)
-            dst.copy_(net.params.detach(), non_blocking=True)
-            done.record(side)
-        del dst, view
+        side.wait_event(ready)
+        from xingtian_amd import lib as L
+        L.memcpy_async(self._pin_addr + self._payload_offset(i) + base, net.params.data_ptr(), nbytes, L.D2H, side)
+        done.record(side)
         self._pending = (k, i, base + nbytes, done)
         return k
 
