@@ -617,12 +617,12 @@ def bench_impala(key, steps, warmup, with_cpu, in_graph=False, quick=False):
         msgs.append({"cur_state": data["obs"][sl], "logit": data["logit"][sl], "action": data["action"][sl],
                      "done": list(data["done"][sl]), "reward": list(data["reward"][sl])})
 
-    def plugin_run(handover):
+    def plugin_run(handover, async_loss=False):
         from xingtian_amd import transport
         model_info = {"actor": {"model_name": "ImpalaCnnOpt", "state_dim": [w["dim"], w["dim"], 4], "input_dtype": "uint8",
                                 "state_mean": w["mean"], "state_std": w["std"], "action_dim": w["a_dim"],
                                 "model_config": {"LR": w["lr"], "sample_batch_step": w["t_len"], "grad_norm_clip": 40.0,
-                                                 "SEED": 0}}}
+                                                 "SEED": 0, "ASYNC_LOSS": bool(async_loss)}}}
         alg = alg_builder("IMPALAOpt", model_info, {"instance_num": 32, "agent_num": 1,
                                                    "prepare_times_per_train": msgs_per_train, "train_per_checkpoint": tpc,
                                                    "BATCH_SIZE": max(f, 512) if key.startswith("breakout_impala") else f})
@@ -668,12 +668,17 @@ def bench_impala(key, steps, warmup, with_cpu, in_graph=False, quick=False):
         return {"value": FRAME_SKIP * f * cnt / tot, "unit": "env-frames/s", "trains": cnt,
                 "ms_per_train": 1e3 * tot / cnt, "prepare_data_ms": 1e3 * t_prep / cnt, "train_ms": 1e3 * t_train / cnt,
                 "weights_ms": 1e3 * t_w / cnt, "train_per_checkpoint": tpc,
+                "async_loss": bool(async_loss),
                 "path": "alg_builder('IMPALAOpt') -> prepare_data x {} -> train() -> every {} train(s): {}".format(
                     msgs_per_train, tpc, "publish_weights(pinned WeightsRing): one D2H into the slot" if handover == "publish"
                     else "get_weights(): dict of private arrays")}
 
     out["e2e"] = plugin_run("get_weights")
     out["e2e_publish"] = plugin_run("publish")
+    # model_config ASYNC_LOSS: train() returns the PREVIOUS train's loss instead of waiting for its own, so the next
+    # message is staged / copied while the GPU runs this train (flagged: the logged loss lags one train; weights do not)
+    out["e2e_publish_async_loss"] = dict(plugin_run("publish", async_loss=True),
+                                         note="model_config ASYNC_LOSS: the reported loss lags one train; weights handed out are current")
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline_impala(w, data)
     return out

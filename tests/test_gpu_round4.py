@@ -278,3 +278,38 @@ def test_rccl_shim_exchange_on_one_rank_matches_the_stepwise_path_bitwise():
         assert err == 0 and calls == 6 * (2 if overlap else 1), (graph, overlap, calls, err)
         assert np.array_equal(net.params.cpu().numpy(), want), (graph, overlap)
     comm.destroy()
+
+
+def test_async_loss_option_lags_the_reported_loss_by_one_train_and_nothing_else():
+    """model_config ASYNC_LOSS (IMPALAOpt): train() returns the previous train's loss without waiting for the update it
+    enqueued (the first call waits for its own), so the host stages the next message while the GPU works.  Same weights
+    after every train, same losses shifted by one."""
+    from xingtian_amd.algorithm import alg_builder
+
+    def mk(async_loss):
+        model_info = {"actor": {"model_name": "ImpalaCnnOpt", "state_dim": [42, 42, 4], "input_dtype": "uint8",
+                                "state_mean": 128.0, "state_std": 128.0, "action_dim": 6,
+                                "model_config": {"LR": 1e-3, "sample_batch_step": 10, "grad_norm_clip": 40.0, "SEED": 0,
+                                                 "ASYNC_LOSS": async_loss, "lr_schedule": [[0, 1e-3], [20000, 1e-6]]}}}
+        return alg_builder("IMPALAOpt", model_info, {"instance_num": 4, "agent_num": 1, "prepare_times_per_train": 1,
+                                                    "train_per_checkpoint": 3, "BATCH_SIZE": 50})
+
+    rng = np.random.default_rng(9)
+    msgs = []
+    for _ in range(5):
+        n = 50
+        msgs.append({"cur_state": rng.integers(0, 256, (n, 42, 42, 4)).astype(np.uint8),
+                     "logit": rng.standard_normal((n, 6)).astype(np.float32), "action": rng.integers(0, 6, n).astype(np.int32),
+                     "done": list(rng.random(n) < 0.05), "reward": list(rng.choice([-1.0, 0.0, 1.0], n))})
+    out = {}
+    for mode in (False, True):
+        alg = mk(mode)
+        losses = []
+        for m in msgs:
+            alg.prepare_data(m)
+            losses.append(float(alg.train()))
+        out[mode] = (losses, alg.get_weights())
+    sync, lag = out[False][0], out[True][0]
+    assert lag[0] == sync[0] and lag[1:] == sync[:-1], (sync, lag)
+    for k in out[False][1]:
+        assert np.array_equal(out[False][1][k], out[True][1][k]), k

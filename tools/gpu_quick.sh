@@ -18,7 +18,7 @@ try:
     for k, v in d.get("e2e", {}).items():
         if isinstance(v, dict): print("e2e", k, {q: (round(x, 3) if isinstance(x, float) else x) for q, x in v.items() if q not in ("path", "note", "gae", "weights_handover", "gbps")})
     for s in d.get("secondary", []):
-        print("SEC", s["workload"][:40], "value", round(s["value"]), "us/train", round(s["us_per_train"], 1), "frac", round(s["update_frac_of_fp32_mfma_peak"], 3), "e2e", {q: (round(x, 3) if isinstance(x, float) else x) for q, x in s["e2e"].items() if q != "path"}, "publish", {q: (round(x, 3) if isinstance(x, float) else x) for q, x in s.get("e2e_publish", {}).items() if q != "path"})
+        print("SEC", s["workload"][:40], "value", round(s["value"]), "us/train", round(s["us_per_train"], 1), "frac", round(s["update_frac_of_fp32_mfma_peak"], 3), "e2e", {q: (round(x, 3) if isinstance(x, float) else x) for q, x in s["e2e"].items() if q != "path"}, "publish", {q: (round(x, 3) if isinstance(x, float) else x) for q, x in s.get("e2e_publish", {}).items() if q != "path"}, "async", {q: (round(x, 3) if isinstance(x, float) else x) for q, x in s.get("e2e_publish_async_loss", {}).items() if q not in ("path", "note")})
         print("   kernels", s["roofline"]["kernels_us_isolated"], "cpu", s.get("cpu_baseline", {}).get("value"))
     print("cpu", d.get("cpu_baseline"))
     print("library", d.get("library"), "box", d.get("box"))

@@ -53,6 +53,13 @@ class ImpalaCnnOpt(XTModel):
         self._rng = np.random.default_rng(self.seed)
         self.use_graph = bool(model_config.get("USE_HIP_GRAPH", True))
         self.stream_ingest = bool(model_config.get("STREAM_INGEST", True))
+        # ASYNC_LOSS (default off): train() does not wait for the update it has just enqueued -- it returns the loss of the
+        # PREVIOUS train (the first call still waits), so the next message is staged and copied to HBM while the GPU runs this
+        # one.  Only the reported number lags (xt/framework/learner.py:348-351 logs it); weights handed out afterwards are
+        # always the ones this train produced.  Pays when weights do not go out after every train (train_per_checkpoint > 1).
+        self.async_loss = bool(model_config.get("ASYNC_LOSS", False))
+        self._loss_pin = self._loss_ev = None
+        self._loss_slot = 0
         self._ingest = None
         self._lr_host = self._lr_dev = None
         super().__init__(model_info)
@@ -95,15 +102,20 @@ class ImpalaCnnOpt(XTModel):
         reference's rmsprop branch ignores lr_schedule, impala_cnn_opt.py:204-206)."""
         if not (self.lr_schedule and self.opt_type == "adam"):
             return None
-        if self._lr_host is None or self._lr_host.numel() < n_chunks:
-            self._lr_host = torch.empty((max(n_chunks, 16),), dtype=torch.float32, pin_memory=True)
+        if self._lr_host is None or self._lr_host[0].numel() < n_chunks:
+            # two pinned blocks, alternating: with ASYNC_LOSS the host may be a whole train ahead of the copy it enqueued
+            self._lr_host = [torch.empty((max(n_chunks, 16),), dtype=torch.float32, pin_memory=True) for _ in range(2)]
             self._lr_dev = torch.empty((max(n_chunks, 16),), dtype=torch.float32, device=self.net.device)
+            self._lr_turn = 0
+            torch.cuda.current_stream(self.net.device).synchronize()
+        host = self._lr_host[self._lr_turn]
+        self._lr_turn ^= 1
         step0 = self._global_step
         for i in range(n_chunks):
             self._global_step = step0 + i
-            self._lr_host[i] = float(self.current_lr())
+            host[i] = float(self.current_lr())
         self._global_step = step0
-        self._lr_dev[:n_chunks].copy_(self._lr_host[:n_chunks], non_blocking=True)
+        self._lr_dev[:n_chunks].copy_(host[:n_chunks], non_blocking=True)
         return self._lr_dev
 
     def train_ingested(self, batch_size):
@@ -119,8 +131,30 @@ class ImpalaCnnOpt(XTModel):
         self._global_step += n_chunks
         if self.eager_snapshot:
             self.net.snapshot_weights_async()   # the D2H of the new weights runs under the loss read-back
+        if self.async_loss:
+            return self._loss_of_previous_train(acc)
         a = acc.cpu().numpy()
         return np.float32(a[0] / max(a[1], 1.0))
+
+    def _loss_of_previous_train(self, acc):
+        """enqueue the read-back of this train's [sum, count] into one of two pinned words, return the other one's (the
+        previous train's: its copy finished long ago); the very first call waits for its own"""
+        from xingtian_amd import lib as L
+        if self._loss_pin is None:
+            self._loss_pin = torch.zeros((2, 2), dtype=torch.float32, pin_memory=True)
+            self._loss_ev = [torch.cuda.Event(), torch.cuda.Event()]
+            self._loss_slot, first = 0, True
+        else:
+            first = False
+        i = self._loss_slot
+        cur = torch.cuda.current_stream(self.net.device)
+        L.memcpy_async(self._loss_pin[i].data_ptr(), acc.data_ptr(), 8, L.D2H, cur)
+        self._loss_ev[i].record(cur)
+        self._loss_slot = i ^ 1
+        j = i if first else i ^ 1
+        self._loss_ev[j].synchronize()
+        a = self._loss_pin[j]
+        return np.float32(float(a[0]) / max(float(a[1]), 1.0))
 
     def train(self, state, label):
         """One chunk: state [n,...], label=[bp_logits, actions, dones, rewards] -> loss
