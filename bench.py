@@ -617,7 +617,7 @@ def bench_impala(key, steps, warmup, with_cpu, in_graph=False, quick=False):
         msgs.append({"cur_state": data["obs"][sl], "logit": data["logit"][sl], "action": data["action"][sl],
                      "done": list(data["done"][sl]), "reward": list(data["reward"][sl])})
 
-    def plugin_run(handover, async_loss=False):
+    def plugin_run(handover, async_loss=False, lag=0):
         from xingtian_amd import transport
         model_info = {"actor": {"model_name": "ImpalaCnnOpt", "state_dim": [w["dim"], w["dim"], 4], "input_dtype": "uint8",
                                 "state_mean": w["mean"], "state_std": w["std"], "action_dim": w["a_dim"],
@@ -645,7 +645,7 @@ def bench_impala(key, steps, warmup, with_cpu, in_graph=False, quick=False):
             t2 = time.perf_counter()
             if alg.checkpoint_ready(i):         # train_count BEFORE its increment, as learner.py:361 passes it
                 if ring is not None:
-                    assert alg.publish_weights(ring) > 0
+                    assert alg.publish_weights(ring, lag=lag) > 0
                 else:
                     wts = alg.get_weights()
                     assert len(wts) >= 8
@@ -668,7 +668,7 @@ def bench_impala(key, steps, warmup, with_cpu, in_graph=False, quick=False):
         return {"value": FRAME_SKIP * f * cnt / tot, "unit": "env-frames/s", "trains": cnt,
                 "ms_per_train": 1e3 * tot / cnt, "prepare_data_ms": 1e3 * t_prep / cnt, "train_ms": 1e3 * t_train / cnt,
                 "weights_ms": 1e3 * t_w / cnt, "train_per_checkpoint": tpc,
-                "async_loss": bool(async_loss),
+                "async_loss": bool(async_loss), "weights_lag_trains": int(lag),
                 "path": "alg_builder('IMPALAOpt') -> prepare_data x {} -> train() -> every {} train(s): {}".format(
                     msgs_per_train, tpc, "publish_weights(pinned WeightsRing): one D2H into the slot" if handover == "publish"
                     else "get_weights(): dict of private arrays")}
@@ -679,6 +679,11 @@ def bench_impala(key, steps, warmup, with_cpu, in_graph=False, quick=False):
     # message is staged / copied while the GPU runs this train (flagged: the logged loss lags one train; weights do not)
     out["e2e_publish_async_loss"] = dict(plugin_run("publish", async_loss=True),
                                          note="model_config ASYNC_LOSS: the reported loss lags one train; weights handed out are current")
+    # fully pipelined learner loop (FLAGGED deviation): ASYNC_LOSS + publish_weights(lag=1) -- the weights handed out after
+    # train k are those of train k-1 (their copy landed long ago), nothing in the loop waits for the GPU; what an
+    # asynchronous algorithm like IMPALA tolerates by design (v-trace corrects the policy lag), not what learner.py does
+    out["e2e_pipelined"] = dict(plugin_run("publish", async_loss=True, lag=1), semantic_change=True,
+                                note="ASYNC_LOSS + publish_weights(lag=1): loss AND published weights lag one train")
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline_impala(w, data)
     return out

@@ -313,3 +313,37 @@ def test_async_loss_option_lags_the_reported_loss_by_one_train_and_nothing_else(
     assert lag[0] == sync[0] and lag[1:] == sync[:-1], (sync, lag)
     for k in out[False][1]:
         assert np.array_equal(out[False][1][k], out[True][1][k]), k
+
+
+def test_publish_weights_with_a_lag_of_one_hands_out_the_previous_update_without_waiting():
+    """publish_weights(ring, lag=1): after update k the readers get the weights of update k-1 (whose D2H landed long ago);
+    the copy of update k stays begun in the ring's next slot.  lag=0 afterwards catches up to the current weights."""
+    from xingtian_amd import transport
+    from xingtian_amd.model import netspec
+    from xingtian_amd.model.hip_net import HipActorCritic
+    net = HipActorCritic(netspec.ppo_mlp((4,), 2, (16, 16), "tanh", True), max_batch=8, seed=0)
+    ring = transport.WeightsRing(slot_bytes=1 << 20, slots=3)
+    assert ring.pin()
+    reader = transport.WeightsRing(name=ring.name, slot_bytes=1 << 20, slots=3, create=False)
+    try:
+        net.attach_weights_ring(ring)
+        hist = []
+        for k in range(5):
+            net.params.add_(1.0)            # "update k"
+            net.touch()
+            net.snapshot_weights_async()    # what every train enqueues
+            hist.append(net.params.cpu().numpy().copy())
+            seq = net.publish_weights(ring, lag=1)
+            got = reader.fetch(newer_than=0)
+            flat = np.concatenate([got[2][n].reshape(-1) for n in net.spec.names])
+            want = hist[max(k - 1, 0)]
+            ref = np.concatenate([want[off:off + int(np.prod(shape))] for off, shape in net.spec.names.values()])
+            assert np.array_equal(flat, ref), (k, seq)
+        assert net.publish_weights(ring, lag=0) == reader.latest()
+        got = reader.fetch(newer_than=0)
+        flat = np.concatenate([got[2][n].reshape(-1) for n in net.spec.names])
+        ref = np.concatenate([hist[-1][off:off + int(np.prod(shape))] for off, shape in net.spec.names.values()])
+        assert np.array_equal(flat, ref)
+    finally:
+        reader.close()
+        ring.close()

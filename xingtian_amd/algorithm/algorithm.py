@@ -129,9 +129,11 @@ class Algorithm(object):
     def set_weights(self, weights):
         return self.actor.set_weights(weights)
 
-    def publish_weights(self, ring, ctr_info=None):
-        """``get_weights`` + hand-over to the explorers in one step (``transport.WeightsRing``)."""
-        return self.actor.publish_weights(ring, ctr_info)
+    def publish_weights(self, ring, ctr_info=None, lag=0):
+        """``get_weights`` + hand-over to the explorers in one step (``transport.WeightsRing``).  ``lag = 1`` hands out
+        the previous update's weights without waiting for the current one (asynchronous algorithms only: a deviation from
+        the reference's learner loop, which publishes what the train has just produced)."""
+        return self.actor.publish_weights(ring, ctr_info, lag=lag)
 
     @staticmethod
     def update_weights_map(agent_in_group="agent_0", agent_in_env="agent_0"):

@@ -97,7 +97,10 @@ class HipActorCritic(object):
         rollout's ingest).  ``get_weights`` picks the block up once its event has fired."""
         ring = getattr(self, "_wring", None)
         if ring is not None:
-            # a page-locked WeightsRing is attached: the copy goes straight into its next slot (no pinned bounce block)
+            # a page-locked WeightsRing is attached: the copy goes straight into its next slot (no pinned bounce block).
+            # Begun publishes beyond the allowed lag belong to updates whose weights were never handed out: reuse their slot
+            while len(ring._pending) > getattr(self, "_wring_lag", 0):
+                ring.retarget_flat_publish()
             ring.begin_flat_publish(self, getattr(self, "_wring_ctr", None))
             self._wring_version = getattr(self, "_version", 0)
             return
@@ -155,15 +158,33 @@ class HipActorCritic(object):
         snap["events"][snap["slot"]].synchronize()
         return snap["host"][snap["slot"]].numpy()
 
-    def publish_weights(self, ring, ctr_info=None):
+    def publish_weights(self, ring, ctr_info=None, lag=0):
         """The learner's weight hand-over (xt/framework/learner.py:361-363) without an intermediate dict: the packed
         parameter block goes pinned block -> ring slot with one copy per variable, or -- when the ring is page-locked
         (``WeightsRing.pin``) -- by ONE D2H straight from HBM into the slot (no host copy at all).  Returns the
         publish's sequence number."""
         if getattr(ring, "pinned", False):
-            if getattr(self, "_wring", None) is ring and ring._pending is not None and \
-                    getattr(self, "_wring_version", -1) == getattr(self, "_version", 0) and not ctr_info:
+            attached = getattr(self, "_wring", None) is ring
+            if lag > 0:
+                # ``lag = 1`` (asynchronous algorithms, flagged deviation): hand out the weights of the PREVIOUS update,
+                # whose copy landed long ago, and never wait for the one just enqueued -- the next rollout message is
+                # ingested while the GPU still runs this update.  The copy of the current update stays begun.
+                if not attached or ring.slots < 3:
+                    raise ValueError("publish_weights(lag=1) needs attach_weights_ring(ring) and a ring of >= 3 slots")
+                self._wring_lag = 1
+                if not ring._pending or getattr(self, "_wring_version", -1) != getattr(self, "_version", 0):
+                    ring.begin_flat_publish(self, ctr_info)
+                    self._wring_version = getattr(self, "_version", 0)
+                if len(ring._pending) > 1 or ring.latest() == 0:
+                    return ring.commit_flat_publish()
+                return ring.latest()
+            self._wring_lag = 0
+            if attached and ring._pending and getattr(self, "_wring_version", -1) == getattr(self, "_version", 0) and not ctr_info:
+                while len(ring._pending) > 1:
+                    ring.commit_flat_publish()
                 return ring.commit_flat_publish()       # the update itself enqueued the copy (snapshot_weights_async)
+            while ring._pending:
+                ring.retarget_flat_publish()
             return ring.publish_flat_from_device(self, ctr_info)
         return ring.publish(self.get_weights(copy=False), ctr_info)
 

@@ -97,13 +97,13 @@ class XTModel(object):
     def set_weights(self, weights):
         self.net.set_weights(weights)
 
-    def publish_weights(self, ring, ctr_info=None):
+    def publish_weights(self, ring, ctr_info=None, lag=0):
         """Hand the current weights to the explorers through a ``transport.WeightsRing`` (the learner's
         ``get_weights`` + ``_dist_policy`` pair, xt/framework/learner.py:361-366) without building an intermediate
         dict of private arrays; on a page-locked ring the parameters travel HBM -> slot with one DMA."""
         if getattr(ring, "pinned", False) and getattr(self.net, "_wring", None) is not ring:
             self.net.attach_weights_ring(ring)      # later updates copy their weights straight into the ring
-        return self.net.publish_weights(ring, ctr_info)
+        return self.net.publish_weights(ring, ctr_info, lag=lag)
 
     # ---- checkpoints
     def save_model(self, file_name):

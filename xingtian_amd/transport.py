@@ -423,7 +423,7 @@ class WeightsRing(object):
                      for i in range(self.slots)]
         self._seen = 0
         self.pinned = False
-        self._pending = None
+        self._pending = []          # begun, uncommitted packed publishes, oldest first: (seq, slot, bytes, event)
 
     def _payload_offset(self, i):
         return _ALIGN + i * (_ALIGN + self.slot_bytes) + _ALIGN
@@ -471,8 +471,8 @@ class WeightsRing(object):
         """First half of a packed publish: write the message header into the next slot and ENQUEUE the device-to-host
         copy of the learner network's flat parameter block straight into the (pinned) slot, ordered behind everything
         already enqueued on the current stream (the update whose result it publishes).  Returns at once; the slot stays
-        invalid (seq 0) until ``commit_flat_publish``.  Calling it again before a commit re-targets the same slot (an
-        update whose weights were never handed out)."""
+        invalid (seq 0) until ``commit_flat_publish``.  Up to ``slots - 2`` publishes may be begun ahead of their commit
+        (``publish_weights(lag=1)``: the weights handed out are one update old, nothing waits)."""
         import torch
         spec = net.spec
         lay = getattr(self, "_flat_layout", None)
@@ -482,7 +482,9 @@ class WeightsRing(object):
                      for name, (off, shape) in spec.names.items()]
             lay = self._flat_layout = (spec, table, {})
         nbytes = int(net.params.numel()) * 4
-        k = int(self._latest[0]) + 1
+        if len(self._pending) >= self.slots - 1:
+            raise RuntimeError("WeightsRing: {} publishes begun and not committed (slots = {})".format(len(self._pending), self.slots))
+        k = int(self._latest[0]) + 1 + len(self._pending)
         i = k % self.slots
         self._hdr[i][0] = 0
         ctr = _plain(dict(ctr_info or {}, cmd="weights", seq=k))
@@ -504,25 +506,32 @@ class WeightsRing(object):
         del view
         st = getattr(self, "_d2h", None)
         if st is None:
-            st = self._d2h = (torch.cuda.Stream(device=net.device), torch.cuda.Event(), torch.cuda.Event())
-        side, ready, done = st
+            st = self._d2h = (torch.cuda.Stream(device=net.device), torch.cuda.Event(),
+                              [torch.cuda.Event() for _ in range(self.slots)])
+        side, ready, dones = st
+        done = dones[i]
         ready.record(torch.cuda.current_stream(net.device))
         side.wait_event(ready)
         from xingtian_amd import lib as L
         L.memcpy_async(self._pin_addr + self._payload_offset(i) + base, net.params.data_ptr(), nbytes, L.D2H, side)
         done.record(side)
-        self._pending = (k, i, base + nbytes, done)
+        self._pending.append((k, i, base + nbytes, done))
         return k
 
     def commit_flat_publish(self):
-        """Second half: wait for the copy and make the publish visible to the readers.  Returns its sequence number."""
-        k, i, total, done = self._pending
-        self._pending = None
+        """Second half: wait for the OLDEST begun copy and make that publish visible to the readers.  Returns its
+        sequence number."""
+        k, i, total, done = self._pending.pop(0)
         done.synchronize()
         self._hdr[i][1] = total
         self._hdr[i][0] = k
         self._latest[0] = k
         return k
+
+    def retarget_flat_publish(self):
+        """Drop the newest begun, uncommitted publish (an update whose weights are never handed out: its slot is reused)."""
+        if self._pending:
+            self._pending.pop()
 
     def publish_flat_from_device(self, net, ctr_info=None):
         """Publish the learner network's packed parameter block with ONE device-to-host copy straight into the (pinned)
