@@ -96,6 +96,8 @@ class HipActorCritic(object):
         publishes).  Returns immediately: the copy runs under whatever the host does next (the loss read-back, the next
         rollout's ingest).  ``get_weights`` picks the block up once its event has fired."""
         ring = getattr(self, "_wring", None)
+        if ring is not None and not getattr(ring, "pinned", False):
+            ring = self._wring = None       # the ring was closed (or un-pinned) behind our back: private snapshots again
         if ring is not None:
             # a page-locked WeightsRing is attached: the copy goes straight into its next slot (no pinned bounce block).
             # Begun publishes beyond the allowed lag belong to updates whose weights were never handed out: reuse their slot
