@@ -1148,3 +1148,38 @@ def test_staging_pool_survives_fork():
     dst[:] = 0
     assert h.xt_stage_rows(ct.c_void_p(dst.ctypes.data), ct.c_void_p(src.ctypes.data), src.nbytes, None, 0, 0, 4, None) == 0
     assert np.array_equal(src, dst)
+
+
+def test_weights_ring_packed_publish_round_trips_names_shapes_and_padded_kernels():
+    """The packed weight message (flat float32 parameter buffer + name table, what the learner's publish DMA-copies into a
+    pinned slot) decodes on the reader side into the name-keyed dict of ``get_weights()`` -- also for a channel-padded
+    first layer, whose TF-shaped kernel is a strided sub-block of its storage.  CPU: published from a CPU replica."""
+    from xingtian_amd import transport
+    from xingtian_amd.model import netspec
+    from xingtian_amd.model.cpu_net import CpuActorCritic
+    for sd in ((42, 42, 4), (42, 42, 3)):
+        spec = netspec.ppo_cnn(sd, 3, (32,), "relu", True)
+        net = CpuActorCritic(spec, seed=4)
+        want = net.get_weights()
+        ring = transport.WeightsRing(slot_bytes=2 << 20, slots=3)
+        reader = transport.WeightsRing(name=ring.name, slot_bytes=2 << 20, slots=3, create=False)
+        try:
+            for rep in range(4):                                  # laps the three slots
+                net.params += 0.5
+                want = net.get_weights()
+                k = ring.publish_flat_host(net.params, spec, {"train_count": rep})
+                seq, ctr, got = reader.fetch()
+                assert seq == k == rep + 1 and ctr["train_count"] == rep and ctr["cmd"] == "weights" and ctr["seq"] == k
+                assert list(got) == list(want)
+                for name in want:
+                    assert got[name].shape == want[name].shape and np.array_equal(got[name], want[name]), name
+            assert reader.fetch() is None
+            replica = CpuActorCritic(spec, seed=0)
+            replica.set_weights(got)
+            back = replica.get_weights()          # (alignment padding between the blocks is not part of any variable)
+            assert all(np.array_equal(back[name], want[name]) for name in want)
+            with pytest.raises(ValueError, match="flat buffer"):
+                ring.publish_flat_host(net.params[:-4], spec)
+        finally:
+            reader.close()
+            ring.close()

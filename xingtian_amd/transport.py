@@ -467,35 +467,28 @@ class WeightsRing(object):
         self.pinned = (rc == 0)
         return self.pinned
 
-    def begin_flat_publish(self, net, ctr_info=None):
-        """First half of a packed publish: write the message header into the next slot and ENQUEUE the device-to-host
-        copy of the learner network's flat parameter block straight into the (pinned) slot, ordered behind everything
-        already enqueued on the current stream (the update whose result it publishes).  Returns at once; the slot stays
-        invalid (seq 0) until ``commit_flat_publish``.  Up to ``slots - 2`` publishes may be begun ahead of their commit
-        (``publish_weights(lag=1)``: the weights handed out are one update old, nothing waits)."""
-        import torch
-        spec = net.spec
+    def _reserve_flat(self, spec, nbytes, ctr_info):
+        """Claim the next slot for a packed publish of ``nbytes`` bytes of ``spec``'s flat parameter buffer and write the
+        message header (the name -> (offset, shape, storage shape) table is packed once per spec; only the control dict
+        changes per publish).  -> (sequence number, slot, byte offset of the array section inside the slot's payload)."""
         lay = getattr(self, "_flat_layout", None)
         if lay is None or lay[0] is not spec:
             table = [[name, int(off), [int(d) for d in shape],
-                      [int(d) for d in spec.store_shape[name]] if name in spec.store_shape else None]
+                      [int(d) for d in spec.store_shape[name]] if name in getattr(spec, "store_shape", {}) else None]
                      for name, (off, shape) in spec.names.items()]
-            lay = self._flat_layout = (spec, table, {})
-        nbytes = int(net.params.numel()) * 4
+            rest = msgpack.packb({"obj": {"__layout__": table}, "arr": [["__flat__", "<f4", [nbytes // 4], 0, nbytes]],
+                                  "order": ["__layout__", "__flat__"]}, use_bin_type=True)
+            assert rest[0] == 0x83              # fixmap of three entries: spliced behind the per-publish "ctr" entry below
+            lay = self._flat_layout = (spec, rest[1:], nbytes)
+        if lay[2] != nbytes:
+            raise ValueError("WeightsRing: the flat buffer of this spec has {} bytes, not {}".format(lay[2], nbytes))
         if len(self._pending) >= self.slots - 1:
             raise RuntimeError("WeightsRing: {} publishes begun and not committed (slots = {})".format(len(self._pending), self.slots))
         k = int(self._latest[0]) + 1 + len(self._pending)
         i = k % self.slots
         self._hdr[i][0] = 0
-        ctr = _plain(dict(ctr_info or {}, cmd="weights", seq=k))
-        hkey = msgpack.packb(ctr, use_bin_type=True)
-        header = lay[2].get(hkey)
-        if header is None:
-            header = msgpack.packb({"ctr": ctr, "obj": {"__layout__": lay[1]},
-                                    "arr": [["__flat__", "<f4", [nbytes // 4], 0, nbytes]], "order": ["__layout__", "__flat__"]},
-                                   use_bin_type=True)
-            if len(lay[2]) < 8:
-                lay[2][hkey] = header
+        header = b"\x84" + msgpack.packb("ctr") + msgpack.packb(_plain(dict(ctr_info or {}, cmd="weights", seq=k)),
+                                                                use_bin_type=True) + lay[1]
         base = _pad(8 + len(header))
         if base + nbytes > self.slot_bytes:
             raise ValueError("weights of {} bytes exceed the {}-byte slot".format(base + nbytes, self.slot_bytes))
@@ -504,6 +497,30 @@ class WeightsRing(object):
         struct.pack_into("<I", view, 4, len(header))
         view[8:8 + len(header)] = header
         del view
+        return k, i, base
+
+    def publish_flat_host(self, flat, spec, ctr_info=None):
+        """Packed publish from a HOST array (the flat float32 parameter buffer of ``spec``, e.g. a CPU replica's): one
+        copy into the slot, same message format as ``publish_flat_from_device``."""
+        flat = np.ascontiguousarray(flat, np.float32).reshape(-1)
+        k, i, base = self._reserve_flat(spec, flat.nbytes, ctr_info)
+        view = self._payload(i)
+        view[base:base + flat.nbytes] = flat.view(np.uint8)
+        del view
+        self._hdr[i][1] = base + flat.nbytes
+        self._hdr[i][0] = k
+        self._latest[0] = k
+        return k
+
+    def begin_flat_publish(self, net, ctr_info=None):
+        """First half of a packed publish: write the message header into the next slot and ENQUEUE the device-to-host
+        copy of the learner network's flat parameter block straight into the (pinned) slot, ordered behind everything
+        already enqueued on the current stream (the update whose result it publishes).  Returns at once; the slot stays
+        invalid (seq 0) until ``commit_flat_publish``.  Up to ``slots - 2`` publishes may be begun ahead of their commit
+        (``publish_weights(lag=1)``: the weights handed out are one update old, nothing waits)."""
+        import torch
+        nbytes = int(net.params.numel()) * 4
+        k, i, base = self._reserve_flat(net.spec, nbytes, ctr_info)
         st = getattr(self, "_d2h", None)
         if st is None:
             st = self._d2h = (torch.cuda.Stream(device=net.device), torch.cuda.Event(),
