@@ -647,7 +647,11 @@ int launch_adam_clip(float* param, const float* grad, float* m, float* v, long l
   XT_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
              "adam: buffers must be 16-byte aligned");
   int nb = (int)((count / 4 + 255) / 256);
-  if (nb > 2048) nb = 2048;
+  // at most 512 blocks, two per CU in one dispatch round: every block re-derives the clip factor from the ~1 700
+  // squared-norm partials before it touches an element, so fewer, fatter blocks repeat that chain less often and the grid
+  // dispatches faster (round 4, same-box A/B per 52-step update: 828 blocks 6.810 / 6.808 ms, 512: 6.769 / 6.776, 256:
+  // 6.789 / 6.797).  Element-wise arithmetic: bitwise the same parameters.
+  if (nb > 512) nb = 512;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(adam_tf_clip_kernel, dim3(nb), dim3(256), 0, st, param, grad, m, v, count, beta1, beta2, eps, state,
                      partial, nblocks, clip_norm, grad_scale);
