@@ -942,13 +942,27 @@ def main():
             rccl.attach(net, overlap=variant.endswith("_overlap"))
         graph = (use_graph or variant.startswith("ingraph")) and not args.no_graph
 
+        # the epoch shuffles travel through a small ring of PINNED blocks (as the product's Model.train does,
+        # xingtian_amd/model/ppo/ppo.py::_take_perms): an asynchronous 64 KB DMA instead of a pageable copy that bounces
+        # through a staging buffer and a blit kernel; a block is reused only after its copy's event has fired
+        perm_pin = [torch.empty((CFG["NUM_SGD_ITER"], n), dtype=torch.int32, pin_memory=True) for _ in range(4)]
+        perm_ev = [None] * len(perm_pin)
+        perm_turn = [0]
+
         def new_perms():
+            k = perm_turn[0] % len(perm_pin)
+            perm_turn[0] += 1
+            if perm_ev[k] is not None:
+                perm_ev[k].synchronize()
+            p = perm_pin[k].numpy()
             inds = np.arange(n)
-            p = np.empty((CFG["NUM_SGD_ITER"], n), np.int32)
             for ep in range(CFG["NUM_SGD_ITER"]):
                 prng.shuffle(inds)
                 p[ep] = inds
-            d_perm.copy_(torch.from_numpy(p), non_blocking=False)
+            d_perm.copy_(perm_pin[k], non_blocking=True)
+            if perm_ev[k] is None:
+                perm_ev[k] = torch.cuda.Event()
+            perm_ev[k].record(torch.cuda.current_stream(dev))
 
         def one_update():
             new_perms()
