@@ -1183,3 +1183,86 @@ def test_weights_ring_packed_publish_round_trips_names_shapes_and_padded_kernels
         finally:
             reader.close()
             ring.close()
+
+
+def _frame_producer(port, n_msgs):
+    from xingtian_amd import transport
+    ch = transport.FrameSocket.connect("127.0.0.1", port)
+    rng = np.random.default_rng(77)
+    for i in range(n_msgs):
+        t = 16 + i
+        ch.send({"cmd": "train", "explorer_id": 3, "seq": i},
+                {"cur_state": rng.integers(0, 256, (t, 84, 84, 4), dtype=np.uint8), "action": rng.integers(0, 4, t).astype(np.int32),
+                 "logp": rng.standard_normal((t, 1)).astype(np.float32), "adv": rng.standard_normal((t, 1)),
+                 "done": [bool(b) for b in rng.random(t) < 0.1], "reward": [float(x) for x in rng.choice([-1.0, 0.0, 1.0], t)]})
+    ch.close()
+
+
+def test_frame_socket_carries_rollout_messages_between_processes_through_a_forwarding_hop():
+    """The inter-node hop of SURVEY 8(f1) (zeus/common/ipc/comm_by_zmq.py:69-97) without zmq: two-frame messages over TCP
+    from an explorer PROCESS, through a broker-like forwarder that never decodes the payload (``recv_bytes`` ->
+    ``send_bytes``, broker.py:97-119), into the learner side's ``recv_into(sink)``: zero-copy views, 64-byte aligned
+    arrays, python-object fields intact, the reusable buffer growing with the messages."""
+    import threading
+    from xingtian_amd import transport
+    n = 5
+    srv_a, port_a = transport.FrameSocket.listen()       # forwarder <- explorer process
+    srv_b, port_b = transport.FrameSocket.listen()       # learner <- forwarder
+    prod = mp.get_context("spawn").Process(target=_frame_producer, args=(port_a, n))
+    prod.start()
+    chans = []
+    try:
+        def forward():
+            src = transport.FrameSocket.accept(srv_a, timeout=60)
+            dst = transport.FrameSocket.connect("127.0.0.1", port_b)
+            chans.extend([src, dst])
+            for _ in range(n):
+                dst.send_bytes(*src.recv_bytes())
+            dst.close()
+        th = threading.Thread(target=forward)
+        th.start()
+        learner = transport.FrameSocket.accept(srv_b, timeout=60)
+        chans.append(learner)
+        rng = np.random.default_rng(77)
+        seen = []
+
+        def sink(data, ctr_info=None):
+            i = ctr_info["seq"]
+            t = 16 + i
+            want_obs = rng.integers(0, 256, (t, 84, 84, 4), dtype=np.uint8)
+            want_act = rng.integers(0, 4, t).astype(np.int32)
+            want_logp = rng.standard_normal((t, 1)).astype(np.float32)
+            want_adv = rng.standard_normal((t, 1))
+            want_done = [bool(b) for b in rng.random(t) < 0.1]
+            want_rew = [float(x) for x in rng.choice([-1.0, 0.0, 1.0], t)]
+            assert ctr_info == {"cmd": "train", "explorer_id": 3, "seq": i}
+            assert list(data) == ["cur_state", "action", "logp", "adv", "done", "reward"]
+            assert data["cur_state"].ctypes.data % 64 == 0 and not data["cur_state"].flags.owndata
+            assert np.array_equal(data["cur_state"], want_obs) and np.array_equal(data["action"], want_act)
+            assert np.array_equal(data["logp"], want_logp) and np.array_equal(data["adv"], want_adv)
+            assert data["done"] == want_done and data["reward"] == want_rew
+            seen.append(i)
+
+        for _ in range(n):
+            learner.recv_into(sink)
+        assert seen == list(range(n))
+        th.join(20)
+        with pytest.raises(ConnectionError):
+            learner.recv_into(sink)                    # the forwarder has closed its end
+        # the (ctr_info, data) contract of CommByZmq.send / recv on a fresh pair
+        srv_c, port_c = transport.FrameSocket.listen()
+        a = transport.FrameSocket.connect("127.0.0.1", port_c)
+        b = transport.FrameSocket.accept(srv_c, timeout=10)
+        chans.extend([a, b])
+        a.send({"cmd": "predict", "n": 1}, {"x": np.arange(6, dtype=np.float64).reshape(2, 3), "note": "hi"})
+        ctr, data = b.recv()
+        assert ctr == {"cmd": "predict", "n": 1} and data["note"] == "hi" and np.array_equal(data["x"], np.arange(6.0).reshape(2, 3))
+        srv_c.close()
+    finally:
+        prod.join(30)
+        if prod.is_alive():
+            prod.terminate()
+        for ch in chans:
+            ch.close()
+        srv_a.close()
+        srv_b.close()

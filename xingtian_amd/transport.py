@@ -23,9 +23,15 @@ rollout batches to the learner (``cmd: train``) and weight dicts back to the exp
   ``hipHostRegister``: the ingest then DMA-copies the uint8 frames to HBM straight out of the slot -- wire -> HBM with
   NO host copy on the learner side.
 
-Plumbing only: no arithmetic; the only GPU-runtime call is the optional ``hipHostRegister`` of ``pin()``.  The zmq socket itself (inter-node) is out of scope; its frames would carry the
-same encoded buffer (``send_bytes`` / ``recv_bytes``, comm_by_zmq.py:87-97).
+* ``FrameSocket`` -- the inter-node hop: the two-frame multipart message of ``CommByZmq`` (control dict | payload,
+  zeus/common/ipc/comm_by_zmq.py:69-97) over a plain stream socket with length-prefixed frames (zmq is not installed
+  here; a maintainer who keeps zmq sends the same two buffers with ``send_multipart``).  ``recv_bytes`` / ``send_bytes``
+  forward a message without decoding its payload (what the broker does, broker.py:97-119); ``recv_into(sink)`` receives
+  into a reusable buffer and hands zero-copy views to ``Algorithm.prepare_data``.
+
+Plumbing only: no arithmetic; the only GPU-runtime call is the optional ``hipHostRegister`` of ``pin()``.
 """
+import socket as _socket
 import struct
 import time
 from multiprocessing import shared_memory
@@ -607,4 +613,121 @@ class WeightsRing(object):
             if self.owner:
                 self.shm.unlink()
         except (BufferError, FileNotFoundError):
+            pass
+
+
+class FrameSocket(object):
+    """Two-frame messages (control dict | payload) over a stream socket: the inter-node counterpart of ``ShmRing`` with
+    the contract of ``CommByZmq`` (zeus/common/ipc/comm_by_zmq.py:69-97: ``send`` / ``recv`` of ``(ctr_info, data)``,
+    ``send_bytes`` / ``recv_bytes`` of the two raw frames for a forwarding broker).  Wire format per message:
+    ``b"XTF1" | u32 n_frames | n_frames x u64 length | the frames``; frame 0 = msgpack of the control dict, frame 1 =
+    ``encode({}, data)`` (msgpack header + raw 64-byte-aligned arrays).  One connection = one producer and one consumer."""
+
+    MAGIC = b"XTF1"
+
+    def __init__(self, sock):
+        self.sock = sock
+        self.sock.setsockopt(_socket.IPPROTO_TCP, _socket.TCP_NODELAY, 1) if sock.family in (_socket.AF_INET, _socket.AF_INET6) else None
+        self._buf = self._aligned(1 << 20)    # reusable receive buffer of recv_into (grows to the largest message)
+
+    @staticmethod
+    def _aligned(nbytes):
+        """writable memoryview of ``nbytes`` bytes whose first byte sits on a 64-byte boundary (the payload's arrays are
+        64-byte aligned relative to the frame start: aligned views for the staging copy / a later hipHostRegister)"""
+        raw = np.empty(nbytes + _ALIGN, np.uint8)
+        off = (-raw.ctypes.data) % _ALIGN
+        return memoryview(raw[off:off + nbytes])
+
+    # ---- connection set-up (the reference binds the learner side and connects the explorers, comm_by_zmq.py:45-66)
+    @staticmethod
+    def listen(addr="127.0.0.1", port=0, backlog=8):
+        """-> (listening socket, bound port); accept connections with ``FrameSocket.accept``."""
+        srv = _socket.socket(_socket.AF_INET, _socket.SOCK_STREAM)
+        srv.setsockopt(_socket.SOL_SOCKET, _socket.SO_REUSEADDR, 1)
+        srv.bind((addr, port))
+        srv.listen(backlog)
+        return srv, srv.getsockname()[1]
+
+    @staticmethod
+    def accept(srv, timeout=None):
+        srv.settimeout(timeout)
+        conn, _ = srv.accept()
+        conn.settimeout(None)
+        return FrameSocket(conn)
+
+    @staticmethod
+    def connect(addr, port, timeout=10.0):
+        t0 = time.monotonic()
+        while True:
+            try:
+                return FrameSocket(_socket.create_connection((addr, port), timeout=timeout))
+            except (ConnectionRefusedError, OSError):
+                if time.monotonic() - t0 > timeout:
+                    raise
+                time.sleep(0.02)
+
+    # ---- frames
+    def send_bytes(self, ctr_frame, data_frame):
+        """Send the two frames as they are (a broker forwards what ``recv_bytes`` gave it without decoding the payload)."""
+        head = self.MAGIC + struct.pack("<IQQ", 2, len(ctr_frame), len(data_frame))
+        self.sock.sendall(head)
+        self.sock.sendall(ctr_frame)
+        self.sock.sendall(data_frame)
+
+    def _recv_exact(self, view):
+        got = 0
+        while got < len(view):
+            k = self.sock.recv_into(view[got:])
+            if k == 0:
+                raise ConnectionError("FrameSocket: peer closed the connection mid-message" if got else "FrameSocket: connection closed")
+            got += k
+
+    def _recv_header(self):
+        head = bytearray(4 + 4 + 16)
+        self._recv_exact(memoryview(head))
+        if bytes(head[:4]) != self.MAGIC:
+            raise ValueError("FrameSocket: not an XTF1 message")
+        n, l0, l1 = struct.unpack_from("<IQQ", head, 4)
+        if n != 2:
+            raise ValueError("FrameSocket: {} frames (expected 2)".format(n))
+        return l0, l1
+
+    def recv_bytes(self):
+        """-> (control frame, payload frame) as private ``bytes`` / ``bytearray`` objects."""
+        l0, l1 = self._recv_header()
+        f0, f1 = bytearray(l0), bytearray(l1)
+        self._recv_exact(memoryview(f0))
+        self._recv_exact(memoryview(f1))
+        return bytes(f0), f1
+
+    # ---- (ctr_info, data) contract
+    def send(self, ctr_info, data):
+        self.send_bytes(msgpack.packb(_plain(ctr_info), use_bin_type=True), encode({}, data))
+
+    def recv(self):
+        """-> (ctr_info, data) with private arrays (views into a buffer this call allocated)."""
+        f0, f1 = self.recv_bytes()
+        return msgpack.unpackb(f0, raw=False, strict_map_key=False), decode(f1)[1]
+
+    def recv_into(self, sink):
+        """Receive the next message into the reusable buffer and hand it to ``sink(data, ctr_info=...)`` as zero-copy
+        views (valid until the next ``recv_into``): the streaming ingest copies what it keeps (one host copy: socket
+        buffer -> pinned staging).  Returns the control dict."""
+        l0, l1 = self._recv_header()
+        base = _pad(l0)                        # payload frame 64-byte aligned inside the buffer: aligned array views
+        if base + l1 > len(self._buf):
+            self._buf = self._aligned(_pad(base + l1))
+        view = self._buf
+        self._recv_exact(view[:l0])
+        self._recv_exact(view[base:base + l1])
+        ctr = msgpack.unpackb(bytes(view[:l0]), raw=False, strict_map_key=False)
+        data = decode(view[base:base + l1])[1]
+        sink(data, ctr_info=ctr)
+        del data, view
+        return ctr
+
+    def close(self):
+        try:
+            self.sock.close()
+        except OSError:
             pass
