@@ -102,6 +102,10 @@ class CpuActorCritic(object):
                 raise KeyError("update {} encounter error: shape {} vs {}".format(name, val.shape, shape))
             self.spec.var_view(self.params, name)[...] = val
 
+    def publish_weights(self, ring, ctr_info=None, lag=0):
+        """hand the replica's weights to a ``transport.WeightsRing`` in the packed form the learner publishes"""
+        return ring.publish_flat_host(self.params, self.spec, ctr_info)
+
     # ------------------------------------------------------------------ forward
     def _layer(self, lay, x):
         """x: [B, H, W, C] float32 -> [B, OH, OW, N]; Conv2D (VALID / TensorFlow's asymmetric SAME) or Dense."""
