@@ -112,7 +112,9 @@ class XTModel(object):
         slot names; the reference's loader skips names it does not know, so the file stays loadable there."""
         if self.max_to_keep > -1:
             check_keep_model(os.path.dirname(file_name), self.max_to_keep)
-        arrays = OrderedDict(self.net.get_weights(copy=False) if hasattr(self.net, "publish_weights") else self.get_weights())
+        # (the learner network hands out views into its pinned snapshot: np.savez consumes them at once)
+        arrays = OrderedDict(self.get_weights() if getattr(self.net, "inference_only", False)
+                             else self.net.get_weights(copy=False))
         if self.save_optimizer and hasattr(self.net, "get_optimizer_state"):
             arrays.update(self.net.get_optimizer_state())
             arrays.update(self.extra_optimizer_state())
