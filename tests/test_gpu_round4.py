@@ -347,3 +347,35 @@ def test_publish_weights_with_a_lag_of_one_hands_out_the_previous_update_without
     finally:
         reader.close()
         ring.close()
+
+
+def test_gae_ragged_degenerate_inputs():
+    """no trajectories at all, and zero-length trajectories between real ones: nothing is written for them, the others
+    are exact (the reference never ships an empty trajectory; the ingest must not trip over one)."""
+    from xingtian_amd import lib as L
+    lib = L.load()
+    z = torch.zeros(4, dtype=torch.float32, device="cuda")
+    z64 = torch.zeros(4, dtype=torch.float64, device="cuda")
+    zu = torch.zeros(4, dtype=torch.uint8, device="cuda")
+    zi = torch.zeros(4, dtype=torch.int32, device="cuda")
+    L.check(lib.xt_gae_f64_ragged(L.ptr(z), L.ptr(z), L.ptr(z64), L.ptr(zu), L.ptr(zi), L.ptr(z64), L.ptr(z64), 0, 0.99, 0.95,
+                                  L.stream_ptr()), "xt_gae_f64_ragged")
+    rng = np.random.default_rng(3)
+    lens = [0, 5, 0, 0, 3, 0]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    n = int(offs[-1])
+    vr, boot = rng.standard_normal(n).astype(np.float32), rng.standard_normal(len(lens)).astype(np.float32)
+    rew, dn = rng.standard_normal(n), (rng.random(n) < 0.3).astype(np.uint8)
+    want_a, want_t = np.empty(n), np.empty(n)
+    for i, t in enumerate(lens):
+        if t:
+            lo, hi = offs[i], offs[i + 1]
+            a, _, tg = returns.gae(np.concatenate([vr[lo:hi], boot[i:i + 1]]).reshape(-1, 1), rew[lo:hi].copy(), dn[lo:hi].astype(bool))
+            want_a[lo:hi], want_t[lo:hi] = a[:, 0], tg[:, 0]
+    adv = torch.full((n,), np.nan, dtype=torch.float64, device="cuda")
+    tgt = torch.full((n,), np.nan, dtype=torch.float64, device="cuda")
+    keep = [_d(vr), _d(boot), _d(rew), _d(dn), _d(offs)]
+    L.check(lib.xt_gae_f64_ragged(*[L.ptr(k) for k in keep], L.ptr(adv), L.ptr(tgt), len(lens), 0.99, 0.95, L.stream_ptr()),
+            "xt_gae_f64_ragged")
+    torch.cuda.synchronize()
+    assert np.array_equal(adv.cpu().numpy(), want_a) and np.array_equal(tgt.cpu().numpy(), want_t)
