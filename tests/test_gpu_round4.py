@@ -398,3 +398,18 @@ def test_cartpole_impala_reward_curve_through_plugins():
     first, last = float(np.nanmean(curve[:5])), float(np.nanmean(curve[-20:]))
     assert first < 40.0, curve[:5]
     assert last > 45.0 and last > 2.0 * first, (first, last)
+
+
+def test_pixel_control_reward_curve_through_the_headline_network():
+    """tools/pixel_catch_e2e.py: breakout_ppo.yaml's model section (PpoCnn, 84x84x4 uint8 stacks, BATCH_SIZE 320, 4 epochs)
+    in a closed loop with a synthetic Atari-shaped game: 32 raw 128-step uint8 trajectories per update through
+    prepare_data, GAE on the GPU, the replayed 52-step graph, weights by name to a second PpoCnn that plays.  Random play
+    scores about -0.7; measured with this seed: +0.25 after 12 updates, +0.9 after 24 (deterministic)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import pixel_catch_e2e
+    curve = pixel_catch_e2e.run(updates=30, env_num=32, seed=0, verbose=False)
+    first, last = float(np.mean(curve[:3])), float(np.mean(curve[-3:]))
+    assert first < -0.4, curve[:3]
+    assert last > 0.5, curve
