@@ -413,3 +413,17 @@ def test_pixel_control_reward_curve_through_the_headline_network():
     first, last = float(np.mean(curve[:3])), float(np.mean(curve[-3:]))
     assert first < -0.4, curve[:3]
     assert last > 0.5, curve
+
+
+def test_pixel_control_reward_curve_impala_vtrace_on_gpu():
+    """tools/pixel_catch_impala_e2e.py: breakout_impala.yaml's sections (IMPALAOpt + ImpalaCnnOpt, 84x84x4 uint8, T = 128,
+    one train per message) in a closed loop with the synthetic catch game; the 32 messages of a round are up to 31 trains
+    stale (v-trace's job).  Random play about -0.7; measured with this seed: +0.38 at round 16, +0.95 at round 24."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import pixel_catch_impala_e2e
+    curve = pixel_catch_impala_e2e.run(rounds=30, seed=0, verbose=False)
+    first, last = float(np.mean(curve[:3])), float(np.mean(curve[-3:]))
+    assert first < -0.4, curve[:3]
+    assert last > 0.4, curve
