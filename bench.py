@@ -936,7 +936,7 @@ def main():
                     help="run the N>1 code path (step-wise fwd/bwd -> all-reduce -> clip+Adam) even with one rank")
     ap.add_argument("--dp-variants", default="all",
                     help="data-parallel paths measured next to the step-wise (eager) one when N > 1 or --force-dp-path: 'all' or "
-                         "a comma list of hook,hook_overlap,ingraph,ingraph_overlap ('none' = eager only).  Each is validated "
+                         "a comma list of hook,hook_overlap,ingraph,ingraph_overlap,direct ('none' = eager only).  Each is validated "
                          "(first update vs eager, replica checksum) before it may carry `value`; failures fall back and are "
                          "reported in dp_variants")
     ap.add_argument("--variant-deadline", type=float, default=120.0,
@@ -1011,8 +1011,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    DP_VARIANTS = ("eager", "hook", "hook_overlap", "ingraph", "ingraph_overlap")
-    comm = {"rccl": None}
+    DP_VARIANTS = ("eager", "hook", "hook_overlap", "ingraph", "ingraph_overlap", "direct")
+    comm = {"rccl": None, "direct": None}
+
+    def get_direct():
+        """the direct 2-phase all-reduce over peer-mapped memory (xt_allreduce_direct): IPC handles gathered over the
+        torch.distributed group; works with the ranks on N GPUs or sharing one"""
+        if comm["direct"] is None:
+            from xingtian_amd.parallel import DirectComm
+            comm["direct"] = DirectComm(rank, world, spec.n_flat, timeout_ms=20000).connect()
+        return comm["direct"]
 
     def get_rccl():
         """one raw RCCL communicator for all hook variants (created on first use; its lazy set-up runs outside any
@@ -1040,6 +1048,7 @@ def main():
           hook_overlap     the same with two buckets: last trunk layer + heads all-reduced from a side stream right after
                            the first backward launch, under the conv backward (XT_XCHG_OVERLAP)
           ingraph[_overlap] the same two, captured into the hipGraph of the whole update (no host work per step)
+          direct           xt_allreduce_direct (2-phase push over peer-mapped memory, csrc/xt_xgmi.hip) inside the update's hipGraph
         fixed_perm_seed: draw the permutations from a private generator (validation runs: same shuffles for all variants)."""
         steps = args.steps if steps is None else steps
         warmup = args.warmup if warmup is None else warmup
@@ -1060,10 +1069,13 @@ def main():
         else:
             cfg = net.make_ppo_cfg(CFG, grad_scale=1.0 / world, global_batch=0)
         rccl = None
-        if variant != "eager":
+        if variant == "direct":
+            rccl = get_direct()
+            rccl.attach(net)
+        elif variant != "eager":
             rccl = get_rccl()
             rccl.attach(net, overlap=variant.endswith("_overlap"))
-        graph = (use_graph or variant.startswith("ingraph")) and not args.no_graph
+        graph = (use_graph or variant.startswith("ingraph") or variant == "direct") and not args.no_graph
 
         # the epoch shuffles travel through a small ring of PINNED blocks (as the product's Model.train does,
         # xingtian_amd/model/ppo/ppo.py::_take_perms): an asynchronous 64 KB DMA instead of a pageable copy that bounces
@@ -1108,7 +1120,11 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        if rccl is not None:
+        if variant == "direct":
+            st = rccl.status()
+            assert st["error_bits"] == 0, "direct all-reduce: a bounded wait ran out: {}".format(st)
+            rccl.detach(net)
+        elif rccl is not None:
             rccl.status(net)
             assert not rccl.errors, "ncclAllReduce failed inside the gradient-exchange hook: {}".format(rccl.errors)
             rccl.detach(net)
@@ -1173,7 +1189,8 @@ def main():
                 dp_variants[variant] = {"valid": True, "ms_per_step": 1e3 * el / args.steps,
                                         "value": FRAME_SKIP * n_v * world * args.steps / el,
                                         "first_update_max_abs_diff_vs_eager": diff, "first_update_bitwise_equal": bitwise,
-                                        "hip_graph": bool(kv["graph"]), "rccl_ranks": get_rccl().count()}
+                                        "hip_graph": bool(kv["graph"]),
+                                        "ranks": world if variant == "direct" else get_rccl().count()}
                 if el < elapsed:
                     elapsed, keep, best_variant = el, kv, variant
                 else:
@@ -1226,7 +1243,7 @@ def main():
             el_s, n_s, keep_s = run_mode("strict")
             strict_variants = {"eager": {"valid": True, "ms_per_step": 1e3 * el_s / args.steps}}
             ref_s = None
-            for variant in ("hook", "ingraph"):
+            for variant in ("hook", "ingraph", "direct"):
                 if args.dp_variants != "all" and variant not in args.dp_variants.split(","):
                     continue
                 try:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define XT_ABI_VERSION 9
+#define XT_ABI_VERSION 10
 
 #define XT_ACT_NONE 0
 #define XT_ACT_RELU 1
@@ -437,6 +437,43 @@ typedef int (*xt_nccl_allreduce_fn)(const void* sendbuff, void* recvbuff, size_t
 int xt_net_set_rccl(xt_net* net, void* comm, xt_nccl_allreduce_fn allreduce, int32_t flags);
 int xt_net_rccl_status(const xt_net* net, int32_t* calls, int32_t* last_error);
 
+/* ---- Direct 2-phase all-reduce over peer-mapped device memory (ABI >= 10; SURVEY.md 8(b) `xt_allreduce_direct`).
+ * Replaces: the reference's only gradient exchange, the host-side float64 sum of the whole flat gradient list through a
+ * shared RawArray (xt/framework/trainer.py:86-92, message shape :139-144; dead code there) -- here between the GPUs of one
+ * node, one process per GPU, without a host hop and without RCCL's ring (xGMI is a point-to-point mesh: both phases talk
+ * to all N-1 peers at once).
+ *
+ *   xt_direct_create   allocates this rank's exchange block (flags + one inbox slot per rank + a result buffer, sized for
+ *                      max_count floats; uncached / fine-grained device memory) and writes its 64-byte hipIpcMemHandle_t to
+ *                      handle_out (may be NULL for in-process groups).  rank in [0, world), world <= 16.
+ *   xt_direct_connect  handles = world x XT_DIRECT_HANDLE_BYTES bytes, rank order (as gathered over any side channel,
+ *                      e.g. torch.distributed all_gather); maps every peer's block (hipIpcOpenMemHandle).
+ *   xt_direct_connect_local  the same for N logical ranks inside ONE process (ranks[q] = the comm object of rank q).
+ *   xt_allreduce_direct  in-place SUM of buf[0..count) over the ranks, enqueued on `stream` as three kernels (push scatter ->
+ *                      fixed-rank-order reduce + push gather -> copy back); capturable into a hipGraph (the sequence number
+ *                      lives in device memory).  Every element is summed by exactly one rank in rank order 0..N-1, so all
+ *                      replicas receive BIT-IDENTICAL results.  count <= max_count, buf 16-byte aligned.  All ranks must
+ *                      call it the same number of times with the same count.  Waits are bounded (default 2 s): a missing
+ *                      peer sets an error bit (xt_direct_status: 1 = scatter data never arrived, 2 = reduced slices never
+ *                      arrived) instead of hanging the device.
+ *   xt_direct_exchange_hook  xt_grad_exchange_fn adapter: xt_net_set_grad_exchange_ex(net, xt_direct_exchange_hook, comm, 0)
+ *                      makes xt_net_ppo_train / xt_net_impala_train exchange through this comm (one bucket per step).
+ */
+#define XT_DIRECT_HANDLE_BYTES 64
+typedef struct xt_direct_comm xt_direct_comm;
+int xt_direct_create(int32_t rank, int32_t world, int64_t max_count, void* handle_out, xt_direct_comm** out);
+int xt_direct_connect(xt_direct_comm* comm, const void* handles);
+int xt_direct_connect_local(xt_direct_comm* comm, xt_direct_comm* const* ranks);
+int xt_allreduce_direct(xt_direct_comm* comm, float* buf, int64_t count, void* stream);
+/* the all-reduce of an in-process group (xt_direct_connect_local) driven by one host thread: launches issued phase by
+ * phase over the n ranks, each on its own stream */
+int xt_allreduce_direct_group(int32_t n, xt_direct_comm* const* comms, float* const* bufs, int64_t count,
+                              void* const* streams);
+int xt_direct_exchange_hook(float* grads, int64_t count, void* user, void* stream);
+int xt_direct_set_timeout_ms(xt_direct_comm* comm, int32_t ms);
+int xt_direct_status(xt_direct_comm* comm, int32_t* calls, int32_t* seq, int32_t* error_bits, int32_t* mem_kind);
+int xt_direct_destroy(xt_direct_comm* comm);
+
 /* One minibatch of Keras `model.fit` for the non-opt IMPALA models (ABI >= 5): forward, xt_keras_impala_loss,
  * backward; the flat gradient is left in the net's gradient buffer for xt_adam_keras.  obs rows are gathered with
  * idx like the label rows (idx may be NULL: rows 0..B-1). */
@@ -453,6 +490,11 @@ typedef struct xt_impala_cfg {
   float rms_decay, rms_eps;     /* tf.train.RMSPropOptimizer(LR, decay=0.99, epsilon=0.1, centered=True),    */
                                 /* impala_cnn_opt.py:205-206: uses adam_m as the mean gradient `mg` and       */
                                 /* adam_v as the mean square `ms` (the caller initialises ms to ONES as TF)   */
+  /* strict data parallelism inside xt_net_impala_train (ABI >= 10): shard_world > 1 -> every rank is handed the SAME   */
+  /* rollout and takes whole-trajectory shard shard_rank (balanced, contiguous) of every BATCH_SIZE chunk; the sum-form */
+  /* loss makes the SUM of the shard gradients the chunk's gradient (grad_scale 1).  A rank whose shard of a chunk is   */
+  /* empty (fewer trajectories than ranks) contributes a zero gradient.  Needs a gradient exchange.                     */
+  int32_t shard_rank, shard_world;
 } xt_impala_cfg;
 
 #define XT_OPT_ADAM 0

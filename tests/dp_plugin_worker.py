@@ -1,0 +1,102 @@
+"""Rank program of tests/test_gpu_dp_plugin.py: N learner PROCESSES on the one visible GPU, each building the SAME
+Algorithm / Model pair through ``alg_builder`` exactly as xt/framework/learner.py:518-525 does; ``WORLD_SIZE > 1`` (set by
+torch.distributed.run) makes the model one data-parallel replica (xingtian_amd/parallel.py::LearnerDP).  The gradient
+exchange is gloo from the library's host hook (``DP_EXCHANGE: torch``; RCCL refuses two ranks on one device) or the direct
+all-reduce over hipIpc-mapped memory captured into the update's hipGraph (``DP_EXCHANGE: direct``).
+Rank r writes <outdir>/<case>_r<r>.npz = final parameters + the losses train() returned + its publisher answers."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+T_LEN, N_TRAJ, A_DIM, DIM = 16, 6, 4, 42
+PPO_MC = dict(LR=2.5e-4, LOSS_CLIPPING=0.1, ENTROPY_LOSS=0.003, VF_CLIP=5.0, CRITIC_LOSS_COEF=1.0, MAX_GRAD_NORM=5.0,
+              BATCH_SIZE=32, NUM_SGD_ITER=2, VF_SHARE_LAYERS=True, activation="relu", hidden_sizes=[64],
+              action_type="Categorical", SEED=3, SUMMARY=False)
+UPDATES = 2
+
+
+def ppo_model_info(extra):
+    return {"actor": {"model_name": "PpoCnn", "state_dim": [DIM, DIM, 4], "action_dim": A_DIM, "input_dtype": "uint8",
+                      "type": "learner", "model_config": dict(PPO_MC, **extra)}}
+
+
+def ppo_trajs(update):
+    """N_TRAJ trajectories of update `update` (the same on every rank)"""
+    from test_gpu_learner import synth_ppo_rollout
+    out = []
+    for i in range(N_TRAJ):
+        rng = np.random.default_rng(5000 + 100 * update + i)
+        obs, lab = synth_ppo_rollout(rng, T_LEN, (DIM, DIM, 4), A_DIM)
+        out.append({"cur_state": obs, "action": lab[0], "logp": lab[1], "adv": lab[2], "old_value": lab[3],
+                    "target_value": lab[4]})
+    return out
+
+
+IMPALA_T, IMPALA_MSGS, IMPALA_ENVS = 10, 4, 2          # 4 messages x 2 envs x T=10 -> 80 frames per train, chunks of 40
+
+
+def impala_model_info(extra):
+    return {"actor": {"model_name": "ImpalaCnnOpt", "state_dim": [DIM, DIM, 4], "input_dtype": "uint8", "type": "learner",
+                      "state_mean": 128.0, "state_std": 128.0, "action_dim": 6,
+                      "model_config": dict({"LR": 1e-3, "sample_batch_step": IMPALA_T, "grad_norm_clip": 40.0, "SEED": 4},
+                                           **extra)}}
+
+
+IMPALA_ALG = {"instance_num": 4, "agent_num": 1, "prepare_times_per_train": IMPALA_MSGS, "BATCH_SIZE": 40}
+
+
+def impala_msgs(update):
+    out = []
+    for i in range(IMPALA_MSGS):
+        rng = np.random.default_rng(7000 + 100 * update + i)
+        n = IMPALA_ENVS * IMPALA_T
+        out.append({"cur_state": rng.integers(0, 256, (n, DIM, DIM, 4)).astype(np.uint8),
+                    "logit": rng.standard_normal((n, 6)).astype(np.float32), "action": rng.integers(0, 6, n).astype(np.int32),
+                    "done": list(rng.random(n) < 0.1), "reward": list(rng.choice([-1.0, 0.0, 1.0], n))})
+    return out
+
+
+def main():
+    outdir, case = sys.argv[1], sys.argv[2]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    import torch
+    from xingtian_amd.algorithm import alg_builder
+    alg_kind, mode, feed, exchange = case.split("-")
+    extra = {"DP": mode, "DP_FEED": feed, "DP_EXCHANGE": exchange, "DP_BACKEND": "gloo", "DP_DEVICE": 0}
+    losses, answers = [], []
+    if alg_kind == "ppo":
+        alg = alg_builder("PPO", ppo_model_info(extra), {"instance_num": N_TRAJ, "agent_num": 1})
+        for u in range(UPDATES):
+            for k, tr in enumerate(ppo_trajs(u)):
+                if feed == "sharded" and k % world != rank:
+                    continue                       # "sharded": this rank is only ever handed its own trajectories
+                alg.prepare_data(tr)
+            losses.append(float(alg.train(episode_num=u)))
+            answers.append(bool(alg.checkpoint_ready(u)))
+    else:
+        alg = alg_builder("IMPALAOpt", impala_model_info(extra), dict(IMPALA_ALG))
+        for u in range(UPDATES):
+            for k, m in enumerate(impala_msgs(u)):
+                if feed == "sharded" and k % world != rank:
+                    continue
+                alg.prepare_data(m)
+            losses.append(float(alg.train(episode_num=u)))
+            answers.append(bool(alg.checkpoint_ready(u)))
+    torch.cuda.synchronize()
+    dp = alg.dp
+    assert dp is not None and dp.world == world and dp.rank == rank
+    assert alg.actor.use_graph == (exchange != "torch")
+    np.savez(os.path.join(outdir, "{}_r{}.npz".format(case, rank)), params=alg.actor.net.params.cpu().numpy(),
+             losses=np.asarray(losses), answers=np.asarray(answers), if_save=np.asarray([alg.if_save(0) is not False]))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

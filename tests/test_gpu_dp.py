@@ -129,8 +129,16 @@ def test_bench_self_spawns_two_ranks_and_reports_weak_strict_and_impala():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["ranks_in_group"] == 2
     assert d["config"]["global_batch"] == 640 and d["config"]["env_steps_per_update"] == 8192
-    assert d["strict"]["rows_per_gpu"] == 160 and d["strict"]["global_batch"] == 320 and d["strict"]["value"] > 0
-    sec = {s["workload"].split()[0]: s for s in d["secondary"]}
+    assert len(lines[0]) < 4000                      # the driver-facing line stays compact (BENCH_r04: parsed = null)
+    assert d["strict"]["rows_per_gpu"] == 160 and d["strict"]["value"] > 0
+    assert d["secondary"]["pong_impala_speedup"]["strict"] > 0 and d["secondary"]["breakout_impala"]["weak"] > 0
+    # the direct all-reduce over hipIpc-mapped memory carries a validated number even with both ranks on one GPU (the RCCL
+    # variants cannot form a communicator there and say so)
+    assert isinstance(d["dp_variants"]["direct"], float) and d["dp_variants"]["direct"] > 0, d["dp_variants"]
+    full = json.load(open(os.path.join(ROOT, d["detail"])))
+    assert full["strict"]["global_batch"] == 320 and full["strict"]["dp_variants"]["direct"]["valid"], full["strict"]
+    assert full["dp_variants"]["direct"]["first_update_bitwise_equal"] is True
+    sec = {s["workload"].split()[0]: s for s in full["secondary"]}
     assert sec["examples/pong_impala_speedup.yaml"]["strict"]["trajectories_per_rank"] == "10..10"
     assert sec["examples/breakout_impala.yaml"]["weak"]["frames_per_train_global"] == 256
     # a launcher environment with another world size is refused, never silently reduced

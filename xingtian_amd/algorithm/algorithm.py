@@ -92,9 +92,19 @@ class Algorithm(object):
         return np.argmax(self.actor.predict(state.reshape((1,) + state.shape)))
 
     # ---- weights out / checkpoints
+    @property
+    def dp(self):
+        """the data-parallel context of this learner rank (xingtian_amd/parallel.py::LearnerDP), or None"""
+        return getattr(self.actor, "_dp", None)
+
+    @property
+    def is_publisher(self):
+        """does THIS learner rank hand weights to explorers and write checkpoints?  (always True without data parallelism)"""
+        return self.dp is None or self.dp.is_publisher
+
     def checkpoint_ready(self, train_count, **kwargs):
         self._train_ready = False
-        return train_count % self.train_per_checkpoint == 0
+        return self.is_publisher and train_count % self.train_per_checkpoint == 0
 
     @property
     def train_per_checkpoint(self):
@@ -107,6 +117,8 @@ class Algorithm(object):
             self.actor.eager_snapshot = (interval == 1)
 
     def if_save(self, train_count):
+        if not self.is_publisher:
+            return False
         if self.if_save_model and train_count % self.save_interval == 0:
             return True
         return None if self.if_save_model else False

@@ -40,6 +40,8 @@ class IMPALAOpt(Algorithm):
                 np.asarray(episode_data["done"], dtype=bool), np.asarray(episode_data["reward"]))
 
     def prepare_data(self, train_data, **kwargs):
+        if self.dp is not None and not self.dp.takes(train_data):
+            return                  # DP_FEED round_robin: this message belongs to another learner rank
         fields = self._data_proc(train_data)
         if getattr(self.actor, "stream_ingest", False) and hasattr(self.actor, "ingest_message"):
             ctr = kwargs.get("ctr_info") or {}
@@ -65,6 +67,8 @@ class IMPALAOpt(Algorithm):
             loss = np.mean(losses)
         self._rollout.reset()
         self._streamed = 0
+        if self.dp is not None:
+            self.dp.new_rollout()
         return loss
 
     def predict(self, state):

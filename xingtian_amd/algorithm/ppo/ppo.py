@@ -44,8 +44,12 @@ class PPO(Algorithm):
     def _forget_rollout(self):
         self._rollout.reset()
         self._streamed = 0
+        if self.dp is not None:
+            self.dp.new_rollout()
 
     def prepare_data(self, train_data, **kwargs):
+        if self.dp is not None and not self.dp.takes(train_data):
+            return                  # DP_FEED round_robin: this trajectory belongs to another learner rank
         streaming = getattr(self.actor, "stream_ingest", False) and hasattr(self.actor, "ingest_trajectory")
         if "adv" not in train_data and not streaming:
             # raw value/reward/done without the streaming ingest (continuous actions, odd vector widths): GAE on the

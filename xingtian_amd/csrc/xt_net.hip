@@ -920,8 +920,10 @@ static int impala_train_enqueue(xt_net* net, const xt_impala_cfg* c, const void*
   for (int lo = 0; lo < n; lo += batch_size, ++chunk) {
     const int nfr = (n - lo) < batch_size ? (n - lo) : batch_size;
     const float* lr_dev = lr_steps ? lr_steps + chunk : nullptr;
-    const void* o = static_cast<const char*>(obs) + frame * lo;
     if (!net->xchg) {
+      XT_REQUIRE(c->shard_world <= 1, "xt_net_impala_train: sharded chunks need a gradient exchange (xt_net_set_rccl / "
+                                      "xt_net_set_grad_exchange)");
+      const void* o = static_cast<const char*>(obs) + frame * lo;
       if (int rc = xt::impala_step(net, c, o, nfr, bp_logits + (size_t)lo * net->A, action + lo, done + lo, reward + lo, 1,
                                    lr_dev, nullptr, loss_acc, st, /*defer_join*/ true))
         return rc;
@@ -929,9 +931,25 @@ static int impala_train_enqueue(xt_net* net, const xt_impala_cfg* c, const void*
     }
     // data parallel: local gradient of this rank's trajectories -> SUM over the replicas (the loss is a sum:
     // grad_scale = 1) -> norm of the exchanged gradient, clip, optimiser
-    if (int rc = xt::impala_step(net, c, o, nfr, bp_logits + (size_t)lo * net->A, action + lo, done + lo, reward + lo, 0,
-                                 lr_dev, nullptr, loss_acc, st))
-      return rc;
+    int lo_s = lo, nfr_s = nfr;
+    if (c->shard_world > 1) {
+      // strict sharding (ABI >= 10): whole-trajectory shard of this chunk (xingtian_amd/parallel.py::shard_range)
+      XT_REQUIRE(c->shard_rank >= 0 && c->shard_rank < c->shard_world, "xt_net_impala_train: shard_rank %d outside [0,%d)",
+                 c->shard_rank, c->shard_world);
+      const int T = c->sample_batch_step, ntraj = nfr / T;
+      const int base = ntraj / c->shard_world, rem = ntraj % c->shard_world;
+      const int b0 = c->shard_rank * base + (c->shard_rank < rem ? c->shard_rank : rem);
+      lo_s = lo + b0 * T;
+      nfr_s = (base + (c->shard_rank < rem ? 1 : 0)) * T;
+    }
+    if (nfr_s > 0) {
+      const void* o = static_cast<const char*>(obs) + frame * lo_s;
+      if (int rc = xt::impala_step(net, c, o, nfr_s, bp_logits + (size_t)lo_s * net->A, action + lo_s, done + lo_s,
+                                   reward + lo_s, 0, lr_dev, nullptr, loss_acc, st))
+        return rc;
+    } else {
+      XT_CHECK_HIP(hipMemsetAsync(net->grads, 0, sizeof(float) * (size_t)net->P, st));   // empty shard: zero contribution
+    }
     XT_REQUIRE(net->xchg(net->grads, net->P, net->xchg_user, st) == 0, "xt_net_impala_train: gradient exchange hook failed");
     // norm of the EXCHANGED gradient (+ the step-size bookkeeping; lr_schedule's value is read on the device), then the
     // configured optimiser: Adam, or centred RMSProp which derives the clip factor from the same partials itself
@@ -971,8 +989,8 @@ int xt_net_impala_train(xt_net* net, const xt_impala_cfg* c, const void* obs, in
   if (!use_graph)
     return impala_train_enqueue(net, c, obs, n, batch_size, bp_logits, action, done, reward, lr_steps, loss_acc, st);
   char key[512];
-  snprintf(key, sizeof(key), "I|%p|%p|%p|%d|%d|%p|%p|%p|%p|%p|%p|%g|%g|%g|%g|%g|%g|%d|%g|%d|%g|%g",
-           (void*)net->xchg, net->xchg_user, obs, n, batch_size, (const void*)bp_logits, (const void*)action,
+  snprintf(key, sizeof(key), "I%d.%d|%p|%p|%p|%d|%d|%p|%p|%p|%p|%p|%p|%g|%g|%g|%g|%g|%g|%d|%g|%d|%g|%g",
+           c->shard_rank, c->shard_world, (void*)net->xchg, net->xchg_user, obs, n, batch_size, (const void*)bp_logits, (const void*)action,
            (const void*)done, (const void*)reward, (const void*)lr_steps, (void*)loss_acc, c->lr, c->beta1, c->beta2,
            c->eps, c->grad_norm_clip, c->gamma, c->sample_batch_step, c->grad_scale, c->opt_type, c->rms_decay, c->rms_eps);
   return xt::graph_run(net, key, st, [&](hipStream_t cs) {

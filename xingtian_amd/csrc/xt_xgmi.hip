@@ -1,0 +1,360 @@
+// Direct 2-phase all-reduce of the flat fp32 gradient over peer-mapped memory (SURVEY.md section 8(b) `xt_allreduce_direct`,
+// section 8(e): "RCCL ncclAllReduce first; then the 2-phase direct xGMI all-reduce because ring is per-link bound").
+//
+// The reference's only multi-device exchange is the dead host-side trainer (xt/framework/trainer.py:86-92,139-144): every
+// process writes its whole flat parameter-gradient list into a shared RawArray, the sum is taken in float64 on the host.
+// Here: one process per GPU, every rank owns ONE device allocation ("exchange block": flags + inbox + result) that all
+// peers map through hipIpcGetMemHandle / hipIpcOpenMemHandle; an all-reduce is three small kernels on the caller's stream
+//
+//   scatter   every rank PUSHES slice q of its gradient into peer q's inbox[rank]  (posted remote writes, no remote reads),
+//             then raises ready_q[rank] = seq
+//   reduce    rank r waits for ready_r[*] == seq, sums its slice over inbox[0..N-1] in FIXED rank order (every element of
+//             the result is computed by exactly one rank -> all replicas receive bit-identical values) and PUSHES the
+//             reduced slice into every peer's result buffer, then raises done_p[r] = seq on every peer
+//   gather    rank r waits for done_r[*] == seq and copies result -> gradient buffer
+//
+// xGMI is a point-to-point mesh (7 links per GPU): both phases talk to all N-1 peers at once, 2 (N-1)/N S bytes leave every
+// GPU spread over N-1 links, against a ring's 2 (N-1)/N S bytes through ONE link pair in 2 (N-1) dependent hops.
+// The sequence number lives in device memory and is advanced by the gather kernel, so the three launches can be captured
+// into the hipGraph of a whole update (xt_net_ppo_train) and replayed.
+//
+// Memory model: the exchange block is allocated uncached / fine-grained (hipExtMallocWithFlags), data is published with a
+// system-scope release (fence + atomic store of the flag) and consumed behind a system-scope acquire -- coarse-grained
+// memory would only be coherent between devices at kernel boundaries.  Every wait is BOUNDED (timeout -> error word, the
+// kernels run to completion with whatever arrived): a lost peer cannot hang the GPU.
+//
+// Verified on one device only (N processes or N in-process ranks sharing the GPU, tests/test_gpu_direct.py): no multi-GPU
+// box was available to the builders; the kernels follow the HIP memory model for peer access, timing over xGMI is open.
+#include <string.h>
+
+#include "xt_common.h"
+
+namespace xt {
+
+constexpr int kMaxWorld = 16;
+constexpr int kFlagWords = 1024;            // uint32 words at the head of the exchange block: ready[64], done[64]
+constexpr int kReadyOff = 0, kDoneOff = 64;
+constexpr int kScatterVecs = 1024;          // float4 per block in scatter / gather (16 KB)
+constexpr int kReduceVecs = 512;            // float4 per block in reduce
+// device-local control words (one small hipMalloc, NOT shared): [0] seq of the last completed all-reduce, [1] error bits,
+// [2] reduce ticket, [3] gather ticket, [8 + q] scatter tickets per peer
+constexpr int kCtlSeq = 0, kCtlErr = 1, kCtlRed = 2, kCtlGat = 3, kCtlScat = 8, kCtlWords = 8 + kMaxWorld;
+
+struct DirectPeers {
+  float* inbox_me[kMaxWorld];     // peer q's inbox slot for THIS rank
+  float* result[kMaxWorld];       // peer q's result buffer
+  uint32_t* flags[kMaxWorld];     // peer q's flag words
+};
+
+__device__ __forceinline__ void slice_of(int64_t nvec, int r, int world, int64_t& b, int64_t& e) {
+  const int64_t base = nvec / world, rem = nvec % world;
+  b = r * base + (r < rem ? r : rem);
+  e = b + base + (r < rem ? 1 : 0);
+}
+
+__device__ __forceinline__ float4 load_vec_tail(const float* p, int64_t v, int64_t count) {
+  // vec v of a buffer of `count` floats (the last vec may be partial: zero filled)
+  const int64_t i = v * 4;
+  if (i + 4 <= count) return *reinterpret_cast<const float4*>(p + i);
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < count) r.x = p[i];
+  if (i + 1 < count) r.y = p[i + 1];
+  if (i + 2 < count) r.z = p[i + 2];
+  return r;
+}
+
+// bounded wait until flags[off + p] == seq for every p < world (thread 0 of the block polls, the block follows)
+__device__ __forceinline__ void wait_all(const uint32_t* flags, int off, int world, uint32_t seq, uint32_t* ctl,
+                                         unsigned long long timeout_ticks, uint32_t errbit) {
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = wall_clock64();
+    for (int p = 0; p < world; ++p) {
+      int spins = 0;
+      while (__hip_atomic_load(flags + off + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+        __builtin_amdgcn_s_sleep(4);
+        if ((++spins & 63) == 0 && wall_clock64() - t0 > timeout_ticks) {
+          atomicOr(ctl + kCtlErr, errbit);
+          p = world;
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+
+// phase 1: push slice q of the local gradient into peer q's inbox[rank]; grid (blocks per slice, world)
+__global__ void __launch_bounds__(256) xgmi_scatter_kernel(const float* __restrict__ grads, int64_t count, int rank, int world,
+                                                           DirectPeers peers, uint32_t* ctl) {
+  const int q = blockIdx.y;
+  const int64_t nvec = (count + 3) / 4;
+  int64_t b, e;
+  slice_of(nvec, q, world, b, e);
+  const int64_t lo = b + (int64_t)blockIdx.x * kScatterVecs;
+  const int64_t hi = lo + kScatterVecs < e ? lo + kScatterVecs : e;
+  float4* dst = reinterpret_cast<float4*>(peers.inbox_me[q]);
+  for (int64_t v = lo + threadIdx.x; v < hi; v += 256) dst[v - b] = load_vec_tail(grads, v, count);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t seq = ctl[kCtlSeq] + 1;
+    if (atomicAdd(ctl + kCtlScat + q, 1u) == gridDim.x - 1) {     // last block of this peer's slice
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
+      __hip_atomic_store(peers.flags[q] + kReadyOff + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// phase 2: sum my slice over the inbox slots in rank order, push the result to every peer; grid = blocks over my slice
+__global__ void __launch_bounds__(256) xgmi_reduce_kernel(const float* __restrict__ inbox, int64_t slice_cap, int64_t count,
+                                                          int rank, int world, DirectPeers peers, const uint32_t* my_flags,
+                                                          uint32_t* ctl, unsigned long long timeout_ticks) {
+  const uint32_t seq = ctl[kCtlSeq] + 1;
+  wait_all(my_flags, kReadyOff, world, seq, ctl, timeout_ticks, 1u);
+  const int64_t nvec = (count + 3) / 4;
+  int64_t b, e;
+  slice_of(nvec, rank, world, b, e);
+  const int64_t lo = b + (int64_t)blockIdx.x * kReduceVecs;
+  const int64_t hi = lo + kReduceVecs < e ? lo + kReduceVecs : e;
+  for (int64_t v = lo + threadIdx.x; v < hi; v += 256) {
+    float4 acc = *reinterpret_cast<const float4*>(inbox + (v - b) * 4);
+    for (int p = 1; p < world; ++p) {           // FIXED order 0, 1, ..., N-1: the sum is a function of the data only
+      const float4 x = *reinterpret_cast<const float4*>(inbox + p * slice_cap + (v - b) * 4);
+      acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+    }
+    for (int p = 0; p < world; ++p) reinterpret_cast<float4*>(peers.result[p])[v] = acc;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(ctl + kCtlRed, 1u) == gridDim.x - 1) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
+    for (int p = 0; p < world; ++p)
+      __hip_atomic_store(peers.flags[p] + kDoneOff + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// phase 3: wait for every rank's reduced slice, copy result -> gradient buffer; the last block advances the sequence
+__global__ void __launch_bounds__(256) xgmi_gather_kernel(float* __restrict__ grads, const float* __restrict__ result,
+                                                          int64_t count, int world, const uint32_t* my_flags, uint32_t* ctl,
+                                                          unsigned long long timeout_ticks) {
+  const uint32_t seq = ctl[kCtlSeq] + 1;
+  wait_all(my_flags, kDoneOff, world, seq, ctl, timeout_ticks, 2u);
+  const int64_t nvec = (count + 3) / 4;
+  const int64_t lo = (int64_t)blockIdx.x * kScatterVecs;
+  const int64_t hi = lo + kScatterVecs < nvec ? lo + kScatterVecs : nvec;
+  for (int64_t v = lo + threadIdx.x; v < hi; v += 256) {
+    const float4 x = reinterpret_cast<const float4*>(result)[v];
+    const int64_t i = v * 4;
+    if (i + 4 <= count) {
+      *reinterpret_cast<float4*>(grads + i) = x;
+    } else {
+      if (i < count) grads[i] = x.x;
+      if (i + 1 < count) grads[i + 1] = x.y;
+      if (i + 2 < count) grads[i + 2] = x.z;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(ctl + kCtlGat, 1u) == gridDim.x - 1) {
+      ctl[kCtlRed] = 0;
+      ctl[kCtlGat] = 0;
+      for (int q = 0; q < world; ++q) ctl[kCtlScat + q] = 0;
+      __threadfence();
+      ctl[kCtlSeq] = seq;
+    }
+  }
+}
+
+}  // namespace xt
+
+struct xt_direct_comm {
+  int rank = 0, world = 1;
+  int64_t max_count = 0, slice_cap = 0;         // floats
+  size_t block_bytes = 0, inbox_off = 0, result_off = 0;
+  char* block = nullptr;                        // own exchange block (device memory, shared with the peers)
+  int mem_kind = 0;                             // 0 uncached, 1 fine-grained, 2 plain hipMalloc
+  char* peer_block[xt::kMaxWorld] = {};
+  bool peer_ipc[xt::kMaxWorld] = {};            // opened with hipIpcOpenMemHandle (to be closed)
+  bool connected = false;
+  uint32_t* ctl = nullptr;                      // device-local control words
+  unsigned long long timeout_ticks = 200000000ull;   // 2 s of the 100 MHz wall clock
+  int calls = 0;
+  xt::DirectPeers peers = {};
+};
+
+extern "C" {
+
+int xt_direct_create(int32_t rank, int32_t world, int64_t max_count, void* handle_out, xt_direct_comm** out) {
+  XT_REQUIRE(out, "xt_direct_create: null out");
+  XT_REQUIRE(world >= 1 && world <= xt::kMaxWorld && rank >= 0 && rank < world, "xt_direct_create: rank %d / world %d (max %d)",
+             rank, world, xt::kMaxWorld);
+  XT_REQUIRE(max_count > 0 && max_count < (1ll << 31), "xt_direct_create: max_count %lld", (long long)max_count);
+  xt_direct_comm* c = new xt_direct_comm();
+  c->rank = rank; c->world = world; c->max_count = max_count;
+  const int64_t nvec = (max_count + 3) / 4;
+  c->slice_cap = ((nvec + world - 1) / world) * 4;
+  c->inbox_off = (size_t)xt::kFlagWords * 4;
+  c->result_off = c->inbox_off + sizeof(float) * (size_t)c->slice_cap * world;
+  c->block_bytes = c->result_off + sizeof(float) * (size_t)nvec * 4;
+  hipError_t e = hipExtMallocWithFlags((void**)&c->block, c->block_bytes, hipDeviceMallocUncached);
+  c->mem_kind = 0;
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    e = hipExtMallocWithFlags((void**)&c->block, c->block_bytes, hipDeviceMallocFinegrained);
+    c->mem_kind = 1;
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    e = hipMalloc((void**)&c->block, c->block_bytes);
+    c->mem_kind = 2;
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    xt::set_error("xt_direct_create: cannot allocate the %zu-byte exchange block: %s", c->block_bytes, hipGetErrorString(e));
+    delete c;
+    return 1;
+  }
+  XT_CHECK_HIP(hipMemset(c->block, 0, c->block_bytes));
+  XT_CHECK_HIP(hipMalloc((void**)&c->ctl, sizeof(uint32_t) * xt::kCtlWords));
+  XT_CHECK_HIP(hipMemset(c->ctl, 0, sizeof(uint32_t) * xt::kCtlWords));
+  XT_CHECK_HIP(hipDeviceSynchronize());
+  if (handle_out) {
+    hipIpcMemHandle_t h;
+    static_assert(sizeof(hipIpcMemHandle_t) == XT_DIRECT_HANDLE_BYTES, "hipIpcMemHandle_t size");
+    e = hipIpcGetMemHandle(&h, c->block);
+    if (e != hipSuccess && world > 1) {
+      (void)hipGetLastError();
+      xt::set_error("xt_direct_create: hipIpcGetMemHandle failed: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 exported?)", hipGetErrorString(e));
+      (void)hipFree(c->block); (void)hipFree(c->ctl); delete c;
+      return 1;
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); memset(&h, 0, sizeof(h)); }
+    memcpy(handle_out, &h, sizeof(h));
+  }
+  *out = c;
+  return 0;
+}
+
+static int direct_finish_connect(xt_direct_comm* c) {
+  for (int q = 0; q < c->world; ++q) {
+    char* blk = c->peer_block[q];
+    c->peers.flags[q] = reinterpret_cast<uint32_t*>(blk);
+    c->peers.inbox_me[q] = reinterpret_cast<float*>(blk + c->inbox_off) + (size_t)c->rank * c->slice_cap;
+    c->peers.result[q] = reinterpret_cast<float*>(blk + c->result_off);
+  }
+  c->connected = true;
+  return 0;
+}
+
+int xt_direct_connect(xt_direct_comm* c, const void* handles) {
+  XT_REQUIRE(c && (handles || c->world == 1), "xt_direct_connect: null argument");
+  XT_REQUIRE(!c->connected, "xt_direct_connect: already connected");
+  for (int q = 0; q < c->world; ++q) {
+    if (q == c->rank) { c->peer_block[q] = c->block; continue; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, static_cast<const char*>(handles) + (size_t)q * XT_DIRECT_HANDLE_BYTES, sizeof(h));
+    void* p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      xt::set_error("xt_direct_connect: hipIpcOpenMemHandle of rank %d's exchange block failed: %s", q, hipGetErrorString(e));
+      return 1;
+    }
+    c->peer_block[q] = static_cast<char*>(p);
+    c->peer_ipc[q] = true;
+  }
+  return direct_finish_connect(c);
+}
+
+int xt_direct_connect_local(xt_direct_comm* c, xt_direct_comm* const* ranks) {
+  XT_REQUIRE(c && ranks, "xt_direct_connect_local: null argument");
+  XT_REQUIRE(!c->connected, "xt_direct_connect_local: already connected");
+  for (int q = 0; q < c->world; ++q) {
+    XT_REQUIRE(ranks[q] && ranks[q]->rank == q && ranks[q]->world == c->world && ranks[q]->max_count == c->max_count,
+               "xt_direct_connect_local: entry %d is not rank %d of the same group", q, q);
+    c->peer_block[q] = ranks[q]->block;
+  }
+  return direct_finish_connect(c);
+}
+
+// phase 0 = scatter, 1 = reduce, 2 = gather, -1 = all three
+static int direct_enqueue(xt_direct_comm* c, float* buf, int64_t count, int phase, hipStream_t st) {
+  XT_REQUIRE(c && buf, "xt_allreduce_direct: null argument");
+  XT_REQUIRE(count > 0 && count <= c->max_count, "xt_allreduce_direct: count %lld outside (0, %lld]", (long long)count,
+             (long long)c->max_count);
+  XT_REQUIRE((reinterpret_cast<uintptr_t>(buf) & 15) == 0, "xt_allreduce_direct: the buffer must be 16-byte aligned");
+  if (phase <= 0) c->calls++;
+  if (c->world == 1) return 0;
+  XT_REQUIRE(c->connected, "xt_allreduce_direct: xt_direct_connect has not been called");
+  const int64_t nvec = (count + 3) / 4;
+  const int64_t slice_max = (nvec + c->world - 1) / c->world;
+  const unsigned sb = (unsigned)((slice_max + xt::kScatterVecs - 1) / xt::kScatterVecs);
+  const unsigned rb = (unsigned)((slice_max + xt::kReduceVecs - 1) / xt::kReduceVecs);
+  const unsigned gb = (unsigned)((nvec + xt::kScatterVecs - 1) / xt::kScatterVecs);
+  const uint32_t* my_flags = reinterpret_cast<const uint32_t*>(c->block);
+  const float* inbox = reinterpret_cast<const float*>(c->block + c->inbox_off);
+  const float* result = reinterpret_cast<const float*>(c->block + c->result_off);
+  if (phase < 0 || phase == 0)
+    hipLaunchKernelGGL(xt::xgmi_scatter_kernel, dim3(sb ? sb : 1, c->world), dim3(256), 0, st, buf, count, c->rank, c->world,
+                       c->peers, c->ctl);
+  if (phase < 0 || phase == 1)
+    hipLaunchKernelGGL(xt::xgmi_reduce_kernel, dim3(rb ? rb : 1), dim3(256), 0, st, inbox, c->slice_cap, count, c->rank,
+                       c->world, c->peers, my_flags, c->ctl, c->timeout_ticks);
+  if (phase < 0 || phase == 2)
+    hipLaunchKernelGGL(xt::xgmi_gather_kernel, dim3(gb ? gb : 1), dim3(256), 0, st, buf, result, count, c->world, my_flags,
+                       c->ctl, c->timeout_ticks);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
+int xt_allreduce_direct(xt_direct_comm* c, float* buf, int64_t count, void* stream) {
+  return direct_enqueue(c, buf, count, -1, static_cast<hipStream_t>(stream));
+}
+
+// N logical ranks driven by ONE host thread (in-process groups): the launches are issued phase by phase, so that no kernel
+// ever waits for one that sits BEHIND it in a hardware queue (streams of one process share a handful of queues)
+int xt_allreduce_direct_group(int32_t n, xt_direct_comm* const* comms, float* const* bufs, int64_t count, void* const* streams) {
+  XT_REQUIRE(n >= 1 && comms && bufs && streams, "xt_allreduce_direct_group: null argument");
+  for (int phase = 0; phase < 3; ++phase)
+    for (int r = 0; r < n; ++r)
+      if (int rc = direct_enqueue(comms[r], bufs[r], count, phase, static_cast<hipStream_t>(streams[r]))) return rc;
+  return 0;
+}
+
+int xt_direct_exchange_hook(float* grads, int64_t count, void* user, void* stream) {
+  return xt_allreduce_direct(static_cast<xt_direct_comm*>(user), grads, count, stream);
+}
+
+int xt_direct_set_timeout_ms(xt_direct_comm* c, int32_t ms) {
+  XT_REQUIRE(c && ms > 0, "xt_direct_set_timeout_ms: bad argument");
+  c->timeout_ticks = (unsigned long long)ms * 100000ull;
+  return 0;
+}
+
+int xt_direct_status(xt_direct_comm* c, int32_t* calls, int32_t* seq, int32_t* error_bits, int32_t* mem_kind) {
+  XT_REQUIRE(c, "xt_direct_status: null comm");
+  uint32_t w[2] = {0, 0};
+  XT_CHECK_HIP(hipDeviceSynchronize());
+  XT_CHECK_HIP(hipMemcpy(w, c->ctl, sizeof(w), hipMemcpyDeviceToHost));     // (synchronises with the null stream only)
+  if (calls) *calls = c->calls;
+  if (seq) *seq = (int32_t)w[0];
+  if (error_bits) *error_bits = (int32_t)w[1];
+  if (mem_kind) *mem_kind = c->mem_kind;
+  return 0;
+}
+
+int xt_direct_destroy(xt_direct_comm* c) {
+  if (!c) return 0;
+  (void)hipDeviceSynchronize();
+  for (int q = 0; q < c->world; ++q)
+    if (c->peer_ipc[q] && c->peer_block[q]) (void)hipIpcCloseMemHandle(c->peer_block[q]);
+  if (c->block) (void)hipFree(c->block);
+  if (c->ctl) (void)hipFree(c->ctl);
+  (void)hipGetLastError();
+  delete c;
+  return 0;
+}
+
+}  // extern "C"

@@ -30,7 +30,7 @@ class LayerDesc(Structure):
     _fields_ = [("g", ConvGeom), ("param_off", c_int64), ("trunk", c_int32)]
 
 
-ABI_VERSION = 9          # XT_ABI_VERSION of include/xt_mi355x.h
+ABI_VERSION = 10         # XT_ABI_VERSION of include/xt_mi355x.h
 ACTION_TYPE = {"Categorical": 0, "DiagGaussian": 1}
 
 
@@ -52,7 +52,8 @@ class PpoCfg(Structure):
 class ImpalaCfg(Structure):
     _fields_ = [("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
                 ("grad_norm_clip", c_float), ("gamma", c_float), ("sample_batch_step", c_int32),
-                ("grad_scale", c_float), ("opt_type", c_int32), ("rms_decay", c_float), ("rms_eps", c_float)]
+                ("grad_scale", c_float), ("opt_type", c_int32), ("rms_decay", c_float), ("rms_eps", c_float),
+                ("shard_rank", c_int32), ("shard_world", c_int32)]
 
 
 class Tuning(Structure):
@@ -66,6 +67,7 @@ class Tuning(Structure):
 
 OPT_TYPE = {"adam": 0, "rmsprop": 1}
 XCHG_OVERLAP = 1         # XT_XCHG_OVERLAP
+DIRECT_HANDLE_BYTES = 64  # XT_DIRECT_HANDLE_BYTES
 _P = c_void_p
 # name -> (restype, argtypes); every symbol include/xt_mi355x.h declares
 SIGNATURES = {
@@ -117,6 +119,15 @@ SIGNATURES = {
     "xt_net_apply": (c_int32, [_P, c_float, c_float, c_float, c_float, c_float, c_float, _P]),
     "xt_net_layer_offsets": (c_int32, [_P, c_int32, POINTER(c_int64)]),
     "xt_net_time_layer": (c_int32, [_P, c_int32, c_int32, _P, _P, c_int32, c_int32, POINTER(c_float), _P]),
+    "xt_direct_create": (c_int32, [c_int32, c_int32, c_int64, _P, POINTER(c_void_p)]),
+    "xt_direct_connect": (c_int32, [_P, _P]),
+    "xt_direct_connect_local": (c_int32, [_P, POINTER(c_void_p)]),
+    "xt_allreduce_direct": (c_int32, [_P, _P, c_int64, _P]),
+    "xt_allreduce_direct_group": (c_int32, [c_int32, POINTER(c_void_p), POINTER(c_void_p), c_int64, POINTER(c_void_p)]),
+    "xt_direct_exchange_hook": (c_int32, [_P, c_int64, _P, _P]),
+    "xt_direct_set_timeout_ms": (c_int32, [_P, c_int32]),
+    "xt_direct_status": (c_int32, [_P, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
+    "xt_direct_destroy": (c_int32, [_P]),
 }
 
 _lib = None

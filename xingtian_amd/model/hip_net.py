@@ -350,8 +350,10 @@ class HipActorCritic(object):
                 "xt_net_ppo_train")
         return self.loss_acc
 
-    def make_impala_cfg(self, lr, grad_norm_clip, sample_batch_step, gamma=0.99, grad_scale=1.0, opt_type="adam"):
+    def make_impala_cfg(self, lr, grad_norm_clip, sample_batch_step, gamma=0.99, grad_scale=1.0, opt_type="adam",
+                        shard_rank=0, shard_world=0):
         c = L.ImpalaCfg()
+        c.shard_rank, c.shard_world = int(shard_rank), int(shard_world)
         c.lr, c.beta1, c.beta2, c.eps = lr, 0.9, 0.999, 1e-8
         c.grad_norm_clip, c.gamma, c.sample_batch_step, c.grad_scale = grad_norm_clip, gamma, int(sample_batch_step), grad_scale
         c.opt_type = L.OPT_TYPE[opt_type]

@@ -61,6 +61,7 @@ class ImpalaCnnOpt(XTModel):
         self._loss_pin = self._loss_ev = None
         self._loss_slot = 0
         self._ingest = None
+        self._dp = None
         self._lr_host = self._lr_dev = None
         super().__init__(model_info)
 
@@ -76,6 +77,20 @@ class ImpalaCnnOpt(XTModel):
         self.net.set_optimizer(self.opt_type)
         self._cfg = self.net.make_impala_cfg(self.lr, self.grad_norm_clip, self.sample_batch_steps, GAMMA,
                                              opt_type=self.opt_type)
+        # one rank of a data-parallel learner (xingtian_amd/parallel.py::LearnerDP): the sum-form loss makes the SUM of the
+        # ranks' gradients the chunk's gradient, no scaling.  strict + replicated feed: whole-trajectory shards of every
+        # chunk, taken inside xt_net_impala_train; sharded feeds: every rank trains BATCH_SIZE / N frames of its own
+        # messages per chunk (strict) or full BATCH_SIZE chunks (weak: global chunk N x BATCH_SIZE, flagged)
+        from xingtian_amd.parallel import LearnerDP
+        self._dp = LearnerDP.from_config(model_info.get("model_config"))
+        if self._dp is not None:
+            self._dp.attach(self.net)
+            if not self._dp.graph_capable:
+                self.use_graph = False
+            if self._dp.mode == "strict" and self._dp.feed == "replicated":
+                self._cfg = self.net.make_impala_cfg(self.lr, self.grad_norm_clip, self.sample_batch_steps, GAMMA,
+                                                     opt_type=self.opt_type, shard_rank=self._dp.rank,
+                                                     shard_world=self._dp.world)
         return True
 
     # ---- resident rollout: every train goes pinned staging -> async H2D -> ONE C call (hipGraph replay) -------
@@ -123,6 +138,15 @@ class ImpalaCnnOpt(XTModel):
         sequential BATCH_SIZE chunks in one C call -> mean of the chunk losses."""
         self._require_learner()
         n, d = self._ingest.finish()
+        dp = self._dp
+        if dp is not None:
+            dp.check_equal(n, "IMPALAOpt.train")
+            if dp.mode == "strict" and dp.feed != "replicated":
+                # the reference's chunk of BATCH_SIZE frames = N local chunks of BATCH_SIZE / N frames (whole trajectories)
+                if batch_size % (dp.world * self.sample_batch_steps):
+                    raise ValueError("strict data parallelism over sharded messages needs BATCH_SIZE ({}) divisible by "
+                                     "ranks x sample_batch_step ({} x {})".format(batch_size, dp.world, self.sample_batch_steps))
+                batch_size //= dp.world
         n_chunks = (n + batch_size - 1) // batch_size
         lr_steps = self._lr_steps(n_chunks)
         acc = self.net.impala_train(self._cfg, d["obs"][:n], batch_size, d["logit"][:n], d["action"][:n], d["done"][:n],
@@ -132,8 +156,11 @@ class ImpalaCnnOpt(XTModel):
         if self.eager_snapshot:
             self.net.snapshot_weights_async()   # the D2H of the new weights runs under the loss read-back
         if self.async_loss:
-            return self._loss_of_previous_train(acc)
+            return self._loss_of_previous_train(acc)       # (data parallel: this rank's share of the sum-form loss)
         a = acc.cpu().numpy()
+        if dp is not None:
+            dp.status()
+            return np.float32(dp.global_loss(a[0], n_chunks))     # SUM of the shard sums / chunks
         return np.float32(a[0] / max(a[1], 1.0))
 
     def _loss_of_previous_train(self, acc):

@@ -37,13 +37,23 @@ def wants_cpu_replica(model_info):
     return not torch.cuda.is_available()
 
 
+def learner_device(model_info):
+    """cuda:0, or -- when the process is one rank of a data-parallel learner (``WORLD_SIZE > 1`` and ``model_config.DP`` not
+    "off", xingtian_amd/parallel.py::LearnerDP) -- the rank's own GPU (``model_config.DP_DEVICE`` or ``LOCAL_RANK``)."""
+    cfg = model_info.get("model_config") or {}
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and cfg.get("DP", "auto") != "off":
+        from xingtian_amd.parallel import LearnerDP
+        return "cuda:{}".format(LearnerDP.device_index(cfg))
+    return "cuda:0"
+
+
 def build_net(model_info, spec, max_batch, seed, init="glorot"):
     """The network object behind a model: HIP learner network, or the inference-only CPU replica (see above)."""
     if wants_cpu_replica(model_info):
         from xingtian_amd.model.cpu_net import CpuActorCritic
         return CpuActorCritic(spec, seed=seed, init=init)
     from xingtian_amd.model.hip_net import HipActorCritic
-    return HipActorCritic(spec, max_batch=max_batch, seed=seed, init=init)
+    return HipActorCritic(spec, max_batch=max_batch, device=learner_device(model_info), seed=seed, init=init)
 
 
 def as_numpy(x):

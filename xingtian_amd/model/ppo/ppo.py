@@ -54,6 +54,7 @@ class PPO(XTModel):
         self.gauss = self.action_type == "DiagGaussian"
         self._resident = None
         self._ingest = None
+        self._dp = None
         self._perm_dense = None
         self._perm_pin = None           # two pinned [NUM_SGD_ITER, n] blocks: this update's shuffles / the next one's
         self._perm_last, self._perm_next = 0, None    # block of the last H2D; block holding shuffles drawn ahead
@@ -91,10 +92,24 @@ class PPO(XTModel):
         if self.net.inference_only:
             self.stream_ingest = False
             return self.net
-        self._cfg = self.net.make_ppo_cfg(dict(
-            LR=self._lr, LOSS_CLIPPING=self.clip_ratio, ENTROPY_LOSS=self.ent_coef, VF_CLIP=self.vf_clip,
-            CRITIC_LOSS_COEF=self.critic_loss_coef, MAX_GRAD_NORM=self._max_grad_norm,
-            BATCH_SIZE=self._batch_size, NUM_SGD_ITER=self.num_sgd_iter))
+        base = dict(LR=self._lr, LOSS_CLIPPING=self.clip_ratio, ENTROPY_LOSS=self.ent_coef, VF_CLIP=self.vf_clip,
+                    CRITIC_LOSS_COEF=self.critic_loss_coef, MAX_GRAD_NORM=self._max_grad_norm,
+                    BATCH_SIZE=self._batch_size, NUM_SGD_ITER=self.num_sgd_iter)
+        self._cfg = self.net.make_ppo_cfg(base)
+        self._perm_rng = self._rng
+        # one rank of a data-parallel learner (torchrun: WORLD_SIZE > 1, or model_config.DP): the replica starts from rank
+        # 0's weights, the gradient exchange is installed on the network, the minibatch split follows DP / DP_FEED
+        from xingtian_amd.parallel import LearnerDP
+        self._dp = LearnerDP.from_config(model_info.get("model_config"))
+        if self._dp is not None:
+            self._dp.attach(self.net)
+            self._cfg, _ = self._dp.ppo_cfg(self.net, base)
+            if not self._dp.graph_capable:
+                self.use_graph = False
+            if self._dp.mode == "strict" and self._dp.feed == "replicated":
+                self._perm_rng = np.random.default_rng(self._dp.shared_seed(self.seed))      # the SAME shuffles everywhere
+            else:
+                self._perm_rng = np.random.default_rng(None if self.seed is None else [int(self.seed), self._dp.rank])
         return self.net
 
     def predict(self, state):
@@ -190,6 +205,8 @@ class PPO(XTModel):
         """``train`` on the rollout that was streamed in through ``ingest_trajectory`` (no concat, no upload)."""
         self._require_learner()
         n, d = self._ingest.finish()
+        if self._dp is not None:
+            self._dp.check_equal(n, "PPO.train")
         perm = d["perm"][:, :n] if d["perm"].shape[1] == n else None
         if perm is None:
             # capacity > n: the kernel expects perm as a dense [epochs, n] array
@@ -222,6 +239,10 @@ class PPO(XTModel):
             self.net.snapshot_weights_async()
         self._draw_ahead(n)
         a = acc.cpu().numpy()
+        if self._dp is not None:
+            # strict: the local sums already carry the GLOBAL 1/B -> SUM over the ranks; weak: mean of the ranks' means
+            self._dp.status()
+            return np.float32(self._dp.global_loss(a[0], a[1] * (self._dp.world if self._dp.mode == "weak" else 1)))
         return np.float32(a[0] / max(a[1], 1.0))
 
     def _perm_block(self, n):
@@ -255,7 +276,7 @@ class PPO(XTModel):
         inds = np.arange(nbatch)
         perms = np.empty((self.num_sgd_iter, nbatch), np.int32) if out is None else out
         for ep in range(self.num_sgd_iter):
-            self._rng.shuffle(inds)
+            self._perm_rng.shuffle(inds)
             perms[ep] = inds
         return perms
 
@@ -265,6 +286,8 @@ class PPO(XTModel):
         self._require_learner()
         r = self._upload(state, label)
         nbatch = r["obs"].shape[0]
+        if self._dp is not None:
+            self._dp.check_equal(nbatch, "PPO.train")
         r["perm"].copy_(self._take_perms(nbatch, perms), non_blocking=True)
         self._normalize_adv(r["adv"])
         acc = self.net.ppo_train(self._cfg, r["obs"], r["perm"], r["action"], r["old_logp"], r["adv"], r["old_v"],

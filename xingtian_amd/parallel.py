@@ -282,3 +282,284 @@ class TorchDistExchange(object):
     def detach(self):
         from xingtian_amd import lib as L
         L.check(self.net.lib.xt_net_set_grad_exchange(self.net.handle, None, None), "xt_net_set_grad_exchange")
+
+
+class DirectComm(object):
+    """The direct 2-phase all-reduce over peer-mapped device memory (C ABI ``xt_direct_*`` / ``xt_allreduce_direct``,
+    ``csrc/xt_xgmi.hip``): every rank pushes slice q of its gradient into peer q's inbox, rank q sums its slice in fixed
+    rank order and pushes the result to everybody -- two hops over the xGMI mesh instead of the 2 (N-1) hops of a ring,
+    replicas bit-identical by construction.  Kernels only, so the exchange is captured into the hipGraph of an update.
+
+    ``DirectComm(rank, world, max_count)`` creates this rank's exchange block; ``connect()`` gathers the 64-byte IPC
+    handles through the ``torch.distributed`` group that already exists (any backend; ``handles=`` passes them
+    explicitly) and maps the peers' blocks.  N processes on ONE GPU take exactly the same code path (the tests)."""
+
+    def __init__(self, rank, world, max_count, timeout_ms=None):
+        import ctypes
+        from xingtian_amd import lib as L
+        self._ct, self._L = ctypes, L
+        self.lib = L.load()
+        self.rank, self.world, self.max_count = int(rank), int(world), int(max_count)
+        self._handle_buf = ctypes.create_string_buffer(L.DIRECT_HANDLE_BYTES)
+        self.comm = ctypes.c_void_p()
+        L.check(self.lib.xt_direct_create(self.rank, self.world, self.max_count, self._handle_buf, ctypes.byref(self.comm)),
+                "xt_direct_create")
+        if timeout_ms:
+            L.check(self.lib.xt_direct_set_timeout_ms(self.comm, int(timeout_ms)), "xt_direct_set_timeout_ms")
+        self.connected = self.world == 1
+
+    @property
+    def handle(self):
+        """this rank's 64-byte hipIpcMemHandle_t"""
+        return bytes(self._handle_buf.raw)
+
+    def connect(self, handles=None, group=None):
+        """Map every peer's exchange block.  ``handles``: list of ``world`` 64-byte handles in rank order; default: gathered
+        over ``torch.distributed`` (``group`` or the default group)."""
+        if self.connected:
+            return self
+        if handles is None:
+            gathered = [None] * self.world
+            dist.all_gather_object(gathered, self.handle, group=group)
+            handles = gathered
+        if len(handles) != self.world or any(len(h) != self._L.DIRECT_HANDLE_BYTES for h in handles):
+            raise ValueError("DirectComm.connect: need {} handles of {} bytes".format(self.world, self._L.DIRECT_HANDLE_BYTES))
+        blob = b"".join(bytes(h) for h in handles)
+        self._L.check(self.lib.xt_direct_connect(self.comm, self._ct.c_char_p(blob)), "xt_direct_connect")
+        self.connected = True
+        return self
+
+    @staticmethod
+    def local_group(world, max_count, timeout_ms=None):
+        """``world`` logical ranks inside THIS process (one device): tests, and single-process multi-stream drivers."""
+        import ctypes
+        ranks = [DirectComm(r, world, max_count, timeout_ms) for r in range(world)]
+        arr = (ctypes.c_void_p * world)(*[c.comm for c in ranks])
+        for c in ranks:
+            if world > 1:
+                c._L.check(c.lib.xt_direct_connect_local(c.comm, arr), "xt_direct_connect_local")
+            c.connected = True
+        return ranks
+
+    @staticmethod
+    def all_reduce_group_(ranks, bufs, streams):
+        """in-process group: one all-reduce over ``bufs[r]`` (float32 device tensors) on ``streams[r]``, phase-ordered"""
+        import ctypes
+        n = len(ranks)
+        c0 = ranks[0]
+        comms = (ctypes.c_void_p * n)(*[c.comm for c in ranks])
+        ptrs = (ctypes.c_void_p * n)(*[b.data_ptr() for b in bufs])
+        sts = (ctypes.c_void_p * n)(*[s.cuda_stream for s in streams])
+        c0._L.check(c0.lib.xt_allreduce_direct_group(n, comms, ptrs, int(bufs[0].numel()), sts), "xt_allreduce_direct_group")
+
+    def all_reduce_(self, flat, stream_ptr=None):
+        """in-place SUM of a float32 device tensor over the ranks, enqueued on the given (default: current) stream"""
+        sp = stream_ptr if stream_ptr is not None else self._L.stream_ptr()
+        self._L.check(self.lib.xt_allreduce_direct(self.comm, self._L.ptr(flat), int(flat.numel()), sp), "xt_allreduce_direct")
+        return flat
+
+    def attach(self, net, overlap=False):
+        """install as ``net``'s gradient exchange (``xt_net_set_grad_exchange_ex`` with the library's own adapter: no
+        Python frame on the enqueue path).  One bucket per step: two concurrent exchanges would share the sequence."""
+        if overlap:
+            raise ValueError("DirectComm: the two-bucket overlap mode needs one comm per bucket; not supported")
+        if int(net.params.numel()) > self.max_count:
+            raise ValueError("DirectComm: the net has {} parameters, the comm was sized for {}".format(net.params.numel(), self.max_count))
+        fn = self._ct.cast(self.lib.xt_direct_exchange_hook, self._ct.c_void_p)
+        self._L.check(net.lib.xt_net_set_grad_exchange_ex(net.handle, fn, self.comm, 0), "xt_net_set_grad_exchange_ex")
+
+    def detach(self, net):
+        self._L.check(net.lib.xt_net_set_grad_exchange(net.handle, None, None), "xt_net_set_grad_exchange")
+
+    def status(self):
+        """dict(calls, seq, error_bits, mem_kind): ``error_bits`` != 0 -> a bounded wait ran out (1: a peer's scatter data,
+        2: a peer's reduced slice); ``mem_kind`` 0 uncached, 1 fine-grained, 2 plain device memory.  Synchronises."""
+        c = self._ct
+        v = [c.c_int32(0) for _ in range(4)]
+        self._L.check(self.lib.xt_direct_status(self.comm, *[c.byref(x) for x in v]), "xt_direct_status")
+        return dict(zip(("calls", "seq", "error_bits", "mem_kind"), (int(x.value) for x in v)))
+
+    def destroy(self):
+        if self.comm:
+            self.lib.xt_direct_destroy(self.comm)
+            self.comm = self._ct.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:       # noqa: BLE001
+            pass
+
+
+class LearnerDP(object):
+    """Data parallelism of ONE learner rank behind the plugin classes (``PPO`` / ``IMPALAOpt`` models): what
+    ``model_config`` / the launcher environment ask for, the gradient exchange attached to the network, who publishes.
+
+    The reference builds one algorithm per learner (xt/framework/learner.py:518-525) and its only multi-device analogue
+    averages ``get_grad()`` results between processes on the host (xt/framework/trainer.py:32-136, dead code).  Here N
+    learner processes (``torchrun --nproc-per-node N``, one per GPU) each build the SAME Algorithm / Model pair; the model
+    finds ``WORLD_SIZE > 1`` (or ``model_config.DP``) and becomes one replica:
+
+    ``model_config`` keys (all optional)
+      DP           "strict" (default when WORLD_SIZE > 1) | "weak" | "off"
+                   strict: the reference's GLOBAL minibatch / chunk is split over the ranks (PPO: BATCH_SIZE rows, loss
+                   means over the global rows; IMPALA: whole-trajectory shards of every BATCH_SIZE chunk, sum-form loss):
+                   the single-GPU update up to fp32 summation order.  weak: every rank trains full BATCH_SIZE minibatches
+                   of its own trajectories, gradients averaged (PPO) / summed (IMPALA): global batch = N x BATCH_SIZE, a
+                   flagged semantic change.
+      DP_FEED      how rollout messages reach the ranks
+                   "replicated" (strict default): every rank is handed every message in the same order and keeps all of
+                   them; shared epoch permutations -> exactly the single-GPU minibatches.
+                   "round_robin": every rank is handed every message and keeps message k iff k % N == rank ("shard whole
+                   trajectories over ranks at ingest"); "sharded" (weak default): every rank is handed only its own.
+                   With these two a strict PPO minibatch is BATCH_SIZE/N rows of EACH rank's local permutation (stratified
+                   over the ranks instead of one global shuffle: documented deviation, SURVEY 8(e) "permute within shards").
+      DP_EXCHANGE  "rccl" (default: raw ncclAllReduce enqueued by the library, captured into the update's hipGraph) |
+                   "direct" (xt_allreduce_direct over peer-mapped memory, also in-graph) | "torch" (torch.distributed from
+                   a host callback: any backend, not capturable -- tests on one GPU go through gloo)
+      DP_BACKEND   torch.distributed backend when the process group does not exist yet ("nccl")
+      DP_DEVICE    device index (default LOCAL_RANK)
+      DP_PUBLISH   "rank0" | "all": which ranks answer ``checkpoint_ready`` / ``if_save`` with True, i.e. hand weights to
+                   explorers and write checkpoints.  Default: rank 0 only when the ranks share one message stream
+                   (replicated / round_robin); every rank when each has its own explorers (sharded) -- the replicas are
+                   bit-identical, so any of them may serve.
+    """
+
+    def __init__(self, rank, world, mode, feed, exchange, publish=None):
+        self.rank, self.world, self.mode, self.feed, self.exchange = rank, world, mode, feed, exchange
+        self.publish = publish or ("all" if feed == "sharded" else "rank0")
+        if self.publish not in ("rank0", "all"):
+            raise ValueError("model_config.DP_PUBLISH must be rank0 | all, got {!r}".format(self.publish))
+        self.comm = None
+        self._msg = 0
+
+    @staticmethod
+    def from_config(model_config):
+        import os
+        cfg = model_config or {}
+        mode = cfg.get("DP")
+        env_world = int(os.environ.get("WORLD_SIZE", "1"))
+        if mode in (None, "auto"):
+            mode = "strict" if env_world > 1 else "off"
+        if mode not in ("strict", "weak", "off"):
+            raise ValueError("model_config.DP must be 'strict', 'weak' or 'off', got {!r}".format(mode))
+        if mode == "off":
+            return None
+        if not (dist.is_available() and dist.is_initialized()):
+            if env_world <= 1:
+                return None                    # DP asked for, but this is a single process: nothing to exchange with
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29544")
+            dist.init_process_group(cfg.get("DP_BACKEND", "nccl"), rank=int(os.environ["RANK"]), world_size=env_world)
+        rank, world = dist.get_rank(), dist.get_world_size()
+        if world == 1:
+            return None
+        feed = cfg.get("DP_FEED", "replicated" if mode == "strict" else "sharded")
+        if feed not in ("replicated", "round_robin", "sharded"):
+            raise ValueError("model_config.DP_FEED must be replicated | round_robin | sharded, got {!r}".format(feed))
+        if mode == "weak" and feed == "replicated":
+            raise ValueError("DP 'weak' trains every rank on its own trajectories: DP_FEED must be round_robin or sharded")
+        exchange = cfg.get("DP_EXCHANGE", "rccl")
+        if exchange not in ("rccl", "direct", "torch"):
+            raise ValueError("model_config.DP_EXCHANGE must be rccl | direct | torch, got {!r}".format(exchange))
+        return LearnerDP(rank, world, mode, feed, exchange, cfg.get("DP_PUBLISH"))
+
+    @staticmethod
+    def device_index(model_config):
+        import os
+        cfg = model_config or {}
+        if cfg.get("DP_DEVICE") is not None:
+            return int(cfg["DP_DEVICE"])
+        return int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+
+    # ---- set-up
+    def attach(self, net):
+        """replicas start identical (rank 0's parameters and optimiser slots), the exchange is installed on ``net``"""
+        for t in (net.params, net.adam_m, net.adam_v, net.adam_state):
+            dist.broadcast(t, src=0)
+        torch.cuda.synchronize()
+        net.touch()
+        if self.exchange == "rccl":
+            self.comm = RcclComm(self.rank, self.world)
+            warm = torch.zeros(1024, dtype=torch.float32, device=net.device)
+            from xingtian_amd import lib as L
+            self.comm.all_reduce_(warm, L.stream_ptr())       # RCCL's lazy allocations must not happen under capture
+            torch.cuda.synchronize()
+            self.comm.attach(net)
+        elif self.exchange == "direct":
+            self.comm = DirectComm(self.rank, self.world, int(net.params.numel())).connect()
+            self.comm.attach(net)
+        else:
+            self.comm = TorchDistExchange(net)
+            self.comm.attach()
+        return self
+
+    @property
+    def graph_capable(self):
+        """the exchange is kernels / RCCL calls on the stream (capturable); the torch.distributed callback is host-synchronous"""
+        return self.exchange in ("rccl", "direct")
+
+    @property
+    def is_publisher(self):
+        return self.rank == 0 or self.publish == "all"
+
+    def shared_seed(self, seed):
+        """one seed for the generators that must agree on every rank (strict + replicated: the epoch permutations)"""
+        t = torch.tensor([int(seed) if seed is not None else int(np.random.SeedSequence().entropy % (1 << 62))],
+                         dtype=torch.int64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.broadcast(t, src=0)
+        return int(t.item())
+
+    # ---- ingest
+    def new_rollout(self):
+        self._msg = 0
+
+    def takes(self, _train_data=None):
+        """does THIS rank keep the next arriving message?  (round_robin: message k belongs to rank k % N)"""
+        k = self._msg
+        self._msg += 1
+        return self.feed != "round_robin" or k % self.world == self.rank
+
+    # ---- PPO
+    def ppo_cfg(self, net, cfg):
+        """(xt_ppo_cfg, rows of a local minibatch) for this rank"""
+        bsz = int(cfg["BATCH_SIZE"])
+        if self.mode == "weak":
+            return net.make_ppo_cfg(cfg, grad_scale=1.0 / self.world, global_batch=0), bsz
+        if self.feed == "replicated":      # shared permutation, this rank's rows of every global minibatch (in the library)
+            return net.make_ppo_cfg(cfg, grad_scale=1.0, global_batch=0, shard_rank=self.rank, shard_world=self.world), bsz
+        if bsz % self.world:
+            raise ValueError("strict data parallelism over sharded trajectories needs BATCH_SIZE ({}) divisible by the "
+                             "number of ranks ({})".format(bsz, self.world))
+        local = bsz // self.world
+        return net.make_ppo_cfg(dict(cfg, BATCH_SIZE=local), grad_scale=1.0, global_batch=bsz), local
+
+    def check_equal(self, n, what):
+        """every rank must hold the same number of rows (same number of SGD steps = same number of collectives)"""
+        t = torch.tensor([n, -n], dtype=torch.int64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if int(t[0]) != -int(t[1]):
+            raise ValueError("data-parallel {}: ranks hold different amounts of data (this rank {}, max {}, min {})".format(
+                what, n, int(t[0]), -int(t[1])))
+
+    def global_loss(self, local_sum, denom):
+        """loss the learner logs: PPO strict -- local sums already carry the global 1/B -> SUM over ranks / minibatches;
+        PPO weak -- mean over ranks of the local means; IMPALA -- SUM of the shard sums / chunks"""
+        t = torch.tensor([float(local_sum)], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item()) / max(float(denom), 1.0)
+
+    def status(self):
+        """exchange health: raises if the library saw a collective fail inside the hook"""
+        if isinstance(self.comm, DirectComm):
+            st = self.comm.status()
+            if st["error_bits"]:
+                raise RuntimeError("direct all-reduce: a bounded wait ran out (error bits {})".format(st["error_bits"]))
+            return st
+        return {}
