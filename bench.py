@@ -191,7 +191,7 @@ def compact_line(out):
         if "error" in st:
             line["strict"]["error"] = str(st["error"])[:120]
     line["parity"] = PARITY
-    line["detail"] = out.get("detail_file", DETAIL_NAME)
+    line["detail"] = out.get("detail_file") or DETAIL_NAME
     txt = json.dumps(line)
     if len(txt) > COMPACT_LIMIT:        # never let the line outgrow the driver again: drop optional blocks, largest first
         for k in ("secondary", "dp_variants", "actor_scan", "env_num_256", "e2e", "sustained", "parity"):
@@ -204,9 +204,12 @@ def compact_line(out):
 
 def emit_result(out):
     """full result -> bench_detail.json (next to bench.py, and gpurun_out/ when it exists) + stderr; compact line -> stdout"""
-    paths = [os.path.join(ROOT, DETAIL_NAME)]
-    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
-        paths.append(os.path.join(ROOT, "gpurun_out", DETAIL_NAME))
+    if out.get("detail_file"):
+        paths = [out["detail_file"]]
+    else:
+        paths = [os.path.join(ROOT, DETAIL_NAME)]
+        if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+            paths.append(os.path.join(ROOT, "gpurun_out", DETAIL_NAME))
     for pth in paths:
         try:
             with open(pth, "w") as f:
@@ -217,8 +220,11 @@ def emit_result(out):
     _emit(compact_line(out))
 
 
+_T0 = time.perf_counter()
+
+
 def log(*a):
-    print("[bench]", *a, file=sys.stderr, flush=True)
+    print("[bench +{:6.1f}s]".format(time.perf_counter() - _T0), *a, file=sys.stderr, flush=True)
 
 
 def host_cores():
@@ -574,7 +580,7 @@ def in_graph_kernel_stats(workload, timeout=240):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def bench_e2e_ppo(env_num, min_seconds=1.0, max_updates=40, via_ring=False, learner_gae=False, handover="get_weights"):
+def bench_e2e_ppo(env_num, min_seconds=1.0, max_updates=40, via_ring=False, learner_gae=False, handover="get_weights", warm=3):
     """(rollout samples consumed by one Algorithm.train()) / (wall time of prepare_data x env_num +
     train() incl. the H2D of the uint8 rollout + get_weights D2H), through the plugin classes exactly as
     xt/framework/learner.py:306-313,346-348,361-363 drives them.  Host arrays are plain (pageable) numpy."""
@@ -654,7 +660,7 @@ def bench_e2e_ppo(env_num, min_seconds=1.0, max_updates=40, via_ring=False, lear
         if timed:
             t_prep += t1 - t0; t_train += t2 - t1; t_w += t3 - t2; updates += 1
 
-    for _ in range(3):
+    for _ in range(warm):
         one(False)
     t_begin = time.perf_counter()
     while updates < max_updates and (updates < 5 or time.perf_counter() - t_begin < min_seconds):
@@ -791,7 +797,7 @@ def bench_impala(key, steps, warmup, with_cpu, in_graph=False, quick=False):
         return {"value": FRAME_SKIP * f * cnt / tot, "unit": "env-frames/s", "trains": cnt,
                 "ms_per_train": 1e3 * tot / cnt, "prepare_data_ms": 1e3 * t_prep / cnt, "train_ms": 1e3 * t_train / cnt,
                 "weights_ms": 1e3 * t_w / cnt, "train_per_checkpoint": tpc,
-                "async_loss": bool(async_loss), "weights_lag_trains": int(lag),
+                "async_loss": bool(async_loss), "weights_lag_trains": int(lag) * int(tpc),
                 "path": "alg_builder('IMPALAOpt') -> prepare_data x {} -> train() -> every {} train(s): {}".format(
                     msgs_per_train, tpc, "publish_weights(pinned WeightsRing): one D2H into the slot" if handover == "publish"
                     else "get_weights(): dict of private arrays")}
@@ -806,7 +812,8 @@ def bench_impala(key, steps, warmup, with_cpu, in_graph=False, quick=False):
     # train k are those of train k-1 (their copy landed long ago), nothing in the loop waits for the GPU; what an
     # asynchronous algorithm like IMPALA tolerates by design (v-trace corrects the policy lag), not what learner.py does
     out["e2e_pipelined"] = dict(plugin_run("publish", async_loss=True, lag=1), semantic_change=True,
-                                note="ASYNC_LOSS + publish_weights(lag=1): loss AND published weights lag one train")
+                                note="ASYNC_LOSS + publish_weights(lag=1): the loss lags one train, the published weights one publish "
+                                     "interval (= train_per_checkpoint trains)")
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline_impala(w, data)
     return out
@@ -856,6 +863,179 @@ def bench_impala_dp(key, rank, world, dev, dist, trains=40, warmup=5):
                      "trajectories_per_rank": ntraj if mode == "weak" else "{}..{}".format(ntraj // world, -(-ntraj // world))}
         assert torch.isfinite(net.params).all()
         del net
+    return res
+
+
+def bench_env_num_256(spec, dev, updates=3):
+    """BASELINE.json configs[3] at its stated per-update scale on ONE GPU: Breakout PPO with env_num = 256
+    -> 32 768 samples = 925 MB of uint8 frames per update, 4 x ceil(32768 / 320) = 412 SGD steps
+    (xt/model/ppo/ppo.py:111-132).  HBM-resident (GAE + xt_net_ppo_train, hipGraph replay) and through the plugin classes
+    (prepare_data x 256 -> train() -> weights)."""
+    from xingtian_amd import lib as L
+    from xingtian_amd.model.hip_net import HipActorCritic
+    lib = L.load()
+    env_num = 256
+    obs, action, logp, value, reward, done = synth_rollout(256, env_num)
+    n = obs.shape[0]
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    net = HipActorCritic(spec, max_batch=CFG["BATCH_SIZE"], device=str(dev), seed=0)
+    cfg = net.make_ppo_cfg(CFG)
+    d_obs, d_act, d_logp = d(obs), d(action), d(logp)
+    d_value, d_reward, d_done = d(value), d(reward), d(done.astype(np.uint8))
+    d_adv = torch.empty((n,), dtype=torch.float64, device=dev)
+    d_tgt = torch.empty((n,), dtype=torch.float64, device=dev)
+    d_oldv = torch.empty((n,), dtype=torch.float32, device=dev)
+    d_perm = torch.empty((CFG["NUM_SGD_ITER"], n), dtype=torch.int32, device=dev)
+    pin = torch.empty((CFG["NUM_SGD_ITER"], n), dtype=torch.int32, pin_memory=True)
+    rng = np.random.default_rng(77)
+
+    def one_update():
+        torch.cuda.current_stream().synchronize()          # (one pinned block: its previous H2D has finished)
+        inds = np.arange(n)
+        p = pin.numpy()
+        for ep in range(CFG["NUM_SGD_ITER"]):
+            rng.shuffle(inds)
+            p[ep] = inds
+        d_perm.copy_(pin, non_blocking=True)
+        L.check(lib.xt_gae_f64(L.ptr(d_value), L.ptr(d_reward), L.ptr(d_done), L.ptr(d_adv), L.ptr(d_tgt), L.ptr(d_oldv),
+                               env_num, T_LEN, 0.99, 0.95, L.stream_ptr()), "gae")
+        net.ppo_train(cfg, d_obs, d_perm, d_act, d_logp, d_adv, d_oldv, d_tgt, use_graph=True)
+
+    one_update()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(updates):
+        one_update()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / updates
+    assert torch.isfinite(net.params).all()
+    sgd = CFG["NUM_SGD_ITER"] * ((n + CFG["BATCH_SIZE"] - 1) // CFG["BATCH_SIZE"])
+    out = {"workload": "BASELINE configs[3] per-update scale on 1 GPU: Breakout PPO env_num=256, 32768 samples (925 MB uint8), "
+                       "{} SGD steps of B=320".format(sgd),
+           "value": FRAME_SKIP * n / el, "unit": "env-frames/s", "ms_per_update": 1e3 * el, "sgd_steps": sgd,
+           "us_per_sgd_step": 1e6 * el / sgd, "rollout_bytes": int(obs.nbytes)}
+    del net, d_obs
+    torch.cuda.empty_cache()
+    for key, kw in (("e2e", dict()), ("e2e_pinned_ring", dict(via_ring=True, handover="publish"))):
+        try:
+            log("env_num 256:", key)
+            r = bench_e2e_ppo(env_num, min_seconds=0.2, max_updates=5, warm=2, **kw)
+        except Exception as exc:      # noqa: BLE001 -- a diagnostic block must not take the line with it
+            r = {"error": repr(exc)[:200]}
+        out[key] = r
+    best = out["e2e_pinned_ring"] if "value" in out.get("e2e_pinned_ring", {}) else out.get("e2e", {})
+    if "value" in best:
+        out.update({"value_e2e": best["value"], "e2e_ms_per_update": best["ms_per_update"],
+                    "e2e_prepare_data_ms": best["prepare_data_ms"], "e2e_train_ms": best["train_ms"],
+                    "h2d_share_of_e2e": best["h2d_ms_at_55GBps"] / best["ms_per_update"]})
+    return out
+
+
+def _scan_producer(name, slots, slot_bytes, wire, stop_flag, backoff):
+    """explorer stand-in of bench_actor_scan: sends ONE pre-encoded rollout message over and over until told to stop"""
+    from xingtian_amd import transport
+    ring = transport.RingSet.attach(name, slots=slots, slot_bytes=slot_bytes)
+    while not stop_flag.value:
+        if not ring.send_bytes(wire, block=False):
+            time.sleep(backoff)            # ring full: the learner is the bottleneck; do not burn the host's cores polling
+    ring.close()
+
+
+def bench_actor_scan(counts=(8, 32, 128, 512), seconds=1.0):
+    """BASELINE.json configs[4] (examples/pong_impala_speedup.yaml:39 "512 actors -> throughput scan") on the learner side:
+    P producer PROCESSES (one shared-memory ring each, transport.RingSet) push pre-encoded 250-frame rollout messages
+    (5 envs x T=50, 42x42x4 uint8, A=6) as fast as the learner drains them; the learner is the plugin pair
+    (IMPALAOpt: prepare_data x 4 -> train() on 1000 frames -> every 3rd train the weights go out through a pinned
+    WeightsRing).  Reports messages/s and env-frames/s per P and where it saturates.  The producers do no environment
+    stepping: this scans the LEARNER's ingest + update capacity, which is what bounds a 512-actor run."""
+    import multiprocessing as mp
+    from xingtian_amd import transport
+    from xingtian_amd.algorithm import alg_builder
+    w = IMPALA["pong_impala_speedup"]
+    fm, msgs_per_train, tpc = 250, 4, 3
+    data = synth_impala(11, fm, w["dim"], w["a_dim"])
+    wire = bytes(transport.encode({"cmd": "train"}, {"cur_state": data["obs"], "logit": data["logit"], "action": data["action"],
+                                                     "done": list(data["done"]), "reward": list(data["reward"])}))
+    slot_bytes = (len(wire) + (1 << 16)) // 4096 * 4096
+    ctx = mp.get_context("fork")
+    res = {"message_bytes": len(wire), "frames_per_message": fm, "scan": {}}
+    cores = host_cores()
+    for n_prod in counts:
+        log("actor scan:", n_prod, "producers")
+        try:
+            st = os.statvfs("/dev/shm")
+            need, free = n_prod * 2 * slot_bytes * 1.1 + (64 << 20), st.f_bavail * st.f_frsize
+        except OSError:
+            need, free = 0, 1
+        if free < need:                 # (a write beyond the tmpfs capacity is a SIGBUS, not an exception: check first)
+            res["scan"][str(n_prod)] = {"skipped": "/dev/shm has {:.0f} MB free, {} rings of 2 x {:.1f} MB need {:.0f} MB".format(
+                free / 1e6, n_prod, slot_bytes / 1e6, need / 1e6)}
+            continue
+        try:
+            rs = transport.RingSet(n_prod, slots=2, slot_bytes=slot_bytes)
+        except OSError as exc:
+            res["scan"][str(n_prod)] = {"skipped": repr(exc)[:120]}
+            continue
+        pinned = bool(rs.pin()) if n_prod <= 128 else False      # (hipHostRegister of 512 x 3.6 MB segments: not worth the set-up)
+        stop = ctx.Value("i", 0)
+        backoff = min(0.005, max(0.0002, 0.25 * n_prod / 8000.0))      # ~1/4 of a producer's turn at ~8k messages/s
+        procs = [ctx.Process(target=_scan_producer, args=(rs.names[i], 2, slot_bytes, wire, stop, backoff), daemon=True)
+                 for i in range(n_prod)]
+        for p in procs:
+            p.start()
+        model_info = {"actor": {"model_name": "ImpalaCnnOpt", "state_dim": [w["dim"], w["dim"], 4], "input_dtype": "uint8",
+                                "state_mean": w["mean"], "state_std": w["std"], "action_dim": w["a_dim"],
+                                "model_config": {"LR": w["lr"], "sample_batch_step": w["t_len"], "grad_norm_clip": 40.0,
+                                                 "SEED": 0}}}
+        alg = alg_builder("IMPALAOpt", model_info, {"instance_num": n_prod, "agent_num": 1,
+                                                   "prepare_times_per_train": msgs_per_train, "train_per_checkpoint": tpc,
+                                                   "BATCH_SIZE": fm * msgs_per_train})
+        wring = transport.WeightsRing(slot_bytes=8 << 20, slots=3)
+        wpin = wring.pin()
+        sink = lambda d_, ctr_info=None: alg.prepare_data(d_, ctr_info=ctr_info)
+        trains = 0
+        try:
+            def one_train():
+                nonlocal trains
+                got = rs.recv_many_into(sink, msgs_per_train, timeout=20.0)
+                if got != msgs_per_train:
+                    raise RuntimeError("producers delivered {} of {} messages in 20 s".format(got, msgs_per_train))
+                loss = alg.train(episode_num=trains)
+                if alg.checkpoint_ready(trains):
+                    alg.publish_weights(wring) if wpin else alg.get_weights()
+                trains += 1
+                return loss
+            for _ in range(6):
+                one_train()
+            trains = 0
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < seconds:
+                one_train()
+            el = time.perf_counter() - t0
+            res["scan"][str(n_prod)] = {"messages_per_s": msgs_per_train * trains / el, "trains_per_s": trains / el,
+                                        "value": FRAME_SKIP * fm * msgs_per_train * trains / el, "unit": "env-frames/s",
+                                        "pinned_rings": pinned, "served_min_max": [int(min(rs.served)), int(max(rs.served))]}
+        except Exception as exc:      # noqa: BLE001
+            res["scan"][str(n_prod)] = {"error": repr(exc)[:200]}
+        finally:
+            stop.value = 1
+            for p in procs:
+                p.join(5)
+                if p.is_alive():
+                    p.terminate()
+            torch.cuda.synchronize()
+            wring.close()
+            rs.close()
+            del alg
+            torch.cuda.empty_cache()
+    ok = {int(k): v["messages_per_s"] for k, v in res["scan"].items() if "messages_per_s" in v}
+    if ok:
+        peak_p = max(ok, key=lambda k: ok[k])
+        res.update({"messages_per_s_peak": ok[peak_p], "producers_at_peak": peak_p, "host_cores": cores,
+                    "value_at_512": res["scan"].get("512", {}).get("value"),
+                    "saturates_at": min((k for k in ok if ok[k] >= 0.9 * ok[peak_p]), default=peak_p),
+                    "note": "learner-side scan: producers replay one encoded message; saturation = the learner's "
+                            "staging + H2D + update rate, not the actors"})
     return res
 
 
@@ -929,6 +1109,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--detail-file", default=None, help="where the full result goes (default: bench_detail.json next to bench.py)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the IMPALA workloads and the plugin-path (e2e) runs")
     ap.add_argument("--quick", action="store_true", help="headline + roofline only (profiling runs)")
@@ -1220,6 +1401,8 @@ def main():
                    "global_batch": bsz * world, "parallelism": "dp{}".format(world), "hip_graph": graph_on,
                    "dp_path": bool(dp_path)},
     }
+    if args.detail_file:
+        out["detail_file"] = os.path.abspath(args.detail_file)
     if args.test_backend:
         out["config"]["DIAGNOSTIC"] = "ranks share GPUs, gradients through {}: not a measurement".format(args.test_backend)
     if dp_path:
@@ -1331,6 +1514,12 @@ def main():
                                           "pinned copy per variant (memcpy / non-temporal stores x inline,1,2,4,8 worker "
                                           "threads, 4 MiB pieces); the fastest is what prepare_data uses")
         out["value_e2e"] = out["e2e"]["env_num_32"]["value"]
+        for key, fn in (("env_num_256", lambda: bench_env_num_256(spec, dev)), ("actor_scan", bench_actor_scan)):
+            try:
+                out[key] = fn()
+            except Exception as exc:      # noqa: BLE001 -- a diagnostic block must not take the line with it
+                out[key] = {"error": repr(exc)[:300]}
+            torch.cuda.empty_cache()
         try:
             out["modelled_scaling"] = model_scaling(spec, dev)
         except Exception as exc:      # noqa: BLE001 -- a diagnostic block must not take the line with it

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: a GPU test that also runs minutes of float64 oracle on the host (still part of -m gpu)")
     # property tests must not replay (or depend on) an example database that is not part of the tree
     try:
         from hypothesis import settings

@@ -113,6 +113,20 @@ def main():
             lr_steps = d(np.asarray([7e-4 / (step + 1)], np.float32)) if mode == "impala_sched" else None
             parallel.dp_impala_step(net, c, 1e-3, 40.0, d(data["obs"]), d(data["bp"]), d(data["act"]), d(data["done"]),
                                     d(data["rew"]), ntraj, tlen, rank, world, lr_steps=lr_steps)
+    elif mode in ("impala_one_traj", "impala_rms_one_traj"):
+        # ONE trajectory over two ranks: rank 1's shard is empty and contributes a zero gradient -- through the step-wise
+        # branch (Adam) and through the hook branch (rmsprop), which must accept the same inputs
+        spec, data, tlen, _ = impala_case()
+        net = HipActorCritic(spec, max_batch=tlen, seed=5)
+        parallel.broadcast_weights_(net.params)
+        rms = mode == "impala_rms_one_traj"
+        if rms:
+            net.set_optimizer("rmsprop")
+        c = net.make_impala_cfg(1e-3, 40.0, tlen, opt_type="rmsprop" if rms else "adam")
+        sl = slice(0, tlen)
+        for _ in range(2):
+            parallel.dp_impala_step(net, c, 1e-3, 40.0, d(data["obs"][sl]), d(data["bp"][sl]), d(data["act"][sl]),
+                                    d(data["done"][sl]), d(data["rew"][sl]), 1, tlen, rank, world)
     elif mode == "impala":
         spec, data, tlen, ntraj = impala_case()
         net = HipActorCritic(spec, max_batch=tlen * ntraj, seed=5)

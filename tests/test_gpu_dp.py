@@ -119,7 +119,10 @@ def test_bench_self_spawns_two_ranks_and_reports_weak_strict_and_impala():
     ``n_gpus: 2``, the weak-scaling headline, the strict-sharding result and the IMPALA data-parallel secondaries
     (here with the diagnostic gloo transport, the two ranks sharing the one GPU)."""
     import json
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--test-backend", "gloo", "--steps", "2", "--warmup", "1"]
+    import tempfile
+    detail = os.path.join(tempfile.mkdtemp(prefix="xt_bench_"), "detail.json")     # (not the tree's bench_detail.json)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--test-backend", "gloo", "--steps", "2", "--warmup", "1",
+           "--detail-file", detail]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
@@ -135,7 +138,8 @@ def test_bench_self_spawns_two_ranks_and_reports_weak_strict_and_impala():
     # the direct all-reduce over hipIpc-mapped memory carries a validated number even with both ranks on one GPU (the RCCL
     # variants cannot form a communicator there and say so)
     assert isinstance(d["dp_variants"]["direct"], float) and d["dp_variants"]["direct"] > 0, d["dp_variants"]
-    full = json.load(open(os.path.join(ROOT, d["detail"])))
+    assert d["detail"] == detail
+    full = json.load(open(detail))
     assert full["strict"]["global_batch"] == 320 and full["strict"]["dp_variants"]["direct"]["valid"], full["strict"]
     assert full["dp_variants"]["direct"]["first_update_bitwise_equal"] is True
     sec = {s["workload"].split()[0]: s for s in full["secondary"]}
@@ -189,6 +193,31 @@ def test_data_parallel_impala_with_rmsprop_and_scheduled_step_sizes(tmp_path, mo
         lr_steps = d(np.asarray([7e-4 / (step + 1)], np.float32)) if mode == "impala_sched" else None
         net.impala_train(c, d(data["obs"]), tlen * ntraj, d(data["bp"]), d(data["act"]), d(data["done"]), d(data["rew"]),
                          lr_steps=lr_steps, use_graph=False)
+    torch.cuda.synchronize()
+    ref = net.params.cpu().numpy()
+    assert not np.array_equal(ref, start)
+    assert _delta_err(got, ref, start) < 5e-3, _delta_err(got, ref, start)
+
+
+@pytest.mark.parametrize("mode", ["impala_one_traj", "impala_rms_one_traj"])
+def test_data_parallel_impala_with_an_empty_shard(tmp_path, mode):
+    """fewer trajectories than ranks: the empty rank contributes a zero gradient in BOTH branches of dp_impala_step (the
+    step-wise Adam path and the hook path with centred RMSProp) -- same contract, same result as one process."""
+    import dp_worker
+    from xingtian_amd.model.hip_net import HipActorCritic
+    got = _run_two_ranks(tmp_path, mode)
+    spec, data, tlen, _ = dp_worker.impala_case()
+    net = HipActorCritic(spec, max_batch=tlen, seed=5)
+    start = net.params.cpu().numpy().copy()
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    rms = mode == "impala_rms_one_traj"
+    if rms:
+        net.set_optimizer("rmsprop")
+    c = net.make_impala_cfg(1e-3, 40.0, tlen, opt_type="rmsprop" if rms else "adam")
+    sl = slice(0, tlen)
+    for _ in range(2):
+        net.impala_train(c, d(data["obs"][sl]), tlen, d(data["bp"][sl]), d(data["act"][sl]), d(data["done"][sl]),
+                         d(data["rew"][sl]), use_graph=False)
     torch.cuda.synchronize()
     ref = net.params.cpu().numpy()
     assert not np.array_equal(ref, start)

@@ -1491,3 +1491,67 @@ def test_fused_update_tail_is_bitwise_the_two_launch_tail():
         assert all(np.array_equal(a, b) for a, b in zip(ref[0], got[0]))
         for a, b in zip(ref[1:], got[1:]):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.slow
+def test_baseline_config1_full_update_env_num_32_against_the_float64_oracle():
+    """BASELINE.json configs[1] at its stated scale, end to end: env_num 32 x 128 steps = 4096 samples,
+    BATCH_SIZE 320, NUM_SGD_ITER 4 -> 52 SGD steps (the last minibatch of every epoch has 256 rows) in ONE Model.train
+    through the plugin classes (hipGraph replay), injected permutations, against the float64 oracle running the same 52
+    steps on the host.  Same bars as the YAML's env_num 10 update above (loss 1e-4; weight delta 2x the fp32-inherent
+    deviation of the oracle's own float32 build; every weight within 2 x steps x LR of the oracle's)."""
+    from xingtian_amd.algorithm import alg_builder
+    model_info = {"actor": {"model_name": "PpoCnn", "state_dim": [84, 84, 4], "action_dim": 4, "input_dtype": "uint8",
+                            "model_config": {"BATCH_SIZE": 320, "CRITIC_LOSS_COEF": 1.0, "ENTROPY_LOSS": 0.003,
+                                             "LOSS_CLIPPING": 0.1, "LR": 0.00025, "MAX_GRAD_NORM": 5.0,
+                                             "NUM_SGD_ITER": 4, "SUMMARY": False, "VF_SHARE_LAYERS": True,
+                                             "activation": "relu", "hidden_sizes": [256],
+                                             "action_type": "Categorical", "SEED": 2}}}
+    env_num, n = 32, 32 * 128
+    alg = alg_builder("PPO", model_info, {"instance_num": env_num, "agent_num": 1})
+    rng = np.random.default_rng(13)
+    all_obs, all_lab = [], [[] for _ in range(5)]
+    for env in range(env_num):
+        obs, lab = synth_ppo_rollout(rng, 128, (84, 84, 4), 4)
+        alg.prepare_data({"cur_state": obs, "action": lab[0], "logp": lab[1], "adv": lab[2], "old_value": lab[3],
+                          "target_value": lab[4]})
+        all_obs.append(obs)
+        for i in range(5):
+            all_lab[i].append(lab[i])
+    w0 = alg.get_weights()
+    inds, perms = np.arange(n), []
+    for _ in range(4):
+        rng.shuffle(inds)
+        perms.append(inds.copy())
+    perms = np.stack(perms).astype(np.int32)
+    loss = alg.train(episode_num=0, perms=perms)
+    steps = 4 * ((n + 319) // 320)
+    assert steps == 52
+    ospec = nets.ppo_cnn_spec((84, 84, 4), 4, (256,), "relu", True)
+    cfg = dict(LR=0.00025, LOSS_CLIPPING=0.1, ENTROPY_LOSS=0.003, VF_CLIP=5.0, CRITIC_LOSS_COEF=1.0,
+               MAX_GRAD_NORM=5.0, BATCH_SIZE=320, NUM_SGD_ITER=4)
+    shapes = nets.init_params(ospec)
+    orc = nets.PpoLearnerOracle(ospec, {k: v.reshape(shapes[k].shape) for k, v in w0.items()}, cfg, np.float64)
+    obs_all, lab_all = [np.concatenate(all_obs)], [np.concatenate(x) for x in all_lab]
+    ref = orc.train(obs_all, lab_all, perms)
+    # the yardstick: the float32 build of the SAME oracle on the same update.  52 sign-like Adam steps amplify fp32 rounding
+    # (the weights of step k feed the losses of step k + 1), so "how far may a correct fp32 learner be from the float64
+    # one after 52 steps" is measured, not guessed; the GPU must stay within 2x of it (per-step bars: 1e-4 on the loss and
+    # 1e-5 per gradient tensor at B = 320, test_ppo_step_loss_and_grads_vs_oracle).
+    orc32 = nets.PpoLearnerOracle(ospec, {k: v.reshape(shapes[k].shape).copy() for k, v in w0.items()}, cfg, np.float32)   # (a float32 oracle updates its arrays in place)
+    ref32 = orc32.train(obs_all, lab_all, perms)
+    w1 = alg.get_weights()
+    scale = max(1.0, abs(ref))
+    e_loss, e_loss32 = abs(loss - ref) / scale, abs(float(ref32) - ref) / scale
+    report = {}
+    for k, r in orc.net.params.items():
+        d64 = r - w0[k].reshape(r.shape)
+        gpu = rel_err(w1[k].reshape(r.shape) - w0[k].reshape(r.shape), d64)
+        f32 = rel_err(orc32.net.params[k].astype(np.float64) - w0[k].reshape(r.shape), d64)
+        report[k] = (float(gpu), float(f32), float(np.abs(w1[k].reshape(r.shape) - r).max()))
+    print("config1 full update: loss gpu", float(loss), "oracle64", float(ref), "oracle32", float(ref32),
+          "| rel dev gpu", e_loss, "oracle32", e_loss32, "| per tensor (gpu, oracle32, max abs):", report)
+    assert e_loss < max(1e-4, 4.0 * e_loss32), (loss, ref, ref32)
+    for k, (gpu, f32, mx) in report.items():
+        assert gpu < max(3.0 * f32, 0.02), (k, gpu, f32)
+        assert mx <= 2 * steps * 0.00025, (k, mx)

@@ -417,6 +417,9 @@ int launch_conv1_fwd_bf16x3(const xt_conv_geom* g, const xt_input_xform* xf, int
   if (HWC % 16 != 0 || HWC > 64 * 1024 || (g->W * 4) % 8 != 0 || (g->S * 4) % 8 != 0) return -1;
   if (g->OH * g->OW > 32 * kC1TileSlots) return -1;
   if (fabsf(xf->mean) >= 1e-4f || g->KH > 8) return -1;     // the mean term would need colsum(W); 4 weight slots/thread
+  // store4_wt addresses y with a 32-bit byte offset: leave outputs of 2 GiB or more to the generic path, whose geometry
+  // check rejects them loudly (make_geom)
+  if ((long long)B * g->OH * g->OW * g->N * 4 >= (1ll << 31)) return -1;
   C1FwdArgs a;
   a.in = static_cast<const uint8_t*>(in); a.idx = idx; a.w = w; a.bias = bias; a.y = y;
   a.B = B; a.H = g->H; a.W = g->W; a.OH = g->OH; a.OW = g->OW; a.S = g->S; a.KH = g->KH; a.act = g->act;

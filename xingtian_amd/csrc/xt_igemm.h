@@ -33,7 +33,10 @@ static inline int make_geom(const xt_conv_geom* g, const xt_input_xform* xf, int
   o->xs = xf ? 1.f / xf->std : 1.f;
   o->xb = -mean * o->xs;
   o->HWC = g->H * g->W * g->C;
-  XT_REQUIRE(m * (long long)g->N < (1ll << 31), "igemm: output tensor too large");
+  // BYTES, not elements: the write-through stores (store4_wt, xt_common.h) address the output through a raw buffer
+  // descriptor with a 32-bit byte offset, i.e. 2 GiB (an 8 GiB tensor passed the old element bound and the
+  // hardware silently dropped the out-of-range stores)
+  XT_REQUIRE(m * (long long)g->N * 4 < (1ll << 31), "igemm: output tensors of 2 GiB or more are not supported (batch %d)", B);
   return 0;
 }
 

@@ -162,6 +162,11 @@ class RolloutIngest(object):
         if len(labels) != len(self.fields):
             raise ValueError("RolloutIngest.put: {} label arrays for fields {}".format(
                 len(labels), [f[0] for f in self.fields]))
+        # a rollout is either all-raw (GAE on the learner) or all with advantages: reject the odd message AS IT ARRIVES
+        # (before any copy is enqueued for it), so that the rollout gathered so far stays usable
+        if (self.adv_traj if _raw else self.raw_traj):
+            raise ValueError("RolloutIngest: a rollout must not mix trajectories with and without advantages "
+                             "(this one {} them)".format("lacks" if _raw else "brings"))
         if not _raw:
             self.adv_traj += 1
         obs_dst = s.host_np["obs"][lo:hi]
@@ -234,7 +239,8 @@ class RolloutIngest(object):
         n = self.n
         if s is None or n == 0:
             raise RuntimeError("RolloutIngest.finish(): nothing was ingested")
-        if self.raw_traj and self.adv_traj:
+        if self.raw_traj and self.adv_traj:       # (unreachable through put / put_raw, which reject the odd message)
+            self.reset()
             raise RuntimeError("RolloutIngest.finish(): a rollout must not mix trajectories with and without advantages")
         dev = s.dev
         self._join_copy_streams(wait=False)

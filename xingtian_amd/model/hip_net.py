@@ -168,9 +168,12 @@ class HipActorCritic(object):
         if getattr(ring, "pinned", False):
             attached = getattr(self, "_wring", None) is ring
             if lag > 0:
-                # ``lag = 1`` (asynchronous algorithms, flagged deviation): hand out the weights of the PREVIOUS update,
-                # whose copy landed long ago, and never wait for the one just enqueued -- the next rollout message is
-                # ingested while the GPU still runs this update.  The copy of the current update stays begun.
+                # ``lag = 1`` (asynchronous algorithms, flagged deviation): hand out the weights whose copy was begun at the
+                # PREVIOUS publish and never wait for the one just enqueued -- the next rollout message is ingested while
+                # the GPU still runs this update.  The copy of the current update stays begun.  With
+                # train_per_checkpoint = 1 every train begins a copy (eager_snapshot), so the lag is ONE TRAIN; with
+                # train_per_checkpoint = k > 1 copies are only begun here, so the lag is one publish INTERVAL = k trains
+                # (pong_impala_speedup.yaml: 3) -- bench.py labels it so.
                 if not attached or ring.slots < 3:
                     raise ValueError("publish_weights(lag=1) needs attach_weights_ring(ring) and a ring of >= 3 slots")
                 self._wring_lag = 1

@@ -136,16 +136,30 @@ def dp_impala_step(net, cfg_struct, lr, grad_norm_clip, obs, bp_logits, action, 
     b, e = shard_range(n_traj, rank, world)
     hook = exchange is not None or lr_steps is not None or int(cfg_struct.opt_type) != L.OPT_TYPE["adam"]
     if hook:
-        if n_traj < world:        # the same test on every rank, before any collective
-            raise ValueError("dp_impala_step: {} trajectories cannot be split over {} ranks".format(n_traj, world))
-        ex = exchange if exchange is not None else TorchDistExchange(net)
-        ex.attach(net) if isinstance(ex, RcclComm) else ex.attach()
+        # one exchange object per net (a fresh ctypes trampoline per step cost ~0.2 ms of host set-up)
+        ex = exchange
+        if ex is None:
+            ex = getattr(net, "_dp_exchange", None)
+            if ex is None:
+                ex = net._dp_exchange = TorchDistExchange(net)
+        native = isinstance(ex, (RcclComm, DirectComm))
+        ex.attach(net) if native else ex.attach()
         try:
-            sl = slice(b * t_len, e * t_len)
-            net.impala_train(cfg_struct, obs[sl], (e - b) * t_len, bp_logits[sl], action[sl], done[sl], reward[sl],
-                             lr_steps=lr_steps, use_graph=False)
+            if e > b:
+                sl = slice(b * t_len, e * t_len)
+                net.impala_train(cfg_struct, obs[sl], (e - b) * t_len, bp_logits[sl], action[sl], done[sl], reward[sl],
+                                 lr_steps=lr_steps, use_graph=False)
+            else:
+                # an empty shard (fewer trajectories than ranks) contributes a ZERO gradient, like the step-wise branch
+                # below: the library does that itself when it shards (xt_impala_cfg.shard_world, ABI 10)
+                import copy
+                c2 = copy.copy(cfg_struct)
+                c2.shard_rank, c2.shard_world = int(rank), int(world)
+                n_all = n_traj * t_len
+                net.impala_train(c2, obs[:n_all], n_all, bp_logits[:n_all], action[:n_all], done[:n_all], reward[:n_all],
+                                 lr_steps=lr_steps, use_graph=False)
         finally:
-            ex.detach(net) if isinstance(ex, RcclComm) else ex.detach()
+            ex.detach(net) if native else ex.detach()
         return
     if e > b:
         sl = slice(b * t_len, e * t_len)

@@ -442,6 +442,11 @@ class WeightsRing(object):
     def publish(self, weights, ctr_info=None):
         """Write the name -> ndarray dict (``get_weights()``: views into the pinned D2H block are fine, every array
         is copied exactly once, into the slot).  Returns the sequence number of this publish."""
+        if self._pending:
+            # a packed publish is begun and not committed: its DMA targets slot (latest + 1) % slots, the one a dict publish
+            # would write now (ADVICE r4)
+            raise RuntimeError("WeightsRing.publish: {} packed publish(es) begun and not committed; commit_flat_publish() "
+                               "or retarget_flat_publish() first".format(len(self._pending)))
         k = int(self._latest[0]) + 1
         i = k % self.slots
         self._hdr[i][0] = 0
@@ -601,6 +606,14 @@ class WeightsRing(object):
         raise RuntimeError("WeightsRing.fetch: no stable publish after {} attempts".format(retries))
 
     def close(self):
+        # begun-but-uncommitted D2H copies may still be in flight INTO the slots: wait for them before the pages are
+        # un-registered and the segment unlinked
+        for pend in getattr(self, "_pending", None) or []:
+            try:
+                pend[3].synchronize()
+            except Exception:       # noqa: BLE001 -- closing must not raise over a dead context
+                pass
+        self._pending = []
         self._latest = None
         self._hdr = None
         if getattr(self, "pinned", False):
