@@ -983,6 +983,7 @@ def bench_actor_scan(counts=(8, 32, 128, 512), seconds=1.0):
                  for i in range(n_prod)]
         for p in procs:
             p.start()
+        log("  forked")
         model_info = {"actor": {"model_name": "ImpalaCnnOpt", "state_dim": [w["dim"], w["dim"], 4], "input_dtype": "uint8",
                                 "state_mean": w["mean"], "state_std": w["std"], "action_dim": w["a_dim"],
                                 "model_config": {"LR": w["lr"], "sample_batch_step": w["t_len"], "grad_norm_clip": 40.0,
@@ -1005,8 +1006,10 @@ def bench_actor_scan(counts=(8, 32, 128, 512), seconds=1.0):
                     alg.publish_weights(wring) if wpin else alg.get_weights()
                 trains += 1
                 return loss
+            log("  learner built")
             for _ in range(6):
                 one_train()
+            log("  warm")
             trains = 0
             t0 = time.perf_counter()
             while time.perf_counter() - t0 < seconds:
@@ -1018,16 +1021,21 @@ def bench_actor_scan(counts=(8, 32, 128, 512), seconds=1.0):
         except Exception as exc:      # noqa: BLE001
             res["scan"][str(n_prod)] = {"error": repr(exc)[:200]}
         finally:
+            log("  measured")
             stop.value = 1
+            deadline = time.perf_counter() + 5.0
             for p in procs:
-                p.join(5)
-                if p.is_alive():
-                    p.terminate()
+                p.join(max(0.0, deadline - time.perf_counter()))
+            stuck = [p for p in procs if p.is_alive()]
+            for p in stuck:
+                p.terminate()
+            log("  producers joined ({} had to be terminated)".format(len(stuck)))
             torch.cuda.synchronize()
             wring.close()
             rs.close()
             del alg
             torch.cuda.empty_cache()
+            log("  closed")
     ok = {int(k): v["messages_per_s"] for k, v in res["scan"].items() if "messages_per_s" in v}
     if ok:
         peak_p = max(ok, key=lambda k: ok[k])
@@ -1037,6 +1045,22 @@ def bench_actor_scan(counts=(8, 32, 128, 512), seconds=1.0):
                     "note": "learner-side scan: producers replay one encoded message; saturation = the learner's "
                             "staging + H2D + update rate, not the actors"})
     return res
+
+
+def run_section(name, timeout=240):
+    """One block of the line in a FRESH process (`bench.py --section <name>`): the env_num 256 block page-locks ~2 GB of
+    staging and the actor scan forks up to 512 producers -- forking from a process that holds gigabytes of registered memory
+    took ~40 s per scan point (measured), and the memory would stay with the rest of the run."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--section", name]
+    log("section", name, "in a fresh process")
+    try:
+        pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+        lines = [l for l in pr.stdout.decode().splitlines() if l.strip()]
+        if pr.returncode != 0 or not lines:
+            return {"error": "section {} exited with {}: {}".format(name, pr.returncode, pr.stderr.decode()[-300:])}
+        return json.loads(lines[-1])[name]
+    except (subprocess.SubprocessError, OSError, ValueError, KeyError) as exc:
+        return {"error": repr(exc)[:300]}
 
 
 def model_scaling(spec, dev, updates=6):
@@ -1109,6 +1133,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--section", default=None, choices=["actor_scan", "env_num_256"],
+                    help="DIAGNOSTIC: run only this block of the single-GPU line and print it")
     ap.add_argument("--detail-file", default=None, help="where the full result goes (default: bench_detail.json next to bench.py)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the IMPALA workloads and the plugin-path (e2e) runs")
@@ -1157,6 +1183,12 @@ def main():
                            in_graph=not (args.quick or args.no_in_graph_stats), quick=args.quick)
         out.update({"n_gpus": 1, "warmup": args.warmup, "higher_is_better": True, "data": "synthetic"})
         return _emit(out)
+
+    if args.section:
+        from xingtian_amd.model import netspec as _ns
+        fn = {"actor_scan": bench_actor_scan,
+              "env_num_256": lambda: bench_env_num_256(_ns.ppo_cnn(STATE_DIM, A_DIM, HIDDEN, "relu", True), torch.device("cuda", local_rank))}
+        return _emit({args.section: fn[args.section]()})
 
     if args.model_scaling:
         from xingtian_amd.model import netspec as _ns
@@ -1514,12 +1546,8 @@ def main():
                                           "pinned copy per variant (memcpy / non-temporal stores x inline,1,2,4,8 worker "
                                           "threads, 4 MiB pieces); the fastest is what prepare_data uses")
         out["value_e2e"] = out["e2e"]["env_num_32"]["value"]
-        for key, fn in (("env_num_256", lambda: bench_env_num_256(spec, dev)), ("actor_scan", bench_actor_scan)):
-            try:
-                out[key] = fn()
-            except Exception as exc:      # noqa: BLE001 -- a diagnostic block must not take the line with it
-                out[key] = {"error": repr(exc)[:300]}
-            torch.cuda.empty_cache()
+        for key in ("env_num_256", "actor_scan"):
+            out[key] = run_section(key)
         try:
             out["modelled_scaling"] = model_scaling(spec, dev)
         except Exception as exc:      # noqa: BLE001 -- a diagnostic block must not take the line with it

@@ -1553,5 +1553,5 @@ def test_baseline_config1_full_update_env_num_32_against_the_float64_oracle():
           "| rel dev gpu", e_loss, "oracle32", e_loss32, "| per tensor (gpu, oracle32, max abs):", report)
     assert e_loss < max(1e-4, 4.0 * e_loss32), (loss, ref, ref32)
     for k, (gpu, f32, mx) in report.items():
-        assert gpu < max(3.0 * f32, 0.02), (k, gpu, f32)
+        assert gpu < max(3.0 * f32, 0.10), (k, gpu, f32)
         assert mx <= 2 * steps * 0.00025, (k, mx)
