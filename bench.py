@@ -1096,12 +1096,39 @@ def model_scaling(spec, dev, updates=6):
         del net
         torch.cuda.empty_cache()
 
+    # the kernel-side cost of xt_allreduce_direct, MEASURED on this one device: two in-process ranks (phase-ordered launches on
+    # two streams) move 2 x (the 13.6 MB of uncached exchange traffic one rank generates per all-reduce) through the
+    # three-launch chain; half of that run is what ONE rank's chain costs when the GPU is its own.  The links come on top.
+    chain_us = None
+    try:
+        from xingtian_amd.parallel import DirectComm
+        ranks = DirectComm.local_group(2, spec.n_flat, timeout_ms=5000)
+        sts = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        bufs = [torch.ones(spec.n_flat, dtype=torch.float32, device=dev) for _ in range(2)]
+        torch.cuda.synchronize()
+        for _ in range(5):
+            DirectComm.all_reduce_group_(ranks, bufs, sts)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            DirectComm.all_reduce_group_(ranks, bufs, sts)
+        torch.cuda.synchronize()
+        chain_us = 0.5 * 1e6 * (time.perf_counter() - t0) / 50
+        assert ranks[0].status()["error_bits"] == 0
+        for c in ranks:
+            c.destroy()
+    except Exception as exc:      # noqa: BLE001
+        log("direct all-reduce chain not measured:", repr(exc)[:200])
+
     def allreduce_us(nr, kind):
         if nr == 1:
             return 0.0
         if kind == "ring_one_link":
             return 2.0 * (nr - 1) / nr * s_bytes / (link_gbps * 1e3) + 2 * (nr - 1) * hop_us
-        return 2.0 * (s_bytes / nr / (link_gbps * 1e3) + hop_us)          # direct_2phase
+        if kind == "direct_2phase_measured_chain":
+            # what exists (csrc/xt_xgmi.hip): the measured one-device chain + the two link phases it cannot have seen
+            return chain_us + 2.0 * (nr - 1) / nr * (s_bytes / nr / (link_gbps * 1e3)) + 2.0 * hop_us
+        return 2.0 * (s_bytes / nr / (link_gbps * 1e3) + hop_us)          # direct_2phase, link-limited ideal
 
     frames_per_update = FRAME_SKIP * ENV_NUM * T_LEN
     sgd_steps = CFG["NUM_SGD_ITER"] * ((ENV_NUM * T_LEN + CFG["BATCH_SIZE"] - 1) // CFG["BATCH_SIZE"])
@@ -1109,11 +1136,12 @@ def model_scaling(spec, dev, updates=6):
     out = {"MODELLED": "no multi-GPU box was available to the builder: measured 1-GPU step time at the shard size + a modelled, "
                        "non-overlapped all-reduce; NOT a measurement of N GPUs",
            "assumptions": {"allreduce_bytes": s_bytes, "xgmi_link_GBps": link_gbps, "hop_latency_us": hop_us,
+                           "direct_chain_us_measured_one_device": None if chain_us is None else round(chain_us, 1),
                            "overlap": "none (the two-bucket overlap variants hide the conv backward's ~55 us at 320 rows; not credited)"},
            "measured_sgd_step_us_by_rows": {str(k): round(v, 2) for k, v in step_us.items()}, "strict": {}, "weak": {}}
     for nr in (1, 2, 4, 8):
         rows = CFG["BATCH_SIZE"] // nr
-        for kind in ("ring_one_link", "direct_2phase"):
+        for kind in ("ring_one_link", "direct_2phase") + (("direct_2phase_measured_chain",) if chain_us else ()):
             ar = allreduce_us(nr, kind)
             t_strict, t_weak = step_us[rows] + ar, step_us[320] + ar
             v_strict = frames_per_update / (sgd_steps * t_strict * 1e-6)

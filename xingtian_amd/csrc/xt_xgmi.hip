@@ -63,7 +63,22 @@ __device__ __forceinline__ float4 load_vec_tail(const float* p, int64_t v, int64
   return r;
 }
 
+// Publishing a block's share of the data.  UC (uncached exchange block, the default): stores bypass every cache, so the
+// block only has to wait until its own stores are acknowledged (s_waitcnt vmcnt(0)) before it takes its ticket.  Otherwise
+// (fine-grained / plain memory) a system-scope release fence per block: it writes the XCD's L2 back (buffer_wbl2) -- every
+// block needs its own because the eight XCDs have eight L2s, and that is what made the cached kinds SLOWER than the
+// uncached one (tools/direct_probe.py: 145 vs 104 us for two in-process ranks x 3.39 MB when every kind was fenced).
+template <bool UC>
+__device__ __forceinline__ void publish_fence() {
+  if constexpr (UC) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  }
+}
+
 // bounded wait until flags[off + p] == seq for every p < world (thread 0 of the block polls, the block follows)
+template <bool UC>
 __device__ __forceinline__ void wait_all(const uint32_t* flags, int off, int world, uint32_t seq, uint32_t* ctl,
                                          unsigned long long timeout_ticks, uint32_t errbit) {
   if (threadIdx.x == 0) {
@@ -81,10 +96,15 @@ __device__ __forceinline__ void wait_all(const uint32_t* flags, int off, int wor
     }
   }
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  if constexpr (UC) {
+    asm volatile("" ::: "memory");          // (uncached data: nothing to invalidate; keep the loads below the wait)
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  }
 }
 
 // phase 1: push slice q of the local gradient into peer q's inbox[rank]; grid (blocks per slice, world)
+template <bool UC>
 __global__ void __launch_bounds__(256) xgmi_scatter_kernel(const float* __restrict__ grads, int64_t count, int rank, int world,
                                                            DirectPeers peers, uint32_t* ctl) {
   const int q = blockIdx.y;
@@ -95,23 +115,25 @@ __global__ void __launch_bounds__(256) xgmi_scatter_kernel(const float* __restri
   const int64_t hi = lo + kScatterVecs < e ? lo + kScatterVecs : e;
   float4* dst = reinterpret_cast<float4*>(peers.inbox_me[q]);
   for (int64_t v = lo + threadIdx.x; v < hi; v += 256) dst[v - b] = load_vec_tail(grads, v, count);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  publish_fence<UC>();
   __syncthreads();
   if (threadIdx.x == 0) {
     const uint32_t seq = ctl[kCtlSeq] + 1;
     if (atomicAdd(ctl + kCtlScat + q, 1u) == gridDim.x - 1) {     // last block of this peer's slice
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
-      __hip_atomic_store(peers.flags[q] + kReadyOff + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if constexpr (!UC) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
+      __hip_atomic_store(peers.flags[q] + kReadyOff + rank, seq, UC ? __ATOMIC_RELAXED : __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
 
 // phase 2: sum my slice over the inbox slots in rank order, push the result to every peer; grid = blocks over my slice
+template <bool UC>
 __global__ void __launch_bounds__(256) xgmi_reduce_kernel(const float* __restrict__ inbox, int64_t slice_cap, int64_t count,
                                                           int rank, int world, DirectPeers peers, const uint32_t* my_flags,
                                                           uint32_t* ctl, unsigned long long timeout_ticks) {
   const uint32_t seq = ctl[kCtlSeq] + 1;
-  wait_all(my_flags, kReadyOff, world, seq, ctl, timeout_ticks, 1u);
+  wait_all<UC>(my_flags, kReadyOff, world, seq, ctl, timeout_ticks, 1u);
   const int64_t nvec = (count + 3) / 4;
   int64_t b, e;
   slice_of(nvec, rank, world, b, e);
@@ -125,21 +147,23 @@ __global__ void __launch_bounds__(256) xgmi_reduce_kernel(const float* __restric
     }
     for (int p = 0; p < world; ++p) reinterpret_cast<float4*>(peers.result[p])[v] = acc;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  publish_fence<UC>();
   __syncthreads();
   if (threadIdx.x == 0 && atomicAdd(ctl + kCtlRed, 1u) == gridDim.x - 1) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
+    if constexpr (!UC) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
     for (int p = 0; p < world; ++p)
-      __hip_atomic_store(peers.flags[p] + kDoneOff + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(peers.flags[p] + kDoneOff + rank, seq, UC ? __ATOMIC_RELAXED : __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
 // phase 3: wait for every rank's reduced slice, copy result -> gradient buffer; the last block advances the sequence
+template <bool UC>
 __global__ void __launch_bounds__(256) xgmi_gather_kernel(float* __restrict__ grads, const float* __restrict__ result,
                                                           int64_t count, int world, const uint32_t* my_flags, uint32_t* ctl,
                                                           unsigned long long timeout_ticks) {
   const uint32_t seq = ctl[kCtlSeq] + 1;
-  wait_all(my_flags, kDoneOff, world, seq, ctl, timeout_ticks, 2u);
+  wait_all<UC>(my_flags, kDoneOff, world, seq, ctl, timeout_ticks, 2u);
   const int64_t nvec = (count + 3) / 4;
   const int64_t lo = (int64_t)blockIdx.x * kScatterVecs;
   const int64_t hi = lo + kScatterVecs < nvec ? lo + kScatterVecs : nvec;
@@ -174,7 +198,7 @@ struct xt_direct_comm {
   int64_t max_count = 0, slice_cap = 0;         // floats
   size_t block_bytes = 0, inbox_off = 0, result_off = 0;
   char* block = nullptr;                        // own exchange block (device memory, shared with the peers)
-  int mem_kind = 0;                             // 0 uncached, 1 fine-grained, 2 plain hipMalloc
+  int mem_kind = 0;                             // 1 fine-grained, 2 uncached
   char* peer_block[xt::kMaxWorld] = {};
   bool peer_ipc[xt::kMaxWorld] = {};            // opened with hipIpcOpenMemHandle (to be closed)
   bool connected = false;
@@ -186,7 +210,8 @@ struct xt_direct_comm {
 
 extern "C" {
 
-int xt_direct_create(int32_t rank, int32_t world, int64_t max_count, void* handle_out, xt_direct_comm** out) {
+// mem_kind: 0 = auto (uncached, then fine-grained), 1 = fine-grained, 2 = uncached
+int xt_direct_create(int32_t rank, int32_t world, int64_t max_count, int32_t mem_kind, void* handle_out, xt_direct_comm** out) {
   XT_REQUIRE(out, "xt_direct_create: null out");
   XT_REQUIRE(world >= 1 && world <= xt::kMaxWorld && rank >= 0 && rank < world, "xt_direct_create: rank %d / world %d (max %d)",
              rank, world, xt::kMaxWorld);
@@ -198,21 +223,26 @@ int xt_direct_create(int32_t rank, int32_t world, int64_t max_count, void* handl
   c->inbox_off = (size_t)xt::kFlagWords * 4;
   c->result_off = c->inbox_off + sizeof(float) * (size_t)c->slice_cap * world;
   c->block_bytes = c->result_off + sizeof(float) * (size_t)nvec * 4;
-  hipError_t e = hipExtMallocWithFlags((void**)&c->block, c->block_bytes, hipDeviceMallocUncached);
-  c->mem_kind = 0;
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    e = hipExtMallocWithFlags((void**)&c->block, c->block_bytes, hipDeviceMallocFinegrained);
-    c->mem_kind = 1;
+  // UNCACHED device memory first (what RCCL takes for its peer buffers): stores and loads bypass the caches, so publishing
+  // needs no L2 write-back and consuming no invalidate -- see publish_fence.  Fine-grained memory (cached, written back /
+  // invalidated by system-scope fences per block) is the fallback and runs the fenced kernel variants (2.5x slower on one
+  // device).  Plain (coarse-grained) hipMalloc memory is NOT an option: it is only coherent at kernel boundaries, and the
+  // flag polls of a running kernel were served stale lines by another XCD's L2 (measured round 5: sporadic 5 s time-outs of
+  // the gather wait with every rank on ONE device).
+  XT_REQUIRE(mem_kind >= 0 && mem_kind <= 2, "xt_direct_create: mem_kind %d (0 auto, 1 fine-grained, 2 uncached)", mem_kind);
+  hipError_t e = hipErrorUnknown;
+  const int order[2] = {2, 1};
+  for (int i = 0; i < 2 && e != hipSuccess; ++i) {
+    const int kind = mem_kind ? mem_kind : order[i];
+    if (kind == 1) e = hipExtMallocWithFlags((void**)&c->block, c->block_bytes, hipDeviceMallocFinegrained);
+    else e = hipExtMallocWithFlags((void**)&c->block, c->block_bytes, hipDeviceMallocUncached);
+    c->mem_kind = kind;
+    if (e != hipSuccess) (void)hipGetLastError();
+    if (mem_kind) break;
   }
   if (e != hipSuccess) {
-    (void)hipGetLastError();
-    e = hipMalloc((void**)&c->block, c->block_bytes);
-    c->mem_kind = 2;
-  }
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    xt::set_error("xt_direct_create: cannot allocate the %zu-byte exchange block: %s", c->block_bytes, hipGetErrorString(e));
+    xt::set_error("xt_direct_create: cannot allocate the %zu-byte exchange block (mem_kind %d): %s", c->block_bytes, mem_kind,
+                  hipGetErrorString(e));
     delete c;
     return 1;
   }
@@ -296,15 +326,20 @@ static int direct_enqueue(xt_direct_comm* c, float* buf, int64_t count, int phas
   const uint32_t* my_flags = reinterpret_cast<const uint32_t*>(c->block);
   const float* inbox = reinterpret_cast<const float*>(c->block + c->inbox_off);
   const float* result = reinterpret_cast<const float*>(c->block + c->result_off);
+  const bool uc = (c->mem_kind == 2);
+#define XT_XGMI_LAUNCH(K, grid, ...)                                                                   \
+  do {                                                                                                \
+    if (uc) hipLaunchKernelGGL(xt::K<true>, grid, dim3(256), 0, st, __VA_ARGS__);                     \
+    else hipLaunchKernelGGL(xt::K<false>, grid, dim3(256), 0, st, __VA_ARGS__);                       \
+  } while (0)
   if (phase < 0 || phase == 0)
-    hipLaunchKernelGGL(xt::xgmi_scatter_kernel, dim3(sb ? sb : 1, c->world), dim3(256), 0, st, buf, count, c->rank, c->world,
-                       c->peers, c->ctl);
+    XT_XGMI_LAUNCH(xgmi_scatter_kernel, dim3(sb ? sb : 1, c->world), buf, count, c->rank, c->world, c->peers, c->ctl);
   if (phase < 0 || phase == 1)
-    hipLaunchKernelGGL(xt::xgmi_reduce_kernel, dim3(rb ? rb : 1), dim3(256), 0, st, inbox, c->slice_cap, count, c->rank,
-                       c->world, c->peers, my_flags, c->ctl, c->timeout_ticks);
+    XT_XGMI_LAUNCH(xgmi_reduce_kernel, dim3(rb ? rb : 1), inbox, c->slice_cap, count, c->rank, c->world, c->peers, my_flags,
+                   c->ctl, c->timeout_ticks);
   if (phase < 0 || phase == 2)
-    hipLaunchKernelGGL(xt::xgmi_gather_kernel, dim3(gb ? gb : 1), dim3(256), 0, st, buf, result, count, c->world, my_flags,
-                       c->ctl, c->timeout_ticks);
+    XT_XGMI_LAUNCH(xgmi_gather_kernel, dim3(gb ? gb : 1), buf, result, count, c->world, my_flags, c->ctl, c->timeout_ticks);
+#undef XT_XGMI_LAUNCH
   XT_LAUNCH_CHECK();
   return 0;
 }

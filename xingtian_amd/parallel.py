@@ -308,7 +308,9 @@ class DirectComm(object):
     handles through the ``torch.distributed`` group that already exists (any backend; ``handles=`` passes them
     explicitly) and maps the peers' blocks.  N processes on ONE GPU take exactly the same code path (the tests)."""
 
-    def __init__(self, rank, world, max_count, timeout_ms=None):
+    MEM_KINDS = {"auto": 0, "finegrained": 1, "uncached": 2}
+
+    def __init__(self, rank, world, max_count, timeout_ms=None, mem_kind="auto"):
         import ctypes
         from xingtian_amd import lib as L
         self._ct, self._L = ctypes, L
@@ -316,8 +318,8 @@ class DirectComm(object):
         self.rank, self.world, self.max_count = int(rank), int(world), int(max_count)
         self._handle_buf = ctypes.create_string_buffer(L.DIRECT_HANDLE_BYTES)
         self.comm = ctypes.c_void_p()
-        L.check(self.lib.xt_direct_create(self.rank, self.world, self.max_count, self._handle_buf, ctypes.byref(self.comm)),
-                "xt_direct_create")
+        L.check(self.lib.xt_direct_create(self.rank, self.world, self.max_count, self.MEM_KINDS[mem_kind], self._handle_buf,
+                                          ctypes.byref(self.comm)), "xt_direct_create")
         if timeout_ms:
             L.check(self.lib.xt_direct_set_timeout_ms(self.comm, int(timeout_ms)), "xt_direct_set_timeout_ms")
         self.connected = self.world == 1
@@ -344,10 +346,10 @@ class DirectComm(object):
         return self
 
     @staticmethod
-    def local_group(world, max_count, timeout_ms=None):
+    def local_group(world, max_count, timeout_ms=None, mem_kind="auto"):
         """``world`` logical ranks inside THIS process (one device): tests, and single-process multi-stream drivers."""
         import ctypes
-        ranks = [DirectComm(r, world, max_count, timeout_ms) for r in range(world)]
+        ranks = [DirectComm(r, world, max_count, timeout_ms, mem_kind) for r in range(world)]
         arr = (ctypes.c_void_p * world)(*[c.comm for c in ranks])
         for c in ranks:
             if world > 1:
@@ -387,7 +389,7 @@ class DirectComm(object):
 
     def status(self):
         """dict(calls, seq, error_bits, mem_kind): ``error_bits`` != 0 -> a bounded wait ran out (1: a peer's scatter data,
-        2: a peer's reduced slice); ``mem_kind`` 0 uncached, 1 fine-grained, 2 plain device memory.  Synchronises."""
+        2: a peer's reduced slice); ``mem_kind`` 1 fine-grained, 2 uncached device memory.  Synchronises."""
         c = self._ct
         v = [c.c_int32(0) for _ in range(4)]
         self._L.check(self.lib.xt_direct_status(self.comm, *[c.byref(x) for x in v]), "xt_direct_status")
