@@ -455,7 +455,7 @@ KERNEL_OF = {
 }
 
 
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def library_identity():
