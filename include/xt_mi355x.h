@@ -445,9 +445,9 @@ int xt_net_rccl_status(const xt_net* net, int32_t* calls, int32_t* last_error);
  *
  *   xt_direct_create   allocates this rank's exchange block (flags + one inbox slot per rank + a result buffer, sized for
  *                      max_count floats) and writes its 64-byte hipIpcMemHandle_t to handle_out (may be NULL for in-process
- *                      groups).  rank in [0, world), world <= 16.  mem_kind: 0 = auto (uncached device memory, then
- *                      fine-grained), 1 = fine-grained / 2 = uncached force one (xt_direct_status reports what was taken;
- *                      plain hipMalloc memory is only coherent at kernel boundaries and is refused).
+ *                      groups).  rank in [0, world), world <= 16.  The block is UNCACHED device memory (published with
+ *                      s_waitcnt + a system-scope flag store, nothing to invalidate on the consumer side); cached kinds
+ *                      measured stale flag polls (plain) / wrong sums (fine-grained) across the XCDs' L2s and are not offered.
  *   xt_direct_connect  handles = world x XT_DIRECT_HANDLE_BYTES bytes, rank order (as gathered over any side channel,
  *                      e.g. torch.distributed all_gather); maps every peer's block (hipIpcOpenMemHandle).
  *   xt_direct_connect_local  the same for N logical ranks inside ONE process (ranks[q] = the comm object of rank q).
@@ -463,8 +463,7 @@ int xt_net_rccl_status(const xt_net* net, int32_t* calls, int32_t* last_error);
  */
 #define XT_DIRECT_HANDLE_BYTES 64
 typedef struct xt_direct_comm xt_direct_comm;
-int xt_direct_create(int32_t rank, int32_t world, int64_t max_count, int32_t mem_kind, void* handle_out,
-                     xt_direct_comm** out);
+int xt_direct_create(int32_t rank, int32_t world, int64_t max_count, void* handle_out, xt_direct_comm** out);
 int xt_direct_connect(xt_direct_comm* comm, const void* handles);
 int xt_direct_connect_local(xt_direct_comm* comm, xt_direct_comm* const* ranks);
 int xt_allreduce_direct(xt_direct_comm* comm, float* buf, int64_t count, void* stream);
@@ -474,7 +473,7 @@ int xt_allreduce_direct_group(int32_t n, xt_direct_comm* const* comms, float* co
                               void* const* streams);
 int xt_direct_exchange_hook(float* grads, int64_t count, void* user, void* stream);
 int xt_direct_set_timeout_ms(xt_direct_comm* comm, int32_t ms);
-int xt_direct_status(xt_direct_comm* comm, int32_t* calls, int32_t* seq, int32_t* error_bits, int32_t* mem_kind);
+int xt_direct_status(xt_direct_comm* comm, int32_t* calls, int32_t* seq, int32_t* error_bits);
 int xt_direct_destroy(xt_direct_comm* comm);
 
 /* One minibatch of Keras `model.fit` for the non-opt IMPALA models (ABI >= 5): forward, xt_keras_impala_loss,

@@ -53,34 +53,6 @@ def test_in_process_group_is_bitwise_the_fixed_order_sum(world):
             c.destroy()
 
 
-def test_fine_grained_exchange_block_runs_the_fenced_kernels_to_the_same_bits():
-    """the fallback memory kind (hipDeviceMallocFinegrained: cached, per-block system-scope release / acquire) against the
-    default uncached one: same results, and xt_direct_status says which was taken; plain memory is refused"""
-    import direct_worker as W
-    from xingtian_amd.parallel import DirectComm
-    for kind, code in (("uncached", 2), ("finegrained", 1)):
-        ranks = DirectComm.local_group(4, 250007, timeout_ms=10000, mem_kind=kind)
-        streams = [torch.cuda.Stream() for _ in range(4)]
-        try:
-            for it in range(6):
-                bufs = [torch.from_numpy(W.rank_input(it, r, 250007)).cuda() for r in range(4)]
-                torch.cuda.synchronize()
-                DirectComm.all_reduce_group_(ranks, bufs, streams)
-                torch.cuda.synchronize()
-                want = W.expected_sum(it, 4, 250007)
-                assert all(np.array_equal(b.cpu().numpy(), want) for b in bufs), (kind, it)
-            st = ranks[0].status()
-            assert st["mem_kind"] == code and st["error_bits"] == 0, st
-        finally:
-            for c in ranks:
-                c.destroy()
-    with pytest.raises(RuntimeError, match="mem_kind"):
-        from xingtian_amd import lib as L
-        import ctypes
-        h = ctypes.c_void_p()
-        L.check(L.load().xt_direct_create(0, 2, 64, 3, None, ctypes.byref(h)), "xt_direct_create")
-
-
 def test_single_rank_is_the_identity_and_bad_arguments_fail_loudly():
     from xingtian_amd.parallel import DirectComm
     c = DirectComm(0, 1, 1024)

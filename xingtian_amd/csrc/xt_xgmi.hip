@@ -63,22 +63,14 @@ __device__ __forceinline__ float4 load_vec_tail(const float* p, int64_t v, int64
   return r;
 }
 
-// Publishing a block's share of the data.  UC (uncached exchange block, the default): stores bypass every cache, so the
-// block only has to wait until its own stores are acknowledged (s_waitcnt vmcnt(0)) before it takes its ticket.  Otherwise
-// (fine-grained / plain memory) a system-scope release fence per block: it writes the XCD's L2 back (buffer_wbl2) -- every
-// block needs its own because the eight XCDs have eight L2s, and that is what made the cached kinds SLOWER than the
-// uncached one (tools/direct_probe.py: 145 vs 104 us for two in-process ranks x 3.39 MB when every kind was fenced).
-template <bool UC>
-__device__ __forceinline__ void publish_fence() {
-  if constexpr (UC) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-  }
-}
+// Publishing a block's share of the data.  The exchange block is UNCACHED device memory: stores bypass every cache, so a
+// block only has to wait until its own stores are acknowledged (s_waitcnt vmcnt(0)) before it takes its ticket, and a
+// consumer has nothing to invalidate.  (First version: a system-scope release fence per block -- a buffer_wbl2 of the XCD's
+// L2, needed per block because eight XCDs have eight L2s -- and an acquire fence per consumer block: 100 / 155 / 303 us for
+// 2 / 4 / 8 in-process ranks x 3.39 MB against 57 / 74 / 142 us without them, tools/direct_probe.py.)
+__device__ __forceinline__ void publish_fence() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // bounded wait until flags[off + p] == seq for every p < world (thread 0 of the block polls, the block follows)
-template <bool UC>
 __device__ __forceinline__ void wait_all(const uint32_t* flags, int off, int world, uint32_t seq, uint32_t* ctl,
                                          unsigned long long timeout_ticks, uint32_t errbit) {
   if (threadIdx.x == 0) {
@@ -96,15 +88,10 @@ __device__ __forceinline__ void wait_all(const uint32_t* flags, int off, int wor
     }
   }
   __syncthreads();
-  if constexpr (UC) {
-    asm volatile("" ::: "memory");          // (uncached data: nothing to invalidate; keep the loads below the wait)
-  } else {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-  }
+  asm volatile("" ::: "memory");            // (uncached data: nothing to invalidate; keep the loads below the wait)
 }
 
 // phase 1: push slice q of the local gradient into peer q's inbox[rank]; grid (blocks per slice, world)
-template <bool UC>
 __global__ void __launch_bounds__(256) xgmi_scatter_kernel(const float* __restrict__ grads, int64_t count, int rank, int world,
                                                            DirectPeers peers, uint32_t* ctl) {
   const int q = blockIdx.y;
@@ -115,25 +102,22 @@ __global__ void __launch_bounds__(256) xgmi_scatter_kernel(const float* __restri
   const int64_t hi = lo + kScatterVecs < e ? lo + kScatterVecs : e;
   float4* dst = reinterpret_cast<float4*>(peers.inbox_me[q]);
   for (int64_t v = lo + threadIdx.x; v < hi; v += 256) dst[v - b] = load_vec_tail(grads, v, count);
-  publish_fence<UC>();
+  publish_fence();
   __syncthreads();
   if (threadIdx.x == 0) {
     const uint32_t seq = ctl[kCtlSeq] + 1;
     if (atomicAdd(ctl + kCtlScat + q, 1u) == gridDim.x - 1) {     // last block of this peer's slice
-      if constexpr (!UC) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
-      __hip_atomic_store(peers.flags[q] + kReadyOff + rank, seq, UC ? __ATOMIC_RELAXED : __ATOMIC_RELEASE,
-                         __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(peers.flags[q] + kReadyOff + rank, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
 
 // phase 2: sum my slice over the inbox slots in rank order, push the result to every peer; grid = blocks over my slice
-template <bool UC>
 __global__ void __launch_bounds__(256) xgmi_reduce_kernel(const float* __restrict__ inbox, int64_t slice_cap, int64_t count,
                                                           int rank, int world, DirectPeers peers, const uint32_t* my_flags,
                                                           uint32_t* ctl, unsigned long long timeout_ticks) {
   const uint32_t seq = ctl[kCtlSeq] + 1;
-  wait_all<UC>(my_flags, kReadyOff, world, seq, ctl, timeout_ticks, 1u);
+  wait_all(my_flags, kReadyOff, world, seq, ctl, timeout_ticks, 1u);
   const int64_t nvec = (count + 3) / 4;
   int64_t b, e;
   slice_of(nvec, rank, world, b, e);
@@ -147,23 +131,20 @@ __global__ void __launch_bounds__(256) xgmi_reduce_kernel(const float* __restric
     }
     for (int p = 0; p < world; ++p) reinterpret_cast<float4*>(peers.result[p])[v] = acc;
   }
-  publish_fence<UC>();
+  publish_fence();
   __syncthreads();
   if (threadIdx.x == 0 && atomicAdd(ctl + kCtlRed, 1u) == gridDim.x - 1) {
-    if constexpr (!UC) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
     for (int p = 0; p < world; ++p)
-      __hip_atomic_store(peers.flags[p] + kDoneOff + rank, seq, UC ? __ATOMIC_RELAXED : __ATOMIC_RELEASE,
-                         __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(peers.flags[p] + kDoneOff + rank, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
 // phase 3: wait for every rank's reduced slice, copy result -> gradient buffer; the last block advances the sequence
-template <bool UC>
 __global__ void __launch_bounds__(256) xgmi_gather_kernel(float* __restrict__ grads, const float* __restrict__ result,
                                                           int64_t count, int world, const uint32_t* my_flags, uint32_t* ctl,
                                                           unsigned long long timeout_ticks) {
   const uint32_t seq = ctl[kCtlSeq] + 1;
-  wait_all<UC>(my_flags, kDoneOff, world, seq, ctl, timeout_ticks, 2u);
+  wait_all(my_flags, kDoneOff, world, seq, ctl, timeout_ticks, 2u);
   const int64_t nvec = (count + 3) / 4;
   const int64_t lo = (int64_t)blockIdx.x * kScatterVecs;
   const int64_t hi = lo + kScatterVecs < nvec ? lo + kScatterVecs : nvec;
@@ -198,7 +179,6 @@ struct xt_direct_comm {
   int64_t max_count = 0, slice_cap = 0;         // floats
   size_t block_bytes = 0, inbox_off = 0, result_off = 0;
   char* block = nullptr;                        // own exchange block (device memory, shared with the peers)
-  int mem_kind = 0;                             // 1 fine-grained, 2 uncached
   char* peer_block[xt::kMaxWorld] = {};
   bool peer_ipc[xt::kMaxWorld] = {};            // opened with hipIpcOpenMemHandle (to be closed)
   bool connected = false;
@@ -210,8 +190,7 @@ struct xt_direct_comm {
 
 extern "C" {
 
-// mem_kind: 0 = auto (uncached, then fine-grained), 1 = fine-grained, 2 = uncached
-int xt_direct_create(int32_t rank, int32_t world, int64_t max_count, int32_t mem_kind, void* handle_out, xt_direct_comm** out) {
+int xt_direct_create(int32_t rank, int32_t world, int64_t max_count, void* handle_out, xt_direct_comm** out) {
   XT_REQUIRE(out, "xt_direct_create: null out");
   XT_REQUIRE(world >= 1 && world <= xt::kMaxWorld && rank >= 0 && rank < world, "xt_direct_create: rank %d / world %d (max %d)",
              rank, world, xt::kMaxWorld);
@@ -223,26 +202,14 @@ int xt_direct_create(int32_t rank, int32_t world, int64_t max_count, int32_t mem
   c->inbox_off = (size_t)xt::kFlagWords * 4;
   c->result_off = c->inbox_off + sizeof(float) * (size_t)c->slice_cap * world;
   c->block_bytes = c->result_off + sizeof(float) * (size_t)nvec * 4;
-  // UNCACHED device memory first (what RCCL takes for its peer buffers): stores and loads bypass the caches, so publishing
-  // needs no L2 write-back and consuming no invalidate -- see publish_fence.  Fine-grained memory (cached, written back /
-  // invalidated by system-scope fences per block) is the fallback and runs the fenced kernel variants (2.5x slower on one
-  // device).  Plain (coarse-grained) hipMalloc memory is NOT an option: it is only coherent at kernel boundaries, and the
-  // flag polls of a running kernel were served stale lines by another XCD's L2 (measured round 5: sporadic 5 s time-outs of
-  // the gather wait with every rank on ONE device).
-  XT_REQUIRE(mem_kind >= 0 && mem_kind <= 2, "xt_direct_create: mem_kind %d (0 auto, 1 fine-grained, 2 uncached)", mem_kind);
-  hipError_t e = hipErrorUnknown;
-  const int order[2] = {2, 1};
-  for (int i = 0; i < 2 && e != hipSuccess; ++i) {
-    const int kind = mem_kind ? mem_kind : order[i];
-    if (kind == 1) e = hipExtMallocWithFlags((void**)&c->block, c->block_bytes, hipDeviceMallocFinegrained);
-    else e = hipExtMallocWithFlags((void**)&c->block, c->block_bytes, hipDeviceMallocUncached);
-    c->mem_kind = kind;
-    if (e != hipSuccess) (void)hipGetLastError();
-    if (mem_kind) break;
-  }
+  // UNCACHED device memory (what RCCL takes for its peer buffers) and nothing else.  Measured round 5 with every rank on ONE
+  // device: plain hipMalloc memory -> sporadic 5 s time-outs of the flag polls (stale lines served by another XCD's L2:
+  // coarse-grained memory is only coherent at kernel boundaries); fine-grained memory with system-scope fences per block ->
+  // no time-outs but WRONG sums (and 2.5x the time).  The uncached form has passed every run of tests/test_gpu_direct.py.
+  hipError_t e = hipExtMallocWithFlags((void**)&c->block, c->block_bytes, hipDeviceMallocUncached);
   if (e != hipSuccess) {
-    xt::set_error("xt_direct_create: cannot allocate the %zu-byte exchange block (mem_kind %d): %s", c->block_bytes, mem_kind,
-                  hipGetErrorString(e));
+    (void)hipGetLastError();
+    xt::set_error("xt_direct_create: cannot allocate the %zu-byte uncached exchange block: %s", c->block_bytes, hipGetErrorString(e));
     delete c;
     return 1;
   }
@@ -326,20 +293,15 @@ static int direct_enqueue(xt_direct_comm* c, float* buf, int64_t count, int phas
   const uint32_t* my_flags = reinterpret_cast<const uint32_t*>(c->block);
   const float* inbox = reinterpret_cast<const float*>(c->block + c->inbox_off);
   const float* result = reinterpret_cast<const float*>(c->block + c->result_off);
-  const bool uc = (c->mem_kind == 2);
-#define XT_XGMI_LAUNCH(K, grid, ...)                                                                   \
-  do {                                                                                                \
-    if (uc) hipLaunchKernelGGL(xt::K<true>, grid, dim3(256), 0, st, __VA_ARGS__);                     \
-    else hipLaunchKernelGGL(xt::K<false>, grid, dim3(256), 0, st, __VA_ARGS__);                       \
-  } while (0)
   if (phase < 0 || phase == 0)
-    XT_XGMI_LAUNCH(xgmi_scatter_kernel, dim3(sb ? sb : 1, c->world), buf, count, c->rank, c->world, c->peers, c->ctl);
+    hipLaunchKernelGGL(xt::xgmi_scatter_kernel, dim3(sb ? sb : 1, c->world), dim3(256), 0, st, buf, count, c->rank, c->world,
+                       c->peers, c->ctl);
   if (phase < 0 || phase == 1)
-    XT_XGMI_LAUNCH(xgmi_reduce_kernel, dim3(rb ? rb : 1), inbox, c->slice_cap, count, c->rank, c->world, c->peers, my_flags,
-                   c->ctl, c->timeout_ticks);
+    hipLaunchKernelGGL(xt::xgmi_reduce_kernel, dim3(rb ? rb : 1), dim3(256), 0, st, inbox, c->slice_cap, count, c->rank,
+                       c->world, c->peers, my_flags, c->ctl, c->timeout_ticks);
   if (phase < 0 || phase == 2)
-    XT_XGMI_LAUNCH(xgmi_gather_kernel, dim3(gb ? gb : 1), buf, result, count, c->world, my_flags, c->ctl, c->timeout_ticks);
-#undef XT_XGMI_LAUNCH
+    hipLaunchKernelGGL(xt::xgmi_gather_kernel, dim3(gb ? gb : 1), dim3(256), 0, st, buf, result, count, c->world, my_flags,
+                       c->ctl, c->timeout_ticks);
   XT_LAUNCH_CHECK();
   return 0;
 }
@@ -368,7 +330,7 @@ int xt_direct_set_timeout_ms(xt_direct_comm* c, int32_t ms) {
   return 0;
 }
 
-int xt_direct_status(xt_direct_comm* c, int32_t* calls, int32_t* seq, int32_t* error_bits, int32_t* mem_kind) {
+int xt_direct_status(xt_direct_comm* c, int32_t* calls, int32_t* seq, int32_t* error_bits) {
   XT_REQUIRE(c, "xt_direct_status: null comm");
   uint32_t w[2] = {0, 0};
   XT_CHECK_HIP(hipDeviceSynchronize());
@@ -376,7 +338,6 @@ int xt_direct_status(xt_direct_comm* c, int32_t* calls, int32_t* seq, int32_t* e
   if (calls) *calls = c->calls;
   if (seq) *seq = (int32_t)w[0];
   if (error_bits) *error_bits = (int32_t)w[1];
-  if (mem_kind) *mem_kind = c->mem_kind;
   return 0;
 }
 

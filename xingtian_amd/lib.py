@@ -119,14 +119,14 @@ SIGNATURES = {
     "xt_net_apply": (c_int32, [_P, c_float, c_float, c_float, c_float, c_float, c_float, _P]),
     "xt_net_layer_offsets": (c_int32, [_P, c_int32, POINTER(c_int64)]),
     "xt_net_time_layer": (c_int32, [_P, c_int32, c_int32, _P, _P, c_int32, c_int32, POINTER(c_float), _P]),
-    "xt_direct_create": (c_int32, [c_int32, c_int32, c_int64, c_int32, _P, POINTER(c_void_p)]),
+    "xt_direct_create": (c_int32, [c_int32, c_int32, c_int64, _P, POINTER(c_void_p)]),
     "xt_direct_connect": (c_int32, [_P, _P]),
     "xt_direct_connect_local": (c_int32, [_P, POINTER(c_void_p)]),
     "xt_allreduce_direct": (c_int32, [_P, _P, c_int64, _P]),
     "xt_allreduce_direct_group": (c_int32, [c_int32, POINTER(c_void_p), POINTER(c_void_p), c_int64, POINTER(c_void_p)]),
     "xt_direct_exchange_hook": (c_int32, [_P, c_int64, _P, _P]),
     "xt_direct_set_timeout_ms": (c_int32, [_P, c_int32]),
-    "xt_direct_status": (c_int32, [_P, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
+    "xt_direct_status": (c_int32, [_P, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
     "xt_direct_destroy": (c_int32, [_P]),
 }
 

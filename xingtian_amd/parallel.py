@@ -308,9 +308,7 @@ class DirectComm(object):
     handles through the ``torch.distributed`` group that already exists (any backend; ``handles=`` passes them
     explicitly) and maps the peers' blocks.  N processes on ONE GPU take exactly the same code path (the tests)."""
 
-    MEM_KINDS = {"auto": 0, "finegrained": 1, "uncached": 2}
-
-    def __init__(self, rank, world, max_count, timeout_ms=None, mem_kind="auto"):
+    def __init__(self, rank, world, max_count, timeout_ms=None):
         import ctypes
         from xingtian_amd import lib as L
         self._ct, self._L = ctypes, L
@@ -318,8 +316,8 @@ class DirectComm(object):
         self.rank, self.world, self.max_count = int(rank), int(world), int(max_count)
         self._handle_buf = ctypes.create_string_buffer(L.DIRECT_HANDLE_BYTES)
         self.comm = ctypes.c_void_p()
-        L.check(self.lib.xt_direct_create(self.rank, self.world, self.max_count, self.MEM_KINDS[mem_kind], self._handle_buf,
-                                          ctypes.byref(self.comm)), "xt_direct_create")
+        L.check(self.lib.xt_direct_create(self.rank, self.world, self.max_count, self._handle_buf, ctypes.byref(self.comm)),
+                "xt_direct_create")
         if timeout_ms:
             L.check(self.lib.xt_direct_set_timeout_ms(self.comm, int(timeout_ms)), "xt_direct_set_timeout_ms")
         self.connected = self.world == 1
@@ -346,10 +344,10 @@ class DirectComm(object):
         return self
 
     @staticmethod
-    def local_group(world, max_count, timeout_ms=None, mem_kind="auto"):
+    def local_group(world, max_count, timeout_ms=None):
         """``world`` logical ranks inside THIS process (one device): tests, and single-process multi-stream drivers."""
         import ctypes
-        ranks = [DirectComm(r, world, max_count, timeout_ms, mem_kind) for r in range(world)]
+        ranks = [DirectComm(r, world, max_count, timeout_ms) for r in range(world)]
         arr = (ctypes.c_void_p * world)(*[c.comm for c in ranks])
         for c in ranks:
             if world > 1:
@@ -388,12 +386,12 @@ class DirectComm(object):
         self._L.check(net.lib.xt_net_set_grad_exchange(net.handle, None, None), "xt_net_set_grad_exchange")
 
     def status(self):
-        """dict(calls, seq, error_bits, mem_kind): ``error_bits`` != 0 -> a bounded wait ran out (1: a peer's scatter data,
-        2: a peer's reduced slice); ``mem_kind`` 1 fine-grained, 2 uncached device memory.  Synchronises."""
+        """dict(calls, seq, error_bits): ``error_bits`` != 0 -> a bounded wait ran out (1: a peer's scatter data, 2: a peer's
+        reduced slice).  Synchronises the device."""
         c = self._ct
-        v = [c.c_int32(0) for _ in range(4)]
+        v = [c.c_int32(0) for _ in range(3)]
         self._L.check(self.lib.xt_direct_status(self.comm, *[c.byref(x) for x in v]), "xt_direct_status")
-        return dict(zip(("calls", "seq", "error_bits", "mem_kind"), (int(x.value) for x in v)))
+        return dict(zip(("calls", "seq", "error_bits"), (int(x.value) for x in v)))
 
     def destroy(self):
         if self.comm:
