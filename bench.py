@@ -1260,7 +1260,7 @@ def main():
         torch.distributed group; works with the ranks on N GPUs or sharing one"""
         if comm["direct"] is None:
             from xingtian_amd.parallel import DirectComm
-            comm["direct"] = DirectComm(rank, world, spec.n_flat, timeout_ms=20000).connect()
+            comm["direct"] = DirectComm(rank, world, spec.n_flat, timeout_ms=3000).connect()
         return comm["direct"]
 
     def get_rccl():

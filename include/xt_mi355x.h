@@ -457,7 +457,7 @@ int xt_net_rccl_status(const xt_net* net, int32_t* calls, int32_t* last_error);
  *                      replicas receive BIT-IDENTICAL results.  count <= max_count, buf 16-byte aligned.  All ranks must
  *                      call it the same number of times with the same count.  Waits are bounded (default 2 s): a missing
  *                      peer sets an error bit (xt_direct_status: 1 = scatter data never arrived, 2 = reduced slices never
- *                      arrived) instead of hanging the device.
+ *                      arrived) instead of hanging the device; the bit is sticky and later waits of the comm return at once.
  *   xt_direct_exchange_hook  xt_grad_exchange_fn adapter: xt_net_set_grad_exchange_ex(net, xt_direct_exchange_hook, comm, 0)
  *                      makes xt_net_ppo_train / xt_net_impala_train exchange through this comm (one bucket per step).
  */
@@ -473,6 +473,9 @@ int xt_allreduce_direct_group(int32_t n, xt_direct_comm* const* comms, float* co
                               void* const* streams);
 int xt_direct_exchange_hook(float* grads, int64_t count, void* user, void* stream);
 int xt_direct_set_timeout_ms(xt_direct_comm* comm, int32_t ms);
+/* xt_allreduce_direct as ONE launch (default, fused = 1: every block runs scatter -> reduce -> gather and only ever waits for
+ * other RANKS' flags) or as the three launches described above (fused = 0; what the in-process group call always uses). */
+int xt_direct_set_fused(xt_direct_comm* comm, int32_t fused);
 int xt_direct_status(xt_direct_comm* comm, int32_t* calls, int32_t* seq, int32_t* error_bits);
 int xt_direct_destroy(xt_direct_comm* comm);
 

@@ -30,11 +30,12 @@ def expected_sum(it, world, count):
 
 def main():
     outdir, iters, batch = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    mode = sys.argv[4] if len(sys.argv) > 4 else "fused"          # "fused": one launch per all-reduce; "chain": three
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from xingtian_amd.parallel import DirectComm
-    comm = DirectComm(rank, world, max(COUNTS), timeout_ms=30000).connect()
+    comm = DirectComm(rank, world, max(COUNTS), timeout_ms=30000).connect().set_fused(mode == "fused")
     it = 0
     bad = []
     while it < iters:
@@ -51,8 +52,20 @@ def main():
         it += len(todo)
     st = comm.status()
     ok = (not bad) and st["error_bits"] == 0 and st["seq"] == iters and st["calls"] == iters
+    # timing (all ranks share ONE GPU: the kernel-side chain + the local traffic of N ranks, not xGMI)
+    import time
+    buf = torch.from_numpy(rank_input(0, rank, COUNTS[0])).cuda()
+    for _ in range(5):
+        comm.all_reduce_(buf)
+    torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(100):
+        comm.all_reduce_(buf)
+    torch.cuda.synchronize()
+    us = 1e6 * (time.perf_counter() - t0) / 100
     with open(os.path.join(outdir, "direct_r{}.txt".format(rank)), "w") as f:
-        f.write("{} bad={} status={}\n".format("OK" if ok else "FAIL", bad[:10], st))
+        f.write("{} bad={} status={} mode={} us_per_allreduce_{}_floats={:.1f}\n".format("OK" if ok else "FAIL", bad[:10], st, mode,
+                                                                                       COUNTS[0], us))
     dist.barrier()
     comm.destroy()
     dist.destroy_process_group()

@@ -46,6 +46,10 @@ def _worker(rank, world, port, out):
         assert [rr.takes() for _ in range(5)] == [k % world == rank for k in range(5)]
         rr.new_rollout()
         assert rr.takes() == (rank == 0) and rr.is_publisher == (rank == 0) and rr.graph_capable
+        # RCCL inside a replayed hipGraph has only met one rank here: eager enqueue unless DP_GRAPH opts in
+        assert not LearnerDP.from_config({"DP_EXCHANGE": "rccl"}).graph_capable
+        assert LearnerDP.from_config({"DP_EXCHANGE": "rccl", "DP_GRAPH": True}).graph_capable
+        assert not LearnerDP.from_config({"DP_EXCHANGE": "direct", "DP_GRAPH": False}).graph_capable
         with pytest.raises(ValueError, match="divisible"):
             rr.ppo_cfg(_FakeNet(), dict(BATCH_SIZE=321))
         # weak: full local minibatches, gradients averaged; every rank serves its own explorers

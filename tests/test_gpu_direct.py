@@ -79,22 +79,33 @@ def test_a_missing_peer_times_out_with_an_error_bit_instead_of_hanging():
     ranks = DirectComm.local_group(2, 4096, timeout_ms=50)
     try:
         x = torch.ones(4096, dtype=torch.float32, device="cuda")
+        import time
+        t0 = time.perf_counter()
         ranks[0].all_reduce_(x)
         torch.cuda.synchronize()
+        first = time.perf_counter() - t0
         st = ranks[0].status()
         assert st["error_bits"] & 1, st
+        # the error is sticky: the next all-reduces of this comm do not wait again
+        t0 = time.perf_counter()
+        for _ in range(10):
+            ranks[0].all_reduce_(x)
+        torch.cuda.synchronize()
+        assert time.perf_counter() - t0 < max(0.05, first), (first, time.perf_counter() - t0)
     finally:
         for c in ranks:
             c.destroy()
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_n_processes_on_one_gpu_over_ipc_handles(tmp_path, world):
+@pytest.mark.parametrize("world,mode", [(2, "fused"), (4, "fused"), (8, "fused"), (2, "chain"), (8, "chain")])
+def test_n_processes_on_one_gpu_over_ipc_handles(tmp_path, world, mode):
     """200 all-reduces in batches of 50 back-to-back launches per rank, sizes cycling through the PpoCnn / ImpalaCnnOpt flat
-    gradient sizes and odd tails: every rank's result bitwise = the fixed-order host sum, no timeout, sequence = 200."""
+    gradient sizes, odd tails and counts smaller than the number of ranks (empty slices): every rank's result bitwise = the
+    fixed-order host sum, no timeout, sequence = 200 -- as ONE launch per all-reduce (fused, the default) and as the
+    three-launch chain."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "direct_worker.py"), str(tmp_path),
-           "200", "50"]
+           "200", "50", mode]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
     outs = []
@@ -102,3 +113,4 @@ def test_n_processes_on_one_gpu_over_ipc_handles(tmp_path, world):
         p = os.path.join(str(tmp_path), "direct_r{}.txt".format(r))
         outs.append(open(p).read() if os.path.exists(p) else "missing")
     assert proc.returncode == 0 and all(o.startswith("OK") for o in outs), (outs, proc.stdout.decode()[-2000:])
+    print("direct all-reduce,", world, "processes on one GPU:", outs[0].strip().split("mode=")[-1])

@@ -73,7 +73,9 @@ __device__ __forceinline__ void publish_fence() { asm volatile("s_waitcnt vmcnt(
 // bounded wait until flags[off + p] == seq for every p < world (thread 0 of the block polls, the block follows)
 __device__ __forceinline__ void wait_all(const uint32_t* flags, int off, int world, uint32_t seq, uint32_t* ctl,
                                          unsigned long long timeout_ticks, uint32_t errbit) {
-  if (threadIdx.x == 0) {
+  // the error word is sticky: once a wait of this comm has run out, later waits do not wait again (a comm that lost a peer
+  // costs ONE time-out, then every kernel runs through with whatever is there and xt_direct_status tells the host)
+  if (threadIdx.x == 0 && __hip_atomic_load(ctl + kCtlErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
     const unsigned long long t0 = wall_clock64();
     for (int p = 0; p < world; ++p) {
       int spins = 0;
@@ -172,6 +174,104 @@ __global__ void __launch_bounds__(256) xgmi_gather_kernel(float* __restrict__ gr
   }
 }
 
+// The three phases in ONE launch (per-process path): a block pushes its chunk of the gradient (scatter), then -- without
+// leaving the kernel -- waits for the peers' chunks of ITS share of this rank's slice, reduces and pushes it (reduce), then
+// waits for the reduced slices and copies its chunk of the result back (gather).  Cross-RANK dependencies only (flags); no
+// block ever waits for another block of its own launch, so the grid needs no barrier -- but every block of every rank's
+// launch must be resident, which 104-208 blocks per rank are, also with eight ranks on one GPU.  Saves two kernel
+// boundaries and two cold prologues per all-reduce (tools/direct_probe.py --procs: see DESIGN.md section 5).
+// Tickets count VECTORS (a block's scatter chunk may straddle two slices): whoever completes a slice raises its flag.
+constexpr int kFusedVecs = 2048;            // float4 per block in the scatter / gather phases (32 KB)
+__global__ void __launch_bounds__(256) xgmi_fused_kernel(float* __restrict__ grads, const float* __restrict__ inbox,
+                                                         const float* __restrict__ result, int64_t slice_cap, int64_t count,
+                                                         int rank, int world, DirectPeers peers, const uint32_t* my_flags,
+                                                         uint32_t* ctl, unsigned long long timeout_ticks) {
+  const uint32_t seq = ctl[kCtlSeq] + 1;
+  const int64_t nvec = (count + 3) / 4;
+  __shared__ uint32_t s_cnt[kMaxWorld];
+  if (threadIdx.x < kMaxWorld) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  // ---- scatter
+  {
+    const int64_t lo = (int64_t)blockIdx.x * kFusedVecs;
+    const int64_t hi = lo + kFusedVecs < nvec ? lo + kFusedVecs : nvec;
+    const int64_t base = nvec / world, rem = nvec % world;
+    for (int64_t v = lo + threadIdx.x; v < hi; v += 256) {
+      // owner of vector v under the balanced contiguous split (the first `rem` slices hold base + 1 vectors)
+      const int64_t cut = rem * (base + 1);
+      const int q = v < cut ? (int)(v / (base + 1)) : (int)(rem + (base ? (v - cut) / base : 0));
+      const int64_t b = q * base + (q < rem ? q : rem);
+      reinterpret_cast<float4*>(peers.inbox_me[q])[v - b] = load_vec_tail(grads, v, count);
+      atomicAdd(&s_cnt[q], 1u);
+    }
+    publish_fence();
+    __syncthreads();
+    if (threadIdx.x < world) {
+      const int q = threadIdx.x;
+      int64_t b, e;
+      slice_of(nvec, q, world, b, e);
+      const uint32_t mine = s_cnt[q];
+      // (an EMPTY slice -- fewer vectors than ranks -- has no last contributor: block 0 raises its flag)
+      const bool last = mine ? atomicAdd(ctl + kCtlScat + q, mine) + mine == (uint32_t)(e - b) : (e == b && blockIdx.x == 0);
+      if (last) __hip_atomic_store(peers.flags[q] + kReadyOff + rank, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  // ---- reduce: this block's share of my slice
+  {
+    wait_all(my_flags, kReadyOff, world, seq, ctl, timeout_ticks, 1u);
+    int64_t b, e;
+    slice_of(nvec, rank, world, b, e);
+    const int64_t per = ((e - b) + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = b + (int64_t)blockIdx.x * per;
+    const int64_t hi = lo + per < e ? lo + per : e;
+    for (int64_t v = lo + threadIdx.x; v < hi; v += 256) {
+      float4 acc = *reinterpret_cast<const float4*>(inbox + (v - b) * 4);
+      for (int p = 1; p < world; ++p) {           // FIXED order 0, 1, ..., N-1
+        const float4 x = *reinterpret_cast<const float4*>(inbox + p * slice_cap + (v - b) * 4);
+        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+      }
+      for (int p = 0; p < world; ++p) reinterpret_cast<float4*>(peers.result[p])[v] = acc;
+    }
+    publish_fence();
+    __syncthreads();
+    const uint32_t mine = hi > lo ? (uint32_t)(hi - lo) : 0u;
+    if (threadIdx.x == 0) {
+      const bool last = mine ? atomicAdd(ctl + kCtlRed, mine) + mine == (uint32_t)(e - b) : (e == b && blockIdx.x == 0);
+      if (last)
+        for (int p = 0; p < world; ++p)
+          __hip_atomic_store(peers.flags[p] + kDoneOff + rank, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  // ---- gather
+  wait_all(my_flags, kDoneOff, world, seq, ctl, timeout_ticks, 2u);
+  {
+    const int64_t lo = (int64_t)blockIdx.x * kFusedVecs;
+    const int64_t hi = lo + kFusedVecs < nvec ? lo + kFusedVecs : nvec;
+    for (int64_t v = lo + threadIdx.x; v < hi; v += 256) {
+      const float4 x = reinterpret_cast<const float4*>(result)[v];
+      const int64_t i = v * 4;
+      if (i + 4 <= count) {
+        *reinterpret_cast<float4*>(grads + i) = x;
+      } else {
+        if (i < count) grads[i] = x.x;
+        if (i + 1 < count) grads[i + 1] = x.y;
+        if (i + 2 < count) grads[i + 2] = x.z;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(ctl + kCtlGat, 1u) == gridDim.x - 1) {
+      ctl[kCtlRed] = 0;
+      ctl[kCtlGat] = 0;
+      for (int q = 0; q < world; ++q) ctl[kCtlScat + q] = 0;
+      __threadfence();
+      ctl[kCtlSeq] = seq;
+    }
+  }
+}
+
 }  // namespace xt
 
 struct xt_direct_comm {
@@ -185,6 +285,7 @@ struct xt_direct_comm {
   uint32_t* ctl = nullptr;                      // device-local control words
   unsigned long long timeout_ticks = 200000000ull;   // 2 s of the 100 MHz wall clock
   int calls = 0;
+  int fused = 1;                                // xt_allreduce_direct: one launch (xgmi_fused_kernel) instead of three
   xt::DirectPeers peers = {};
 };
 
@@ -307,7 +408,27 @@ static int direct_enqueue(xt_direct_comm* c, float* buf, int64_t count, int phas
 }
 
 int xt_allreduce_direct(xt_direct_comm* c, float* buf, int64_t count, void* stream) {
-  return direct_enqueue(c, buf, count, -1, static_cast<hipStream_t>(stream));
+  if (!c || !c->fused || c->world == 1) return direct_enqueue(c, buf, count, -1, static_cast<hipStream_t>(stream));
+  XT_REQUIRE(buf, "xt_allreduce_direct: null argument");
+  XT_REQUIRE(count > 0 && count <= c->max_count, "xt_allreduce_direct: count %lld outside (0, %lld]", (long long)count,
+             (long long)c->max_count);
+  XT_REQUIRE((reinterpret_cast<uintptr_t>(buf) & 15) == 0, "xt_allreduce_direct: the buffer must be 16-byte aligned");
+  XT_REQUIRE(c->connected, "xt_allreduce_direct: xt_direct_connect has not been called");
+  c->calls++;
+  const int64_t nvec = (count + 3) / 4;
+  const unsigned g = (unsigned)((nvec + xt::kFusedVecs - 1) / xt::kFusedVecs);
+  hipLaunchKernelGGL(xt::xgmi_fused_kernel, dim3(g ? g : 1), dim3(256), 0, static_cast<hipStream_t>(stream), buf,
+                     reinterpret_cast<const float*>(c->block + c->inbox_off),
+                     reinterpret_cast<const float*>(c->block + c->result_off), c->slice_cap, count, c->rank, c->world, c->peers,
+                     reinterpret_cast<const uint32_t*>(c->block), c->ctl, c->timeout_ticks);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
+int xt_direct_set_fused(xt_direct_comm* c, int32_t fused) {
+  XT_REQUIRE(c, "xt_direct_set_fused: null comm");
+  c->fused = fused ? 1 : 0;
+  return 0;
 }
 
 // N logical ranks driven by ONE host thread (in-process groups): the launches are issued phase by phase, so that no kernel

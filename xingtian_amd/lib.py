@@ -126,6 +126,7 @@ SIGNATURES = {
     "xt_allreduce_direct_group": (c_int32, [c_int32, POINTER(c_void_p), POINTER(c_void_p), c_int64, POINTER(c_void_p)]),
     "xt_direct_exchange_hook": (c_int32, [_P, c_int64, _P, _P]),
     "xt_direct_set_timeout_ms": (c_int32, [_P, c_int32]),
+    "xt_direct_set_fused": (c_int32, [_P, c_int32]),
     "xt_direct_status": (c_int32, [_P, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
     "xt_direct_destroy": (c_int32, [_P]),
 }

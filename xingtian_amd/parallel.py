@@ -366,6 +366,11 @@ class DirectComm(object):
         sts = (ctypes.c_void_p * n)(*[s.cuda_stream for s in streams])
         c0._L.check(c0.lib.xt_allreduce_direct_group(n, comms, ptrs, int(bufs[0].numel()), sts), "xt_allreduce_direct_group")
 
+    def set_fused(self, fused):
+        """one launch per all-reduce (default) or the three-launch form (``xt_direct_set_fused``)"""
+        self._L.check(self.lib.xt_direct_set_fused(self.comm, 1 if fused else 0), "xt_direct_set_fused")
+        return self
+
     def all_reduce_(self, flat, stream_ptr=None):
         """in-place SUM of a float32 device tensor over the ranks, enqueued on the given (default: current) stream"""
         sp = stream_ptr if stream_ptr is not None else self._L.stream_ptr()
@@ -431,6 +436,10 @@ class LearnerDP(object):
       DP_EXCHANGE  "rccl" (default: raw ncclAllReduce enqueued by the library, captured into the update's hipGraph) |
                    "direct" (xt_allreduce_direct over peer-mapped memory, also in-graph) | "torch" (torch.distributed from
                    a host callback: any backend, not capturable -- tests on one GPU go through gloo)
+      DP_GRAPH     capture the data-parallel update into a hipGraph?  Default: yes for "direct" (kernels only), NO for
+                   "rccl": RCCL collectives inside a replayed hipGraph have only ever been validated with a 1-rank
+                   communicator here, and the eager form (ONE C call per update enqueues every kernel and every
+                   ncclAllReduce) measured the same on one rank (7.73 vs 7.77 ms); `DP_GRAPH: true` opts in.
       DP_BACKEND   torch.distributed backend when the process group does not exist yet ("nccl")
       DP_DEVICE    device index (default LOCAL_RANK)
       DP_PUBLISH   "rank0" | "all": which ranks answer ``checkpoint_ready`` / ``if_save`` with True, i.e. hand weights to
@@ -439,8 +448,9 @@ class LearnerDP(object):
                    bit-identical, so any of them may serve.
     """
 
-    def __init__(self, rank, world, mode, feed, exchange, publish=None):
+    def __init__(self, rank, world, mode, feed, exchange, publish=None, graph=None):
         self.rank, self.world, self.mode, self.feed, self.exchange = rank, world, mode, feed, exchange
+        self.graph = (exchange == "direct") if graph is None else bool(graph)
         self.publish = publish or ("all" if feed == "sharded" else "rank0")
         if self.publish not in ("rank0", "all"):
             raise ValueError("model_config.DP_PUBLISH must be rank0 | all, got {!r}".format(self.publish))
@@ -476,7 +486,7 @@ class LearnerDP(object):
         exchange = cfg.get("DP_EXCHANGE", "rccl")
         if exchange not in ("rccl", "direct", "torch"):
             raise ValueError("model_config.DP_EXCHANGE must be rccl | direct | torch, got {!r}".format(exchange))
-        return LearnerDP(rank, world, mode, feed, exchange, cfg.get("DP_PUBLISH"))
+        return LearnerDP(rank, world, mode, feed, exchange, cfg.get("DP_PUBLISH"), cfg.get("DP_GRAPH"))
 
     @staticmethod
     def device_index(model_config):
@@ -510,8 +520,9 @@ class LearnerDP(object):
 
     @property
     def graph_capable(self):
-        """the exchange is kernels / RCCL calls on the stream (capturable); the torch.distributed callback is host-synchronous"""
-        return self.exchange in ("rccl", "direct")
+        """may the data-parallel update be captured into a hipGraph?  The torch.distributed callback is host-synchronous
+        (never); kernels-only exchanges yes; RCCL calls only when DP_GRAPH asks for it (see the class docstring)"""
+        return self.exchange in ("rccl", "direct") and self.graph
 
     @property
     def is_publisher(self):
