@@ -17,7 +17,7 @@ T_LEN, N_TRAJ, A_DIM, DIM = 16, 6, 4, 42
 PPO_MC = dict(LR=2.5e-4, LOSS_CLIPPING=0.1, ENTROPY_LOSS=0.003, VF_CLIP=5.0, CRITIC_LOSS_COEF=1.0, MAX_GRAD_NORM=5.0,
               BATCH_SIZE=32, NUM_SGD_ITER=2, VF_SHARE_LAYERS=True, activation="relu", hidden_sizes=[64],
               action_type="Categorical", SEED=3, SUMMARY=False)
-UPDATES = 2
+UPDATES = int(os.environ.get("XT_DP_UPDATES", "2"))       # (the soak test raises it)
 
 
 def ppo_model_info(extra):

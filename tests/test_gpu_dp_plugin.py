@@ -28,10 +28,12 @@ def _free_port():
     return p
 
 
-def _run(tmp_path, case, world=2):
+def _run(tmp_path, case, world=2, updates=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dp_plugin_worker.py"), str(tmp_path), case]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    if updates:
+        env["XT_DP_UPDATES"] = str(updates)
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert proc.returncode == 0, proc.stdout.decode()[-3000:]
     res = [np.load(os.path.join(str(tmp_path), "{}_r{}.npz".format(case, r))) for r in range(world)]
@@ -188,3 +190,13 @@ def test_impala_weak_sums_the_ranks_full_chunks(tmp_path):
     ref, start, losses = _single_impala(80, [0, 2, 1, 3])
     assert _delta_err(res[0]["params"], ref, start) < 5e-3
     assert np.allclose(res[0]["losses"], losses, rtol=2e-3, atol=1e-4)
+
+
+def test_direct_exchange_soak_25_updates_of_the_replayed_graph_stay_bitwise_on_the_gloo_path(tmp_path):
+    """25 PPO updates (150 SGD steps = 150 all-reduces inside the replayed hipGraph, one launch each) through the plugin pair
+    on two ranks: parameters and every reported loss bit for bit those of the host-synchronous gloo exchange -- a stale
+    inbox / result read or a lost flag anywhere in the run would show."""
+    a = _run(tmp_path, "ppo-strict-replicated-torch", updates=25)
+    b = _run(tmp_path, "ppo-strict-replicated-direct", updates=25)
+    assert len(a[0]["losses"]) == 25
+    assert np.array_equal(a[0]["params"], b[0]["params"]) and np.array_equal(a[0]["losses"], b[0]["losses"])
