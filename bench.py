@@ -1074,10 +1074,18 @@ def model_scaling(spec, dev, updates=6):
     link_gbps, hop_us = 153.0, 2.0
     s_bytes = spec.n_flat * 4
     rng = np.random.default_rng(5)
-    step_us = {}
-    for rows in (320, 160, 80, 40):
+    step_us, step_us_dp = {}, {}
+    from xingtian_amd.parallel import DirectComm
+    for rows, dp_form in [(r, f) for r in (320, 160, 80, 40) for f in (False, True)]:
         n = ENV_NUM * T_LEN * rows // 320           # the same 52 SGD steps per update at every shard size
         net = HipActorCritic(spec, max_batch=rows, device=str(dev), seed=0)
+        one = None
+        if dp_form:
+            # the data-parallel FORM of the step with nobody to exchange with: a one-rank direct comm is the identity (no
+            # launch), so this times what the step costs beyond the all-reduce itself -- the gradient-reduction launch with
+            # the loss / step-size block, then squared-norm partials + Adam on the "exchanged" gradient (12 launches vs 11)
+            one = DirectComm(0, 1, spec.n_flat)
+            one.attach(net)
         d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         obs = d(rng.integers(0, 256, (n,) + STATE_DIM, dtype=np.uint8))
         act, logp = d(rng.integers(0, A_DIM, n).astype(np.int32)), d((-np.abs(rng.standard_normal(n)) - 0.5).astype(np.float32))
@@ -1092,7 +1100,10 @@ def model_scaling(spec, dev, updates=6):
             net.ppo_train(cfg, obs, perm, act, logp, adv, oldv, tgt, use_graph=True)
         torch.cuda.synchronize()
         nsteps = CFG["NUM_SGD_ITER"] * ((n + rows - 1) // rows)
-        step_us[rows] = 1e6 * (time.perf_counter() - t0) / (updates * nsteps)
+        (step_us_dp if dp_form else step_us)[rows] = 1e6 * (time.perf_counter() - t0) / (updates * nsteps)
+        if one is not None:
+            one.detach(net)
+            one.destroy()
         del net
         torch.cuda.empty_cache()
 
@@ -1133,17 +1144,20 @@ def model_scaling(spec, dev, updates=6):
     frames_per_update = FRAME_SKIP * ENV_NUM * T_LEN
     sgd_steps = CFG["NUM_SGD_ITER"] * ((ENV_NUM * T_LEN + CFG["BATCH_SIZE"] - 1) // CFG["BATCH_SIZE"])
     base = frames_per_update / (sgd_steps * step_us[320] * 1e-6)
-    out = {"MODELLED": "no multi-GPU box was available to the builder: measured 1-GPU step time at the shard size + a modelled, "
-                       "non-overlapped all-reduce; NOT a measurement of N GPUs",
+    out = {"MODELLED": "no multi-GPU box was available to the builder: measured 1-GPU time of the data-parallel FORM of the step at the "
+                       "shard size + a modelled, non-overlapped all-reduce; NOT a measurement of N GPUs",
            "assumptions": {"allreduce_bytes": s_bytes, "xgmi_link_GBps": link_gbps, "hop_latency_us": hop_us,
                            "direct_chain_us_measured_one_device": None if chain_us is None else round(chain_us, 1),
                            "overlap": "none (the two-bucket overlap variants hide the conv backward's ~55 us at 320 rows; not credited)"},
-           "measured_sgd_step_us_by_rows": {str(k): round(v, 2) for k, v in step_us.items()}, "strict": {}, "weak": {}}
+           "measured_sgd_step_us_by_rows": {str(k): round(v, 2) for k, v in step_us.items()},
+           "measured_dp_form_step_us_by_rows": {str(k): round(v, 2) for k, v in step_us_dp.items()}, "strict": {}, "weak": {}}
     for nr in (1, 2, 4, 8):
         rows = CFG["BATCH_SIZE"] // nr
         for kind in ("ring_one_link", "direct_2phase") + (("direct_2phase_measured_chain",) if chain_us else ()):
             ar = allreduce_us(nr, kind)
-            t_strict, t_weak = step_us[rows] + ar, step_us[320] + ar
+            # N > 1 runs the data-parallel FORM of the step (measured above), N = 1 the plain one
+            t_strict = (step_us_dp[rows] if nr > 1 else step_us[rows]) + ar
+            t_weak = (step_us_dp[320] if nr > 1 else step_us[320]) + ar
             v_strict = frames_per_update / (sgd_steps * t_strict * 1e-6)
             v_weak = nr * frames_per_update / (sgd_steps * t_weak * 1e-6)
             out["strict"].setdefault(str(nr), {})[kind] = {"value": v_strict, "step_us": round(t_strict, 1), "allreduce_us": round(ar, 1),

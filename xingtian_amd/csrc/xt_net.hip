@@ -49,6 +49,7 @@ int launch_grads_finish(GradTable*, float*, int, int*, const FinalizeArgs*, hipS
                         unsigned early = 0);
 int grads_finish_resident_blocks();
 int grads_finish_fused_grid(const GradTable*);
+int launch_sqnorm_partial(const float*, long long, float*, int*, hipStream_t);
 int launch_norm_finalize(const float*, int, float, float, float, float, float, int, float*, const LossArgs*, hipStream_t,
                          const float* lr_dev = nullptr);
 int launch_ppo_heads_fused(const PpoHeadArgs&, hipStream_t);
@@ -412,7 +413,10 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
                     bool defer_join = false) {
   XT_REQUIRE(n->params && n->ws, "xt_net: buffers not bound (call xt_net_bind)");
   XT_REQUIRE(B > 0 && B <= n->maxB, "xt_net_ppo_step: batch %d outside (0,%d]", B, n->maxB);
-  XT_REQUIRE(apply >= 0 && apply <= 2, "xt_net_ppo_step: bad apply mode %d", apply);
+  // apply (internal): 0 gradient only (+ a loss-reduction launch), 1 full step, 2 overlapped data-parallel exchange,
+  // 3 gradient + everything of the step's tail that does not depend on the EXCHANGED gradient (loss scalars, Adam step-size
+  //   advance: the extra block of the gradient-reduction launch), no update -- the data-parallel step of xt_net_ppo_train
+  XT_REQUIRE(apply >= 0 && apply <= 3, "xt_net_ppo_step: bad apply mode %d", apply);
   XT_REQUIRE(apply != 2 || (n->xchg && n->xchg_stream && n->xchg_fork && n->xchg_join),
              "xt_net_ppo_step: the overlapped exchange mode needs a hook installed with XT_XCHG_OVERLAP");
   const bool gauss = (n->action_type == XT_ACTION_DIAG_GAUSSIAN);
@@ -503,6 +507,13 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
   LossArgs la{};
   la.terms = n->ws + n->off_terms; la.B = B; la.ent_coef = c->ent_coef; la.critic_coef = c->critic_coef;
   la.inv_b = inv_b; la.out = lo; la.acc = loss_acc;
+  if (apply == 3) {
+    FinalizeArgs fin{};
+    fin.enable = 2; fin.counter = reinterpret_cast<unsigned int*>(n->ws + n->off_counter);
+    fin.clip_norm = c->max_grad_norm; fin.grad_scale = c->grad_scale; fin.lr = c->lr; fin.beta1 = c->beta1;
+    fin.beta2 = c->beta2; fin.state = n->state; fin.loss = la;
+    return grads_finish(n, B, &fin, st, 0, nullptr);
+  }
   if (apply == 1) {
     const int tail_mode = tuning().finalize_ticket ? 1 : 2;     // 1: the old "last block finalises" form (A/B)
     FinalizeArgs fin{};
@@ -866,15 +877,24 @@ static int ppo_train_enqueue(xt_net* net, const xt_ppo_cfg* c, const void* obs, 
       const bool overlap = (net->xchg_flags & XT_XCHG_OVERLAP) && net->n_trunks == 1 && net->layers.size() > 1 &&
                            off_a > 0 && net->pi_off > off_a && net->v_off > off_a && net->xchg_stream != nullptr;
       if (int rc = xt::ppo_step(net, &cc, obs, rows, B, action, old_logp, adv, old_v,
-                                target_v, overlap ? 2 : 0, nullptr, loss_acc, st))
+                                target_v, overlap ? 2 : 3, nullptr, loss_acc, st))
         return rc;
       if (overlap) {
         XT_REQUIRE(net->xchg(net->grads, off_a, net->xchg_user, st) == 0, "xt_net_ppo_train: gradient exchange hook failed");
         XT_CHECK_HIP(hipStreamWaitEvent(st, net->xchg_join, 0));      // first bucket's exchange has finished
-      } else {
-        XT_REQUIRE(net->xchg(net->grads, net->P, net->xchg_user, st) == 0, "xt_net_ppo_train: gradient exchange hook failed");
+        if (int rc = xt::net_apply(net, cc.lr, cc.beta1, cc.beta2, cc.eps, cc.max_grad_norm, cc.grad_scale, 0, nullptr, st))
+          return rc;
+        continue;
       }
-      if (int rc = xt::net_apply(net, cc.lr, cc.beta1, cc.beta2, cc.eps, cc.max_grad_norm, cc.grad_scale, 0, nullptr, st))
+      XT_REQUIRE(net->xchg(net->grads, net->P, net->xchg_user, st) == 0, "xt_net_ppo_train: gradient exchange hook failed");
+      // (round 5) the loss scalars and the Adam step-size advance rode in the gradient-reduction launch (apply == 3); what
+      // is left after the exchange: the squared-norm partials of the EXCHANGED gradient, then Adam, every block deriving
+      // the clip factor from them itself -- two launches instead of the four of the step-wise path (loss reduction,
+      // partials, finalize, Adam).  Same partials, same fixed-order sum: bitwise the step-wise path's parameters.
+      int nb = 0;
+      if (int rc = xt::launch_sqnorm_partial(net->grads, net->P, net->ws + net->off_norm, &nb, st)) return rc;
+      if (int rc = xt::launch_adam_clip(net->params, net->grads, net->m, net->v, net->P, cc.beta1, cc.beta2, cc.eps, net->state,
+                                        net->ws + net->off_norm, nb, cc.max_grad_norm, cc.grad_scale, st))
         return rc;
     }
   }

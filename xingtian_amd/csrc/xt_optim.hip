@@ -747,6 +747,20 @@ int launch_norm_finalize(const float* partial, int nblocks, float clip_norm, flo
   return 0;
 }
 
+// only the per-block squared-norm partials of a flat gradient (the first launch of launch_global_norm): for a consumer that
+// derives the clip factor itself (adam_tf_clip_kernel) -- the data-parallel step after the exchange
+int launch_sqnorm_partial(const float* grad, long long count, float* scratch, int* nblocks_out, hipStream_t st) {
+  XT_REQUIRE(count > 0 && grad && scratch && nblocks_out, "sqnorm_partial: bad arguments");
+  XT_REQUIRE(((uintptr_t)grad & 15) == 0, "sqnorm_partial: grad must be 16-byte aligned");
+  int nb = (int)((count / 4 + 255) / 256);
+  if (nb > kNormBlocks) nb = kNormBlocks;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nb), dim3(256), 0, st, grad, count, scratch);
+  XT_LAUNCH_CHECK();
+  *nblocks_out = nb;
+  return 0;
+}
+
 int launch_global_norm(const float* grad, long long count, float clip_norm, float grad_scale, float lr, float beta1,
                        float beta2, int advance, float* state, float* scratch, hipStream_t st, const float* lr_dev,
                        int* nblocks_out) {
