@@ -61,6 +61,29 @@ def impala_msgs(update):
     return out
 
 
+def yaml_config(extra):
+    """examples/breakout_ppo.yaml as the reference ships it (parsed, from the reference-executed fixture
+    tests/golden/learner_config.json) + the data-parallel keys in model_config: what INTEGRATION.md section 3b tells a
+    maintainer to hand to build_learner_algorithm in every rank"""
+    import copy
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "learner_config.json")) as f:
+        cfg = copy.deepcopy(json.load(f)["examples/breakout_ppo.yaml"]["config"])
+    cfg["model_para"]["actor"]["model_config"].update(dict(extra, SEED=6))
+    return cfg
+
+
+def yaml_trajs(update, env_num):
+    from test_gpu_learner import synth_ppo_rollout
+    out = []
+    for i in range(env_num):
+        rng = np.random.default_rng(9000 + 100 * update + i)
+        obs, lab = synth_ppo_rollout(rng, 128, (84, 84, 4), 4)
+        out.append({"cur_state": obs, "action": lab[0], "logp": lab[1], "adv": lab[2], "old_value": lab[3],
+                    "target_value": lab[4]})
+    return out
+
+
 def main():
     outdir, case = sys.argv[1], sys.argv[2]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -69,7 +92,17 @@ def main():
     alg_kind, mode, feed, exchange = case.split("-")
     extra = {"DP": mode, "DP_FEED": feed, "DP_EXCHANGE": exchange, "DP_BACKEND": "gloo", "DP_DEVICE": 0}
     losses, answers = [], []
-    if alg_kind == "ppo":
+    if alg_kind == "yaml":
+        from xingtian_amd.config import build_learner_algorithm
+        cfg = yaml_config(extra)
+        alg = build_learner_algorithm(cfg)
+        assert alg.prepare_data_times == cfg["env_num"] == 10
+        for u in range(UPDATES):
+            for tr in yaml_trajs(u, cfg["env_num"]):
+                alg.prepare_data(tr)
+            losses.append(float(alg.train(episode_num=u)))
+            answers.append(bool(alg.checkpoint_ready(u)))
+    elif alg_kind == "ppo":
         alg = alg_builder("PPO", ppo_model_info(extra), {"instance_num": N_TRAJ, "agent_num": 1})
         for u in range(UPDATES):
             for k, tr in enumerate(ppo_trajs(u)):

@@ -200,3 +200,26 @@ def test_direct_exchange_soak_25_updates_of_the_replayed_graph_stay_bitwise_on_t
     b = _run(tmp_path, "ppo-strict-replicated-direct", updates=25)
     assert len(a[0]["losses"]) == 25
     assert np.array_equal(a[0]["params"], b[0]["params"]) and np.array_equal(a[0]["losses"], b[0]["losses"])
+
+
+def test_breakout_ppo_yaml_through_build_learner_algorithm_as_two_ranks(tmp_path):
+    """INTEGRATION.md section 3b end to end: every rank runs ``build_learner_algorithm(<examples/breakout_ppo.yaml>)`` (the
+    reference's own YAML, env_num 10 x 128 steps, BATCH_SIZE 320, 4 epochs = 16 SGD steps of 160 + 160 rows) with only the
+    data-parallel keys added to ``model_config``; exchange = the direct all-reduce inside the replayed hipGraph.  Against the
+    single-process learner built from the same YAML."""
+    import dp_plugin_worker as W
+    from xingtian_amd.config import build_learner_algorithm
+    res = _run(tmp_path, "yaml-strict-replicated-direct")
+    alg = build_learner_algorithm(W.yaml_config({"DP": "off"}))
+    start = alg.actor.net.params.cpu().numpy().copy()
+    losses = []
+    for u in range(W.UPDATES):
+        for tr in W.yaml_trajs(u, 10):
+            alg.prepare_data(tr)
+        losses.append(float(alg.train(episode_num=u)))
+    torch.cuda.synchronize()
+    ref = alg.actor.net.params.cpu().numpy()
+    # 2 x 16 sign-like Adam steps on noise: the summation-order bar of the full-size update (test_gpu_learner: 0.15)
+    assert _delta_err(res[0]["params"], ref, start) < 0.15, _delta_err(res[0]["params"], ref, start)
+    assert np.allclose(res[0]["losses"], losses, rtol=5e-3, atol=1e-4), (res[0]["losses"], losses)
+    assert res[0]["answers"].all() and not res[1]["answers"].any()
