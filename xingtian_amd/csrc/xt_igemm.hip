@@ -115,8 +115,15 @@ template <int TI, int TJ, int SA, int SB>
 __device__ __forceinline__ void mma_tile(const float* As, const float* Bs, int a_off, int b_off,
                                          f32x16 (&acc)[TI][TJ], int lane) {
   const int kl = lane >> 5, il = lane & 31;
+  // XT_EXP_WGRAD_KK (experiment builds only, `make alt ALTFLAGS=-DXT_EXP_WGRAD_KK=6`; results are WRONG): issue only that
+  // many of the step's 16 fp32 MFMAs -- 6 x 64 cycles = the matrix-pipe time of a bf16x6 step (12 x 32) with every load, LDS
+  // write and barrier of the step left as it is: an UPPER BOUND of what moving the weight gradients to the bf16 pipe can
+  // return (tools/experiments/README.md, round 5)
+#ifndef XT_EXP_WGRAD_KK
+#define XT_EXP_WGRAD_KK 16
+#endif
 #pragma unroll
-  for (int kk = 0; kk < 16; ++kk) {        // (reads of the whole step hoisted in front of the MFMAs: slower with three
+  for (int kk = 0; kk < XT_EXP_WGRAD_KK; ++kk) {        // (reads of the whole step hoisted in front of the MFMAs: slower with three
     float a[TI], b[TJ];                    //  co-resident waves per SIMD -- conv2/conv3/Dense bwd +1.1/+1.1/+1.3 us)
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti) a[ti] = As[(kk * 2 + kl) * SA + a_off + ti * 32 + il];
