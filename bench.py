@@ -585,7 +585,7 @@ def bench_e2e_ppo(env_num, min_seconds=1.0, max_updates=40, via_ring=False, lear
     train() incl. the H2D of the uint8 rollout + get_weights D2H), through the plugin classes exactly as
     xt/framework/learner.py:306-313,346-348,361-363 drives them.  Host arrays are plain (pageable) numpy."""
     from xingtian_amd.algorithm import alg_builder
-    from oracle import returns      # baseline-side helper only: the actors' GAE (not timed, not the product path)
+    from xingtian_amd import ops      # the actors' GAE for the synthetic trajectories (not timed): the product's own bit-exact kernel
     model_info = {"actor": {"model_name": "PpoCnn", "state_dim": list(STATE_DIM), "action_dim": A_DIM,
                             "input_dtype": "uint8",
                             "model_config": dict(CFG, SUMMARY=False, VF_SHARE_LAYERS=True, activation="relu",
@@ -593,8 +593,9 @@ def bench_e2e_ppo(env_num, min_seconds=1.0, max_updates=40, via_ring=False, lear
     alg = alg_builder("PPO", model_info, {"instance_num": env_num, "agent_num": 1})
     obs, action, logp, value, reward, done = synth_rollout(100 + env_num, env_num)
     trajs = []
+    adv_all, oldv_all, tgt_all = ops.gae(value, reward, done, 0.99, 0.95)      # [env_num, T] float64 / float32 / float64
     for i in range(env_num):
-        a, ov, tg = returns.gae(value[i].reshape(-1, 1), reward[i].copy(), done[i])
+        a, ov, tg = adv_all[i].reshape(-1, 1), oldv_all[i].reshape(-1, 1), tgt_all[i].reshape(-1, 1)
         sl = slice(i * T_LEN, (i + 1) * T_LEN)
         if learner_gae:
             # the trajectory as the explorer holds it BEFORE data_proc: the learner stages value / reward / done with the
