@@ -115,6 +115,9 @@ typedef struct xt_tuning {
   int32_t tail_fused;         /* 1: slab reduction + global norm + clip + Adam in ONE launch: the thread that reduced a group of
                                  elements also updates it, only the squared-norm partials and the step size cross a grid
                                  barrier (all workgroups resident, checked; Adam only; ABI >= 8)                          */
+  int32_t dense_wgrad_x6;     /* 1 (default): the weight gradient of Dense trunk layers on the bf16 matrix cores (bf16x6, both
+                                 operands split when they are written to LDS) inside the fused backward launch; 0: fp32 MFMA
+                                 (ABI >= 10; measured 18.0 -> 16.9 us for PpoCnn's Dense backward, conv layers lose)        */
 } xt_tuning;
 int xt_tuning_get(xt_tuning* out);
 int xt_tuning_set(const xt_tuning* in);

@@ -486,19 +486,44 @@ struct WgradArgs {
                    // partials of the global norm, so that the reduction launch does not read the tensor again
 };
 
+// XT_EXP_WGRAD_X6 (experiment builds: `make alt ALTFLAGS=-DXT_EXP_WGRAD_X6=1`): the LDS-tiled fp32 weight gradients on the
+// bf16 matrix cores with a CONSUMER-side split -- both operands split into three bf16 planes when they are written to LDS
+// (natural [m][k] / [m][n] orientation, gathered by ds_read_b64_tr_b16 like the forward's weight operand), six
+// v_mfma_f32_32x32x16_bf16 per 16 rows.  Round 2 measured this idea at < 0.3 us; round 5 measured the CEILING of the
+// matrix-pipe relief at -8.5 us per step (XT_EXP_WGRAD_KK) and re-measured it with the round-3/4 loops -- numbers in
+// tools/experiments/README.md.
+#ifdef XT_EXP_WGRAD_X6
+constexpr bool kWgradX6 = true;
+#else
+constexpr bool kWgradX6 = false;
+#endif
 constexpr int kRowTab = 1024;                       // rows decoded at once into the LDS row table
 constexpr long long kRowInvalid = -(1ll << 62);
 
 // Each thread owns a fixed group of 4 k's (its (ky,kx,c) offset is computed once); the rows of the block's
 // m-range are decoded once into an LDS table (base offset [+ coordinates when PADDED]), so a reduction step
 // costs one ds_read + one 64-bit add per row.
-template <int BI, int BJ, bool PADDED>
-constexpr int wgrad_smem_floats() { return 2 * (32 * BI + 32 * BJ) + 2 * kRowTab + (PADDED ? kRowTab : 0); }
+template <int BI, int BJ>
+struct WgX6Lay {          // bf16x6 stage: [3 planes][32 rows][BI * 2 + 32 bytes] then [3][32][BJ * 2 + 32]
+  static constexpr int RowA = BI * 2 + 32, RowB = BJ * 2 + 32, PlaneA = 32 * RowA, PlaneB = 32 * RowB;
+  static constexpr int Stage = 3 * (PlaneA + PlaneB);      // bytes
+};
+template <int BI, int BJ, bool PADDED, bool WX6 = false>
+constexpr int wgrad_smem_floats() {
+  return 2 * ((kWgradX6 || WX6) ? WgX6Lay<BI, BJ>::Stage / 4 : (32 * BI + 32 * BJ)) + 2 * kRowTab + (PADDED ? kRowTab : 0);
+}
 
 // PF4 (round 3): four register stages instead of two -- a step is 16 MFMAs (0.43 us), a global round trip under load
 // 2-3 us: with two steps in flight the m loop ran at ~1 us per step (timeline).  Needs the 256-VGPR budget of a kernel
 // instance limited to two workgroups per CU.
-template <int BI, int BJ, int WI, int WJ, bool U8, bool PADDED, bool PF4 = false>
+// WX6 (round 5): the weight gradient on the bf16 matrix cores -- both operands split into three bf16 planes when they
+// are written to LDS (natural [m][k] / [m][n] orientation, row strides BI * 2 + 32 / BJ * 2 + 32 bytes), gathered by
+// ds_read_b64_tr_b16 like the forward's weight operand, six v_mfma_f32_32x32x16_bf16 per 16 rows; the bias column sums add
+// the three planes back up (exactly the fp32 values).  Measured layer by layer (tools/experiments/README.md, round 5): pays
+// for the Dense layer's backward (18.04 -> 16.90 us: ten short steps, the co-resident input-gradient blocks get the pipe),
+// LOSES for the conv layers (more elements to split per step; conv3 also drops from three to two workgroups per CU) -- so
+// only the Dense instance of the fused backward selects it (xt_tuning.dense_wgrad_x6).
+template <int BI, int BJ, int WI, int WJ, bool U8, bool PADDED, bool PF4 = false, bool WX6 = false>
 __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int bx, const int by, const int bz,
                                                  float* smem) {
   constexpr int TI = BI / (32 * WI), TJ = BJ / (32 * WJ);
@@ -506,7 +531,9 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
   constexpr int CPRA = BI / 4, RPA = 256 / CPRA, NA = 32 / RPA;
   constexpr int CPRB = BJ / 4, RPB = 256 / CPRB, NB = 32 / RPB;
   constexpr int RG = 256 / BJ;           // row groups for the bias column sums
-  constexpr int BUF = 32 * SA + 32 * SB;
+  constexpr bool X6W = (kWgradX6 || WX6) && !U8;
+  using XL = WgX6Lay<BI, BJ>;
+  constexpr int BUF = X6W ? XL::Stage / 4 : 32 * SA + 32 * SB;
   long long* rowtab = reinterpret_cast<long long*>(smem + 2 * BUF);
   int* rowxy = reinterpret_cast<int*>(smem + 2 * BUF + 2 * kRowTab);
   const Geom& g = p.g;
@@ -595,6 +622,17 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
       }
     };
     auto stash = [&](const Regs& R, float* As, float* Bs) {
+      if constexpr (X6W) {
+        uint8_t* Ap = reinterpret_cast<uint8_t*>(As);
+        uint8_t* Bp = Ap + 3 * XL::PlaneA;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+          split3_store(Ap + (rowa + RPA * i) * XL::RowA + ca * 8, XL::PlaneA, cook4<U8>(R.a[i], (R.ok >> i) & 1u, g.xs, g.xb));
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+          split3_store(Bp + (rowb + RPB * i) * XL::RowB + cb * 8, XL::PlaneB, sel4((R.ok >> (8 + i)) & 1u, R.b[i]));
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < NA; ++i)
         *reinterpret_cast<float4*>(&As[(rowa + RPA * i) * SA + ca * 4]) =
@@ -603,10 +641,55 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
       for (int i = 0; i < NB; ++i)
         *reinterpret_cast<float4*>(&Bs[(rowb + RPB * i) * SB + cb * 4]) = sel4((R.ok >> (8 + i)) & 1u, R.b[i]);
     };
-    auto colsum = [&](const float* Bs) {
+    auto colsum = [&](const float* stage) {       // (stage base: A part first, then B)
       if (do_bias) {
+        if constexpr (X6W) {      // the three planes add up to the fp32 value exactly: same sums, bit for bit
+          const uint8_t* Bp = reinterpret_cast<const uint8_t*>(stage) + 3 * XL::PlaneA;
+#pragma unroll
+          for (int q = 0; q < 32 / RG; ++q) {
+            const uint8_t* e = Bp + (brg + RG * q) * XL::RowB + bcol * 2;
+            const float h = __uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(e) << 16);
+            const float m2 = __uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(e + XL::PlaneB) << 16);
+            const float l = __uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(e + 2 * XL::PlaneB) << 16);
+            bsum += (h + m2) + l;
+          }
+          return;
+        }
+        const float* Bs = stage + 32 * SA;
 #pragma unroll
         for (int q = 0; q < 32 / RG; ++q) bsum += Bs[(brg + RG * q) * SB + bcol];
+      }
+    };
+    // the 32-row step on the matrix cores: fp32 MFMAs, or (X6W) two 16-row chunks of six bf16 MFMAs with both operands
+    // gathered from their natural-orientation planes by ds_read_b64_tr_b16
+    auto mma_step = [&](const float* stage) {
+      if constexpr (X6W) {
+        const uint8_t* Ap = reinterpret_cast<const uint8_t*>(stage);
+        const uint8_t* Bp = Ap + 3 * XL::PlaneA;
+        const int kl = lane >> 5, c16 = lane & 15;
+        const int colq = ((lane >> 4) & 1) * 16 + 4 * (c16 & 3);
+        const uint8_t* aq = Ap + (8 * kl + (c16 >> 2)) * XL::RowA + (wi * TI * 32 + colq) * 2;
+        const uint8_t* bq = Bp + (8 * kl + (c16 >> 2)) * XL::RowB + (wj * TJ * 32 + colq) * 2;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+          bf16x8 a[TI][3], b[TJ][3];
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+              a[ti][pl] = lds_read_tr16x2(aq + pl * XL::PlaneA + ch * 16 * XL::RowA + ti * 64, 4 * XL::RowA);
+#pragma unroll
+          for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+              b[tj][pl] = lds_read_tr16x2(bq + pl * XL::PlaneB + ch * 16 * XL::RowB + tj * 64, 4 * XL::RowB);
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TJ; ++tj) acc[ti][tj] = mfma_bf16x6(a[ti], b[tj], acc[ti][tj]);
+        }
+      } else {
+        mma_tile<TI, TJ, SA, SB>(stage, stage + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
       }
     };
 
@@ -657,6 +740,15 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
         }
       };
       auto lstash = [&](const LRegs& Rs, float* As, float* Bs) {
+        if constexpr (X6W) {
+          uint8_t* Ap = reinterpret_cast<uint8_t*>(As);
+          uint8_t* Bp = Ap + 3 * XL::PlaneA;
+#pragma unroll
+          for (int i = 0; i < NA; ++i) split3_store(Ap + (rowa + RPA * i) * XL::RowA + ca * 8, XL::PlaneA, Rs.a[i]);
+#pragma unroll
+          for (int i = 0; i < NB; ++i) split3_store(Bp + (rowb + RPB * i) * XL::RowB + cb * 8, XL::PlaneB, Rs.b[i]);
+          return;
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i) *reinterpret_cast<float4*>(&As[(rowa + RPA * i) * SA + ca * 4]) = Rs.a[i];
 #pragma unroll
@@ -676,8 +768,8 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
               __syncthreads();
               if (s == 0 && u == 0 && sub == mbeg) XT_TL(2);
               if (s + u + 4 < nsteps) lfetch(s + u + 4, R[u]);
-              colsum(stage + 32 * SA);
-              mma_tile<TI, TJ, SA, SB>(stage, stage + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+              colsum(stage);
+              mma_step(stage);
             }
           }
         }
@@ -691,14 +783,14 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
           __syncthreads();
           if (s == 0 && sub == mbeg) XT_TL(2);
           if (s + 2 < nsteps) lfetch(s + 2, R0);
-          colsum(smem + 32 * SA);
-          mma_tile<TI, TJ, SA, SB>(smem, smem + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+          colsum(smem);
+          mma_step(smem);
           if (s + 1 < nsteps) {
             lstash(R1, smem + BUF, smem + BUF + 32 * SA);
             __syncthreads();
             if (s + 3 < nsteps) lfetch(s + 3, R1);
-            colsum(smem + BUF + 32 * SA);
-            mma_tile<TI, TJ, SA, SB>(smem + BUF, smem + BUF + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+            colsum(smem + BUF);
+            mma_step(smem + BUF);
           }
         }
       }
@@ -719,8 +811,8 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
             __syncthreads();
             if (s == 0 && u == 0 && sub == mbeg) XT_TL(2);
             if (s + u + 4 < nsteps) fetch(s + u + 4, R[u]);
-            colsum(stage + 32 * SA);
-            mma_tile<TI, TJ, SA, SB>(stage, stage + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+            colsum(stage);
+            mma_step(stage);
           }
         }
       }
@@ -736,14 +828,14 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
       __syncthreads();
       if (s == 0 && sub == mbeg) XT_TL(2);
       if (s + 2 < nsteps) fetch(s + 2, R0);
-      colsum(smem + 32 * SA);
-      mma_tile<TI, TJ, SA, SB>(smem, smem + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+      colsum(smem);
+      mma_step(smem);
       if (s + 1 < nsteps) {
         stash(R1, smem + BUF, smem + BUF + 32 * SA);
         __syncthreads();
         if (s + 3 < nsteps) fetch(s + 3, R1);
-        colsum(smem + BUF + 32 * SA);
-        mma_tile<TI, TJ, SA, SB>(smem + BUF, smem + BUF + 32 * SA, wi * TI * 32, wj * TJ * 32, acc, lane);
+        colsum(smem + BUF);
+        mma_step(smem + BUF);
       }
     }
     __syncthreads();   // row table and LDS stages are reused by the next sub-range
@@ -1537,10 +1629,10 @@ struct BwdLayerArgs {
 // a kernel is the maximum over all of its paths: the generic form needs 144 VGPR (LDS-tiled dgrad) + 32 AGPR
 // (register-direct dgrad) = two workgroups per CU, this one three.
 template <int WBI, int WBJ, int WWI, int WWJ, bool WPAD, int DBI, int DBJ, int DWI, int DWJ, int D4 = 0, int HALO = 0,
-          bool DX6 = false, int WROWS = 0>
+          bool DX6 = false, int WROWS = 0, bool WX6 = false>
 __global__ __launch_bounds__(256, WROWS ? 2 : 3) void igemm_bwd_layer_kernel(const BwdLayerArgs p) {
   constexpr int SMD = HALO == 5 ? 18 * 1024 : HALO == 3 ? 8 * 1024 : HALO == 2 ? 11 * 1024 : HALO == 1 ? 9 * 1024 : dgrad_smem_floats<DBI, DBJ, DX6>();
-  constexpr int SMW = (WROWS == 1 || WROWS == 2) ? kWrMaxSmemFloats : wgrad_smem_floats<WBI, WBJ, WPAD>();
+  constexpr int SMW = (WROWS == 1 || WROWS == 2) ? kWrMaxSmemFloats : wgrad_smem_floats<WBI, WBJ, WPAD, WX6>();
   constexpr int SM0 = SMW > SMD ? SMW : SMD;
   constexpr int SM = (D4 && dgrad4_smem_floats<D4 == 2>() > SM0) ? dgrad4_smem_floats<D4 == 2>() : SM0;
   __shared__ __attribute__((aligned(16))) float smem[SM];
@@ -1594,7 +1686,7 @@ __global__ __launch_bounds__(256, WROWS ? 2 : 3) void igemm_bwd_layer_kernel(con
       return;
     }
     const int bx = b % p.wg_gx, r = b / p.wg_gx;
-    igemm_wgrad_body<WBI, WBJ, WWI, WWJ, false, WPAD, (WROWS == 3)>(p.wg, bx, r % p.wg_gy, r / p.wg_gy, smem);
+    igemm_wgrad_body<WBI, WBJ, WWI, WWJ, false, WPAD, (WROWS == 3), WX6>(p.wg, bx, r % p.wg_gy, r / p.wg_gy, smem);
     return;
   }
   b -= p.n_wg;
@@ -2049,7 +2141,12 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
     if (x6) hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, 2>), dim3(total), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((igemm_bwd_layer_kernel<128, 32, 4, 1, false, 128, 32, 4, 1, 1>), dim3(total), dim3(256), 0, st, a);
   } else if (pf_generic) {
-    hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 64, 64, 2, 2, 0, 0, true, 3>), dim3(total2), dim3(256), 0, st, a);
+    if (tuning().dense_wgrad_x6) {        // (round 5) the Dense weight gradient on the bf16 matrix cores as well
+      last_arith() = XT_ARITH_BF16X6;
+      hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 64, 64, 2, 2, 0, 0, true, 3, true>), dim3(total2), dim3(256), 0, st, a);
+    } else {
+      hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 64, 64, 2, 2, 0, 0, true, 3>), dim3(total2), dim3(256), 0, st, a);
+    }
   } else if (wsmall && dsmall) XT_BWD(128, 32, 4, 1, 128, 32, 4, 1);
   else if (wsmall) XT_BWD(128, 32, 4, 1, 64, 64, 2, 2);
   else if (dsmall) XT_BWD(64, 64, 2, 2, 128, 32, 4, 1);

@@ -29,7 +29,7 @@ xt_tuning& tuning() {
                         /*direct_waves*/ 1536, /*direct_max_waves*/ 8, /*direct_tile64_tiles*/ 3072,
                         /*fwd_split_target*/ 256, /*wgrad_split_target*/ 512, /*reduce_z_lanes*/ 8,
                         /*defer_splitk*/ 1, /*finalize_ticket*/ 0, /*fwd_tiled_valid*/ 1, /*wgrad_rows*/ 4, /*fwd_prefetch_all*/ 0, /*bwd_deep_prefetch*/ 1, /*fwd_four_groups*/ 1, /*reduce_deep_lanes*/ 128, /*fwd_xcd_chunk*/ 1,
-                        /*tail_overlap*/ 0, /*tail_fused*/ 0};
+                        /*tail_overlap*/ 0, /*tail_fused*/ 0, /*dense_wgrad_x6*/ 1};
   return t;
 }
 
