@@ -117,7 +117,9 @@ typedef struct xt_tuning {
                                  barrier (all workgroups resident, checked; Adam only; ABI >= 8)                          */
   int32_t dense_wgrad_x6;     /* 1 (default): the weight gradient of Dense trunk layers on the bf16 matrix cores (bf16x6, both
                                  operands split when they are written to LDS) inside the fused backward launch; 0: fp32 MFMA
-                                 (ABI >= 10; measured 18.0 -> 16.9 us for PpoCnn's Dense backward, conv layers lose)        */
+                                 (ABI >= 10; measured 18.0 -> 16.9 us for PpoCnn's Dense backward, conv layers lose);
+                                 2 = experiment: additionally the halo-instance conv weight gradient (PpoCnn conv3) in a
+                                 one-LDS-stage bf16x6 form -- measured +0.9 us per step, kept for A/Bs only               */
 } xt_tuning;
 int xt_tuning_get(xt_tuning* out);
 int xt_tuning_set(const xt_tuning* in);

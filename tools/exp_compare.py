@@ -15,6 +15,9 @@ def dump(lib_path, out):
     import torch
     from xingtian_amd import lib as L
     L.LIB_PATH = os.path.abspath(lib_path)
+    if len(sys.argv) > 4:           # optional xt_tuning knobs as JSON
+        import json
+        L.set_tuning(**json.loads(sys.argv[4]))
     import bench
     from xingtian_amd.model import netspec
     from xingtian_amd.model.hip_net import HipActorCritic

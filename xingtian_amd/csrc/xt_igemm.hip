@@ -508,9 +508,10 @@ struct WgX6Lay {          // bf16x6 stage: [3 planes][32 rows][BI * 2 + 32 bytes
   static constexpr int RowA = BI * 2 + 32, RowB = BJ * 2 + 32, PlaneA = 32 * RowA, PlaneB = 32 * RowB;
   static constexpr int Stage = 3 * (PlaneA + PlaneB);      // bytes
 };
-template <int BI, int BJ, bool PADDED, bool WX6 = false>
+template <int BI, int BJ, bool PADDED, int WX6 = 0>       // WX6: 0 fp32, 1 bf16x6 with two LDS stages, 2 with ONE stage
 constexpr int wgrad_smem_floats() {
-  return 2 * ((kWgradX6 || WX6) ? WgX6Lay<BI, BJ>::Stage / 4 : (32 * BI + 32 * BJ)) + 2 * kRowTab + (PADDED ? kRowTab : 0);
+  return (WX6 == 2 ? 1 : 2) * ((kWgradX6 || WX6) ? WgX6Lay<BI, BJ>::Stage / 4 : (32 * BI + 32 * BJ)) + 2 * kRowTab +
+         (PADDED ? kRowTab : 0);
 }
 
 // PF4 (round 3): four register stages instead of two -- a step is 16 MFMAs (0.43 us), a global round trip under load
@@ -523,7 +524,7 @@ constexpr int wgrad_smem_floats() {
 // for the Dense layer's backward (18.04 -> 16.90 us: ten short steps, the co-resident input-gradient blocks get the pipe),
 // LOSES for the conv layers (more elements to split per step; conv3 also drops from three to two workgroups per CU) -- so
 // only the Dense instance of the fused backward selects it (xt_tuning.dense_wgrad_x6).
-template <int BI, int BJ, int WI, int WJ, bool U8, bool PADDED, bool PF4 = false, bool WX6 = false>
+template <int BI, int BJ, int WI, int WJ, bool U8, bool PADDED, bool PF4 = false, int WX6 = 0>
 __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int bx, const int by, const int bz,
                                                  float* smem) {
   constexpr int TI = BI / (32 * WI), TJ = BJ / (32 * WJ);
@@ -531,11 +532,13 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
   constexpr int CPRA = BI / 4, RPA = 256 / CPRA, NA = 32 / RPA;
   constexpr int CPRB = BJ / 4, RPB = 256 / CPRB, NB = 32 / RPB;
   constexpr int RG = 256 / BJ;           // row groups for the bias column sums
-  constexpr bool X6W = (kWgradX6 || WX6) && !U8;
+  constexpr bool X6W = (kWgradX6 || WX6 != 0) && !U8;
+  constexpr bool X6S = X6W && WX6 == 2;      // one LDS stage (half the LDS: a third workgroup per CU), two barriers per step
   using XL = WgX6Lay<BI, BJ>;
   constexpr int BUF = X6W ? XL::Stage / 4 : 32 * SA + 32 * SB;
-  long long* rowtab = reinterpret_cast<long long*>(smem + 2 * BUF);
-  int* rowxy = reinterpret_cast<int*>(smem + 2 * BUF + 2 * kRowTab);
+  constexpr int BUF2 = X6S ? 0 : BUF;         // offset of the second stage (none in the one-stage form)
+  long long* rowtab = reinterpret_cast<long long*>(smem + (X6S ? 1 : 2) * BUF);
+  int* rowxy = reinterpret_cast<int*>(smem + (X6S ? 1 : 2) * BUF + 2 * kRowTab);
   const Geom& g = p.g;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i0 = bx * BI, j0 = by * BJ;     // i = k, j = n
@@ -763,13 +766,14 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             if (s + u < nsteps) {                                                   // block-uniform
-              float* stage = smem + (u & 1) * BUF;
+              float* stage = smem + (u & 1) * BUF2;
               lstash(R[u], stage, stage + 32 * SA);
               __syncthreads();
               if (s == 0 && u == 0 && sub == mbeg) XT_TL(2);
               if (s + u + 4 < nsteps) lfetch(s + u + 4, R[u]);
               colsum(stage);
               mma_step(stage);
+              if constexpr (X6S) __syncthreads();
             }
           }
         }
@@ -785,12 +789,14 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
           if (s + 2 < nsteps) lfetch(s + 2, R0);
           colsum(smem);
           mma_step(smem);
+          if constexpr (X6S) __syncthreads();
           if (s + 1 < nsteps) {
-            lstash(R1, smem + BUF, smem + BUF + 32 * SA);
+            lstash(R1, smem + BUF2, smem + BUF2 + 32 * SA);
             __syncthreads();
             if (s + 3 < nsteps) lfetch(s + 3, R1);
-            colsum(smem + BUF);
-            mma_step(smem + BUF);
+            colsum(smem + BUF2);
+            mma_step(smem + BUF2);
+            if constexpr (X6S) __syncthreads();
           }
         }
       }
@@ -806,13 +812,14 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if (s + u < nsteps) {                                                   // block-uniform
-            float* stage = smem + (u & 1) * BUF;
+            float* stage = smem + (u & 1) * BUF2;
             stash(R[u], stage, stage + 32 * SA);
             __syncthreads();
             if (s == 0 && u == 0 && sub == mbeg) XT_TL(2);
             if (s + u + 4 < nsteps) fetch(s + u + 4, R[u]);
             colsum(stage);
             mma_step(stage);
+            if constexpr (X6S) __syncthreads();
           }
         }
       }
@@ -830,12 +837,14 @@ __device__ __forceinline__ void igemm_wgrad_body(const WgradArgs& p, const int b
       if (s + 2 < nsteps) fetch(s + 2, R0);
       colsum(smem);
       mma_step(smem);
+      if constexpr (X6S) __syncthreads();
       if (s + 1 < nsteps) {
-        stash(R1, smem + BUF, smem + BUF + 32 * SA);
+        stash(R1, smem + BUF2, smem + BUF2 + 32 * SA);
         __syncthreads();
         if (s + 3 < nsteps) fetch(s + 3, R1);
-        colsum(smem + BUF);
-        mma_step(smem + BUF);
+        colsum(smem + BUF2);
+        mma_step(smem + BUF2);
+        if constexpr (X6S) __syncthreads();
       }
     }
     __syncthreads();   // row table and LDS stages are reused by the next sub-range
@@ -1629,7 +1638,7 @@ struct BwdLayerArgs {
 // a kernel is the maximum over all of its paths: the generic form needs 144 VGPR (LDS-tiled dgrad) + 32 AGPR
 // (register-direct dgrad) = two workgroups per CU, this one three.
 template <int WBI, int WBJ, int WWI, int WWJ, bool WPAD, int DBI, int DBJ, int DWI, int DWJ, int D4 = 0, int HALO = 0,
-          bool DX6 = false, int WROWS = 0, bool WX6 = false>
+          bool DX6 = false, int WROWS = 0, int WX6 = 0>
 __global__ __launch_bounds__(256, WROWS ? 2 : 3) void igemm_bwd_layer_kernel(const BwdLayerArgs p) {
   constexpr int SMD = HALO == 5 ? 18 * 1024 : HALO == 3 ? 8 * 1024 : HALO == 2 ? 11 * 1024 : HALO == 1 ? 9 * 1024 : dgrad_smem_floats<DBI, DBJ, DX6>();
   constexpr int SMW = (WROWS == 1 || WROWS == 2) ? kWrMaxSmemFloats : wgrad_smem_floats<WBI, WBJ, WPAD, WX6>();
@@ -2118,8 +2127,12 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
     const int hx6 = tuning().bf16x6;     // 0: fp32 MFMA (A/B)
     const int nsamp = 63 / (g.H * g.W) + 2;
     if (hx6 && (size_t)3 * (nsamp * g.OHOW + 1) * (g.N * 2 + 16) <= 44 * 1024) last_arith() = XT_ARITH_FP32_BF16X6;
-    if (hx6 && (size_t)3 * (nsamp * g.OHOW + 1) * (g.N * 2 + 16) <= 44 * 1024)
-      hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1, 0, 2>), dim3(total), dim3(256), 0, st, a);
+    if (hx6 && (size_t)3 * (nsamp * g.OHOW + 1) * (g.N * 2 + 16) <= 44 * 1024) {
+      if (tuning().dense_wgrad_x6 == 2)      // EXPERIMENT (off by default): conv3's weight gradient bf16x6 with one LDS stage
+        hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1, 0, 2, false, 0, 2>), dim3(total), dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1, 0, 2>), dim3(total), dim3(256), 0, st, a);
+    }
     else
       hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 128, 32, 4, 1, 0, 1>), dim3(total), dim3(256), 0, st, a);
   } else if (a.dg_direct == 2 && pf4_only) {
@@ -2143,7 +2156,7 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
   } else if (pf_generic) {
     if (tuning().dense_wgrad_x6) {        // (round 5) the Dense weight gradient on the bf16 matrix cores as well
       last_arith() = XT_ARITH_BF16X6;
-      hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 64, 64, 2, 2, 0, 0, true, 3, true>), dim3(total2), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 64, 64, 2, 2, 0, 0, true, 3, 1>), dim3(total2), dim3(256), 0, st, a);
     } else {
       hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 64, 64, 2, 2, 0, 0, true, 3>), dim3(total2), dim3(256), 0, st, a);
     }
