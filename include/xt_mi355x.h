@@ -115,9 +115,11 @@ typedef struct xt_tuning {
   int32_t tail_fused;         /* 1: slab reduction + global norm + clip + Adam in ONE launch: the thread that reduced a group of
                                  elements also updates it, only the squared-norm partials and the step size cross a grid
                                  barrier (all workgroups resident, checked; Adam only; ABI >= 8)                          */
-  int32_t dense_wgrad_x6;     /* 1 (default): the weight gradient of Dense trunk layers on the bf16 matrix cores (bf16x6, both
-                                 operands split when they are written to LDS) inside the fused backward launch; 0: fp32 MFMA
-                                 (ABI >= 10; measured 18.0 -> 16.9 us for PpoCnn's Dense backward, conv layers lose);
+  int32_t dense_wgrad_x6;     /* 1 (default): the weight gradient of Dense trunk layers and of the generic 64x64 fused-backward
+                                 pair (ImpalaCnnOpt's 11x11 conv) on the bf16 matrix cores (bf16x6, both operands split when
+                                 they are written to LDS) inside the fused backward launch; 0: fp32 MFMA (ABI >= 10; measured
+                                 18.0 -> 16.9 us for PpoCnn's Dense backward, -1.1 % for pong_impala_speedup; the other conv
+                                 layers lose);
                                  2 = experiment: additionally the halo-instance conv weight gradient (PpoCnn conv3) in a
                                  one-LDS-stage bf16x6 form -- measured +0.9 us per step, kept for A/Bs only               */
 } xt_tuning;

@@ -2163,7 +2163,12 @@ int launch_bwd_layer(const xt_conv_geom* cg, int B, const float* x_in, const flo
   } else if (wsmall && dsmall) XT_BWD(128, 32, 4, 1, 128, 32, 4, 1);
   else if (wsmall) XT_BWD(128, 32, 4, 1, 64, 64, 2, 2);
   else if (dsmall) XT_BWD(64, 64, 2, 2, 128, 32, 4, 1);
-  else XT_BWD(64, 64, 2, 2, 64, 64, 2, 2);
+  else if (tuning().dense_wgrad_x6 && dx6 && !pad) {
+    // the generic 64x64 pair (ImpalaCnnOpt's 11x11 "dense" conv) with the one-LDS-stage bf16x6 weight gradient (three
+    // workgroups per CU as before): pong_impala_speedup 214.6 -> 212.3 us per 1000-frame train, breakout_impala unchanged
+    last_arith() = XT_ARITH_BF16X6;
+    hipLaunchKernelGGL((igemm_bwd_layer_kernel<64, 64, 2, 2, false, 64, 64, 2, 2, 0, 0, true, 0, 2>), dim3(total), dim3(256), 0, st, a);
+  } else XT_BWD(64, 64, 2, 2, 64, 64, 2, 2);
 #undef XT_BWD
 #undef XT_BWD2
   XT_LAUNCH_CHECK();
