@@ -98,3 +98,40 @@ def test_learner_dp_is_off_in_a_single_process():
         for k, v in env.items():
             if v is not None:
                 os.environ[k] = v
+
+
+def test_direct_allreduce_slice_arithmetic_is_consistent_for_every_size_and_world():
+    """The index arithmetic of csrc/xt_xgmi.hip restated in Python and checked exhaustively: ``slice_of`` (balanced contiguous
+    split of the float4 vectors, the first ``rem`` slices one longer) and the owner-of-vector formula of the fused kernel's
+    scatter phase (``v < cut ? v / (base + 1) : rem + (v - cut) / base``) must agree for every vector of every (count, world),
+    the slices must tile [0, nvec) in rank order, an inbox slot (slice_cap) must hold the longest slice, and the per-slice
+    vector tickets must add up to the slice lengths (the flag of a slice is raised by whoever completes its count)."""
+    def slice_of(nvec, r, world):
+        base, rem = divmod(nvec, world)
+        b = r * base + min(r, rem)
+        return b, b + base + (1 if r < rem else 0)
+
+    def owner(v, nvec, world):
+        base, rem = divmod(nvec, world)
+        cut = rem * (base + 1)
+        return v // (base + 1) if v < cut else rem + ((v - cut) // base if base else 0)
+
+    for world in range(1, 17):
+        for count in list(range(1, 200)) + [847496, 1005109, 250007, 4099]:
+            nvec = (count + 3) // 4
+            slice_cap = ((nvec + world - 1) // world) * 4                      # floats per inbox slot (xt_direct_create)
+            edges = [slice_of(nvec, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == nvec
+            assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+            assert max(e - b for b, e in edges) * 4 <= slice_cap
+            if nvec <= 4096:
+                tickets = [0] * world
+                for v in range(nvec):
+                    q = owner(v, nvec, world)
+                    assert edges[q][0] <= v < edges[q][1], (count, world, v, q)
+                    tickets[q] += 1
+                assert tickets == [e - b for b, e in edges]
+            else:                                                             # the big sizes: the slice boundaries only
+                for b, e in edges:
+                    for v in {b, e - 1} if e > b else set():
+                        assert owner(v, nvec, world) == edges.index((b, e))
