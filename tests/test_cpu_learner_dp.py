@@ -58,6 +58,9 @@ def _worker(rank, world, port, out):
         assert c["batch"] == 320 and c["grad_scale"] == 1.0 / world and c["global_batch"] == 0 and wk.feed == "sharded"
         assert wk.is_publisher and LearnerDP.from_config({"DP": "weak", "DP_PUBLISH": "rank0"}).is_publisher == (rank == 0)
         assert LearnerDP.from_config({"DP": "off"}) is None
+        # a model that is not the learner's never becomes a replica implicitly (attaching is a collective), only on request
+        assert LearnerDP.from_config({}, is_learner=False) is None
+        assert LearnerDP.from_config({"DP": "weak"}, is_learner=False).mode == "weak"
         for bad in ({"DP": "weak", "DP_FEED": "replicated"}, {"DP": "sideways"}, {"DP_FEED": "x"}, {"DP_EXCHANGE": "mpi"},
                     {"DP_PUBLISH": "nobody"}):
             with pytest.raises(ValueError):

@@ -82,7 +82,7 @@ class ImpalaCnnOpt(XTModel):
         # chunk, taken inside xt_net_impala_train; sharded feeds: every rank trains BATCH_SIZE / N frames of its own
         # messages per chunk (strict) or full BATCH_SIZE chunks (weak: global chunk N x BATCH_SIZE, flagged)
         from xingtian_amd.parallel import LearnerDP
-        self._dp = LearnerDP.from_config(model_info.get("model_config"))
+        self._dp = LearnerDP.from_config(model_info.get("model_config"), is_learner=model_info.get("type") == "learner")
         if self._dp is not None:
             self._dp.attach(self.net)
             if not self._dp.graph_capable:

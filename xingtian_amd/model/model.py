@@ -41,7 +41,8 @@ def learner_device(model_info):
     """cuda:0, or -- when the process is one rank of a data-parallel learner (``WORLD_SIZE > 1`` and ``model_config.DP`` not
     "off", xingtian_amd/parallel.py::LearnerDP) -- the rank's own GPU (``model_config.DP_DEVICE`` or ``LOCAL_RANK``)."""
     cfg = model_info.get("model_config") or {}
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and cfg.get("DP", "auto") != "off":
+    implicit = model_info.get("type") == "learner" and cfg.get("DP", "auto") != "off"
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and (implicit or cfg.get("DP") in ("strict", "weak")):
         from xingtian_amd.parallel import LearnerDP
         return "cuda:{}".format(LearnerDP.device_index(cfg))
     return "cuda:0"

@@ -100,7 +100,7 @@ class PPO(XTModel):
         # one rank of a data-parallel learner (torchrun: WORLD_SIZE > 1, or model_config.DP): the replica starts from rank
         # 0's weights, the gradient exchange is installed on the network, the minibatch split follows DP / DP_FEED
         from xingtian_amd.parallel import LearnerDP
-        self._dp = LearnerDP.from_config(model_info.get("model_config"))
+        self._dp = LearnerDP.from_config(model_info.get("model_config"), is_learner=model_info.get("type") == "learner")
         if self._dp is not None:
             self._dp.attach(self.net)
             self._cfg, _ = self._dp.ppo_cfg(self.net, base)

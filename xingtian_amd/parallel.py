@@ -458,13 +458,17 @@ class LearnerDP(object):
         self._msg = 0
 
     @staticmethod
-    def from_config(model_config):
+    def from_config(model_config, is_learner=True):
+        """``is_learner``: the model is the learner's (``model_info["type"] == "learner"``, xt/framework/learner.py:544).  Only
+        such a model becomes a replica IMPLICITLY (``WORLD_SIZE > 1`` without a ``DP`` key): attaching is a collective
+        (weight broadcast, communicator set-up), and an evaluator-side model that happens to be built on a GPU inside a
+        torchrun-launched process must not wait for peers that never build one.  An explicit ``DP`` key always counts."""
         import os
         cfg = model_config or {}
         mode = cfg.get("DP")
         env_world = int(os.environ.get("WORLD_SIZE", "1"))
         if mode in (None, "auto"):
-            mode = "strict" if env_world > 1 else "off"
+            mode = "strict" if (env_world > 1 and is_learner) else "off"
         if mode not in ("strict", "weak", "off"):
             raise ValueError("model_config.DP must be 'strict', 'weak' or 'off', got {!r}".format(mode))
         if mode == "off":
