@@ -84,6 +84,70 @@ def yaml_trajs(update, env_num):
     return out
 
 
+# ---- BASELINE configs[3] / configs[4] at their PER-RANK shapes: examples/breakout_ppo.yaml
+# (PpoCnn 84x84x4, BATCH_SIZE 320 -> 40-row shards at 8 ranks) and examples/pong_impala_speedup.yaml (ImpalaCnnOpt
+# 42x42x4, A = 6, 4 messages x 5 envs x T = 50 = 20 trajectories per 1000-frame chunk -> 3,3,3,3,2,2,2,2 at 8 ranks)
+C3_SEED, C4_SEED = 6, 8
+
+
+def c3_config(extra, one_step=False):
+    cfg = yaml_config(extra)
+    if one_step:        # exactly ONE SGD step per update: the exchanged gradient of that step can be read back
+        cfg["model_para"]["actor"]["model_config"]["NUM_SGD_ITER"] = 1
+    return cfg
+
+
+def c3_trajs(update, n_traj, t_len):
+    """``n_traj`` trajectories of ``t_len`` rows (7 x 128 = 896 rows = 2 minibatches of 320 + one of 256 per epoch)"""
+    from test_gpu_learner import synth_ppo_rollout
+    out = []
+    for i in range(n_traj):
+        rng = np.random.default_rng(11000 + 100 * update + i)
+        obs, lab = synth_ppo_rollout(rng, t_len, (84, 84, 4), 4)
+        out.append({"cur_state": obs, "action": lab[0], "logp": lab[1], "adv": lab[2], "old_value": lab[3],
+                    "target_value": lab[4]})
+    return out
+
+
+def c3_shape(feed, world, one_step):
+    """(trajectories, rows per trajectory) of one update"""
+    if one_step:
+        return (5, 64) if feed == "replicated" else (world, 320 // world)       # 320 rows: one global minibatch
+    return (7, 128) if feed == "replicated" else (world, 128)     # sharded feeds: one 128-row trajectory per rank
+
+
+def c4_config(extra, batch_size=None, max_batch=None):
+    import copy
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "learner_config.json")) as f:
+        cfg = copy.deepcopy(json.load(f)["examples/pong_impala_speedup.yaml"]["config"])
+    cfg["model_para"]["actor"]["model_config"].update(dict(extra, SEED=C4_SEED))
+    if batch_size:
+        cfg["alg_para"]["alg_config"]["BATCH_SIZE"] = int(batch_size)
+    if max_batch:
+        cfg["model_para"]["actor"]["model_config"]["MAX_BATCH"] = int(max_batch)
+    return cfg
+
+
+def c4_msg(update, k, envs=5, t_len=50):
+    """message k of update `update`: `envs` trajectories of T = 50, env-major rows (atari_impala_opt.py:96-109)"""
+    rng = np.random.default_rng(13000 + 100 * update + k)
+    n = envs * t_len
+    return {"cur_state": rng.integers(0, 256, (n, 42, 42, 4)).astype(np.uint8),
+            "logit": rng.standard_normal((n, 6)).astype(np.float32), "action": rng.integers(0, 6, n).astype(np.int32),
+            "done": list(rng.random(n) < 0.02), "reward": list(rng.choice([-1.0, 0.0, 1.0], n, p=[0.05, 0.9, 0.05]))}
+
+
+def exchanged_gradient(alg):
+    """the gradient the LAST SGD step applied (after the exchange), as a host array"""
+    dp, net = alg.dp, alg.actor.net
+    if dp is not None and hasattr(dp, "exchanged_gradient"):
+        return dp.exchanged_gradient(net)
+    import torch
+    torch.cuda.synchronize()
+    return net.grads.detach().cpu().numpy().copy()
+
+
 def main():
     outdir, case = sys.argv[1], sys.argv[2]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -92,7 +156,42 @@ def main():
     alg_kind, mode, feed, exchange = case.split("-")
     extra = {"DP": mode, "DP_FEED": feed, "DP_EXCHANGE": exchange, "DP_BACKEND": "gloo", "DP_DEVICE": 0}
     losses, answers = [], []
-    if alg_kind == "yaml":
+    grad1 = None
+    if alg_kind in ("c3", "c3g"):
+        from xingtian_amd.config import build_learner_algorithm
+        one = alg_kind == "c3g"
+        alg = build_learner_algorithm(c3_config(extra, one_step=one))
+        n_traj, t_len = c3_shape(feed, world, one)
+        for u in range(UPDATES):
+            for k, tr in enumerate(c3_trajs(u, n_traj, t_len)):
+                if feed == "sharded" and k % world != rank:
+                    continue
+                alg.prepare_data(tr)
+            losses.append(float(alg.train(episode_num=u)))
+            answers.append(bool(alg.checkpoint_ready(u)))
+            if one and u == 0:
+                grad1 = exchanged_gradient(alg)
+    elif alg_kind == "c4":
+        from xingtian_amd.config import build_learner_algorithm
+        if mode == "weak":        # every rank trains a full 250-frame chunk of its OWN message: global chunk world x 250
+            cfg = c4_config(extra, batch_size=250)
+            cfg["alg_para"]["alg_config"]["prepare_times_per_train"] = 1
+        else:
+            cfg = c4_config(extra)
+        alg = build_learner_algorithm(cfg)
+        for u in range(UPDATES):
+            if mode == "weak":
+                alg.prepare_data(c4_msg(u, rank))
+            else:
+                for k in range(4):
+                    if feed == "sharded" and k % world != rank:
+                        continue
+                    alg.prepare_data(c4_msg(u, k))
+            losses.append(float(alg.train(episode_num=u)))
+            answers.append(bool(alg.checkpoint_ready(u)))
+            if u == 0:
+                grad1 = exchanged_gradient(alg)     # (one 1000-frame chunk per train = one step)
+    elif alg_kind == "yaml":
         from xingtian_amd.config import build_learner_algorithm
         cfg = yaml_config(extra)
         alg = build_learner_algorithm(cfg)
@@ -124,8 +223,11 @@ def main():
     dp = alg.dp
     assert dp is not None and dp.world == world and dp.rank == rank
     assert alg.actor.use_graph == (exchange != "torch")
+    st = dp.status() or {}
     np.savez(os.path.join(outdir, "{}_r{}.npz".format(case, rank)), params=alg.actor.net.params.cpu().numpy(),
-             losses=np.asarray(losses), answers=np.asarray(answers), if_save=np.asarray([alg.if_save(0) is not False]))
+             losses=np.asarray(losses), answers=np.asarray(answers), if_save=np.asarray([alg.if_save(0) is not False]),
+             grad1=np.zeros(0, np.float32) if grad1 is None else grad1,
+             error_bits=np.asarray([int(st.get("error_bits", 0))]))
     import torch.distributed as dist
     dist.barrier()
     dist.destroy_process_group()

@@ -1,0 +1,236 @@
+"""The plugin pair data parallel as FOUR and EIGHT learner processes at the BASELINE configs[3] / configs[4] per-rank shapes
+(VERDICT r5 item 1).  A two-rank sum is the same in either order, so world = 2 proves nothing about the fixed-order
+reduction inside the training graph; here eight processes share the one GPU of the test box (`tests/dp_plugin_worker.py`
+under `torch.distributed.run`), each building the reference's own YAML through ``build_learner_algorithm``:
+
+* configs[3]: examples/breakout_ppo.yaml, PpoCnn 84x84x4, BATCH_SIZE 320 -> 40-row shards of every global minibatch and
+  32-row shards of the 256-row tail (xt/model/ppo/ppo.py:111-132), `DP: strict`, direct exchange inside the replayed hipGraph;
+* configs[4]: examples/pong_impala_speedup.yaml, ImpalaCnnOpt 42x42x4, A = 6, 20 trajectories x T = 50 per 1000-frame
+  chunk -> whole-trajectory shards 3,3,3,3,2,2,2,2 (xt/algorithm/impala/impala_opt.py:73-106), strict and weak.
+
+Checked: replicas and reported losses bitwise equal across the ranks; the parameters against the single-process update of
+the same YAML; the FIRST step's exchanged gradient bit for bit against a host fp32 sum, in rank order 0..N-1, of the N
+per-shard gradients computed by ONE process; rank 0 alone publishes; a 25-update soak.  The reference's only analogue is
+the dead host-side trainer, xt/framework/trainer.py:86-92."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from test_gpu_dp_plugin import _cumulative_perms, _delta_err, _run      # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _shard(n, r, world):
+    from xingtian_amd.parallel import shard_range
+    return shard_range(n, r, world)
+
+
+def _host_fixed_order_sum(parts):
+    """((g0 + g1) + g2) + ... in float32: the order xt_xgmi.hip's reduce phase uses"""
+    acc = parts[0].astype(np.float32).copy()
+    for g in parts[1:]:
+        acc = (acc + g.astype(np.float32)).astype(np.float32)
+    return acc
+
+
+def _check_common(res, world, publisher_only_rank0=True, tpc=1):
+    """no exchange error anywhere; rank 0 alone (or every rank) answers checkpoint_ready on every `tpc`-th train"""
+    for r in range(world):
+        assert int(res[r]["error_bits"][0]) == 0, "rank {}: the direct all-reduce reported error bits".format(r)
+    want = np.arange(len(res[0]["answers"])) % tpc == 0
+    assert np.array_equal(res[0]["answers"], want), res[0]["answers"]
+    for r in range(1, world):
+        if publisher_only_rank0:
+            assert not res[r]["answers"].any() and not res[r]["if_save"][0]
+        else:
+            assert np.array_equal(res[r]["answers"], want)
+
+
+# ------------------------------------------------------------------------------------------------ configs[3]: Breakout PPO
+def _single_c3(n_traj, t_len, order=None, perms_of=None, one_step=False, updates=None):
+    import dp_plugin_worker as W
+    from xingtian_amd.config import build_learner_algorithm
+    alg = build_learner_algorithm(W.c3_config({"DP": "off"}, one_step=one_step))
+    start = alg.actor.net.params.cpu().numpy().copy()
+    losses = []
+    for u in range(W.UPDATES if updates is None else updates):
+        trs = W.c3_trajs(u, n_traj, t_len)
+        for k in (order if order is not None else range(n_traj)):
+            alg.prepare_data(trs[k])
+        losses.append(float(alg.train(perms=None if perms_of is None else perms_of(u))))
+    torch.cuda.synchronize()
+    return alg, alg.actor.net.params.cpu().numpy(), start, losses
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_config3_strict_replicated_direct_exchange_in_the_graph(tmp_path, world):
+    """7 trajectories x 128 rows = 896 rows: per epoch two global minibatches of 320 (shards of 80 / 40 rows) and one of 256
+    (64 / 32), 4 epochs = 12 SGD steps per update, two updates, every all-reduce inside the replayed hipGraph."""
+    res = _run(tmp_path, "c3-strict-replicated-direct", world=world)
+    _check_common(res, world)
+    _alg, ref, start, losses = _single_c3(7, 128)
+    # 2 x 12 sign-like Adam steps on noise; summation order differs (N shard sums instead of one): the bar of the full-size
+    # single-GPU update against its own fp32 oracle (test_gpu_learner: 0.15)
+    assert _delta_err(res[0]["params"], ref, start) < 0.15, _delta_err(res[0]["params"], ref, start)
+    assert np.allclose(res[0]["losses"], losses, rtol=5e-3, atol=1e-4), (res[0]["losses"], losses)
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_config3_first_step_gradient_is_bitwise_the_fixed_rank_order_sum_of_the_shard_gradients(tmp_path, world):
+    """ONE global minibatch of 320 rows (NUM_SGD_ITER 1): every rank dumps the gradient its Adam consumed.  One process then
+    computes the N shard gradients (rows perm[shard r], loss means over the 320 global rows) and sums them on the host in
+    float32 in rank order -- the direct exchange's reduce phase must produce exactly those bits on every rank."""
+    import dp_plugin_worker as W
+    res = _run(tmp_path, "c3g-strict-replicated-direct", world=world, updates=1)
+    _check_common(res, world)
+    for r in range(1, world):
+        assert np.array_equal(res[0]["grad1"], res[r]["grad1"])
+    alg, _ref, _start, _losses = _single_c3(5, 64, one_step=True, updates=0)
+    net = alg.actor.net
+    trs = W.c3_trajs(0, 5, 64)
+    cat = lambda k, dt: torch.from_numpy(np.ascontiguousarray(np.concatenate([t[k] for t in trs]).astype(dt))).cuda()
+    obs = cat("cur_state", np.uint8)
+    action, logp = cat("action", np.int32), cat("logp", np.float32).reshape(-1)
+    adv, old_v, tgt = cat("adv", np.float64).reshape(-1), cat("old_value", np.float32).reshape(-1), cat("target_value", np.float64).reshape(-1)
+    perm = _cumulative_perms(np.random.default_rng(W.C3_SEED), 320, 1)[0]
+    mc = alg.actor
+    base = dict(LR=mc._lr, LOSS_CLIPPING=mc.clip_ratio, ENTROPY_LOSS=mc.ent_coef, VF_CLIP=mc.vf_clip,
+                CRITIC_LOSS_COEF=mc.critic_loss_coef, MAX_GRAD_NORM=mc._max_grad_norm, BATCH_SIZE=320, NUM_SGD_ITER=1)
+    cfg = net.make_ppo_cfg(base, grad_scale=1.0, global_batch=320)
+    parts = []
+    for r in range(world):
+        b, e = _shard(320, r, world)
+        idx = torch.from_numpy(perm[b:e].astype(np.int32)).cuda()
+        net.ppo_step(cfg, obs, idx, action, logp, adv, old_v, tgt, apply=False)
+        torch.cuda.synchronize()
+        parts.append(net.grads.detach().cpu().numpy()[:net.spec.n_flat].copy())
+    want = _host_fixed_order_sum(parts)
+    got = res[0]["grad1"][:want.size]
+    assert got.size == want.size
+    assert np.array_equal(got, want), "max |diff| {}".format(np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_config3_strict_round_robin_feed_is_the_single_gpu_update_on_stratified_minibatches(tmp_path, world):
+    """trajectory k lives on rank k (kept at ingest from the replicated stream); a global minibatch of 320 = 320 / N rows of
+    EACH rank's local permutation; the local 128 rows give three full local minibatches and a short one (8 x N rows ... the
+    global tail).  One process fed the same trajectories in rank order with the concatenated local minibatches."""
+    import dp_plugin_worker as W
+    res = _run(tmp_path, "c3-strict-round_robin-direct", world=world)
+    _check_common(res, world)
+    nl, lb = 128, 320 // world
+    rngs = [np.random.default_rng([W.C3_SEED, r]) for r in range(world)]
+
+    def perms(u):
+        loc = [_cumulative_perms(rngs[r], nl, 4) for r in range(world)]
+        out = []
+        for ep in range(4):
+            row = []
+            for s in range(0, nl, lb):
+                for r in range(world):
+                    row += list(r * nl + loc[r][ep, s:s + lb])
+            out.append(row)
+        return np.asarray(out, np.int32)
+
+    _alg, ref, start, losses = _single_c3(world, 128, perms_of=perms)
+    assert _delta_err(res[0]["params"], ref, start) < 0.15, _delta_err(res[0]["params"], ref, start)
+    assert np.allclose(res[0]["losses"], losses, rtol=5e-3, atol=1e-4), (res[0]["losses"], losses)
+
+
+# ------------------------------------------------------------------------------------------------ configs[4]: Pong IMPALA
+def _single_c4(batch_size=None, max_batch=None, msgs_of=None, updates=None):
+    import dp_plugin_worker as W
+    from xingtian_amd.config import build_learner_algorithm
+    cfg = W.c4_config({"DP": "off"}, batch_size=batch_size, max_batch=max_batch)
+    alg = build_learner_algorithm(cfg)
+    start = alg.actor.net.params.cpu().numpy().copy()
+    losses = []
+    for u in range(W.UPDATES if updates is None else updates):
+        for m in (msgs_of(u) if msgs_of else [W.c4_msg(u, k) for k in range(4)]):
+            alg.prepare_data(m)
+        losses.append(float(alg.train()))
+    torch.cuda.synchronize()
+    return alg, alg.actor.net.params.cpu().numpy(), start, losses
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_config4_strict_uneven_trajectory_shards_and_the_first_gradient_bitwise(tmp_path, world):
+    """20 trajectories x T = 50 per chunk over 8 ranks -> 3,3,3,3,2,2,2,2 (5 each at 4 ranks), sum-form loss, gradients SUMMED
+    by the direct exchange in the graph; the first train's exchanged gradient = the host's rank-order fp32 sum of the shard
+    gradients one process computes with the same trajectory slices."""
+    import dp_plugin_worker as W
+    res = _run(tmp_path, "c4-strict-replicated-direct", world=world)
+    _check_common(res, world, tpc=3)         # (pong_impala_speedup.yaml: train_per_checkpoint 3)
+    for r in range(1, world):
+        assert np.array_equal(res[0]["grad1"], res[r]["grad1"])
+    alg, ref, start, losses = _single_c4()
+    assert _delta_err(res[0]["params"], ref, start) < 2e-2, _delta_err(res[0]["params"], ref, start)
+    assert np.allclose(res[0]["losses"], losses, rtol=2e-3, atol=1e-3), (res[0]["losses"], losses)
+    # shard gradients of update 0 from the INITIAL parameters, one process
+    alg2, _r, _s, _l = _single_c4(updates=0)
+    net = alg2.actor.net
+    msgs = [W.c4_msg(0, k) for k in range(4)]
+    cat = lambda k, dt: torch.from_numpy(np.ascontiguousarray(np.concatenate([np.asarray(m[k]) for m in msgs]).astype(dt))).cuda()
+    obs, logit, action = cat("cur_state", np.uint8), cat("logit", np.float32), cat("action", np.int32)
+    done, reward = cat("done", np.uint8), cat("reward", np.float32)
+    cfg = alg2.actor._cfg
+    parts = []
+    for r in range(world):
+        b, e = _shard(20, r, world)
+        sl = slice(b * 50, e * 50)
+        net.impala_step(cfg, obs[sl], logit[sl], action[sl], done[sl], reward[sl], apply=False)
+        torch.cuda.synchronize()
+        parts.append(net.grads.detach().cpu().numpy()[:net.spec.n_flat].copy())
+    want = _host_fixed_order_sum(parts)
+    got = res[0]["grad1"][:want.size]
+    assert np.array_equal(got, want), "max |diff| {}".format(np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_config4_weak_every_rank_trains_its_own_message(tmp_path, world):
+    """weak + sharded feed: every rank trains one full 250-frame chunk of its OWN message per train, gradients summed: one
+    process with BATCH_SIZE = world x 250 fed the same messages in rank order (a flagged change of the global chunk)."""
+    import dp_plugin_worker as W
+    res = _run(tmp_path, "c4-weak-sharded-direct", world=world)
+    _check_common(res, world, publisher_only_rank0=False, tpc=3)     # every rank has its own explorers: every rank publishes
+
+    def msgs_of(u):
+        return [W.c4_msg(u, r) for r in range(world)]
+
+    import copy
+    from xingtian_amd.config import build_learner_algorithm
+    cfg = W.c4_config({"DP": "off"}, batch_size=250 * world, max_batch=250 * world)
+    cfg["alg_para"]["alg_config"]["prepare_times_per_train"] = world
+    alg = build_learner_algorithm(copy.deepcopy(cfg))
+    start = alg.actor.net.params.cpu().numpy().copy()
+    losses = []
+    for u in range(W.UPDATES):
+        for m in msgs_of(u):
+            alg.prepare_data(m)
+        losses.append(float(alg.train()))
+    torch.cuda.synchronize()
+    ref = alg.actor.net.params.cpu().numpy()
+    assert _delta_err(res[0]["params"], ref, start) < 2e-2, _delta_err(res[0]["params"], ref, start)
+    assert np.allclose(res[0]["losses"], losses, rtol=2e-3, atol=1e-3), (res[0]["losses"], losses)
+
+
+def test_eight_rank_soak_25_updates_in_the_replayed_graph(tmp_path):
+    """25 IMPALA trains + 25 PPO updates as eight processes, direct exchange inside the replayed hipGraph: no time-out (error
+    bits 0), replicas and every reported loss bitwise equal across the ranks, losses finite; the first updates agree with the
+    host-synchronous gloo exchange (whose summation order differs) to the summation-order bar."""
+    a = _run(tmp_path, "ppo-strict-replicated-direct", world=8, updates=25)
+    _check_common(a, 8)
+    assert len(a[0]["losses"]) == 25 and np.isfinite(a[0]["losses"]).all()
+    b = _run(tmp_path, "ppo-strict-replicated-torch", world=8, updates=3)
+    assert np.allclose(a[0]["losses"][:3], b[0]["losses"], rtol=5e-3, atol=1e-5), (a[0]["losses"][:3], b[0]["losses"])
+    c = _run(tmp_path, "c4-strict-replicated-direct", world=8, updates=25)
+    _check_common(c, 8, tpc=3)
+    assert len(c[0]["losses"]) == 25 and np.isfinite(c[0]["losses"]).all()
