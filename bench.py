@@ -1082,11 +1082,13 @@ def model_scaling(spec, dev, updates=6):
         net = HipActorCritic(spec, max_batch=rows, device=str(dev), seed=0)
         one = None
         if dp_form:
-            # the data-parallel FORM of the step with nobody to exchange with: a one-rank direct comm is the identity (no
-            # launch), so this times what the step costs beyond the all-reduce itself -- the gradient-reduction launch with
-            # the loss / step-size block, then squared-norm partials + Adam on the "exchanged" gradient (12 launches vs 11)
-            one = DirectComm(0, 1, spec.n_flat)
-            one.attach(net)
+            # the data-parallel FORM of the step with nobody to exchange with
+            # (round 6) the FUSED direct exchange as a one-rank group: every kernel of the real chain runs against the rank's
+            # own exchange block -- the gradient reduction scatters into the inbox (uncached), one reduce launch, Adam waits
+            # for the done flag and reads the result buffer: 13 launches vs 11, what a rank pays besides the links
+            one = DirectComm(0, 1, int(net.grads_xchg.numel()))
+            net.set_dp(0, 1, 1.0)
+            one.attach_fused(net)
         d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         obs = d(rng.integers(0, 256, (n,) + STATE_DIM, dtype=np.uint8))
         act, logp = d(rng.integers(0, A_DIM, n).astype(np.int32)), d((-np.abs(rng.standard_normal(n)) - 0.5).astype(np.float32))
@@ -1103,7 +1105,9 @@ def model_scaling(spec, dev, updates=6):
         nsteps = CFG["NUM_SGD_ITER"] * ((n + rows - 1) // rows)
         (step_us_dp if dp_form else step_us)[rows] = 1e6 * (time.perf_counter() - t0) / (updates * nsteps)
         if one is not None:
+            assert one.status()["error_bits"] == 0
             one.detach(net)
+            net.set_dp(0, 0)
             one.destroy()
         del net
         torch.cuda.empty_cache()
@@ -1275,7 +1279,7 @@ def main():
         torch.distributed group; works with the ranks on N GPUs or sharing one"""
         if comm["direct"] is None:
             from xingtian_amd.parallel import DirectComm
-            comm["direct"] = DirectComm(rank, world, spec.n_flat, timeout_ms=3000).connect()
+            comm["direct"] = DirectComm(rank, world, (spec.n_flat + 3) // 4 * 4 + L.DP_TAIL_FLOATS, timeout_ms=3000).connect()
         return comm["direct"]
 
     def get_rccl():
@@ -1304,7 +1308,8 @@ def main():
           hook_overlap     the same with two buckets: last trunk layer + heads all-reduced from a side stream right after
                            the first backward launch, under the conv backward (XT_XCHG_OVERLAP)
           ingraph[_overlap] the same two, captured into the hipGraph of the whole update (no host work per step)
-          direct           xt_allreduce_direct (2-phase push over peer-mapped memory, csrc/xt_xgmi.hip) inside the update's hipGraph
+          direct           the 2-phase push exchange over peer-mapped memory (csrc/xt_xgmi.hip) FUSED into the step
+                           (xt_net_set_direct), inside the update's hipGraph
         fixed_perm_seed: draw the permutations from a private generator (validation runs: same shuffles for all variants)."""
         steps = args.steps if steps is None else steps
         warmup = args.warmup if warmup is None else warmup
@@ -1326,8 +1331,11 @@ def main():
             cfg = net.make_ppo_cfg(CFG, grad_scale=1.0 / world, global_batch=0)
         rccl = None
         if variant == "direct":
+            # (round 6) the exchange FUSED into the step (xt_net_set_dp + xt_net_set_direct): the gradient reduction scatters
+            # straight into the owners' inboxes, one reduce launch, Adam reads the exchange block
             rccl = get_direct()
-            rccl.attach(net)
+            net.set_dp(rank, world, 1.0 / world if mode == "weak" else 1.0)
+            rccl.attach_fused(net)
         elif variant != "eager":
             rccl = get_rccl()
             rccl.attach(net, overlap=variant.endswith("_overlap"))
@@ -1380,6 +1388,7 @@ def main():
             st = rccl.status()
             assert st["error_bits"] == 0, "direct all-reduce: a bounded wait ran out: {}".format(st)
             rccl.detach(net)
+            net.set_dp(0, 0)
         elif rccl is not None:
             rccl.status(net)
             assert not rccl.errors, "ncclAllReduce failed inside the gradient-exchange hook: {}".format(rccl.errors)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define XT_ABI_VERSION 10
+#define XT_ABI_VERSION 11
 
 #define XT_ACT_NONE 0
 #define XT_ACT_RELU 1
@@ -402,8 +402,8 @@ int xt_net_ppo_step(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, const i
 
 /* Model.train of xt/model/ppo/ppo.py:111-132 in one call: NUM_SGD_ITER epochs x
  * ceil(n/BATCH_SIZE) minibatches; perm [num_sgd_iter, n] int32 holds the epoch
- * permutations (the reference's np.random.shuffle, injected).  loss_acc[0] receives the
- * SUM of minibatch losses, loss_acc[1] the number of minibatches.  use_graph != 0
+ * permutations (the reference's np.random.shuffle, injected).  loss_acc (4 floats): [0] receives the
+ * SUM of minibatch losses, [1] the number of minibatches, [2] data-parallel error bits (0 = none; ABI >= 11).  use_graph != 0
  * captures the whole call into a hipGraph on first use and replays it afterwards
  * (pointers and sizes must then stay the same between calls). */
 int xt_net_ppo_train(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, int32_t n,
@@ -485,6 +485,44 @@ int xt_direct_set_timeout_ms(xt_direct_comm* comm, int32_t ms);
 int xt_direct_set_fused(xt_direct_comm* comm, int32_t fused);
 int xt_direct_status(xt_direct_comm* comm, int32_t* calls, int32_t* seq, int32_t* error_bits);
 int xt_direct_destroy(xt_direct_comm* comm);
+/* ABI >= 11.  xt_direct_info: how many ranks of the group live on THIS rank's device (read from the device identity every
+ * rank leaves in its exchange block; 1 on a real multi-GPU node, N when N test processes share one GPU) and the workgroup
+ * cap the spinning kernels of this comm are launched with: (resident workgroups of the device) / (ranks on the device) --
+ * a kernel whose blocks wait for other ranks' flags must leave room for those ranks' kernels.
+ * xt_direct_read_result: the reduced buffer of the most recent exchange (tests; synchronises the device).
+ * xt_direct_reset: clears the sticky error word, the tickets, the sequence number and this rank's flag words.  COLLECTIVE:
+ * every rank calls it between two host barriers, with no exchange in flight (xingtian_amd/parallel.py::DirectComm.reset). */
+int xt_direct_info(xt_direct_comm* comm, int32_t* ranks_on_device, int32_t* block_cap);
+int xt_direct_read_result(xt_direct_comm* comm, float* host_out, int64_t count);
+int xt_direct_reset(xt_direct_comm* comm);
+
+/* ---- The data-parallel SGD step without host collectives and without gradient copies (ABI >= 11).
+ * Replaces the two host-synchronous collectives per Model.train of ABI 10's learner (row-count check, global loss) and the
+ * scatter / gather copies of the direct exchange; the reference's analogue of the message is xt/framework/trainer.py:139-144.
+ *
+ * xt_net_set_dp(net, rank, world, loss_scale): from now on the gradient buffer bound with xt_net_bind holds
+ * align4(n_params) + XT_DP_TAIL_FLOATS floats and every exchange of xt_net_ppo_train / xt_net_impala_train covers the TAIL
+ * too: slot [r] = rows rank r was handed for this update, slot [16 + r] = rank r's share of the step's loss, all other slots
+ * zero -- after the SUM every rank holds every rank's values exactly and the optimiser kernel adds
+ * loss_scale * (sum in rank order) to loss_acc[0] (PPO strict / IMPALA: 1, the shares of one sum; PPO weak: 1 / world, the
+ * mean of the ranks' means) and raises loss_acc[2] (error bits, 4 = the ranks hold different numbers of rows) -- so one
+ * train() is one C call and one read-back of loss_acc, as on one GPU.  world <= 0 switches it off; world == 1 is a
+ * one-rank group (the whole chain runs against the rank's own buffers: how bench.py times the data-parallel form of the
+ * step on one GPU).  The overlapped
+ * two-bucket mode (XT_XCHG_OVERLAP) carries the tail in its first bucket.
+ *
+ * xt_net_set_direct(net, comm): the direct exchange FUSED into the step (needs xt_net_set_dp; comm sized for
+ * align4(n_params) + XT_DP_TAIL_FLOATS floats): the gradient-reduction kernel writes every reduced float4 straight into the
+ * owning peer's inbox and raises the ready flags; ONE small launch reduces this rank's slice in rank order, pushes it to every
+ * peer's result buffer and leaves the squared-norm partials of the slice with it; the optimiser kernel waits for the done
+ * flags, derives the clip factor from all ranks' partials (fixed order: bitwise the same factor everywhere) and reads the
+ * gradient out of the result buffer.  Three launches per step tail instead of five, no scatter / gather copy, no separate
+ * norm launch.  A wait that runs out (or a row mismatch) sets the sticky error word: the optimiser then SKIPS the update
+ * (parameters and slots stay those of the last good step) and loss_acc[2] carries the bits to the host with the loss.
+ * comm == NULL detaches. */
+#define XT_DP_TAIL_FLOATS 32
+int xt_net_set_dp(xt_net* net, int32_t rank, int32_t world, float loss_scale);
+int xt_net_set_direct(xt_net* net, xt_direct_comm* comm);
 
 /* One minibatch of Keras `model.fit` for the non-opt IMPALA models (ABI >= 5): forward, xt_keras_impala_loss,
  * backward; the flat gradient is left in the net's gradient buffer for xt_adam_keras.  obs rows are gathered with
@@ -556,6 +594,13 @@ int32_t xt_last_launch_arith(void);
 int xt_net_time_layer(xt_net* net, int32_t layer, int32_t which /* 0 fwd, 1 wgrad, 2 dgrad, 3 fused dgrad+wgrad */,
                       const void* obs, const int32_t* idx, int32_t B, int32_t reps,
                       float* ms_out, void* stream);
+
+/* kernel-time probe of the SGD step's TAIL (ABI >= 11): average duration (ms, HIP events on `stream`) of `reps` back-to-back
+ * repetitions of what follows the backward pass -- gradient reduction, [data parallel: exchange], global-norm clip + Adam --
+ * in the net's CURRENT mode (plain; exchange hook; xt_net_set_dp + xt_net_set_direct: the fused three-launch chain), on the
+ * weight-gradient slabs the most recent gradient step left in the workspace (parameters and slots ARE updated).  N processes
+ * running it at the same time on one device give the kernel-side cost of the exchange per rank (tools/direct_probe.py). */
+int xt_net_time_tail(xt_net* net, float lr, float clip_norm, int32_t reps, float* ms_out, void* stream);
 
 #ifdef __cplusplus
 }

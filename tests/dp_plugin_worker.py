@@ -224,10 +224,12 @@ def main():
     assert dp is not None and dp.world == world and dp.rank == rank
     assert alg.actor.use_graph == (exchange != "torch")
     st = dp.status() or {}
+    info = dp.comm.info() if hasattr(dp.comm, "info") else {}
     np.savez(os.path.join(outdir, "{}_r{}.npz".format(case, rank)), params=alg.actor.net.params.cpu().numpy(),
              losses=np.asarray(losses), answers=np.asarray(answers), if_save=np.asarray([alg.if_save(0) is not False]),
              grad1=np.zeros(0, np.float32) if grad1 is None else grad1,
-             error_bits=np.asarray([int(st.get("error_bits", 0))]))
+             error_bits=np.asarray([int(st.get("error_bits", 0))]),
+             ranks_on_device=np.asarray([int(info.get("ranks_on_device", 0))]), block_cap=np.asarray([int(info.get("block_cap", 0))]))
     import torch.distributed as dist
     dist.barrier()
     dist.destroy_process_group()

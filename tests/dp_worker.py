@@ -75,6 +75,7 @@ def main():
         obs, lab, _ = ppo_rollout(200 + rank, n)
         _, _, perms = ppo_rollout(100, n)
         ex = parallel.TorchDistExchange(net)
+        ex.record_calls = True
         ex.attach(overlap=(mode == "hook_overlap"))
         c = net.make_ppo_cfg(cfg, grad_scale=1.0 / world, global_batch=0)
         net.ppo_train(c, net.to_device_obs(obs), d(perms), d(lab[0]), d(lab[1].reshape(-1)), d(lab[2].reshape(-1)),
@@ -93,6 +94,7 @@ def main():
         parallel.broadcast_weights_(net.params)
         obs, lab, perms = ppo_rollout(100, n)
         ex = parallel.TorchDistExchange(net)
+        ex.record_calls = True
         ex.attach()
         c = net.make_ppo_cfg(cfg, grad_scale=1.0, global_batch=0, shard_rank=rank, shard_world=world)
         net.ppo_train(c, net.to_device_obs(obs), d(perms), d(lab[0]), d(lab[1].reshape(-1)), d(lab[2].reshape(-1)),

@@ -1,7 +1,7 @@
 """``parallel.LearnerDP`` (data parallelism behind the plugin pair) without a GPU: two gloo ranks exercise what the model
 constructors and the algorithms call on it -- configuration from the launcher environment, the minibatch split arithmetic of
-every mode x feed, the round-robin ingest filter, the shared permutation seed, the row-count guard (must fail on EVERY rank,
-not dead-lock) and the global loss.  The GPU half is tests/test_gpu_dp_plugin.py."""
+every mode x feed, the round-robin ingest filter, the shared permutation seed and the arithmetic of the data-parallel tail
+(rows + loss shares travelling with the gradient instead of two host collectives per train).  The GPU half is tests/test_gpu_dp_plugin.py."""
 import os
 import socket
 
@@ -71,12 +71,26 @@ def _worker(rank, world, port, out):
         seeds = [None] * world
         dist.all_gather_object(seeds, s)
         assert len(set(seeds)) == 1
-        # the row-count guard raises on EVERY rank when the ranks disagree, and passes when they agree
-        dp.check_equal(4096, "PPO.train")
-        with pytest.raises(ValueError, match="different amounts of data"):
-            dp.check_equal(4096 + rank, "PPO.train")
-        # the loss the learner logs: strict = SUM of the ranks' shares / minibatches
-        assert abs(dp.global_loss(1.5 + rank, 4) - sum(1.5 + r for r in range(world)) / 4) < 1e-12
+        # the data-parallel TAIL (include/xt_mi355x.h `xt_net_set_dp`) restated on the host: every rank fills slot [rank] with
+        # its rows and slot [16 + rank] with its loss share, zeros elsewhere; after ONE SUM all-reduce every rank holds every
+        # rank's values exactly (one non-zero summand per slot), derives the same global loss in rank order and sees a row
+        # mismatch -- what replaced the two host collectives per train (row-count check, global loss) of ABI 10
+        import torch
+        from xingtian_amd.lib import DP_TAIL_FLOATS
+        for rows_of in (lambda r: 4096.0, lambda r: 4096.0 + r):
+            tail = torch.zeros(DP_TAIL_FLOATS, dtype=torch.float32)
+            tail[rank], tail[16 + rank] = float(rows_of(rank)), float(np.float32(1.5 + 0.1 * rank))
+            dist.all_reduce(tail)
+            t = tail.numpy()
+            assert [t[r] for r in range(world)] == [np.float32(rows_of(r)) for r in range(world)]
+            loss = np.float32(0.0)
+            for r in range(world):
+                loss = np.float32(loss + t[16 + r])
+            want = np.float32(0.0)
+            for r in range(world):
+                want = np.float32(want + np.float32(1.5 + 0.1 * r))
+            assert loss == want and not t[world:16].any() and not t[16 + world:].any()
+            assert (len({float(t[r]) for r in range(world)}) > 1) == (rows_of(1) != rows_of(0))
         out[rank] = 1
     finally:
         if dist.is_initialized():
@@ -138,3 +152,33 @@ def test_direct_allreduce_slice_arithmetic_is_consistent_for_every_size_and_worl
                 for b, e in edges:
                     for v in {b, e - 1} if e > b else set():
                         assert owner(v, nvec, world) == edges.index((b, e))
+
+
+def test_gradient_entries_and_the_tail_tile_the_exchanged_buffer():
+    """The gradient-reduction launch of a fused data-parallel step (csrc/xt_optim.hip, DpFinish.scatter) writes every entry's
+    float4s (entries start 16-byte aligned; a short last vector is zero padded) and the 8 tail vectors straight into the
+    owners' inboxes; nothing else ever writes the inboxes of a step.  For the real layouts: the entries' vector ranges and
+    the tail are disjoint, lie inside the exchanged buffer and COVER it (an uncovered vector would carry a stale value into
+    the sum), and every rank's slice is non-empty for every world size the comm accepts."""
+    from xingtian_amd.lib import DP_TAIL_FLOATS
+    from xingtian_amd.model import netspec
+    specs = [netspec.ppo_cnn((84, 84, 4), 4, (256,), "relu", True), netspec.impala_cnn_opt((42, 42, 4), 6, 128.0, 128.0, "uint8"),
+             netspec.ppo_mlp((4,), 2, (64, 64), "tanh", False), netspec.ppo_cnn((84, 84, 3), 4, (256,), "relu", True)]
+    for spec in specs:
+        nvec = (spec.n_flat + 3) // 4 + DP_TAIL_FLOATS // 4
+        # kernel + bias of a layer are ONE entry of the gradient table: merge neighbours that touch
+        merged = []
+        for off, cnt in sorted(spec.var_extent(name) for name in spec.names):
+            if merged and merged[-1][0] + merged[-1][1] == off:
+                merged[-1][1] += cnt
+            else:
+                merged.append([off, cnt])
+        covered = np.zeros(nvec, np.int32)
+        for off, cnt in merged:
+            assert off % 4 == 0 and off + cnt <= spec.n_flat
+            covered[off // 4:off // 4 + (cnt + 3) // 4] += 1
+        covered[nvec - DP_TAIL_FLOATS // 4:] += 1
+        assert (covered == 1).all(), "vectors written {} times: {}".format(set(covered.tolist()), spec.state_dim)
+        for world in range(1, 17):
+            base, rem = divmod(nvec, world)
+            assert base >= 1

@@ -45,6 +45,9 @@ def _check_common(res, world, publisher_only_rank0=True, tpc=1):
     """no exchange error anywhere; rank 0 alone (or every rank) answers checkpoint_ready on every `tpc`-th train"""
     for r in range(world):
         assert int(res[r]["error_bits"][0]) == 0, "rank {}: the direct all-reduce reported error bits".format(r)
+        if int(res[r]["ranks_on_device"][0]):       # direct exchange: every rank found all the others on ITS device (the one
+            assert int(res[r]["ranks_on_device"][0]) == world       # GPU of the box) and sized its spinning launches for that
+            assert 1 <= int(res[r]["block_cap"][0]) <= 4096 // world
     want = np.arange(len(res[0]["answers"])) % tpc == 0
     assert np.array_equal(res[0]["answers"], want), res[0]["answers"]
     for r in range(1, world):

@@ -262,6 +262,53 @@ struct FinalizeArgs {
   } ap;
 };
 
+// ---- data-parallel step (xingtian_amd/parallel.py::LearnerDP; the reference's only analogue is the dead host-side
+// trainer, xt/framework/trainer.py:86-92,139-144).  The exchanged buffer is the flat gradient followed by a TAIL of
+// XT_DP_TAIL_FLOATS = 2 x 16 slots: [r] = rows rank r held for this update, [16 + r] = rank r's share of the step's loss.
+// Every rank fills its own two slots and zeroes the others, so after the SUM all-reduce every rank holds every rank's
+// values EXACTLY (one non-zero summand per slot) and derives the same global loss in rank order -- no host collective.
+constexpr int kDpMaxWorld = 16;
+constexpr int kDpTailFloats = XT_DP_TAIL_FLOATS;
+constexpr int kDpRedBlocksMax = 128;          // workgroups of the direct exchange's reduce launch (per rank)
+
+struct DirectPeers {
+  float* inbox_me[kDpMaxWorld];     // peer q's inbox slot for THIS rank
+  float* result[kDpMaxWorld];       // peer q's result buffer
+  uint32_t* flags[kDpMaxWorld];     // peer q's flag words
+  float* norm_part[kDpMaxWorld];    // peer q's squared-norm partials [world][reduce blocks]
+};
+
+struct DpFinish {                   // what grads_finish_kernel does for a data-parallel step
+  float* tail;                      // != nullptr: the extra block writes this rank's tail slots here (plain exchange)
+  int rank, world;
+  float rows;
+  // direct exchange fused into the step: every reduced float4 goes straight into the owning peer's inbox (no gradient
+  // buffer round trip, no scatter launch); the last block of the launch raises the ready flags (FinalizeArgs.counter)
+  int scatter;
+  const float* grads_base;          // flat index of an entry = dst - grads_base
+  long long nvec;                   // float4s of the exchanged buffer (gradient + tail)
+  DirectPeers peers;
+  uint32_t* ctl;                    // the comm's device-local control words
+};
+
+struct DpStep {                     // what the optimiser kernels do for a data-parallel step
+  const float* tail;                // the EXCHANGED tail (nullptr: none): block 0 adds the global loss to acc, checks the rows
+  int world;
+  float loss_scale;                 // PPO weak mode: 1 / world (mean of the ranks' means); else 1 (shares of one sum)
+  float* acc;                       // [0] += loss, [1] += 1, [2] = error bits
+  // direct exchange fused into the step: the first `red_blocks` workgroups of the optimiser launch first REDUCE this rank's
+  // slice (wait for every rank's scatter, sum the inbox slots in fixed rank order, push the slice and its squared-norm
+  // partials to every peer, raise the done flags); then every workgroup waits for all ranks' done flags and reads gradient
+  // and partials out of the exchange block; the last block re-arms the comm (tickets, sequence number)
+  const uint32_t* flags;            // my flag words (nullptr: plain exchange, nothing to wait for)
+  uint32_t* ctl;
+  unsigned long long timeout_ticks;
+  const float* inbox;               // my inbox: world slots of slice_cap floats
+  long long slice_cap, nvec, nvec_grad;
+  int rank, red_blocks;
+  DirectPeers peers;
+};
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // One-time set-up PER DEVICE (function attributes such as the dynamic-LDS limit belong to the device's copy of the

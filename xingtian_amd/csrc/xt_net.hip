@@ -46,7 +46,13 @@ int launch_dgrad(const xt_conv_geom*, int, const float*, const float*, const flo
 int launch_global_norm(const float*, long long, float, float, float, float, float, int, float*, float*, hipStream_t,
                        const float* lr_dev = nullptr, int* nblocks_out = nullptr);
 int launch_grads_finish(GradTable*, float*, int, int*, const FinalizeArgs*, hipStream_t, unsigned select = 0,
-                        unsigned early = 0);
+                        unsigned early = 0, const DpFinish* dpf = nullptr);
+int launch_dp_tail_write(float*, int, float, const float*, float*, float, const float*, float, float, int, hipStream_t);
+int launch_dp_tail_consume(const DpStep*, hipStream_t);
+// the direct exchange fused into the step (xt_xgmi.hip)
+int direct_fill_finish(xt_direct_comm*, int64_t, DpFinish*);
+int direct_launch_scatter(xt_direct_comm*, const float*, int64_t, hipStream_t);
+int direct_fill_step(xt_direct_comm*, int64_t, int64_t, DpStep*, const float**, const float**, int*, int*);
 int grads_finish_resident_blocks();
 int grads_finish_fused_grid(const GradTable*);
 int launch_sqnorm_partial(const float*, long long, float*, int*, hipStream_t);
@@ -54,9 +60,10 @@ int launch_norm_finalize(const float*, int, float, float, float, float, float, i
                          const float* lr_dev = nullptr);
 int launch_ppo_heads_fused(const PpoHeadArgs&, hipStream_t);
 int launch_adam_clip(float*, const float*, float*, float*, long long, float, float, float, float*, const float*, int,
-                     float, float, hipStream_t);
+                     float, float, hipStream_t, const DpStep* dp = nullptr, int block_cap = 0);
 int launch_rmsprop_clip(float*, const float*, float*, float*, long long, float, float, float, float*, const float*, int,
-                        float, float, hipStream_t, const float* lr_dev = nullptr);
+                        float, float, hipStream_t, const float* lr_dev = nullptr, const DpStep* dp = nullptr,
+                        int block_cap = 0);
 int launch_impala_heads_fwd(const ImpalaHeadArgs&, hipStream_t);
 int launch_impala_vtrace_bwd(const ImpalaLossArgs&, int, hipStream_t);
 int launch_impala_loss_reduce(const float*, int, float*, float*, hipStream_t);
@@ -120,6 +127,12 @@ struct xt_net {
   void* rccl_comm = nullptr;
   xt_nccl_allreduce_fn rccl_fn = nullptr;
   int rccl_calls = 0, rccl_last_error = 0;
+  // xt_net_set_dp: the exchanged buffer carries a tail of rows / loss shares behind the gradient (no host collectives);
+  // xt_net_set_direct: the direct exchange fused into the step (scatter inside the gradient reduction, gather inside the
+  // optimiser kernel)
+  int dp_rank = 0, dp_world = 0;
+  float dp_loss_scale = 1.f, dp_rows = 0.f;
+  xt_direct_comm* direct = nullptr;
   hipStream_t xchg_stream = nullptr;   // side stream of the first bucket's exchange
   hipEvent_t xchg_fork = nullptr, xchg_join = nullptr;
   // single-GPU tail overlap (xt_tuning.tail_overlap): a side stream for the first gradient bucket's slab reduction and
@@ -300,7 +313,8 @@ static int trunk_backward(xt_net* n, const void* obs, const int32_t* idx, int B,
 // PpoCnn's parameters); part 2: the remaining layers.  Parts 1 / 2 serve the overlapped data-parallel exchange.
 // fin->enable == 3 asks for the fused tail (reduction + norm + clip + Adam in one launch); *fused_out tells whether it ran
 // that way (it is downgraded to enable == 2 when its grid could not be resident at once)
-static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t st, int part = 0, bool* fused_out = nullptr) {
+static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t st, int part = 0, bool* fused_out = nullptr,
+                        const DpFinish* dpf = nullptr) {
   const int F = n->feat, A = n->A;
   GradTable tab;
   tab.n = 0;
@@ -352,7 +366,54 @@ static int grads_finish(xt_net* n, int B, const FinalizeArgs* fin, hipStream_t s
     }
     fin = &f2;
   }
-  return launch_grads_finish(&tab, n->ws + n->off_norm, kMaxNormPartials, &n->norm_blocks, fin, st, select, first_bucket);
+  return launch_grads_finish(&tab, n->ws + n->off_norm, kMaxNormPartials, &n->norm_blocks, fin, st, select, first_bucket, dpf);
+}
+
+// loss_acc = [sum, count, data-parallel error bits, -].  TWO 8-byte memsets, the second only for a data-parallel net: ONE
+// 16-byte hipMemsetAsync captured into a hipGraph wrote garbage (a pointer-looking 64-bit word) into bytes 8..15 on every
+// REPLAY on this stack (ROCm 7.0 runtime of PyTorch 2.10; measured round 6, tools/dbg_acc.py) -- the 8-byte node has been
+// replayed correctly since round 1
+static int clear_loss_acc(const xt_net* n, float* loss_acc, hipStream_t st) {
+  XT_CHECK_HIP(hipMemsetAsync(loss_acc, 0, 2 * sizeof(float), st));
+  if (n->dp_world >= 1) XT_CHECK_HIP(hipMemsetAsync(loss_acc + 2, 0, 2 * sizeof(float), st));
+  return 0;
+}
+
+// ---- data-parallel step helpers (xt_net_set_dp / xt_net_set_direct)
+static inline int64_t dp_tail_off(const xt_net* n) { return align4(n->P); }
+static inline int64_t dp_xcount(const xt_net* n) { return n->dp_world >= 1 ? align4(n->P) + kDpTailFloats : n->P; }
+// what the gradient-reduction launch of a data-parallel step does besides reducing: the tail, and -- fused direct
+// exchange -- the scatter into the owners' inboxes
+static int dp_finish_args(xt_net* n, DpFinish* d) {
+  memset(d, 0, sizeof(*d));
+  if (n->dp_world < 1) return 0;
+  d->rank = n->dp_rank; d->world = n->dp_world; d->rows = n->dp_rows;
+  if (n->direct) {
+    if (int rc = direct_fill_finish(n->direct, dp_xcount(n), d)) return rc;
+    d->grads_base = n->grads;
+  } else {
+    d->tail = n->grads + dp_tail_off(n);
+  }
+  return 0;
+}
+// after the local gradient is complete: exchange + squared norm of the EXCHANGED gradient (fused direct form: nothing is
+// launched here -- the optimiser launch reduces this rank's slice itself) -> what the optimiser launch needs
+struct DpApply { const float* g; const float* partial; int npartial; DpStep step; int block_cap; };
+static int dp_exchange(xt_net* n, hipStream_t st, float* loss_acc, DpApply* a) {
+  memset(a, 0, sizeof(*a));
+  a->step.world = n->dp_world; a->step.loss_scale = n->dp_loss_scale; a->step.acc = loss_acc;
+  if (n->direct && n->dp_world >= 1) {
+    if (int rc = direct_fill_step(n->direct, dp_xcount(n), n->P, &a->step, &a->g, &a->partial, &a->npartial, &a->block_cap))
+      return rc;
+    a->step.tail = a->g + dp_tail_off(n);
+    return 0;
+  }
+  XT_REQUIRE(n->xchg(n->grads, dp_xcount(n), n->xchg_user, st) == 0, "xt_net: gradient exchange hook failed");
+  int nb = 0;
+  if (int rc = launch_sqnorm_partial(n->grads, n->P, n->ws + n->off_norm, &nb, st)) return rc;
+  a->g = n->grads; a->partial = n->ws + n->off_norm; a->npartial = nb;
+  if (n->dp_world >= 1) a->step.tail = n->grads + dp_tail_off(n);
+  return 0;
 }
 
 // mode 0: gradient was changed after grads_finish (all-reduce) -> recompute the norm;
@@ -482,15 +543,25 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
   }
   // data-parallel overlap (apply == 2): reduce + exchange the last trunk layer's and the heads' gradient right after
   // the first backward launch, on the side stream, while the conv backward runs
-  struct Ovl { xt_net* n; int B; hipStream_t st; } ovl{n, B, st};
+  struct Ovl { xt_net* n; int B; hipStream_t st; float ent_coef, critic_coef, inv_b; } ovl{n, B, st, c->ent_coef, c->critic_coef, inv_b};
   AfterFirstBwd af{[](void* arg) -> int {
                      Ovl* o = static_cast<Ovl*>(arg);
                      xt_net* n = o->n;
                      if (int rc = grads_finish(n, o->B, nullptr, o->st, 1)) return rc;
                      const int64_t off = n->layers.back().poff;
+                     if (n->dp_world >= 1) {
+                       // the data-parallel tail rides in the FIRST bucket: the per-sample loss terms exist since the head
+                       // kernel, so the step's loss share can be reduced now (not added to loss_acc: the optimiser side does)
+                       if (int rc = xt_ppo_loss_reduce(n->ws + n->off_terms, o->B, o->ent_coef, o->critic_coef, o->inv_b,
+                                                       n->ws + n->off_loss, nullptr, o->st))
+                         return rc;
+                       if (int rc = launch_dp_tail_write(n->grads + dp_tail_off(n), n->dp_rank, n->dp_rows, n->ws + n->off_loss,
+                                                         nullptr, 0.f, nullptr, 0.f, 0.f, 0, o->st))
+                         return rc;
+                     }
                      XT_CHECK_HIP(hipEventRecord(n->xchg_fork, o->st));
                      XT_CHECK_HIP(hipStreamWaitEvent(n->xchg_stream, n->xchg_fork, 0));
-                     XT_REQUIRE(n->xchg(n->grads + off, n->P - off, n->xchg_user, n->xchg_stream) == 0,
+                     XT_REQUIRE(n->xchg(n->grads + off, dp_xcount(n) - off, n->xchg_user, n->xchg_stream) == 0,
                                 "xt_net: gradient exchange hook failed (first bucket)");
                      XT_CHECK_HIP(hipEventRecord(n->xchg_join, n->xchg_stream));
                      return 0;
@@ -502,6 +573,7 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
   if (int rc = trunk_backward(n, obs, idx, B, st, apply == 2 ? &af : (tov & 1) ? &tf : nullptr)) return rc;
   if (apply == 2) {
     if (int rc = grads_finish(n, B, nullptr, st, 2)) return rc;
+    if (n->dp_world >= 1) return 0;        // (loss share already in the tail of the first bucket)
     return xt_ppo_loss_reduce(n->ws + n->off_terms, B, c->ent_coef, c->critic_coef, inv_b, lo, loss_acc, st);
   }
   LossArgs la{};
@@ -512,7 +584,10 @@ static int ppo_step(xt_net* n, const xt_ppo_cfg* c, const void* obs, const int32
     fin.enable = 2; fin.counter = reinterpret_cast<unsigned int*>(n->ws + n->off_counter);
     fin.clip_norm = c->max_grad_norm; fin.grad_scale = c->grad_scale; fin.lr = c->lr; fin.beta1 = c->beta1;
     fin.beta2 = c->beta2; fin.state = n->state; fin.loss = la;
-    return grads_finish(n, B, &fin, st, 0, nullptr);
+    DpFinish dpf;
+    if (int rc = dp_finish_args(n, &dpf)) return rc;
+    if (n->dp_world >= 1) fin.loss.acc = nullptr;      // the GLOBAL loss is added on the optimiser side, from the exchanged tail
+    return grads_finish(n, B, &fin, st, 0, nullptr, &dpf);
   }
   if (apply == 1) {
     const int tail_mode = tuning().finalize_ticket ? 1 : 2;     // 1: the old "last block finalises" form (A/B)
@@ -618,8 +693,9 @@ static int impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int n
   } else {
     if (int rc = net_forward(n, obs, nullptr, nfr, true, st)) return rc;
     if (int rc = xt_impala_loss(n->ws + n->off_logits, n->ws + n->off_value, bp_logits, action, done, reward, ntraj, T,
-                                A, c->gamma, n->ws + n->off_dlogits, n->ws + n->off_dvalue, lo, loss_acc, nullptr,
-                                nullptr, st))
+                                A, c->gamma, n->ws + n->off_dlogits, n->ws + n->off_dvalue, lo,
+                                (apply == 3 && n->dp_world >= 1) ? nullptr : loss_acc,      // (tail mode: the optimiser side adds the GLOBAL loss)
+                                nullptr, nullptr, st))
       return rc;
     if (loss_out) XT_CHECK_HIP(hipMemcpyAsync(loss_out, lo, sizeof(float), hipMemcpyDeviceToDevice, st));
     if (int rc = launch_heads_dfeat(n->ws + (Lp.z_off >= 0 ? Lp.z_off : Lp.act_off), n->ws + (Lv.z_off >= 0 ? Lv.z_off : Lv.act_off), nfr, F, A, n->params + n->pi_off,
@@ -627,7 +703,7 @@ static int impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int n
                                     n->ws + Lp.dact_off, n->ws + Lv.dact_off, st))
       return rc;
   }
-  const int tov = (apply && c->opt_type == XT_OPT_ADAM) ? tail_overlap_mode(n) : 0;
+  const int tov = (apply == 1 && c->opt_type == XT_OPT_ADAM) ? tail_overlap_mode(n) : 0;
   TailFork tfk{n, nfr, st, false};
   AfterFirstBwd tf{tail_fork_first_bucket, &tfk};
   if (int rc = trunk_backward(n, obs, nullptr, nfr, st, (tov & 1) ? &tf : nullptr)) return rc;
@@ -643,6 +719,19 @@ static int impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int n
   fin.lr = c->lr; fin.beta1 = c->beta1; fin.beta2 = c->beta2; fin.state = n->state; fin.lr_dev = lr_dev;
   if (loss_pending) {
     fin.loss.traj_loss = lo + 4; fin.loss.n_traj = ntraj; fin.loss.out = loss_out ? loss_out : lo; fin.loss.acc = loss_acc;
+  }
+  if (apply == 3) {
+    // the data-parallel chunk of xt_net_impala_train: gradient + loss scalar + step-size advance (+ the tail / the scatter
+    // into the owners' inboxes), no update -- the optimiser runs on the EXCHANGED gradient
+    if (!loss_pending) {      // (unfused heads: the loss scalar sits in lo[0] already; as a one-trajectory sum for the block)
+      fin.loss.traj_loss = lo; fin.loss.n_traj = 1; fin.loss.out = loss_out ? loss_out : lo; fin.loss.acc = nullptr;
+    }
+    DpFinish dpf;
+    if (int rc = dp_finish_args(n, &dpf)) return rc;
+    fin.counter = reinterpret_cast<unsigned int*>(n->ws + n->off_counter);      // (the scatter ticket of the fused exchange)
+    if (n->dp_world >= 1) fin.loss.acc = nullptr;
+    else if (!loss_pending) fin.loss.traj_loss = nullptr;      // (xt_impala_loss has added it to loss_acc itself)
+    return grads_finish(n, nfr, &fin, st, 0, nullptr, &dpf);
   }
   bool fused_tail = false;
   if (tfk.done) {
@@ -842,7 +931,9 @@ int xt_net_ppo_step(xt_net* net, const xt_ppo_cfg* cfg, const void* obs, const i
 static int ppo_train_enqueue(xt_net* net, const xt_ppo_cfg* c, const void* obs, int32_t n, const int32_t* perm,
                              const void* action, const float* old_logp, const double* adv, const float* old_v,
                              const double* target_v, float* loss_acc, hipStream_t st) {
-  XT_CHECK_HIP(hipMemsetAsync(loss_acc, 0, 2 * sizeof(float), st));
+  if (int rc = xt::clear_loss_acc(net, loss_acc, st)) return rc;
+  XT_REQUIRE(n < (1 << 24), "xt_net_ppo_train: %d rows do not fit the data-parallel tail's float slot", n);
+  net->dp_rows = (float)n;
   for (int ep = 0; ep < c->num_sgd_iter; ++ep) {
     for (int start = 0; start < n; start += c->batch_size) {
       int B = (n - start) < c->batch_size ? (n - start) : c->batch_size;
@@ -875,7 +966,7 @@ static int ppo_train_enqueue(xt_net* net, const xt_ppo_cfg* c, const void* obs, 
       // gradient, clip, Adam
       const int64_t off_a = net->layers.back().poff;      // first bucket = [off_a, P): last trunk layer + heads
       const bool overlap = (net->xchg_flags & XT_XCHG_OVERLAP) && net->n_trunks == 1 && net->layers.size() > 1 &&
-                           off_a > 0 && net->pi_off > off_a && net->v_off > off_a && net->xchg_stream != nullptr;
+                           off_a > 0 && net->pi_off > off_a && net->v_off > off_a && net->xchg_stream != nullptr && !net->direct;
       if (int rc = xt::ppo_step(net, &cc, obs, rows, B, action, old_logp, adv, old_v,
                                 target_v, overlap ? 2 : 3, nullptr, loss_acc, st))
         return rc;
@@ -884,17 +975,23 @@ static int ppo_train_enqueue(xt_net* net, const xt_ppo_cfg* c, const void* obs, 
         XT_CHECK_HIP(hipStreamWaitEvent(st, net->xchg_join, 0));      // first bucket's exchange has finished
         if (int rc = xt::net_apply(net, cc.lr, cc.beta1, cc.beta2, cc.eps, cc.max_grad_norm, cc.grad_scale, 0, nullptr, st))
           return rc;
+        if (net->dp_world >= 1) {
+          xt::DpStep ds{};
+          ds.tail = net->grads + xt::dp_tail_off(net); ds.world = net->dp_world; ds.loss_scale = net->dp_loss_scale; ds.acc = loss_acc;
+          if (int rc = xt::launch_dp_tail_consume(&ds, st)) return rc;
+        }
         continue;
       }
-      XT_REQUIRE(net->xchg(net->grads, net->P, net->xchg_user, st) == 0, "xt_net_ppo_train: gradient exchange hook failed");
       // (round 5) the loss scalars and the Adam step-size advance rode in the gradient-reduction launch (apply == 3); what
       // is left after the exchange: the squared-norm partials of the EXCHANGED gradient, then Adam, every block deriving
-      // the clip factor from them itself -- two launches instead of the four of the step-wise path (loss reduction,
-      // partials, finalize, Adam).  Same partials, same fixed-order sum: bitwise the step-wise path's parameters.
-      int nb = 0;
-      if (int rc = xt::launch_sqnorm_partial(net->grads, net->P, net->ws + net->off_norm, &nb, st)) return rc;
-      if (int rc = xt::launch_adam_clip(net->params, net->grads, net->m, net->v, net->P, cc.beta1, cc.beta2, cc.eps, net->state,
-                                        net->ws + net->off_norm, nb, cc.max_grad_norm, cc.grad_scale, st))
+      // the clip factor from them itself.  (round 6) xt_net_set_dp: the tail of the exchanged buffer carries every rank's
+      // rows and loss share -- the optimiser's block 0 adds the GLOBAL loss, no host collective per train; xt_net_set_direct:
+      // the gradient reduction scattered straight into the owners' inboxes, dp_exchange is ONE small reduce launch that also
+      // leaves the squared-norm partials, Adam reads the exchange block: three launches after the backward pass.
+      xt::DpApply da;
+      if (int rc = xt::dp_exchange(net, st, loss_acc, &da)) return rc;
+      if (int rc = xt::launch_adam_clip(net->params, da.g, net->m, net->v, net->P, cc.beta1, cc.beta2, cc.eps, net->state,
+                                        da.partial, da.npartial, cc.max_grad_norm, cc.grad_scale, st, &da.step, da.block_cap))
         return rc;
     }
   }
@@ -912,8 +1009,9 @@ int xt_net_ppo_train(xt_net* net, const xt_ppo_cfg* c, const void* obs, int32_t 
   if (!use_graph)
     return ppo_train_enqueue(net, c, obs, n, perm, action, old_logp, adv, old_v, target_v, loss_acc, st);
   char key[512];
-  snprintf(key, sizeof(key), "P%d.%d.%d|%p|%p|%p|%d|%p|%p|%p|%p|%p|%p|%p|%g|%g|%g|%g|%g|%g|%g|%g|%g|%d|%d|%g|%d",
-           net->xchg_flags, c->shard_rank, c->shard_world, (void*)net->xchg, net->xchg_user, obs, n,
+  snprintf(key, sizeof(key), "P%d.%d.%d.%d.%d.%g.%p|%p|%p|%p|%d|%p|%p|%p|%p|%p|%p|%p|%g|%g|%g|%g|%g|%g|%g|%g|%g|%d|%d|%g|%d",
+           net->xchg_flags, c->shard_rank, c->shard_world, net->dp_rank, net->dp_world, net->dp_loss_scale, (void*)net->direct,
+           (void*)net->xchg, net->xchg_user, obs, n,
            (const void*)perm, (const void*)action, (const void*)old_logp, (const void*)adv, (const void*)old_v,
            (const void*)target_v, (void*)loss_acc, c->lr, c->beta1, c->beta2, c->eps, c->clip_ratio, c->ent_coef,
            c->vf_clip, c->critic_coef, c->max_grad_norm, c->batch_size, c->num_sgd_iter, c->grad_scale,
@@ -934,7 +1032,9 @@ int xt_net_impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int32
 static int impala_train_enqueue(xt_net* net, const xt_impala_cfg* c, const void* obs, int32_t n, int32_t batch_size,
                                 const float* bp_logits, const int32_t* action, const uint8_t* done, const float* reward,
                                 const float* lr_steps, float* loss_acc, hipStream_t st) {
-  XT_CHECK_HIP(hipMemsetAsync(loss_acc, 0, 2 * sizeof(float), st));
+  if (int rc = xt::clear_loss_acc(net, loss_acc, st)) return rc;
+  XT_REQUIRE(n < (1 << 24), "xt_net_impala_train: %d frames do not fit the data-parallel tail's float slot", n);
+  net->dp_rows = (float)n;
   const size_t frame = (size_t)net->in_h * net->in_w * net->in_c * (net->xf.is_u8 ? 1 : 4);
   int chunk = 0;
   for (int lo = 0; lo < n; lo += batch_size, ++chunk) {
@@ -963,28 +1063,36 @@ static int impala_train_enqueue(xt_net* net, const xt_impala_cfg* c, const void*
       nfr_s = (base + (c->shard_rank < rem ? 1 : 0)) * T;
     }
     if (nfr_s > 0) {
+      // gradient of this rank's trajectories + the loss scalar + the step-size advance (lr_schedule's value is read on the
+      // device) in the gradient-reduction launch; with xt_net_set_dp also the tail, with xt_net_set_direct the scatter
       const void* o = static_cast<const char*>(obs) + frame * lo_s;
       if (int rc = xt::impala_step(net, c, o, nfr_s, bp_logits + (size_t)lo_s * net->A, action + lo_s, done + lo_s,
-                                   reward + lo_s, 0, lr_dev, nullptr, loss_acc, st))
+                                   reward + lo_s, 3, lr_dev, nullptr, loss_acc, st))
         return rc;
     } else {
-      XT_CHECK_HIP(hipMemsetAsync(net->grads, 0, sizeof(float) * (size_t)net->P, st));   // empty shard: zero contribution
+      // empty shard (fewer trajectories than ranks): a ZERO contribution -- zeros, the step-size advance, the tail (loss 0)
+      const int64_t xc = xt::dp_xcount(net);
+      XT_CHECK_HIP(hipMemsetAsync(net->grads, 0, sizeof(float) * (size_t)xc, st));
+      if (int rc = xt::launch_dp_tail_write(net->dp_world >= 1 ? net->grads + xt::dp_tail_off(net) : net->ws + net->off_loss,
+                                            net->dp_world >= 1 ? net->dp_rank : 0, net->dp_rows, nullptr, net->state, c->lr,
+                                            lr_dev, c->beta1, c->beta2, 1, st))
+        return rc;
+      if (net->direct && net->dp_world >= 1)
+        if (int rc = xt::direct_launch_scatter(net->direct, net->grads, xc, st)) return rc;
     }
-    XT_REQUIRE(net->xchg(net->grads, net->P, net->xchg_user, st) == 0, "xt_net_impala_train: gradient exchange hook failed");
-    // norm of the EXCHANGED gradient (+ the step-size bookkeeping; lr_schedule's value is read on the device), then the
-    // configured optimiser: Adam, or centred RMSProp which derives the clip factor from the same partials itself
-    int nb = 0;
-    if (int rc = xt::launch_global_norm(net->grads, net->P, c->grad_norm_clip, c->grad_scale, c->lr, c->beta1, c->beta2, 1,
-                                        net->state, net->ws + net->off_norm, st, lr_dev, &nb))
-      return rc;
+    // exchange -> squared norm of the EXCHANGED gradient -> the configured optimiser (Adam, or centred RMSProp), every block
+    // deriving the clip factor from the partials itself
+    xt::DpApply da;
+    if (int rc = xt::dp_exchange(net, st, loss_acc, &da)) return rc;
     if (c->opt_type == XT_OPT_RMSPROP_CENTERED) {
-      if (int rc = xt::launch_rmsprop_clip(net->params, net->grads, net->m, net->v, net->P, c->lr, c->rms_decay, c->rms_eps,
-                                           net->state, net->ws + net->off_norm, nb, c->grad_norm_clip, c->grad_scale, st,
-                                           lr_dev))
+      if (int rc = xt::launch_rmsprop_clip(net->params, da.g, net->m, net->v, net->P, c->lr, c->rms_decay, c->rms_eps,
+                                           net->state, da.partial, da.npartial, c->grad_norm_clip, c->grad_scale, st,
+                                           lr_dev, &da.step, da.block_cap))
         return rc;
     } else {
       XT_REQUIRE(c->opt_type == XT_OPT_ADAM, "xt_net_impala_train: unknown opt_type %d", c->opt_type);
-      if (int rc = xt::launch_adam(net->params, net->grads, net->m, net->v, net->P, c->beta1, c->beta2, c->eps, net->state, st))
+      if (int rc = xt::launch_adam_clip(net->params, da.g, net->m, net->v, net->P, c->beta1, c->beta2, c->eps, net->state,
+                                        da.partial, da.npartial, c->grad_norm_clip, c->grad_scale, st, &da.step, da.block_cap))
         return rc;
     }
   }
@@ -1009,8 +1117,8 @@ int xt_net_impala_train(xt_net* net, const xt_impala_cfg* c, const void* obs, in
   if (!use_graph)
     return impala_train_enqueue(net, c, obs, n, batch_size, bp_logits, action, done, reward, lr_steps, loss_acc, st);
   char key[512];
-  snprintf(key, sizeof(key), "I%d.%d|%p|%p|%p|%d|%d|%p|%p|%p|%p|%p|%p|%g|%g|%g|%g|%g|%g|%d|%g|%d|%g|%g",
-           c->shard_rank, c->shard_world, (void*)net->xchg, net->xchg_user, obs, n, batch_size, (const void*)bp_logits, (const void*)action,
+  snprintf(key, sizeof(key), "I%d.%d.%d.%d.%p|%p|%p|%p|%d|%d|%p|%p|%p|%p|%p|%p|%g|%g|%g|%g|%g|%g|%d|%g|%d|%g|%g",
+           c->shard_rank, c->shard_world, net->dp_rank, net->dp_world, (void*)net->direct, (void*)net->xchg, net->xchg_user, obs, n, batch_size, (const void*)bp_logits, (const void*)action,
            (const void*)done, (const void*)reward, (const void*)lr_steps, (void*)loss_acc, c->lr, c->beta1, c->beta2,
            c->eps, c->grad_norm_clip, c->gamma, c->sample_batch_step, c->grad_scale, c->opt_type, c->rms_decay, c->rms_eps);
   return xt::graph_run(net, key, st, [&](hipStream_t cs) {
@@ -1059,6 +1167,38 @@ int xt_net_set_grad_exchange(xt_net* net, xt_grad_exchange_fn fn, void* user) {
   return xt_net_set_grad_exchange_ex(net, fn, user, 0);
 }
 
+int xt_net_set_dp(xt_net* net, int32_t rank, int32_t world, float loss_scale) {
+  XT_REQUIRE(net, "xt_net_set_dp: null net");
+  if (world <= 0) {
+    XT_REQUIRE(!net->direct, "xt_net_set_dp: detach the direct exchange (xt_net_set_direct(net, NULL)) first");
+    net->dp_rank = 0; net->dp_world = 0; net->dp_loss_scale = 1.f;
+    return 0;
+  }
+  XT_REQUIRE(world <= xt::kDpMaxWorld && rank >= 0 && rank < world, "xt_net_set_dp: rank %d / world %d (max %d)", rank, world,
+             xt::kDpMaxWorld);
+  XT_REQUIRE(net->grads, "xt_net_set_dp: buffers not bound");
+  net->dp_rank = rank; net->dp_world = world; net->dp_loss_scale = loss_scale;
+  return 0;
+}
+
+int xt_net_set_direct(xt_net* net, xt_direct_comm* comm) {
+  XT_REQUIRE(net, "xt_net_set_direct: null net");
+  if (!comm) {
+    net->direct = nullptr;
+    return xt_net_set_grad_exchange_ex(net, nullptr, nullptr, 0);
+  }
+  XT_REQUIRE(net->dp_world >= 1, "xt_net_set_direct: call xt_net_set_dp(net, rank, world, ...) first (the fused exchange "
+                                "carries the data-parallel tail)");
+  xt::DpFinish probe;
+  memset(&probe, 0, sizeof(probe));
+  if (int rc = xt::direct_fill_finish(comm, xt::dp_xcount(net), &probe)) return rc;
+  XT_REQUIRE(probe.rank == net->dp_rank && probe.world == net->dp_world,
+             "xt_net_set_direct: the comm is rank %d of %d, the net was set up as rank %d of %d", probe.rank, probe.world,
+             net->dp_rank, net->dp_world);
+  net->direct = comm;
+  return xt_net_set_grad_exchange_ex(net, xt_direct_exchange_hook, comm, 0);
+}
+
 // the exchange served by the library: ncclAllReduce(grads, grads, count, ncclFloat32, ncclSum, comm, stream) through the
 // function pointer the caller resolved from the RCCL instance of its process (dlsym / ctypes)
 static int rccl_exchange(float* grads, int64_t count, void* user, void* stream) {
@@ -1090,6 +1230,43 @@ int xt_net_apply(xt_net* n, float lr, float beta1, float beta2, float eps, float
                  void* stream) {
   XT_REQUIRE(n && n->params && n->m && n->v && n->state, "xt_net_apply: buffers not bound");
   return xt::net_apply(n, lr, beta1, beta2, eps, clip_norm, grad_scale, 0, nullptr, xt::as_stream(stream));
+}
+
+int xt_net_time_tail(xt_net* n, float lr, float clip_norm, int32_t reps, float* ms_out, void* stream) {
+  XT_REQUIRE(n && n->params && n->ws && ms_out && reps > 0, "xt_net_time_tail: bad arguments");
+  hipStream_t st = xt::as_stream(stream);
+  auto one = [&]() -> int {
+    xt::FinalizeArgs fin{};
+    fin.enable = 2; fin.counter = reinterpret_cast<unsigned int*>(n->ws + n->off_counter);
+    fin.clip_norm = clip_norm; fin.grad_scale = 1.f; fin.lr = lr; fin.beta1 = 0.9f; fin.beta2 = 0.999f; fin.state = n->state;
+    if (n->xchg || n->dp_world >= 1) {
+      xt::DpFinish dpf;
+      if (int rc = xt::dp_finish_args(n, &dpf)) return rc;
+      if (int rc = xt::grads_finish(n, 1, &fin, st, 0, nullptr, &dpf)) return rc;
+      xt::DpApply da;
+      if (int rc = xt::dp_exchange(n, st, nullptr, &da)) return rc;
+      return xt::launch_adam_clip(n->params, da.g, n->m, n->v, n->P, 0.9f, 0.999f, 1e-8f, n->state, da.partial, da.npartial,
+                                  clip_norm, 1.f, st, &da.step, da.block_cap);
+    }
+    if (int rc = xt::grads_finish(n, 1, &fin, st)) return rc;
+    return xt::net_apply(n, lr, 0.9f, 0.999f, 1e-8f, clip_norm, 1.f, 3, nullptr, st);
+  };
+  hipEvent_t e0, e1;
+  XT_CHECK_HIP(hipEventCreate(&e0));
+  XT_CHECK_HIP(hipEventCreate(&e1));
+  int rc = one();
+  if (!rc) {
+    hipEventRecord(e0, st);
+    for (int i = 0; i < reps && !rc; ++i) rc = one();
+    hipEventRecord(e1, st);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    *ms_out = ms / reps;
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return rc;
 }
 
 int xt_net_layer_offsets(const xt_net* n, int32_t layer, int64_t* out4) {

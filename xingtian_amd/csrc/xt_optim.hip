@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "xt_common.h"
+#include "xt_xgmi_dev.h"
 #include <atomic>
 
 namespace xt {
@@ -47,8 +48,31 @@ __device__ __forceinline__ void adam_advance(float* state, float lr, float beta1
 __device__ void finalize_body(const float* partial, int nblocks, float clip_norm, float grad_scale, float lr,
                               float beta1, float beta2, int advance, float* state, const LossArgs& la, double* sh);
 
+// data-parallel tail slots of THIS rank for one step: [rank] = rows, [16 + rank] = loss share, everything else zero
+__device__ __forceinline__ float dp_tail_value(int i, int rank, float rows, float loss) {
+  return i == rank ? rows : (i == kDpMaxWorld + rank ? loss : 0.f);
+}
+
+// the scatter ticket of the gradient-reduction launch (fused direct exchange): every block has pushed its float4s into the
+// owners' inboxes and drained its stores; the LAST block of the launch raises this rank's ready flag at every peer.  Two-level
+// block ticket (64 sub-counters + a top counter, one 128-byte line each, both re-armed by their last arriver): ~1700 blocks
+// bumping one word would serialise at ~12 ns each -- measured round 6: 20 of the launch's 30 us with per-owner word tickets.
+__device__ __forceinline__ void dp_scatter_ticket(const DpFinish& d, unsigned int* counter) {
+  if (threadIdx.x != 0) return;
+  const unsigned nsub = gridDim.x < 64u ? gridDim.x : 64u;
+  const unsigned sub = blockIdx.x % nsub;
+  const unsigned cnt = (gridDim.x - sub + nsub - 1u) / nsub;
+  if (__hip_atomic_fetch_add(counter + 32u * (1u + sub), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != cnt - 1u) return;
+  __hip_atomic_store(counter + 32u * (1u + sub), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != nsub - 1u) return;
+  __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t seq = d.ctl[kCtlSeq] + 1;
+  for (int q = 0; q < d.world; ++q)
+    __hip_atomic_store(d.peers.flags[q] + kReadyOff + d.rank, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(256) void grads_finish_kernel(const GradTable tab, float* __restrict__ partial,
-                                                           const FinalizeArgs fin) {
+                                                           const FinalizeArgs fin, const DpFinish dpf) {
   __shared__ float4 sh4[256];
   __shared__ float shs[256];
   __shared__ int s_last;
@@ -69,6 +93,28 @@ __global__ __launch_bounds__(256) void grads_finish_kernel(const GradTable tab, 
         __hip_atomic_store(fin.state + 3, fin.state[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         grid_arrive(fin.counter, bar_flag, s_sense);
+      }
+      shs[0] = fin.loss.out ? fin.loss.out[0] : 0.f;        // (thread 0 wrote it itself a few lines up)
+    }
+    if (dpf.tail || dpf.scatter) {
+      // data-parallel tail: this rank's rows and loss share in its own two slots, zeros elsewhere (SUM = every rank's values)
+      __syncthreads();
+      const float loss = shs[0];
+      if (!dpf.scatter) {
+        if (threadIdx.x < kDpTailFloats) dpf.tail[threadIdx.x] = dp_tail_value(threadIdx.x, dpf.rank, dpf.rows, loss);
+      } else {
+        if (threadIdx.x < kDpTailFloats / 4) {
+          const int i = 4 * (int)threadIdx.x;
+          const long long v = dpf.nvec - kDpTailFloats / 4 + threadIdx.x;
+          int64_t b;
+          const int q = owner_of(v, dpf.nvec, dpf.world, b);
+          reinterpret_cast<float4*>(dpf.peers.inbox_me[q])[v - b] =
+              make_float4(dp_tail_value(i, dpf.rank, dpf.rows, loss), dp_tail_value(i + 1, dpf.rank, dpf.rows, loss),
+                          dp_tail_value(i + 2, dpf.rank, dpf.rows, loss), dp_tail_value(i + 3, dpf.rank, dpf.rows, loss));
+        }
+        publish_fence();
+        __syncthreads();
+        dp_scatter_ticket(dpf, fin.counter);
       }
     }
     return;
@@ -118,7 +164,20 @@ __global__ __launch_bounds__(256) void grads_finish_kernel(const GradTable tab, 
       r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
     }
     float* dp = E.dst + e0;
-    if (full) {
+    if (dpf.scatter) {
+      // direct exchange fused into the step: the reduced float4 goes straight into its OWNER's inbox (posted remote write);
+      // the lanes past the entry's end are alignment padding of the flat buffer: zeros
+      if (!full) {
+        if (e0 + 1 >= E.count) r.y = 0.f;
+        if (e0 + 2 >= E.count) r.z = 0.f;
+        r.w = 0.f;
+      }
+      const long long v = ((long long)(dp - dpf.grads_base)) >> 2;
+      int64_t b;
+      const int q = owner_of(v, dpf.nvec, dpf.world, b);
+      reinterpret_cast<float4*>(dpf.peers.inbox_me[q])[v - b] = r;
+      sq = r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
+    } else if (full) {
       if (E.nslab > 1 || E.src != E.dst) *reinterpret_cast<float4*>(dp) = r;
       sq = r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
     } else {
@@ -213,6 +272,12 @@ __global__ __launch_bounds__(256) void grads_finish_kernel(const GradTable tab, 
     return;
   }
   if (fin.enable != 1) {
+    if (dpf.scatter) {            // (the local squared-norm partials are of no use: the norm is that of the EXCHANGED gradient)
+      publish_fence();
+      __syncthreads();
+      dp_scatter_ticket(dpf, fin.counter);
+      return;
+    }
     if (t == 0) partial[E.pblk0 + ((int)blockIdx.x - E.blk0)] = shs[0];
     return;
   }
@@ -463,13 +528,118 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, con
 // grads_finish_kernel (1920 floats from L2, fixed-order double sum -> bitwise the same factor in every block):
 // removes the serial "last block finalises" tail (ticket + 6 us single-block reduction) from the step.  Block 0
 // also publishes scale / gnorm to state[2] / state[4] (nobody reads them inside this launch).
+// ---- the data-parallel part of an optimiser launch (DpStep)
+// begin: direct exchange -> reduce my slice (the first workgroups), then wait for every rank's reduced slice; returns false
+// when the comm's sticky error word is set (a
+// bounded wait ran out, now or earlier): the update is then SKIPPED -- parameters and slots stay those of the last good step
+// instead of absorbing whatever arrived -- and the bits travel to the host in loss_acc[2]
+__device__ bool dp_step_begin(const DpStep& dp) {
+  __shared__ int s_ok;
+  __shared__ float s_sq[256];
+  if (!dp.flags) return true;
+  const uint32_t seq = dp.ctl[kCtlSeq] + 1;
+  if ((int)blockIdx.x < dp.red_blocks) {
+    // ---- reduce phase (what was a launch of its own): my slice, FIXED rank order 0..N-1 -> every peer's result buffer
+    wait_all(dp.flags, kReadyOff, dp.world, seq, dp.ctl, dp.timeout_ticks, kErrScatterWait);
+    int64_t b, e;
+    slice_of(dp.nvec, dp.rank, dp.world, b, e);
+    const int64_t per = ((e - b) + dp.red_blocks - 1) / dp.red_blocks;
+    const int64_t lo = b + (int64_t)blockIdx.x * per;
+    const int64_t hi = lo + per < e ? lo + per : e;
+    float sq = 0.f;
+    // four vectors per thread in flight (clamped unconditional loads): the inbox is UNCACHED memory, every load is a full
+    // memory round trip -- a rolled loop serialised them (one-rank group: 6.5 dependent round trips per thread)
+    for (int64_t v0 = lo + threadIdx.x; v0 < hi; v0 += 4 * 256) {
+      float4 acc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t v = v0 + u * 256 < hi ? v0 + u * 256 : v0;
+        acc[u] = *reinterpret_cast<const float4*>(dp.inbox + (v - b) * 4);
+      }
+      for (int p = 1; p < dp.world; ++p) {          // FIXED order 0, 1, ..., N-1: the sum is a function of the data only
+        float4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t v = v0 + u * 256 < hi ? v0 + u * 256 : v0;
+          x[u] = *reinterpret_cast<const float4*>(dp.inbox + p * dp.slice_cap + (v - b) * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc[u].x += x[u].x; acc[u].y += x[u].y; acc[u].z += x[u].z; acc[u].w += x[u].w; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t v = v0 + u * 256;
+        if (v < hi) {
+          for (int p = 0; p < dp.world; ++p) reinterpret_cast<float4*>(dp.peers.result[p])[v] = acc[u];
+          if (v < dp.nvec_grad)      // (not the tail slots)
+            sq += acc[u].x * acc[u].x + acc[u].y * acc[u].y + acc[u].z * acc[u].z + acc[u].w * acc[u].w;
+        }
+      }
+    }
+    s_sq[threadIdx.x] = sq;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) s_sq[threadIdx.x] += s_sq[threadIdx.x + o];
+      __syncthreads();
+    }
+    if ((int)threadIdx.x < dp.world) dp.peers.norm_part[threadIdx.x][dp.rank * dp.red_blocks + blockIdx.x] = s_sq[0];
+    publish_fence();
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(dp.ctl + kCtlRed, 1u) == (uint32_t)dp.red_blocks - 1u) {
+      for (int p = 0; p < dp.world; ++p)
+        __hip_atomic_store(dp.peers.flags[p] + kDoneOff + dp.rank, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  wait_all(dp.flags, kDoneOff, dp.world, seq, dp.ctl, dp.timeout_ticks, kErrReduceWait);
+  if (threadIdx.x == 0)
+    s_ok = __hip_atomic_load(dp.ctl + kCtlErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u ? 1 : 0;
+  __syncthreads();
+  return s_ok != 0;
+}
+// block 0: the global loss (every rank's share, rank order -> the same bits everywhere) and the row check
+__device__ void dp_tail_consume(const DpStep& dp, bool ok) {
+  if (!dp.tail || blockIdx.x != 0 || threadIdx.x != 0) return;
+  uint32_t err = 0u;
+  if (ok) {
+    float s = 0.f;
+    const float rows0 = dp.tail[0];
+    for (int r = 0; r < dp.world; ++r) {
+      s += dp.tail[kDpMaxWorld + r];
+      if (dp.tail[r] != rows0) err = kErrRowsMismatch;
+    }
+    if (dp.acc) { dp.acc[0] += dp.loss_scale * s; dp.acc[1] += 1.f; }
+    if (err && dp.ctl) atomicOr(dp.ctl + kCtlErr, err);
+  }
+  if (dp.ctl) err |= __hip_atomic_load(dp.ctl + kCtlErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (err && dp.acc) dp.acc[2] = (float)err;
+}
+// end: direct exchange -> the last block re-arms the comm for the next step (tickets, sequence number)
+__device__ void dp_step_end(const DpStep& dp) {
+  if (!dp.flags) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(dp.ctl + kCtlGat, 1u) == gridDim.x - 1) {
+      const uint32_t seq = dp.ctl[kCtlSeq] + 1;
+      dp.ctl[kCtlRed] = 0;
+      dp.ctl[kCtlGat] = 0;
+      for (int q = 0; q < dp.world; ++q) dp.ctl[kCtlScat + q] = 0;
+      __threadfence();
+      dp.ctl[kCtlSeq] = seq;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void adam_tf_clip_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                            float* __restrict__ m, float* __restrict__ v, long long count,
                                                            float beta1, float beta2, float eps, float* __restrict__ state,
                                                            const float* __restrict__ partial, int nblocks,
-                                                           float clip_norm, float grad_scale) {
+                                                           float clip_norm, float grad_scale, const DpStep dp) {
   __shared__ double sh[256];
   __shared__ float s_scale;
+  const bool ok = dp_step_begin(dp);
+  dp_tail_consume(dp, ok);
+  if (!ok) { dp_step_end(dp); return; }
   const double sq = sqnorm_total(partial, nblocks, sh);
   if (threadIdx.x == 0) {
     float gnorm, sc;
@@ -508,6 +678,7 @@ __global__ __launch_bounds__(256) void adam_tf_clip_kernel(float* __restrict__ p
     m[i] = mm; v[i] = vv;
     p[i] -= (mm * alpha) / (sqrtf(vv) + eps);
   }
+  dp_step_end(dp);
 }
 
 // tf.train.RMSPropOptimizer(centered=True, momentum=0) after tf.clip_by_global_norm, TF1 apply_centered_rms_prop:
@@ -518,10 +689,13 @@ __global__ __launch_bounds__(256) void rmsprop_tf_clip_kernel(float* __restrict_
                                                               long long count, float lr_arg, float decay, float eps,
                                                               float* __restrict__ state, const float* __restrict__ partial,
                                                               int nblocks, float clip_norm, float grad_scale,
-                                                              const float* __restrict__ lr_dev) {
+                                                              const float* __restrict__ lr_dev, const DpStep dp) {
   __shared__ double sh[256];
   __shared__ float s_scale;
   const float lr = lr_dev ? lr_dev[0] : lr_arg;
+  const bool ok = dp_step_begin(dp);
+  dp_tail_consume(dp, ok);
+  if (!ok) { dp_step_end(dp); return; }
   const double sq = sqnorm_total(partial, nblocks, sh);
   if (threadIdx.x == 0) {
     float gnorm, sc;
@@ -539,6 +713,7 @@ __global__ __launch_bounds__(256) void rmsprop_tf_clip_kernel(float* __restrict_
     ms[i] = a; mg[i] = b;
     p[i] -= lr * gg / sqrtf(a - b * b + eps);
   }
+  dp_step_end(dp);
 }
 
 __global__ void adam_state_init_kernel(float* state) {
@@ -551,7 +726,7 @@ __global__ void adam_state_init_kernel(float* state) {
 // same norm) as one launch.  `early` = the entries whose slots come first: a partial launch of exactly these entries
 // may run before the slab counts of the others are known (their slots do not depend on them).
 int launch_grads_finish(GradTable* tab, float* partial, int max_partials, int* nblocks_out, const FinalizeArgs* fin,
-                        hipStream_t st, unsigned select, unsigned early) {
+                        hipStream_t st, unsigned select, unsigned early, const DpFinish* dpf) {
   int blk = 0;
   for (int pass = 0; pass < 2; ++pass)
   for (int i = 0; i < tab->n; ++i) {
@@ -582,7 +757,8 @@ int launch_grads_finish(GradTable* tab, float* partial, int max_partials, int* n
     if (select && !((select >> i) & 1u)) continue;
     if (tab->e[i].pre > 0) {
       any_pre = true;
-      if (!fused) continue;               // reduced and squared by its producer; the fused tail still has to update it
+      // reduced and squared by its producer; the fused tail still has to update it, the direct exchange still has to push it
+      if (!fused && !(dpf && dpf->scatter)) continue;
     }
     GradEntry& E = sub.e[sub.n++];
     E = tab->e[i];
@@ -595,7 +771,20 @@ int launch_grads_finish(GradTable* tab, float* partial, int max_partials, int* n
              "pre-reduced entries)");
   XT_REQUIRE(!fused || (!select && f.counter), "grads_finish: the fused tail takes the whole table and a barrier scratch");
   if (fused) f.ap.npartials = blk;
-  hipLaunchKernelGGL(grads_finish_kernel, dim3(grid + (f.enable >= 2 ? 1 : 0)), dim3(256), 0, st, sub, partial, f);
+  DpFinish d;
+  if (dpf) d = *dpf; else memset(&d, 0, sizeof(d));
+  if (d.tail || d.scatter)
+    XT_REQUIRE(f.enable == 2 && !select, "grads_finish: the data-parallel tail rides in the extra block of the whole-table launch");
+  if (d.scatter) {
+    XT_REQUIRE(d.world >= 1 && d.world <= kDpMaxWorld && d.grads_base && d.ctl && f.counter &&
+               d.nvec >= kDpTailFloats / 4 + d.world, "grads_finish: bad direct-exchange arguments");
+    for (int i = 0; i < sub.n; ++i) {
+      const long long off = (long long)(sub.e[i].dst - d.grads_base);
+      XT_REQUIRE(off >= 0 && off % 4 == 0 && off + sub.e[i].count <= (d.nvec - kDpTailFloats / 4) * 4,
+                 "grads_finish: entry %d lies outside the exchanged buffer", i);
+    }
+  }
+  hipLaunchKernelGGL(grads_finish_kernel, dim3(grid + (f.enable >= 2 ? 1 : 0)), dim3(256), 0, st, sub, partial, f, d);
   XT_LAUNCH_CHECK();
   *nblocks_out = blk;
   return 0;
@@ -631,19 +820,23 @@ int grads_finish_fused_grid(const GradTable* tab) {
 
 int launch_rmsprop_clip(float* param, const float* grad, float* mg, float* ms, long long count, float lr, float decay,
                         float eps, float* state, const float* partial, int nblocks, float clip_norm, float grad_scale,
-                        hipStream_t st, const float* lr_dev) {
+                        hipStream_t st, const float* lr_dev, const DpStep* dp, int block_cap) {
   int nb = (int)((count + 255) / 256);
   if (nb > 2048) nb = 2048;
+  if (block_cap > 0 && nb > block_cap) nb = block_cap;      // (blocks that wait for other ranks must all be resident)
   if (nb < 1) nb = 1;
+  DpStep d;
+  if (dp) d = *dp; else memset(&d, 0, sizeof(d));
+  if (d.flags && nb < d.red_blocks) nb = d.red_blocks;      // (the first red_blocks workgroups reduce this rank's slice)
   hipLaunchKernelGGL(rmsprop_tf_clip_kernel, dim3(nb), dim3(256), 0, st, param, grad, mg, ms, count, lr, decay, eps,
-                     state, partial, nblocks, clip_norm, grad_scale, lr_dev);
+                     state, partial, nblocks, clip_norm, grad_scale, lr_dev, d);
   XT_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_adam_clip(float* param, const float* grad, float* m, float* v, long long count, float beta1, float beta2,
                      float eps, float* state, const float* partial, int nblocks, float clip_norm, float grad_scale,
-                     hipStream_t st) {
+                     hipStream_t st, const DpStep* dp, int block_cap) {
   XT_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
              "adam: buffers must be 16-byte aligned");
   int nb = (int)((count / 4 + 255) / 256);
@@ -652,9 +845,13 @@ int launch_adam_clip(float* param, const float* grad, float* m, float* v, long l
   // dispatches faster (round 4, same-box A/B per 52-step update: 828 blocks 6.810 / 6.808 ms, 512: 6.769 / 6.776, 256:
   // 6.789 / 6.797).  Element-wise arithmetic: bitwise the same parameters.
   if (nb > 512) nb = 512;
+  if (block_cap > 0 && nb > block_cap) nb = block_cap;      // (blocks that wait for other ranks must all be resident)
   if (nb < 1) nb = 1;
+  DpStep d;
+  if (dp) d = *dp; else memset(&d, 0, sizeof(d));
+  if (d.flags && nb < d.red_blocks) nb = d.red_blocks;      // (the first red_blocks workgroups reduce this rank's slice)
   hipLaunchKernelGGL(adam_tf_clip_kernel, dim3(nb), dim3(256), 0, st, param, grad, m, v, count, beta1, beta2, eps, state,
-                     partial, nblocks, clip_norm, grad_scale);
+                     partial, nblocks, clip_norm, grad_scale, d);
   XT_LAUNCH_CHECK();
   return 0;
 }
@@ -773,6 +970,32 @@ int launch_global_norm(const float* grad, long long count, float clip_norm, floa
   XT_LAUNCH_CHECK();
   if (nblocks_out) *nblocks_out = nb;
   return launch_norm_finalize(scratch, nb, clip_norm, grad_scale, lr, beta1, beta2, advance, state, nullptr, st, lr_dev);
+}
+
+// ---- stand-alone forms of the data-parallel tail for the steps whose gradient reduction / optimiser launches do not carry
+// it: the overlapped two-bucket exchange (the tail must be in the FIRST bucket, before the backward has finished) and a rank
+// whose trajectory shard of a chunk is empty (no gradient-reduction launch at all: zeros, the step-size advance, the tail)
+__global__ void dp_tail_write_kernel(float* __restrict__ tail, int rank, float rows, const float* __restrict__ loss,
+                                     float* __restrict__ state, float lr, const float* __restrict__ lr_dev, float beta1,
+                                     float beta2, int advance) {
+  if (threadIdx.x == 0 && advance) adam_advance(state, lr_dev ? lr_dev[0] : lr, beta1, beta2);
+  if (threadIdx.x < kDpTailFloats) tail[threadIdx.x] = dp_tail_value(threadIdx.x, rank, rows, loss ? loss[0] : 0.f);
+}
+__global__ void dp_tail_consume_kernel(const DpStep dp) { dp_tail_consume(dp, true); }
+
+int launch_dp_tail_write(float* tail, int rank, float rows, const float* loss, float* state, float lr, const float* lr_dev,
+                         float beta1, float beta2, int advance, hipStream_t st) {
+  XT_REQUIRE(tail && rank >= 0 && rank < kDpMaxWorld, "dp_tail_write: bad arguments");
+  hipLaunchKernelGGL(dp_tail_write_kernel, dim3(1), dim3(64), 0, st, tail, rank, rows, loss, state, lr, lr_dev, beta1, beta2,
+                     advance);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+int launch_dp_tail_consume(const DpStep* dp, hipStream_t st) {
+  XT_REQUIRE(dp && dp->tail && !dp->flags, "dp_tail_consume: bad arguments");
+  hipLaunchKernelGGL(dp_tail_consume_kernel, dim3(1), dim3(64), 0, st, *dp);
+  XT_LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_adam(float* param, const float* grad, float* m, float* v, long long count, float beta1, float beta2,

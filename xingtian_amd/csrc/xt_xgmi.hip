@@ -27,30 +27,12 @@
 // box was available to the builders; the kernels follow the HIP memory model for peer access, timing over xGMI is open.
 #include <string.h>
 
-#include "xt_common.h"
+#include "xt_xgmi_dev.h"
 
 namespace xt {
 
-constexpr int kMaxWorld = 16;
-constexpr int kFlagWords = 1024;            // uint32 words at the head of the exchange block: ready[64], done[64]
-constexpr int kReadyOff = 0, kDoneOff = 64;
 constexpr int kScatterVecs = 1024;          // float4 per block in scatter / gather (16 KB)
 constexpr int kReduceVecs = 512;            // float4 per block in reduce
-// device-local control words (one small hipMalloc, NOT shared): [0] seq of the last completed all-reduce, [1] error bits,
-// [2] reduce ticket, [3] gather ticket, [8 + q] scatter tickets per peer
-constexpr int kCtlSeq = 0, kCtlErr = 1, kCtlRed = 2, kCtlGat = 3, kCtlScat = 8, kCtlWords = 8 + kMaxWorld;
-
-struct DirectPeers {
-  float* inbox_me[kMaxWorld];     // peer q's inbox slot for THIS rank
-  float* result[kMaxWorld];       // peer q's result buffer
-  uint32_t* flags[kMaxWorld];     // peer q's flag words
-};
-
-__device__ __forceinline__ void slice_of(int64_t nvec, int r, int world, int64_t& b, int64_t& e) {
-  const int64_t base = nvec / world, rem = nvec % world;
-  b = r * base + (r < rem ? r : rem);
-  e = b + base + (r < rem ? 1 : 0);
-}
 
 __device__ __forceinline__ float4 load_vec_tail(const float* p, int64_t v, int64_t count) {
   // vec v of a buffer of `count` floats (the last vec may be partial: zero filled)
@@ -61,36 +43,6 @@ __device__ __forceinline__ float4 load_vec_tail(const float* p, int64_t v, int64
   if (i + 1 < count) r.y = p[i + 1];
   if (i + 2 < count) r.z = p[i + 2];
   return r;
-}
-
-// Publishing a block's share of the data.  The exchange block is UNCACHED device memory: stores bypass every cache, so a
-// block only has to wait until its own stores are acknowledged (s_waitcnt vmcnt(0)) before it takes its ticket, and a
-// consumer has nothing to invalidate.  (First version: a system-scope release fence per block -- a buffer_wbl2 of the XCD's
-// L2, needed per block because eight XCDs have eight L2s -- and an acquire fence per consumer block: 100 / 155 / 303 us for
-// 2 / 4 / 8 in-process ranks x 3.39 MB against 57 / 74 / 142 us without them, tools/direct_probe.py.)
-__device__ __forceinline__ void publish_fence() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// bounded wait until flags[off + p] == seq for every p < world (thread 0 of the block polls, the block follows)
-__device__ __forceinline__ void wait_all(const uint32_t* flags, int off, int world, uint32_t seq, uint32_t* ctl,
-                                         unsigned long long timeout_ticks, uint32_t errbit) {
-  // the error word is sticky: once a wait of this comm has run out, later waits do not wait again (a comm that lost a peer
-  // costs ONE time-out, then every kernel runs through with whatever is there and xt_direct_status tells the host)
-  if (threadIdx.x == 0 && __hip_atomic_load(ctl + kCtlErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-    const unsigned long long t0 = wall_clock64();
-    for (int p = 0; p < world; ++p) {
-      int spins = 0;
-      while (__hip_atomic_load(flags + off + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-        __builtin_amdgcn_s_sleep(4);
-        if ((++spins & 63) == 0 && wall_clock64() - t0 > timeout_ticks) {
-          atomicOr(ctl + kCtlErr, errbit);
-          p = world;
-          break;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  asm volatile("" ::: "memory");            // (uncached data: nothing to invalidate; keep the loads below the wait)
 }
 
 // phase 1: push slice q of the local gradient into peer q's inbox[rank]; grid (blocks per slice, world)
@@ -191,18 +143,16 @@ __global__ void __launch_bounds__(256) xgmi_fused_kernel(float* __restrict__ gra
   __shared__ uint32_t s_cnt[kMaxWorld];
   if (threadIdx.x < kMaxWorld) s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  // ---- scatter
+  // ---- scatter (the grid is CAPPED at what can be resident next to the other ranks' kernels: chunks are grid-strided)
   {
-    const int64_t lo = (int64_t)blockIdx.x * kFusedVecs;
-    const int64_t hi = lo + kFusedVecs < nvec ? lo + kFusedVecs : nvec;
-    const int64_t base = nvec / world, rem = nvec % world;
-    for (int64_t v = lo + threadIdx.x; v < hi; v += 256) {
-      // owner of vector v under the balanced contiguous split (the first `rem` slices hold base + 1 vectors)
-      const int64_t cut = rem * (base + 1);
-      const int q = v < cut ? (int)(v / (base + 1)) : (int)(rem + (base ? (v - cut) / base : 0));
-      const int64_t b = q * base + (q < rem ? q : rem);
-      reinterpret_cast<float4*>(peers.inbox_me[q])[v - b] = load_vec_tail(grads, v, count);
-      atomicAdd(&s_cnt[q], 1u);
+    for (int64_t lo = (int64_t)blockIdx.x * kFusedVecs; lo < nvec; lo += (int64_t)gridDim.x * kFusedVecs) {
+      const int64_t hi = lo + kFusedVecs < nvec ? lo + kFusedVecs : nvec;
+      for (int64_t v = lo + threadIdx.x; v < hi; v += 256) {
+        int64_t b;
+        const int q = owner_of(v, nvec, world, b);
+        reinterpret_cast<float4*>(peers.inbox_me[q])[v - b] = load_vec_tail(grads, v, count);
+        atomicAdd(&s_cnt[q], 1u);
+      }
     }
     publish_fence();
     __syncthreads();
@@ -244,8 +194,7 @@ __global__ void __launch_bounds__(256) xgmi_fused_kernel(float* __restrict__ gra
   }
   // ---- gather
   wait_all(my_flags, kDoneOff, world, seq, ctl, timeout_ticks, 2u);
-  {
-    const int64_t lo = (int64_t)blockIdx.x * kFusedVecs;
+  for (int64_t lo = (int64_t)blockIdx.x * kFusedVecs; lo < nvec; lo += (int64_t)gridDim.x * kFusedVecs) {
     const int64_t hi = lo + kFusedVecs < nvec ? lo + kFusedVecs : nvec;
     for (int64_t v = lo + threadIdx.x; v < hi; v += 256) {
       const float4 x = reinterpret_cast<const float4*>(result)[v];
@@ -277,7 +226,7 @@ __global__ void __launch_bounds__(256) xgmi_fused_kernel(float* __restrict__ gra
 struct xt_direct_comm {
   int rank = 0, world = 1;
   int64_t max_count = 0, slice_cap = 0;         // floats
-  size_t block_bytes = 0, inbox_off = 0, result_off = 0;
+  size_t block_bytes = 0, norm_off = 0, inbox_off = 0, result_off = 0;
   char* block = nullptr;                        // own exchange block (device memory, shared with the peers)
   char* peer_block[xt::kMaxWorld] = {};
   bool peer_ipc[xt::kMaxWorld] = {};            // opened with hipIpcOpenMemHandle (to be closed)
@@ -286,8 +235,69 @@ struct xt_direct_comm {
   unsigned long long timeout_ticks = 200000000ull;   // 2 s of the 100 MHz wall clock
   int calls = 0;
   int fused = 1;                                // xt_allreduce_direct: one launch (xgmi_fused_kernel) instead of three
+  int ranks_on_device = 1;                      // ranks of the group whose exchange block lives on THIS device
+  int resident_blocks = 0;                      // 256-thread workgroups the device can hold at once
   xt::DirectPeers peers = {};
 };
+
+namespace xt {
+
+// workgroups a kernel of this comm whose blocks SPIN on other ranks' flags may be launched with: all of them must be
+// resident together with the same kernel of every other rank that shares the device (N test processes on one GPU) --
+// otherwise producer blocks queue behind spinning ones until the bounded wait runs out
+static int spin_block_cap(const xt_direct_comm* c) {
+  const int res = c->resident_blocks > 0 ? c->resident_blocks : 2048;
+  const int cap = res / (c->ranks_on_device > 0 ? c->ranks_on_device : 1);
+  return cap < 1 ? 1 : cap;
+}
+
+static int reduce_blocks(int64_t nvec, int world) {
+  const int64_t slice_max = (nvec + world - 1) / world;
+  int64_t rb = (slice_max + 255) / 256;
+  if (rb > kDpRedBlocksMax) rb = kDpRedBlocksMax;
+  return rb < 1 ? 1 : (int)rb;
+}
+
+// ---- the pieces of the exchange fused into the SGD step (called by xt_net.hip)
+int direct_fill_finish(xt_direct_comm* c, int64_t count, DpFinish* f) {
+  XT_REQUIRE(c && f && c->connected, "direct exchange: the comm is not connected");
+  XT_REQUIRE(count > 0 && count <= c->max_count && count % 4 == 0, "direct exchange: count %lld outside (0, %lld] or not a multiple of 4",
+             (long long)count, (long long)c->max_count);
+  XT_REQUIRE(count / 4 >= c->world, "direct exchange: %lld float4s cannot be split over %d ranks", (long long)(count / 4), c->world);
+  f->scatter = 1; f->rank = c->rank; f->world = c->world; f->nvec = count / 4; f->peers = c->peers; f->ctl = c->ctl;
+  return 0;
+}
+
+int direct_launch_scatter(xt_direct_comm* c, const float* buf, int64_t count, hipStream_t st);
+
+// what the optimiser kernel of a fused step needs: the inbox to reduce (its first `red_blocks` workgroups sum this rank's
+// slice in rank order and push it, with its squared-norm partials, to every peer), the flags to wait for, the reduced buffer
+// and all ranks' partials to read.  red_blocks depends on (count, world) only: the same on every rank.
+int direct_fill_step(xt_direct_comm* c, int64_t count, int64_t count_grad, DpStep* s, const float** result,
+                     const float** partial, int* npartial, int* block_cap) {
+  XT_REQUIRE(c && s && c->connected, "direct exchange: the comm is not connected");
+  XT_REQUIRE(count > 0 && count <= c->max_count, "direct exchange: count %lld outside (0, %lld]", (long long)count,
+             (long long)c->max_count);
+  const int64_t nvec = (count + 3) / 4;
+  const int rb = reduce_blocks(nvec, c->world);
+  XT_REQUIRE(spin_block_cap(c) >= rb, "direct exchange: %d reduce workgroups cannot be resident with %d ranks on this device",
+             rb, c->ranks_on_device);
+  s->flags = reinterpret_cast<const uint32_t*>(c->block);
+  s->ctl = c->ctl;
+  s->timeout_ticks = c->timeout_ticks;
+  s->world = c->world;
+  s->inbox = reinterpret_cast<const float*>(c->block + c->inbox_off);
+  s->slice_cap = c->slice_cap; s->nvec = nvec; s->nvec_grad = (count_grad + 3) / 4;
+  s->rank = c->rank; s->red_blocks = rb; s->peers = c->peers;
+  *result = reinterpret_cast<const float*>(c->block + c->result_off);
+  *partial = reinterpret_cast<const float*>(c->block + c->norm_off);
+  *npartial = c->world * rb;
+  *block_cap = spin_block_cap(c);
+  c->calls++;
+  return 0;
+}
+
+}  // namespace xt
 
 extern "C" {
 
@@ -300,7 +310,8 @@ int xt_direct_create(int32_t rank, int32_t world, int64_t max_count, void* handl
   c->rank = rank; c->world = world; c->max_count = max_count;
   const int64_t nvec = (max_count + 3) / 4;
   c->slice_cap = ((nvec + world - 1) / world) * 4;
-  c->inbox_off = (size_t)xt::kFlagWords * 4;
+  c->norm_off = (size_t)xt::kFlagWords * 4;
+  c->inbox_off = c->norm_off + sizeof(float) * (size_t)xt::kMaxWorld * xt::kDpRedBlocksMax;
   c->result_off = c->inbox_off + sizeof(float) * (size_t)c->slice_cap * world;
   c->block_bytes = c->result_off + sizeof(float) * (size_t)nvec * 4;
   // UNCACHED device memory (what RCCL takes for its peer buffers) and nothing else.  Measured round 5 with every rank on ONE
@@ -317,6 +328,24 @@ int xt_direct_create(int32_t rank, int32_t world, int64_t max_count, void* handl
   XT_CHECK_HIP(hipMemset(c->block, 0, c->block_bytes));
   XT_CHECK_HIP(hipMalloc((void**)&c->ctl, sizeof(uint32_t) * xt::kCtlWords));
   XT_CHECK_HIP(hipMemset(c->ctl, 0, sizeof(uint32_t) * xt::kCtlWords));
+  {
+    // the identity of the DEVICE this block lives on, left in the block for the peers: lets every rank count how many ranks
+    // share its device (xt_direct_info) and size its spinning launches for that
+    int dev = 0, cus = 0, per_cu = 0;
+    XT_CHECK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    XT_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    uint32_t ident[4] = {0, 0, 0, 0};
+    memcpy(ident, prop.uuid.bytes, sizeof(ident));
+    if ((ident[0] | ident[1] | ident[2] | ident[3]) == 0u) {      // (no uuid: PCI location)
+      ident[0] = 0x58544456u; ident[1] = (uint32_t)prop.pciDomainID; ident[2] = (uint32_t)prop.pciBusID; ident[3] = (uint32_t)prop.pciDeviceID;
+    }
+    XT_CHECK_HIP(hipMemcpy(c->block + (size_t)xt::kIdentOff * 4, ident, sizeof(ident), hipMemcpyHostToDevice));
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, xt::xgmi_fused_kernel, 256, 0) == hipSuccess)
+      c->resident_blocks = cus * per_cu;
+    (void)hipGetLastError();
+  }
   XT_CHECK_HIP(hipDeviceSynchronize());
   if (handle_out) {
     hipIpcMemHandle_t h;
@@ -336,12 +365,23 @@ int xt_direct_create(int32_t rank, int32_t world, int64_t max_count, void* handl
 }
 
 static int direct_finish_connect(xt_direct_comm* c) {
+  uint32_t mine[4] = {0, 0, 0, 0};
+  XT_CHECK_HIP(hipMemcpy(mine, c->block + (size_t)xt::kIdentOff * 4, sizeof(mine), hipMemcpyDeviceToHost));
+  int same = 0;
   for (int q = 0; q < c->world; ++q) {
     char* blk = c->peer_block[q];
     c->peers.flags[q] = reinterpret_cast<uint32_t*>(blk);
+    c->peers.norm_part[q] = reinterpret_cast<float*>(blk + c->norm_off);
     c->peers.inbox_me[q] = reinterpret_cast<float*>(blk + c->inbox_off) + (size_t)c->rank * c->slice_cap;
     c->peers.result[q] = reinterpret_cast<float*>(blk + c->result_off);
+    uint32_t theirs[4] = {1, 1, 1, 1};
+    if (q == c->rank || hipMemcpy(theirs, blk + (size_t)xt::kIdentOff * 4, sizeof(theirs), hipMemcpyDeviceToHost) == hipSuccess) {
+      if (q == c->rank || memcmp(mine, theirs, sizeof(mine)) == 0) ++same;
+    } else {
+      (void)hipGetLastError();
+    }
   }
+  c->ranks_on_device = same < 1 ? 1 : same;
   c->connected = true;
   return 0;
 }
@@ -391,6 +431,12 @@ static int direct_enqueue(xt_direct_comm* c, float* buf, int64_t count, int phas
   const unsigned sb = (unsigned)((slice_max + xt::kScatterVecs - 1) / xt::kScatterVecs);
   const unsigned rb = (unsigned)((slice_max + xt::kReduceVecs - 1) / xt::kReduceVecs);
   const unsigned gb = (unsigned)((nvec + xt::kScatterVecs - 1) / xt::kScatterVecs);
+  // the reduce / gather blocks of the three-launch form spin on other ranks' flags: all of them must fit next to the
+  // other ranks' launches (the scatter blocks never wait).  One block covers a fixed chunk, so a buffer too large for the cap
+  // is refused instead of risking the bounded wait (the fused single launch grid-strides and has no such limit)
+  XT_REQUIRE((int)rb <= xt::spin_block_cap(c) && (int)gb <= xt::spin_block_cap(c),
+             "xt_allreduce_direct (three launches): %u reduce / %u gather workgroups exceed the %d that can be resident with %d "
+             "rank(s) on this device; use the fused form (xt_direct_set_fused)", rb, gb, xt::spin_block_cap(c), c->ranks_on_device);
   const uint32_t* my_flags = reinterpret_cast<const uint32_t*>(c->block);
   const float* inbox = reinterpret_cast<const float*>(c->block + c->inbox_off);
   const float* result = reinterpret_cast<const float*>(c->block + c->result_off);
@@ -416,7 +462,11 @@ int xt_allreduce_direct(xt_direct_comm* c, float* buf, int64_t count, void* stre
   XT_REQUIRE(c->connected, "xt_allreduce_direct: xt_direct_connect has not been called");
   c->calls++;
   const int64_t nvec = (count + 3) / 4;
-  const unsigned g = (unsigned)((nvec + xt::kFusedVecs - 1) / xt::kFusedVecs);
+  // every block of every rank's launch must be resident at once (its blocks wait for OTHER ranks' blocks): the grid is capped
+  // at (resident workgroups) / (ranks sharing this device) and the chunks are grid-strided
+  unsigned g = (unsigned)((nvec + xt::kFusedVecs - 1) / xt::kFusedVecs);
+  const unsigned cap = (unsigned)xt::spin_block_cap(c);
+  if (g > cap) g = cap;
   hipLaunchKernelGGL(xt::xgmi_fused_kernel, dim3(g ? g : 1), dim3(256), 0, static_cast<hipStream_t>(stream), buf,
                      reinterpret_cast<const float*>(c->block + c->inbox_off),
                      reinterpret_cast<const float*>(c->block + c->result_off), c->slice_cap, count, c->rank, c->world, c->peers,
@@ -462,6 +512,29 @@ int xt_direct_status(xt_direct_comm* c, int32_t* calls, int32_t* seq, int32_t* e
   return 0;
 }
 
+int xt_direct_info(xt_direct_comm* c, int32_t* ranks_on_device, int32_t* block_cap) {
+  XT_REQUIRE(c, "xt_direct_info: null comm");
+  if (ranks_on_device) *ranks_on_device = c->ranks_on_device;
+  if (block_cap) *block_cap = xt::spin_block_cap(c);
+  return 0;
+}
+
+int xt_direct_read_result(xt_direct_comm* c, float* host_out, int64_t count) {
+  XT_REQUIRE(c && host_out && count > 0 && count <= c->max_count, "xt_direct_read_result: bad argument");
+  XT_CHECK_HIP(hipDeviceSynchronize());
+  XT_CHECK_HIP(hipMemcpy(host_out, c->block + c->result_off, sizeof(float) * (size_t)count, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int xt_direct_reset(xt_direct_comm* c) {
+  XT_REQUIRE(c, "xt_direct_reset: null comm");
+  XT_CHECK_HIP(hipDeviceSynchronize());
+  XT_CHECK_HIP(hipMemset(c->ctl, 0, sizeof(uint32_t) * xt::kCtlWords));
+  XT_CHECK_HIP(hipMemset(c->block, 0, (size_t)xt::kIdentOff * 4));          // ready / done flags (the identity words stay)
+  XT_CHECK_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
 int xt_direct_destroy(xt_direct_comm* c) {
   if (!c) return 0;
   (void)hipDeviceSynchronize();
@@ -475,3 +548,19 @@ int xt_direct_destroy(xt_direct_comm* c) {
 }
 
 }  // extern "C"
+
+namespace xt {
+// the scatter phase alone, for a step whose gradient did not come out of grads_finish_kernel (an EMPTY trajectory shard
+// contributes zeros): copies buf -> the owners' inboxes and raises the ready flags; the step's reduce / optimiser launches
+// follow as usual (the tickets are per phase and re-armed by the optimiser kernel)
+int direct_launch_scatter(xt_direct_comm* c, const float* buf, int64_t count, hipStream_t st) {
+  XT_REQUIRE(c && c->connected && buf && count > 0 && count <= c->max_count, "direct exchange (scatter): bad comm / count");
+  const int64_t nvec = (count + 3) / 4;
+  const int64_t slice_max = (nvec + c->world - 1) / c->world;
+  const unsigned sb = (unsigned)((slice_max + kScatterVecs - 1) / kScatterVecs);
+  hipLaunchKernelGGL(xgmi_scatter_kernel, dim3(sb ? sb : 1, c->world), dim3(256), 0, st, buf, count, c->rank, c->world,
+                     c->peers, c->ctl);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace xt

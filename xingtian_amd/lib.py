@@ -30,7 +30,7 @@ class LayerDesc(Structure):
     _fields_ = [("g", ConvGeom), ("param_off", c_int64), ("trunk", c_int32)]
 
 
-ABI_VERSION = 10         # XT_ABI_VERSION of include/xt_mi355x.h
+ABI_VERSION = 11         # XT_ABI_VERSION of include/xt_mi355x.h
 ACTION_TYPE = {"Categorical": 0, "DiagGaussian": 1}
 
 
@@ -68,6 +68,9 @@ class Tuning(Structure):
 OPT_TYPE = {"adam": 0, "rmsprop": 1}
 XCHG_OVERLAP = 1         # XT_XCHG_OVERLAP
 DIRECT_HANDLE_BYTES = 64  # XT_DIRECT_HANDLE_BYTES
+DP_TAIL_FLOATS = 32       # XT_DP_TAIL_FLOATS: 2 x 16 slots behind the gradient (rows / loss share of every rank)
+DP_ERR_BITS = {1: "a peer's gradient slices never arrived (scatter wait)", 2: "a peer's reduced slice never arrived (reduce wait)",
+               4: "the ranks hold different numbers of rows"}
 _P = c_void_p
 # name -> (restype, argtypes); every symbol include/xt_mi355x.h declares
 SIGNATURES = {
@@ -129,7 +132,19 @@ SIGNATURES = {
     "xt_direct_set_fused": (c_int32, [_P, c_int32]),
     "xt_direct_status": (c_int32, [_P, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
     "xt_direct_destroy": (c_int32, [_P]),
+    "xt_direct_info": (c_int32, [_P, POINTER(c_int32), POINTER(c_int32)]),
+    "xt_direct_read_result": (c_int32, [_P, _P, c_int64]),
+    "xt_direct_reset": (c_int32, [_P]),
+    "xt_net_set_dp": (c_int32, [_P, c_int32, c_int32, c_float]),
+    "xt_net_set_direct": (c_int32, [_P, _P]),
+    "xt_net_time_tail": (c_int32, [_P, c_float, c_float, c_int32, POINTER(c_float), _P]),
 }
+
+
+def dp_error_text(bits):
+    """human-readable form of the data-parallel error bits a train leaves in loss_acc[2] / xt_direct_status"""
+    bits = int(bits)
+    return "; ".join(t for b, t in DP_ERR_BITS.items() if bits & b) or "bits {}".format(bits)
 
 _lib = None
 

@@ -23,7 +23,10 @@ class HipActorCritic(object):
         torch.cuda.set_device(self.device)
         n = spec.n_flat
         self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
-        self.grads = torch.zeros(n, dtype=torch.float32, device=self.device)
+        # the gradient buffer carries XT_DP_TAIL_FLOATS behind align4(n): the data-parallel tail (rows / loss share of every
+        # rank, include/xt_mi355x.h `xt_net_set_dp`) travels with the gradient in ONE exchange; `grads` is the gradient view
+        self.grads_xchg = torch.zeros(((n + 3) // 4) * 4 + L.DP_TAIL_FLOATS, dtype=torch.float32, device=self.device)
+        self.grads = self.grads_xchg[:n]
         self.adam_m = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.adam_v = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.adam_state = torch.zeros(8, dtype=torch.float32, device=self.device)
@@ -323,6 +326,37 @@ class HipActorCritic(object):
                                             L.ptr(value[s:e]), L.stream_ptr()), "xt_net_forward")
         return logits, value
 
+    def set_dp(self, rank, world, loss_scale=1.0):
+        """C ABI ``xt_net_set_dp``: switch the data-parallel tail on (``world`` >= 1: rows + loss shares of every rank travel
+        behind the gradient in the same exchange, the optimiser adds the GLOBAL loss to ``loss_acc``) or off (``world`` = 0)"""
+        L.check(self.lib.xt_net_set_dp(self.handle, int(rank), int(world), float(loss_scale)), "xt_net_set_dp")
+
+    def read_loss(self, acc=None, wait=True):
+        """[sum of step losses, number of steps, data-parallel error bits, -] of the train(s) enqueued so far: ONE 16-byte D2H
+        into a pinned block + an event wait instead of a pageable ``.cpu()`` (a staging copy, an allocation and a device-wide
+        synchronisation: ~30 us of a 128-frame IMPALA train).  Two blocks alternate; ``wait=False`` returns the block of the
+        PREVIOUS call instead (ASYNC_LOSS: its copy landed long ago; the very first call still waits for its own).  Raises if
+        the train left error bits (the update was skipped on this rank: include/xt_mi355x.h ``xt_net_set_direct``)."""
+        acc = self.loss_acc if acc is None else acc
+        rb = getattr(self, "_loss_rb", None)
+        if rb is None:
+            pin = torch.zeros((2, 4), dtype=torch.float32, pin_memory=True)
+            rb = self._loss_rb = dict(pin=pin, np=pin.numpy(), ev=[torch.cuda.Event(), torch.cuda.Event()], slot=0, n=0)
+        i = rb["slot"]
+        cur = torch.cuda.current_stream(self.device)
+        L.memcpy_async(rb["pin"][i].data_ptr(), acc.data_ptr(), 16, L.D2H, cur)
+        rb["ev"][i].record(cur)
+        rb["slot"] = i ^ 1
+        j = i if (wait or rb["n"] == 0) else i ^ 1
+        rb["n"] += 1
+        rb["ev"][j].synchronize()
+        a = rb["np"][j]
+        if a[2] != 0.0:
+            raise RuntimeError("xingtian_amd: the data-parallel update failed on this rank -- {} (error bits {}); the "
+                               "optimiser skipped the update, parameters are those of the last good step".format(
+                                   L.dp_error_text(a[2]), int(a[2])))
+        return a
+
     def make_ppo_cfg(self, cfg, grad_scale=1.0, global_batch=0, shard_rank=0, shard_world=0):
         c = L.PpoCfg()
         c.lr, c.beta1, c.beta2, c.eps = cfg["LR"], 0.9, 0.999, 1e-8
@@ -443,6 +477,15 @@ class HipActorCritic(object):
         ms = ctypes.c_float()
         L.check(self.lib.xt_net_time_layer(self.handle, layer, which, L.ptr(obs), L.ptr(idx), b, reps,
                                            ctypes.byref(ms), L.stream_ptr()), "xt_net_time_layer")
+        return ms.value
+
+    def time_tail(self, lr=2.5e-4, clip_norm=5.0, reps=50):
+        """average ms of the step's tail (gradient reduction, [exchange], clip + Adam) in the net's current mode, on the
+        slabs of the most recent gradient step (C ABI xt_net_time_tail)"""
+        ms = ctypes.c_float()
+        self.touch()
+        L.check(self.lib.xt_net_time_tail(self.handle, float(lr), float(clip_norm), int(reps), ctypes.byref(ms),
+                                          L.stream_ptr()), "xt_net_time_tail")
         return ms.value
 
     def grads_dict(self):

@@ -58,8 +58,6 @@ class ImpalaCnnOpt(XTModel):
         # one.  Only the reported number lags (xt/framework/learner.py:348-351 logs it); weights handed out afterwards are
         # always the ones this train produced.  Pays when weights do not go out after every train (train_per_checkpoint > 1).
         self.async_loss = bool(model_config.get("ASYNC_LOSS", False))
-        self._loss_pin = self._loss_ev = None
-        self._loss_slot = 0
         self._ingest = None
         self._dp = None
         self._lr_host = self._lr_dev = None
@@ -84,7 +82,7 @@ class ImpalaCnnOpt(XTModel):
         from xingtian_amd.parallel import LearnerDP
         self._dp = LearnerDP.from_config(model_info.get("model_config"), is_learner=model_info.get("type") == "learner")
         if self._dp is not None:
-            self._dp.attach(self.net)
+            self._dp.attach(self.net, loss_scale=1.0)       # sum-form loss: the ranks' shares of one sum
             if not self._dp.graph_capable:
                 self.use_graph = False
             if self._dp.mode == "strict" and self._dp.feed == "replicated":
@@ -140,7 +138,6 @@ class ImpalaCnnOpt(XTModel):
         n, d = self._ingest.finish()
         dp = self._dp
         if dp is not None:
-            dp.check_equal(n, "IMPALAOpt.train")
             if dp.mode == "strict" and dp.feed != "replicated":
                 # the reference's chunk of BATCH_SIZE frames = N local chunks of BATCH_SIZE / N frames (whole trajectories)
                 if batch_size % (dp.world * self.sample_batch_steps):
@@ -155,32 +152,9 @@ class ImpalaCnnOpt(XTModel):
         self._global_step += n_chunks
         if self.eager_snapshot:
             self.net.snapshot_weights_async()   # the D2H of the new weights runs under the loss read-back
-        if self.async_loss:
-            return self._loss_of_previous_train(acc)       # (data parallel: this rank's share of the sum-form loss)
-        a = acc.cpu().numpy()
-        if dp is not None:
-            dp.status()
-            return np.float32(dp.global_loss(a[0], n_chunks))     # SUM of the shard sums / chunks
-        return np.float32(a[0] / max(a[1], 1.0))
-
-    def _loss_of_previous_train(self, acc):
-        """enqueue the read-back of this train's [sum, count] into one of two pinned words, return the other one's (the
-        previous train's: its copy finished long ago); the very first call waits for its own"""
-        from xingtian_amd import lib as L
-        if self._loss_pin is None:
-            self._loss_pin = torch.zeros((2, 2), dtype=torch.float32, pin_memory=True)
-            self._loss_ev = [torch.cuda.Event(), torch.cuda.Event()]
-            self._loss_slot, first = 0, True
-        else:
-            first = False
-        i = self._loss_slot
-        cur = torch.cuda.current_stream(self.net.device)
-        L.memcpy_async(self._loss_pin[i].data_ptr(), acc.data_ptr(), 8, L.D2H, cur)
-        self._loss_ev[i].record(cur)
-        self._loss_slot = i ^ 1
-        j = i if first else i ^ 1
-        self._loss_ev[j].synchronize()
-        a = self._loss_pin[j]
+        # one pinned 16-byte read-back ([sum, chunks, error bits]); ASYNC_LOSS: the PREVIOUS train's (no wait for this one).
+        # Data parallel: the sum is the GLOBAL one (the ranks' shares travelled in the tail of the exchanged gradient)
+        a = self.net.read_loss(acc, wait=not self.async_loss)
         return np.float32(float(a[0]) / max(float(a[1]), 1.0))
 
     def train(self, state, label):

@@ -102,8 +102,13 @@ class PPO(XTModel):
         from xingtian_amd.parallel import LearnerDP
         self._dp = LearnerDP.from_config(model_info.get("model_config"), is_learner=model_info.get("type") == "learner")
         if self._dp is not None:
-            self._dp.attach(self.net)
+            # (weak: the reported loss is the mean of the ranks' minibatch means; strict: the ranks' shares of one mean)
+            self._dp.attach(self.net, loss_scale=1.0 / self._dp.world if self._dp.mode == "weak" else 1.0)
             self._cfg, _ = self._dp.ppo_cfg(self.net, base)
+            if self.adv_norm and not (self._dp.mode == "strict" and self._dp.feed == "replicated"):
+                # every rank would normalise with the mean / std of ITS trajectories only: not the single-GPU update
+                raise ValueError("ADV_NORM under data parallelism needs DP: strict with DP_FEED: replicated (every rank "
+                                 "holds the whole rollout); got DP {} / DP_FEED {}".format(self._dp.mode, self._dp.feed))
             if not self._dp.graph_capable:
                 self.use_graph = False
             if self._dp.mode == "strict" and self._dp.feed == "replicated":
@@ -205,8 +210,6 @@ class PPO(XTModel):
         """``train`` on the rollout that was streamed in through ``ingest_trajectory`` (no concat, no upload)."""
         self._require_learner()
         n, d = self._ingest.finish()
-        if self._dp is not None:
-            self._dp.check_equal(n, "PPO.train")
         perm = d["perm"][:, :n] if d["perm"].shape[1] == n else None
         if perm is None:
             # capacity > n: the kernel expects perm as a dense [epochs, n] array
@@ -238,11 +241,9 @@ class PPO(XTModel):
         if self.eager_snapshot:
             self.net.snapshot_weights_async()
         self._draw_ahead(n)
-        a = acc.cpu().numpy()
-        if self._dp is not None:
-            # strict: the local sums already carry the GLOBAL 1/B -> SUM over the ranks; weak: mean of the ranks' means
-            self._dp.status()
-            return np.float32(self._dp.global_loss(a[0], a[1] * (self._dp.world if self._dp.mode == "weak" else 1)))
+        # data parallel: the GLOBAL loss (every rank's share travelled in the tail of the exchanged gradient, summed in
+        # rank order on the device: the same bits on every rank) -- no host collective; error bits raise
+        a = self.net.read_loss(acc)
         return np.float32(a[0] / max(a[1], 1.0))
 
     def _perm_block(self, n):
@@ -286,8 +287,6 @@ class PPO(XTModel):
         self._require_learner()
         r = self._upload(state, label)
         nbatch = r["obs"].shape[0]
-        if self._dp is not None:
-            self._dp.check_equal(nbatch, "PPO.train")
         r["perm"].copy_(self._take_perms(nbatch, perms), non_blocking=True)
         self._normalize_adv(r["adv"])
         acc = self.net.ppo_train(self._cfg, r["obs"], r["perm"], r["action"], r["old_logp"], r["adv"], r["old_v"],

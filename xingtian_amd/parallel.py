@@ -269,17 +269,21 @@ class TorchDistExchange(object):
     def __init__(self, net):
         import ctypes
         self._ct = ctypes
-        self.net = net
-        self.calls = []                      # (offset, count) of every call, for the tests
+        import weakref
+        net_ref = weakref.ref(net)           # (the net may cache this object: no reference cycle)
+        self.calls = []                      # (offset, count) of every call -- only while `record_calls` (the tests)
+        self.record_calls = False
         hip = ctypes.CDLL("libamdhip64.so")
         hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
 
         def _exchange(grads, count, user, stream):
             try:
+                net = net_ref()
                 hip.hipStreamSynchronize(stream)
                 off = (int(grads) - net.grads.data_ptr()) // 4
-                self.calls.append((off, int(count)))
-                view = net.grads[off:off + int(count)]
+                if self.record_calls:
+                    self.calls.append((off, int(count)))
+                view = net.grads_xchg[off:off + int(count)]       # (gradient + the data-parallel tail behind it)
                 allreduce_sum_(view)
                 torch.cuda.synchronize()
                 return 0
@@ -288,14 +292,23 @@ class TorchDistExchange(object):
 
         self._cb = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p)(_exchange)
 
+        self._net_ref = net_ref
+
+    @property
+    def net(self):
+        return self._net_ref()
+
     def attach(self, overlap=False):
         from xingtian_amd import lib as L
-        L.check(self.net.lib.xt_net_set_grad_exchange_ex(self.net.handle, self._ct.cast(self._cb, self._ct.c_void_p), None,
-                                                         L.XCHG_OVERLAP if overlap else 0), "xt_net_set_grad_exchange_ex")
+        net = self.net
+        L.check(net.lib.xt_net_set_grad_exchange_ex(net.handle, self._ct.cast(self._cb, self._ct.c_void_p), None,
+                                                    L.XCHG_OVERLAP if overlap else 0), "xt_net_set_grad_exchange_ex")
 
     def detach(self):
         from xingtian_amd import lib as L
-        L.check(self.net.lib.xt_net_set_grad_exchange(self.net.handle, None, None), "xt_net_set_grad_exchange")
+        net = self.net
+        if net is not None:
+            L.check(net.lib.xt_net_set_grad_exchange(net.handle, None, None), "xt_net_set_grad_exchange")
 
 
 class DirectComm(object):
@@ -321,6 +334,8 @@ class DirectComm(object):
         if timeout_ms:
             L.check(self.lib.xt_direct_set_timeout_ms(self.comm, int(timeout_ms)), "xt_direct_set_timeout_ms")
         self.connected = self.world == 1
+        if self.world == 1:       # a one-rank group is its own peer (the fused step then runs against the rank's own block)
+            L.check(self.lib.xt_direct_connect(self.comm, None), "xt_direct_connect")
 
     @property
     def handle(self):
@@ -387,12 +402,46 @@ class DirectComm(object):
         fn = self._ct.cast(self.lib.xt_direct_exchange_hook, self._ct.c_void_p)
         self._L.check(net.lib.xt_net_set_grad_exchange_ex(net.handle, fn, self.comm, 0), "xt_net_set_grad_exchange_ex")
 
+    def attach_fused(self, net):
+        """the exchange FUSED into the SGD step (C ABI ``xt_net_set_direct``; needs ``xt_net_set_dp`` on the net and a comm
+        sized for ``net.grads_xchg``): the gradient reduction writes straight into the owners' inboxes, one small launch
+        reduces this rank's slice and leaves the squared-norm partials, the optimiser reads the exchange block -- three
+        launches behind the backward pass, no scatter / gather copies."""
+        if int(net.grads_xchg.numel()) > self.max_count:
+            raise ValueError("DirectComm: the exchanged buffer holds {} floats, the comm was sized for {}".format(
+                net.grads_xchg.numel(), self.max_count))
+        self._L.check(net.lib.xt_net_set_direct(net.handle, self.comm), "xt_net_set_direct")
+
     def detach(self, net):
-        self._L.check(net.lib.xt_net_set_grad_exchange(net.handle, None, None), "xt_net_set_grad_exchange")
+        self._L.check(net.lib.xt_net_set_direct(net.handle, None), "xt_net_set_direct")
+
+    def info(self):
+        """dict(ranks_on_device, block_cap): how many ranks of the group share THIS rank's device (1 on a multi-GPU node) and
+        the workgroup cap its spinning launches get (resident workgroups / ranks on the device)"""
+        c = self._ct
+        a, b = c.c_int32(0), c.c_int32(0)
+        self._L.check(self.lib.xt_direct_info(self.comm, c.byref(a), c.byref(b)), "xt_direct_info")
+        return dict(ranks_on_device=int(a.value), block_cap=int(b.value))
+
+    def read_result(self, count):
+        """the reduced buffer of the most recent exchange as a host array (tests; synchronises the device)"""
+        out = np.empty(int(count), np.float32)
+        self._L.check(self.lib.xt_direct_read_result(self.comm, self._ct.c_void_p(out.ctypes.data), int(count)),
+                      "xt_direct_read_result")
+        return out
+
+    def reset(self, group=None):
+        """COLLECTIVE: clear the sticky error word, tickets, sequence number and this rank's flags between two barriers
+        (every rank calls it, no exchange in flight) -- the way back from a time-out without rebuilding the group"""
+        if self.world > 1:
+            dist.barrier(group=group)
+        self._L.check(self.lib.xt_direct_reset(self.comm), "xt_direct_reset")
+        if self.world > 1:
+            dist.barrier(group=group)
 
     def status(self):
         """dict(calls, seq, error_bits): ``error_bits`` != 0 -> a bounded wait ran out (1: a peer's scatter data, 2: a peer's
-        reduced slice).  Synchronises the device."""
+        reduced slice) or the ranks held different numbers of rows (4).  Synchronises the device."""
         c = self._ct
         v = [c.c_int32(0) for _ in range(3)]
         self._L.check(self.lib.xt_direct_status(self.comm, *[c.byref(x) for x in v]), "xt_direct_status")
@@ -434,8 +483,12 @@ class LearnerDP(object):
                    With these two a strict PPO minibatch is BATCH_SIZE/N rows of EACH rank's local permutation (stratified
                    over the ranks instead of one global shuffle: documented deviation, SURVEY 8(e) "permute within shards").
       DP_EXCHANGE  "rccl" (default: raw ncclAllReduce enqueued by the library, captured into the update's hipGraph) |
-                   "direct" (xt_allreduce_direct over peer-mapped memory, also in-graph) | "torch" (torch.distributed from
-                   a host callback: any backend, not capturable -- tests on one GPU go through gloo)
+                   "direct" (the 2-phase exchange over peer-mapped memory FUSED into the step, xt_net_set_direct, also
+                   in-graph.  EXPERIMENTAL across devices: every run so far had all ranks on ONE GPU -- up to eight
+                   processes, tests/test_gpu_dp_ranks.py; its cross-device ordering (uncached peer writes + s_waitcnt
+                   before the flag store) has not met real xGMI links.  ``tools/multi_gpu_preflight.py`` checks it against
+                   torch.distributed in under a minute on any box with >= 2 GPUs) | "torch" (torch.distributed from a
+                   host callback: any backend, not capturable -- tests on one GPU go through gloo)
       DP_GRAPH     capture the data-parallel update into a hipGraph?  Default: yes for "direct" (kernels only), NO for
                    "rccl": RCCL collectives inside a replayed hipGraph have only ever been validated with a 1-rank
                    communicator here, and the eager form (ONE C call per update enqueues every kernel and every
@@ -501,26 +554,37 @@ class LearnerDP(object):
         return int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
 
     # ---- set-up
-    def attach(self, net):
-        """replicas start identical (rank 0's parameters and optimiser slots), the exchange is installed on ``net``"""
+    def attach(self, net, loss_scale=1.0):
+        """replicas start identical (rank 0's parameters and optimiser slots), the data-parallel tail is switched on
+        (``xt_net_set_dp``: rows + loss shares travel behind the gradient, so a train needs no host collective) and the
+        exchange is installed on ``net``.  ``loss_scale``: 1 when the ranks' losses are shares of one sum (PPO strict, IMPALA),
+        1 / world for the mean of the ranks' means (PPO weak)."""
+        from xingtian_amd import lib as L
         for t in (net.params, net.adam_m, net.adam_v, net.adam_state):
             dist.broadcast(t, src=0)
         torch.cuda.synchronize()
         net.touch()
+        net.set_dp(self.rank, self.world, loss_scale)
         if self.exchange == "rccl":
             self.comm = RcclComm(self.rank, self.world)
             warm = torch.zeros(1024, dtype=torch.float32, device=net.device)
-            from xingtian_amd import lib as L
             self.comm.all_reduce_(warm, L.stream_ptr())       # RCCL's lazy allocations must not happen under capture
             torch.cuda.synchronize()
             self.comm.attach(net)
         elif self.exchange == "direct":
-            self.comm = DirectComm(self.rank, self.world, int(net.params.numel())).connect()
-            self.comm.attach(net)
+            self.comm = DirectComm(self.rank, self.world, int(net.grads_xchg.numel())).connect()
+            self.comm.attach_fused(net)
         else:
             self.comm = TorchDistExchange(net)
             self.comm.attach()
         return self
+
+    def exchanged_gradient(self, net):
+        """the gradient the last SGD step applied (after the exchange) as a host array (tests)"""
+        torch.cuda.synchronize()
+        if isinstance(self.comm, DirectComm):
+            return self.comm.read_result(int(net.grads.numel()))
+        return net.grads.detach().cpu().numpy().copy()
 
     @property
     def graph_capable(self):
@@ -565,30 +629,14 @@ class LearnerDP(object):
         local = bsz // self.world
         return net.make_ppo_cfg(dict(cfg, BATCH_SIZE=local), grad_scale=1.0, global_batch=bsz), local
 
-    def check_equal(self, n, what):
-        """every rank must hold the same number of rows (same number of SGD steps = same number of collectives)"""
-        t = torch.tensor([n, -n], dtype=torch.int64)
-        if dist.get_backend() == "nccl":
-            t = t.cuda()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        if int(t[0]) != -int(t[1]):
-            raise ValueError("data-parallel {}: ranks hold different amounts of data (this rank {}, max {}, min {})".format(
-                what, n, int(t[0]), -int(t[1])))
-
-    def global_loss(self, local_sum, denom):
-        """loss the learner logs: PPO strict -- local sums already carry the global 1/B -> SUM over ranks / minibatches;
-        PPO weak -- mean over ranks of the local means; IMPALA -- SUM of the shard sums / chunks"""
-        t = torch.tensor([float(local_sum)], dtype=torch.float64)
-        if dist.get_backend() == "nccl":
-            t = t.cuda()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        return float(t.item()) / max(float(denom), 1.0)
-
     def status(self):
-        """exchange health: raises if the library saw a collective fail inside the hook"""
+        """exchange health (synchronises the device; the trains themselves learn of an error from ``loss_acc[2]``, which
+        travels with the loss): raises if a bounded wait of the direct exchange ran out or the rows disagreed"""
+        from xingtian_amd import lib as L
         if isinstance(self.comm, DirectComm):
             st = self.comm.status()
             if st["error_bits"]:
-                raise RuntimeError("direct all-reduce: a bounded wait ran out (error bits {})".format(st["error_bits"]))
+                raise RuntimeError("direct all-reduce: {} (error bits {})".format(L.dp_error_text(st["error_bits"]),
+                                                                                st["error_bits"]))
             return st
         return {}
