@@ -1179,84 +1179,70 @@ def test_weights_ring_packed_publish_round_trips_names_shapes_and_padded_kernels
             ring.close()
 
 
-def _frame_producer(port, n_msgs):
+def test_prefetcher_stages_one_train_ahead_in_arrival_order_and_hands_out_tokens():
+    """transport.Prefetcher (asynchronous algorithms): a thread owns the consumer end of the ring and hands every message to
+    ``alg.stage_message`` as it arrives -- at most ONE train ahead of the learner (it waits for ``staged_generation`` before
+    the first message of the next train), in arrival order; the learner's unchanged loop ``recv_into(alg.prepare_data)`` x
+    prepare_data_times gets a token per message.  Reference loop: xt/framework/learner.py:306-348."""
+    import time
     from xingtian_amd import transport
-    ch = transport.FrameSocket.connect("127.0.0.1", port)
-    rng = np.random.default_rng(77)
-    for i in range(n_msgs):
-        t = 16 + i
-        ch.send({"cmd": "train", "explorer_id": 3, "seq": i},
-                {"cur_state": rng.integers(0, 256, (t, 84, 84, 4), dtype=np.uint8), "action": rng.integers(0, 4, t).astype(np.int32),
-                 "logp": rng.standard_normal((t, 1)).astype(np.float32), "adv": rng.standard_normal((t, 1)),
-                 "done": [bool(b) for b in rng.random(t) < 0.1], "reward": [float(x) for x in rng.choice([-1.0, 0.0, 1.0], t)]})
-    ch.close()
 
+    class FakeAlg(object):
+        prepare_data_times = 2
 
-def test_frame_socket_carries_rollout_messages_between_processes_through_a_forwarding_hop():
-    """The inter-node hop of SURVEY 8(f1) (zeus/common/ipc/comm_by_zmq.py:69-97) without zmq: two-frame messages over TCP
-    from an explorer PROCESS, through a broker-like forwarder that never decodes the payload (``recv_bytes`` ->
-    ``send_bytes``, broker.py:97-119), into the learner side's ``recv_into(sink)``: zero-copy views, 64-byte aligned
-    arrays, python-object fields intact, the reusable buffer growing with the messages."""
-    import threading
-    from xingtian_amd import transport
-    n = 5
-    srv_a, port_a = transport.FrameSocket.listen()       # forwarder <- explorer process
-    srv_b, port_b = transport.FrameSocket.listen()       # learner <- forwarder
-    prod = mp.get_context("spawn").Process(target=_frame_producer, args=(port_a, n))
-    prod.start()
-    chans = []
+        def __init__(self):
+            self.gen, self.staged, self.booked = 0, [], []
+
+        def stage_message(self, data, ctr_info=None):
+            assert isinstance(data["cur_state"], np.ndarray) and data["cur_state"].shape == (4, 3)
+            self.staged.append(int(ctr_info["k"]))
+            return int(data["cur_state"].shape[0])
+
+        def staged_generation(self):
+            return self.gen
+
+        def prepare_data(self, data, ctr_info=None):
+            assert data == {"_prefetched": 4}
+            self.booked.append(int(ctr_info["k"]))
+
+    ring = transport.ShmRing(slots=8, slot_bytes=1 << 12)
     try:
-        def forward():
-            src = transport.FrameSocket.accept(srv_a, timeout=60)
-            dst = transport.FrameSocket.connect("127.0.0.1", port_b)
-            chans.extend([src, dst])
-            for _ in range(n):
-                dst.send_bytes(*src.recv_bytes())
-            dst.close()
-        th = threading.Thread(target=forward)
-        th.start()
-        learner = transport.FrameSocket.accept(srv_b, timeout=60)
-        chans.append(learner)
-        rng = np.random.default_rng(77)
-        seen = []
-
-        def sink(data, ctr_info=None):
-            i = ctr_info["seq"]
-            t = 16 + i
-            want_obs = rng.integers(0, 256, (t, 84, 84, 4), dtype=np.uint8)
-            want_act = rng.integers(0, 4, t).astype(np.int32)
-            want_logp = rng.standard_normal((t, 1)).astype(np.float32)
-            want_adv = rng.standard_normal((t, 1))
-            want_done = [bool(b) for b in rng.random(t) < 0.1]
-            want_rew = [float(x) for x in rng.choice([-1.0, 0.0, 1.0], t)]
-            assert ctr_info == {"cmd": "train", "explorer_id": 3, "seq": i}
-            assert list(data) == ["cur_state", "action", "logp", "adv", "done", "reward"]
-            assert data["cur_state"].ctypes.data % 64 == 0 and not data["cur_state"].flags.owndata
-            assert np.array_equal(data["cur_state"], want_obs) and np.array_equal(data["action"], want_act)
-            assert np.array_equal(data["logp"], want_logp) and np.array_equal(data["adv"], want_adv)
-            assert data["done"] == want_done and data["reward"] == want_rew
-            seen.append(i)
-
-        for _ in range(n):
-            learner.recv_into(sink)
-        assert seen == list(range(n))
-        th.join(20)
-        with pytest.raises(ConnectionError):
-            learner.recv_into(sink)                    # the forwarder has closed its end
-        # the (ctr_info, data) contract of CommByZmq.send / recv on a fresh pair
-        srv_c, port_c = transport.FrameSocket.listen()
-        a = transport.FrameSocket.connect("127.0.0.1", port_c)
-        b = transport.FrameSocket.accept(srv_c, timeout=10)
-        chans.extend([a, b])
-        a.send({"cmd": "predict", "n": 1}, {"x": np.arange(6, dtype=np.float64).reshape(2, 3), "note": "hi"})
-        ctr, data = b.recv()
-        assert ctr == {"cmd": "predict", "n": 1} and data["note"] == "hi" and np.array_equal(data["x"], np.arange(6.0).reshape(2, 3))
-        srv_c.close()
+        for k in range(6):
+            assert ring.send({"k": k}, {"cur_state": np.full((4, 3), k, np.float32)})
+        alg = FakeAlg()
+        pf = transport.Prefetcher(ring, alg)
+        try:
+            t0 = time.monotonic()
+            while len(alg.staged) < 2 and time.monotonic() - t0 < 5:
+                time.sleep(0.001)
+            time.sleep(0.05)
+            assert alg.staged == [0, 1]                       # train 0 staged, train 1 NOT before the learner took train 0 over
+            for train in range(3):
+                assert pf.recv_many_into(alg.prepare_data, 2, timeout=5) == 2
+                alg.gen += 1                                   # (what RolloutIngest.finish does inside alg.train())
+                pf.notify()
+                t0 = time.monotonic()
+                want = min(6, 2 * (train + 2))
+                while len(alg.staged) < want and time.monotonic() - t0 < 5:
+                    time.sleep(0.001)
+                assert alg.staged == list(range(want))
+            assert alg.booked == list(range(6))
+            assert pf.recv_into(alg.prepare_data, block=False) is None
+        finally:
+            pf.close()
     finally:
-        prod.join(30)
-        if prod.is_alive():
-            prod.terminate()
-        for ch in chans:
-            ch.close()
-        srv_a.close()
-        srv_b.close()
+        ring.close()
+
+    class Broken(FakeAlg):
+        def stage_message(self, data, ctr_info=None):
+            raise ValueError("boom")
+
+    ring = transport.ShmRing(slots=2, slot_bytes=1 << 12)
+    try:
+        ring.send({"k": 0}, {"cur_state": np.zeros((4, 3), np.float32)})
+        pf = transport.Prefetcher(ring, Broken())
+        with pytest.raises(RuntimeError, match="staging thread failed"):
+            pf.recv_into(lambda d, ctr_info=None: None, timeout=5)
+        pf.close()
+    finally:
+        ring.close()

@@ -39,7 +39,39 @@ class IMPALAOpt(Algorithm):
         return (episode_data["cur_state"], episode_data["logit"], episode_data["action"],
                 np.asarray(episode_data["done"], dtype=bool), np.asarray(episode_data["reward"]))
 
+    # ---- asynchronous ingest (transport.Prefetcher): the H2D of train k+1's messages under the GPU's train k
+    def stage_message(self, train_data, ctr_info=None):
+        """Called on the Prefetcher's thread AS A MESSAGE ARRIVES: decode + pinned staging (or DMA straight out of a pinned
+        transport slot) + asynchronous H2D start now; ``prepare_data`` of the learner thread later only books the message
+        (``{"_prefetched": rows}``).  Same data, same order, same train -- only the copy happens earlier.  -> rows staged."""
+        if self.dp is not None and self.dp.feed == "round_robin":
+            raise RuntimeError("IMPALAOpt.stage_message: DP_FEED round_robin filters messages in prepare_data; hand every "
+                               "rank its own source (DP_FEED sharded) to prefetch")
+        if not (getattr(self.actor, "stream_ingest", False) and hasattr(self.actor, "ingest_message")):
+            raise RuntimeError("IMPALAOpt.stage_message needs the streaming ingest (model_config STREAM_INGEST)")
+        fields = self._data_proc(train_data)
+        ctr = ctr_info or {}
+        self.actor.ingest_message(*fields, pinned=bool(ctr.get("_pinned_views")), slot_guard=ctr.get("_slot_guard"))
+        return int(np.asarray(fields[0]).shape[0])
+
+    def staged_generation(self):
+        """trains whose buffer set the learner thread has taken over (the Prefetcher stays at most one train ahead)"""
+        return self.actor.ingest_generation()
+
+    def stage_thread_init(self, wake=None):
+        """first call on the staging thread: bind it to the learner's device; ``wake`` is called whenever the learner takes
+        over a buffer set"""
+        import torch
+        torch.cuda.set_device(self.actor.net.device)
+        if wake is not None:
+            self.actor._ingest_obj().on_finish = wake
+
     def prepare_data(self, train_data, **kwargs):
+        if "_prefetched" in train_data:
+            # staged by a transport.Prefetcher when it arrived: the frames are (on their way) in HBM, only the books remain
+            self._streamed += 1
+            self._rollout.add(**{k: None for k in self.FIELDS})
+            return
         if self.dp is not None and not self.dp.takes(train_data):
             return                  # DP_FEED round_robin: this message belongs to another learner rank
         fields = self._data_proc(train_data)

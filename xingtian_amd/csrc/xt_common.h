@@ -296,10 +296,10 @@ struct DpStep {                     // what the optimiser kernels do for a data-
   int world;
   float loss_scale;                 // PPO weak mode: 1 / world (mean of the ranks' means); else 1 (shares of one sum)
   float* acc;                       // [0] += loss, [1] += 1, [2] = error bits
-  // direct exchange fused into the step: the first `red_blocks` workgroups of the optimiser launch first REDUCE this rank's
-  // slice (wait for every rank's scatter, sum the inbox slots in fixed rank order, push the slice and its squared-norm
-  // partials to every peer, raise the done flags); then every workgroup waits for all ranks' done flags and reads gradient
-  // and partials out of the exchange block; the last block re-arms the comm (tickets, sequence number)
+  // direct exchange fused into the step: ONE small launch in front of the optimiser (dp_reduce_wait_kernel, red_blocks <= 128
+  // workgroups) waits for every rank's scatter, sums this rank's slice over the inbox slots in fixed rank order, pushes
+  // the slice and its squared-norm partials to every peer, raises the done flags and waits for everybody's; the optimiser
+  // launch then reads gradient and partials out of the exchange block without spinning, its last block re-arms the comm
   const uint32_t* flags;            // my flag words (nullptr: plain exchange, nothing to wait for)
   uint32_t* ctl;
   unsigned long long timeout_ticks;

@@ -49,6 +49,7 @@ int launch_grads_finish(GradTable*, float*, int, int*, const FinalizeArgs*, hipS
                         unsigned early = 0, const DpFinish* dpf = nullptr);
 int launch_dp_tail_write(float*, int, float, const float*, float*, float, const float*, float, float, int, hipStream_t);
 int launch_dp_tail_consume(const DpStep*, hipStream_t);
+int launch_dp_reduce_wait(const DpStep*, hipStream_t);
 // the direct exchange fused into the step (xt_xgmi.hip)
 int direct_fill_finish(xt_direct_comm*, int64_t, DpFinish*);
 int direct_launch_scatter(xt_direct_comm*, const float*, int64_t, hipStream_t);
@@ -396,8 +397,8 @@ static int dp_finish_args(xt_net* n, DpFinish* d) {
   }
   return 0;
 }
-// after the local gradient is complete: exchange + squared norm of the EXCHANGED gradient (fused direct form: nothing is
-// launched here -- the optimiser launch reduces this rank's slice itself) -> what the optimiser launch needs
+// after the local gradient is complete: exchange + squared norm of the EXCHANGED gradient (fused direct form: one small
+// launch reduces this rank's slice, leaves the partials and waits for the other ranks') -> what the optimiser launch needs
 struct DpApply { const float* g; const float* partial; int npartial; DpStep step; int block_cap; };
 static int dp_exchange(xt_net* n, hipStream_t st, float* loss_acc, DpApply* a) {
   memset(a, 0, sizeof(*a));
@@ -405,6 +406,8 @@ static int dp_exchange(xt_net* n, hipStream_t st, float* loss_acc, DpApply* a) {
   if (n->direct && n->dp_world >= 1) {
     if (int rc = direct_fill_step(n->direct, dp_xcount(n), n->P, &a->step, &a->g, &a->partial, &a->npartial, &a->block_cap))
       return rc;
+    if (int rc = launch_dp_reduce_wait(&a->step, st)) return rc;
+    a->block_cap = 0;                 // (the optimiser launch does not spin)
     a->step.tail = a->g + dp_tail_off(n);
     return 0;
   }

@@ -529,73 +529,91 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, con
 // removes the serial "last block finalises" tail (ticket + 6 us single-block reduction) from the step.  Block 0
 // also publishes scale / gnorm to state[2] / state[4] (nobody reads them inside this launch).
 // ---- the data-parallel part of an optimiser launch (DpStep)
-// begin: direct exchange -> reduce my slice (the first workgroups), then wait for every rank's reduced slice; returns false
-// when the comm's sticky error word is set (a
+// begin: returns false when the comm's sticky error word is set (a
 // bounded wait ran out, now or earlier): the update is then SKIPPED -- parameters and slots stay those of the last good step
 // instead of absorbing whatever arrived -- and the bits travel to the host in loss_acc[2]
 __device__ bool dp_step_begin(const DpStep& dp) {
   __shared__ int s_ok;
-  __shared__ float s_sq[256];
   if (!dp.flags) return true;
-  const uint32_t seq = dp.ctl[kCtlSeq] + 1;
-  if ((int)blockIdx.x < dp.red_blocks) {
-    // ---- reduce phase (what was a launch of its own): my slice, FIXED rank order 0..N-1 -> every peer's result buffer
-    wait_all(dp.flags, kReadyOff, dp.world, seq, dp.ctl, dp.timeout_ticks, kErrScatterWait);
-    int64_t b, e;
-    slice_of(dp.nvec, dp.rank, dp.world, b, e);
-    const int64_t per = ((e - b) + dp.red_blocks - 1) / dp.red_blocks;
-    const int64_t lo = b + (int64_t)blockIdx.x * per;
-    const int64_t hi = lo + per < e ? lo + per : e;
-    float sq = 0.f;
-    // four vectors per thread in flight (clamped unconditional loads): the inbox is UNCACHED memory, every load is a full
-    // memory round trip -- a rolled loop serialised them (one-rank group: 6.5 dependent round trips per thread)
-    for (int64_t v0 = lo + threadIdx.x; v0 < hi; v0 += 4 * 256) {
-      float4 acc[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int64_t v = v0 + u * 256 < hi ? v0 + u * 256 : v0;
-        acc[u] = *reinterpret_cast<const float4*>(dp.inbox + (v - b) * 4);
-      }
-      for (int p = 1; p < dp.world; ++p) {          // FIXED order 0, 1, ..., N-1: the sum is a function of the data only
-        float4 x[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int64_t v = v0 + u * 256 < hi ? v0 + u * 256 : v0;
-          x[u] = *reinterpret_cast<const float4*>(dp.inbox + p * dp.slice_cap + (v - b) * 4);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { acc[u].x += x[u].x; acc[u].y += x[u].y; acc[u].z += x[u].z; acc[u].w += x[u].w; }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int64_t v = v0 + u * 256;
-        if (v < hi) {
-          for (int p = 0; p < dp.world; ++p) reinterpret_cast<float4*>(dp.peers.result[p])[v] = acc[u];
-          if (v < dp.nvec_grad)      // (not the tail slots)
-            sq += acc[u].x * acc[u].x + acc[u].y * acc[u].y + acc[u].z * acc[u].z + acc[u].w * acc[u].w;
-        }
-      }
-    }
-    s_sq[threadIdx.x] = sq;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) s_sq[threadIdx.x] += s_sq[threadIdx.x + o];
-      __syncthreads();
-    }
-    if ((int)threadIdx.x < dp.world) dp.peers.norm_part[threadIdx.x][dp.rank * dp.red_blocks + blockIdx.x] = s_sq[0];
-    publish_fence();
-    __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(dp.ctl + kCtlRed, 1u) == (uint32_t)dp.red_blocks - 1u) {
-      for (int p = 0; p < dp.world; ++p)
-        __hip_atomic_store(dp.peers.flags[p] + kDoneOff + dp.rank, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-  wait_all(dp.flags, kDoneOff, dp.world, seq, dp.ctl, dp.timeout_ticks, kErrReduceWait);
+  // (no wait here: dp_reduce_wait_kernel's last block has seen every rank's done flag before this launch started -- an
+  // optimiser launch whose 512 workgroups all spin on another process's flags starved that process's kernels when the
+  // ranks share one GPU: measured round 6, two ranks x B = 320: 3 s time-outs; the reduce launch's <= 128 small
+  // workgroups are the footprint that has run since round 5)
   if (threadIdx.x == 0)
     s_ok = __hip_atomic_load(dp.ctl + kCtlErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u ? 1 : 0;
   __syncthreads();
   return s_ok != 0;
 }
+
+// The exchange launch of the step that has the direct exchange fused in (xt_net_set_direct).  The scatter was done by the
+// gradient-reduction kernel (every reduced float4 written straight into its owner's inbox), the gather is done by the
+// optimiser kernel (reads the result buffer).  <= 128 small workgroups: (1) wait for every rank's scatter, sum my slice
+// over the inbox slots in FIXED rank order 0..N-1, push it to every peer's result buffer and leave the squared norm of
+// each workgroup's share (gradient part only: the tail slots carry rows / losses) in every peer's norm_part[rank][block],
+// raise my done flag everywhere; (2) wait until every rank's done flag has arrived -- so that the optimiser launch behind
+// this one starts with the whole reduced gradient and all partials in place and never spins.
+__global__ void __launch_bounds__(256) dp_reduce_wait_kernel(const DpStep dp) {
+  __shared__ float s_sq[256];
+  const uint32_t seq = dp.ctl[kCtlSeq] + 1;
+  wait_all(dp.flags, kReadyOff, dp.world, seq, dp.ctl, dp.timeout_ticks, kErrScatterWait);
+  int64_t b, e;
+  slice_of(dp.nvec, dp.rank, dp.world, b, e);
+  const int64_t per = ((e - b) + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = b + (int64_t)blockIdx.x * per;
+  const int64_t hi = lo + per < e ? lo + per : e;
+  float sq = 0.f;
+  // four vectors per thread in flight (clamped unconditional loads): the inbox is UNCACHED memory, every load is a full
+  // memory round trip
+  for (int64_t v0 = lo + threadIdx.x; v0 < hi; v0 += 4 * 256) {
+    float4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t v = v0 + u * 256 < hi ? v0 + u * 256 : v0;
+      acc[u] = *reinterpret_cast<const float4*>(dp.inbox + (v - b) * 4);
+    }
+    for (int p = 1; p < dp.world; ++p) {          // FIXED order 0, 1, ..., N-1: the sum is a function of the data only
+      float4 x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t v = v0 + u * 256 < hi ? v0 + u * 256 : v0;
+        x[u] = *reinterpret_cast<const float4*>(dp.inbox + p * dp.slice_cap + (v - b) * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { acc[u].x += x[u].x; acc[u].y += x[u].y; acc[u].z += x[u].z; acc[u].w += x[u].w; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t v = v0 + u * 256;
+      if (v < hi) {
+        for (int p = 0; p < dp.world; ++p) reinterpret_cast<float4*>(dp.peers.result[p])[v] = acc[u];
+        if (v < dp.nvec_grad)      // (not the tail slots)
+          sq += acc[u].x * acc[u].x + acc[u].y * acc[u].y + acc[u].z * acc[u].z + acc[u].w * acc[u].w;
+      }
+    }
+  }
+  s_sq[threadIdx.x] = sq;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s_sq[threadIdx.x] += s_sq[threadIdx.x + o];
+    __syncthreads();
+  }
+  if ((int)threadIdx.x < dp.world) dp.peers.norm_part[threadIdx.x][dp.rank * gridDim.x + blockIdx.x] = s_sq[0];
+  publish_fence();
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(dp.ctl + kCtlRed, 1u) == gridDim.x - 1u) {
+    for (int p = 0; p < dp.world; ++p)
+      __hip_atomic_store(dp.peers.flags[p] + kDoneOff + dp.rank, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  wait_all(dp.flags, kDoneOff, dp.world, seq, dp.ctl, dp.timeout_ticks, kErrReduceWait);
+}
+
+int launch_dp_reduce_wait(const DpStep* dp, hipStream_t st) {
+  XT_REQUIRE(dp && dp->flags && dp->red_blocks >= 1 && dp->red_blocks <= kDpRedBlocksMax, "dp_reduce_wait: bad arguments");
+  hipLaunchKernelGGL(dp_reduce_wait_kernel, dim3(dp->red_blocks), dim3(256), 0, st, *dp);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
 // block 0: the global loss (every rank's share, rank order -> the same bits everywhere) and the row check
 __device__ void dp_tail_consume(const DpStep& dp, bool ok) {
   if (!dp.tail || blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -827,7 +845,7 @@ int launch_rmsprop_clip(float* param, const float* grad, float* mg, float* ms, l
   if (nb < 1) nb = 1;
   DpStep d;
   if (dp) d = *dp; else memset(&d, 0, sizeof(d));
-  if (d.flags && nb < d.red_blocks) nb = d.red_blocks;      // (the first red_blocks workgroups reduce this rank's slice)
+
   hipLaunchKernelGGL(rmsprop_tf_clip_kernel, dim3(nb), dim3(256), 0, st, param, grad, mg, ms, count, lr, decay, eps,
                      state, partial, nblocks, clip_norm, grad_scale, lr_dev, d);
   XT_LAUNCH_CHECK();
@@ -849,7 +867,7 @@ int launch_adam_clip(float* param, const float* grad, float* m, float* v, long l
   if (nb < 1) nb = 1;
   DpStep d;
   if (dp) d = *dp; else memset(&d, 0, sizeof(d));
-  if (d.flags && nb < d.red_blocks) nb = d.red_blocks;      // (the first red_blocks workgroups reduce this rank's slice)
+
   hipLaunchKernelGGL(adam_tf_clip_kernel, dim3(nb), dim3(256), 0, st, param, grad, m, v, count, beta1, beta2, eps, state,
                      partial, nblocks, clip_norm, grad_scale, d);
   XT_LAUNCH_CHECK();

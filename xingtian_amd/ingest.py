@@ -112,6 +112,8 @@ class RolloutIngest(object):
         self.sets = [None, None]
         self.cur = 0
         self.n = 0
+        self.generation = 0             # rollouts handed to the learner so far (finish() calls)
+        self.on_finish = None           # callable: a transport.Prefetcher staging one train ahead is woken here
         self._lib = L.load()            # (the staging-copy variant for this host is picked on the first host copy)
 
     # ------------------------------------------------------------------
@@ -186,8 +188,11 @@ class RolloutIngest(object):
         elif plain:
             if not _TUNED:
                 staging_report()        # measure the host's copy variants once per process, on first use
+            # a message of a few MB (one 128-step Atari trajectory: 3.6 MB) ships in 1 MiB pieces, so that its H2D runs under
+            # its own staging instead of behind it; big rollouts keep the 4 MiB default (fewer DMA set-ups)
+            ship = (1 << 20) if obs.nbytes <= (8 << 20) else 0
             L.check(self._lib.xt_stage_rows(ctypes.c_void_p(s.host["obs"].data_ptr() + lo * row_bytes),
-                                            ctypes.c_void_p(obs.ctypes.data), obs.nbytes, ctypes.c_void_p(dev_ptr), 0, 0, -1,
+                                            ctypes.c_void_p(obs.ctypes.data), obs.nbytes, ctypes.c_void_p(dev_ptr), 0, ship, -1,
                                             ctypes.c_void_p(cstream.cuda_stream)), "xt_stage_rows")
         else:       # a cast on the way in (float frames for a uint8 network, ...): as the upload path casts them
             np.copyto(obs_dst, obs.reshape(obs_dst.shape), casting="unsafe")
@@ -265,6 +270,9 @@ class RolloutIngest(object):
         self.n = 0
         self.last = s
         self.last_raw_traj, self.raw_traj, self.adv_traj = self.raw_traj, 0, 0
+        self.generation += 1
+        if self.on_finish is not None:
+            self.on_finish()
         return n, dev
 
     def _join_copy_streams(self, wait=True):

@@ -101,6 +101,12 @@ class HipActorCritic(object):
         ring = getattr(self, "_wring", None)
         if ring is not None and not getattr(ring, "pinned", False):
             ring = self._wring = None       # the ring was closed (or un-pinned) behind our back: private snapshots again
+        if ring is not None and getattr(ring, "async_commit", False):
+            # asynchronous commit (WeightsRing.start_committer): every begun copy IS a publish; the ring's helper thread makes
+            # it visible when it lands (begin blocks only when slots - 1 copies are still in flight)
+            ring.begin_flat_publish(self, getattr(self, "_wring_ctr", None))
+            self._wring_version = getattr(self, "_version", 0)
+            return
         if ring is not None:
             # a page-locked WeightsRing is attached: the copy goes straight into its next slot (no pinned bounce block).
             # Begun publishes beyond the allowed lag belong to updates whose weights were never handed out: reuse their slot
@@ -170,6 +176,15 @@ class HipActorCritic(object):
         publish's sequence number."""
         if getattr(ring, "pinned", False):
             attached = getattr(self, "_wring", None) is ring
+            if getattr(ring, "async_commit", False):
+                # the update enqueued the D2H into the ring slot (or it is enqueued now); the ring's committer thread makes it
+                # visible when it lands -- this thread goes on (content = THIS update's weights, no lag)
+                if not attached:
+                    raise ValueError("publish_weights on a ring with an asynchronous committer needs attach_weights_ring(ring)")
+                if getattr(self, "_wring_version", -1) != getattr(self, "_version", 0) or ctr_info:
+                    ring.begin_flat_publish(self, ctr_info)
+                    self._wring_version = getattr(self, "_version", 0)
+                return ring._last_begun
             if lag > 0:
                 # ``lag = 1`` (asynchronous algorithms, flagged deviation): hand out the weights whose copy was begun at the
                 # PREVIOUS publish and never wait for the one just enqueued -- the next rollout message is ingested while

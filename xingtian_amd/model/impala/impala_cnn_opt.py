@@ -110,6 +110,11 @@ class ImpalaCnnOpt(XTModel):
     def ingested(self):
         return 0 if self._ingest is None else self._ingest.n
 
+    def ingest_generation(self):
+        """rollouts the learner has taken over so far (``RolloutIngest.finish`` calls): a ``transport.Prefetcher`` stages
+        at most one train ahead of it"""
+        return self._ingest_obj().generation
+
     def _lr_steps(self, n_chunks):
         """Step size of the next ``n_chunks`` updates as a device array, or None when it is the constant LR (the
         reference's rmsprop branch ignores lr_schedule, impala_cnn_opt.py:204-206)."""

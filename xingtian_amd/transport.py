@@ -23,16 +23,17 @@ rollout batches to the learner (``cmd: train``) and weight dicts back to the exp
   ``hipHostRegister``: the ingest then DMA-copies the uint8 frames to HBM straight out of the slot -- wire -> HBM with
   NO host copy on the learner side.
 
-* ``FrameSocket`` -- the inter-node hop: the two-frame multipart message of ``CommByZmq`` (control dict | payload,
-  zeus/common/ipc/comm_by_zmq.py:69-97) over a plain stream socket with length-prefixed frames (zmq is not installed
-  here; a maintainer who keeps zmq sends the same two buffers with ``send_multipart``).  ``recv_bytes`` / ``send_bytes``
-  forward a message without decoding its payload (what the broker does, broker.py:97-119); ``recv_into(sink)`` receives
-  into a reusable buffer and hands zero-copy views to ``Algorithm.prepare_data``.
+* ``Prefetcher`` -- learner side, asynchronous algorithms (IMPALA): a thread that owns the consumer end of a ring / ring set
+  and hands every message to the algorithm's ingest AS IT ARRIVES, so the H2D of train k+1's messages runs under the GPU's
+  train k; the learner loop (``recv_into(alg.prepare_data)`` x prepare_data_times -> ``train()``) is unchanged.
+  ``WeightsRing.start_committer()`` -- the other end: the D2H an update enqueued into a ring slot is committed (made visible
+  to the explorers) by a helper thread when it lands; the learner thread does not wait (as the reference's learner hands the
+  weights object to its send queue, xt/framework/learner.py:361-374).
 
 Plumbing only: no arithmetic; the only GPU-runtime call is the optional ``hipHostRegister`` of ``pin()``.
 """
-import socket as _socket
 import struct
+import threading
 import time
 from multiprocessing import shared_memory
 
@@ -430,6 +431,9 @@ class WeightsRing(object):
         self._seen = 0
         self.pinned = False
         self._pending = []          # begun, uncommitted packed publishes, oldest first: (seq, slot, bytes, event)
+        self._wlock = threading.Condition(threading.RLock())     # writer state (_pending, headers, latest)
+        self.async_commit = False   # start_committer(): begun publishes are committed by a helper thread as their copies land
+        self._committer = None
 
     def _payload_offset(self, i):
         return _ALIGN + i * (_ALIGN + self.slot_bytes) + _ALIGN
@@ -494,7 +498,11 @@ class WeightsRing(object):
         if lay[2] != nbytes:
             raise ValueError("WeightsRing: the flat buffer of this spec has {} bytes, not {}".format(lay[2], nbytes))
         if len(self._pending) >= self.slots - 1:
-            raise RuntimeError("WeightsRing: {} publishes begun and not committed (slots = {})".format(len(self._pending), self.slots))
+            if not self.async_commit:
+                raise RuntimeError("WeightsRing: {} publishes begun and not committed (slots = {})".format(len(self._pending), self.slots))
+            with self._wlock:           # the committer thread drains them as their copies land: wait for a free slot
+                while len(self._pending) >= self.slots - 1:
+                    self._wlock.wait(0.001)
         k = int(self._latest[0]) + 1 + len(self._pending)
         i = k % self.slots
         self._hdr[i][0] = 0
@@ -531,6 +539,11 @@ class WeightsRing(object):
         (``publish_weights(lag=1)``: the weights handed out are one update old, nothing waits)."""
         import torch
         nbytes = int(net.params.numel()) * 4
+        with self._wlock:
+            return self._begin_flat_publish_locked(net, ctr_info, nbytes)
+
+    def _begin_flat_publish_locked(self, net, ctr_info, nbytes):
+        import torch
         k, i, base = self._reserve_flat(net.spec, nbytes, ctr_info)
         st = getattr(self, "_d2h", None)
         if st is None:
@@ -544,17 +557,65 @@ class WeightsRing(object):
         L.memcpy_async(self._pin_addr + self._payload_offset(i) + base, net.params.data_ptr(), nbytes, L.D2H, side)
         done.record(side)
         self._pending.append((k, i, base + nbytes, done))
+        self._last_begun = k
+        self._wlock.notify_all()
         return k
 
     def commit_flat_publish(self):
         """Second half: wait for the OLDEST begun copy and make that publish visible to the readers.  Returns its
         sequence number."""
-        k, i, total, done = self._pending.pop(0)
+        with self._wlock:
+            k, i, total, done = self._pending[0]
         done.synchronize()
-        self._hdr[i][1] = total
-        self._hdr[i][0] = k
-        self._latest[0] = k
+        with self._wlock:
+            if self._pending and self._pending[0][0] == k:
+                self._pending.pop(0)
+                self._hdr[i][1] = total
+                self._hdr[i][0] = k
+                self._latest[0] = k
+                self._wlock.notify_all()
         return k
+
+    def start_committer(self):
+        """ASYNCHRONOUS commit (asynchronous algorithms): from now on a begun packed publish -- the D2H the update itself
+        enqueued into the ring slot (``HipActorCritic.attach_weights_ring`` + ``snapshot_weights_async``) -- is made visible
+        to the readers by a helper thread as soon as its copy has landed; ``publish_weights(ring)`` returns the sequence
+        number it WILL carry without waiting.  The weights handed out are exactly those of the train that published them (no
+        lag in content); only the learner thread does not sit through the D2H -- as the reference's learner hands the
+        weights object to its send queue and goes on (xt/framework/learner.py:361-374; zeus/common/ipc/share_buffer.py).
+        ``drain()`` waits until everything begun is visible."""
+        if self._committer is not None:
+            return self
+        self.async_commit = True
+        self._stop_committer = False
+
+        def run():
+            while True:
+                with self._wlock:
+                    while not self._pending and not self._stop_committer:
+                        self._wlock.wait(0.005)
+                    if self._stop_committer and not self._pending:
+                        return
+                try:
+                    self.commit_flat_publish()
+                except Exception:       # noqa: BLE001 -- a dead context at shutdown must not kill the interpreter's exit
+                    return
+
+        self._committer = threading.Thread(target=run, name="xt-weights-commit", daemon=True)
+        self._committer.start()
+        return self
+
+    def drain(self, timeout=5.0):
+        """wait until every begun publish is visible to the readers; -> latest sequence number"""
+        t0 = time.monotonic()
+        with self._wlock:
+            while self._pending and time.monotonic() - t0 < timeout:
+                if self._committer is None:
+                    break
+                self._wlock.wait(0.001)
+        while self._pending and self._committer is None:
+            self.commit_flat_publish()
+        return int(self._latest[0])
 
     def retarget_flat_publish(self):
         """Drop the newest begun, uncommitted publish (an update whose weights are never handed out: its slot is reused)."""
@@ -606,6 +667,12 @@ class WeightsRing(object):
         raise RuntimeError("WeightsRing.fetch: no stable publish after {} attempts".format(retries))
 
     def close(self):
+        if getattr(self, "_committer", None) is not None:
+            self._stop_committer = True
+            with self._wlock:
+                self._wlock.notify_all()
+            self._committer.join(timeout=5.0)
+            self._committer = None
         # begun-but-uncommitted D2H copies may still be in flight INTO the slots: wait for them before the pages are
         # un-registered and the segment unlinked
         for pend in getattr(self, "_pending", None) or []:
@@ -629,118 +696,110 @@ class WeightsRing(object):
             pass
 
 
-class FrameSocket(object):
-    """Two-frame messages (control dict | payload) over a stream socket: the inter-node counterpart of ``ShmRing`` with
-    the contract of ``CommByZmq`` (zeus/common/ipc/comm_by_zmq.py:69-97: ``send`` / ``recv`` of ``(ctr_info, data)``,
-    ``send_bytes`` / ``recv_bytes`` of the two raw frames for a forwarding broker).  Wire format per message:
-    ``b"XTF1" | u32 n_frames | n_frames x u64 length | the frames``; frame 0 = msgpack of the control dict, frame 1 =
-    ``encode({}, data)`` (msgpack header + raw 64-byte-aligned arrays).  One connection = one producer and one consumer."""
+class Prefetcher(object):
+    """Learner side of an ASYNCHRONOUS algorithm (IMPALA: explorers never wait for weights, the next rollout message is
+    usually in the ring while the GPU still runs the current train).  The reference's learner thread receives and
+    ``prepare_data``-s the messages of train k+1 only after ``train()`` k has returned (xt/framework/learner.py:306-348): the
+    H2D of 3.6 MB of frames then sits between two trains.  Here a thread owns the consumer end of ``source`` (a ``ShmRing`` or
+    ``RingSet``) and hands every message to ``alg.stage_message`` AS IT ARRIVES -- decode, pinned staging / DMA straight out
+    of a pinned slot, asynchronous H2D into the ingest's OTHER buffer set -- at most one train ahead: before it stages the
+    first message of train k+1 it waits until the learner has taken over train k's buffer set (``RolloutIngest.finish``).
 
-    MAGIC = b"XTF1"
+    The learner loop keeps its shape and its semantics: ``pf.recv_into(alg.prepare_data)`` x ``prepare_data_times`` hands
+    ``prepare_data`` a token (the control dict + ``{"_prefetched": n_rows}``) for a message whose data is already on its
+    way to HBM, in arrival order; ``alg.train()`` trains exactly the messages it would have been handed.  What changes is
+    WHEN the copy happens, not what is trained or published."""
 
-    def __init__(self, sock):
-        self.sock = sock
-        self.sock.setsockopt(_socket.IPPROTO_TCP, _socket.TCP_NODELAY, 1) if sock.family in (_socket.AF_INET, _socket.AF_INET6) else None
-        self._buf = self._aligned(1 << 20)    # reusable receive buffer of recv_into (grows to the largest message)
+    def __init__(self, source, alg, group=None, poll_s=0.0002):
+        if not hasattr(alg, "stage_message"):
+            raise TypeError("Prefetcher: {} has no stage_message (only streaming-ingest algorithms can be prefetched)".format(
+                type(alg).__name__))
+        self.source, self.alg = source, alg
+        self.group = int(group or alg.prepare_data_times)
+        self._poll = float(poll_s)
+        self._tokens = []                   # staged, not yet handed to prepare_data: control dicts in arrival order
+        self._cv = threading.Condition()
+        self._staged = 0                    # messages staged so far
+        self._error = None
+        self._stop = False
+        self._ingest_gen = alg.staged_generation
+        self._ingest_gen()                  # (creates the ingest on THIS thread, before the staging thread touches it)
+        self._thread = threading.Thread(target=self._run, name="xt-prefetch", daemon=True)
+        self._thread.start()
 
-    @staticmethod
-    def _aligned(nbytes):
-        """writable memoryview of ``nbytes`` bytes whose first byte sits on a 64-byte boundary (the payload's arrays are
-        64-byte aligned relative to the frame start: aligned views for the staging copy / a later hipHostRegister)"""
-        raw = np.empty(nbytes + _ALIGN, np.uint8)
-        off = (-raw.ctypes.data) % _ALIGN
-        return memoryview(raw[off:off + nbytes])
+    # ---- pump thread
+    def _stage(self, data, ctr_info=None):
+        ctr = dict(ctr_info or {})
+        rows = self.alg.stage_message(data, ctr_info=ctr)
+        ctr.pop("_slot_guard", None)
+        ctr.pop("_pinned_views", None)
+        with self._cv:
+            self._tokens.append((ctr, rows))
+            self._staged += 1
+            self._cv.notify_all()
 
-    # ---- connection set-up (the reference binds the learner side and connects the explorers, comm_by_zmq.py:45-66)
-    @staticmethod
-    def listen(addr="127.0.0.1", port=0, backlog=8):
-        """-> (listening socket, bound port); accept connections with ``FrameSocket.accept``."""
-        srv = _socket.socket(_socket.AF_INET, _socket.SOCK_STREAM)
-        srv.setsockopt(_socket.SOL_SOCKET, _socket.SO_REUSEADDR, 1)
-        srv.bind((addr, port))
-        srv.listen(backlog)
-        return srv, srv.getsockname()[1]
+    def _run(self):
+        try:
+            if hasattr(self.alg, "stage_thread_init"):
+                self.alg.stage_thread_init(wake=self.notify)
+            multi = hasattr(self.source, "poll_into")
+            while not self._stop:
+                # one train ahead at most: the first message of the NEXT train goes into the buffer set the learner is about
+                # to release -- wait until train (staged / group - 1) has been taken over by the learner (finish())
+                if self._staged and self._staged % self.group == 0:
+                    with self._cv:
+                        while not self._stop and self._ingest_gen() < self._staged // self.group:
+                            self._cv.wait(0.001)
+                    if self._stop:
+                        break
+                if multi:
+                    room = self.group - self._staged % self.group
+                    got = self.source.poll_into(self._stage, max_msgs=room)
+                else:
+                    got = 1 if self.source.recv_into(self._stage, block=False) is not None else 0
+                if not got:
+                    if hasattr(self.source, "reap"):
+                        self.source.reap()
+                    time.sleep(self._poll)
+        except BaseException as exc:        # noqa: BLE001 -- surfaces in the learner thread's next recv_into
+            with self._cv:
+                # (without its traceback: the frames hold zero-copy views into the ring's shared memory)
+                self._error = exc.with_traceback(None)
+                self._cv.notify_all()
 
-    @staticmethod
-    def accept(srv, timeout=None):
-        srv.settimeout(timeout)
-        conn, _ = srv.accept()
-        conn.settimeout(None)
-        return FrameSocket(conn)
-
-    @staticmethod
-    def connect(addr, port, timeout=10.0):
+    # ---- learner thread: the ring's receive contract
+    def recv_into(self, sink, block=True, timeout=None):
+        """hand the oldest staged message's token to ``sink(data, ctr_info=...)`` (``Algorithm.prepare_data``); -> its control
+        dict, or None (non-blocking / timed out)"""
         t0 = time.monotonic()
-        while True:
-            try:
-                return FrameSocket(_socket.create_connection((addr, port), timeout=timeout))
-            except (ConnectionRefusedError, OSError):
-                if time.monotonic() - t0 > timeout:
-                    raise
-                time.sleep(0.02)
-
-    # ---- frames
-    def send_bytes(self, ctr_frame, data_frame):
-        """Send the two frames as they are (a broker forwards what ``recv_bytes`` gave it without decoding the payload)."""
-        head = self.MAGIC + struct.pack("<IQQ", 2, len(ctr_frame), len(data_frame))
-        self.sock.sendall(head)
-        self.sock.sendall(ctr_frame)
-        self.sock.sendall(data_frame)
-
-    def _recv_exact(self, view):
-        got = 0
-        while got < len(view):
-            k = self.sock.recv_into(view[got:])
-            if k == 0:
-                raise ConnectionError("FrameSocket: peer closed the connection mid-message" if got else "FrameSocket: connection closed")
-            got += k
-
-    def _recv_header(self):
-        head = bytearray(4 + 4 + 16)
-        self._recv_exact(memoryview(head))
-        if bytes(head[:4]) != self.MAGIC:
-            raise ValueError("FrameSocket: not an XTF1 message")
-        n, l0, l1 = struct.unpack_from("<IQQ", head, 4)
-        if n != 2:
-            raise ValueError("FrameSocket: {} frames (expected 2)".format(n))
-        return l0, l1
-
-    def recv_bytes(self):
-        """-> (control frame, payload frame) as private ``bytes`` / ``bytearray`` objects."""
-        l0, l1 = self._recv_header()
-        f0, f1 = bytearray(l0), bytearray(l1)
-        self._recv_exact(memoryview(f0))
-        self._recv_exact(memoryview(f1))
-        return bytes(f0), f1
-
-    # ---- (ctr_info, data) contract
-    def send(self, ctr_info, data):
-        self.send_bytes(msgpack.packb(_plain(ctr_info), use_bin_type=True), encode({}, data))
-
-    def recv(self):
-        """-> (ctr_info, data) with private arrays (views into a buffer this call allocated)."""
-        f0, f1 = self.recv_bytes()
-        return msgpack.unpackb(f0, raw=False, strict_map_key=False), decode(f1)[1]
-
-    def recv_into(self, sink):
-        """Receive the next message into the reusable buffer and hand it to ``sink(data, ctr_info=...)`` as zero-copy
-        views (valid until the next ``recv_into``): the streaming ingest copies what it keeps (one host copy: socket
-        buffer -> pinned staging).  Returns the control dict."""
-        l0, l1 = self._recv_header()
-        base = _pad(l0)                        # payload frame 64-byte aligned inside the buffer: aligned array views
-        if base + l1 > len(self._buf):
-            self._buf = self._aligned(_pad(base + l1))
-        view = self._buf
-        self._recv_exact(view[:l0])
-        self._recv_exact(view[base:base + l1])
-        ctr = msgpack.unpackb(bytes(view[:l0]), raw=False, strict_map_key=False)
-        data = decode(view[base:base + l1])[1]
-        sink(data, ctr_info=ctr)
-        del data, view
+        with self._cv:
+            while not self._tokens:
+                if self._error is not None:
+                    raise RuntimeError("Prefetcher: the staging thread failed") from self._error
+                if not block or (timeout is not None and time.monotonic() - t0 > timeout):
+                    return None
+                self._cv.wait(0.0005)
+            ctr, rows = self._tokens.pop(0)
+        sink({"_prefetched": rows}, ctr_info=ctr)
         return ctr
 
+    def recv_many_into(self, sink, count, timeout=None):
+        got = 0
+        t0 = time.monotonic()
+        while got < count:
+            left = None if timeout is None else max(0.0, timeout - (time.monotonic() - t0))
+            if self.recv_into(sink, timeout=left) is None:
+                break
+            got += 1
+        return got
+
+    def notify(self):
+        """the learner has taken over a buffer set (``train()`` called ``finish()``): wake the staging thread"""
+        with self._cv:
+            self._cv.notify_all()
+
     def close(self):
-        try:
-            self.sock.close()
-        except OSError:
-            pass
+        self._stop = True
+        with self._cv:
+            self._cv.notify_all()
+        self._thread.join(timeout=5.0)
