@@ -985,7 +985,7 @@ def bench_env_num_256(spec, dev, updates=3):
 
 
 def impala_ring_loop(w, fm, msgs_per_train, tpc, n_prod, seconds, prefetch=True, async_commit=True, pinned=True, slots=4,
-                     min_trains=20):
+                     min_trains=20, gate=True):
     """The IMPALAOpt plugin pair fed as a learner is fed (xt/framework/learner.py:298-380): `n_prod` producer PROCESSES push
     pre-encoded rollout messages of `fm` frames into their own shared-memory ring (transport.RingSet); the learner loop is
     the reference's -- recv + prepare_data x msgs_per_train -> train() -> every tpc-th train the weights go out.
@@ -1032,7 +1032,7 @@ def impala_ring_loop(w, fm, msgs_per_train, tpc, n_prod, seconds, prefetch=True,
     if wpin and async_commit:
         wring.start_committer()
         alg.actor.net.attach_weights_ring(wring)
-    src = transport.Prefetcher(rs, alg) if prefetch else rs
+    src = transport.Prefetcher(rs, alg, gate=gate) if prefetch else rs
     sink = lambda d_, ctr_info=None: alg.prepare_data(d_, ctr_info=ctr_info)   # noqa: E731
     trains = 0
     t_recv = t_train = t_w = 0.0

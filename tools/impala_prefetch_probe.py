@@ -1,0 +1,51 @@
+#!/usr/bin/env python
+"""Where the host time of one IMPALAOpt train goes on the ring-fed, prefetched path (bench.impala_ring_loop): per-call wall
+time of the pieces of train() on the learner thread, breakout_impala shape by default.  GPU box."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from xingtian_amd import ingest, transport  # noqa: E402
+from xingtian_amd.model import hip_net  # noqa: E402
+
+T = {}
+
+
+def wrap(cls, name, key=None):
+    fn = getattr(cls, name)
+    key = key or "{}.{}".format(cls.__name__, name)
+
+    def timed(*a, **k):
+        t0 = time.perf_counter()
+        try:
+            return fn(*a, **k)
+        finally:
+            d = T.setdefault(key, [0.0, 0])
+            d[0] += time.perf_counter() - t0
+            d[1] += 1
+    setattr(cls, name, timed)
+
+
+wrap(ingest.RolloutIngest, "finish")
+wrap(ingest.RolloutIngest, "mark_consumed")
+wrap(ingest.RolloutIngest, "put")
+wrap(ingest.RolloutIngest, "ship_labels")
+wrap(hip_net.HipActorCritic, "impala_train")
+wrap(hip_net.HipActorCritic, "snapshot_weights_async")
+wrap(hip_net.HipActorCritic, "read_loss")
+wrap(hip_net.HipActorCritic, "publish_weights")
+wrap(transport.WeightsRing, "_reserve_flat")
+wrap(transport.Prefetcher, "recv_into")
+key = sys.argv[1] if len(sys.argv) > 1 else "breakout_impala"
+w = bench.IMPALA[key]
+mpt = w.get("msgs_per_train", 1 if key == "breakout_impala" else 4)
+res = bench.impala_ring_loop(w, w["frames_per_train"] // mpt, mpt, w.get("train_per_checkpoint", 1), n_prod=2, seconds=1.0,
+                             prefetch=(len(sys.argv) < 3 or sys.argv[2] != "blocking"),
+                             async_commit=(len(sys.argv) < 3 or sys.argv[2] != "blocking"),
+                             gate=(len(sys.argv) > 2 and sys.argv[2] == "gate"))
+print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in res.items()})
+for k, (tot, n) in sorted(T.items(), key=lambda kv: -kv[1][0]):
+    print("%-42s %7d calls  %8.1f us/call" % (k, n, 1e6 * tot / max(n, 1)))

@@ -54,17 +54,23 @@ class IMPALAOpt(Algorithm):
         self.actor.ingest_message(*fields, pinned=bool(ctr.get("_pinned_views")), slot_guard=ctr.get("_slot_guard"))
         return int(np.asarray(fields[0]).shape[0])
 
+    def stage_group_complete(self):
+        """(staging thread) the last message of a train has been staged: its label block follows the frames to HBM now"""
+        self.actor._ingest_obj().ship_labels()
+
     def staged_generation(self):
         """trains whose buffer set the learner thread has taken over (the Prefetcher stays at most one train ahead)"""
         return self.actor.ingest_generation()
 
-    def stage_thread_init(self, wake=None):
+    def stage_thread_init(self, wake=None, idle=None, bind_device=True):
         """first call on the staging thread: bind it to the learner's device; ``wake`` is called whenever the learner takes
-        over a buffer set"""
-        import torch
-        torch.cuda.set_device(self.actor.net.device)
-        if wake is not None:
-            self.actor._ingest_obj().on_finish = wake
+        over a buffer set; ``idle`` (threading.Event) is SET by the model while the learner thread waits for the GPU -- the
+        staging thread does its Python work then instead of fighting the learner for the GIL"""
+        if bind_device:
+            import torch
+            torch.cuda.set_device(self.actor.net.device)
+        self.actor._ingest_obj().on_finish = wake
+        self.actor.net.idle_gate = idle
 
     def prepare_data(self, train_data, **kwargs):
         if "_prefetched" in train_data:

@@ -175,13 +175,23 @@ class RolloutIngest(object):
         row_bytes = obs_dst.dtype.itemsize * int(np.prod(obs_dst.shape[1:], dtype=np.int64))
         dev_ptr = s.dev["obs"].data_ptr() + lo * row_bytes
         plain = obs.dtype == obs_dst.dtype and obs.flags.c_contiguous and obs.size == obs_dst.size
-        if pinned and plain and obs.flags.writeable:
-            # DMA source = the pinned transport slot: no host copy at all; the caller recycles the slot right after
-            with torch.cuda.stream(cstream):
-                s.dev["obs"][lo:hi].copy_(torch.from_numpy(obs.reshape(obs_dst.shape)), non_blocking=True)
+        if pinned and plain:
+            # DMA source = the pinned transport slot: no host copy at all; the caller recycles the slot right after.  One raw
+            # hipMemcpyAsync (a torch copy_ under a stream context costs ~40 us of Python per message) and pooled events
+            L.memcpy_async(dev_ptr, obs.ctypes.data, obs.nbytes, L.H2D, cstream)
             if slot_guard is not None:      # the ring keeps the slot until this event has fired: no wait here
-                ev = torch.cuda.Event()
+                pool = getattr(self, "_guard_events", None)
+                if pool is None:
+                    pool = self._guard_events = []
+                ev = None
+                for k, cand in enumerate(pool):      # an event whose copy has landed (and whose slot was released) is free again
+                    if cand.query():
+                        ev = pool.pop(k)
+                        break
+                if ev is None:
+                    ev = torch.cuda.Event()
                 ev.record(cstream)
+                pool.append(ev)
                 slot_guard.hold(ev)
             else:
                 cstream.synchronize()
@@ -237,6 +247,21 @@ class RolloutIngest(object):
                                             L.ptr(dev["offsets"]), L.ptr(dev["adv"]), L.ptr(dev["target_v"]), k,
                                             float(gamma), float(lam), stream_ptr), "xt_gae_f64_ragged")
 
+    def ship_labels(self):
+        """The rollout is complete: enqueue the ONE copy of its label block (and join the frame copies) now.  ``finish``
+        does it itself; a ``transport.Prefetcher`` calls it from its staging thread as soon as the last message of a train
+        has been staged, so that the DMA's latency is not paid between ``train()`` and the GPU's first kernel."""
+        s = self.sets[self.cur]
+        if s is None or self.n == 0 or getattr(s, "shipped_n", -1) == self.n:
+            return
+        self._join_copy_streams(wait=False)
+        # the labels of the whole rollout: ONE copy (a few 10 KB)
+        L.memcpy_async(s.lab_dev.data_ptr(), s.lab_host.data_ptr(), s.lab_host.numel(), L.H2D, self.copy_stream)
+        if self.raw_traj:
+            L.memcpy_async(s.dev["offsets"].data_ptr(), s.host["offsets"].data_ptr(), 4 * (self.raw_traj + 1), L.H2D,
+                           self.copy_stream)
+        s.shipped_n = self.n
+
     def finish(self):
         """All trajectories are in: make the compute stream wait for the copies, return (n, device buffers) and
         switch to the other buffer set for the next rollout."""
@@ -248,12 +273,8 @@ class RolloutIngest(object):
             self.reset()
             raise RuntimeError("RolloutIngest.finish(): a rollout must not mix trajectories with and without advantages")
         dev = s.dev
-        self._join_copy_streams(wait=False)
-        # the labels of the whole rollout: ONE copy (a few 10 KB)
-        L.memcpy_async(s.lab_dev.data_ptr(), s.lab_host.data_ptr(), s.lab_host.numel(), L.H2D, self.copy_stream)
-        if self.raw_traj:
-            L.memcpy_async(s.dev["offsets"].data_ptr(), s.host["offsets"].data_ptr(), 4 * (self.raw_traj + 1), L.H2D,
-                           self.copy_stream)
+        self.ship_labels()
+        s.shipped_n = -1
         if self.pad_channels is not None and s.dev["obs"].shape[-1] != self.pad_channels[0]:
             c_dst, fill = self.pad_channels
             src = s.dev["obs"]
@@ -265,7 +286,7 @@ class RolloutIngest(object):
                                               ctypes.c_void_p(self.copy_stream.cuda_stream)), "xt_pad_channels")
             dev = dict(s.dev, obs=s.dev_padded)
         s.done.record(self.copy_stream)
-        torch.cuda.current_stream(self.device).wait_event(s.done)
+        L.current_stream(self.device).wait_event(s.done)
         self.cur ^= 1
         self.n = 0
         self.last = s
@@ -289,7 +310,7 @@ class RolloutIngest(object):
         """call after the update that reads the last finished set has been enqueued on the compute stream"""
         if self.last.free is None:
             self.last.free = torch.cuda.Event()
-        self.last.free.record(torch.cuda.current_stream(self.device))
+        self.last.free.record(L.current_stream(self.device))
 
     def reset(self):
         self.n = 0

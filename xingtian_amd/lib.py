@@ -205,9 +205,34 @@ def ptr(t):
     return c_void_p(t.data_ptr())
 
 
+_STREAMS = {}
+
+
+def current_stream(device=None):
+    """``torch.cuda.current_stream(device)`` without its ~6 us of Python per call (four of them sat in every 128-frame
+    IMPALA train): the Stream object is cached per device and reused while the raw handle of the current stream
+    (``torch._C._cuda_getCurrentRawStream``, ~0.3 us) has not changed"""
+    idx = torch.cuda.current_device() if device is None else (device.index if hasattr(device, "index") else int(device))
+    if idx is None:
+        idx = torch.cuda.current_device()
+    try:
+        raw = torch._C._cuda_getCurrentRawStream(idx)
+    except AttributeError:          # (a torch without the private accessor)
+        return torch.cuda.current_stream(idx)
+    hit = _STREAMS.get(idx)
+    if hit is not None and hit[0] == raw:
+        return hit[1]
+    st = torch.cuda.current_stream(idx)
+    _STREAMS[idx] = (raw, st)
+    return st
+
+
 def stream_ptr():
     """The current PyTorch HIP stream as a void* (kernels are enqueued on it)."""
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    try:
+        return c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+    except AttributeError:
+        return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def kernel_sources_sha():

@@ -124,7 +124,7 @@ class HipActorCritic(object):
             snap["ready"] = [torch.cuda.Event() for _ in range(self.SNAP_SLOTS)]
         i = (snap["slot"] + 1) % self.SNAP_SLOTS
         ready = snap["ready"][i]
-        ready.record(torch.cuda.current_stream(self.device))
+        ready.record(L.current_stream(self.device))
         snap["stream"].wait_event(ready)
         L.memcpy_async(snap["host"][i].data_ptr(), self.params.data_ptr(), self.params.numel() * 4, L.D2H, snap["stream"])
         snap["events"][i].record(snap["stream"])
@@ -358,13 +358,19 @@ class HipActorCritic(object):
             pin = torch.zeros((2, 4), dtype=torch.float32, pin_memory=True)
             rb = self._loss_rb = dict(pin=pin, np=pin.numpy(), ev=[torch.cuda.Event(), torch.cuda.Event()], slot=0, n=0)
         i = rb["slot"]
-        cur = torch.cuda.current_stream(self.device)
+        cur = L.current_stream(self.device)
         L.memcpy_async(rb["pin"][i].data_ptr(), acc.data_ptr(), 16, L.D2H, cur)
         rb["ev"][i].record(cur)
         rb["slot"] = i ^ 1
         j = i if (wait or rb["n"] == 0) else i ^ 1
         rb["n"] += 1
-        rb["ev"][j].synchronize()
+        gate = getattr(self, "idle_gate", None)        # (transport.Prefetcher: its staging thread works while we wait)
+        if gate is not None:
+            gate.set()
+            rb["ev"][j].synchronize()
+            gate.clear()
+        else:
+            rb["ev"][j].synchronize()
         a = rb["np"][j]
         if a[2] != 0.0:
             raise RuntimeError("xingtian_amd: the data-parallel update failed on this rank -- {} (error bits {}); the "

@@ -540,6 +540,8 @@ class WeightsRing(object):
         import torch
         nbytes = int(net.params.numel()) * 4
         with self._wlock:
+            if self.async_commit:
+                return self._begin_staged_publish_locked(net, ctr_info, nbytes)
             return self._begin_flat_publish_locked(net, ctr_info, nbytes)
 
     def _begin_flat_publish_locked(self, net, ctr_info, nbytes):
@@ -551,12 +553,39 @@ class WeightsRing(object):
                               [torch.cuda.Event() for _ in range(self.slots)])
         side, ready, dones = st
         done = dones[i]
-        ready.record(torch.cuda.current_stream(net.device))
-        side.wait_event(ready)
         from xingtian_amd import lib as L
+        ready.record(L.current_stream(net.device))
+        side.wait_event(ready)
         L.memcpy_async(self._pin_addr + self._payload_offset(i) + base, net.params.data_ptr(), nbytes, L.D2H, side)
         done.record(side)
         self._pending.append((k, i, base + nbytes, done))
+        self._last_begun = k
+        self._wlock.notify_all()
+        return k
+
+    def _begin_staged_publish_locked(self, net, ctr_info, nbytes):
+        """asynchronous-commit form of ``begin_flat_publish``: the parameters are SNAPSHOT on the device (one D2D copy on the
+        compute stream, in order behind the update: the next update's optimiser cannot tear it) and the D2H is enqueued by
+        the committer thread only once that snapshot is complete -- a D2H enqueued up front sits in the DMA queue blocked on
+        its dependency and the NEXT message's H2D queues behind it (measured round 6: the prefetched loop no faster than
+        the blocking one)."""
+        import torch
+        from xingtian_amd import lib as L
+        st = getattr(self, "_staged", None)
+        if st is None or st["snap"][0].numel() * 4 != nbytes:
+            st = self._staged = dict(snap=[torch.empty(nbytes // 4, dtype=torch.float32, device=net.device) for _ in range(2)],
+                                     ready=[torch.cuda.Event(), torch.cuda.Event()], busy=[False, False], turn=0,
+                                     side=torch.cuda.Stream(device=net.device), done=torch.cuda.Event())
+        b = st["turn"]
+        while st["busy"][b]:                 # (both snapshots still on their way out: the learner is ahead of the PCIe link)
+            self._wlock.wait(0.001)
+        st["turn"] = b ^ 1
+        k, i, base = self._reserve_flat(net.spec, nbytes, ctr_info)
+        cur = L.current_stream(net.device)
+        L.memcpy_async(st["snap"][b].data_ptr(), net.params.data_ptr(), nbytes, L.D2D, cur)
+        st["ready"][b].record(cur)
+        st["busy"][b] = True
+        self._pending.append((k, i, base + nbytes, None, b))
         self._last_begun = k
         self._wlock.notify_all()
         return k
@@ -565,8 +594,21 @@ class WeightsRing(object):
         """Second half: wait for the OLDEST begun copy and make that publish visible to the readers.  Returns its
         sequence number."""
         with self._wlock:
-            k, i, total, done = self._pending[0]
-        done.synchronize()
+            item = self._pending[0]
+        k, i, total, done = item[:4]
+        if done is None:                     # staged form: the device-side snapshot is complete -> D2H now -> wait
+            from xingtian_amd import lib as L
+            st, b = self._staged, item[4]
+            st["ready"][b].synchronize()
+            nbytes = st["snap"][b].numel() * 4
+            L.memcpy_async(self._pin_addr + self._payload_offset(i) + (total - nbytes), st["snap"][b].data_ptr(), nbytes, L.D2H,
+                           st["side"])
+            st["done"].record(st["side"])
+            st["done"].synchronize()
+            with self._wlock:
+                st["busy"][b] = False
+        else:
+            done.synchronize()
         with self._wlock:
             if self._pending and self._pending[0][0] == k:
                 self._pending.pop(0)
@@ -677,7 +719,8 @@ class WeightsRing(object):
         # un-registered and the segment unlinked
         for pend in getattr(self, "_pending", None) or []:
             try:
-                pend[3].synchronize()
+                if pend[3] is not None:
+                    pend[3].synchronize()
             except Exception:       # noqa: BLE001 -- closing must not raise over a dead context
                 pass
         self._pending = []
@@ -710,7 +753,7 @@ class Prefetcher(object):
     way to HBM, in arrival order; ``alg.train()`` trains exactly the messages it would have been handed.  What changes is
     WHEN the copy happens, not what is trained or published."""
 
-    def __init__(self, source, alg, group=None, poll_s=0.0002):
+    def __init__(self, source, alg, group=None, poll_s=0.0002, gate=True):
         if not hasattr(alg, "stage_message"):
             raise TypeError("Prefetcher: {} has no stage_message (only streaming-ingest algorithms can be prefetched)".format(
                 type(alg).__name__))
@@ -719,6 +762,14 @@ class Prefetcher(object):
         self._poll = float(poll_s)
         self._tokens = []                   # staged, not yet handed to prepare_data: control dicts in arrival order
         self._cv = threading.Condition()
+        # SET while the learner thread is blocked (waiting for the GPU inside train(), or for a message here): the staging
+        # thread does its Python work then.  Two Python threads that both issue dozens of short runtime calls per train hand
+        # the GIL back and forth at every one of them: measured round 6, every call of the learner's train() 2-3x slower
+        # (graph launch 30 -> 78 us, weight snapshot 30 -> 86 us) and the prefetched loop no faster than the blocking one
+        self.learner_idle = threading.Event()
+        self.learner_idle.set()
+        self.gate = bool(gate)              # False: the staging thread runs whenever a message is there (same-box A/B,
+                                            # round 6: breakout_impala 1.3-1.6 M ungated vs 1.9-2.0 M gated, pong 10-11 vs 12-13 M)
         self._staged = 0                    # messages staged so far
         self._error = None
         self._stop = False
@@ -733,6 +784,8 @@ class Prefetcher(object):
         rows = self.alg.stage_message(data, ctr_info=ctr)
         ctr.pop("_slot_guard", None)
         ctr.pop("_pinned_views", None)
+        if (self._staged + 1) % self.group == 0 and hasattr(self.alg, "stage_group_complete"):
+            self.alg.stage_group_complete()         # the train's label block goes to HBM now, not inside train()
         with self._cv:
             self._tokens.append((ctr, rows))
             self._staged += 1
@@ -741,7 +794,7 @@ class Prefetcher(object):
     def _run(self):
         try:
             if hasattr(self.alg, "stage_thread_init"):
-                self.alg.stage_thread_init(wake=self.notify)
+                self.alg.stage_thread_init(wake=self.notify, idle=self.learner_idle if self.gate else None)
             multi = hasattr(self.source, "poll_into")
             while not self._stop:
                 # one train ahead at most: the first message of the NEXT train goes into the buffer set the learner is about
@@ -752,6 +805,8 @@ class Prefetcher(object):
                             self._cv.wait(0.001)
                     if self._stop:
                         break
+                if self.gate:
+                    self.learner_idle.wait(0.002)   # (bounded: a learner that never blocks must not starve the ingest)
                 if multi:
                     room = self.group - self._staged % self.group
                     got = self.source.poll_into(self._stage, max_msgs=room)
@@ -778,8 +833,10 @@ class Prefetcher(object):
                     raise RuntimeError("Prefetcher: the staging thread failed") from self._error
                 if not block or (timeout is not None and time.monotonic() - t0 > timeout):
                     return None
+                self.learner_idle.set()
                 self._cv.wait(0.0005)
             ctr, rows = self._tokens.pop(0)
+        self.learner_idle.clear()
         sink({"_prefetched": rows}, ctr_info=ctr)
         return ctr
 
@@ -800,6 +857,12 @@ class Prefetcher(object):
 
     def close(self):
         self._stop = True
+        self.learner_idle.set()
         with self._cv:
             self._cv.notify_all()
         self._thread.join(timeout=5.0)
+        if hasattr(self.alg, "stage_thread_init"):
+            try:
+                self.alg.stage_thread_init(wake=None, idle=None, bind_device=False)
+            except Exception:       # noqa: BLE001
+                pass
