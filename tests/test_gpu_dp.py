@@ -134,6 +134,10 @@ def test_bench_self_spawns_two_ranks_and_reports_weak_strict_and_impala():
     assert d["config"]["global_batch"] == 640 and d["config"]["env_steps_per_update"] == 8192
     assert len(lines[0]) < 4000                      # the driver-facing line stays compact (BENCH_r04: parsed = null)
     assert d["strict"]["rows_per_gpu"] == 160 and d["strict"]["value"] > 0
+    # the N > 1 line is a complete line: roofline + cpu_baseline, and the strict (reference-semantics)
+    # number sits at the top level next to the weak-mode `value`
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["bound"] == "mfma" and d["cpu_baseline"]["value"] > 0
+    assert d["value_strict"] == d["strict"]["value"] and d["global_batch"] == 640 and d["global_batch_strict"] == 320
     assert d["secondary"]["pong_impala_speedup"]["strict"] > 0 and d["secondary"]["breakout_impala"]["weak"] > 0
     # the direct all-reduce over hipIpc-mapped memory carries a validated number even with both ranks on one GPU (the RCCL
     # variants cannot form a communicator there and say so)

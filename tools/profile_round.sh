@@ -7,12 +7,13 @@
 #   gpurun_out/<tag>_bench.json                 the default `python bench.py` line (the compact driver-facing one), run LAST so that
 #   gpurun_out/<tag>_bench_detail.json          its roofline joins the counters just collected (copied to profiles/ on the box)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r05}
+TAG=${1:-r06}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for W in ppo breakout_impala pong_impala_speedup; do
   rm -rf /tmp/ks; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $R/bench.py --workload $W --steps 8 --warmup 2 --no-cpu-baseline --quick > /tmp/ks.log 2>&1
-  cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $R/gpurun_out/${TAG}_kernel_stats_$W.csv
+  # per-kernel mean / MEDIAN / p99 / outlier count from the raw trace (rocprofv3's own stats table has no median)
+  python $R/tools/kernel_trace_stats.py /tmp/ks $R/gpurun_out/${TAG}_kernel_stats_$W.csv || cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $R/gpurun_out/${TAG}_kernel_stats_$W.csv
 done
 for W in ppo breakout_impala pong_impala_speedup; do
   for P in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
