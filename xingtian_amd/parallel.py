@@ -573,11 +573,29 @@ class LearnerDP(object):
             self.comm.attach(net)
         elif self.exchange == "direct":
             self.comm = DirectComm(self.rank, self.world, int(net.grads_xchg.numel())).connect()
+            self._direct_self_test(net.device)
             self.comm.attach_fused(net)
         else:
             self.comm = TorchDistExchange(net)
             self.comm.attach()
         return self
+
+    def _direct_self_test(self, device):
+        """one value-checked all-reduce through the freshly connected exchange blocks BEFORE the learner depends on them:
+        integer-valued data whose sum is exact in float32, so any stale / torn / misdirected slice shows (the cross-device
+        ordering of the direct exchange has only ever been exercised with all ranks on one GPU)"""
+        n = 4099
+        base = torch.arange(n, dtype=torch.float32, device=device) % 977.0
+        buf = base * float(self.rank + 1)
+        self.comm.all_reduce_(buf)
+        torch.cuda.synchronize()
+        want = base * float(self.world * (self.world + 1) // 2)
+        st = self.comm.status()
+        if st["error_bits"] or not torch.equal(buf, want):
+            bad = int((buf != want).sum().item())
+            raise RuntimeError("DP_EXCHANGE direct: the start-up self-test all-reduce failed on rank {} (error bits {}, {} of {} "
+                               "elements wrong) -- use DP_EXCHANGE rccl on this machine and run tools/multi_gpu_preflight.py".format(
+                                   self.rank, st["error_bits"], bad, n))
 
     def exchanged_gradient(self, net):
         """the gradient the last SGD step applied (after the exchange) as a host array (tests)"""
