@@ -122,6 +122,12 @@ typedef struct xt_tuning {
                                  layers lose);
                                  2 = experiment: additionally the halo-instance conv weight gradient (PpoCnn conv3) in a
                                  one-LDS-stage bf16x6 form -- measured +0.9 us per step, kept for A/Bs only               */
+  int32_t fwd_fuse12;         /* (round 6) > 0: a network whose first two layers are ImpalaCnnOpt's 84x84 pair (uint8 8x8/4 SAME
+                               * 4 -> 16, then 4x4/2 SAME 16 -> 32) runs them as ONE launch per frame stack (conv1's output stays
+                               * in LDS for conv2, xt_conv1.hip: conv_u8c4_same_fwd2_kernel) when the batch has at most this many
+                               * frames.  DEFAULT 0 (two launches): built, parity-green and MEASURED SLOWER -- 87.6 vs 83.7 us
+                               * per 128-frame train, same box: 128 workgroups leave half the CUs idle and conv2 from LDS on fp32
+                               * MFMA is 64 MFMAs x 64 cycles per wave, two waves per SIMD = 3.4 us */
 } xt_tuning;
 int xt_tuning_get(xt_tuning* out);
 int xt_tuning_set(const xt_tuning* in);

@@ -609,3 +609,33 @@ def test_adv_normalize_f64_matches_numpy(L, n):
     d2 = torch.from_numpy(adv.copy()).cuda()              # reproducible: same bits run to run
     L.check(L.load().xt_adv_normalize_f64(L.ptr(d2), n, 1e-8, None, None), "xt_adv_normalize_f64")
     assert torch.equal(d, d2)
+
+
+@pytest.mark.parametrize("b", [1, 3, 128, 256])
+def test_conv1_conv2_of_a_frame_stack_in_one_launch_equals_the_two_launches(b):
+    """xt_tuning.fwd_fuse12 (round 6): ImpalaCnnOpt 84x84's first two layers (uint8 8x8/4 SAME 4 -> 16, 4x4/2 SAME 16 -> 32,
+    xt/model/impala/impala_cnn_opt.py:118-125) as ONE launch per frame stack -- conv1's tiles are computed exactly as by the
+    separate kernel (bit for bit), conv2 comes out of LDS on fp32 MFMA with the K halves combined in fixed order (vs the
+    register-direct kernel: rounding of a different summation order only); against the float64 oracle both stay <= 3e-6."""
+    from xingtian_amd import lib as L
+    from xingtian_amd.model import netspec
+    from xingtian_amd.model.hip_net import HipActorCritic
+    spec = netspec.impala_cnn_opt((84, 84, 4), 4, 0.0, 255.0, "uint8")
+    rng = np.random.default_rng(40 + b)
+    obs = rng.integers(0, 256, (b, 84, 84, 4)).astype(np.uint8)
+    outs = []
+    for knob in (0, 256):
+        old = L.set_tuning(fwd_fuse12=knob)
+        try:
+            net = HipActorCritic(spec, max_batch=b, seed=7)
+            logits, value = net.forward(obs)
+            torch.cuda.synchronize()
+            a1, _ = net.layer_buffers(0, b)
+            a2, _ = net.layer_buffers(1, b)
+            outs.append((a1.cpu().numpy().copy(), a2.cpu().numpy().copy(), logits.cpu().numpy().copy(), value.cpu().numpy().copy()))
+        finally:
+            L.set_tuning(**old)
+    (r1, r2, rl, rv), (f1, f2, fl, fv) = outs
+    assert np.abs(r2).max() > 0 and np.array_equal(r1, f1)
+    assert np.linalg.norm(f2 - r2) / np.linalg.norm(r2) < 2e-6
+    assert np.allclose(fl, rl, rtol=1e-5, atol=1e-6) and np.allclose(fv, rv, rtol=1e-5, atol=1e-6)

@@ -1018,6 +1018,185 @@ __global__ __launch_bounds__(512, (KW == 4 && SLOTS == 1) ? 8 : 2) void conv_u8c
   XT_TL_DRAIN(5);
 }
 
+// ---- conv1 -> conv2 of ONE frame stack in one workgroup (ImpalaCnnOpt 84x84: 8x8/4 SAME 4 -> 16, then 4x4/2 SAME 16 -> 32;
+// xt/model/impala/impala_cnn_opt.py:118-125).  At a few hundred frames per train (examples/breakout_impala.yaml: 128) the
+// two forward launches are latency chains of ~7.8 + ~7.0 us that each fill the chip once; here a workgroup runs a whole
+// frame: phase 1 = the kernel above on the frame's 441 positions (14 tiles on 8 waves x 2 slots), the activated tiles go to
+// global memory (the backward pass reads them) AND stay in LDS; phase 2 = conv2 as an implicit GEMM out of LDS,
+// M = 121 positions (4 tiles) x N = 32 x K = 256 on fp32 MFMA (v_mfma_f32_32x32x2_f32): wave = (M tile, K half), the
+// wave's 8 kernel taps x 8 channels of the B operand live in 64 registers (loaded while phase 1's epilogue runs), the A
+// operand is two 16-byte LDS reads per tap (SAME padding = a zero select).  The K halves are combined through LDS in fixed
+// order.  One load phase, one launch boundary and the 1.8 MB round trip of conv1's output less.
+struct C1s2Args {
+  C1sArgs c1;
+  const float* w2;     // [4*4*16][32]
+  const float* b2;     // [32]
+  float* y2;           // [B*OH2*OW2][32]
+  int OH2, OW2, S2, PT2, PL2, act2;
+};
+constexpr int kA1Stride = 20;      // floats per conv1 output position in LDS (16 channels + 4: 80-byte rows spread the banks)
+
+__global__ __launch_bounds__(512, 1) void conv_u8c4_same_fwd2_kernel(const C1s2Args q2) {
+  const C1sArgs& p = q2.c1;
+  constexpr int NW = 8, NT = 512, SLOTS = 2, KW = 8, NOUT = 16, NS = KW * KW / 4, U = 14;
+  extern __shared__ __attribute__((aligned(16))) uint8_t limg[];
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int OHOW = p.OH * p.OW, WrowP = p.Wp * 4;
+  const int p0 = blockIdx.x * OHOW, p1 = p0 + OHOW;            // one frame stack per workgroup
+  uint4* wpl = reinterpret_cast<uint4*>(limg + 2 * p.img_cap);     // [NS][3 planes][64 lanes] x 16 B
+  float* a1 = reinterpret_cast<float*>(limg + 2 * p.img_cap + NS * 3 * 64 * 16);     // [OHOW][kA1Stride]
+  constexpr int WQ = (NS * 64 + NT - 1) / NT;
+  float wv[WQ][8];
+#pragma unroll
+  for (int q = 0; q < WQ; ++q) {
+    const int slot = t + NT * q;
+    const int sc = slot < NS * 64 ? slot : 0;
+    const int n = sc & 31, k0 = (sc >> 6) * 16 + 8 * ((sc & 63) >> 5);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[q][j] = p.w[(size_t)(k0 + j) * NOUT + (n < NOUT ? n : 0)];
+  }
+  int shift[1];
+  stage_rows_padded<1, NT, U, true>(p, KW, p0, p1, limg, t, shift);
+#pragma unroll
+  for (int q = 0; q < WQ; ++q) {
+    const int slot = t + NT * q;
+    if (slot < NS * 64) {
+      const bool live = (slot & 31) < NOUT;
+      BF8 b1, b2, b3;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float w0 = live ? wv[q][2 * e] : 0.f, w1 = live ? wv[q][2 * e + 1] : 0.f;
+        const float r0 = w0 - trunc_bf16(w0), r1 = w1 - trunc_bf16(w1);
+        const float q0 = r0 - trunc_bf16(r0), q1 = r1 - trunc_bf16(r1);
+        b1.u[e] = pack_hi16(w0, w1);
+        b2.u[e] = pack_hi16(r0, r1);
+        b3.u[e] = pack_hi16(q0, q1);
+      }
+      const int sidx = slot >> 6, ln = slot & 63;
+      wpl[(sidx * 3 + 0) * 64 + ln] = make_uint4(b1.u[0], b1.u[1], b1.u[2], b1.u[3]);
+      wpl[(sidx * 3 + 1) * 64 + ln] = make_uint4(b2.u[0], b2.u[1], b2.u[2], b2.u[3]);
+      wpl[(sidx * 3 + 2) * 64 + ln] = make_uint4(b3.u[0], b3.u[1], b3.u[2], b3.u[3]);
+    }
+  }
+  const int il = lane & 31, h = lane >> 5;
+  int poff[SLOTS];
+#pragma unroll
+  for (int ti = 0; ti < SLOTS; ++ti) {
+    const int rem = min((wave + NW * ti) * 32 + il, OHOW - 1);
+    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+    poff[ti] = 2 * (shift[0] + (p.S * oy * p.Wp + p.S * ox) * 4 + 8 * h);
+  }
+  f32x16 acc[SLOTS];
+#pragma unroll
+  for (int ti = 0; ti < SLOTS; ++ti)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
+  const float bias = il < NOUT ? p.bias[il] : 0.f;
+  __syncthreads();
+  uint4 wq[2][3], aq[2][SLOTS];
+  auto lds_fetch = [&](int s, uint4 (&w3)[3], uint4 (&a2)[SLOTS]) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) w3[pl] = wpl[(s * 3 + pl) * 64 + lane];
+    const int koff = 2 * ((s >> 1) * WrowP + (s & 1) * 16);
+#pragma unroll
+    for (int ti = 0; ti < SLOTS; ++ti) a2[ti] = *reinterpret_cast<const uint4*>(limg + poff[ti] + koff);
+  };
+  lds_fetch(0, wq[0], aq[0]);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int cur = s & 1;
+    BF8 bp[3], av[SLOTS];
+    if (s + 1 < NS) lds_fetch(s + 1, wq[cur ^ 1], aq[cur ^ 1]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) { bp[pl].u[0] = wq[cur][pl].x; bp[pl].u[1] = wq[cur][pl].y; bp[pl].u[2] = wq[cur][pl].z; bp[pl].u[3] = wq[cur][pl].w; }
+#pragma unroll
+    for (int ti = 0; ti < SLOTS; ++ti) { av[ti].u[0] = aq[cur][ti].x; av[ti].u[1] = aq[cur][ti].y; av[ti].u[2] = aq[cur][ti].z; av[ti].u[3] = aq[cur][ti].w; }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int ti = 0; ti < SLOTS; ++ti)
+        acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ti].v, bp[pl].v, acc[ti], 0, 0, 0);
+  }
+  // phase 2's B operand: wave = (M tile mt, K half kh); taps 8 kh .. 8 kh + 7, lane (n = il, channel half h): 64 values,
+  // issued now so that their latency hides behind phase 1's epilogue
+  const int mt = wave & 3, kh = wave >> 2;
+  float wb[8][8];
+#pragma unroll
+  for (int tt = 0; tt < 8; ++tt)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wb[tt][j] = q2.w2[(size_t)((8 * kh + tt) * 16 + 8 * h + j) * 32 + il];
+  const float bias2 = q2.b2[il];
+  __syncthreads();
+  // phase 1 epilogue: the tile through LDS (the image is dead) -> 16-byte rows to global memory AND into the LDS copy
+  float* tbuf = reinterpret_cast<float*>(limg) + wave * (32 * 36);
+#pragma unroll
+  for (int ti = 0; ti < SLOTS; ++ti) {
+    const int row0 = (wave + NW * ti) * 32;              // first position of the tile inside the frame
+    if (row0 < OHOW) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        tbuf[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + il] = act_apply(fmaf(acc[ti][r], p.xs, bias), p.act);
+      constexpr int LPR = NOUT / 4;            // lanes per output row
+#pragma unroll
+      for (int q = 0; q < 32 * LPR / 64; ++q) {
+        const int row = q * (64 / LPR) + lane / LPR, c4 = (lane % LPR) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(&tbuf[row * 36 + c4]);
+        if (row0 + row < OHOW) {
+          *reinterpret_cast<float4*>(&p.y[(size_t)(p0 + row0 + row) * NOUT + c4]) = v;
+          *reinterpret_cast<float4*>(&a1[(row0 + row) * kA1Stride + c4]) = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: conv2 out of LDS.  Output position pos = 32 mt + il (A rows), taps 8 kh .. 8 kh + 7
+  const int OHOW2 = q2.OH2 * q2.OW2;
+  const int pos = min(32 * mt + il, OHOW2 - 1);
+  const int oy2 = pos / q2.OW2, ox2 = pos - oy2 * q2.OW2;
+  f32x16 c2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c2[r] = 0.f;
+#pragma unroll
+  for (int tt = 0; tt < 8; ++tt) {
+    const int tap = 8 * kh + tt, ky = tap >> 2, kx = tap & 3;
+    const int iy = q2.S2 * oy2 + ky - q2.PT2, ix = q2.S2 * ox2 + kx - q2.PL2;
+    const bool in = iy >= 0 && iy < p.OH && ix >= 0 && ix < p.OW;
+    const float* ap = a1 + ((in ? iy : 0) * p.OW + (in ? ix : 0)) * kA1Stride + 8 * h;
+    float4 lo = *reinterpret_cast<const float4*>(ap), hi = *reinterpret_cast<const float4*>(ap + 4);
+    if (!in) { lo = make_float4(0.f, 0.f, 0.f, 0.f); hi = lo; }
+    c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(lo.x, wb[tt][0], c2, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(lo.y, wb[tt][1], c2, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(lo.z, wb[tt][2], c2, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(lo.w, wb[tt][3], c2, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(hi.x, wb[tt][4], c2, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(hi.y, wb[tt][5], c2, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(hi.z, wb[tt][6], c2, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(hi.w, wb[tt][7], c2, 0, 0, 0);
+  }
+  // combine the K halves (fixed order: lower half + upper half), bias, activation, 16-byte rows out
+  float* cbuf = reinterpret_cast<float*>(limg) + mt * (32 * 36);      // (aliases phase 1's transposition buffers: dead)
+  if (kh == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cbuf[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + il] = c2[r];
+  }
+  __syncthreads();
+  if (kh == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      cbuf[row * 36 + il] = act_apply((c2[r] + cbuf[row * 36 + il]) + bias2, q2.act2);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {               // 32 columns: 8 lanes per row, 8 rows per pass
+      const int row = q * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+      const float4 v = *reinterpret_cast<const float4*>(&cbuf[row * 36 + c4]);
+      if (32 * mt + row < OHOW2)
+        *reinterpret_cast<float4*>(&q2.y2[((size_t)blockIdx.x * OHOW2 + 32 * mt + row) * 32 + c4]) = v;
+    }
+  }
+}
+
 // weight gradient: PB positions per workgroup (NSTEP = PB / 16 pixel steps), 8 waves = NPG pixel-step groups x NKQ
 // k-tile groups of RQ 32-row k tiles each (K = KW*KW*4: 8 tiles for KW = 8, 2 for KW = 4).
 template <int PB, int KW, int NOUT>
@@ -1230,6 +1409,35 @@ int launch_conv1_same_fwd(const xt_conv_geom* g, const xt_input_xform* xf, int B
     if (two) hipLaunchKernelGGL((conv_u8c4_same_fwd_kernel<2, 4, 16>), grid, blk, fl, st, a);
     else hipLaunchKernelGGL((conv_u8c4_same_fwd_kernel<1, 4, 16>), grid, blk, fl, st, a);
   }
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+
+// conv1 -> conv2 of a frame stack in one launch (conv_u8c4_same_fwd2_kernel): returns 0 launched, 1 error, -1 geometry not
+// handled (the caller then launches the two layers separately)
+int launch_conv12_same_fwd(const xt_conv_geom* g, const xt_input_xform* xf, const xt_conv_geom* g2, int B, const void* in,
+                           const int32_t* idx, const float* w, const float* bias, float* y, const float* w2, const float* b2,
+                           float* y2, hipStream_t st) {
+  if (!c1s_geometry(g, xf) || g->KW != 8) return -1;
+  const int OHOW = g->OH * g->OW, OHOW2 = g2->OH * g2->OW;
+  if (OHOW > 14 * 32 || g2->C != 16 || g2->N != 32 || g2->KH != 4 || g2->KW != 4 || g2->H != g->OH || g2->W != g->OW ||
+      OHOW2 > 128 || g2->PT < 0 || g2->PL < 0)
+    return -1;
+  C1s2Args a;
+  c1s_fill(&a.c1, g, xf, B);
+  a.c1.in = static_cast<const uint8_t*>(in); a.c1.idx = idx; a.c1.w = w; a.c1.bias = bias; a.c1.y = y; a.c1.dy = nullptr; a.c1.out = nullptr;
+  // the whole padded frame: rows [0, S (OH - 1) + KH)
+  a.c1.img_cap = ((g->S * (g->OH - 1) + g->KH) * a.c1.Wp * 4 + 15) & ~15;
+  a.w2 = w2; a.b2 = b2; a.y2 = y2; a.OH2 = g2->OH; a.OW2 = g2->OW; a.S2 = g2->S; a.PT2 = g2->PT; a.PL2 = g2->PL; a.act2 = g2->act;
+  const size_t fl = (size_t)2 * a.c1.img_cap + (size_t)16 * 3 * 64 * 16 + (size_t)OHOW * kA1Stride * 4;
+  if (fl > 160 * 1024 || (size_t)2 * a.c1.img_cap < (size_t)8 * 32 * 36 * 4) return -1;
+  if (a.c1.img_cap / 8 > 512 * 14) return -1;                                   // staging: 14 pixel pairs per thread
+  static PerDeviceOnce attr_once;
+  attr_once.run([] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_u8c4_same_fwd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+  });
+  hipLaunchKernelGGL(conv_u8c4_same_fwd2_kernel, dim3(B), dim3(512), fl, st, a);
   XT_LAUNCH_CHECK();
   return 0;
 }

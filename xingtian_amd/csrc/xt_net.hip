@@ -29,7 +29,7 @@ xt_tuning& tuning() {
                         /*direct_waves*/ 1536, /*direct_max_waves*/ 8, /*direct_tile64_tiles*/ 3072,
                         /*fwd_split_target*/ 256, /*wgrad_split_target*/ 512, /*reduce_z_lanes*/ 8,
                         /*defer_splitk*/ 1, /*finalize_ticket*/ 0, /*fwd_tiled_valid*/ 1, /*wgrad_rows*/ 4, /*fwd_prefetch_all*/ 0, /*bwd_deep_prefetch*/ 1, /*fwd_four_groups*/ 1, /*reduce_deep_lanes*/ 128, /*fwd_xcd_chunk*/ 1,
-                        /*tail_overlap*/ 0, /*tail_fused*/ 0, /*dense_wgrad_x6*/ 1};
+                        /*tail_overlap*/ 0, /*tail_fused*/ 0, /*dense_wgrad_x6*/ 1, /*fwd_fuse12*/ 0};
   return t;
 }
 
@@ -40,6 +40,8 @@ int launch_bwd_layer(const xt_conv_geom*, int, const float*, const float*, const
                      int, const HeadWgArgs*, int*, hipStream_t, const uint32_t* xmask = nullptr, int slab_cap = 0,
                      const float* x_grad = nullptr, float* sq_partials = nullptr, int* npre_out = nullptr);
 int launch_act_apply(const float* z, float* y, long long count, int act, hipStream_t st);
+int launch_conv12_same_fwd(const xt_conv_geom*, const xt_input_xform*, const xt_conv_geom*, int, const void*, const int32_t*,
+                           const float*, const float*, float*, const float*, const float*, float*, hipStream_t);
 int launch_wgrad(const xt_conv_geom*, const xt_input_xform*, int, const void*, const int32_t*, const float*,
                  float*, float*, int, hipStream_t, int reduce_now = 1, int* msplit_out = nullptr, int slab_cap = 0);
 int launch_dgrad(const xt_conv_geom*, int, const float*, const float*, const float*, int, float*, hipStream_t);
@@ -211,6 +213,24 @@ static int net_forward(xt_net* n, const void* obs, const int32_t* idx, int B, bo
       L.last_ksplit = 1;
       L.mask_valid = 0;
       if (!first) { if (int rc = join_pending_update(n, st)) return rc; }
+      if (first && tuning().fwd_fuse12 > 0 && B <= tuning().fwd_fuse12 && l + 2 < n->t_end[tr] && L.z_off < 0 &&
+          L.mask_off < 0 && n->layers[l + 1].z_off < 0 && n->layers[l + 1].mask_off < 0) {
+        // ImpalaCnnOpt 84x84 at a few hundred frames: conv1 -> conv2 of a frame stack in ONE launch (conv1's output stays in
+        // LDS for conv2; both activations still go to their workspace buffers for the backward pass).  -1: not that geometry
+        Layer& L2 = n->layers[l + 1];
+        if (int rcj = join_pending_update(n, st)) return rcj;      // (the launch reads the second layer's weights too)
+        const int rc = launch_conv12_same_fwd(&L.g, &n->xf, &L2.g, B, x, idx, n->params + L.poff,
+                                              n->params + L.poff + (int64_t)L.K * L.g.N, n->ws + L.act_off, n->params + L2.poff,
+                                              n->params + L2.poff + (int64_t)L2.K * L2.g.N, n->ws + L2.act_off, st);
+        if (rc > 0) return rc;
+        if (rc == 0) {
+          L2.last_ksplit = 1;
+          L2.mask_valid = 0;
+          x = n->ws + L2.act_off;
+          ++l;
+          continue;
+        }
+      }
       if (L.z_off >= 0) {
         // swish / gelu: the layer writes its PRE-activation (the backward pass needs it), then one elementwise launch
         // produces the output the next layer reads -- a slow path, taken by no bundled configuration

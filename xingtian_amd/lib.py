@@ -62,7 +62,7 @@ class Tuning(Structure):
         "bf16x6", "dgrad_all_classes", "dgrad_tile64", "dgrad_halo", "bwd_own_instance", "bwd_fit_slots",
         "conv1_bf16x3", "conv1_flat", "conv1_waves", "fwd_two_groups", "direct", "direct_fwd", "direct_dgrad",
         "direct_all", "direct_waves", "direct_max_waves", "direct_tile64_tiles", "fwd_split_target",
-        "wgrad_split_target", "reduce_z_lanes", "defer_splitk", "finalize_ticket", "fwd_tiled_valid", "wgrad_rows", "fwd_prefetch_all", "bwd_deep_prefetch", "fwd_four_groups", "reduce_deep_lanes", "fwd_xcd_chunk", "tail_overlap", "tail_fused", "dense_wgrad_x6")]
+        "wgrad_split_target", "reduce_z_lanes", "defer_splitk", "finalize_ticket", "fwd_tiled_valid", "wgrad_rows", "fwd_prefetch_all", "bwd_deep_prefetch", "fwd_four_groups", "reduce_deep_lanes", "fwd_xcd_chunk", "tail_overlap", "tail_fused", "dense_wgrad_x6", "fwd_fuse12")]
 
 
 OPT_TYPE = {"adam": 0, "rmsprop": 1}
