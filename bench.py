@@ -502,7 +502,7 @@ KERNEL_OF = {
 }
 
 
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def library_identity():

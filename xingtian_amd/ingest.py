@@ -198,9 +198,11 @@ class RolloutIngest(object):
         elif plain:
             if not _TUNED:
                 staging_report()        # measure the host's copy variants once per process, on first use
-            # a message of a few MB (one 128-step Atari trajectory: 3.6 MB) ships in 1 MiB pieces, so that its H2D runs under
-            # its own staging instead of behind it; big rollouts keep the 4 MiB default (fewer DMA set-ups)
-            ship = (1 << 20) if obs.nbytes <= (8 << 20) else 0
+            # an IMPALA message of a few MB (one 128-step Atari trajectory: 3.6 MB) ships in 1 MiB pieces, so that its H2D runs
+            # under its own staging instead of behind it; everything else keeps the 4 MiB default (fewer DMA set-ups)
+            # (IMPALA ingests only, n_epochs == 0: a PPO rollout's 32+ trajectories already overlap each other's H2D, and three
+            # more DMA set-ups per trajectory cost that path 0.7 ms per update, measured round 6)
+            ship = (1 << 20) if (self.n_epochs == 0 and obs.nbytes <= (8 << 20)) else 0
             L.check(self._lib.xt_stage_rows(ctypes.c_void_p(s.host["obs"].data_ptr() + lo * row_bytes),
                                             ctypes.c_void_p(obs.ctypes.data), obs.nbytes, ctypes.c_void_p(dev_ptr), 0, ship, -1,
                                             ctypes.c_void_p(cstream.cuda_stream)), "xt_stage_rows")

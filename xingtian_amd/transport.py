@@ -571,6 +571,8 @@ class WeightsRing(object):
         the blocking one)."""
         import torch
         from xingtian_amd import lib as L
+        if getattr(self, "_commit_error", None) is not None:
+            raise RuntimeError("WeightsRing: the committer thread failed") from self._commit_error
         st = getattr(self, "_staged", None)
         if st is None or st["snap"][0].numel() * 4 != nbytes:
             st = self._staged = dict(snap=[torch.empty(nbytes // 4, dtype=torch.float32, device=net.device) for _ in range(2)],
@@ -628,8 +630,12 @@ class WeightsRing(object):
         ``drain()`` waits until everything begun is visible."""
         if self._committer is not None:
             return self
+        if not self.pinned:
+            raise RuntimeError("WeightsRing.start_committer: the ring must be page-locked first (pin()): the committer DMA-copies "
+                               "the device-side snapshot straight into the slot")
         self.async_commit = True
         self._stop_committer = False
+        self._commit_error = None
 
         def run():
             while True:
@@ -640,7 +646,11 @@ class WeightsRing(object):
                         return
                 try:
                     self.commit_flat_publish()
-                except Exception:       # noqa: BLE001 -- a dead context at shutdown must not kill the interpreter's exit
+                except Exception as exc:       # noqa: BLE001 -- surfaces in the learner thread's next publish
+                    with self._wlock:
+                        self._commit_error = exc
+                        self._pending.clear()
+                        self._wlock.notify_all()
                     return
 
         self._committer = threading.Thread(target=run, name="xt-weights-commit", daemon=True)
