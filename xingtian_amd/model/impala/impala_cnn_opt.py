@@ -153,6 +153,11 @@ class ImpalaCnnOpt(XTModel):
         lr_steps = self._lr_steps(n_chunks)
         acc = self.net.impala_train(self._cfg, d["obs"][:n], batch_size, d["logit"][:n], d["action"][:n], d["done"][:n],
                                     d["reward"][:n], lr_steps=lr_steps, use_graph=self.use_graph)
+        gate = getattr(self.net, "idle_gate", None)
+        if gate is not None:
+            # a transport.Prefetcher's staging thread may start on the next message NOW: the GPU has this train's work, what is
+            # left on this thread (marking the buffer set, the weight snapshot, the loss wait) is short and mostly waiting
+            gate.set()
         self._ingest.mark_consumed()
         self._global_step += n_chunks
         if self.eager_snapshot:
