@@ -578,6 +578,36 @@ int xt_net_impala_train(xt_net* net, const xt_impala_cfg* cfg, const void* obs, 
                         const float* bp_logits, const int32_t* action, const uint8_t* done, const float* reward,
                         const float* lr_steps, float* loss_acc, int32_t use_graph, void* stream);
 
+/* xt_net_impala_train plus the runtime calls a learner loop issues around it, in ONE call (ABI >= 11): the per-train host path
+ * of IMPALAOpt.train (xt/algorithm/impala/impala_opt.py:73-106 inside xt/framework/learner.py:298-380) was ~10 separate
+ * Python-level runtime calls (wait for the rollout's copies, launch, mark the buffer set consumed, snapshot the weights, read
+ * the loss back, wait) around an 85 us train.  Every member of `io` is optional (NULL / 0 = skip):
+ *   wait_event      the stream waits for this event before the first kernel (the rollout's H2D copies)
+ *   consumed_event  recorded right behind the train (the rollout's buffer set may be overwritten once it has fired)
+ *   loss_host       page-locked host block of 4 floats: loss_acc is copied there; loss_event is recorded behind the copy;
+ *                   wait_loss != 0: the call returns when that copy has landed (hipEventSynchronize; the caller's language
+ *                   runtime lock is released for the whole call by ctypes)
+ *   publish_dst     page-locked HOST block of n_params floats (a transport.WeightsRing slot): the new parameters are copied
+ *                   there in stream order BEHIND the loss copy (the next update cannot tear them, the caller's loss wait does
+ *                   not include them); publish_event is recorded behind the copy (the ring's committer thread waits for it).
+ *                   (Measured alternatives, round 6: a device-side snapshot + the D2H on a side stream under the next train is
+ *                   SLOWER -- the D2H into registered host memory is a blit KERNEL that competes with the train's kernels:
+ *                   0.29 vs 0.27 ms per 128-frame train --, and the same D2H enqueued later by a helper thread serialises with
+ *                   the learner thread's next launch.)
+ * Events are hipEvent_t handles (e.g. torch.cuda.Event.cuda_event). */
+typedef struct xt_train_io {
+  void* wait_event;
+  void* consumed_event;
+  float* loss_host;
+  void* loss_event;
+  float* publish_dst;
+  void* publish_event;
+  int32_t wait_loss;
+} xt_train_io;
+int xt_net_impala_train_io(xt_net* net, const xt_impala_cfg* cfg, const void* obs, int32_t n, int32_t batch_size,
+                           const float* bp_logits, const int32_t* action, const uint8_t* done, const float* reward,
+                           const float* lr_steps, float* loss_acc, int32_t use_graph, const xt_train_io* io, void* stream);
+
 /* clip + Adam on the net's flat gradient (second half of a data-parallel step) */
 int xt_net_apply(xt_net* net, float lr, float beta1, float beta2, float eps, float clip_norm,
                  float grad_scale, void* stream);

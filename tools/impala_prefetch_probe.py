@@ -30,10 +30,9 @@ def wrap(cls, name, key=None):
 
 
 wrap(ingest.RolloutIngest, "finish")
-wrap(ingest.RolloutIngest, "mark_consumed")
 wrap(ingest.RolloutIngest, "put")
 wrap(ingest.RolloutIngest, "ship_labels")
-wrap(hip_net.HipActorCritic, "impala_train")
+wrap(hip_net.HipActorCritic, "impala_train_io")
 wrap(hip_net.HipActorCritic, "snapshot_weights_async")
 wrap(hip_net.HipActorCritic, "read_loss")
 wrap(hip_net.HipActorCritic, "publish_weights")

@@ -1149,6 +1149,28 @@ int xt_net_impala_train(xt_net* net, const xt_impala_cfg* c, const void* obs, in
   });
 }
 
+int xt_net_impala_train_io(xt_net* net, const xt_impala_cfg* c, const void* obs, int32_t n, int32_t batch_size,
+                           const float* bp_logits, const int32_t* action, const uint8_t* done, const float* reward,
+                           const float* lr_steps, float* loss_acc, int32_t use_graph, const xt_train_io* io, void* stream) {
+  hipStream_t st = xt::as_stream(stream);
+  if (io && io->wait_event) XT_CHECK_HIP(hipStreamWaitEvent(st, static_cast<hipEvent_t>(io->wait_event), 0));
+  if (int rc = xt_net_impala_train(net, c, obs, n, batch_size, bp_logits, action, done, reward, lr_steps, loss_acc, use_graph, stream))
+    return rc;
+  if (!io) return 0;
+  if (io->consumed_event) XT_CHECK_HIP(hipEventRecord(static_cast<hipEvent_t>(io->consumed_event), st));
+  if (io->loss_host) {
+    XT_CHECK_HIP(hipMemcpyAsync(io->loss_host, loss_acc, 4 * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (io->loss_event) XT_CHECK_HIP(hipEventRecord(static_cast<hipEvent_t>(io->loss_event), st));
+  }
+  if (io->publish_dst) {
+    XT_CHECK_HIP(hipMemcpyAsync(io->publish_dst, net->params, sizeof(float) * (size_t)net->P, hipMemcpyDeviceToHost, st));
+    if (io->publish_event) XT_CHECK_HIP(hipEventRecord(static_cast<hipEvent_t>(io->publish_event), st));
+  }
+  if (io->loss_host && io->loss_event && io->wait_loss)
+    XT_CHECK_HIP(hipEventSynchronize(static_cast<hipEvent_t>(io->loss_event)));
+  return 0;
+}
+
 int xt_net_keras_impala_step(xt_net* n, const void* obs, const int32_t* idx, int32_t B, const float* adv,
                              const float* onehot, const float* target_v, float ent_coef, float* loss_out,
                              float* loss_acc, void* stream) {

@@ -264,9 +264,10 @@ class RolloutIngest(object):
                            self.copy_stream)
         s.shipped_n = self.n
 
-    def finish(self):
+    def finish(self, wait_on_stream=True):
         """All trajectories are in: make the compute stream wait for the copies, return (n, device buffers) and
-        switch to the other buffer set for the next rollout."""
+        switch to the other buffer set for the next rollout.  ``wait_on_stream=False``: the caller makes its stream wait for
+        ``self.last.done`` itself (``xt_net_impala_train_io`` does it inside the train's C call)."""
         s = self.sets[self.cur]
         n = self.n
         if s is None or n == 0:
@@ -288,7 +289,8 @@ class RolloutIngest(object):
                                               ctypes.c_void_p(self.copy_stream.cuda_stream)), "xt_pad_channels")
             dev = dict(s.dev, obs=s.dev_padded)
         s.done.record(self.copy_stream)
-        L.current_stream(self.device).wait_event(s.done)
+        if wait_on_stream:
+            L.current_stream(self.device).wait_event(s.done)
         self.cur ^= 1
         self.n = 0
         self.last = s
@@ -307,6 +309,14 @@ class RolloutIngest(object):
             self.copy_stream.wait_event(self._join_ev[i])
         if wait:
             self.copy_stream.synchronize()
+
+    def consumed_event(self):
+        """the event that marks the last finished set as consumed (raw-handle users record it themselves: the event exists,
+        i.e. has been recorded once, when this returns)"""
+        if self.last.free is None:
+            self.last.free = torch.cuda.Event()
+            self.last.free.record(L.current_stream(self.device))
+        return self.last.free
 
     def mark_consumed(self):
         """call after the update that reads the last finished set has been enqueued on the compute stream"""

@@ -65,6 +65,12 @@ class Tuning(Structure):
         "wgrad_split_target", "reduce_z_lanes", "defer_splitk", "finalize_ticket", "fwd_tiled_valid", "wgrad_rows", "fwd_prefetch_all", "bwd_deep_prefetch", "fwd_four_groups", "reduce_deep_lanes", "fwd_xcd_chunk", "tail_overlap", "tail_fused", "dense_wgrad_x6", "fwd_fuse12")]
 
 
+class TrainIO(ctypes.Structure):
+    """xt_train_io of include/xt_mi355x.h: the runtime calls around one train, folded into the train's C call"""
+    _fields_ = [("wait_event", c_void_p), ("consumed_event", c_void_p), ("loss_host", c_void_p), ("loss_event", c_void_p),
+                ("publish_dst", c_void_p), ("publish_event", c_void_p), ("wait_loss", c_int32)]
+
+
 OPT_TYPE = {"adam": 0, "rmsprop": 1}
 XCHG_OVERLAP = 1         # XT_XCHG_OVERLAP
 DIRECT_HANDLE_BYTES = 64  # XT_DIRECT_HANDLE_BYTES
@@ -138,6 +144,8 @@ SIGNATURES = {
     "xt_net_set_dp": (c_int32, [_P, c_int32, c_int32, c_float]),
     "xt_net_set_direct": (c_int32, [_P, _P]),
     "xt_net_time_tail": (c_int32, [_P, c_float, c_float, c_int32, POINTER(c_float), _P]),
+    "xt_net_impala_train_io": (c_int32, [_P, POINTER(ImpalaCfg), _P, c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_int32,
+                                         POINTER(TrainIO), _P]),
 }
 
 

@@ -449,6 +449,56 @@ class HipActorCritic(object):
                                              L.stream_ptr()), "xt_net_impala_train")
         return self.loss_acc
 
+    def impala_train_io(self, c, obs, batch_size, bp_logits, action, done, reward, lr_steps=None, use_graph=False,
+                        wait_event=None, consumed_event=None, publish=None, wait_loss=True):
+        """``impala_train`` + the runtime calls of the learner loop around it in ONE C call (``xt_net_impala_train_io``): the
+        compute stream waits for ``wait_event`` (the rollout's copies), ``consumed_event`` is recorded behind the train,
+        ``loss_acc`` is copied into the next pinned read-back block and -- ``wait_loss`` -- awaited with the GIL released,
+        ``publish`` = (host address of a pinned weights-ring slot, raw event handle) receives the new parameters by a D2H in
+        stream order behind the loss copy (``WeightsRing.publish_reserve``).  Returns the pinned
+        [sum, count, error bits, -] block of THIS train (``wait_loss``) or of the previous one; raises on error bits."""
+        n = int(obs.shape[0])
+        self.touch()
+        rb = getattr(self, "_loss_rb", None)
+        if rb is None:
+            pin = torch.zeros((2, 4), dtype=torch.float32, pin_memory=True)
+            rb = self._loss_rb = dict(pin=pin, np=pin.numpy(), ev=[torch.cuda.Event(), torch.cuda.Event()], slot=0, n=0)
+        if "raw" not in rb:
+            cur = L.current_stream(self.device)
+            for ev in rb["ev"]:
+                ev.record(cur)                 # (a torch event gets its handle at its first record)
+            rb["raw"] = [ev.cuda_event for ev in rb["ev"]]
+            rb["ptr"] = [rb["pin"][k].data_ptr() for k in range(2)]
+        i = rb["slot"]
+        io = L.TrainIO()
+        io.wait_event = wait_event.cuda_event if wait_event is not None else None
+        io.consumed_event = consumed_event.cuda_event if consumed_event is not None else None
+        if publish is not None:
+            io.publish_dst, io.publish_event = publish[0], publish[1]
+        io.loss_host, io.loss_event, io.wait_loss = rb["ptr"][i], rb["raw"][i], 1 if (wait_loss or rb["n"] == 0) else 0
+        gate = getattr(self, "idle_gate", None)
+        if gate is not None:
+            gate.set()              # the staging thread may work from here on: this thread is inside C (GIL released)
+        try:
+            L.check(self.lib.xt_net_impala_train_io(self.handle, ctypes.byref(c), L.ptr(obs), n, int(batch_size),
+                                                    L.ptr(bp_logits), L.ptr(action), L.ptr(done), L.ptr(reward),
+                                                    L.ptr(lr_steps), L.ptr(self.loss_acc), 1 if use_graph else 0,
+                                                    ctypes.byref(io), L.stream_ptr()), "xt_net_impala_train_io")
+        finally:
+            if gate is not None:
+                gate.clear()
+        rb["slot"] = i ^ 1
+        j = i if (wait_loss or rb["n"] == 0) else i ^ 1
+        rb["n"] += 1
+        if j != i:
+            rb["ev"][j].synchronize()
+        a = rb["np"][j]
+        if a[2] != 0.0:
+            raise RuntimeError("xingtian_amd: the data-parallel update failed on this rank -- {} (error bits {}); the "
+                               "optimiser skipped the update, parameters are those of the last good step".format(
+                                   L.dp_error_text(a[2]), int(a[2])))
+        return a
+
     def keras_impala_step(self, obs, idx, adv, onehot, target_v, ent_coef, loss_acc=None):
         """One ``model.fit`` minibatch of the non-opt IMPALA models (C ABI xt_net_keras_impala_step): forward, Keras
         impala_loss + 0.5 mse, backward; the gradient stays in ``self.grads`` for ``adam_keras``.  Returns the device

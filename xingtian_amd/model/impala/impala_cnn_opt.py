@@ -140,7 +140,7 @@ class ImpalaCnnOpt(XTModel):
         """``IMPALAOpt.train`` (impala_opt.py:73-106) on the rollout streamed in through ``ingest_message``: all
         sequential BATCH_SIZE chunks in one C call -> mean of the chunk losses."""
         self._require_learner()
-        n, d = self._ingest.finish()
+        n, d = self._ingest.finish(wait_on_stream=False)       # (the train's C call makes the stream wait for the copies)
         dp = self._dp
         if dp is not None:
             if dp.mode == "strict" and dp.feed != "replicated":
@@ -151,20 +151,25 @@ class ImpalaCnnOpt(XTModel):
                 batch_size //= dp.world
         n_chunks = (n + batch_size - 1) // batch_size
         lr_steps = self._lr_steps(n_chunks)
-        acc = self.net.impala_train(self._cfg, d["obs"][:n], batch_size, d["logit"][:n], d["action"][:n], d["done"][:n],
-                                    d["reward"][:n], lr_steps=lr_steps, use_graph=self.use_graph)
-        gate = getattr(self.net, "idle_gate", None)
-        if gate is not None:
-            # a transport.Prefetcher's staging thread may start on the next message NOW: the GPU has this train's work, what is
-            # left on this thread (marking the buffer set, the weight snapshot, the loss wait) is short and mostly waiting
-            gate.set()
-        self._ingest.mark_consumed()
+        # ONE C call: wait for the rollout's copies -> all chunks (hipGraph replay) -> mark the buffer set consumed -> loss
+        # read-back into a pinned block -> [the new parameters into the weights ring's slot, D2H in stream order] -> wait for
+        # the loss (GIL released).  (Round 6: these were ~10 Python-level runtime calls around an 85 us train.)
+        ring = getattr(self.net, "_wring", None) if self.eager_snapshot else None
+        ticket = None
+        if ring is not None and getattr(ring, "async_commit", False) and getattr(ring, "pinned", False):
+            ticket = ring.publish_reserve(self.net, getattr(self.net, "_wring_ctr", None))
+        ing = self._ingest
+        a = self.net.impala_train_io(self._cfg, d["obs"][:n], batch_size, d["logit"][:n], d["action"][:n], d["done"][:n],
+                                     d["reward"][:n], lr_steps=lr_steps, use_graph=self.use_graph, wait_event=ing.last.done,
+                                     consumed_event=ing.consumed_event(), publish=None if ticket is None else (ticket[3], ticket[4]),
+                                     wait_loss=not self.async_loss)
         self._global_step += n_chunks
-        if self.eager_snapshot:
-            self.net.snapshot_weights_async()   # the D2H of the new weights runs under the loss read-back
-        # one pinned 16-byte read-back ([sum, chunks, error bits]); ASYNC_LOSS: the PREVIOUS train's (no wait for this one).
+        if ticket is not None:
+            ring.publish_enqueued(ticket)
+            self.net._wring_version = getattr(self.net, "_version", 0)
+        elif self.eager_snapshot:
+            self.net.snapshot_weights_async()   # (no committer ring: the D2H of the new weights is enqueued behind the train)
         # Data parallel: the sum is the GLOBAL one (the ranks' shares travelled in the tail of the exchanged gradient)
-        a = self.net.read_loss(acc, wait=not self.async_loss)
         return np.float32(float(a[0]) / max(float(a[1]), 1.0))
 
     def train(self, state, label):

@@ -540,11 +540,11 @@ class WeightsRing(object):
         import torch
         nbytes = int(net.params.numel()) * 4
         with self._wlock:
-            if self.async_commit:
-                return self._begin_staged_publish_locked(net, ctr_info, nbytes)
-            return self._begin_flat_publish_locked(net, ctr_info, nbytes)
+            if getattr(self, "_commit_error", None) is not None:
+                raise RuntimeError("WeightsRing: the committer thread failed") from self._commit_error
+            return self._begin_flat_publish_locked(net, ctr_info, nbytes, in_stream=self.async_commit)
 
-    def _begin_flat_publish_locked(self, net, ctr_info, nbytes):
+    def _begin_flat_publish_locked(self, net, ctr_info, nbytes, in_stream=False):
         import torch
         k, i, base = self._reserve_flat(net.spec, nbytes, ctr_info)
         st = getattr(self, "_d2h", None)
@@ -554,63 +554,62 @@ class WeightsRing(object):
         side, ready, dones = st
         done = dones[i]
         from xingtian_amd import lib as L
-        ready.record(L.current_stream(net.device))
-        side.wait_event(ready)
-        L.memcpy_async(self._pin_addr + self._payload_offset(i) + base, net.params.data_ptr(), nbytes, L.D2H, side)
-        done.record(side)
+        if in_stream:
+            # asynchronous commit: the D2H goes on the CURRENT stream, in order behind the update -- the next update cannot
+            # tear it, and nothing sits in a DMA queue blocked on a dependency (a D2H enqueued up front on a side stream held
+            # up the next message's H2D; a device-side snapshot + a D2H enqueued later by the committer thread serialised with
+            # the learner thread's next launch: both measured, round 6).  Nobody on the host waits for it.
+            cur = L.current_stream(net.device)
+            L.memcpy_async(self._pin_addr + self._payload_offset(i) + base, net.params.data_ptr(), nbytes, L.D2H, cur)
+            done.record(cur)
+        else:
+            ready.record(L.current_stream(net.device))
+            side.wait_event(ready)
+            L.memcpy_async(self._pin_addr + self._payload_offset(i) + base, net.params.data_ptr(), nbytes, L.D2H, side)
+            done.record(side)
         self._pending.append((k, i, base + nbytes, done))
         self._last_begun = k
         self._wlock.notify_all()
         return k
 
-    def _begin_staged_publish_locked(self, net, ctr_info, nbytes):
-        """asynchronous-commit form of ``begin_flat_publish``: the parameters are SNAPSHOT on the device (one D2D copy on the
-        compute stream, in order behind the update: the next update's optimiser cannot tear it) and the D2H is enqueued by
-        the committer thread only once that snapshot is complete -- a D2H enqueued up front sits in the DMA queue blocked on
-        its dependency and the NEXT message's H2D queues behind it (measured round 6: the prefetched loop no faster than
-        the blocking one)."""
+    def publish_reserve(self, net, ctr_info=None):
+        """asynchronous commit, split form (``xt_net_impala_train_io``): claim the next slot and write its header; -> ticket
+        (seq, slot, total bytes, HOST address of the slot's array section, raw handle of the slot's event, event).  The caller
+        enqueues the D2H of the parameter block to that address IN STREAM ORDER behind its update, records the event, then
+        calls ``publish_enqueued(ticket)``."""
         import torch
         from xingtian_amd import lib as L
-        if getattr(self, "_commit_error", None) is not None:
-            raise RuntimeError("WeightsRing: the committer thread failed") from self._commit_error
-        st = getattr(self, "_staged", None)
-        if st is None or st["snap"][0].numel() * 4 != nbytes:
-            st = self._staged = dict(snap=[torch.empty(nbytes // 4, dtype=torch.float32, device=net.device) for _ in range(2)],
-                                     ready=[torch.cuda.Event(), torch.cuda.Event()], busy=[False, False], turn=0,
-                                     side=torch.cuda.Stream(device=net.device), done=torch.cuda.Event())
-        b = st["turn"]
-        while st["busy"][b]:                 # (both snapshots still on their way out: the learner is ahead of the PCIe link)
-            self._wlock.wait(0.001)
-        st["turn"] = b ^ 1
-        k, i, base = self._reserve_flat(net.spec, nbytes, ctr_info)
-        cur = L.current_stream(net.device)
-        L.memcpy_async(st["snap"][b].data_ptr(), net.params.data_ptr(), nbytes, L.D2D, cur)
-        st["ready"][b].record(cur)
-        st["busy"][b] = True
-        self._pending.append((k, i, base + nbytes, None, b))
-        self._last_begun = k
-        self._wlock.notify_all()
+        nbytes = int(net.params.numel()) * 4
+        with self._wlock:
+            if getattr(self, "_commit_error", None) is not None:
+                raise RuntimeError("WeightsRing: the committer thread failed") from self._commit_error
+            k, i, base = self._reserve_flat(net.spec, nbytes, ctr_info)
+            st = getattr(self, "_d2h", None)
+            if st is None:
+                st = self._d2h = (torch.cuda.Stream(device=net.device), torch.cuda.Event(),
+                                  [torch.cuda.Event() for _ in range(self.slots)])
+            if not getattr(self, "_d2h_primed", False):
+                cur = L.current_stream(net.device)
+                for ev in st[2]:
+                    ev.record(cur)                   # (a torch event gets its handle at its first record)
+                self._d2h_primed = True
+            done = st[2][i]
+            return (k, i, base + nbytes, self._pin_addr + self._payload_offset(i) + base, done.cuda_event, done)
+
+    def publish_enqueued(self, ticket):
+        k, i, total, _addr, _raw, done = ticket[:6]
+        with self._wlock:
+            self._pending.append((k, i, total, done))
+            self._last_begun = k
+            self._wlock.notify_all()
         return k
 
     def commit_flat_publish(self):
         """Second half: wait for the OLDEST begun copy and make that publish visible to the readers.  Returns its
         sequence number."""
         with self._wlock:
-            item = self._pending[0]
-        k, i, total, done = item[:4]
-        if done is None:                     # staged form: the device-side snapshot is complete -> D2H now -> wait
-            from xingtian_amd import lib as L
-            st, b = self._staged, item[4]
-            st["ready"][b].synchronize()
-            nbytes = st["snap"][b].numel() * 4
-            L.memcpy_async(self._pin_addr + self._payload_offset(i) + (total - nbytes), st["snap"][b].data_ptr(), nbytes, L.D2H,
-                           st["side"])
-            st["done"].record(st["side"])
-            st["done"].synchronize()
-            with self._wlock:
-                st["busy"][b] = False
-        else:
-            done.synchronize()
+            k, i, total, done = self._pending[0]
+        done.synchronize()
         with self._wlock:
             if self._pending and self._pending[0][0] == k:
                 self._pending.pop(0)
@@ -622,8 +621,8 @@ class WeightsRing(object):
 
     def start_committer(self):
         """ASYNCHRONOUS commit (asynchronous algorithms): from now on a begun packed publish -- the D2H the update itself
-        enqueued into the ring slot (``HipActorCritic.attach_weights_ring`` + ``snapshot_weights_async``) -- is made visible
-        to the readers by a helper thread as soon as its copy has landed; ``publish_weights(ring)`` returns the sequence
+        enqueued into the ring slot IN STREAM ORDER (``HipActorCritic.attach_weights_ring`` + ``snapshot_weights_async`` /
+        ``xt_net_impala_train_io``) -- is made visible to the readers by a helper thread as soon as its copy has landed; ``publish_weights(ring)`` returns the sequence
         number it WILL carry without waiting.  The weights handed out are exactly those of the train that published them (no
         lag in content); only the learner thread does not sit through the D2H -- as the reference's learner hands the
         weights object to its send queue and goes on (xt/framework/learner.py:361-374; zeus/common/ipc/share_buffer.py).
@@ -729,8 +728,7 @@ class WeightsRing(object):
         # un-registered and the segment unlinked
         for pend in getattr(self, "_pending", None) or []:
             try:
-                if pend[3] is not None:
-                    pend[3].synchronize()
+                pend[3].synchronize()
             except Exception:       # noqa: BLE001 -- closing must not raise over a dead context
                 pass
         self._pending = []
