@@ -37,3 +37,15 @@ def test_preflight_passes_on_every_visible_gpu():
     assert res["world"] == torch.cuda.device_count()
     assert all(all(row) for row in res["peer_access"])
     assert res["checks"]["direct_exchange_200_value_checked"]["all_reduces"] == 200
+
+
+def test_preflight_script_logic_runs_with_two_ranks_sharing_the_one_gpu():
+    """`--one-gpu-selftest`: the same worker code (200 value-checked direct all-reduces over hipIpc-mapped blocks, strict and
+    weak updates through the fused direct exchange inside a replayed hipGraph against the step-wise path) with two ranks on
+    device 0 over gloo; the RCCL checks are skipped (RCCL refuses two ranks on one device).  Keeps the script itself honest
+    until it meets a multi-GPU node."""
+    rc, res = _run(["--one-gpu-selftest", "--gpus", "2"])
+    assert rc == 0 and res["ok"], json.dumps(res)[:3000]
+    assert res["checks"]["direct_exchange_200_value_checked"]["all_reduces"] == 200
+    for k in ("update_strict_direct_in_graph", "update_weak_direct_in_graph"):
+        assert res["checks"][k]["ok"] and res["checks"][k]["rel_err_vs_stepwise"] < 5e-3

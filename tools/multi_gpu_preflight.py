@@ -45,16 +45,25 @@ def launcher(args):
     import torch
     n_dev = torch.cuda.device_count()
     world = args.gpus or n_dev
-    if n_dev < 2 or world < 2:
+    if args.one_gpu_selftest:
+        # the SCRIPT's own logic exercised on a one-GPU box: `--gpus N` ranks share device 0, torch.distributed over gloo, the
+        # RCCL checks are skipped (RCCL refuses several ranks on one device) -- so that the first run on a real multi-GPU node
+        # does not die of a typo in this file
+        world = max(2, args.gpus or 2)
+        peer = [[True] * world for _ in range(world)]
+    elif n_dev < 2 or world < 2:
         print(json.dumps({"ok": False, "skipped": "needs >= 2 visible GPUs, found {}".format(n_dev)}))
         return 2
-    if world > n_dev:
+    elif world > n_dev:
         print(json.dumps({"ok": False, "error": "--gpus {} > {} visible devices".format(world, n_dev)}))
         return 1
-    peer = [[bool(i == j or torch.cuda.can_device_access_peer(i, j)) for j in range(world)] for i in range(world)]
+    else:
+        peer = [[bool(i == j or torch.cuda.can_device_access_peer(i, j)) for j in range(world)] for i in range(world)]
     out = os.path.join(args.outdir, "preflight_{}.json".format(os.getpid()))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), "--worker", "--out", out]
+    if args.one_gpu_selftest:
+        cmd.append("--one-gpu-selftest")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
     t0 = time.time()
     try:
@@ -80,9 +89,12 @@ def worker(args):
     import torch
     import torch.distributed as dist
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    one_gpu = bool(args.one_gpu_selftest)
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", rank=rank, world_size=world)
+    dist.init_process_group("gloo" if one_gpu else "nccl", rank=rank, world_size=world)
     from xingtian_amd import lib as L
     from xingtian_amd.model import netspec
     from xingtian_amd.model.hip_net import HipActorCritic
@@ -116,7 +128,8 @@ def worker(args):
         assert torch.equal(x, y), "raw ncclAllReduce disagrees with torch.distributed"
         return {"ranks": r.count()}
 
-    record("rccl_raw_communicator", rccl_check)
+    if not one_gpu:
+        record("rccl_raw_communicator", rccl_check)
 
     # ---- 3. the direct exchange across devices
     counts = [847496 + 32, 1005112 + 32, 4099, 7]
@@ -124,8 +137,8 @@ def worker(args):
     def direct_check():
         c = state["direct"] = DirectComm(rank, world, max(counts), timeout_ms=5000).connect()
         info = c.info()
-        assert info["ranks_on_device"] == 1, "xt_direct_info: {} ranks on this device (one process per GPU expected)".format(
-            info["ranks_on_device"])
+        assert info["ranks_on_device"] == (world if one_gpu else 1), "xt_direct_info: {} ranks on this device ({} expected)".format(
+            info["ranks_on_device"], world if one_gpu else 1)
         n_done = 0
         for fused in (True, False):
             c.set_fused(fused)
@@ -205,7 +218,7 @@ def worker(args):
         return body
 
     for mode in ("strict", "weak"):
-        for exchange in ("direct", "rccl"):
+        for exchange in (("direct",) if one_gpu else ("direct", "rccl")):
             record("update_{}_{}_in_graph".format(mode, exchange), update_check(mode, exchange))
 
     dist.barrier()
@@ -223,6 +236,8 @@ def main():
     ap.add_argument("--timeout", type=int, default=240)
     ap.add_argument("--outdir", default="/tmp")
     ap.add_argument("--worker", action="store_true")
+    ap.add_argument("--one-gpu-selftest", action="store_true",
+                    help="exercise this script on a ONE-GPU box: the ranks share device 0 over gloo, RCCL checks skipped")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     sys.exit(worker(args) if args.worker else launcher(args))
