@@ -112,6 +112,11 @@ class RolloutIngest(object):
         self.sets = [None, None]
         self.cur = 0
         self.n = 0
+        # True: the label block is NOT copied to HBM -- the kernels read the page-locked staging block directly over PCIe
+        # (``mapped_labels``).  For per-message trains (IMPALA: a few KB of labels read once, by the v-trace kernel) the label
+        # H2D was a runtime blit kernel that queued behind the weights publish and held the train's first kernel up by ~30 us
+        # (rocprofv3 trace of the loop, round 6)
+        self.zero_copy_labels = False
         self.generation = 0             # rollouts handed to the learner so far (finish() calls)
         self.on_finish = None           # callable: a transport.Prefetcher staging one train ahead is woken here
         self._lib = L.load()            # (the staging-copy variant for this host is picked on the first host copy)
@@ -256,6 +261,10 @@ class RolloutIngest(object):
         s = self.sets[self.cur]
         if s is None or self.n == 0 or getattr(s, "shipped_n", -1) == self.n:
             return
+        if self.zero_copy_labels and not self.raw_traj:
+            self._join_copy_streams(wait=False)
+            s.shipped_n = self.n
+            return
         self._join_copy_streams(wait=False)
         # the labels of the whole rollout: ONE copy (a few 10 KB)
         L.memcpy_async(s.lab_dev.data_ptr(), s.lab_host.data_ptr(), s.lab_host.numel(), L.H2D, self.copy_stream)
@@ -309,6 +318,19 @@ class RolloutIngest(object):
             self.copy_stream.wait_event(self._join_ev[i])
         if wait:
             self.copy_stream.synchronize()
+
+    def mapped_labels(self, n):
+        """device-visible addresses of the LAST finished set's label arrays inside its page-locked staging block
+        (``zero_copy_labels``): name -> int, or None when the block is not mapped into the device's address space"""
+        s = self.last
+        base = getattr(s, "_lab_mapped", None)
+        if base is None:
+            got = L.host_device_ptr(s.lab_host.data_ptr())
+            base = s._lab_mapped = got if got is not None else 0
+        if not base:
+            return None
+        h0 = s.lab_host.data_ptr()
+        return {name: base + (s.host[name].data_ptr() - h0) for name, _dt, _w in self.fields}
 
     def consumed_event(self):
         """the event that marks the last finished set as consumed (raw-handle users record it themselves: the event exists,

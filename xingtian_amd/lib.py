@@ -207,9 +207,11 @@ def check(rc, what=""):
 
 
 def ptr(t):
-    """Device pointer of a torch tensor (or None)."""
+    """Device pointer of a torch tensor (or None); an int is taken as a raw device-visible address."""
     if t is None:
         return None
+    if isinstance(t, int):
+        return c_void_p(t)
     return c_void_p(t.data_ptr())
 
 
@@ -273,6 +275,22 @@ def memcpy_async(dst_ptr, src_ptr, nbytes, kind, stream):
     rc = _hip.hipMemcpyAsync(c_void_p(int(dst_ptr)), c_void_p(int(src_ptr)), int(nbytes), kind, c_void_p(h))
     if rc != 0:
         raise RuntimeError("hipMemcpyAsync failed with hipError {}".format(rc))
+
+
+def host_device_ptr(host_addr):
+    """device-side address of a page-locked host block (hipHostGetDevicePointer): kernels can then read / write it directly
+    over PCIe -- a few KB of labels per train cost one DMA set-up less that way.  -> int, or None when it is not mapped"""
+    global _hip
+    if _hip is None:
+        memcpy_async  # noqa: B018  (loads the runtime lazily)
+        _hip = ctypes.CDLL("libamdhip64.so")
+        _hip.hipMemcpyAsync.argtypes = [c_void_p, c_void_p, ctypes.c_size_t, c_int32, c_void_p]
+        _hip.hipMemcpyAsync.restype = c_int32
+    out = c_void_p()
+    _hip.hipHostGetDevicePointer.argtypes = [POINTER(c_void_p), c_void_p, ctypes.c_uint]
+    _hip.hipHostGetDevicePointer.restype = c_int32
+    rc = _hip.hipHostGetDevicePointer(ctypes.byref(out), c_void_p(int(host_addr)), 0)
+    return int(out.value) if rc == 0 and out.value else None
 
 
 def built_sources_sha():

@@ -58,6 +58,8 @@ class ImpalaCnnOpt(XTModel):
         # one.  Only the reported number lags (xt/framework/learner.py:348-351 logs it); weights handed out afterwards are
         # always the ones this train produced.  Pays when weights do not go out after every train (train_per_checkpoint > 1).
         self.async_loss = bool(model_config.get("ASYNC_LOSS", False))
+        # (not with ASYNC_LOSS: the staging block of train k may then be rewritten for train k + 2 while train k still runs)
+        self.zero_copy_labels = bool(model_config.get("ZERO_COPY_LABELS", True)) and not self.async_loss
         self._ingest = None
         self._dp = None
         self._lr_host = self._lr_dev = None
@@ -100,6 +102,8 @@ class ImpalaCnnOpt(XTModel):
                                          obs_u8=bool(self.net.spec.input_xform[0]),
                                          fields=impala_fields(self.action_dim),
                                          pad_channels=(cpad, self.net.obs_fill_byte()) if cpad else None)
+            # the few KB of labels of a train are read by the v-trace kernel straight out of the page-locked staging block
+            self._ingest.zero_copy_labels = bool(self.zero_copy_labels)
         return self._ingest
 
     def ingest_message(self, states, bp_logic_outs, actions, dones, rewards, pinned=False, slot_guard=None):
@@ -159,8 +163,11 @@ class ImpalaCnnOpt(XTModel):
         if ring is not None and getattr(ring, "async_commit", False) and getattr(ring, "pinned", False):
             ticket = ring.publish_reserve(self.net, getattr(self.net, "_wring_ctr", None))
         ing = self._ingest
-        a = self.net.impala_train_io(self._cfg, d["obs"][:n], batch_size, d["logit"][:n], d["action"][:n], d["done"][:n],
-                                     d["reward"][:n], lr_steps=lr_steps, use_graph=self.use_graph, wait_event=ing.last.done,
+        lab = ing.mapped_labels(n) if ing.zero_copy_labels else None
+        if lab is None:
+            lab = {k: d[k][:n] for k in ("logit", "action", "done", "reward")}
+        a = self.net.impala_train_io(self._cfg, d["obs"][:n], batch_size, lab["logit"], lab["action"], lab["done"],
+                                     lab["reward"], lr_steps=lr_steps, use_graph=self.use_graph, wait_event=ing.last.done,
                                      consumed_event=ing.consumed_event(), publish=None if ticket is None else (ticket[3], ticket[4]),
                                      wait_loss=not self.async_loss)
         self._global_step += n_chunks
