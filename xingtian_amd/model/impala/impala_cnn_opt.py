@@ -103,7 +103,10 @@ class ImpalaCnnOpt(XTModel):
                                          fields=impala_fields(self.action_dim),
                                          pad_channels=(cpad, self.net.obs_fill_byte()) if cpad else None)
             # the few KB of labels of a train are read by the v-trace kernel straight out of the page-locked staging block
-            self._ingest.zero_copy_labels = bool(self.zero_copy_labels)
+            # (only if page-locked host memory is mapped into the device's address space here: probed once)
+            from xingtian_amd import lib as L
+            probe = torch.empty(64, dtype=torch.uint8, pin_memory=True)
+            self._ingest.zero_copy_labels = bool(self.zero_copy_labels) and L.host_device_ptr(probe.data_ptr()) is not None
         return self._ingest
 
     def ingest_message(self, states, bp_logic_outs, actions, dones, rewards, pinned=False, slot_guard=None):
@@ -165,6 +168,9 @@ class ImpalaCnnOpt(XTModel):
         ing = self._ingest
         lab = ing.mapped_labels(n) if ing.zero_copy_labels else None
         if lab is None:
+            if ing.zero_copy_labels:
+                raise RuntimeError("ImpalaCnnOpt: the label staging block is not mapped into the device's address space "
+                                   "(set model_config ZERO_COPY_LABELS: false)")
             lab = {k: d[k][:n] for k in ("logit", "action", "done", "reward")}
         a = self.net.impala_train_io(self._cfg, d["obs"][:n], batch_size, lab["logit"], lab["action"], lab["done"],
                                      lab["reward"], lr_steps=lr_steps, use_graph=self.use_graph, wait_event=ing.last.done,
