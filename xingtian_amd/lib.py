@@ -262,17 +262,24 @@ _hip = None
 H2D, D2H, D2D = 1, 2, 3        # hipMemcpyKind
 
 
-def memcpy_async(dst_ptr, src_ptr, nbytes, kind, stream):
-    """hipMemcpyAsync on an explicit stream (a ``torch.cuda.Stream`` or a raw handle) straight through the HIP runtime
-    PyTorch already loaded: the per-message copies of the ingest / publish paths without ``with torch.cuda.stream(...)``
-    (each enter / exit costs ~10 us of Python and runtime calls: a third of the host time of a 128-frame IMPALA train)."""
+def _hiplib():
+    """the HIP runtime PyTorch already loaded, with the few prototypes the host plumbing calls directly"""
     global _hip
     if _hip is None:
         _hip = ctypes.CDLL("libamdhip64.so")
         _hip.hipMemcpyAsync.argtypes = [c_void_p, c_void_p, ctypes.c_size_t, c_int32, c_void_p]
         _hip.hipMemcpyAsync.restype = c_int32
+        _hip.hipHostGetDevicePointer.argtypes = [POINTER(c_void_p), c_void_p, ctypes.c_uint]
+        _hip.hipHostGetDevicePointer.restype = c_int32
+    return _hip
+
+
+def memcpy_async(dst_ptr, src_ptr, nbytes, kind, stream):
+    """hipMemcpyAsync on an explicit stream (a ``torch.cuda.Stream`` or a raw handle) straight through the HIP runtime
+    PyTorch already loaded: the per-message copies of the ingest / publish paths without ``with torch.cuda.stream(...)``
+    (each enter / exit costs ~10 us of Python and runtime calls: a third of the host time of a 128-frame IMPALA train)."""
     h = stream.cuda_stream if hasattr(stream, "cuda_stream") else stream
-    rc = _hip.hipMemcpyAsync(c_void_p(int(dst_ptr)), c_void_p(int(src_ptr)), int(nbytes), kind, c_void_p(h))
+    rc = _hiplib().hipMemcpyAsync(c_void_p(int(dst_ptr)), c_void_p(int(src_ptr)), int(nbytes), kind, c_void_p(h))
     if rc != 0:
         raise RuntimeError("hipMemcpyAsync failed with hipError {}".format(rc))
 
@@ -280,16 +287,8 @@ def memcpy_async(dst_ptr, src_ptr, nbytes, kind, stream):
 def host_device_ptr(host_addr):
     """device-side address of a page-locked host block (hipHostGetDevicePointer): kernels can then read / write it directly
     over PCIe -- a few KB of labels per train cost one DMA set-up less that way.  -> int, or None when it is not mapped"""
-    global _hip
-    if _hip is None:
-        memcpy_async  # noqa: B018  (loads the runtime lazily)
-        _hip = ctypes.CDLL("libamdhip64.so")
-        _hip.hipMemcpyAsync.argtypes = [c_void_p, c_void_p, ctypes.c_size_t, c_int32, c_void_p]
-        _hip.hipMemcpyAsync.restype = c_int32
     out = c_void_p()
-    _hip.hipHostGetDevicePointer.argtypes = [POINTER(c_void_p), c_void_p, ctypes.c_uint]
-    _hip.hipHostGetDevicePointer.restype = c_int32
-    rc = _hip.hipHostGetDevicePointer(ctypes.byref(out), c_void_p(int(host_addr)), 0)
+    rc = _hiplib().hipHostGetDevicePointer(ctypes.byref(out), c_void_p(int(host_addr)), 0)
     return int(out.value) if rc == 0 and out.value else None
 
 
