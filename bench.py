@@ -1182,20 +1182,30 @@ def model_scaling(spec, dev, updates=6):
     link_gbps, hop_us = 153.0, 2.0
     s_bytes = spec.n_flat * 4
     rng = np.random.default_rng(5)
-    step_us, step_us_dp = {}, {}
+    # three forms of the SGD step, each the replayed hipGraph of a whole update on THIS GPU:
+    #   plain  what N = 1 runs
+    #   hook   the data-parallel form behind a generic exchange hook (the RCCL path): row / loss tail in the gradient
+    #          buffer, gradient reduction, [hook: nobody to exchange with], squared norm, clip + Adam
+    #   fused  the direct exchange FUSED into the step, as a one-rank group: every kernel of the real chain runs against
+    #          the rank's own exchange block -- the gradient reduction scatters into the inbox (uncached), one reduce
+    #          launch, Adam reads the result buffer.  One rank moves the same 4 x S bytes of uncached traffic through
+    #          its device as each of N ranks does (S/N to each of N owners, N inbox slices in, N result slices out, the
+    #          whole result read back), so this form already CONTAINS the kernel-side cost of the exchange; only the link
+    #          phases are missing.  (Rounds 4-5 added a separately measured three-launch chain on top of the hook form;
+    #          with the fused kernels that would count the exchange kernels twice.)
+    step_us, step_us_hook, step_us_fused = {}, {}, {}
     from xingtian_amd.parallel import DirectComm
-    for rows, dp_form in [(r, f) for r in (320, 160, 80, 40) for f in (False, True)]:
+    for rows, form in [(r, f) for r in (320, 160, 80, 40) for f in ("plain", "hook", "fused")]:
         n = ENV_NUM * T_LEN * rows // 320           # the same 52 SGD steps per update at every shard size
         net = HipActorCritic(spec, max_batch=rows, device=str(dev), seed=0)
         one = None
-        if dp_form:
-            # the data-parallel FORM of the step with nobody to exchange with
-            # (round 6) the FUSED direct exchange as a one-rank group: every kernel of the real chain runs against the rank's
-            # own exchange block -- the gradient reduction scatters into the inbox (uncached), one reduce launch, Adam waits
-            # for the done flag and reads the result buffer: 13 launches vs 11, what a rank pays besides the links
+        if form != "plain":
             one = DirectComm(0, 1, int(net.grads_xchg.numel()))
             net.set_dp(0, 1, 1.0)
-            one.attach_fused(net)
+            if form == "fused":
+                one.attach_fused(net)
+            else:
+                one.attach(net)
         d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         obs = d(rng.integers(0, 256, (n,) + STATE_DIM, dtype=np.uint8))
         act, logp = d(rng.integers(0, A_DIM, n).astype(np.int32)), d((-np.abs(rng.standard_normal(n)) - 0.5).astype(np.float32))
@@ -1210,71 +1220,54 @@ def model_scaling(spec, dev, updates=6):
             net.ppo_train(cfg, obs, perm, act, logp, adv, oldv, tgt, use_graph=True)
         torch.cuda.synchronize()
         nsteps = CFG["NUM_SGD_ITER"] * ((n + rows - 1) // rows)
-        (step_us_dp if dp_form else step_us)[rows] = 1e6 * (time.perf_counter() - t0) / (updates * nsteps)
+        {"plain": step_us, "hook": step_us_hook, "fused": step_us_fused}[form][rows] = \
+            1e6 * (time.perf_counter() - t0) / (updates * nsteps)
         if one is not None:
             assert one.status()["error_bits"] == 0
-            one.detach(net)
+            if form == "fused":
+                one.detach(net)
+            else:
+                net.lib.xt_net_set_grad_exchange_ex(net.handle, None, None, 0)
             net.set_dp(0, 0)
             one.destroy()
         del net
         torch.cuda.empty_cache()
 
-    # the kernel-side cost of xt_allreduce_direct, MEASURED on this one device: two in-process ranks (phase-ordered launches on
-    # two streams) move 2 x (the 13.6 MB of uncached exchange traffic one rank generates per all-reduce) through the
-    # three-launch chain; half of that run is what ONE rank's chain costs when the GPU is its own.  The links come on top.
-    chain_us = None
-    try:
-        from xingtian_amd.parallel import DirectComm
-        ranks = DirectComm.local_group(2, spec.n_flat, timeout_ms=5000)
-        sts = [torch.cuda.Stream(device=dev) for _ in range(2)]
-        bufs = [torch.ones(spec.n_flat, dtype=torch.float32, device=dev) for _ in range(2)]
-        torch.cuda.synchronize()
-        for _ in range(5):
-            DirectComm.all_reduce_group_(ranks, bufs, sts)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(50):
-            DirectComm.all_reduce_group_(ranks, bufs, sts)
-        torch.cuda.synchronize()
-        chain_us = 0.5 * 1e6 * (time.perf_counter() - t0) / 50
-        assert ranks[0].status()["error_bits"] == 0
-        for c in ranks:
-            c.destroy()
-    except Exception as exc:      # noqa: BLE001
-        log("direct all-reduce chain not measured:", repr(exc)[:200])
-
-    def allreduce_us(nr, kind):
+    def links_us(nr, kind):
         if nr == 1:
             return 0.0
         if kind == "ring_one_link":
             return 2.0 * (nr - 1) / nr * s_bytes / (link_gbps * 1e3) + 2 * (nr - 1) * hop_us
-        if kind == "direct_2phase_measured_chain":
-            # what exists (csrc/xt_xgmi.hip): the measured one-device chain + the two link phases it cannot have seen
-            return chain_us + 2.0 * (nr - 1) / nr * (s_bytes / nr / (link_gbps * 1e3)) + 2.0 * hop_us
-        return 2.0 * (s_bytes / nr / (link_gbps * 1e3) + hop_us)          # direct_2phase, link-limited ideal
+        # direct_2phase: scatter and gather each move (N-1)/N of a slice set over N-1 links at once + one hop each
+        return 2.0 * (s_bytes / nr / (link_gbps * 1e3) + hop_us)
 
     frames_per_update = FRAME_SKIP * ENV_NUM * T_LEN
     sgd_steps = CFG["NUM_SGD_ITER"] * ((ENV_NUM * T_LEN + CFG["BATCH_SIZE"] - 1) // CFG["BATCH_SIZE"])
     base = frames_per_update / (sgd_steps * step_us[320] * 1e-6)
     out = {"MODELLED": "no multi-GPU box was available to the builder: measured 1-GPU time of the data-parallel FORM of the step at the "
-                       "shard size + a modelled, non-overlapped all-reduce; NOT a measurement of N GPUs",
+                       "shard size + modelled, non-overlapped link phases; NOT a measurement of N GPUs",
            "assumptions": {"allreduce_bytes": s_bytes, "xgmi_link_GBps": link_gbps, "hop_latency_us": hop_us,
-                           "direct_chain_us_measured_one_device": None if chain_us is None else round(chain_us, 1),
+                           "ring_one_link": "hook-form step (no exchange kernels) + 2 (N-1)/N S / link + 2 (N-1) hops; RCCL's own "
+                                            "kernel time is not priced",
+                           "direct_2phase": "fused-form step (the exchange kernels run as a one-rank group against uncached "
+                                            "memory: the kernel-side cost is IN the measured step) + 2 (S/N / link + one hop)",
                            "overlap": "none (the two-bucket overlap variants hide the conv backward's ~55 us at 320 rows; not credited)"},
            "measured_sgd_step_us_by_rows": {str(k): round(v, 2) for k, v in step_us.items()},
-           "measured_dp_form_step_us_by_rows": {str(k): round(v, 2) for k, v in step_us_dp.items()}, "strict": {}, "weak": {}}
+           "measured_hook_form_step_us_by_rows": {str(k): round(v, 2) for k, v in step_us_hook.items()},
+           "measured_fused_form_step_us_by_rows": {str(k): round(v, 2) for k, v in step_us_fused.items()},
+           "strict": {}, "weak": {}}
     for nr in (1, 2, 4, 8):
         rows = CFG["BATCH_SIZE"] // nr
-        for kind in ("ring_one_link", "direct_2phase") + (("direct_2phase_measured_chain",) if chain_us else ()):
-            ar = allreduce_us(nr, kind)
+        for kind, form in (("ring_one_link", step_us_hook), ("direct_2phase", step_us_fused)):
+            ar = links_us(nr, kind)
             # N > 1 runs the data-parallel FORM of the step (measured above), N = 1 the plain one
-            t_strict = (step_us_dp[rows] if nr > 1 else step_us[rows]) + ar
-            t_weak = (step_us_dp[320] if nr > 1 else step_us[320]) + ar
+            t_strict = (form[rows] if nr > 1 else step_us[rows]) + ar
+            t_weak = (form[320] if nr > 1 else step_us[320]) + ar
             v_strict = frames_per_update / (sgd_steps * t_strict * 1e-6)
             v_weak = nr * frames_per_update / (sgd_steps * t_weak * 1e-6)
-            out["strict"].setdefault(str(nr), {})[kind] = {"value": v_strict, "step_us": round(t_strict, 1), "allreduce_us": round(ar, 1),
+            out["strict"].setdefault(str(nr), {})[kind] = {"value": v_strict, "step_us": round(t_strict, 1), "links_us": round(ar, 1),
                                                            "speedup_vs_1gpu": round(v_strict / base, 2)}
-            out["weak"].setdefault(str(nr), {})[kind] = {"value": v_weak, "step_us": round(t_weak, 1), "allreduce_us": round(ar, 1),
+            out["weak"].setdefault(str(nr), {})[kind] = {"value": v_weak, "step_us": round(t_weak, 1), "links_us": round(ar, 1),
                                                          "speedup_vs_1gpu": round(v_weak / base, 2)}
     return out
 
