@@ -1009,7 +1009,7 @@ def bench_env_num_256(spec, dev, updates=3):
 
 
 def impala_ring_loop(w, fm, msgs_per_train, tpc, n_prod, seconds, prefetch=True, async_commit=True, pinned=True, slots=4,
-                     min_trains=20, gate=True):
+                     min_trains=20, gate=True, model_config=None):
     """The IMPALAOpt plugin pair fed as a learner is fed (xt/framework/learner.py:298-380): `n_prod` producer PROCESSES push
     pre-encoded rollout messages of `fm` frames into their own shared-memory ring (transport.RingSet); the learner loop is
     the reference's -- recv + prepare_data x msgs_per_train -> train() -> every tpc-th train the weights go out.
@@ -1046,8 +1046,8 @@ def impala_ring_loop(w, fm, msgs_per_train, tpc, n_prod, seconds, prefetch=True,
         p_.start()
     model_info = {"actor": {"model_name": "ImpalaCnnOpt", "state_dim": [w["dim"], w["dim"], 4], "input_dtype": "uint8",
                             "state_mean": w["mean"], "state_std": w["std"], "action_dim": w["a_dim"],
-                            "model_config": {"LR": w["lr"], "sample_batch_step": w["t_len"], "grad_norm_clip": 40.0,
-                                             "SEED": 0}}}
+                            "model_config": dict({"LR": w["lr"], "sample_batch_step": w["t_len"], "grad_norm_clip": 40.0,
+                                                  "SEED": 0}, **(model_config or {}))}}
     alg = alg_builder("IMPALAOpt", model_info, {"instance_num": max(n_prod, 1), "agent_num": 1,
                                                "prepare_times_per_train": msgs_per_train, "train_per_checkpoint": tpc,
                                                "BATCH_SIZE": max(fm * msgs_per_train, 512) if w["dim"] == 84 else fm * msgs_per_train})

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define XT_ABI_VERSION 11
+#define XT_ABI_VERSION 12
 
 #define XT_ACT_NONE 0
 #define XT_ACT_RELU 1
@@ -594,6 +594,21 @@ int xt_net_impala_train(xt_net* net, const xt_impala_cfg* cfg, const void* obs, 
  *                   SLOWER -- the D2H into registered host memory is a blit KERNEL that competes with the train's kernels:
  *                   0.29 vs 0.27 ms per 128-frame train --, and the same D2H enqueued later by a helper thread serialises with
  *                   the learner thread's next launch.)
+ *   tail_in_graph   (ABI >= 12; honoured with wait_loss != 0 and loss_host set; wait_loss == 2: do not wait, see xt_net_io_wait)
+ *                   the loss read-back and the parameter copy become the last two KERNELS OF THE TRAIN ITSELF -- inside the
+ *                   replayed hipGraph, whose kernel arguments are fixed: the learner thread writes {destination, sequence
+ *                   number} into a 64-byte page-locked mailbox the library owns; the first tail kernel reads the mailbox
+ *                   over the bus, writes the loss sums + the sequence number back into it (and the sums to loss_acc) and hands
+ *                   the destination to the copy kernel through device memory (so the host may rewrite the mailbox as soon as
+ *                   it has seen the loss).  The chunks of such a train accumulate into 4 floats of the workspace that the loss
+ *                   kernel re-arms: the graph holds no memset node.  The call returns when the sequence number has landed (a
+ *                   bounded poll of the page-locked word, stream health checked every ~0.3 ms) and has copied the 4 floats to
+ *                   loss_host.  consumed_event / publish_event are recorded behind the graph; loss_event is not used.  What
+ *                   it removes (rocprofv3 traces of the loop, round 6): the 19-27 us between a replayed graph and the next
+ *                   launch on the stream (twice), the wake-up of hipEventSynchronize, and -- because the learner thread learns
+ *                   of the loss while the 73 us parameter copy is still running -- the host's share of the next train's
+ *                   launch.  (Measured and rejected, again: the parameter copy from a device-side snapshot on a low-priority
+ *                   side stream under the next train -- the next graph still starts only after that kernel, DESIGN.md s. 4.)
  * Events are hipEvent_t handles (e.g. torch.cuda.Event.cuda_event). */
 typedef struct xt_train_io {
   void* wait_event;
@@ -603,10 +618,22 @@ typedef struct xt_train_io {
   float* publish_dst;
   void* publish_event;
   int32_t wait_loss;
+  int32_t tail_in_graph;
 } xt_train_io;
 int xt_net_impala_train_io(xt_net* net, const xt_impala_cfg* cfg, const void* obs, int32_t n, int32_t batch_size,
                            const float* bp_logits, const int32_t* action, const uint8_t* done, const float* reward,
                            const float* lr_steps, float* loss_acc, int32_t use_graph, const xt_train_io* io, void* stream);
+/* Second half of a train enqueued with io->tail_in_graph and io->wait_loss == 2 (ABI >= 12): xt_net_impala_train_io returned
+ * right behind the launch -- the caller does whatever of its own book-keeping does not depend on the loss while the device
+ * trains -- and this call waits (bounded poll of the mailbox, as above) for the loss of the MOST RECENT such train and copies
+ * loss_acc's 4 floats to loss_host4 (any host memory). */
+int xt_net_io_wait(xt_net* net, float* loss_host4, void* stream);
+
+/* diagnostic (ABI >= 12): host time (us, accumulated over *calls_out calls with a non-NULL io) of xt_net_impala_train_io's
+ * phases -- [0] before the launch (wait for the copies, mailbox), [1] the launch (hipGraphLaunch, or the eager enqueue), [2] the
+ * runtime calls behind it (event records, the separate copies when tail_in_graph is off), [3] the wait for the loss.
+ * reset != 0 clears the accumulators. */
+int xt_net_io_times(xt_net* net, double* us_out4, int64_t* calls_out, int32_t reset);
 
 /* clip + Adam on the net's flat gradient (second half of a data-parallel step) */
 int xt_net_apply(xt_net* net, float lr, float beta1, float beta2, float eps, float clip_norm,

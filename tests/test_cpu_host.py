@@ -28,7 +28,7 @@ def test_cabi_library_loads_and_exports_every_header_symbol():
     for name in sorted(declared):
         assert hasattr(handle, name), "missing C-ABI symbol " + name
         assert name in lib.SIGNATURES, "no ctypes prototype for " + name
-    assert handle.xt_abi_version() == lib.ABI_VERSION == 11
+    assert handle.xt_abi_version() == lib.ABI_VERSION == 12
     assert handle.xt_build_arch() == b"gfx950"
     # the binary carries the digest of the sources it was compiled from: a stale prebuilt .so next to newer kernel
     # sources is caught here (and profile artefacts are tagged with THIS digest, not with the tree's)

@@ -19,11 +19,12 @@ pytestmark = pytest.mark.gpu
 T_LEN, ENVS, A_DIM, DIM, MSGS_PER_TRAIN, TRAINS = 10, 2, 6, 42, 2, 9
 
 
-def _alg(tpc):
+def _alg(tpc, tail=True):
     from xingtian_amd.algorithm import alg_builder
     mi = {"actor": {"model_name": "ImpalaCnnOpt", "state_dim": [DIM, DIM, 4], "input_dtype": "uint8", "state_mean": 128.0,
                     "state_std": 128.0, "action_dim": A_DIM, "type": "learner",
-                    "model_config": {"LR": 1e-3, "sample_batch_step": T_LEN, "grad_norm_clip": 40.0, "SEED": 4}}}
+                    "model_config": {"LR": 1e-3, "sample_batch_step": T_LEN, "grad_norm_clip": 40.0, "SEED": 4,
+                                     "IO_TAIL_IN_GRAPH": tail}}}
     return alg_builder("IMPALAOpt", mi, {"instance_num": 4, "agent_num": 1, "prepare_times_per_train": MSGS_PER_TRAIN,
                                         "train_per_checkpoint": tpc, "BATCH_SIZE": ENVS * T_LEN * MSGS_PER_TRAIN})
 
@@ -36,9 +37,9 @@ def _msg(k):
             "done": list(rng.random(n) < 0.1), "reward": list(rng.choice([-1.0, 0.0, 1.0], n))}
 
 
-def _run(prefetch, tpc, pinned):
+def _run(prefetch, tpc, pinned, tail=True):
     from xingtian_amd import transport
-    alg = _alg(tpc)
+    alg = _alg(tpc, tail)
     ring = transport.ShmRing(slots=4, slot_bytes=1 << 20)
     wring = transport.WeightsRing(slot_bytes=8 << 20, slots=4)
     reader = transport.WeightsRing(name=wring.name, create=False, slot_bytes=8 << 20, slots=4)
@@ -83,8 +84,10 @@ def _run(prefetch, tpc, pinned):
 @pytest.mark.parametrize("tpc", [1, 3])
 @pytest.mark.parametrize("pinned", [True, False])
 def test_prefetch_and_asynchronous_commit_train_and_publish_exactly_what_the_blocking_loop_does(tpc, pinned):
-    ref = _run(False, tpc, pinned)
-    got = _run(True, tpc, pinned)
+    # the blocking loop with the loss read-back and the weights copy as separate launches behind the train (events), the
+    # asynchronous path with both as the train's own last kernels inside its replayed hipGraph (xt_train_io.tail_in_graph)
+    ref = _run(False, tpc, pinned, tail=False)
+    got = _run(True, tpc, pinned, tail=True)
     assert ref[0] == got[0], (ref[0], got[0])                       # every reported loss, bit for bit
     assert np.array_equal(ref[1], got[1])                           # final parameters
     assert ref[3] == got[3] and got[4] == len(got[3]) == (TRAINS + tpc - 1) // tpc       # publish sequence numbers, all visible
@@ -97,3 +100,68 @@ def test_prefetch_and_asynchronous_commit_train_and_publish_exactly_what_the_blo
     assert seq_r == seq
     for name in w:
         assert np.array_equal(w[name], w_r[name]), name
+
+
+@pytest.mark.parametrize("prefetch", [True, False])
+def test_the_in_graph_tail_reports_and_publishes_what_the_separate_launches_do(prefetch):
+    """xt_train_io.tail_in_graph on / off, everything else equal (train_per_checkpoint 3: trains WITH and WITHOUT a publish
+    alternate through the same replayed graphs -- the destination travels through the mailbox)"""
+    a = _run(prefetch, 3, True, tail=False)
+    b = _run(prefetch, 3, True, tail=True)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[3] == b[3] and a[4] == b[4]
+    assert a[5][0] == b[5][0]
+    for name in a[5][2]:
+        assert np.array_equal(a[5][2][name], b[5][2][name]), name
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("defer", [False, True])
+def test_train_io_tail_in_graph_through_the_c_abi(use_graph, defer):
+    """xt_net_impala_train_io with tail_in_graph against the same trains with the separate launches (loss copy + event,
+    parameter copy + event): 6 trains on two alternating input sets, a publish on every second one (the destination travels
+    through the mailbox: the replayed graphs are the same with and without it); every loss block, the device-side loss_acc,
+    every published parameter block and the final parameters bit for bit; ``defer``: the split form (xt_net_io_wait)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dp_worker
+    from xingtian_amd.model.hip_net import HipActorCritic
+    spec, data, tlen, ntraj = dp_worker.impala_case()
+    n = tlen * ntraj
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    rng = np.random.default_rng(9)
+    sets = []
+    for k in range(2):
+        obs = data["obs"] if k == 0 else rng.integers(0, 256, data["obs"].shape).astype(data["obs"].dtype)
+        sets.append([d(obs), d(data["bp"] + 0.1 * k), d(data["act"]), d(data["done"]), d(data["rew"])])
+
+    def run(tail):
+        net = HipActorCritic(spec, max_batch=n, seed=5)
+        c = net.make_impala_cfg(1e-3, 40.0, tlen)
+        slots = [torch.zeros(spec.n_flat, dtype=torch.float32, pin_memory=True) for _ in range(3)]
+        evs = [torch.cuda.Event() for _ in range(3)]
+        for ev in evs:
+            ev.record()
+        losses, accs, pubs = [], [], []
+        for t in range(6):
+            obs, bp, act, done, rew = sets[t % 2]
+            pub = (slots[t % 3].data_ptr(), evs[t % 3].cuda_event) if t % 2 == 0 else None
+            a = net.impala_train_io(c, obs, n, bp, act, done, rew, use_graph=use_graph, publish=pub, wait_loss=True,
+                                    tail_in_graph=tail, defer=defer and tail)
+            if a is None:
+                a = net.impala_wait_loss()
+            losses.append(a.copy())
+            torch.cuda.synchronize()
+            accs.append(net.loss_acc.cpu().numpy()[:4].copy())
+            if pub is not None:
+                assert np.array_equal(slots[t % 3].numpy(), net.params.cpu().numpy())
+                pubs.append(slots[t % 3].numpy().copy())
+        return losses, accs, pubs, net.params.cpu().numpy().copy()
+
+    ref, got = run(False), run(True)
+    for a, b in zip(ref[0], got[0]):
+        assert np.array_equal(a, b), (a, b)
+    for a, b, c_ in zip(got[0], got[1], ref[1]):
+        assert np.array_equal(a, b) and np.array_equal(b, c_)       # the device-side loss_acc holds the same four floats
+    assert len(ref[2]) == len(got[2]) == 3
+    for a, b in zip(ref[2], got[2]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(ref[3], got[3])

@@ -1,7 +1,7 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/tr; rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tr -- python $R/tools/impala_prefetch_probe.py breakout_impala gate > /tmp/tr.log 2>&1
+rm -rf /tmp/tr; rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tr -- python $R/tools/impala_prefetch_probe.py ${1:-breakout_impala} prefetch ${2:-tail} > /tmp/tr.log 2>&1
 tail -3 /tmp/tr.log | cut -c1-200
 python - <<'P'
 import csv, glob

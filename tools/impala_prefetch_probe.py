@@ -33,18 +33,45 @@ wrap(ingest.RolloutIngest, "finish")
 wrap(ingest.RolloutIngest, "put")
 wrap(ingest.RolloutIngest, "ship_labels")
 wrap(hip_net.HipActorCritic, "impala_train_io")
+NETS = []
+_init = hip_net.HipActorCritic.__init__
+
+
+def _init_keep(self, *a, **k):
+    _init(self, *a, **k)
+    NETS.append(self)
+
+
+hip_net.HipActorCritic.__init__ = _init_keep
 wrap(hip_net.HipActorCritic, "snapshot_weights_async")
 wrap(hip_net.HipActorCritic, "read_loss")
 wrap(hip_net.HipActorCritic, "publish_weights")
 wrap(transport.WeightsRing, "_reserve_flat")
 wrap(transport.Prefetcher, "recv_into")
+wrap(transport.WeightsRing, "publish_reserve")
+wrap(transport.WeightsRing, "publish_enqueued")
+wrap(ingest.RolloutIngest, "mapped_labels")
+wrap(ingest.RolloutIngest, "consumed_event")
+from xingtian_amd.model.impala import impala_cnn_opt  # noqa: E402
+from xingtian_amd.algorithm.impala import impala_opt  # noqa: E402
+wrap(impala_cnn_opt.ImpalaCnnOpt, "train_ingested")
+wrap(impala_cnn_opt.ImpalaCnnOpt, "_lr_steps")
+wrap(impala_opt.IMPALAOpt, "train")
+wrap(impala_opt.IMPALAOpt, "prepare_data")
+wrap(impala_opt.IMPALAOpt, "publish_weights")
+wrap(impala_opt.IMPALAOpt, "checkpoint_ready")
 key = sys.argv[1] if len(sys.argv) > 1 else "breakout_impala"
 w = bench.IMPALA[key]
 mpt = w.get("msgs_per_train", 1 if key == "breakout_impala" else 4)
 res = bench.impala_ring_loop(w, w["frames_per_train"] // mpt, mpt, w.get("train_per_checkpoint", 1), n_prod=2, seconds=1.0,
                              prefetch=(len(sys.argv) < 3 or sys.argv[2] != "blocking"),
                              async_commit=(len(sys.argv) < 3 or sys.argv[2] != "blocking"),
-                             gate=(len(sys.argv) > 2 and sys.argv[2] == "gate"))
+                             gate=(len(sys.argv) < 3 or sys.argv[2] != "nogate"),
+                             model_config={"IO_TAIL_IN_GRAPH": "notail" not in sys.argv[2:], "USE_HIP_GRAPH": "nograph" not in sys.argv[2:]})
 print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in res.items()})
 for k, (tot, n) in sorted(T.items(), key=lambda kv: -kv[1][0]):
     print("%-42s %7d calls  %8.1f us/call" % (k, n, 1e6 * tot / max(n, 1)))
+for net in NETS:
+    t = net.io_times()
+    if t["calls"]:
+        print("xt_net_impala_train_io phases (us/call):", {k: round(v, 1) if isinstance(v, float) else v for k, v in t.items()})

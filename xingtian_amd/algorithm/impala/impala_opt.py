@@ -55,8 +55,9 @@ class IMPALAOpt(Algorithm):
         return int(np.asarray(fields[0]).shape[0])
 
     def stage_group_complete(self):
-        """(staging thread) the last message of a train has been staged: its label block follows the frames to HBM now"""
-        self.actor._ingest_obj().ship_labels()
+        """(staging thread) the last message of a train has been staged: its label block follows the frames to HBM and the
+        buffer set's copies-done event is recorded now, not between ``train()`` and the GPU's first kernel"""
+        self.actor._ingest_obj().seal()
 
     def staged_generation(self):
         """trains whose buffer set the learner thread has taken over (the Prefetcher stays at most one train ahead)"""

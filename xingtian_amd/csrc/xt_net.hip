@@ -2,6 +2,7 @@
 // minibatches of xt/model/ppo/ppo.py:111-132, or one ImpalaCnnOpt.train chunk) on a HIP
 // stream, optionally captured once into a hipGraph and replayed (a B=320 step is ~20
 // short kernels; the reference pays a feed_dict H2D + session dispatch per minibatch).
+#include <chrono>
 #include <mutex>
 #include <vector>
 #include <string>
@@ -97,6 +98,16 @@ struct Layer {
 
 static inline int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
 
+// xt_train_io.tail_in_graph: what the learner thread and the tail kernels of a train say to each other (page-locked host memory)
+struct IoMailbox {
+  unsigned long long publish_dst;   // host -> device: device-side address the new parameters go to (0: nobody asked)
+  uint32_t seq;                     // host -> device: sequence number of the train being launched
+  uint32_t pad0;
+  float loss[4];                    // device -> host: loss_acc of that train
+  uint32_t loss_seq;                // device -> host: == seq once loss[] has landed
+  uint32_t pad1[7];
+};
+static_assert(sizeof(IoMailbox) == 64, "IoMailbox is one 64-byte line");
 }  // namespace xt
 
 struct xt_net {
@@ -149,6 +160,17 @@ struct xt_net {
   GraphSlot gslots[4];
   unsigned long long gclock = 0;
   hipStream_t cap_stream = nullptr;   // capture happens on our own stream: the legacy null stream cannot be captured
+  // xt_train_io.tail_in_graph: the 64-byte page-locked mailbox between the learner thread and the train's two tail kernels
+  // (host side / the same block through the device's address space), the sequence number of the last train that used it, and
+  // whether the train being enqueued carries the tail (part of the graph key)
+  xt::IoMailbox* io_mb = nullptr;
+  xt::IoMailbox* io_mb_dev = nullptr;
+  uint32_t io_seq = 0;
+  bool io_acc_clean = false;          // the library-owned loss accumulator of tail_in_graph trains is zero (its loss kernel re-arms it)
+  double io_us[4] = {0, 0, 0, 0};     // xt_net_io_times: host time of xt_net_impala_train_io's phases, accumulated
+  long long io_calls = 0;
+  int64_t off_iofwd = 0;              // 4 floats of the workspace: {destination (64 bit), sequence number} handed kernel to kernel
+  int64_t off_ioacc = 0;              // 4 floats: the loss accumulator of tail_in_graph trains (no memset node in their graph)
 };
 
 namespace xt {
@@ -897,6 +919,8 @@ int xt_net_create(const xt_net_desc* d, int32_t max_batch, xt_net** out) {
   n->off_loss = off; off += xt::align4(8 + 2 * max_batch);     // 4 + n_traj (v-trace) / 4 + 2 B (Keras loss terms)
   n->off_norm = off; off += xt::kMaxNormPartials;
   n->off_counter = off; off += 32 * 66;   // 1 top + 64 sub ticket counters, one 128-B line each
+  n->off_iofwd = off; off += 4;           // tail_in_graph: {destination, sequence number} from the loss kernel to the copy kernel
+  n->off_ioacc = off; off += 4;
   n->ws_floats = off;
   *out = n;
   return 0;
@@ -911,6 +935,7 @@ void xt_net_destroy(xt_net* net) {
     for (hipEvent_t e : {net->tail_fork, net->tail_join, net->adam_fork, net->adam_join}) if (e) hipEventDestroy(e);
   }
   if (net->xchg_stream) { hipStreamDestroy(net->xchg_stream); hipEventDestroy(net->xchg_fork); hipEventDestroy(net->xchg_join); }
+  if (net->io_mb) hipHostFree(net->io_mb);
   delete net;
 }
 
@@ -923,6 +948,7 @@ int xt_net_bind(xt_net* n, float* params, float* grads, float* adam_m, float* ad
              (long long)workspace_bytes, (long long)(n->ws_floats * 4));
   XT_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)workspace) & 15) == 0,
              "xt_net_bind: buffers must be 16-byte aligned");
+  n->io_acc_clean = false;             // (a new workspace: the tail_in_graph accumulator lives in it)
   n->params = params; n->grads = grads; n->m = adam_m; n->v = adam_v; n->state = adam_state;
   n->ws = static_cast<float*>(workspace);
   XT_CHECK_HIP(hipMemset(n->ws + n->off_counter, 0, 32 * 66 * 4));   // ticket counter of grads_finish_kernel
@@ -1054,8 +1080,9 @@ int xt_net_impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int32
 
 static int impala_train_enqueue(xt_net* net, const xt_impala_cfg* c, const void* obs, int32_t n, int32_t batch_size,
                                 const float* bp_logits, const int32_t* action, const uint8_t* done, const float* reward,
-                                const float* lr_steps, float* loss_acc, hipStream_t st) {
-  if (int rc = xt::clear_loss_acc(net, loss_acc, st)) return rc;
+                                const float* lr_steps, float* loss_acc, hipStream_t st, bool clear = true) {
+  if (clear)
+    if (int rc = xt::clear_loss_acc(net, loss_acc, st)) return rc;
   XT_REQUIRE(n < (1 << 24), "xt_net_impala_train: %d frames do not fit the data-parallel tail's float slot", n);
   net->dp_rows = (float)n;
   const size_t frame = (size_t)net->in_h * net->in_w * net->in_c * (net->xf.is_u8 ? 1 : 4);
@@ -1122,9 +1149,72 @@ static int impala_train_enqueue(xt_net* net, const xt_impala_cfg* c, const void*
   return xt::join_pending_update(net, st);
 }
 
-int xt_net_impala_train(xt_net* net, const xt_impala_cfg* c, const void* obs, int32_t n, int32_t batch_size,
-                        const float* bp_logits, const int32_t* action, const uint8_t* done, const float* reward,
-                        const float* lr_steps, float* loss_acc, int32_t use_graph, void* stream) {
+namespace xt {
+// device -> page-locked HOST copies as plain kernels on the learner's stream.  hipMemcpyAsync into registered host memory runs
+// a runtime blit kernel anyway (__amd_rocclr_copyBuffer, 73 us for the 4 MB parameter block) but pays 15-25 us of
+// submission latency on either side of it (rocprofv3 trace of the IMPALA loop, round 6: adam -> loss copy 22 us, loss copy ->
+// parameter copy 14 us, parameter copy -> next train 17 us); a kernel launch behind a kernel costs ~2 us.
+__global__ void __launch_bounds__(64) host_copy4_kernel(float* __restrict__ dst_host, const float* __restrict__ src) {
+  if (threadIdx.x < 4) dst_host[threadIdx.x] = src[threadIdx.x];
+}
+__device__ __forceinline__ void publish_copy(float* __restrict__ dst_host, const float* __restrict__ src, long long count) {
+  const long long n4 = count >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
+    reinterpret_cast<float4*>(dst_host)[i] = reinterpret_cast<const float4*>(src)[i];
+  if (blockIdx.x == 0 && threadIdx.x < (count & 3)) dst_host[(n4 << 2) + threadIdx.x] = src[(n4 << 2) + threadIdx.x];
+}
+__global__ void __launch_bounds__(256) host_publish_kernel(float* __restrict__ dst_host, const float* __restrict__ src,
+                                                           long long count) {
+  publish_copy(dst_host, src, count);
+}
+// xt_train_io.tail_in_graph: the same two copies as the LAST KERNELS OF THE TRAIN (inside its replayed hipGraph: the arguments
+// are fixed, so what changes from train to train travels through the mailbox).  The first kernel reads {destination, sequence
+// number} from the page-locked mailbox, hands them to the copy kernel through device memory -- the learner thread rewrites the
+// mailbox for the next train as soon as it has seen this train's loss, possibly while the copy kernel is still starting -- and
+// writes loss_acc + the sequence number back: data, a system-scope fence, then the word the learner thread polls.
+__global__ void __launch_bounds__(64) io_loss_kernel(IoMailbox* __restrict__ mb, float* __restrict__ acc,
+                                                     unsigned long long* __restrict__ fwd, float* __restrict__ loss_acc_out) {
+  const int t = threadIdx.x;
+  uint32_t seq = 0;
+  if (t == 0) {
+    const unsigned long long dst = __hip_atomic_load(&mb->publish_dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    seq = __hip_atomic_load(&mb->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    fwd[0] = dst;
+    fwd[1] = seq;
+  }
+  if (t < 4) {
+    const float v = acc[t];
+    mb->loss[t] = v;
+    loss_acc_out[t] = v;      // (the caller's device-side loss_acc, as every other train entry point leaves it)
+    acc[t] = 0.f;             // re-armed for the next train: its graph has no memset node
+  }
+  __threadfence_system();
+  if (t == 0) __hip_atomic_store(&mb->loss_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void __launch_bounds__(256) io_publish_kernel(const unsigned long long* __restrict__ fwd,
+                                                         const float* __restrict__ src, long long count) {
+  float* dst = reinterpret_cast<float*>(fwd[0]);
+  if (dst) publish_copy(dst, src, count);
+}
+// the device-side address of a page-locked host block (hipHostMalloc'ed or hipHostRegister'ed), or nullptr
+static float* host_device_ptr(void* host) {
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, host, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return static_cast<float*>(d);
+}
+static int io_tail_enqueue(xt_net* net, float* loss_acc, hipStream_t st) {
+  unsigned long long* fwd = reinterpret_cast<unsigned long long*>(net->ws + net->off_iofwd);
+  hipLaunchKernelGGL(io_loss_kernel, dim3(1), dim3(64), 0, st, net->io_mb_dev, net->ws + net->off_ioacc, fwd, loss_acc);
+  XT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(io_publish_kernel, dim3(256), dim3(256), 0, st, fwd, net->params, (long long)net->P);
+  XT_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace xt
+
+static int impala_train_run(xt_net* net, const xt_impala_cfg* c, const void* obs, int32_t n, int32_t batch_size,
+                            const float* bp_logits, const int32_t* action, const uint8_t* done, const float* reward,
+                            const float* lr_steps, float* loss_acc, int32_t use_graph, bool io_tail, void* stream) {
   XT_REQUIRE(net && c && obs && bp_logits && action && done && reward && loss_acc, "xt_net_impala_train: null argument");
   XT_REQUIRE(net->params && net->ws, "xt_net_impala_train: buffers not bound");
   const int T = c->sample_batch_step;
@@ -1137,51 +1227,107 @@ int xt_net_impala_train(xt_net* net, const xt_impala_cfg* c, const void* obs, in
              batch_size < n ? batch_size : n, net->maxB);
   hipStream_t st = xt::as_stream(stream);
   (void)xt::tail_overlap_mode(net);
-  if (!use_graph)
-    return impala_train_enqueue(net, c, obs, n, batch_size, bp_logits, action, done, reward, lr_steps, loss_acc, st);
+  auto enqueue = [&](hipStream_t cs) {
+    // tail_in_graph: the chunks accumulate into the library's own 4 floats, which the loss kernel re-arms -- no memset node
+    if (int rc = impala_train_enqueue(net, c, obs, n, batch_size, bp_logits, action, done, reward, lr_steps,
+                                      io_tail ? net->ws + net->off_ioacc : loss_acc, cs, /*clear*/ !io_tail))
+      return rc;
+    return io_tail ? xt::io_tail_enqueue(net, loss_acc, cs) : 0;
+  };
+  if (!use_graph) return enqueue(st);
   char key[512];
-  snprintf(key, sizeof(key), "I%d.%d.%d.%d.%p|%p|%p|%p|%d|%d|%p|%p|%p|%p|%p|%p|%g|%g|%g|%g|%g|%g|%d|%g|%d|%g|%g",
+  snprintf(key, sizeof(key), "I%d.%d.%d.%d.%p|%p|%p|%p|%d|%d|%p|%p|%p|%p|%p|%p|%g|%g|%g|%g|%g|%g|%d|%g|%d|%g|%g|%p",
            c->shard_rank, c->shard_world, net->dp_rank, net->dp_world, (void*)net->direct, (void*)net->xchg, net->xchg_user, obs, n, batch_size, (const void*)bp_logits, (const void*)action,
            (const void*)done, (const void*)reward, (const void*)lr_steps, (void*)loss_acc, c->lr, c->beta1, c->beta2,
-           c->eps, c->grad_norm_clip, c->gamma, c->sample_batch_step, c->grad_scale, c->opt_type, c->rms_decay, c->rms_eps);
-  return xt::graph_run(net, key, st, [&](hipStream_t cs) {
-    return impala_train_enqueue(net, c, obs, n, batch_size, bp_logits, action, done, reward, lr_steps, loss_acc, cs);
-  });
+           c->eps, c->grad_norm_clip, c->gamma, c->sample_batch_step, c->grad_scale, c->opt_type, c->rms_decay, c->rms_eps,
+           io_tail ? (void*)net->io_mb_dev : nullptr);
+  return xt::graph_run(net, key, st, enqueue);
 }
 
-namespace xt {
-// device -> page-locked HOST copies as plain kernels on the learner's stream.  hipMemcpyAsync into registered host memory runs
-// a runtime blit kernel anyway (__amd_rocclr_copyBuffer, 73 us for the 4 MB parameter block) but pays 15-25 us of
-// submission latency on either side of it (rocprofv3 trace of the IMPALA loop, round 6: adam -> loss copy 22 us, loss copy ->
-// parameter copy 14 us, parameter copy -> next train 17 us); a kernel launch behind a kernel costs ~2 us.
-__global__ void __launch_bounds__(64) host_copy4_kernel(float* __restrict__ dst_host, const float* __restrict__ src) {
-  if (threadIdx.x < 4) dst_host[threadIdx.x] = src[threadIdx.x];
+int xt_net_impala_train(xt_net* net, const xt_impala_cfg* c, const void* obs, int32_t n, int32_t batch_size,
+                        const float* bp_logits, const int32_t* action, const uint8_t* done, const float* reward,
+                        const float* lr_steps, float* loss_acc, int32_t use_graph, void* stream) {
+  return impala_train_run(net, c, obs, n, batch_size, bp_logits, action, done, reward, lr_steps, loss_acc, use_graph, false,
+                          stream);
 }
-__global__ void __launch_bounds__(256) host_publish_kernel(float* __restrict__ dst_host, const float* __restrict__ src,
-                                                           long long count) {
-  const long long n4 = count >> 2;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
-    reinterpret_cast<float4*>(dst_host)[i] = reinterpret_cast<const float4*>(src)[i];
-  if (blockIdx.x == 0 && threadIdx.x < (count & 3)) dst_host[(n4 << 2) + threadIdx.x] = src[(n4 << 2) + threadIdx.x];
+
+// tail_in_graph: wait (bounded) until the train's first tail kernel has written `seq` into the mailbox
+static int io_wait_loss(xt_net* net, uint32_t seq, hipStream_t st) {
+  const uint32_t* word = &net->io_mb->loss_seq;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 1;; ++spins) {
+    if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return 0;
+    __builtin_ia32_pause();
+    if ((spins & 0x3fff) != 0) continue;
+    // every ~0.3 ms: is the stream still working?  (an idle or failed stream will never write the word)
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipErrorNotReady) { (void)hipGetLastError(); }
+    else {
+      if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return 0;
+      XT_CHECK_HIP(q);
+      XT_REQUIRE(false, "xt_net_impala_train_io: the stream is idle but the train's tail kernel did not report (sequence %u, "
+                        "mailbox holds %u)", seq, *word);
+    }
+    XT_REQUIRE(std::chrono::steady_clock::now() - t0 < std::chrono::seconds(30),
+               "xt_net_impala_train_io: no loss from the device after 30 s (sequence %u)", seq);
+  }
 }
-// the device-side address of a page-locked host block (hipHostMalloc'ed or hipHostRegister'ed), or nullptr
-static float* host_device_ptr(void* host) {
-  void* d = nullptr;
-  if (hipHostGetDevicePointer(&d, host, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  return static_cast<float*>(d);
-}
-}  // namespace xt
 
 int xt_net_impala_train_io(xt_net* net, const xt_impala_cfg* c, const void* obs, int32_t n, int32_t batch_size,
                            const float* bp_logits, const int32_t* action, const uint8_t* done, const float* reward,
                            const float* lr_steps, float* loss_acc, int32_t use_graph, const xt_train_io* io, void* stream) {
   hipStream_t st = xt::as_stream(stream);
-  if (io && io->wait_event) XT_CHECK_HIP(hipStreamWaitEvent(st, static_cast<hipEvent_t>(io->wait_event), 0));
-  if (int rc = xt_net_impala_train(net, c, obs, n, batch_size, bp_logits, action, done, reward, lr_steps, loss_acc, use_graph, stream))
+  XT_REQUIRE(net, "xt_net_impala_train_io: null net");
+  const bool tail = io && io->tail_in_graph && io->wait_loss && io->loss_host;
+  const auto t_begin = std::chrono::steady_clock::now();
+  // the rollout's copies: usually long done (they ran under the previous train) -- then there is nothing to wait for and the
+  // stream is spared a cross-stream barrier in front of the train
+  if (io && io->wait_event && hipEventQuery(static_cast<hipEvent_t>(io->wait_event)) != hipSuccess) {
+    (void)hipGetLastError();
+    XT_CHECK_HIP(hipStreamWaitEvent(st, static_cast<hipEvent_t>(io->wait_event), 0));
+  }
+  bool published = false;
+  uint32_t seq = 0;
+  if (tail) {
+    if (!net->io_mb) {
+      void *h = nullptr, *d = nullptr;
+      XT_CHECK_HIP(hipHostMalloc(&h, sizeof(xt::IoMailbox), hipHostMallocMapped | hipHostMallocCoherent));
+      memset(h, 0, sizeof(xt::IoMailbox));
+      if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); hipHostFree(h); XT_REQUIRE(false, "xt_net_impala_train_io: the mailbox is not mapped into the device's address space"); }
+      net->io_mb = static_cast<xt::IoMailbox*>(h);
+      net->io_mb_dev = static_cast<xt::IoMailbox*>(d);
+    }
+    float* d = io->publish_dst ? xt::host_device_ptr(io->publish_dst) : nullptr;
+    published = d && (reinterpret_cast<uintptr_t>(d) & 15) == 0;
+    seq = ++net->io_seq;
+    if (seq == 0) seq = ++net->io_seq;       // (0 is what an untouched mailbox holds)
+    net->io_mb->publish_dst = published ? reinterpret_cast<unsigned long long>(d) : 0ull;
+    net->io_mb->seq = seq;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);  // the mailbox is written before the launch's doorbell
+    if (!net->io_acc_clean) {                 // first use / after a rebind or a failed enqueue: zero the accumulator once
+      XT_CHECK_HIP(hipMemsetAsync(net->ws + net->off_ioacc, 0, 2 * sizeof(float), st));
+      XT_CHECK_HIP(hipMemsetAsync(net->ws + net->off_ioacc + 2, 0, 2 * sizeof(float), st));
+    }
+    net->io_acc_clean = false;
+  }
+  const auto t_pre = std::chrono::steady_clock::now();
+  if (int rc = impala_train_run(net, c, obs, n, batch_size, bp_logits, action, done, reward, lr_steps, loss_acc, use_graph, tail,
+                                stream))
     return rc;
   if (!io) return 0;
+  if (tail) net->io_acc_clean = true;         // (the loss kernel is enqueued: it leaves the accumulator zero)
+  const auto t_launch = std::chrono::steady_clock::now();
+  auto account = [&](std::chrono::steady_clock::time_point t_post) {
+    const auto t_end = std::chrono::steady_clock::now();
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+      return std::chrono::duration<double, std::micro>(b - a).count();
+    };
+    net->io_us[0] += us(t_begin, t_pre); net->io_us[1] += us(t_pre, t_launch);
+    net->io_us[2] += us(t_launch, t_post); net->io_us[3] += us(t_post, t_end);
+    net->io_calls++;
+  };
   if (io->consumed_event) XT_CHECK_HIP(hipEventRecord(static_cast<hipEvent_t>(io->consumed_event), st));
-  if (io->loss_host) {
+  if (io->loss_host && !tail) {
     if (float* d = xt::host_device_ptr(io->loss_host)) {
       hipLaunchKernelGGL(xt::host_copy4_kernel, dim3(1), dim3(64), 0, st, d, loss_acc);
       XT_LAUNCH_CHECK();
@@ -1191,17 +1337,47 @@ int xt_net_impala_train_io(xt_net* net, const xt_impala_cfg* c, const void* obs,
     if (io->loss_event) XT_CHECK_HIP(hipEventRecord(static_cast<hipEvent_t>(io->loss_event), st));
   }
   if (io->publish_dst) {
-    float* d = xt::host_device_ptr(io->publish_dst);
-    if (d && (reinterpret_cast<uintptr_t>(d) & 15) == 0) {
-      hipLaunchKernelGGL(xt::host_publish_kernel, dim3(256), dim3(256), 0, st, d, net->params, (long long)net->P);
-      XT_LAUNCH_CHECK();
-    } else {
-      XT_CHECK_HIP(hipMemcpyAsync(io->publish_dst, net->params, sizeof(float) * (size_t)net->P, hipMemcpyDeviceToHost, st));
+    if (!published) {
+      float* d = xt::host_device_ptr(io->publish_dst);
+      if (d && (reinterpret_cast<uintptr_t>(d) & 15) == 0) {
+        hipLaunchKernelGGL(xt::host_publish_kernel, dim3(256), dim3(256), 0, st, d, net->params, (long long)net->P);
+        XT_LAUNCH_CHECK();
+      } else {
+        XT_CHECK_HIP(hipMemcpyAsync(io->publish_dst, net->params, sizeof(float) * (size_t)net->P, hipMemcpyDeviceToHost, st));
+      }
     }
     if (io->publish_event) XT_CHECK_HIP(hipEventRecord(static_cast<hipEvent_t>(io->publish_event), st));
   }
+  const auto t_post = std::chrono::steady_clock::now();
+  if (tail) {
+    if (io->wait_loss != 2) {              // (2: the caller comes back for the loss with xt_net_io_wait)
+      if (int rc = io_wait_loss(net, seq, st)) return rc;
+      memcpy(io->loss_host, net->io_mb->loss, 4 * sizeof(float));
+    }
+    account(t_post);
+    return 0;
+  }
   if (io->loss_host && io->loss_event && io->wait_loss)
     XT_CHECK_HIP(hipEventSynchronize(static_cast<hipEvent_t>(io->loss_event)));
+  account(t_post);
+  return 0;
+}
+
+int xt_net_io_wait(xt_net* net, float* loss_host4, void* stream) {
+  XT_REQUIRE(net && loss_host4, "xt_net_io_wait: null argument");
+  XT_REQUIRE(net->io_mb && net->io_seq, "xt_net_io_wait: no train with tail_in_graph has been enqueued on this net");
+  const auto t0 = std::chrono::steady_clock::now();
+  if (int rc = io_wait_loss(net, net->io_seq, xt::as_stream(stream))) return rc;
+  memcpy(loss_host4, net->io_mb->loss, 4 * sizeof(float));
+  net->io_us[3] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  return 0;
+}
+
+int xt_net_io_times(xt_net* net, double* us_out4, int64_t* calls_out, int32_t reset) {
+  XT_REQUIRE(net && us_out4 && calls_out, "xt_net_io_times: null argument");
+  for (int i = 0; i < 4; ++i) us_out4[i] = net->io_us[i];
+  *calls_out = net->io_calls;
+  if (reset) { for (double& v : net->io_us) v = 0; net->io_calls = 0; }
   return 0;
 }
 

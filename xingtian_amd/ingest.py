@@ -273,6 +273,19 @@ class RolloutIngest(object):
                            self.copy_stream)
         s.shipped_n = self.n
 
+    def seal(self):
+        """(a ``transport.Prefetcher``'s staging thread) the last message of a rollout has been staged: ship its labels and
+        record the set's copies-done event NOW, so that ``finish`` on the learner thread only switches buffer sets.  A ``put``
+        after this un-seals the set (``finish`` then does both again)."""
+        s = self.sets[self.cur]
+        if s is None or self.n == 0:
+            return
+        if self.pad_channels is not None and s.dev["obs"].shape[-1] != self.pad_channels[0]:
+            return                              # (the channel padding runs in finish, in front of the event)
+        self.ship_labels()
+        s.done.record(self.copy_stream)
+        s.sealed_n = self.n
+
     def finish(self, wait_on_stream=True):
         """All trajectories are in: make the compute stream wait for the copies, return (n, device buffers) and
         switch to the other buffer set for the next rollout.  ``wait_on_stream=False``: the caller makes its stream wait for
@@ -285,7 +298,10 @@ class RolloutIngest(object):
             self.reset()
             raise RuntimeError("RolloutIngest.finish(): a rollout must not mix trajectories with and without advantages")
         dev = s.dev
-        self.ship_labels()
+        sealed = getattr(s, "sealed_n", -1) == n      # (seal(): labels shipped and the event recorded by the staging thread)
+        s.sealed_n = -1
+        if not sealed:
+            self.ship_labels()
         s.shipped_n = -1
         if self.pad_channels is not None and s.dev["obs"].shape[-1] != self.pad_channels[0]:
             c_dst, fill = self.pad_channels
@@ -297,7 +313,8 @@ class RolloutIngest(object):
                                               src.element_size(), int(fill),
                                               ctypes.c_void_p(self.copy_stream.cuda_stream)), "xt_pad_channels")
             dev = dict(s.dev, obs=s.dev_padded)
-        s.done.record(self.copy_stream)
+        if not sealed:
+            s.done.record(self.copy_stream)
         if wait_on_stream:
             L.current_stream(self.device).wait_event(s.done)
         self.cur ^= 1

@@ -30,7 +30,7 @@ class LayerDesc(Structure):
     _fields_ = [("g", ConvGeom), ("param_off", c_int64), ("trunk", c_int32)]
 
 
-ABI_VERSION = 11         # XT_ABI_VERSION of include/xt_mi355x.h
+ABI_VERSION = 12         # XT_ABI_VERSION of include/xt_mi355x.h
 ACTION_TYPE = {"Categorical": 0, "DiagGaussian": 1}
 
 
@@ -68,7 +68,7 @@ class Tuning(Structure):
 class TrainIO(ctypes.Structure):
     """xt_train_io of include/xt_mi355x.h: the runtime calls around one train, folded into the train's C call"""
     _fields_ = [("wait_event", c_void_p), ("consumed_event", c_void_p), ("loss_host", c_void_p), ("loss_event", c_void_p),
-                ("publish_dst", c_void_p), ("publish_event", c_void_p), ("wait_loss", c_int32)]
+                ("publish_dst", c_void_p), ("publish_event", c_void_p), ("wait_loss", c_int32), ("tail_in_graph", c_int32)]
 
 
 OPT_TYPE = {"adam": 0, "rmsprop": 1}
@@ -146,6 +146,8 @@ SIGNATURES = {
     "xt_net_time_tail": (c_int32, [_P, c_float, c_float, c_int32, POINTER(c_float), _P]),
     "xt_net_impala_train_io": (c_int32, [_P, POINTER(ImpalaCfg), _P, c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_int32,
                                          POINTER(TrainIO), _P]),
+    "xt_net_io_times": (c_int32, [_P, POINTER(c_double), POINTER(c_int64), c_int32]),
+    "xt_net_io_wait": (c_int32, [_P, _P, _P]),
 }
 
 

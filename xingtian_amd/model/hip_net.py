@@ -450,15 +450,19 @@ class HipActorCritic(object):
         return self.loss_acc
 
     def impala_train_io(self, c, obs, batch_size, bp_logits, action, done, reward, lr_steps=None, use_graph=False,
-                        wait_event=None, consumed_event=None, publish=None, wait_loss=True):
+                        wait_event=None, consumed_event=None, publish=None, wait_loss=True, tail_in_graph=True, defer=False):
         """``impala_train`` + the runtime calls of the learner loop around it in ONE C call (``xt_net_impala_train_io``): the
         compute stream waits for ``wait_event`` (the rollout's copies), ``consumed_event`` is recorded behind the train,
         ``loss_acc`` is copied into the next pinned read-back block and -- ``wait_loss`` -- awaited with the GIL released,
         ``publish`` = (host address of a pinned weights-ring slot, raw event handle) receives the new parameters by a D2H in
-        stream order behind the loss copy (``WeightsRing.publish_reserve``).  Returns the pinned
-        [sum, count, error bits, -] block of THIS train (``wait_loss``) or of the previous one; raises on error bits."""
+        stream order behind the loss copy (``WeightsRing.publish_reserve``).  ``tail_in_graph`` (with ``wait_loss``): both
+        copies are the train's own last kernels, inside its replayed hipGraph, and the loss is awaited by polling a
+        page-locked word (``xt_train_io.tail_in_graph``); ``defer`` (with both): return right behind the launch -- the caller
+        does its loss-independent book-keeping under the device's train and fetches the loss with ``impala_wait_loss()``.
+        Returns the pinned [sum, count, error bits, -] block of THIS train (``wait_loss``) or of the previous one (None when
+        deferred); raises on error bits."""
         n = int(obs.shape[0])
-        self.touch()
+        self._version = getattr(self, "_version", 0) + 1          # touch()
         rb = getattr(self, "_loss_rb", None)
         if rb is None:
             pin = torch.zeros((2, 4), dtype=torch.float32, pin_memory=True)
@@ -469,35 +473,77 @@ class HipActorCritic(object):
                 ev.record(cur)                 # (a torch event gets its handle at its first record)
             rb["raw"] = [ev.cuda_event for ev in rb["ev"]]
             rb["ptr"] = [rb["pin"][k].data_ptr() for k in range(2)]
+            rb["io"] = L.TrainIO()             # one descriptor, rewritten per train
+            rb["io_ref"] = ctypes.byref(rb["io"])
+            rb["fn"] = self.lib.xt_net_impala_train_io
+            rb["dev"] = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            rb["acc"] = self.loss_acc.data_ptr()
         i = rb["slot"]
-        io = L.TrainIO()
+        io = rb["io"]
         io.wait_event = wait_event.cuda_event if wait_event is not None else None
         io.consumed_event = consumed_event.cuda_event if consumed_event is not None else None
         if publish is not None:
             io.publish_dst, io.publish_event = publish[0], publish[1]
-        io.loss_host, io.loss_event, io.wait_loss = rb["ptr"][i], rb["raw"][i], 1 if (wait_loss or rb["n"] == 0) else 0
+        else:
+            io.publish_dst, io.publish_event = None, None
+        sync = bool(wait_loss or rb["n"] == 0)
+        tail = bool(tail_in_graph and sync)
+        deferred = bool(defer and tail)
+        io.loss_host, io.loss_event, io.wait_loss = rb["ptr"][i], rb["raw"][i], (2 if deferred else 1) if sync else 0
+        io.tail_in_graph = 1 if tail else 0
+        ptr = L.ptr
         gate = getattr(self, "idle_gate", None)
         if gate is not None:
             gate.set()              # the staging thread may work from here on: this thread is inside C (GIL released)
         try:
-            L.check(self.lib.xt_net_impala_train_io(self.handle, ctypes.byref(c), L.ptr(obs), n, int(batch_size),
-                                                    L.ptr(bp_logits), L.ptr(action), L.ptr(done), L.ptr(reward),
-                                                    L.ptr(lr_steps), L.ptr(self.loss_acc), 1 if use_graph else 0,
-                                                    ctypes.byref(io), L.stream_ptr()), "xt_net_impala_train_io")
+            rc = rb["fn"](self.handle, ctypes.byref(c), ptr(obs), n, int(batch_size), ptr(bp_logits), ptr(action), ptr(done),
+                          ptr(reward), ptr(lr_steps), rb["acc"], 1 if use_graph else 0, rb["io_ref"],
+                          torch._C._cuda_getCurrentRawStream(rb["dev"]))
+            if rc:
+                L.check(rc, "xt_net_impala_train_io")
+        finally:
+            if gate is not None and not deferred:
+                gate.clear()
+        rb["slot"] = i ^ 1
+        rb["n"] += 1
+        if deferred:
+            rb["deferred"] = i
+            return None
+        j = i if sync else i ^ 1
+        if j != i:
+            rb["ev"][j].synchronize()
+        return self._loss_block(rb["np"][j])
+
+    def impala_wait_loss(self):
+        """second half of ``impala_train_io(..., defer=True)``: wait for that train's loss (C ABI ``xt_net_io_wait``, GIL
+        released) -> its pinned [sum, count, error bits, -] block"""
+        rb = self._loss_rb
+        i = rb.pop("deferred")
+        gate = getattr(self, "idle_gate", None)
+        try:
+            rc = self.lib.xt_net_io_wait(self.handle, rb["ptr"][i], torch._C._cuda_getCurrentRawStream(rb["dev"]))
+            if rc:
+                L.check(rc, "xt_net_io_wait")
         finally:
             if gate is not None:
                 gate.clear()
-        rb["slot"] = i ^ 1
-        j = i if (wait_loss or rb["n"] == 0) else i ^ 1
-        rb["n"] += 1
-        if j != i:
-            rb["ev"][j].synchronize()
-        a = rb["np"][j]
+        return self._loss_block(rb["np"][i])
+
+    @staticmethod
+    def _loss_block(a):
         if a[2] != 0.0:
             raise RuntimeError("xingtian_amd: the data-parallel update failed on this rank -- {} (error bits {}); the "
                                "optimiser skipped the update, parameters are those of the last good step".format(
                                    L.dp_error_text(a[2]), int(a[2])))
         return a
+
+    def io_times(self, reset=True):
+        """host time per call (us) of the phases of ``impala_train_io`` -- before the launch, the launch, the runtime calls
+        behind it, the wait for the loss (C ABI ``xt_net_io_times``; diagnostic)"""
+        us, calls = (ctypes.c_double * 4)(), ctypes.c_int64()
+        L.check(self.lib.xt_net_io_times(self.handle, us, ctypes.byref(calls), 1 if reset else 0), "xt_net_io_times")
+        n = max(int(calls.value), 1)
+        return dict(calls=int(calls.value), pre_us=us[0] / n, launch_us=us[1] / n, post_us=us[2] / n, wait_us=us[3] / n)
 
     def keras_impala_step(self, obs, idx, adv, onehot, target_v, ent_coef, loss_acc=None):
         """One ``model.fit`` minibatch of the non-opt IMPALA models (C ABI xt_net_keras_impala_step): forward, Keras

@@ -60,6 +60,9 @@ class ImpalaCnnOpt(XTModel):
         self.async_loss = bool(model_config.get("ASYNC_LOSS", False))
         # (not with ASYNC_LOSS: the staging block of train k may then be rewritten for train k + 2 while train k still runs)
         self.zero_copy_labels = bool(model_config.get("ZERO_COPY_LABELS", True)) and not self.async_loss
+        # IO_TAIL_IN_GRAPH (default on; synchronous loss only): the loss read-back and the weights-ring copy are the train's own
+        # last kernels inside its replayed hipGraph, the loss is awaited by polling a page-locked word (xt_train_io.tail_in_graph)
+        self.io_tail_in_graph = bool(model_config.get("IO_TAIL_IN_GRAPH", True))
         self._ingest = None
         self._dp = None
         self._lr_host = self._lr_dev = None
@@ -172,16 +175,25 @@ class ImpalaCnnOpt(XTModel):
                 raise RuntimeError("ImpalaCnnOpt: the label staging block is not mapped into the device's address space "
                                    "(set model_config ZERO_COPY_LABELS: false)")
             lab = {k: d[k][:n] for k in ("logit", "action", "done", "reward")}
+        # (in-graph tail: the call returns right behind the launch; what does not depend on the loss -- handing the publish
+        # to the ring's committer, reserving the NEXT publish's slot and header -- happens while the device trains)
+        defer = self.io_tail_in_graph and not self.async_loss
         a = self.net.impala_train_io(self._cfg, d["obs"][:n], batch_size, lab["logit"], lab["action"], lab["done"],
                                      lab["reward"], lr_steps=lr_steps, use_graph=self.use_graph, wait_event=ing.last.done,
                                      consumed_event=ing.consumed_event(), publish=None if ticket is None else (ticket[3], ticket[4]),
-                                     wait_loss=not self.async_loss)
-        self._global_step += n_chunks
-        if ticket is not None:
-            ring.publish_enqueued(ticket)
-            self.net._wring_version = getattr(self.net, "_version", 0)
-        elif self.eager_snapshot:
-            self.net.snapshot_weights_async()   # (no committer ring: the D2H of the new weights is enqueued behind the train)
+                                     wait_loss=not self.async_loss, tail_in_graph=self.io_tail_in_graph, defer=defer)
+        try:
+            self._global_step += n_chunks
+            if ticket is not None:
+                ring.publish_enqueued(ticket)
+                self.net._wring_version = getattr(self.net, "_version", 0)
+                if a is None:
+                    ring.publish_prereserve(self.net, getattr(self.net, "_wring_ctr", None))
+            elif self.eager_snapshot:
+                self.net.snapshot_weights_async()   # (no committer ring: the D2H of the new weights is enqueued behind the train)
+        finally:
+            if a is None:
+                a = self.net.impala_wait_loss()
         # Data parallel: the sum is the GLOBAL one (the ranks' shares travelled in the tail of the exchanged gradient)
         return np.float32(float(a[0]) / max(float(a[1]), 1.0))
 
