@@ -629,6 +629,16 @@ int xt_net_impala_train_io(xt_net* net, const xt_impala_cfg* cfg, const void* ob
  * loss_acc's 4 floats to loss_host4 (any host memory). */
 int xt_net_io_wait(xt_net* net, float* loss_host4, void* stream);
 
+/* The parameter copy of a tail_in_graph train reports its own completion (ABI >= 12): the copy kernel's last workgroup writes
+ * the train's sequence number into the mailbox, so a caller that passes NO publish_event / consumed_event (event records behind
+ * a replayed graph delay the next graph on the stream by ~20 us) still learns when the block at publish_dst is complete:
+ * xt_net_io_seq = sequence number of the most recent tail_in_graph train of this net (read it right behind the launch);
+ * xt_net_io_publish_wait returns 0 once the copy of train `seq` (or a later one) has landed, 1 when timeout_ms ran out
+ * (0 = query, < 0 = no limit).  The train's inputs are consumed once its loss has been seen (the loss kernel runs behind every
+ * kernel that reads them). */
+uint32_t xt_net_io_seq(const xt_net* net);
+int xt_net_io_publish_wait(xt_net* net, uint32_t seq, int32_t timeout_ms);
+
 /* diagnostic (ABI >= 12): host time (us, accumulated over *calls_out calls with a non-NULL io) of xt_net_impala_train_io's
  * phases -- [0] before the launch (wait for the copies, mailbox), [1] the launch (hipGraphLaunch, or the eager enqueue), [2] the
  * runtime calls behind it (event records, the separate copies when tail_in_graph is off), [3] the wait for the loss.

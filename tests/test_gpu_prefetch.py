@@ -143,9 +143,16 @@ def test_train_io_tail_in_graph_through_the_c_abi(use_graph, defer):
         losses, accs, pubs = [], [], []
         for t in range(6):
             obs, bp, act, done, rew = sets[t % 2]
-            pub = (slots[t % 3].data_ptr(), evs[t % 3].cuda_event) if t % 2 == 0 else None
+            # (tail: no event behind the graph -- the copy kernel reports its own completion through the mailbox)
+            pub = (slots[t % 3].data_ptr(), None if tail else evs[t % 3].cuda_event) if t % 2 == 0 else None
             a = net.impala_train_io(c, obs, n, bp, act, done, rew, use_graph=use_graph, publish=pub, wait_loss=True,
                                     tail_in_graph=tail, defer=defer and tail)
+            landed = None
+            if tail and pub is not None:
+                handle = net.io_publish_done()
+                handle.synchronize()
+                assert handle.query()
+                landed = slots[t % 3].numpy().copy()      # what the host sees the moment the sequence number has arrived
             if a is None:
                 a = net.impala_wait_loss()
             losses.append(a.copy())
@@ -153,6 +160,7 @@ def test_train_io_tail_in_graph_through_the_c_abi(use_graph, defer):
             accs.append(net.loss_acc.cpu().numpy()[:4].copy())
             if pub is not None:
                 assert np.array_equal(slots[t % 3].numpy(), net.params.cpu().numpy())
+                assert landed is None or np.array_equal(landed, slots[t % 3].numpy())
                 pubs.append(slots[t % 3].numpy().copy())
         return losses, accs, pubs, net.params.cpu().numpy().copy()
 
@@ -165,3 +173,33 @@ def test_train_io_tail_in_graph_through_the_c_abi(use_graph, defer):
     for a, b in zip(ref[2], got[2]):
         assert np.array_equal(a, b)
     assert np.array_equal(ref[3], got[3])
+
+
+def test_the_copy_kernels_sequence_number_is_only_seen_behind_the_whole_parameter_block():
+    """The in-graph parameter copy reports its own completion from INSIDE the kernel (system-scope write-through stores, every
+    workgroup's stores acknowledged, a ticket, the last workgroup writes the sequence number -- no fence, no event): 150
+    trains of the breakout_impala shape (4.2 MB of parameters over the bus per train), the page-locked destination read by
+    the host the moment the number has arrived must already be the train's parameters, bit for bit."""
+    from xingtian_amd.model import netspec
+    from xingtian_amd.model.hip_net import HipActorCritic
+    tlen = 64
+    spec = netspec.impala_cnn_opt((84, 84, 4), 4, 0.0, 255.0, "uint8")
+    net = HipActorCritic(spec, max_batch=tlen, seed=3)
+    c = net.make_impala_cfg(1e-3, 40.0, tlen)
+    rng = np.random.default_rng(1)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    obs = d(rng.integers(0, 256, (tlen, 84, 84, 4)).astype(np.uint8))
+    bp, act = d(rng.standard_normal((tlen, 4)).astype(np.float32)), d(rng.integers(0, 4, tlen).astype(np.int32))
+    done, rew = d((rng.random(tlen) < 0.05).astype(np.uint8)), d(rng.choice([-1.0, 0.0, 1.0], tlen).astype(np.float32))
+    slots = [torch.zeros(spec.n_flat, dtype=torch.float32, pin_memory=True) for _ in range(2)]
+    landed = np.empty(spec.n_flat, np.float32)
+    for t in range(150):
+        a = net.impala_train_io(c, obs, tlen, bp, act, done, rew, use_graph=True, publish=(slots[t % 2].data_ptr(), None),
+                                wait_loss=True, tail_in_graph=True, defer=True)
+        assert a is None
+        net.io_publish_done().synchronize()
+        np.copyto(landed, slots[t % 2].numpy())
+        a = net.impala_wait_loss()
+        torch.cuda.synchronize()
+        assert np.isfinite(a[0]) and a[1] == 1.0
+        assert np.array_equal(landed, net.params.cpu().numpy()), t

@@ -57,6 +57,30 @@ from xingtian_amd.algorithm.impala import impala_opt  # noqa: E402
 wrap(impala_cnn_opt.ImpalaCnnOpt, "train_ingested")
 wrap(impala_cnn_opt.ImpalaCnnOpt, "_lr_steps")
 wrap(impala_opt.IMPALAOpt, "train")
+wrap(impala_opt.IMPALAOpt, "stage_message")
+wrap(impala_opt.IMPALAOpt, "stage_group_complete")
+wrap(transport.Prefetcher, "_stage")
+wrap(transport.RingSet, "poll_into")
+wrap(transport.ShmRing, "recv_into", "ShmRing.recv_into")
+wrap(transport.ShmRing, "recv_view")
+wrap(transport.ShmRing, "_done_with_slot")
+wrap(transport.ShmRing, "_reap")
+wrap(transport.SlotGuard, "hold")
+wrap(hip_net.HipActorCritic, "impala_wait_loss")
+_dec = transport.decode
+
+
+def _decode_timed(*a, **k):
+    t0 = time.perf_counter()
+    try:
+        return _dec(*a, **k)
+    finally:
+        d = T.setdefault("transport.decode", [0.0, 0])
+        d[0] += time.perf_counter() - t0
+        d[1] += 1
+
+
+transport.decode = _decode_timed
 wrap(impala_opt.IMPALAOpt, "prepare_data")
 wrap(impala_opt.IMPALAOpt, "publish_weights")
 wrap(impala_opt.IMPALAOpt, "checkpoint_ready")
@@ -67,7 +91,8 @@ res = bench.impala_ring_loop(w, w["frames_per_train"] // mpt, mpt, w.get("train_
                              prefetch=(len(sys.argv) < 3 or sys.argv[2] != "blocking"),
                              async_commit=(len(sys.argv) < 3 or sys.argv[2] != "blocking"),
                              gate=(len(sys.argv) < 3 or sys.argv[2] != "nogate"),
-                             model_config={"IO_TAIL_IN_GRAPH": "notail" not in sys.argv[2:], "USE_HIP_GRAPH": "nograph" not in sys.argv[2:]})
+                             model_config={"IO_TAIL_IN_GRAPH": "notail" not in sys.argv[2:], "USE_HIP_GRAPH": "nograph" not in sys.argv[2:],
+                                           "INGEST_COPY_STREAMS": 2 if "cs2" in sys.argv[2:] else 1})
 print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in res.items()})
 for k, (tot, n) in sorted(T.items(), key=lambda kv: -kv[1][0]):
     print("%-42s %7d calls  %8.1f us/call" % (k, n, 1e6 * tot / max(n, 1)))

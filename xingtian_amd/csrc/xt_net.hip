@@ -3,6 +3,7 @@
 // stream, optionally captured once into a hipGraph and replayed (a B=320 step is ~20
 // short kernels; the reference pays a feed_dict H2D + session dispatch per minibatch).
 #include <chrono>
+#include <thread>
 #include <mutex>
 #include <vector>
 #include <string>
@@ -105,7 +106,8 @@ struct IoMailbox {
   uint32_t pad0;
   float loss[4];                    // device -> host: loss_acc of that train
   uint32_t loss_seq;                // device -> host: == seq once loss[] has landed
-  uint32_t pad1[7];
+  uint32_t publish_seq;             // device -> host: sequence number of the last train whose parameter copy has landed
+  uint32_t pad1[6];
 };
 static_assert(sizeof(IoMailbox) == 64, "IoMailbox is one 64-byte line");
 }  // namespace xt
@@ -919,7 +921,7 @@ int xt_net_create(const xt_net_desc* d, int32_t max_batch, xt_net** out) {
   n->off_loss = off; off += xt::align4(8 + 2 * max_batch);     // 4 + n_traj (v-trace) / 4 + 2 B (Keras loss terms)
   n->off_norm = off; off += xt::kMaxNormPartials;
   n->off_counter = off; off += 32 * 66;   // 1 top + 64 sub ticket counters, one 128-B line each
-  n->off_iofwd = off; off += 4;           // tail_in_graph: {destination, sequence number} from the loss kernel to the copy kernel
+  n->off_iofwd = off; off += 8;           // tail_in_graph: {destination, sequence number, block ticket} between its two kernels
   n->off_ioacc = off; off += 4;
   n->ws_floats = off;
   *out = n;
@@ -952,6 +954,7 @@ int xt_net_bind(xt_net* n, float* params, float* grads, float* adam_m, float* ad
   n->params = params; n->grads = grads; n->m = adam_m; n->v = adam_v; n->state = adam_state;
   n->ws = static_cast<float*>(workspace);
   XT_CHECK_HIP(hipMemset(n->ws + n->off_counter, 0, 32 * 66 * 4));   // ticket counter of grads_finish_kernel
+  XT_CHECK_HIP(hipMemset(n->ws + n->off_iofwd, 0, 8 * 4));           // (the copy kernel's block ticket starts at 0)
   for (auto& g : n->gslots) if (g.exec) { hipGraphExecDestroy(g.exec); g.exec = nullptr; g.key.clear(); }
   return 0;
 }
@@ -1157,11 +1160,23 @@ namespace xt {
 __global__ void __launch_bounds__(64) host_copy4_kernel(float* __restrict__ dst_host, const float* __restrict__ src) {
   if (threadIdx.x < 4) dst_host[threadIdx.x] = src[threadIdx.x];
 }
+// SYSTEM-scope write-through stores (sc0 sc1): whatever memory type the page-locked destination was mapped with, a store that
+// has been acknowledged (s_waitcnt vmcnt(0)) is at the system's coherence point -- what lets io_publish_kernel report its own
+// completion from inside the kernel without a system-scope fence (which would write the whole L2 back first)
 __device__ __forceinline__ void publish_copy(float* __restrict__ dst_host, const float* __restrict__ src, long long count) {
   const long long n4 = count >> 2;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
-    reinterpret_cast<float4*>(dst_host)[i] = reinterpret_cast<const float4*>(src)[i];
-  if (blockIdx.x == 0 && threadIdx.x < (count & 3)) dst_host[(n4 << 2) + threadIdx.x] = src[(n4 << 2) + threadIdx.x];
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst_host, 0, 0x7fffffff, 0x00020000);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(src)[i];
+    xt_u32x4 q;
+    q.x = __float_as_uint(v.x); q.y = __float_as_uint(v.y); q.z = __float_as_uint(v.z); q.w = __float_as_uint(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(q, rs, (int)(i * 16), 0, /*sc0*/ 1 | kAuxSc1);
+  }
+#endif
+  if (blockIdx.x == 0 && threadIdx.x < (count & 3))
+    __hip_atomic_store(dst_host + (n4 << 2) + threadIdx.x, src[(n4 << 2) + threadIdx.x], __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __global__ void __launch_bounds__(256) host_publish_kernel(float* __restrict__ dst_host, const float* __restrict__ src,
                                                            long long count) {
@@ -1184,17 +1199,32 @@ __global__ void __launch_bounds__(64) io_loss_kernel(IoMailbox* __restrict__ mb,
   }
   if (t < 4) {
     const float v = acc[t];
-    mb->loss[t] = v;
+    __hip_atomic_store(&mb->loss[t], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     loss_acc_out[t] = v;      // (the caller's device-side loss_acc, as every other train entry point leaves it)
     acc[t] = 0.f;             // re-armed for the next train: its graph has no memset node
   }
-  __threadfence_system();
-  if (t == 0) __hip_atomic_store(&mb->loss_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  // system-scope stores into coherent host memory: acknowledged = visible to the host, so the data only has to be
+  // acknowledged before the sequence number leaves (a system-scope FENCE would write the whole L2 back first)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (t == 0) __hip_atomic_store(&mb->loss_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__global__ void __launch_bounds__(256) io_publish_kernel(const unsigned long long* __restrict__ fwd,
-                                                         const float* __restrict__ src, long long count) {
+// ... and tells the host when the block has landed: every workgroup's stores, a system-scope fence, a ticket; the last one
+// writes the train's sequence number into the mailbox (no event record behind the graph: a record costs the NEXT graph on the
+// stream ~20 us of start latency, rocprofv3 trace of the loop, round 6)
+__global__ void __launch_bounds__(256) io_publish_kernel(unsigned long long* __restrict__ fwd, const float* __restrict__ src,
+                                                         long long count, IoMailbox* __restrict__ mb) {
   float* dst = reinterpret_cast<float*>(fwd[0]);
-  if (dst) publish_copy(dst, src, count);
+  if (!dst) return;
+  publish_copy(dst, src, count);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (this workgroup's system-scope stores are acknowledged)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(fwd + 2);
+    if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+      *ticket = 0u;
+      __hip_atomic_store(&mb->publish_seq, (uint32_t)fwd[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 // the device-side address of a page-locked host block (hipHostMalloc'ed or hipHostRegister'ed), or nullptr
 static float* host_device_ptr(void* host) {
@@ -1206,7 +1236,7 @@ static int io_tail_enqueue(xt_net* net, float* loss_acc, hipStream_t st) {
   unsigned long long* fwd = reinterpret_cast<unsigned long long*>(net->ws + net->off_iofwd);
   hipLaunchKernelGGL(io_loss_kernel, dim3(1), dim3(64), 0, st, net->io_mb_dev, net->ws + net->off_ioacc, fwd, loss_acc);
   XT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(io_publish_kernel, dim3(256), dim3(256), 0, st, fwd, net->params, (long long)net->P);
+  hipLaunchKernelGGL(io_publish_kernel, dim3(256), dim3(256), 0, st, fwd, net->params, (long long)net->P, net->io_mb_dev);
   XT_LAUNCH_CHECK();
   return 0;
 }
@@ -1371,6 +1401,23 @@ int xt_net_io_wait(xt_net* net, float* loss_host4, void* stream) {
   memcpy(loss_host4, net->io_mb->loss, 4 * sizeof(float));
   net->io_us[3] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
   return 0;
+}
+
+uint32_t xt_net_io_seq(const xt_net* net) { return net ? net->io_seq : 0u; }
+
+int xt_net_io_publish_wait(xt_net* net, uint32_t seq, int32_t timeout_ms) {
+  XT_REQUIRE(net && net->io_mb, "xt_net_io_publish_wait: no train with tail_in_graph has been enqueued on this net");
+  const uint32_t* word = &net->io_mb->publish_seq;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 1;; ++spins) {
+    if ((int32_t)(__atomic_load_n(word, __ATOMIC_ACQUIRE) - seq) >= 0) return 0;
+    if (timeout_ms == 0) return 1;           // (query form: not yet)
+    __builtin_ia32_pause();
+    if ((spins & 0xfff) == 0) {
+      if (timeout_ms > 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms)) return 1;
+      std::this_thread::yield();             // (a helper thread waits here: it must not keep a core from the learner)
+    }
+  }
 }
 
 int xt_net_io_times(xt_net* net, double* us_out4, int64_t* calls_out, int32_t reset) {

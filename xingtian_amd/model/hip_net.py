@@ -14,6 +14,23 @@ from xingtian_amd import lib as L
 from xingtian_amd.model.cpu_net import initial_weights
 
 
+class _MailboxDone(object):
+    """see ``HipActorCritic.io_publish_done``"""
+    __slots__ = ("net", "seq")
+
+    def __init__(self, net, seq):
+        self.net, self.seq = net, seq
+
+    def synchronize(self):
+        rc = self.net.lib.xt_net_io_publish_wait(self.net.handle, self.seq, 30000)        # (ctypes releases the GIL)
+        if rc == 1:
+            raise RuntimeError("xingtian_amd: the parameter copy of train {} did not land within 30 s".format(self.seq))
+        L.check(rc, "xt_net_io_publish_wait")
+
+    def query(self):
+        return self.net.lib.xt_net_io_publish_wait(self.net.handle, self.seq, 0) == 0
+
+
 class HipActorCritic(object):
     def __init__(self, spec, max_batch, device="cuda:0", seed=None, init="glorot"):
         L.require_gpu()
@@ -492,9 +509,12 @@ class HipActorCritic(object):
         io.loss_host, io.loss_event, io.wait_loss = rb["ptr"][i], rb["raw"][i], (2 if deferred else 1) if sync else 0
         io.tail_in_graph = 1 if tail else 0
         ptr = L.ptr
-        gate = getattr(self, "idle_gate", None)
+        # the staging thread may work while this thread is inside C with the GIL released -- in the deferred form only from
+        # impala_wait_loss() on: the launch is ~15 us and the book-keeping behind it needs the GIL to itself (two Python
+        # threads hand it back and forth at every runtime call: measured, the 16 us C call took 56-67 us with the gate open)
+        gate = None if deferred else getattr(self, "idle_gate", None)
         if gate is not None:
-            gate.set()              # the staging thread may work from here on: this thread is inside C (GIL released)
+            gate.set()
         try:
             rc = rb["fn"](self.handle, ctypes.byref(c), ptr(obs), n, int(batch_size), ptr(bp_logits), ptr(action), ptr(done),
                           ptr(reward), ptr(lr_steps), rb["acc"], 1 if use_graph else 0, rb["io_ref"],
@@ -502,7 +522,7 @@ class HipActorCritic(object):
             if rc:
                 L.check(rc, "xt_net_impala_train_io")
         finally:
-            if gate is not None and not deferred:
+            if gate is not None:
                 gate.clear()
         rb["slot"] = i ^ 1
         rb["n"] += 1
@@ -514,12 +534,21 @@ class HipActorCritic(object):
             rb["ev"][j].synchronize()
         return self._loss_block(rb["np"][j])
 
+    def io_publish_done(self):
+        """completion handle (``synchronize()`` / ``query()``, the two calls a ``transport.WeightsRing`` makes on a publish's
+        event) of the parameter copy of the most recent ``tail_in_graph`` train: the copy kernel's last workgroup writes the
+        train's sequence number into the mailbox (C ABI ``xt_net_io_seq`` / ``xt_net_io_publish_wait``) -- no event record
+        behind the replayed graph"""
+        return _MailboxDone(self, int(self.lib.xt_net_io_seq(self.handle)))
+
     def impala_wait_loss(self):
         """second half of ``impala_train_io(..., defer=True)``: wait for that train's loss (C ABI ``xt_net_io_wait``, GIL
         released) -> its pinned [sum, count, error bits, -] block"""
         rb = self._loss_rb
         i = rb.pop("deferred")
         gate = getattr(self, "idle_gate", None)
+        if gate is not None:
+            gate.set()
         try:
             rc = self.lib.xt_net_io_wait(self.handle, rb["ptr"][i], torch._C._cuda_getCurrentRawStream(rb["dev"]))
             if rc:

@@ -63,6 +63,9 @@ class ImpalaCnnOpt(XTModel):
         # IO_TAIL_IN_GRAPH (default on; synchronous loss only): the loss read-back and the weights-ring copy are the train's own
         # last kernels inside its replayed hipGraph, the loss is awaited by polling a page-locked word (xt_train_io.tail_in_graph)
         self.io_tail_in_graph = bool(model_config.get("IO_TAIL_IN_GRAPH", True))
+        # HIP streams the frames of consecutive messages alternate between (joined by two event calls per train): ONE for an
+        # IMPALA learner -- its few messages per train share the bus anyway, and the join costs the staging thread ~10 us
+        self.ingest_copy_streams = int(model_config.get("INGEST_COPY_STREAMS", 1))
         self._ingest = None
         self._dp = None
         self._lr_host = self._lr_dev = None
@@ -104,7 +107,8 @@ class ImpalaCnnOpt(XTModel):
             self._ingest = RolloutIngest(self.net.device, 0, initial_capacity=self.max_batch,
                                          obs_u8=bool(self.net.spec.input_xform[0]),
                                          fields=impala_fields(self.action_dim),
-                                         pad_channels=(cpad, self.net.obs_fill_byte()) if cpad else None)
+                                         pad_channels=(cpad, self.net.obs_fill_byte()) if cpad else None,
+                                         copy_streams=self.ingest_copy_streams)
             # the few KB of labels of a train are read by the v-trace kernel straight out of the page-locked staging block
             # (only if page-locked host memory is mapped into the device's address space here: probed once)
             from xingtian_amd import lib as L
@@ -177,14 +181,22 @@ class ImpalaCnnOpt(XTModel):
             lab = {k: d[k][:n] for k in ("logit", "action", "done", "reward")}
         # (in-graph tail: the call returns right behind the launch; what does not depend on the loss -- handing the publish
         # to the ring's committer, reserving the NEXT publish's slot and header -- happens while the device trains)
+        # No event records behind the graph either (each delays the NEXT graph on the stream): the buffer set is consumed once
+        # the loss has been seen (the loss kernel runs behind every kernel that reads it), the parameter copy reports its own
+        # completion through the mailbox (net.io_publish_done()).
         defer = self.io_tail_in_graph and not self.async_loss
         a = self.net.impala_train_io(self._cfg, d["obs"][:n], batch_size, lab["logit"], lab["action"], lab["done"],
                                      lab["reward"], lr_steps=lr_steps, use_graph=self.use_graph, wait_event=ing.last.done,
-                                     consumed_event=ing.consumed_event(), publish=None if ticket is None else (ticket[3], ticket[4]),
+                                     consumed_event=None if defer else ing.consumed_event(),
+                                     publish=None if ticket is None else (ticket[3], None if defer else ticket[4]),
                                      wait_loss=not self.async_loss, tail_in_graph=self.io_tail_in_graph, defer=defer)
         try:
             self._global_step += n_chunks
+            if a is None:
+                ing.last.free = None             # (host-confirmed below: impala_wait_loss returns behind the loss kernel)
             if ticket is not None:
+                if a is None:
+                    ticket = ticket[:5] + (self.net.io_publish_done(),)
                 ring.publish_enqueued(ticket)
                 self.net._wring_version = getattr(self.net, "_version", 0)
                 if a is None:
