@@ -639,6 +639,12 @@ int xt_net_io_wait(xt_net* net, float* loss_host4, void* stream);
 uint32_t xt_net_io_seq(const xt_net* net);
 int xt_net_io_publish_wait(xt_net* net, uint32_t seq, int32_t timeout_ms);
 
+/* One synchronous device -> page-locked-host copy on the SDMA engine through the HSA runtime of the process (ABI >= 12;
+ * csrc/xt_sdma.hip says why not hipMemcpyAsync).  dst_host: hipHostMalloc'ed or hipHostRegister'ed memory; src_dev: a device
+ * allocation; the caller has made sure the source is complete (no stream is involved).  Diagnostic / test entry: the library
+ * uses the same copy for the parameter block of xt_net_impala_train_io (tail_in_graph = 2). */
+int xt_sdma_copy_d2h(void* dst_host, const void* src_dev, int64_t bytes);
+
 /* diagnostic (ABI >= 12): host time (us, accumulated over *calls_out calls with a non-NULL io) of xt_net_impala_train_io's
  * phases -- [0] before the launch (wait for the copies, mailbox), [1] the launch (hipGraphLaunch, or the eager enqueue), [2] the
  * runtime calls behind it (event records, the separate copies when tail_in_graph is off), [3] the wait for the loss.

@@ -102,12 +102,13 @@ def test_prefetch_and_asynchronous_commit_train_and_publish_exactly_what_the_blo
         assert np.array_equal(w[name], w_r[name]), name
 
 
+@pytest.mark.parametrize("tail", [1, 2])
 @pytest.mark.parametrize("prefetch", [True, False])
-def test_the_in_graph_tail_reports_and_publishes_what_the_separate_launches_do(prefetch):
+def test_the_in_graph_tail_reports_and_publishes_what_the_separate_launches_do(prefetch, tail):
     """xt_train_io.tail_in_graph on / off, everything else equal (train_per_checkpoint 3: trains WITH and WITHOUT a publish
     alternate through the same replayed graphs -- the destination travels through the mailbox)"""
     a = _run(prefetch, 3, True, tail=False)
-    b = _run(prefetch, 3, True, tail=True)
+    b = _run(prefetch, 3, True, tail=tail)
     assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[3] == b[3] and a[4] == b[4]
     assert a[5][0] == b[5][0]
     for name in a[5][2]:
@@ -116,7 +117,8 @@ def test_the_in_graph_tail_reports_and_publishes_what_the_separate_launches_do(p
 
 @pytest.mark.parametrize("use_graph", [False, True])
 @pytest.mark.parametrize("defer", [False, True])
-def test_train_io_tail_in_graph_through_the_c_abi(use_graph, defer):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_train_io_tail_in_graph_through_the_c_abi(use_graph, defer, mode):
     """xt_net_impala_train_io with tail_in_graph against the same trains with the separate launches (loss copy + event,
     parameter copy + event): 6 trains on two alternating input sets, a publish on every second one (the destination travels
     through the mailbox: the replayed graphs are the same with and without it); every loss block, the device-side loss_acc,
@@ -144,6 +146,7 @@ def test_train_io_tail_in_graph_through_the_c_abi(use_graph, defer):
         for t in range(6):
             obs, bp, act, done, rew = sets[t % 2]
             # (tail: no event behind the graph -- the copy kernel reports its own completion through the mailbox)
+            # (mode 2: a snapshot in the graph; the SDMA copy is made by handle.synchronize(), i.e. by whoever waits)
             pub = (slots[t % 3].data_ptr(), None if tail else evs[t % 3].cuda_event) if t % 2 == 0 else None
             a = net.impala_train_io(c, obs, n, bp, act, done, rew, use_graph=use_graph, publish=pub, wait_loss=True,
                                     tail_in_graph=tail, defer=defer and tail)
@@ -164,7 +167,7 @@ def test_train_io_tail_in_graph_through_the_c_abi(use_graph, defer):
                 pubs.append(slots[t % 3].numpy().copy())
         return losses, accs, pubs, net.params.cpu().numpy().copy()
 
-    ref, got = run(False), run(True)
+    ref, got = run(0), run(mode)
     for a, b in zip(ref[0], got[0]):
         assert np.array_equal(a, b), (a, b)
     for a, b, c_ in zip(got[0], got[1], ref[1]):
@@ -175,7 +178,8 @@ def test_train_io_tail_in_graph_through_the_c_abi(use_graph, defer):
     assert np.array_equal(ref[3], got[3])
 
 
-def test_the_copy_kernels_sequence_number_is_only_seen_behind_the_whole_parameter_block():
+@pytest.mark.parametrize("mode", [1, 2])
+def test_the_copy_kernels_sequence_number_is_only_seen_behind_the_whole_parameter_block(mode):
     """The in-graph parameter copy reports its own completion from INSIDE the kernel (system-scope write-through stores, every
     workgroup's stores acknowledged, a ticket, the last workgroup writes the sequence number -- no fence, no event): 150
     trains of the breakout_impala shape (4.2 MB of parameters over the bus per train), the page-locked destination read by
@@ -195,9 +199,9 @@ def test_the_copy_kernels_sequence_number_is_only_seen_behind_the_whole_paramete
     landed = np.empty(spec.n_flat, np.float32)
     for t in range(150):
         a = net.impala_train_io(c, obs, tlen, bp, act, done, rew, use_graph=True, publish=(slots[t % 2].data_ptr(), None),
-                                wait_loss=True, tail_in_graph=True, defer=True)
+                                wait_loss=True, tail_in_graph=mode, defer=True)
         assert a is None
-        net.io_publish_done().synchronize()
+        net.io_publish_done().synchronize()       # (mode 2: waits for the snapshot's report, then the SDMA copy, synchronously)
         np.copyto(landed, slots[t % 2].numpy())
         a = net.impala_wait_loss()
         torch.cuda.synchronize()

@@ -91,7 +91,7 @@ res = bench.impala_ring_loop(w, w["frames_per_train"] // mpt, mpt, w.get("train_
                              prefetch=(len(sys.argv) < 3 or sys.argv[2] != "blocking"),
                              async_commit=(len(sys.argv) < 3 or sys.argv[2] != "blocking"),
                              gate=(len(sys.argv) < 3 or sys.argv[2] != "nogate"),
-                             model_config={"IO_TAIL_IN_GRAPH": "notail" not in sys.argv[2:], "USE_HIP_GRAPH": "nograph" not in sys.argv[2:],
+                             model_config={"IO_TAIL_IN_GRAPH": 0 if "notail" in sys.argv[2:] else 1 if "ingraph" in sys.argv[2:] else 2, "USE_HIP_GRAPH": "nograph" not in sys.argv[2:],
                                            "INGEST_COPY_STREAMS": 2 if "cs2" in sys.argv[2:] else 1})
 print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in res.items()})
 for k, (tot, n) in sorted(T.items(), key=lambda kv: -kv[1][0]):

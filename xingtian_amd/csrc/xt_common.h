@@ -327,4 +327,8 @@ struct PerDeviceOnce {
   }
 };
 
+// xt_sdma.hip: a device -> page-locked-host copy on the SDMA engine through the process's HSA runtime, synchronous; -> nullptr
+// or why this process cannot do it.  `sig_io`: an hsa_signal_t handle kept by the caller (0 = create one)
+const char* sdma_copy_d2h(void* dst_host, const void* src_dev, size_t bytes, unsigned long long* sig_io);
+void sdma_signal_destroy(unsigned long long* sig);
 }  // namespace xt

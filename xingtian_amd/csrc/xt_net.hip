@@ -2,6 +2,7 @@
 // minibatches of xt/model/ppo/ppo.py:111-132, or one ImpalaCnnOpt.train chunk) on a HIP
 // stream, optionally captured once into a hipGraph and replayed (a B=320 step is ~20
 // short kernels; the reference pays a feed_dict H2D + session dispatch per minibatch).
+#include <atomic>
 #include <chrono>
 #include <thread>
 #include <mutex>
@@ -107,7 +108,8 @@ struct IoMailbox {
   float loss[4];                    // device -> host: loss_acc of that train
   uint32_t loss_seq;                // device -> host: == seq once loss[] has landed
   uint32_t publish_seq;             // device -> host: sequence number of the last train whose parameter copy has landed
-  uint32_t pad1[6];
+  uint32_t snap_seq;                // device -> host: ... whose parameter SNAPSHOT is complete in device memory (mode 2)
+  uint32_t pad1[5];
 };
 static_assert(sizeof(IoMailbox) == 64, "IoMailbox is one 64-byte line");
 }  // namespace xt
@@ -168,6 +170,17 @@ struct xt_net {
   xt::IoMailbox* io_mb = nullptr;
   xt::IoMailbox* io_mb_dev = nullptr;
   uint32_t io_seq = 0;
+  // tail_in_graph = 2: the 80 us bus-bound copy of the new parameters runs UNDER THE NEXT TRAIN -- the train's graph ends with
+  // a device-side snapshot (params -> io_snap[seq & 1], ~5 us, reported through the mailbox), the copy snapshot -> page-locked
+  // destination runs on the SDMA engine, issued through the HSA runtime by whoever waits for the publish (the weights ring's
+  // committer thread: xt_net_io_publish_wait); no HIP stream or event is involved.  (A copy KERNEL beside the train does not
+  // work, and this process's hipMemcpyAsync is one: xt_sdma.hip.)
+  float* io_snap[2] = {nullptr, nullptr};
+  // per snapshot buffer: the page-locked destination and the sequence number of the publish that owns it (0: none yet; written
+  // by the learner thread before the launch), the publish some thread has CLAIMED the copy of, the publish whose copy has landed
+  void* io_dst[2] = {nullptr, nullptr};
+  std::atomic<uint32_t> io_snap_owner[2] = {{0}, {0}}, io_copying[2] = {{0}, {0}}, io_copied[2] = {{0}, {0}};
+  unsigned long long io_sig[2] = {0, 0};          // hsa_signal_t handles of the copies (xt_sdma.hip), created on first use
   bool io_acc_clean = false;          // the library-owned loss accumulator of tail_in_graph trains is zero (its loss kernel re-arms it)
   double io_us[4] = {0, 0, 0, 0};     // xt_net_io_times: host time of xt_net_impala_train_io's phases, accumulated
   long long io_calls = 0;
@@ -938,6 +951,8 @@ void xt_net_destroy(xt_net* net) {
   }
   if (net->xchg_stream) { hipStreamDestroy(net->xchg_stream); hipEventDestroy(net->xchg_fork); hipEventDestroy(net->xchg_join); }
   if (net->io_mb) hipHostFree(net->io_mb);
+  for (float* p : net->io_snap) if (p) hipFree(p);
+  for (auto& h : net->io_sig) xt::sdma_signal_destroy(&h);
   delete net;
 }
 
@@ -1226,17 +1241,40 @@ __global__ void __launch_bounds__(256) io_publish_kernel(unsigned long long* __r
     }
   }
 }
+// the snapshot form of the train's last kernel (tail_in_graph = 2): the new parameters -> the snapshot buffer of this train's
+// parity at HBM speed, only when a destination was announced, with system-scope write-through stores -- the SDMA engine reads
+// memory, not an XCD's L2 -- and the same in-kernel completion report as io_publish_kernel (mailbox word snap_seq)
+__global__ void __launch_bounds__(256) io_snapshot_kernel(unsigned long long* __restrict__ fwd, const float* __restrict__ src,
+                                                          float* __restrict__ snap0, float* __restrict__ snap1, long long count,
+                                                          IoMailbox* __restrict__ mb) {
+  if (fwd[0] == 0ull) return;
+  publish_copy((fwd[1] & 1ull) ? snap1 : snap0, src, count);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(fwd + 2);
+    if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+      *ticket = 0u;
+      __hip_atomic_store(&mb->snap_seq, (uint32_t)fwd[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
 // the device-side address of a page-locked host block (hipHostMalloc'ed or hipHostRegister'ed), or nullptr
 static float* host_device_ptr(void* host) {
   void* d = nullptr;
   if (hipHostGetDevicePointer(&d, host, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   return static_cast<float*>(d);
 }
-static int io_tail_enqueue(xt_net* net, float* loss_acc, hipStream_t st) {
+static int io_tail_enqueue(xt_net* net, float* loss_acc, int mode, hipStream_t st) {
   unsigned long long* fwd = reinterpret_cast<unsigned long long*>(net->ws + net->off_iofwd);
   hipLaunchKernelGGL(io_loss_kernel, dim3(1), dim3(64), 0, st, net->io_mb_dev, net->ws + net->off_ioacc, fwd, loss_acc);
   XT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(io_publish_kernel, dim3(256), dim3(256), 0, st, fwd, net->params, (long long)net->P, net->io_mb_dev);
+  if (mode == 2) {
+    hipLaunchKernelGGL(io_snapshot_kernel, dim3(512), dim3(256), 0, st, fwd, net->params, net->io_snap[0], net->io_snap[1],
+                       (long long)net->P, net->io_mb_dev);
+  } else {
+    hipLaunchKernelGGL(io_publish_kernel, dim3(256), dim3(256), 0, st, fwd, net->params, (long long)net->P, net->io_mb_dev);
+  }
   XT_LAUNCH_CHECK();
   return 0;
 }
@@ -1244,7 +1282,7 @@ static int io_tail_enqueue(xt_net* net, float* loss_acc, hipStream_t st) {
 
 static int impala_train_run(xt_net* net, const xt_impala_cfg* c, const void* obs, int32_t n, int32_t batch_size,
                             const float* bp_logits, const int32_t* action, const uint8_t* done, const float* reward,
-                            const float* lr_steps, float* loss_acc, int32_t use_graph, bool io_tail, void* stream) {
+                            const float* lr_steps, float* loss_acc, int32_t use_graph, int io_tail, void* stream) {
   XT_REQUIRE(net && c && obs && bp_logits && action && done && reward && loss_acc, "xt_net_impala_train: null argument");
   XT_REQUIRE(net->params && net->ws, "xt_net_impala_train: buffers not bound");
   const int T = c->sample_batch_step;
@@ -1262,7 +1300,7 @@ static int impala_train_run(xt_net* net, const xt_impala_cfg* c, const void* obs
     if (int rc = impala_train_enqueue(net, c, obs, n, batch_size, bp_logits, action, done, reward, lr_steps,
                                       io_tail ? net->ws + net->off_ioacc : loss_acc, cs, /*clear*/ !io_tail))
       return rc;
-    return io_tail ? xt::io_tail_enqueue(net, loss_acc, cs) : 0;
+    return io_tail ? xt::io_tail_enqueue(net, loss_acc, io_tail, cs) : 0;
   };
   if (!use_graph) return enqueue(st);
   char key[512];
@@ -1270,14 +1308,14 @@ static int impala_train_run(xt_net* net, const xt_impala_cfg* c, const void* obs
            c->shard_rank, c->shard_world, net->dp_rank, net->dp_world, (void*)net->direct, (void*)net->xchg, net->xchg_user, obs, n, batch_size, (const void*)bp_logits, (const void*)action,
            (const void*)done, (const void*)reward, (const void*)lr_steps, (void*)loss_acc, c->lr, c->beta1, c->beta2,
            c->eps, c->grad_norm_clip, c->gamma, c->sample_batch_step, c->grad_scale, c->opt_type, c->rms_decay, c->rms_eps,
-           io_tail ? (void*)net->io_mb_dev : nullptr);
+           io_tail ? (void*)(reinterpret_cast<char*>(net->io_mb_dev) + io_tail) : nullptr);
   return xt::graph_run(net, key, st, enqueue);
 }
 
 int xt_net_impala_train(xt_net* net, const xt_impala_cfg* c, const void* obs, int32_t n, int32_t batch_size,
                         const float* bp_logits, const int32_t* action, const uint8_t* done, const float* reward,
                         const float* lr_steps, float* loss_acc, int32_t use_graph, void* stream) {
-  return impala_train_run(net, c, obs, n, batch_size, bp_logits, action, done, reward, lr_steps, loss_acc, use_graph, false,
+  return impala_train_run(net, c, obs, n, batch_size, bp_logits, action, done, reward, lr_steps, loss_acc, use_graph, 0,
                           stream);
 }
 
@@ -1309,6 +1347,7 @@ int xt_net_impala_train_io(xt_net* net, const xt_impala_cfg* c, const void* obs,
   hipStream_t st = xt::as_stream(stream);
   XT_REQUIRE(net, "xt_net_impala_train_io: null net");
   const bool tail = io && io->tail_in_graph && io->wait_loss && io->loss_host;
+  const int mode = !tail ? 0 : (io->tail_in_graph == 2 ? 2 : 1);    // 2: snapshot in the graph, the runtime's D2H on the side stream
   const auto t_begin = std::chrono::steady_clock::now();
   // the rollout's copies: usually long done (they ran under the previous train) -- then there is nothing to wait for and the
   // stream is spared a cross-stream barrier in front of the train
@@ -1327,13 +1366,25 @@ int xt_net_impala_train_io(xt_net* net, const xt_impala_cfg* c, const void* obs,
       net->io_mb = static_cast<xt::IoMailbox*>(h);
       net->io_mb_dev = static_cast<xt::IoMailbox*>(d);
     }
+    if (mode == 2 && !net->io_snap[0])
+      for (int k = 0; k < 2; ++k)
+        XT_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->io_snap[k]), sizeof(float) * (size_t)xt::align4(net->P)));
     float* d = io->publish_dst ? xt::host_device_ptr(io->publish_dst) : nullptr;
-    published = d && (reinterpret_cast<uintptr_t>(d) & 15) == 0;
+    published = mode == 2 ? io->publish_dst != nullptr : (d && (reinterpret_cast<uintptr_t>(d) & 15) == 0);
+    if (mode == 2 && published && !d) d = io->publish_dst;      // (only "a destination exists" travels through the mailbox)
     seq = ++net->io_seq;
     if (seq == 0) seq = ++net->io_seq;       // (0 is what an untouched mailbox holds)
     net->io_mb->publish_dst = published ? reinterpret_cast<unsigned long long>(d) : 0ull;
     net->io_mb->seq = seq;
     __atomic_thread_fence(__ATOMIC_SEQ_CST);  // the mailbox is written before the launch's doorbell
+    if (mode == 2 && published) {
+      // the snapshot buffer of this parity is free once the copy of the publish that owns it has left it -- long ago,
+      // normally; otherwise it is made here and now (nobody waited for that publish yet)
+      if (const uint32_t owner = net->io_snap_owner[seq & 1].load())
+        if (int rc = xt_net_io_publish_wait(net, owner, -1)) return rc;
+      net->io_dst[seq & 1] = io->publish_dst;
+      net->io_snap_owner[seq & 1].store(seq);
+    }
     if (!net->io_acc_clean) {                 // first use / after a rebind or a failed enqueue: zero the accumulator once
       XT_CHECK_HIP(hipMemsetAsync(net->ws + net->off_ioacc, 0, 2 * sizeof(float), st));
       XT_CHECK_HIP(hipMemsetAsync(net->ws + net->off_ioacc + 2, 0, 2 * sizeof(float), st));
@@ -1341,7 +1392,7 @@ int xt_net_impala_train_io(xt_net* net, const xt_impala_cfg* c, const void* obs,
     net->io_acc_clean = false;
   }
   const auto t_pre = std::chrono::steady_clock::now();
-  if (int rc = impala_train_run(net, c, obs, n, batch_size, bp_logits, action, done, reward, lr_steps, loss_acc, use_graph, tail,
+  if (int rc = impala_train_run(net, c, obs, n, batch_size, bp_logits, action, done, reward, lr_steps, loss_acc, use_graph, mode,
                                 stream))
     return rc;
   if (!io) return 0;
@@ -1366,7 +1417,11 @@ int xt_net_impala_train_io(xt_net* net, const xt_impala_cfg* c, const void* obs,
     }
     if (io->loss_event) XT_CHECK_HIP(hipEventRecord(static_cast<hipEvent_t>(io->loss_event), st));
   }
-  if (io->publish_dst) {
+  if (io->publish_dst && mode == 2) {
+    // (the copy snapshot -> publish_dst is made by whoever waits for this publish: xt_net_io_publish_wait)
+    XT_REQUIRE(!io->publish_event, "xt_net_impala_train_io: tail_in_graph = 2 reports a publish through xt_net_io_publish_wait, "
+                                   "not through an event");
+  } else if (io->publish_dst) {
     if (!published) {
       float* d = xt::host_device_ptr(io->publish_dst);
       if (d && (reinterpret_cast<uintptr_t>(d) & 15) == 0) {
@@ -1407,11 +1462,33 @@ uint32_t xt_net_io_seq(const xt_net* net) { return net ? net->io_seq : 0u; }
 
 int xt_net_io_publish_wait(xt_net* net, uint32_t seq, int32_t timeout_ms) {
   XT_REQUIRE(net && net->io_mb, "xt_net_io_publish_wait: no train with tail_in_graph has been enqueued on this net");
-  const uint32_t* word = &net->io_mb->publish_seq;
+  const int b = seq & 1;
+  auto landed = [&] { const uint32_t c = net->io_copied[b].load(std::memory_order_acquire); return c != 0 && (int32_t)(c - seq) >= 0; };
+  if (landed()) return 0;
+  // a tail_in_graph = 2 publish (it owns its parity's snapshot buffer): wait for the snapshot's report, then the SDMA copy is
+  // made HERE, by the first thread that comes for it; otherwise the in-graph copy kernel's own report is awaited
+  const bool snap = net->io_snap_owner[b].load() == seq;
+  if (snap && timeout_ms == 0) return 1;                     // (the query form does not start the copy)
+  const uint32_t* word = snap ? &net->io_mb->snap_seq : &net->io_mb->publish_seq;
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spins = 1;; ++spins) {
-    if ((int32_t)(__atomic_load_n(word, __ATOMIC_ACQUIRE) - seq) >= 0) return 0;
-    if (timeout_ms == 0) return 1;           // (query form: not yet)
+    if (snap && landed()) return 0;
+    if ((int32_t)(__atomic_load_n(word, __ATOMIC_ACQUIRE) - seq) >= 0) {
+      if (!snap) return 0;
+      uint32_t claimed = net->io_copying[b].load();
+      if ((int32_t)(claimed - seq) < 0 && net->io_copying[b].compare_exchange_strong(claimed, seq)) {
+        const size_t bytes = sizeof(float) * (size_t)net->P;
+        if (xt::sdma_copy_d2h(net->io_dst[b], net->io_snap[b], bytes, &net->io_sig[b]) != nullptr) {
+          // this process cannot (no HSA runtime to be had): the runtime's synchronous copy, a blit kernel
+          XT_CHECK_HIP(hipMemcpy(net->io_dst[b], net->io_snap[b], bytes, hipMemcpyDeviceToHost));
+        }
+        net->io_copied[b].store(seq, std::memory_order_release);
+        return 0;
+      }
+      // (another thread is making this copy: wait for it below)
+    } else if (timeout_ms == 0) {
+      return 1;                                              // (query form: not yet)
+    }
     __builtin_ia32_pause();
     if ((spins & 0xfff) == 0) {
       if (timeout_ms > 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms)) return 1;

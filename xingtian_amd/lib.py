@@ -148,6 +148,7 @@ SIGNATURES = {
                                          POINTER(TrainIO), _P]),
     "xt_net_io_times": (c_int32, [_P, POINTER(c_double), POINTER(c_int64), c_int32]),
     "xt_net_io_wait": (c_int32, [_P, _P, _P]),
+    "xt_sdma_copy_d2h": (c_int32, [_P, _P, c_int64]),
     "xt_net_io_seq": (ctypes.c_uint32, [_P]),
     "xt_net_io_publish_wait": (c_int32, [_P, ctypes.c_uint32, c_int32]),
 }

@@ -507,7 +507,7 @@ class HipActorCritic(object):
         tail = bool(tail_in_graph and sync)
         deferred = bool(defer and tail)
         io.loss_host, io.loss_event, io.wait_loss = rb["ptr"][i], rb["raw"][i], (2 if deferred else 1) if sync else 0
-        io.tail_in_graph = 1 if tail else 0
+        io.tail_in_graph = (2 if int(tail_in_graph) == 2 else 1) if tail else 0      # (2: snapshot + side-stream D2H)
         ptr = L.ptr
         # the staging thread may work while this thread is inside C with the GIL released -- in the deferred form only from
         # impala_wait_loss() on: the launch is ~15 us and the book-keeping behind it needs the GIL to itself (two Python

@@ -62,7 +62,10 @@ class ImpalaCnnOpt(XTModel):
         self.zero_copy_labels = bool(model_config.get("ZERO_COPY_LABELS", True)) and not self.async_loss
         # IO_TAIL_IN_GRAPH (default on; synchronous loss only): the loss read-back and the weights-ring copy are the train's own
         # last kernels inside its replayed hipGraph, the loss is awaited by polling a page-locked word (xt_train_io.tail_in_graph)
-        self.io_tail_in_graph = bool(model_config.get("IO_TAIL_IN_GRAPH", True))
+        # (2: the weights copy leaves the graph again -- a device-side snapshot is the train's last kernel and the bus-bound
+        # copy snapshot -> ring slot runs on the SDMA engine UNDER THE NEXT TRAIN, issued through the HSA runtime by the ring's
+        # committer thread when it waits for the publish: csrc/xt_sdma.hip)
+        self.io_tail_in_graph = int(model_config.get("IO_TAIL_IN_GRAPH", 2))
         # HIP streams the frames of consecutive messages alternate between (joined by two event calls per train): ONE for an
         # IMPALA learner -- its few messages per train share the bus anyway, and the join costs the staging thread ~10 us
         self.ingest_copy_streams = int(model_config.get("INGEST_COPY_STREAMS", 1))
@@ -184,7 +187,7 @@ class ImpalaCnnOpt(XTModel):
         # No event records behind the graph either (each delays the NEXT graph on the stream): the buffer set is consumed once
         # the loss has been seen (the loss kernel runs behind every kernel that reads it), the parameter copy reports its own
         # completion through the mailbox (net.io_publish_done()).
-        defer = self.io_tail_in_graph and not self.async_loss
+        defer = bool(self.io_tail_in_graph) and not self.async_loss
         a = self.net.impala_train_io(self._cfg, d["obs"][:n], batch_size, lab["logit"], lab["action"], lab["done"],
                                      lab["reward"], lr_steps=lr_steps, use_graph=self.use_graph, wait_event=ing.last.done,
                                      consumed_event=None if defer else ing.consumed_event(),
@@ -196,6 +199,8 @@ class ImpalaCnnOpt(XTModel):
                 ing.last.free = None             # (host-confirmed below: impala_wait_loss returns behind the loss kernel)
             if ticket is not None:
                 if a is None:
+                    # the ring's committer thread waits through the mailbox: for the in-graph copy kernel's report (mode 1),
+                    # or for the snapshot's and then makes the SDMA copy itself, under the next train (mode 2)
                     ticket = ticket[:5] + (self.net.io_publish_done(),)
                 ring.publish_enqueued(ticket)
                 self.net._wring_version = getattr(self.net, "_version", 0)
