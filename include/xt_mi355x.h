@@ -595,7 +595,7 @@ int xt_net_impala_train(xt_net* net, const xt_impala_cfg* cfg, const void* obs, 
  *                   0.29 vs 0.27 ms per 128-frame train --, and the same D2H enqueued later by a helper thread serialises with
  *                   the learner thread's next launch.)
  *   tail_in_graph   (ABI >= 12; honoured with wait_loss != 0 and loss_host set; wait_loss == 2: do not wait, see xt_net_io_wait)
- *                   the loss read-back and the parameter copy become the last two KERNELS OF THE TRAIN ITSELF -- inside the
+ *                   1: the loss read-back and the parameter copy become the last two KERNELS OF THE TRAIN ITSELF -- inside the
  *                   replayed hipGraph, whose kernel arguments are fixed: the learner thread writes {destination, sequence
  *                   number} into a 64-byte page-locked mailbox the library owns; the first tail kernel reads the mailbox
  *                   over the bus, writes the loss sums + the sequence number back into it (and the sums to loss_acc) and hands
@@ -603,12 +603,19 @@ int xt_net_impala_train(xt_net* net, const xt_impala_cfg* cfg, const void* obs, 
  *                   it has seen the loss).  The chunks of such a train accumulate into 4 floats of the workspace that the loss
  *                   kernel re-arms: the graph holds no memset node.  The call returns when the sequence number has landed (a
  *                   bounded poll of the page-locked word, stream health checked every ~0.3 ms) and has copied the 4 floats to
- *                   loss_host.  consumed_event / publish_event are recorded behind the graph; loss_event is not used.  What
- *                   it removes (rocprofv3 traces of the loop, round 6): the 19-27 us between a replayed graph and the next
- *                   launch on the stream (twice), the wake-up of hipEventSynchronize, and -- because the learner thread learns
- *                   of the loss while the 73 us parameter copy is still running -- the host's share of the next train's
- *                   launch.  (Measured and rejected, again: the parameter copy from a device-side snapshot on a low-priority
- *                   side stream under the next train -- the next graph still starts only after that kernel, DESIGN.md s. 4.)
+ *                   loss_host.  consumed_event / publish_event are optional (an event record behind a replayed graph costs the
+ *                   next graph ~10 us: the train's inputs are consumed once its loss has been seen, and the copy kernel reports
+ *                   its own completion, xt_net_io_publish_wait); loss_event is not used.
+ *                   2: the parameter copy leaves the GPU's critical path: the train's last kernel is a device-side SNAPSHOT
+ *                   (params -> one of two buffers of the library, ~5 us, reported through the mailbox), and the 80 us bus-bound
+ *                   copy snapshot -> publish_dst runs on the SDMA ENGINE under the next train, issued through the HSA runtime
+ *                   by whoever calls xt_net_io_publish_wait for that train (a weights ring's committer thread; the learner
+ *                   thread itself when it needs the buffer back, two publishes later).  publish_event must be NULL.  Why not a
+ *                   copy kernel or hipMemcpyAsync on a side stream: csrc/xt_sdma.hip (both measured, round 6).
+ *                   What 1 / 2 remove (rocprofv3 traces of the 128-frame loop): the 19-27 us between a replayed graph and the
+ *                   next launch on the stream (twice), the wake-up of hipEventSynchronize, the host's share of the next
+ *                   train's launch, and (2) the 74 us copy from between two trains: 210-235 -> ~194 (1) -> ~130 us of GPU time
+ *                   per train + publish.
  * Events are hipEvent_t handles (e.g. torch.cuda.Event.cuda_event). */
 typedef struct xt_train_io {
   void* wait_event;
@@ -634,7 +641,9 @@ int xt_net_io_wait(xt_net* net, float* loss_host4, void* stream);
  * a replayed graph delay the next graph on the stream by ~20 us) still learns when the block at publish_dst is complete:
  * xt_net_io_seq = sequence number of the most recent tail_in_graph train of this net (read it right behind the launch);
  * xt_net_io_publish_wait returns 0 once the copy of train `seq` (or a later one) has landed, 1 when timeout_ms ran out
- * (0 = query, < 0 = no limit).  The train's inputs are consumed once its loss has been seen (the loss kernel runs behind every
+ * (0 = query, < 0 = no limit).  For a tail_in_graph = 2 train it waits for the snapshot's report and then MAKES the copy (SDMA
+ * engine, synchronous for the caller; the first thread that comes for a publish makes it, others wait for it; the query form
+ * never starts it).  The train's inputs are consumed once its loss has been seen (the loss kernel runs behind every
  * kernel that reads them). */
 uint32_t xt_net_io_seq(const xt_net* net);
 int xt_net_io_publish_wait(xt_net* net, uint32_t seq, int32_t timeout_ms);
