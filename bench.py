@@ -891,6 +891,9 @@ def bench_impala(key, steps, warmup, with_cpu, in_graph=False, quick=False):
     out["e2e_ring_blocking"] = dict(impala_ring_loop(w, fm, msgs_per_train, tpc, n_prod=2, seconds=0.7, prefetch=False,
                                                      async_commit=False),
                                     path="the same rings, learner thread receives + waits for the weights D2H itself")
+    out["e2e_ring_prefetch_python_lists"] = dict(impala_ring_loop(w, fm, msgs_per_train, tpc, n_prod=2, seconds=0.7, pack_lists=False),
+                                                 path="as e2e_ring_prefetch, done / reward on the wire as python lists (msgpack): "
+                                                      "the sender did not use transport.encode(pack_lists=True)")
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline_impala(w, data)
     return out
@@ -1009,7 +1012,7 @@ def bench_env_num_256(spec, dev, updates=3):
 
 
 def impala_ring_loop(w, fm, msgs_per_train, tpc, n_prod, seconds, prefetch=True, async_commit=True, pinned=True, slots=4,
-                     min_trains=20, gate=True, model_config=None):
+                     min_trains=20, gate=True, model_config=None, pack_lists=True, strict=False):
     """The IMPALAOpt plugin pair fed as a learner is fed (xt/framework/learner.py:298-380): `n_prod` producer PROCESSES push
     pre-encoded rollout messages of `fm` frames into their own shared-memory ring (transport.RingSet); the learner loop is
     the reference's -- recv + prepare_data x msgs_per_train -> train() -> every tpc-th train the weights go out.
@@ -1021,8 +1024,12 @@ def impala_ring_loop(w, fm, msgs_per_train, tpc, n_prod, seconds, prefetch=True,
     from xingtian_amd import transport
     from xingtian_amd.algorithm import alg_builder
     data = synth_impala(11, fm, w["dim"], w["a_dim"])
+    # done / reward leave the agent as per-step python lists (xt/agent/impala); pack_lists: the SENDER ships them as typed arrays
+    # (transport.encode(pack_lists=True), an explorer-side option of this transport) -- the learner's serial staging thread then
+    # gets zero-copy views instead of 2 x T boxed scalars through msgpack + np.asarray per message
     wire = bytes(transport.encode({"cmd": "train"}, {"cur_state": data["obs"], "logit": data["logit"], "action": data["action"],
-                                                     "done": list(data["done"]), "reward": list(data["reward"])}))
+                                                     "done": list(data["done"]), "reward": list(data["reward"])},
+                                  pack_lists=pack_lists))
     slot_bytes = (len(wire) + (1 << 16)) // 4096 * 4096
     ctx = mp.get_context("fork")
     try:
@@ -1056,7 +1063,7 @@ def impala_ring_loop(w, fm, msgs_per_train, tpc, n_prod, seconds, prefetch=True,
     if wpin and async_commit:
         wring.start_committer()
         alg.actor.net.attach_weights_ring(wring)
-    src = transport.Prefetcher(rs, alg, gate=gate) if prefetch else rs
+    src = transport.Prefetcher(rs, alg, gate=gate, strict=strict) if prefetch else rs
     sink = lambda d_, ctr_info=None: alg.prepare_data(d_, ctr_info=ctr_info)   # noqa: E731
     trains = 0
     t_recv = t_train = t_w = 0.0
@@ -1094,6 +1101,7 @@ def impala_ring_loop(w, fm, msgs_per_train, tpc, n_prod, seconds, prefetch=True,
                "ms_per_train": 1e3 * el / trains, "recv_prepare_ms": 1e3 * t_recv / trains, "train_ms": 1e3 * t_train / trains,
                "weights_ms": 1e3 * t_w / trains, "train_per_checkpoint": tpc, "producers": n_prod,
                "pinned_rings": is_pinned, "prefetch": bool(prefetch), "async_weights_commit": bool(wpin and async_commit),
+               "lists_packed_by_sender": bool(pack_lists),
                "served_min_max": [int(min(rs.served)), int(max(rs.served))]}
     except Exception as exc:      # noqa: BLE001
         out = {"error": repr(exc)[:200]}

@@ -626,6 +626,7 @@ typedef struct xt_train_io {
   void* publish_event;
   int32_t wait_loss;
   int32_t tail_in_graph;
+  uint64_t wait_dma_ticket;   /* != 0: the call waits (host side, before the launch) for xt_dma_wait_upto(ticket) */
 } xt_train_io;
 int xt_net_impala_train_io(xt_net* net, const xt_impala_cfg* cfg, const void* obs, int32_t n, int32_t batch_size,
                            const float* bp_logits, const int32_t* action, const uint8_t* done, const float* reward,
@@ -653,6 +654,16 @@ int xt_net_io_publish_wait(xt_net* net, uint32_t seq, int32_t timeout_ms);
  * allocation; the caller has made sure the source is complete (no stream is involved).  Diagnostic / test entry: the library
  * uses the same copy for the parameter block of xt_net_impala_train_io (tail_in_graph = 2). */
 int xt_sdma_copy_d2h(void* dst_host, const void* src_dev, int64_t bytes);
+
+/* Asynchronous page-locked-host -> device copies on the SDMA engines through the HSA runtime, with TICKETS instead of streams and
+ * events (ABI >= 12): the rollout ingest's per-message H2D (hipMemcpyAsync + the event records around it cost the staging thread
+ * ~30 us per message; this ~5).  xt_dma_h2d_async starts one copy and returns its ticket (tickets count up from 1; at most 64 in
+ * flight); xt_dma_wait_upto returns 0 once EVERY copy with a ticket <= `ticket` has landed, 1 when timeout_ms ran out (0 = query,
+ * < 0 = no limit).  No ordering against any HIP stream: the caller knows that the destination is free (xt_train_io: a train's
+ * inputs are consumed once its loss has been seen) and waits for the ticket before it launches what reads the data
+ * (xt_train_io.wait_dma_ticket). */
+int xt_dma_h2d_async(void* dst_dev, const void* src_host, int64_t bytes, uint64_t* ticket_out);
+int xt_dma_wait_upto(uint64_t ticket, int32_t timeout_ms);
 
 /* diagnostic (ABI >= 12): host time (us, accumulated over *calls_out calls with a non-NULL io) of xt_net_impala_train_io's
  * phases -- [0] before the launch (wait for the copies, mailbox), [1] the launch (hipGraphLaunch, or the eager enqueue), [2] the

@@ -7,6 +7,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import torch  # noqa: E402
 import bench  # noqa: E402
 from xingtian_amd import ingest, transport  # noqa: E402
 from xingtian_amd.model import hip_net  # noqa: E402
@@ -39,6 +40,7 @@ _init = hip_net.HipActorCritic.__init__
 
 def _init_keep(self, *a, **k):
     _init(self, *a, **k)
+    self.gate_at_launch = "gatewait" not in sys.argv[2:]
     NETS.append(self)
 
 
@@ -58,6 +60,29 @@ wrap(impala_cnn_opt.ImpalaCnnOpt, "train_ingested")
 wrap(impala_cnn_opt.ImpalaCnnOpt, "_lr_steps")
 wrap(impala_opt.IMPALAOpt, "train")
 wrap(impala_opt.IMPALAOpt, "stage_message")
+wrap(ingest.RolloutIngest, "_ensure")
+wrap(ingest.RolloutIngest, "seal")
+wrap(ingest.RolloutIngest, "_join_copy_streams")
+import numpy as _np  # noqa: E402
+from xingtian_amd import lib as _L  # noqa: E402
+for _mod, _name in ((_L, "memcpy_async"), (ingest.np, "copyto"), (ingest.np, "asarray")):
+    _fn = getattr(_mod, _name)
+
+    def _timed(*a, _fn=_fn, _key="fn." + _name, **k):
+        t0 = time.perf_counter()
+        try:
+            return _fn(*a, **k)
+        finally:
+            d = T.setdefault(_key, [0.0, 0])
+            d[0] += time.perf_counter() - t0
+            d[1] += 1
+    if _mod is _L:
+        ingest.L.memcpy_async = _timed
+    else:
+        pass    # (numpy functions are shared module attributes: timed through their callers only)
+wrap(torch.cuda.Event, "record", "Event.record")
+wrap(torch.cuda.Event, "query", "Event.query")
+wrap(torch.cuda.Stream, "wait_event", "Stream.wait_event")
 wrap(impala_opt.IMPALAOpt, "stage_group_complete")
 wrap(transport.Prefetcher, "_stage")
 wrap(transport.RingSet, "poll_into")
@@ -90,7 +115,7 @@ mpt = w.get("msgs_per_train", 1 if key == "breakout_impala" else 4)
 res = bench.impala_ring_loop(w, w["frames_per_train"] // mpt, mpt, w.get("train_per_checkpoint", 1), n_prod=2, seconds=1.0,
                              prefetch=(len(sys.argv) < 3 or sys.argv[2] != "blocking"),
                              async_commit=(len(sys.argv) < 3 or sys.argv[2] != "blocking"),
-                             gate=(len(sys.argv) < 3 or sys.argv[2] != "nogate"),
+                             gate=(len(sys.argv) < 3 or sys.argv[2] != "nogate"), pack_lists="pylists" not in sys.argv[2:], strict="nostrict" not in sys.argv[2:],
                              model_config={"IO_TAIL_IN_GRAPH": 0 if "notail" in sys.argv[2:] else 1 if "ingraph" in sys.argv[2:] else 2, "USE_HIP_GRAPH": "nograph" not in sys.argv[2:],
                                            "INGEST_COPY_STREAMS": 2 if "cs2" in sys.argv[2:] else 1})
 print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in res.items()})

@@ -1355,6 +1355,9 @@ int xt_net_impala_train_io(xt_net* net, const xt_impala_cfg* c, const void* obs,
     (void)hipGetLastError();
     XT_CHECK_HIP(hipStreamWaitEvent(st, static_cast<hipEvent_t>(io->wait_event), 0));
   }
+  if (io && io->wait_dma_ticket)
+    XT_REQUIRE(xt_dma_wait_upto(io->wait_dma_ticket, 30000) == 0, "xt_net_impala_train_io: the rollout's copies (ticket %llu) did "
+               "not land within 30 s", (unsigned long long)io->wait_dma_ticket);
   bool published = false;
   uint32_t seq = 0;
   if (tail) {

@@ -78,11 +78,28 @@ class _BufferSet(object):
         self.host_np = {k: v.numpy() for k, v in self.host.items()}
         self.done = torch.cuda.Event()
         self.free = None          # recorded on the compute stream after the update that read this set
+        self.dma_ticket = 0       # newest xt_dma_h2d_async copy into this set (RolloutIngest.dma_h2d); 0 = none
+        self.used_stream = False  # a copy of the current rollout went through a HIP copy stream (then `done` matters)
 
 
 # extra label fields of a trajectory that arrives WITHOUT advantages (value / reward / done instead): the inputs of the
 # learner-side GAE (xt/agent/ppo/ppo.py:77-106 moved to the learner GPU, one xt_gae_f64_ragged per rollout)
 PPO_RAW_FIELDS = (("reward", torch.float64, 0), ("done", torch.uint8, 0), ("boot", torch.float32, 0))
+
+
+class _DmaDone(object):
+    """completion handle of an ``xt_dma_h2d_async`` copy with the two methods a ``transport.SlotGuard`` calls on an event"""
+    __slots__ = ("lib", "ticket")
+
+    def __init__(self, lib, ticket):
+        self.lib, self.ticket = lib, ticket
+
+    def query(self):
+        return self.lib.xt_dma_wait_upto(self.ticket, 0) == 0
+
+    def synchronize(self):
+        if self.lib.xt_dma_wait_upto(self.ticket, 30000) != 0:
+            raise RuntimeError("xingtian_amd: a rollout copy (ticket {}) did not land within 30 s".format(self.ticket))
 
 
 class RolloutIngest(object):
@@ -118,6 +135,10 @@ class RolloutIngest(object):
         # (rocprofv3 trace of the loop, round 6)
         self.zero_copy_labels = False
         self.generation = 0             # rollouts handed to the learner so far (finish() calls)
+        # dma_h2d (set by the model: ImpalaCnnOpt with zero-copy labels): frames that sit in page-locked transport slots go
+        # to HBM through xt_dma_h2d_async -- the SDMA engines through the HSA runtime, tickets instead of streams and events
+        # (hipMemcpyAsync costs the staging thread ~20 us per message, the event records around it ~12 more)
+        self.dma_h2d = False
         self.on_finish = None           # callable: a transport.Prefetcher staging one train ahead is woken here
         self._lib = L.load()            # (the staging-copy variant for this host is picked on the first host copy)
 
@@ -157,9 +178,14 @@ class RolloutIngest(object):
         obs = np.asarray(obs)
         t = obs.shape[0]
         s = self._ensure(self.n + t, obs)
-        if self.n == 0 and s.free is not None:      # do not overwrite a set an enqueued update still reads
-            for cs in self.copy_streams:
-                cs.wait_event(s.free)
+        dma = bool(self.dma_h2d and pinned and self.zero_copy_labels and not _raw)
+        if self.n == 0:
+            s.used_stream = False
+            if s.free is not None:      # do not overwrite a set an enqueued update still reads
+                if dma:
+                    s.free.synchronize()        # (no stream to order against; with the in-graph tail `free` is None here)
+                for cs in self.copy_streams:
+                    cs.wait_event(s.free)
         cstream = self.copy_streams[self._rr % len(self.copy_streams)]
         self._rr += 1
         lo, hi = self.n, self.n + t
@@ -180,9 +206,20 @@ class RolloutIngest(object):
         row_bytes = obs_dst.dtype.itemsize * int(np.prod(obs_dst.shape[1:], dtype=np.int64))
         dev_ptr = s.dev["obs"].data_ptr() + lo * row_bytes
         plain = obs.dtype == obs_dst.dtype and obs.flags.c_contiguous and obs.size == obs_dst.size
-        if pinned and plain:
+        if pinned and plain and dma:
+            # ... and no stream either: one asynchronous SDMA copy with a ticket
+            tk = ctypes.c_uint64()
+            L.check(self._lib.xt_dma_h2d_async(ctypes.c_void_p(dev_ptr), ctypes.c_void_p(obs.ctypes.data), obs.nbytes,
+                                               ctypes.byref(tk)), "xt_dma_h2d_async")
+            s.dma_ticket = int(tk.value)
+            if slot_guard is not None:      # the ring keeps the slot until the copy has landed: no wait here
+                slot_guard.hold(_DmaDone(self._lib, s.dma_ticket))
+            else:
+                _DmaDone(self._lib, s.dma_ticket).synchronize()
+        elif pinned and plain:
             # DMA source = the pinned transport slot: no host copy at all; the caller recycles the slot right after.  One raw
             # hipMemcpyAsync (a torch copy_ under a stream context costs ~40 us of Python per message) and pooled events
+            s.used_stream = True
             L.memcpy_async(dev_ptr, obs.ctypes.data, obs.nbytes, L.H2D, cstream)
             if slot_guard is not None:      # the ring keeps the slot until this event has fired: no wait here
                 pool = getattr(self, "_guard_events", None)
@@ -201,6 +238,7 @@ class RolloutIngest(object):
             else:
                 cstream.synchronize()
         elif plain:
+            s.used_stream = True
             if not _TUNED:
                 staging_report()        # measure the host's copy variants once per process, on first use
             # an IMPALA message of a few MB (one 128-step Atari trajectory: 3.6 MB) ships in 1 MiB pieces, so that its H2D runs
@@ -212,6 +250,7 @@ class RolloutIngest(object):
                                             ctypes.c_void_p(obs.ctypes.data), obs.nbytes, ctypes.c_void_p(dev_ptr), 0, ship, -1,
                                             ctypes.c_void_p(cstream.cuda_stream)), "xt_stage_rows")
         else:       # a cast on the way in (float frames for a uint8 network, ...): as the upload path casts them
+            s.used_stream = True
             np.copyto(obs_dst, obs.reshape(obs_dst.shape), casting="unsafe")
             with torch.cuda.stream(cstream):
                 s.dev["obs"][lo:hi].copy_(s.host["obs"][lo:hi], non_blocking=True)
@@ -283,7 +322,8 @@ class RolloutIngest(object):
         if self.pad_channels is not None and s.dev["obs"].shape[-1] != self.pad_channels[0]:
             return                              # (the channel padding runs in finish, in front of the event)
         self.ship_labels()
-        s.done.record(self.copy_stream)
+        if s.used_stream or not self.zero_copy_labels:
+            s.done.record(self.copy_stream)
         s.sealed_n = self.n
 
     def finish(self, wait_on_stream=True):
@@ -309,14 +349,21 @@ class RolloutIngest(object):
             if s.dev_padded is None:
                 s.dev_padded = torch.empty(tuple(src.shape[:-1]) + (c_dst,), dtype=src.dtype, device=src.device)
             rows = n * int(np.prod(src.shape[1:-1], dtype=np.int64))
+            if s.dma_ticket:                    # (ticketed copies are ordered against no stream: they have to be over first)
+                _DmaDone(self._lib, s.dma_ticket).synchronize()
             L.check(self._lib.xt_pad_channels(L.ptr(src), L.ptr(s.dev_padded), rows, int(src.shape[-1]), c_dst,
                                               src.element_size(), int(fill),
                                               ctypes.c_void_p(self.copy_stream.cuda_stream)), "xt_pad_channels")
             dev = dict(s.dev, obs=s.dev_padded)
-        if not sealed:
+        stream_copies = s.used_stream or not self.zero_copy_labels or self.raw_traj > 0 or dev is not s.dev
+        if not sealed and stream_copies:
             s.done.record(self.copy_stream)
         if wait_on_stream:
-            L.current_stream(self.device).wait_event(s.done)
+            if stream_copies:
+                L.current_stream(self.device).wait_event(s.done)
+            if s.dma_ticket:
+                _DmaDone(self._lib, s.dma_ticket).synchronize()
+        s.wait_stream = stream_copies        # (wait_on_stream=False: the caller waits for `done` iff this, and for dma_ticket)
         self.cur ^= 1
         self.n = 0
         self.last = s

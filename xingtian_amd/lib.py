@@ -68,7 +68,8 @@ class Tuning(Structure):
 class TrainIO(ctypes.Structure):
     """xt_train_io of include/xt_mi355x.h: the runtime calls around one train, folded into the train's C call"""
     _fields_ = [("wait_event", c_void_p), ("consumed_event", c_void_p), ("loss_host", c_void_p), ("loss_event", c_void_p),
-                ("publish_dst", c_void_p), ("publish_event", c_void_p), ("wait_loss", c_int32), ("tail_in_graph", c_int32)]
+                ("publish_dst", c_void_p), ("publish_event", c_void_p), ("wait_loss", c_int32), ("tail_in_graph", c_int32),
+                ("wait_dma_ticket", ctypes.c_uint64)]
 
 
 OPT_TYPE = {"adam": 0, "rmsprop": 1}
@@ -149,6 +150,8 @@ SIGNATURES = {
     "xt_net_io_times": (c_int32, [_P, POINTER(c_double), POINTER(c_int64), c_int32]),
     "xt_net_io_wait": (c_int32, [_P, _P, _P]),
     "xt_sdma_copy_d2h": (c_int32, [_P, _P, c_int64]),
+    "xt_dma_h2d_async": (c_int32, [_P, _P, c_int64, POINTER(ctypes.c_uint64)]),
+    "xt_dma_wait_upto": (c_int32, [ctypes.c_uint64, c_int32]),
     "xt_net_io_seq": (ctypes.c_uint32, [_P]),
     "xt_net_io_publish_wait": (c_int32, [_P, ctypes.c_uint32, c_int32]),
 }

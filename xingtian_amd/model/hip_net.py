@@ -467,7 +467,8 @@ class HipActorCritic(object):
         return self.loss_acc
 
     def impala_train_io(self, c, obs, batch_size, bp_logits, action, done, reward, lr_steps=None, use_graph=False,
-                        wait_event=None, consumed_event=None, publish=None, wait_loss=True, tail_in_graph=True, defer=False):
+                        wait_event=None, consumed_event=None, publish=None, wait_loss=True, tail_in_graph=True, defer=False,
+                        wait_dma_ticket=0):
         """``impala_train`` + the runtime calls of the learner loop around it in ONE C call (``xt_net_impala_train_io``): the
         compute stream waits for ``wait_event`` (the rollout's copies), ``consumed_event`` is recorded behind the train,
         ``loss_acc`` is copied into the next pinned read-back block and -- ``wait_loss`` -- awaited with the GIL released,
@@ -498,6 +499,7 @@ class HipActorCritic(object):
         i = rb["slot"]
         io = rb["io"]
         io.wait_event = wait_event.cuda_event if wait_event is not None else None
+        io.wait_dma_ticket = int(wait_dma_ticket)      # (xt_dma_h2d_async copies of the rollout: awaited before the launch)
         io.consumed_event = consumed_event.cuda_event if consumed_event is not None else None
         if publish is not None:
             io.publish_dst, io.publish_event = publish[0], publish[1]
@@ -512,7 +514,9 @@ class HipActorCritic(object):
         # the staging thread may work while this thread is inside C with the GIL released -- in the deferred form only from
         # impala_wait_loss() on: the launch is ~15 us and the book-keeping behind it needs the GIL to itself (two Python
         # threads hand it back and forth at every runtime call: measured, the 16 us C call took 56-67 us with the gate open)
-        gate = None if deferred else getattr(self, "idle_gate", None)
+        gate = getattr(self, "idle_gate", None)
+        if deferred and not getattr(self, "gate_at_launch", True):
+            gate = None
         if gate is not None:
             gate.set()
         try:
@@ -522,7 +526,7 @@ class HipActorCritic(object):
             if rc:
                 L.check(rc, "xt_net_impala_train_io")
         finally:
-            if gate is not None:
+            if gate is not None and not deferred:
                 gate.clear()
         rb["slot"] = i ^ 1
         rb["n"] += 1

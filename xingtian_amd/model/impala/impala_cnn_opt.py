@@ -69,6 +69,7 @@ class ImpalaCnnOpt(XTModel):
         # HIP streams the frames of consecutive messages alternate between (joined by two event calls per train): ONE for an
         # IMPALA learner -- its few messages per train share the bus anyway, and the join costs the staging thread ~10 us
         self.ingest_copy_streams = int(model_config.get("INGEST_COPY_STREAMS", 1))
+        self.ingest_dma = bool(model_config.get("INGEST_DMA", True))
         self._ingest = None
         self._dp = None
         self._lr_host = self._lr_dev = None
@@ -117,6 +118,8 @@ class ImpalaCnnOpt(XTModel):
             from xingtian_amd import lib as L
             probe = torch.empty(64, dtype=torch.uint8, pin_memory=True)
             self._ingest.zero_copy_labels = bool(self.zero_copy_labels) and L.host_device_ptr(probe.data_ptr()) is not None
+            # frames out of page-locked transport slots: SDMA copies with tickets (xt_dma_h2d_async), no stream, no events
+            self._ingest.dma_h2d = bool(self.ingest_dma) and self._ingest.zero_copy_labels
         return self._ingest
 
     def ingest_message(self, states, bp_logic_outs, actions, dones, rewards, pinned=False, slot_guard=None):
@@ -189,7 +192,9 @@ class ImpalaCnnOpt(XTModel):
         # completion through the mailbox (net.io_publish_done()).
         defer = bool(self.io_tail_in_graph) and not self.async_loss
         a = self.net.impala_train_io(self._cfg, d["obs"][:n], batch_size, lab["logit"], lab["action"], lab["done"],
-                                     lab["reward"], lr_steps=lr_steps, use_graph=self.use_graph, wait_event=ing.last.done,
+                                     lab["reward"], lr_steps=lr_steps, use_graph=self.use_graph,
+                                     wait_event=ing.last.done if getattr(ing.last, "wait_stream", True) else None,
+                                     wait_dma_ticket=ing.last.dma_ticket,
                                      consumed_event=None if defer else ing.consumed_event(),
                                      publish=None if ticket is None else (ticket[3], None if defer else ticket[4]),
                                      wait_loss=not self.async_loss, tail_in_graph=self.io_tail_in_graph, defer=defer)

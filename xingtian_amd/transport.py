@@ -59,11 +59,32 @@ def _plain(obj):
     return obj
 
 
-def _layout(ctr_info, data):
+def _as_typed_array(val):
+    """a python list / tuple of >= 8 bools, or of ints / floats, as the array ``np.asarray`` makes of it (bool, int64, float64);
+    None for anything else (nested, mixed with other types, short)"""
+    if not isinstance(val, (list, tuple)) or len(val) < 8:
+        return None
+    kinds = set(map(type, val))
+    if kinds == {bool} or kinds == {np.bool_} or kinds <= {bool, np.bool_}:
+        return np.asarray(val, dtype=np.bool_)
+    if kinds <= {int, float, np.float64, np.float32, np.int64, np.int32} and kinds:
+        arr = np.asarray(val)
+        return arr if arr.dtype != object and arr.ndim == 1 else None
+    return None
+
+
+def _layout(ctr_info, data, pack_lists=False):
     """-> (msgpack header bytes, byte offset of the array section, [(offset, nbytes, contiguous array)], total bytes)"""
     arrays, objects, metas = [], {}, []
     off = 0
     for key, val in data.items():
+        if pack_lists:
+            # SENDER-side option: per-step python lists (the agents ship done / reward that way, xt/agent/*) travel as typed
+            # arrays -- the learner's np.asarray(list) of every message (hundreds of boxed scalars through msgpack, ~20 us of
+            # its serial staging time per message) becomes a zero-copy view; 512 explorers pay 6 us each in parallel instead
+            packed = _as_typed_array(val)
+            if packed is not None:
+                val = packed
         if isinstance(val, np.ndarray) and val.dtype != object:
             arr = np.ascontiguousarray(val)            # (promotes 0-d to 1-d: the shape on the wire is the original one)
             metas.append([key, arr.dtype.str, list(val.shape), off, arr.nbytes])
@@ -86,19 +107,20 @@ def _write(view, header, base, arrays):
             view[base + aoff:base + aoff + nbytes] = arr.reshape(-1).view(np.uint8)
 
 
-def encode(ctr_info, data):
+def encode(ctr_info, data, pack_lists=False):
     """``data``: dict field -> ndarray | python object (the reference's train_data / weights dict).  Returns a
-    ``bytearray``: MAGIC | u32 header length | msgpack header | padding | array bytes (64-byte aligned each)."""
-    header, base, arrays, total = _layout(ctr_info, data)
+    ``bytearray``: MAGIC | u32 header length | msgpack header | padding | array bytes (64-byte aligned each).
+    ``pack_lists``: homogeneous numeric / bool lists travel as arrays (the receiver gets an ndarray where a list was sent)."""
+    header, base, arrays, total = _layout(ctr_info, data, pack_lists)
     buf = bytearray(total)
     _write(memoryview(buf), header, base, arrays)
     return buf
 
 
-def encode_into(view, ctr_info, data):
+def encode_into(view, ctr_info, data, pack_lists=False):
     """Encode straight into a writable buffer (a shared-memory slot): one copy per array, no intermediate message.
     Returns the encoded length; ValueError if the buffer is too small."""
-    header, base, arrays, total = _layout(ctr_info, data)
+    header, base, arrays, total = _layout(ctr_info, data, pack_lists)
     if total > len(view):
         raise ValueError("message of {} bytes exceeds the {}-byte buffer".format(total, len(view)))
     _write(view, header, base, arrays)
@@ -190,9 +212,9 @@ class ShmRing(object):
         return self.pinned
 
     # ---- producer side
-    def send(self, ctr_info, data, block=True, timeout=None):
+    def send(self, ctr_info, data, block=True, timeout=None, pack_lists=False):
         """Encode straight into the next free slot (ShareByPlasma.send / CommByZmq.send contract)."""
-        msg = encode(ctr_info, data)
+        msg = encode(ctr_info, data, pack_lists)
         return self.send_bytes(msg, block=block, timeout=timeout)
 
     def send_bytes(self, msg, block=True, timeout=None):
@@ -776,6 +798,48 @@ class WeightsRing(object):
             pass
 
 
+class _IdleGate(object):
+    """``threading.Event`` of the learner thread's idleness (``set`` while it is inside the train's C calls or waits for a
+    message) with STRICT ALTERNATION (``strict``): ``clear()`` -- the learner is about to run Python again -- first lets a
+    message that is being staged finish, instead of fighting it for the interpreter: two Python threads that both issue a
+    dozen short runtime calls hand the GIL back and forth at every one of them (round 6: the same loop ran 3.2-4.0 M
+    env-frames/s when the two did not collide and 2.0-2.2 M when they did).  OFF by default: measured same-box (4 x 2 runs)
+    2.81-3.57 M strict against 3.12-3.73 M without -- the wait it adds to the learner thread costs what the collisions do."""
+
+    def __init__(self, strict=False):
+        self._idle = threading.Event()
+        self._quiet = threading.Event()       # SET while no message is being staged
+        self._quiet.set()
+        self.strict = bool(strict)
+
+    def set(self):
+        self._idle.set()
+
+    def is_set(self):
+        return self._idle.is_set()
+
+    def wait(self, timeout=None):
+        return self._idle.wait(timeout)
+
+    def clear(self, wait_s=0.002):
+        self._idle.clear()
+        if self.strict and not self._quiet.is_set():
+            self._quiet.wait(wait_s)          # (bounded: a stuck staging thread surfaces through its own error path)
+
+    # ---- staging thread
+    def begin(self):
+        """-> may a message be staged now?  (announce first, then look again: either the learner's clear() sees the
+        announcement and waits, or this sees the cleared flag and backs off)"""
+        self._quiet.clear()
+        if self._idle.is_set():
+            return True
+        self._quiet.set()
+        return False
+
+    def end(self):
+        self._quiet.set()
+
+
 class Prefetcher(object):
     """Learner side of an ASYNCHRONOUS algorithm (IMPALA: explorers never wait for weights, the next rollout message is
     usually in the ring while the GPU still runs the current train).  The reference's learner thread receives and
@@ -790,7 +854,7 @@ class Prefetcher(object):
     way to HBM, in arrival order; ``alg.train()`` trains exactly the messages it would have been handed.  What changes is
     WHEN the copy happens, not what is trained or published."""
 
-    def __init__(self, source, alg, group=None, poll_s=0.0002, gate=True):
+    def __init__(self, source, alg, group=None, poll_s=0.0002, gate=True, strict=False):
         if not hasattr(alg, "stage_message"):
             raise TypeError("Prefetcher: {} has no stage_message (only streaming-ingest algorithms can be prefetched)".format(
                 type(alg).__name__))
@@ -803,7 +867,7 @@ class Prefetcher(object):
         # thread does its Python work then.  Two Python threads that both issue dozens of short runtime calls per train hand
         # the GIL back and forth at every one of them: measured round 6, every call of the learner's train() 2-3x slower
         # (graph launch 30 -> 78 us, weight snapshot 30 -> 86 us) and the prefetched loop no faster than the blocking one
-        self.learner_idle = threading.Event()
+        self.learner_idle = _IdleGate(strict)
         self.learner_idle.set()
         self.gate = bool(gate)              # False: the staging thread runs whenever a message is there (same-box A/B,
                                             # round 6: breakout_impala 1.3-1.6 M ungated vs 1.9-2.0 M gated, pong 10-11 vs 12-13 M)
@@ -842,13 +906,22 @@ class Prefetcher(object):
                             self._cv.wait(0.001)
                     if self._stop:
                         break
+                announced = False
                 if self.gate:
-                    self.learner_idle.wait(0.002)   # (bounded: a learner that never blocks must not starve the ingest)
-                if multi:
-                    room = self.group - self._staged % self.group
-                    got = self.source.poll_into(self._stage, max_msgs=room)
-                else:
-                    got = 1 if self.source.recv_into(self._stage, block=False) is not None else 0
+                    # (bounded: a learner that never blocks must not starve the ingest -- after 2 ms the message is staged anyway)
+                    if self.learner_idle.wait(0.002):
+                        announced = self.learner_idle.begin()
+                        if not announced:
+                            continue
+                try:
+                    if multi:
+                        room = 1 if self.gate else self.group - self._staged % self.group     # (gated: one message per turn)
+                        got = self.source.poll_into(self._stage, max_msgs=room)
+                    else:
+                        got = 1 if self.source.recv_into(self._stage, block=False) is not None else 0
+                finally:
+                    if announced:
+                        self.learner_idle.end()
                 if not got:
                     if hasattr(self.source, "reap"):
                         self.source.reap()
