@@ -1246,3 +1246,29 @@ def test_prefetcher_stages_one_train_ahead_in_arrival_order_and_hands_out_tokens
         pf.close()
     finally:
         ring.close()
+
+
+def test_sender_side_list_packing_ships_per_step_lists_as_typed_arrays():
+    """transport.encode(pack_lists=True): the done / reward lists an agent ships (xt/agent/*: per-step python scalars) arrive as
+    the arrays ``np.asarray`` makes of them -- what ``IMPALAOpt._data_proc`` / ``PPO.prepare_data`` compute anyway --, short,
+    nested and mixed lists stay python objects, and without the option nothing changes."""
+    from xingtian_amd import transport
+    rng = np.random.default_rng(3)
+    data = {"cur_state": rng.integers(0, 256, (16, 4, 4, 4)).astype(np.uint8), "done": [bool(b) for b in rng.random(16) < 0.3],
+            "reward": [float(r) for r in rng.choice([-1.0, 0.0, 1.0], 16)], "ints": list(range(16)), "few": [1.0, 2.0],
+            "nested": [[1, 2]] * 8, "mixed": [1, "a"] * 8, "np_bools": list(rng.random(16) < 0.5)}
+    ctr, out = transport.decode(transport.encode({"cmd": "train"}, data, pack_lists=True))
+    assert ctr == {"cmd": "train"} and list(out) == list(data)
+    for key, dtype in (("done", np.bool_), ("reward", np.float64), ("ints", np.int64), ("np_bools", np.bool_)):
+        assert isinstance(out[key], np.ndarray) and out[key].dtype == dtype and np.array_equal(out[key], np.asarray(data[key]))
+    for key in ("few", "nested", "mixed"):
+        assert isinstance(out[key], list) and out[key] == [list(x) if isinstance(x, list) else x for x in data[key]]
+    _ctr, plain = transport.decode(transport.encode({"cmd": "train"}, data))
+    assert isinstance(plain["done"], list) and plain["done"] == data["done"] and plain["reward"] == data["reward"]
+    # the algorithm-side view is the same either way
+    from xingtian_amd.algorithm.impala.impala_opt import IMPALAOpt
+    msg = dict(data, logit=np.zeros((16, 2), np.float32), action=np.zeros(16, np.int32))
+    a = IMPALAOpt._data_proc(transport.decode(transport.encode({}, msg, pack_lists=True))[1])
+    b = IMPALAOpt._data_proc(transport.decode(transport.encode({}, msg))[1])
+    for x, y in zip(a, b):
+        assert np.asarray(x).dtype == np.asarray(y).dtype and np.array_equal(x, y)

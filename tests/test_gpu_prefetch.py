@@ -207,3 +207,49 @@ def test_the_copy_kernels_sequence_number_is_only_seen_behind_the_whole_paramete
         torch.cuda.synchronize()
         assert np.isfinite(a[0]) and a[1] == 1.0
         assert np.array_equal(landed, net.params.cpu().numpy()), t
+
+
+def test_sdma_copies_through_the_hsa_runtime_of_the_process():
+    """csrc/xt_sdma.hip through the C ABI: ticketed page-locked-host -> device copies (xt_dma_h2d_async / xt_dma_wait_upto:
+    tickets count up, ``upto`` covers every earlier copy, the query form) out of a torch pinned tensor and out of a
+    hipHostRegister'ed /dev/shm ring, and the synchronous device -> host copy (xt_sdma_copy_d2h) back into both; bytes exact."""
+    import ctypes
+    from xingtian_amd import lib as L, transport
+    lib = L.load()
+    n = 1_051_003
+    rng = np.random.default_rng(2)
+    ring = transport.WeightsRing(slot_bytes=8 << 20, slots=2)
+    assert ring.pin()
+    shm = np.frombuffer(ring.shm.buf, dtype=np.float32, count=n, offset=8192 + 328)
+    shm_addr = ring._pin_addr + 8192 + 328
+    pinned = torch.empty(n, dtype=torch.float32, pin_memory=True)
+    try:
+        tickets = []
+        for k, (host_np, addr) in enumerate(((pinned.numpy(), pinned.data_ptr()), (shm, shm_addr)) * 2):
+            host_np[:] = rng.standard_normal(n).astype(np.float32)
+            dev = torch.zeros(n, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            tk = ctypes.c_uint64()
+            L.check(lib.xt_dma_h2d_async(dev.data_ptr(), addr, n * 4, ctypes.byref(tk)), "xt_dma_h2d_async")
+            tickets.append(int(tk.value))
+            assert lib.xt_dma_wait_upto(tk.value, 5000) == 0 and lib.xt_dma_wait_upto(tk.value, 0) == 0
+            assert np.array_equal(dev.cpu().numpy(), host_np)
+            back = pinned if k % 2 else None
+            dst_np, dst_addr = (pinned.numpy(), pinned.data_ptr()) if back is not None else (shm, shm_addr)
+            dev.mul_(2.0)
+            torch.cuda.synchronize()
+            L.check(lib.xt_sdma_copy_d2h(dst_addr, dev.data_ptr(), n * 4), "xt_sdma_copy_d2h")
+            assert np.array_equal(dst_np, dev.cpu().numpy())
+        assert tickets == list(range(tickets[0], tickets[0] + 4))
+        # several copies in flight, one wait for all of them
+        devs = [torch.zeros(n, dtype=torch.float32, device="cuda") for _ in range(6)]
+        torch.cuda.synchronize()
+        last = ctypes.c_uint64()
+        for d_ in devs:
+            L.check(lib.xt_dma_h2d_async(d_.data_ptr(), pinned.data_ptr(), n * 4, ctypes.byref(last)), "xt_dma_h2d_async")
+        assert lib.xt_dma_wait_upto(last.value, 5000) == 0
+        for d_ in devs:
+            assert np.array_equal(d_.cpu().numpy(), pinned.numpy())
+    finally:
+        host_np = dst_np = shm = None        # (no view into the ring's shared memory may outlive it)
+        ring.close()
