@@ -209,8 +209,11 @@ class RolloutIngest(object):
         if pinned and plain and dma:
             # ... and no stream either: one asynchronous SDMA copy with a ticket
             tk = ctypes.c_uint64()
-            L.check(self._lib.xt_dma_h2d_async(ctypes.c_void_p(dev_ptr), ctypes.c_void_p(obs.ctypes.data), obs.nbytes,
-                                               ctypes.byref(tk)), "xt_dma_h2d_async")
+            if self._lib.xt_dma_h2d_async(ctypes.c_void_p(dev_ptr), ctypes.c_void_p(obs.ctypes.data), obs.nbytes,
+                                          ctypes.byref(tk)) != 0:
+                # this process cannot (no HSA runtime to be had, memory it does not know): the stream path from now on
+                self.dma_h2d = dma = False
+        if pinned and plain and dma:
             s.dma_ticket = int(tk.value)
             if slot_guard is not None:      # the ring keeps the slot until the copy has landed: no wait here
                 slot_guard.hold(_DmaDone(self._lib, s.dma_ticket))
