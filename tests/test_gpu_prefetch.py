@@ -19,28 +19,28 @@ pytestmark = pytest.mark.gpu
 T_LEN, ENVS, A_DIM, DIM, MSGS_PER_TRAIN, TRAINS = 10, 2, 6, 42, 2, 9
 
 
-def _alg(tpc, tail=True):
+def _alg(tpc, tail=True, dim=DIM, t_len=T_LEN, envs=ENVS):
     from xingtian_amd.algorithm import alg_builder
-    mi = {"actor": {"model_name": "ImpalaCnnOpt", "state_dim": [DIM, DIM, 4], "input_dtype": "uint8", "state_mean": 128.0,
+    mi = {"actor": {"model_name": "ImpalaCnnOpt", "state_dim": [dim, dim, 4], "input_dtype": "uint8", "state_mean": 128.0,
                     "state_std": 128.0, "action_dim": A_DIM, "type": "learner",
-                    "model_config": {"LR": 1e-3, "sample_batch_step": T_LEN, "grad_norm_clip": 40.0, "SEED": 4,
+                    "model_config": {"LR": 1e-3, "sample_batch_step": t_len, "grad_norm_clip": 40.0, "SEED": 4,
                                      "IO_TAIL_IN_GRAPH": tail}}}
     return alg_builder("IMPALAOpt", mi, {"instance_num": 4, "agent_num": 1, "prepare_times_per_train": MSGS_PER_TRAIN,
-                                        "train_per_checkpoint": tpc, "BATCH_SIZE": ENVS * T_LEN * MSGS_PER_TRAIN})
+                                        "train_per_checkpoint": tpc, "BATCH_SIZE": envs * t_len * MSGS_PER_TRAIN})
 
 
-def _msg(k):
+def _msg(k, dim=DIM, t_len=T_LEN, envs=ENVS):
     rng = np.random.default_rng(4000 + k)
-    n = ENVS * T_LEN
-    return {"cur_state": rng.integers(0, 256, (n, DIM, DIM, 4)).astype(np.uint8),
+    n = envs * t_len
+    return {"cur_state": rng.integers(0, 256, (n, dim, dim, 4)).astype(np.uint8),
             "logit": rng.standard_normal((n, A_DIM)).astype(np.float32), "action": rng.integers(0, A_DIM, n).astype(np.int32),
             "done": list(rng.random(n) < 0.1), "reward": list(rng.choice([-1.0, 0.0, 1.0], n))}
 
 
-def _run(prefetch, tpc, pinned, tail=True):
+def _run(prefetch, tpc, pinned, tail=True, dim=DIM, t_len=T_LEN, envs=ENVS, trains=TRAINS):
     from xingtian_amd import transport
-    alg = _alg(tpc, tail)
-    ring = transport.ShmRing(slots=4, slot_bytes=1 << 20)
+    alg = _alg(tpc, tail, dim, t_len, envs)
+    ring = transport.ShmRing(slots=4, slot_bytes=max(1 << 20, envs * t_len * dim * dim * 4 + (1 << 16)))
     wring = transport.WeightsRing(slot_bytes=8 << 20, slots=4)
     reader = transport.WeightsRing(name=wring.name, create=False, slot_bytes=8 << 20, slots=4)
     if pinned:
@@ -51,15 +51,15 @@ def _run(prefetch, tpc, pinned, tail=True):
         alg.actor.net.attach_weights_ring(wring)
 
     def produce():
-        for k in range(TRAINS * MSGS_PER_TRAIN):
-            assert ring.send({"cmd": "train", "k": k}, _msg(k), timeout=30)
+        for k in range(trains * MSGS_PER_TRAIN):
+            assert ring.send({"cmd": "train", "k": k}, _msg(k, dim, t_len, envs), timeout=30)
 
     prod = threading.Thread(target=produce, daemon=True)
     prod.start()
     src = transport.Prefetcher(ring, alg) if prefetch else ring
     losses, seqs = [], []
     try:
-        for t in range(TRAINS):
+        for t in range(trains):
             for _ in range(MSGS_PER_TRAIN):
                 assert src.recv_into(alg.prepare_data, timeout=30) is not None
             losses.append(float(alg.train(episode_num=t)))
@@ -253,3 +253,21 @@ def test_sdma_copies_through_the_hsa_runtime_of_the_process():
     finally:
         host_np = dst_np = shm = None        # (no view into the ring's shared memory may outlive it)
         ring.close()
+
+
+def test_ticketed_sdma_ingest_trains_on_the_same_bytes_as_the_stream_copies():
+    """The frames of a message in a page-locked ring slot reach HBM through xt_dma_h2d_async (SDMA engine via HSA: ordered
+    against no stream, invisible to the device's caches), the frames of a pageable ring through pinned staging + hipMemcpyAsync
+    on a copy stream.  Same messages -> every loss and the final parameters bit for bit (a kernel that read a stale cached
+    line of a reused buffer set would show here: 9 trains over 2 buffer sets, every message different)."""
+    a = _run(True, 1, False, tail=2)          # pageable ring: staging copy + stream H2D
+    b = _run(True, 1, True, tail=2)           # pinned ring: ticketed SDMA copies
+    c = _run(False, 1, True, tail=0)          # pinned ring, blocking loop, separate launches (events, no mailbox)
+    assert a[0] == b[0] == c[0], (a[0], b[0], c[0])
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[1], c[1])
+    # the breakout_impala shape: 2 x 1.8 MB of frames per train through 2 buffer sets, 24 trains
+    big = dict(dim=84, t_len=32, envs=2, trains=24)
+    a = _run(True, 1, False, tail=2, **big)
+    b = _run(True, 1, True, tail=2, **big)
+    assert a[0] == b[0], (a[0], b[0])
+    assert np.array_equal(a[1], b[1])
