@@ -886,11 +886,15 @@ def bench_impala(key, steps, warmup, with_cpu, in_graph=False, quick=False):
     # thread when it lands.  Same messages, same order, same trains, same weights -- no flag.  The blocking form of the same
     # ring-fed loop sits next to it.
     out["e2e_ring_prefetch"] = dict(impala_ring_loop(w, fm, msgs_per_train, tpc, n_prod=2, seconds=1.0),
-                                    path="producer processes -> pinned RingSet -> transport.Prefetcher -> prepare_data x {} -> train() "
+                                    path="producer processes -> pinned RingSet -> transport.Prefetcher (inline: the learner thread stages the "
+                                         "next message itself while the device trains) -> prepare_data x {} -> train() "
                                          "-> every {} train(s): publish_weights(pinned WeightsRing, committer thread)".format(msgs_per_train, tpc))
     out["e2e_ring_blocking"] = dict(impala_ring_loop(w, fm, msgs_per_train, tpc, n_prod=2, seconds=0.7, prefetch=False,
                                                      async_commit=False),
                                     path="the same rings, learner thread receives + waits for the weights D2H itself")
+    out["e2e_ring_prefetch_thread"] = dict(impala_ring_loop(w, fm, msgs_per_train, tpc, n_prod=2, seconds=0.7, inline=False),
+                                           path="as e2e_ring_prefetch with the staging on a THREAD of its own (transport.Prefetcher("
+                                                "inline=False)): two Python threads on one interpreter lock")
     out["e2e_ring_prefetch_python_lists"] = dict(impala_ring_loop(w, fm, msgs_per_train, tpc, n_prod=2, seconds=0.7, pack_lists=False),
                                                  path="as e2e_ring_prefetch, done / reward on the wire as python lists (msgpack): "
                                                       "the sender did not use transport.encode(pack_lists=True)")
@@ -1012,7 +1016,7 @@ def bench_env_num_256(spec, dev, updates=3):
 
 
 def impala_ring_loop(w, fm, msgs_per_train, tpc, n_prod, seconds, prefetch=True, async_commit=True, pinned=True, slots=4,
-                     min_trains=20, gate=True, model_config=None, pack_lists=True, strict=False):
+                     min_trains=20, gate=True, model_config=None, pack_lists=True, strict=False, inline=None):
     """The IMPALAOpt plugin pair fed as a learner is fed (xt/framework/learner.py:298-380): `n_prod` producer PROCESSES push
     pre-encoded rollout messages of `fm` frames into their own shared-memory ring (transport.RingSet); the learner loop is
     the reference's -- recv + prepare_data x msgs_per_train -> train() -> every tpc-th train the weights go out.
@@ -1063,7 +1067,7 @@ def impala_ring_loop(w, fm, msgs_per_train, tpc, n_prod, seconds, prefetch=True,
     if wpin and async_commit:
         wring.start_committer()
         alg.actor.net.attach_weights_ring(wring)
-    src = transport.Prefetcher(rs, alg, gate=gate, strict=strict) if prefetch else rs
+    src = transport.Prefetcher(rs, alg, gate=gate, strict=strict, inline=inline) if prefetch else rs
     sink = lambda d_, ctr_info=None: alg.prepare_data(d_, ctr_info=ctr_info)   # noqa: E731
     trains = 0
     t_recv = t_train = t_w = 0.0

@@ -647,6 +647,9 @@ int xt_net_io_wait(xt_net* net, float* loss_host4, void* stream);
  * never starts it).  The train's inputs are consumed once its loss has been seen (the loss kernel runs behind every
  * kernel that reads them). */
 uint32_t xt_net_io_seq(const xt_net* net);
+/* 1 once the loss of the most recent tail_in_graph train has landed in the mailbox (xt_net_io_wait would return at once), else 0:
+ * a learner thread that stages the next rollout message ITSELF while the device trains polls this between two messages */
+int32_t xt_net_io_loss_ready(const xt_net* net);
 int xt_net_io_publish_wait(xt_net* net, uint32_t seq, int32_t timeout_ms);
 
 /* One synchronous device -> page-locked-host copy on the SDMA engine through the HSA runtime of the process (ABI >= 12;

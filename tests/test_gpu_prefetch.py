@@ -56,7 +56,8 @@ def _run(prefetch, tpc, pinned, tail=True, dim=DIM, t_len=T_LEN, envs=ENVS, trai
 
     prod = threading.Thread(target=produce, daemon=True)
     prod.start()
-    src = transport.Prefetcher(ring, alg) if prefetch else ring
+    # prefetch: True = the default form (inline: the learner thread stages while the device trains), "thread" = a staging thread
+    src = transport.Prefetcher(ring, alg, inline=(False if prefetch == "thread" else None)) if prefetch else ring
     losses, seqs = [], []
     try:
         for t in range(trains):
@@ -78,16 +79,19 @@ def _run(prefetch, tpc, pinned, tail=True, dim=DIM, t_len=T_LEN, envs=ENVS, trai
         reader.close()
         wring.close()
         ring.close()
-    return losses, params, weights, seqs, latest, got
+    return losses, params, weights, seqs, latest, got, bool(getattr(src, "inline", False))
 
 
 @pytest.mark.parametrize("tpc", [1, 3])
 @pytest.mark.parametrize("pinned", [True, False])
-def test_prefetch_and_asynchronous_commit_train_and_publish_exactly_what_the_blocking_loop_does(tpc, pinned):
+@pytest.mark.parametrize("how", [True, "thread"])
+def test_prefetch_and_asynchronous_commit_train_and_publish_exactly_what_the_blocking_loop_does(tpc, pinned, how):
     # the blocking loop with the loss read-back and the weights copy as separate launches behind the train (events), the
     # asynchronous path with both as the train's own last kernels inside its replayed hipGraph (xt_train_io.tail_in_graph)
     ref = _run(False, tpc, pinned, tail=False)
-    got = _run(True, tpc, pinned, tail=True)
+    got = _run(how, tpc, pinned, tail=True)
+    if how is True:
+        assert got[6]                  # (the default picked the inline form for this algorithm)
     assert ref[0] == got[0], (ref[0], got[0])                       # every reported loss, bit for bit
     assert np.array_equal(ref[1], got[1])                           # final parameters
     assert ref[3] == got[3] and got[4] == len(got[3]) == (TRAINS + tpc - 1) // tpc       # publish sequence numbers, all visible
@@ -103,7 +107,7 @@ def test_prefetch_and_asynchronous_commit_train_and_publish_exactly_what_the_blo
 
 
 @pytest.mark.parametrize("tail", [1, 2])
-@pytest.mark.parametrize("prefetch", [True, False])
+@pytest.mark.parametrize("prefetch", [True, "thread", False])
 def test_the_in_graph_tail_reports_and_publishes_what_the_separate_launches_do(prefetch, tail):
     """xt_train_io.tail_in_graph on / off, everything else equal (train_per_checkpoint 3: trains WITH and WITHOUT a publish
     alternate through the same replayed graphs -- the destination travels through the mailbox)"""

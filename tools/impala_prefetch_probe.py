@@ -115,7 +115,7 @@ mpt = w.get("msgs_per_train", 1 if key == "breakout_impala" else 4)
 res = bench.impala_ring_loop(w, w["frames_per_train"] // mpt, mpt, w.get("train_per_checkpoint", 1), n_prod=2, seconds=1.0,
                              prefetch=(len(sys.argv) < 3 or sys.argv[2] != "blocking"),
                              async_commit=(len(sys.argv) < 3 or sys.argv[2] != "blocking"),
-                             gate=(len(sys.argv) < 3 or sys.argv[2] != "nogate"), pack_lists="pylists" not in sys.argv[2:], strict="nostrict" not in sys.argv[2:],
+                             gate=(len(sys.argv) < 3 or sys.argv[2] != "nogate"), pack_lists="pylists" not in sys.argv[2:], strict="strict" in sys.argv[2:], inline=(False if "thread" in sys.argv[2:] else None),
                              model_config={"IO_TAIL_IN_GRAPH": 0 if "notail" in sys.argv[2:] else 1 if "ingraph" in sys.argv[2:] else 2, "USE_HIP_GRAPH": "nograph" not in sys.argv[2:],
                                            "INGEST_COPY_STREAMS": 2 if "cs2" in sys.argv[2:] else 1})
 print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in res.items()})

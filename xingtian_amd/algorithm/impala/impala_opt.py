@@ -63,6 +63,20 @@ class IMPALAOpt(Algorithm):
         """trains whose buffer set the learner thread has taken over (the Prefetcher stays at most one train ahead)"""
         return self.actor.ingest_generation()
 
+    def stage_inline_capable(self):
+        """does the model call an inline prefetcher's hook while the device trains?  (the deferred in-graph tail of
+        ``ImpalaCnnOpt.train_ingested``: synchronous loss, IO_TAIL_IN_GRAPH on, hipGraph or not)"""
+        a = self.actor
+        return bool(getattr(a, "stream_ingest", False) and getattr(a, "io_tail_in_graph", 0) and not getattr(a, "async_loss", False)
+                    and hasattr(getattr(a, "net", None), "impala_wait_loss"))
+
+    def stage_inline(self, hook):
+        """an inline ``transport.Prefetcher``: ``hook()`` stages one waiting message (-> did it?) and is called by the model
+        between two looks at the loss while the device trains; None detaches"""
+        self.actor._ingest_obj().on_finish = None
+        self.actor.net.idle_gate = None
+        self.actor.net.idle_hook = hook
+
     def stage_thread_init(self, wake=None, idle=None, bind_device=True):
         """first call on the staging thread: bind it to the learner's device; ``wake`` is called whenever the learner takes
         over a buffer set; ``idle`` (threading.Event) is SET by the model while the learner thread waits for the GPU -- the

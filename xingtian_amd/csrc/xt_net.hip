@@ -1463,6 +1463,11 @@ int xt_net_io_wait(xt_net* net, float* loss_host4, void* stream) {
 
 uint32_t xt_net_io_seq(const xt_net* net) { return net ? net->io_seq : 0u; }
 
+int32_t xt_net_io_loss_ready(const xt_net* net) {
+  if (!net || !net->io_mb || !net->io_seq) return 1;
+  return __atomic_load_n(&net->io_mb->loss_seq, __ATOMIC_ACQUIRE) == net->io_seq ? 1 : 0;
+}
+
 int xt_net_io_publish_wait(xt_net* net, uint32_t seq, int32_t timeout_ms) {
   XT_REQUIRE(net && net->io_mb, "xt_net_io_publish_wait: no train with tail_in_graph has been enqueued on this net");
   const int b = seq & 1;

@@ -153,6 +153,7 @@ SIGNATURES = {
     "xt_dma_h2d_async": (c_int32, [_P, _P, c_int64, POINTER(ctypes.c_uint64)]),
     "xt_dma_wait_upto": (c_int32, [ctypes.c_uint64, c_int32]),
     "xt_net_io_seq": (ctypes.c_uint32, [_P]),
+    "xt_net_io_loss_ready": (c_int32, [_P]),
     "xt_net_io_publish_wait": (c_int32, [_P, ctypes.c_uint32, c_int32]),
 }
 

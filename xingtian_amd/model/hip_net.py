@@ -550,6 +550,14 @@ class HipActorCritic(object):
         released) -> its pinned [sum, count, error bits, -] block"""
         rb = self._loss_rb
         i = rb.pop("deferred")
+        # an INLINE prefetcher (transport.Prefetcher(inline=True)): this thread stages the next rollout message(s) itself while
+        # the device trains -- one interpreter thread, nobody to fight for the lock -- and looks at the mailbox in between
+        hook = getattr(self, "idle_hook", None)
+        if hook is not None:
+            ready = self.lib.xt_net_io_loss_ready
+            while not ready(self.handle):
+                if not hook():
+                    break               # (nothing to stage: wait in C below)
         gate = getattr(self, "idle_gate", None)
         if gate is not None:
             gate.set()
