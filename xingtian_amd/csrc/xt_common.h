@@ -327,6 +327,28 @@ struct PerDeviceOnce {
   }
 };
 
+// xt_train_io.tail_in_graph: what the learner thread and the tail kernels of a train say to each other (page-locked host memory)
+struct IoMailbox {
+  unsigned long long publish_dst;   // host -> device: device-side address the new parameters go to (0: nobody asked)
+  uint32_t seq;                     // host -> device: sequence number of the train being launched
+  uint32_t pad0;
+  float loss[4];                    // device -> host: loss_acc of that train
+  uint32_t loss_seq;                // device -> host: == seq once loss[] has landed
+  uint32_t publish_seq;             // device -> host: sequence number of the last train whose parameter copy has landed
+  uint32_t snap_seq;                // device -> host: ... whose parameter SNAPSHOT is complete in device memory (mode 2)
+  uint32_t pad1[5];
+};
+static_assert(sizeof(IoMailbox) == 64, "IoMailbox is one 64-byte line");
+// ... and the same tail FOLDED into the Adam kernel of the train's last chunk (tail_in_graph = 2, Adam, no gradient exchange): its
+// block 0 reports the loss before it updates anything, every block writes its updated parameters to the snapshot buffer as
+// well (system-scope write-through), the last block to finish reports the snapshot -- no kernel behind the optimiser at all
+struct IoFold {
+  IoMailbox* mb;               // device-side address of the mailbox
+  float* acc;                  // the library-owned loss accumulator (re-armed here)
+  float* loss_out;             // the caller's device-side loss_acc
+  unsigned long long* fwd;     // [0] destination announced, [1] sequence number, [2] block ticket
+  float* snap;                 // the snapshot buffer of this train's parity
+};
 // xt_sdma.hip: a device -> page-locked-host copy on the SDMA engine through the process's HSA runtime, synchronous; -> nullptr
 // or why this process cannot do it.  `sig_io`: an hsa_signal_t handle kept by the caller (0 = create one)
 const char* sdma_copy_d2h(void* dst_host, const void* src_dev, size_t bytes, unsigned long long* sig_io);

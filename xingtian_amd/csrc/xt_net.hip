@@ -66,7 +66,7 @@ int launch_norm_finalize(const float*, int, float, float, float, float, float, i
                          const float* lr_dev = nullptr);
 int launch_ppo_heads_fused(const PpoHeadArgs&, hipStream_t);
 int launch_adam_clip(float*, const float*, float*, float*, long long, float, float, float, float*, const float*, int,
-                     float, float, hipStream_t, const DpStep* dp = nullptr, int block_cap = 0);
+                     float, float, hipStream_t, const DpStep* dp = nullptr, int block_cap = 0, const IoFold* io = nullptr);
 int launch_rmsprop_clip(float*, const float*, float*, float*, long long, float, float, float, float*, const float*, int,
                         float, float, hipStream_t, const float* lr_dev = nullptr, const DpStep* dp = nullptr,
                         int block_cap = 0);
@@ -100,18 +100,6 @@ struct Layer {
 
 static inline int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
 
-// xt_train_io.tail_in_graph: what the learner thread and the tail kernels of a train say to each other (page-locked host memory)
-struct IoMailbox {
-  unsigned long long publish_dst;   // host -> device: device-side address the new parameters go to (0: nobody asked)
-  uint32_t seq;                     // host -> device: sequence number of the train being launched
-  uint32_t pad0;
-  float loss[4];                    // device -> host: loss_acc of that train
-  uint32_t loss_seq;                // device -> host: == seq once loss[] has landed
-  uint32_t publish_seq;             // device -> host: sequence number of the last train whose parameter copy has landed
-  uint32_t snap_seq;                // device -> host: ... whose parameter SNAPSHOT is complete in device memory (mode 2)
-  uint32_t pad1[5];
-};
-static_assert(sizeof(IoMailbox) == 64, "IoMailbox is one 64-byte line");
 }  // namespace xt
 
 struct xt_net {
@@ -161,7 +149,7 @@ struct xt_net {
   // hipGraph cache of the whole-update entry points: a few slots, because the streaming ingest alternates between
   // two rollout buffer sets (two pointer sets -> two graphs), least recently used replaced
   struct GraphSlot { std::string key; hipGraphExec_t exec = nullptr; unsigned long long used = 0; };
-  GraphSlot gslots[4];
+  GraphSlot gslots[8];
   unsigned long long gclock = 0;
   hipStream_t cap_stream = nullptr;   // capture happens on our own stream: the legacy null stream cannot be captured
   // xt_train_io.tail_in_graph: the 64-byte page-locked mailbox between the learner thread and the train's two tail kernels
@@ -181,6 +169,7 @@ struct xt_net {
   void* io_dst[2] = {nullptr, nullptr};
   std::atomic<uint32_t> io_snap_owner[2] = {{0}, {0}}, io_copying[2] = {{0}, {0}}, io_copied[2] = {{0}, {0}};
   unsigned long long io_sig[2] = {0, 0};          // hsa_signal_t handles of the copies (xt_sdma.hip), created on first use
+  const xt::IoFold* io_fold = nullptr;  // set while the LAST chunk of a tail_in_graph = 2 train is enqueued: its Adam kernel carries the tail
   bool io_acc_clean = false;          // the library-owned loss accumulator of tail_in_graph trains is zero (its loss kernel re-arms it)
   double io_us[4] = {0, 0, 0, 0};     // xt_net_io_times: host time of xt_net_impala_train_io's phases, accumulated
   long long io_calls = 0;
@@ -483,7 +472,7 @@ static int net_apply(xt_net* n, float lr, float b1, float b2, float eps, float c
                      const LossArgs* la, hipStream_t st) {
   if (mode == 3)
     return launch_adam_clip(n->params, n->grads, n->m, n->v, n->P, b1, b2, eps, n->state, n->ws + n->off_norm,
-                            n->norm_blocks, clip, gscale, st);
+                            n->norm_blocks, clip, gscale, st, nullptr, 0, n->io_fold);
   if (mode == 1) {
     if (int rc = launch_norm_finalize(n->ws + n->off_norm, n->norm_blocks, clip, gscale, lr, b1, b2, 1, n->state, la, st))
       return rc;
@@ -1098,7 +1087,8 @@ int xt_net_impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int32
 
 static int impala_train_enqueue(xt_net* net, const xt_impala_cfg* c, const void* obs, int32_t n, int32_t batch_size,
                                 const float* bp_logits, const int32_t* action, const uint8_t* done, const float* reward,
-                                const float* lr_steps, float* loss_acc, hipStream_t st, bool clear = true) {
+                                const float* lr_steps, float* loss_acc, hipStream_t st, bool clear = true,
+                                const xt::IoFold* fold = nullptr) {
   if (clear)
     if (int rc = xt::clear_loss_acc(net, loss_acc, st)) return rc;
   XT_REQUIRE(n < (1 << 24), "xt_net_impala_train: %d frames do not fit the data-parallel tail's float slot", n);
@@ -1112,9 +1102,11 @@ static int impala_train_enqueue(xt_net* net, const xt_impala_cfg* c, const void*
       XT_REQUIRE(c->shard_world <= 1, "xt_net_impala_train: sharded chunks need a gradient exchange (xt_net_set_rccl / "
                                       "xt_net_set_grad_exchange)");
       const void* o = static_cast<const char*>(obs) + frame * lo;
-      if (int rc = xt::impala_step(net, c, o, nfr, bp_logits + (size_t)lo * net->A, action + lo, done + lo, reward + lo, 1,
-                                   lr_dev, nullptr, loss_acc, st, /*defer_join*/ true))
-        return rc;
+      net->io_fold = (lo + batch_size >= n) ? fold : nullptr;       // (the last chunk's Adam kernel carries the folded tail)
+      const int rc = xt::impala_step(net, c, o, nfr, bp_logits + (size_t)lo * net->A, action + lo, done + lo, reward + lo, 1,
+                                     lr_dev, nullptr, loss_acc, st, /*defer_join*/ true);
+      net->io_fold = nullptr;
+      if (rc) return rc;
       continue;
     }
     // data parallel: local gradient of this rank's trajectories -> SUM over the replicas (the loss is a sum:
@@ -1282,7 +1274,8 @@ static int io_tail_enqueue(xt_net* net, float* loss_acc, int mode, hipStream_t s
 
 static int impala_train_run(xt_net* net, const xt_impala_cfg* c, const void* obs, int32_t n, int32_t batch_size,
                             const float* bp_logits, const int32_t* action, const uint8_t* done, const float* reward,
-                            const float* lr_steps, float* loss_acc, int32_t use_graph, int io_tail, void* stream) {
+                            const float* lr_steps, float* loss_acc, int32_t use_graph, int io_tail, void* stream,
+                            uint32_t io_seq = 0) {
   XT_REQUIRE(net && c && obs && bp_logits && action && done && reward && loss_acc, "xt_net_impala_train: null argument");
   XT_REQUIRE(net->params && net->ws, "xt_net_impala_train: buffers not bound");
   const int T = c->sample_batch_step;
@@ -1295,20 +1288,33 @@ static int impala_train_run(xt_net* net, const xt_impala_cfg* c, const void* obs
              batch_size < n ? batch_size : n, net->maxB);
   hipStream_t st = xt::as_stream(stream);
   (void)xt::tail_overlap_mode(net);
+  // tail_in_graph = 2 with plain Adam (no gradient exchange, no split / fused tail experiment): the tail is FOLDED into the
+  // Adam kernel of the last chunk -- no kernel behind the optimiser (the two tail kernels + their launch boundaries were
+  // ~15 us of a 128-frame train's ~115)
+  xt::IoFold fold_args{};
+  const bool fold = io_tail == 2 && c->opt_type == XT_OPT_ADAM && !net->xchg && xt::tail_overlap_mode(net) == 0 &&
+                    !xt::tuning().tail_fused && net->io_snap[0] && (long long)net->P * 4 < 0x7fffffffLL;
+  if (fold) {
+    fold_args.mb = net->io_mb_dev; fold_args.acc = net->ws + net->off_ioacc; fold_args.loss_out = loss_acc;
+    fold_args.fwd = reinterpret_cast<unsigned long long*>(net->ws + net->off_iofwd);
+    fold_args.snap = net->io_snap[io_seq & 1];
+  }
   auto enqueue = [&](hipStream_t cs) {
     // tail_in_graph: the chunks accumulate into the library's own 4 floats, which the loss kernel re-arms -- no memset node
     if (int rc = impala_train_enqueue(net, c, obs, n, batch_size, bp_logits, action, done, reward, lr_steps,
-                                      io_tail ? net->ws + net->off_ioacc : loss_acc, cs, /*clear*/ !io_tail))
+                                      io_tail ? net->ws + net->off_ioacc : loss_acc, cs, /*clear*/ !io_tail,
+                                      fold ? &fold_args : nullptr))
       return rc;
-    return io_tail ? xt::io_tail_enqueue(net, loss_acc, io_tail, cs) : 0;
+    return (io_tail && !fold) ? xt::io_tail_enqueue(net, loss_acc, io_tail, cs) : 0;
   };
   if (!use_graph) return enqueue(st);
   char key[512];
-  snprintf(key, sizeof(key), "I%d.%d.%d.%d.%p|%p|%p|%p|%d|%d|%p|%p|%p|%p|%p|%p|%g|%g|%g|%g|%g|%g|%d|%g|%d|%g|%g|%p",
+  snprintf(key, sizeof(key), "I%d.%d.%d.%d.%p|%p|%p|%p|%d|%d|%p|%p|%p|%p|%p|%p|%g|%g|%g|%g|%g|%g|%d|%g|%d|%g|%g|%p|%d",
            c->shard_rank, c->shard_world, net->dp_rank, net->dp_world, (void*)net->direct, (void*)net->xchg, net->xchg_user, obs, n, batch_size, (const void*)bp_logits, (const void*)action,
            (const void*)done, (const void*)reward, (const void*)lr_steps, (void*)loss_acc, c->lr, c->beta1, c->beta2,
            c->eps, c->grad_norm_clip, c->gamma, c->sample_batch_step, c->grad_scale, c->opt_type, c->rms_decay, c->rms_eps,
-           io_tail ? (void*)(reinterpret_cast<char*>(net->io_mb_dev) + io_tail) : nullptr);
+           io_tail ? (void*)(reinterpret_cast<char*>(net->io_mb_dev) + io_tail) : nullptr,
+           fold ? 1 + (int)(io_seq & 1) : 0);      // (folded: the snapshot buffer of the train's parity is a kernel argument)
   return xt::graph_run(net, key, st, enqueue);
 }
 
@@ -1380,13 +1386,16 @@ int xt_net_impala_train_io(xt_net* net, const xt_impala_cfg* c, const void* obs,
     net->io_mb->publish_dst = published ? reinterpret_cast<unsigned long long>(d) : 0ull;
     net->io_mb->seq = seq;
     __atomic_thread_fence(__ATOMIC_SEQ_CST);  // the mailbox is written before the launch's doorbell
-    if (mode == 2 && published) {
+    if (mode == 2) {
       // the snapshot buffer of this parity is free once the copy of the publish that owns it has left it -- long ago,
-      // normally; otherwise it is made here and now (nobody waited for that publish yet)
+      // normally; otherwise it is made here and now (nobody waited for that publish yet).  (Every train: the folded form
+      // snapshots whether or not a destination was announced.)
       if (const uint32_t owner = net->io_snap_owner[seq & 1].load())
         if (int rc = xt_net_io_publish_wait(net, owner, -1)) return rc;
-      net->io_dst[seq & 1] = io->publish_dst;
-      net->io_snap_owner[seq & 1].store(seq);
+      if (published) {
+        net->io_dst[seq & 1] = io->publish_dst;
+        net->io_snap_owner[seq & 1].store(seq);
+      }
     }
     if (!net->io_acc_clean) {                 // first use / after a rebind or a failed enqueue: zero the accumulator once
       XT_CHECK_HIP(hipMemsetAsync(net->ws + net->off_ioacc, 0, 2 * sizeof(float), st));
@@ -1396,7 +1405,7 @@ int xt_net_impala_train_io(xt_net* net, const xt_impala_cfg* c, const void* obs,
   }
   const auto t_pre = std::chrono::steady_clock::now();
   if (int rc = impala_train_run(net, c, obs, n, batch_size, bp_logits, action, done, reward, lr_steps, loss_acc, use_graph, mode,
-                                stream))
+                                stream, seq))
     return rc;
   if (!io) return 0;
   if (tail) net->io_acc_clean = true;         // (the loss kernel is enqueued: it leaves the accumulator zero)

@@ -648,16 +648,39 @@ __device__ void dp_step_end(const DpStep& dp) {
   }
 }
 
+// IO (xt_train_io.tail_in_graph = 2 with the tail folded in, IoFold in xt_common.h): block 0 first reports the train's loss to
+// the host through the mailbox (the sums are final before the optimiser runs), every block also writes its updated parameters
+// to the snapshot buffer with system-scope write-through stores (the SDMA engine that copies it out reads memory, not an XCD's
+// L2), and the last block to finish reports the snapshot.  IO = false is the kernel of every other path, unchanged.
+template <bool IO>
 __global__ __launch_bounds__(256) void adam_tf_clip_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                            float* __restrict__ m, float* __restrict__ v, long long count,
                                                            float beta1, float beta2, float eps, float* __restrict__ state,
                                                            const float* __restrict__ partial, int nblocks,
-                                                           float clip_norm, float grad_scale, const DpStep dp) {
+                                                           float clip_norm, float grad_scale, const DpStep dp, const IoFold io) {
   __shared__ double sh[256];
   __shared__ float s_scale;
   const bool ok = dp_step_begin(dp);
   dp_tail_consume(dp, ok);
   if (!ok) { dp_step_end(dp); return; }
+  if (IO && blockIdx.x == 0) {
+    const int t = threadIdx.x;
+    uint32_t seq = 0;
+    if (t == 0) {
+      const unsigned long long dst = __hip_atomic_load(&io.mb->publish_dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      seq = __hip_atomic_load(&io.mb->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(io.fwd + 0, dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(io.fwd + 1, (unsigned long long)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (t < 4) {
+      const float val = io.acc[t];
+      __hip_atomic_store(&io.mb->loss[t], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      io.loss_out[t] = val;
+      io.acc[t] = 0.f;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t == 0) __hip_atomic_store(&io.mb->loss_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   const double sq = sqnorm_total(partial, nblocks, sh);
   if (threadIdx.x == 0) {
     float gnorm, sc;
@@ -686,6 +709,16 @@ __global__ __launch_bounds__(256) void adam_tf_clip_kernel(float* __restrict__ p
     reinterpret_cast<float4*>(m)[i] = mv;
     reinterpret_cast<float4*>(v)[i] = vv;
     reinterpret_cast<float4*>(p)[i] = pv;
+    if (IO) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(io.snap, 0, 0x7fffffff, 0x00020000);
+      xt_u32x4 q;
+      q.x = __float_as_uint(pv.x); q.y = __float_as_uint(pv.y); q.z = __float_as_uint(pv.z); q.w = __float_as_uint(pv.w);
+      // sc1: written THROUGH the L2 to memory (what the SDMA engine reads) like every large output of this library; the
+      // system-scope form (sc0 sc1) made this kernel 21.5 us instead of 7.4 + 8 for the separate snapshot kernel
+      __builtin_amdgcn_raw_buffer_store_b128(q, rs, (int)(i * 16), 0, kAuxSc1);
+#endif
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x < (count & 3)) {
     const long long i = (n4 << 2) + threadIdx.x;
@@ -694,7 +727,25 @@ __global__ __launch_bounds__(256) void adam_tf_clip_kernel(float* __restrict__ p
     mm += (gg - mm) * omb1;
     vv += (gg * gg - vv) * omb2;
     m[i] = mm; v[i] = vv;
-    p[i] -= (mm * alpha) / (sqrtf(vv) + eps);
+    const float pn = p[i] - (mm * alpha) / (sqrtf(vv) + eps);
+    p[i] = pn;
+    if (IO) __hip_atomic_store(io.snap + i, pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (IO) {
+    // this block's snapshot stores are acknowledged; the last block to get here reports the snapshot (the sequence number
+    // through device memory: the host may have rewritten the mailbox for the next train since block 0 reported the loss)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      // (no fence: block 0's agent-scope stores to fwd were acknowledged before ITS ticket, the load below is agent-scope too;
+      // a __threadfence() per block is an L2 write-back per block -- it made this kernel 24 us)
+      unsigned int* ticket = reinterpret_cast<unsigned int*>(io.fwd + 2);
+      if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long seq = __hip_atomic_load(io.fwd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&io.mb->snap_seq, (uint32_t)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
   dp_step_end(dp);
 }
@@ -854,7 +905,7 @@ int launch_rmsprop_clip(float* param, const float* grad, float* mg, float* ms, l
 
 int launch_adam_clip(float* param, const float* grad, float* m, float* v, long long count, float beta1, float beta2,
                      float eps, float* state, const float* partial, int nblocks, float clip_norm, float grad_scale,
-                     hipStream_t st, const DpStep* dp, int block_cap) {
+                     hipStream_t st, const DpStep* dp, int block_cap, const IoFold* io) {
   XT_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
              "adam: buffers must be 16-byte aligned");
   int nb = (int)((count / 4 + 255) / 256);
@@ -868,8 +919,17 @@ int launch_adam_clip(float* param, const float* grad, float* m, float* v, long l
   DpStep d;
   if (dp) d = *dp; else memset(&d, 0, sizeof(d));
 
-  hipLaunchKernelGGL(adam_tf_clip_kernel, dim3(nb), dim3(256), 0, st, param, grad, m, v, count, beta1, beta2, eps, state,
-                     partial, nblocks, clip_norm, grad_scale, d);
+  IoFold f;
+  memset(&f, 0, sizeof(f));
+  if (io) {
+    XT_REQUIRE(count * 4 < 0x7fffffffLL, "adam: %lld parameters exceed the snapshot store's 2 GiB offset range", count);
+    f = *io;
+    hipLaunchKernelGGL(adam_tf_clip_kernel<true>, dim3(nb), dim3(256), 0, st, param, grad, m, v, count, beta1, beta2, eps,
+                       state, partial, nblocks, clip_norm, grad_scale, d, f);
+  } else {
+    hipLaunchKernelGGL(adam_tf_clip_kernel<false>, dim3(nb), dim3(256), 0, st, param, grad, m, v, count, beta1, beta2, eps,
+                       state, partial, nblocks, clip_norm, grad_scale, d, f);
+  }
   XT_LAUNCH_CHECK();
   return 0;
 }
