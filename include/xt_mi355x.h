@@ -611,7 +611,9 @@ int xt_net_impala_train(xt_net* net, const xt_impala_cfg* cfg, const void* obs, 
  *                   copy snapshot -> publish_dst runs on the SDMA ENGINE under the next train, issued through the HSA runtime
  *                   by whoever calls xt_net_io_publish_wait for that train (a weights ring's committer thread; the learner
  *                   thread itself when it needs the buffer back, two publishes later).  publish_event must be NULL.  Why not a
- *                   copy kernel or hipMemcpyAsync on a side stream: csrc/xt_sdma.hip (both measured, round 6).
+ *                   copy kernel or hipMemcpyAsync on a side stream: csrc/xt_sdma.hip (both measured, round 6).  With plain Adam
+ *                   and no gradient exchange both tail kernels are FOLDED into the Adam kernel of the train's last chunk (its
+ *                   block 0 reports the loss before the update, every block writes the snapshot too, the last block reports it).
  *                   What 1 / 2 remove (rocprofv3 traces of the 128-frame loop): the 19-27 us between a replayed graph and the
  *                   next launch on the stream (twice), the wake-up of hipEventSynchronize, the host's share of the next
  *                   train's launch, and (2) the 74 us copy from between two trains: 210-235 -> ~194 (1) -> ~130 us of GPU time
