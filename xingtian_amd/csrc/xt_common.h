@@ -185,6 +185,7 @@ struct LossArgs {
   // in trajectory order; used when terms == nullptr and traj_loss != nullptr
   const float* traj_loss;
   int n_traj;
+  int acc_set;          // != 0: this is the FIRST chunk of a train -- acc = {loss, 1} instead of +=: no memset node in front of it
 };
 
 // One entry per parameter block: sum `nslab` partial slabs (fixed order) into dst and accumulate the

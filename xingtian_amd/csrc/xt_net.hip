@@ -702,7 +702,7 @@ static int graph_run(xt_net* net, const char* key, hipStream_t st, F enqueue) {
 // step size in device memory (lr_schedule evaluated by the caller; lets a replayed hipGraph see a new value).
 static int impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int nfr, const float* bp_logits,
                        const int32_t* action, const uint8_t* done, const float* reward, int apply, const float* lr_dev,
-                       float* loss_out, float* loss_acc, hipStream_t st, bool defer_join = false) {
+                       float* loss_out, float* loss_acc, hipStream_t st, bool defer_join = false, bool first_chunk = false) {
   const int T = c->sample_batch_step;
   XT_REQUIRE(T >= 2 && nfr > 0 && nfr % T == 0, "xt_net_impala_step: n=%d must be a multiple of sample_batch_step=%d",
              nfr, T);
@@ -715,6 +715,12 @@ static int impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int n
   // d(heads) + d(features) in the next, loss scalar in the gradient-reduction launch
   const bool fused = (n->n_trunks == 1 && A <= 8 && F <= 512 && T <= 256 && Lp.z_off < 0);
   bool loss_pending = false;
+  // the first chunk of a train clears loss_acc: in the fused form by WRITING {loss, 1} where later chunks add (LossArgs.acc_set,
+  // the extra block of the gradient-reduction launch) -- no memset node in front of the train (a 2.4-4.8 us fill kernel + a
+  // launch boundary of a 128-frame train's 85 us) --, otherwise with the memset
+  const bool set_acc = first_chunk && fused && apply == 1 && loss_acc && n->dp_world < 1;
+  if (first_chunk && !set_acc && loss_acc)
+    if (int rc = clear_loss_acc(n, loss_acc, st)) return rc;
   if (fused) {
     if (int rc = net_forward(n, obs, nullptr, nfr, false, st, true)) return rc;
     ImpalaHeadArgs h{};
@@ -768,6 +774,7 @@ static int impala_step(xt_net* n, const xt_impala_cfg* c, const void* obs, int n
   fin.lr = c->lr; fin.beta1 = c->beta1; fin.beta2 = c->beta2; fin.state = n->state; fin.lr_dev = lr_dev;
   if (loss_pending) {
     fin.loss.traj_loss = lo + 4; fin.loss.n_traj = ntraj; fin.loss.out = loss_out ? loss_out : lo; fin.loss.acc = loss_acc;
+    fin.loss.acc_set = set_acc ? 1 : 0;
   }
   if (apply == 3) {
     // the data-parallel chunk of xt_net_impala_train: gradient + loss scalar + step-size advance (+ the tail / the scatter
@@ -1089,7 +1096,7 @@ static int impala_train_enqueue(xt_net* net, const xt_impala_cfg* c, const void*
                                 const float* bp_logits, const int32_t* action, const uint8_t* done, const float* reward,
                                 const float* lr_steps, float* loss_acc, hipStream_t st, bool clear = true,
                                 const xt::IoFold* fold = nullptr) {
-  if (clear)
+  if (clear && net->xchg)       // (without an exchange the first chunk clears it itself: impala_step, first_chunk)
     if (int rc = xt::clear_loss_acc(net, loss_acc, st)) return rc;
   XT_REQUIRE(n < (1 << 24), "xt_net_impala_train: %d frames do not fit the data-parallel tail's float slot", n);
   net->dp_rows = (float)n;
@@ -1104,7 +1111,7 @@ static int impala_train_enqueue(xt_net* net, const xt_impala_cfg* c, const void*
       const void* o = static_cast<const char*>(obs) + frame * lo;
       net->io_fold = (lo + batch_size >= n) ? fold : nullptr;       // (the last chunk's Adam kernel carries the folded tail)
       const int rc = xt::impala_step(net, c, o, nfr, bp_logits + (size_t)lo * net->A, action + lo, done + lo, reward + lo, 1,
-                                     lr_dev, nullptr, loss_acc, st, /*defer_join*/ true);
+                                     lr_dev, nullptr, loss_acc, st, /*defer_join*/ true, /*first_chunk*/ clear && lo == 0);
       net->io_fold = nullptr;
       if (rc) return rc;
       continue;

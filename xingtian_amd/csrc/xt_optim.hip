@@ -375,7 +375,10 @@ __device__ void loss_reduce_body(const LossArgs& la, double* sh) {
       float s = 0.f;                            // impala_loss_reduce_kernel)
       for (int i = 0; i < la.n_traj; ++i) s += la.traj_loss[i];
       if (la.out) la.out[0] = s;
-      if (la.acc) { la.acc[0] += s; la.acc[1] += 1.f; }
+      if (la.acc) {
+        if (la.acc_set) { la.acc[0] = s; la.acc[1] = 1.f; }
+        else { la.acc[0] += s; la.acc[1] += 1.f; }
+      }
     }
     return;
   }
