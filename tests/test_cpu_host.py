@@ -1272,3 +1272,60 @@ def test_sender_side_list_packing_ships_per_step_lists_as_typed_arrays():
     b = IMPALAOpt._data_proc(transport.decode(transport.encode({}, msg))[1])
     for x, y in zip(a, b):
         assert np.asarray(x).dtype == np.asarray(y).dtype and np.array_equal(x, y)
+
+
+def test_inline_prefetcher_stages_on_the_learner_thread_one_train_ahead():
+    """transport.Prefetcher(inline=True): no thread -- ``pump_once()`` (the hook the model calls between two looks at the loss
+    while the device trains) stages one waiting message per call, at most one train ahead of ``staged_generation``, in arrival
+    order; ``recv_into`` pumps itself when no token is staged (the starved learner); the default picks the inline form exactly
+    when the algorithm says its model calls the hook (``stage_inline_capable``)."""
+    from xingtian_amd import transport
+
+    class FakeAlg(object):
+        prepare_data_times = 2
+
+        def __init__(self, capable):
+            self.gen, self.staged, self.booked, self.hook, self.capable = 0, [], [], "unset", capable
+
+        def stage_message(self, data, ctr_info=None):
+            self.staged.append(int(ctr_info["k"]))
+            return int(data["cur_state"].shape[0])
+
+        def staged_generation(self):
+            return self.gen
+
+        def stage_inline_capable(self):
+            return self.capable
+
+        def stage_inline(self, hook):
+            self.hook = hook
+
+        def prepare_data(self, data, ctr_info=None):
+            assert data == {"_prefetched": 4}
+            self.booked.append(int(ctr_info["k"]))
+
+    ring = transport.ShmRing(slots=8, slot_bytes=1 << 12)
+    try:
+        for k in range(5):
+            assert ring.send({"k": k}, {"cur_state": np.full((4, 3), k, np.float32)})
+        alg = FakeAlg(capable=True)
+        pf = transport.Prefetcher(ring, alg)                  # default -> inline
+        assert pf.inline and pf._thread is None and alg.hook == pf.pump_once and alg.staged == []
+        assert pf.pump_once() and pf.pump_once() and alg.staged == [0, 1]
+        assert not pf.pump_once() and alg.staged == [0, 1]   # train 1 NOT before the learner has taken train 0 over
+        assert pf.recv_many_into(alg.prepare_data, 2, timeout=5) == 2 and alg.booked == [0, 1]
+        alg.gen += 1                                          # (RolloutIngest.finish inside alg.train())
+        assert alg.hook() and alg.staged == [0, 1, 2]         # the model's call while the device trains
+        assert pf.recv_into(alg.prepare_data, timeout=5) == {"k": 2}
+        assert pf.recv_into(alg.prepare_data, timeout=5) == {"k": 3} and alg.staged == [0, 1, 2, 3]     # starved: pumped itself
+        alg.gen += 1
+        assert pf.recv_into(alg.prepare_data, timeout=5) == {"k": 4}
+        assert pf.recv_into(alg.prepare_data, block=False) is None and alg.booked == [0, 1, 2, 3, 4]
+        pf.close()
+        assert alg.hook is None                               # detached
+        alg2 = FakeAlg(capable=False)
+        pf2 = transport.Prefetcher(ring, alg2)                # default -> the thread
+        assert not pf2.inline and pf2._thread is not None and alg2.hook == "unset"
+        pf2.close()
+    finally:
+        ring.close()
